@@ -1,0 +1,96 @@
+"""ctypes binding of libtrimodal_hip.so (the C ABI declared in include/trimodal_hip.h).
+
+There is no CPU fallback: if the library is missing or a symbol is absent the import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrimodal_hip.so")
+
+
+class Window(C.Structure):
+    """struct tg_window (include/trimodal_hip.h)."""
+    _fields_ = [("ptr", C.c_void_p), ("batch_stride", C.c_int64), ("row_stride", C.c_int64), ("rows_in", C.c_int32),
+                ("rows_out", C.c_int32), ("row_step", C.c_int32), ("shift", C.c_int32), ("dil", C.c_int32),
+                ("cw", C.c_int32), ("K", C.c_int32)]
+
+
+P, I32, I64, F32, U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
+WP = C.POINTER(Window)
+
+# name -> argtypes (all return int); mirrors include/trimodal_hip.h one to one
+SIGNATURES = {
+    "tg_gemm_nt": [WP, P, I64, P, P, I64, I64, I32, I32, I32, F32, I32, P],
+    "tg_gemm_tn": [P, I64, WP, P, I64, I32, I32, I32, P],
+    "tg_colsum": [P, I64, I32, I32, P, I32, P],
+    "tg_gru_forward": [P, I64, P, P, P, P, P, P, I64, I32, I32, I32, P],
+    "tg_gru_backward": [P, P, P, I64, P, P, P, P, I64, P, I32, I32, I32, P],
+    "tg_bn_train_stats": [P, I32, I32, I32, P, P, P, P, P, P, F32, F32, I32, P],
+    "tg_bn_eval_stats": [P, P, I32, F32, P, P, P],
+    "tg_bn_apply": [P, P, I32, I32, I32, P, P, P, P, F32, P],
+    "tg_bn_backward": [P, P, P, I32, I32, P, P, P, P, F32, P, P, P, P],
+    "tg_add_relu": [P, P, P, I64, P],
+    "tg_act_mask_bwd": [P, P, P, F32, P, I64, P],
+    "tg_mul": [P, P, P, I64, P],
+    "tg_axpy": [P, P, F32, I32, I64, P],
+    "tg_copy2d": [P, I64, P, I64, I32, I32, I32, P],
+    "tg_repeat_rows": [P, I64, P, I64, I32, I32, I32, P],
+    "tg_sum_rows": [P, I64, P, I64, I32, I32, I32, I32, P],
+    "tg_add_halves": [P, P, I32, I32, P],
+    "tg_dup_halves": [P, P, I32, I32, P],
+    "tg_make_pre_seq": [P, P, I32, I32, I32, I32, P],
+    "tg_embed_gather": [P, P, P, I32, I32, I32, P],
+    "tg_embed_scatter_add": [P, P, P, I32, I32, I32, P],
+    "tg_permute3": [P, P, I32, I32, I32, I32, I32, I32, P],
+    "tg_conv_dgrad_pack": [P, P, I32, I32, I32, I32, P],
+    "tg_weight_norm_fwd": [P, P, P, I32, I32, I32, P],
+    "tg_weight_norm_bwd": [P, P, P, P, P, I32, I32, I32, P],
+    "tg_rng_advance": [P, P],
+    "tg_dropout_mask": [P, I64, F32, P, U32, P],
+    "tg_normal": [P, I64, P, U32, P],
+    "tg_randperm": [P, I32, P, U32, P],
+    "tg_gather_i64": [P, P, P, I32, P],
+    "tg_reparam_fwd": [P, P, P, P, I64, P],
+    "tg_reparam_bwd": [P, P, P, P, P, I64, P],
+    "tg_gan_d_loss": [P, P, I32, P, P, P, P],
+    "tg_gan_g_loss": [P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32, F32, I32, P, P, P, P, P, P, P],
+    "tg_l1_mean": [P, P, I64, P, P],
+    "tg_sigmoid": [P, P, I64, P],
+    "tg_sigmoid_bwd": [P, P, P, I64, P],
+    "tg_ae_loss": [P, P, I32, I32, I32, P, P, P],
+    "tg_counter_inc": [P, P],
+    "tg_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, P, P],
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise with a build hint if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C gesture-generation-from-trimodal-context_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.tg_version.restype = C.c_int
+    lib.tg_last_error.restype = C.c_char_p
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: intended
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.tg_version() != ABI_VERSION:
+        raise RuntimeError(f"libtrimodal_hip.so ABI {lib.tg_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.tg_last_error().decode()}")

@@ -1,0 +1,84 @@
+// Shared helpers for the gfx950 kernels of libtrimodal_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/trimodal_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace tg {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return 1;
+    }
+    return 0;
+}
+
+#define TG_REQUIRE(cond, ...)              \
+    do {                                   \
+        if (!(cond)) {                     \
+            tg::set_error(__VA_ARGS__);    \
+            return 2;                      \
+        }                                  \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// grid for a grid-stride element-wise kernel: enough blocks to fill 256 CUs, capped (guide: Guideline 11)
+inline int ew_grid(int64_t n, int block = 256, int per_thread = 4) {
+    int64_t b = (n + (int64_t)block * per_thread - 1) / ((int64_t)block * per_thread);
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+// device copy of tg_window
+struct Win {
+    const float* ptr;
+    long bs, rs;
+    int rows_in, rows_out, step, shift, dil, cw, K;
+};
+
+inline Win to_win(const tg_window* w) {
+    Win d;
+    d.ptr = w->ptr; d.bs = w->batch_stride; d.rs = w->row_stride; d.rows_in = w->rows_in; d.rows_out = w->rows_out;
+    d.step = w->row_step; d.shift = w->shift; d.dil = w->dil; d.cw = w->cw; d.K = w->K;
+    return d;
+}
+
+__device__ __forceinline__ float act_fn(float x, float slope) { return x >= 0.f ? x : x * slope; }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t idx, uint32_t site, uint32_t step, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), site, step};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+
+}  // namespace tg

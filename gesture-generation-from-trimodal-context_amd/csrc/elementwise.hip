@@ -1,0 +1,452 @@
+// Element-wise, data-movement, embedding, weight-norm, RNG and optimiser kernels.  All are HBM- or latency-bound:
+// grid-stride loops, 16-byte accesses where the layout allows, no host synchronisation, graph-capture safe.
+#include "common.hpp"
+
+namespace tg {
+
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+__global__ void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
+    GRID_STRIDE(i, n) { const float v = a[i] + b[i]; y[i] = v > 0.f ? v : 0.f; }
+}
+__global__ void act_mask_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ mask, float slope,
+                                    float* __restrict__ dx, long n) {
+    GRID_STRIDE(i, n) {
+        float g = dy[i] * (y[i] > 0.f ? 1.f : slope);
+        if (mask) g *= mask[i];
+        dx[i] = g;
+    }
+}
+__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ y, long n) {
+    GRID_STRIDE(i, n) y[i] = x[i] * m[i];
+}
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, float alpha, int acc, long n) {
+    GRID_STRIDE(i, n) y[i] = acc ? y[i] + alpha * x[i] : alpha * x[i];
+}
+__global__ void copy2d_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, int rows, int cols, int acc) {
+    const long n = (long)rows * cols;
+    GRID_STRIDE(i, n) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float v = src[r * lds_ + c];
+        float* d = dst + r * ldd + c;
+        *d = acc ? *d + v : v;
+    }
+}
+__global__ void repeat_rows_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, int B, int T, int cols) {
+    const long n = (long)B * T * cols;
+    GRID_STRIDE(i, n) {
+        const long bt = i / cols;
+        const int c = (int)(i - bt * cols);
+        dst[bt * ldd + c] = src[(bt / T) * lds_ + c];
+    }
+}
+__global__ void sum_rows_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, int B, int T, int cols, int acc) {
+    const long n = (long)B * cols;
+    GRID_STRIDE(i, n) {
+        const long b = i / cols;
+        const int c = (int)(i - b * cols);
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += src[(b * T + t) * lds_ + c];
+        float* d = dst + b * ldd + c;
+        *d = acc ? *d + s : s;
+    }
+}
+__global__ void add_halves_kernel(const float* __restrict__ y, float* __restrict__ o, long M, int H) {
+    const long n = M * H;
+    GRID_STRIDE(i, n) {
+        const long m = i / H;
+        const int j = (int)(i - m * H);
+        o[i] = y[m * 2 * H + j] + y[m * 2 * H + H + j];
+    }
+}
+__global__ void dup_halves_kernel(const float* __restrict__ d_o, float* __restrict__ dy, long M, int H) {
+    const long n = M * H;
+    GRID_STRIDE(i, n) {
+        const long m = i / H;
+        const int j = (int)(i - m * H);
+        const float v = d_o[i];
+        dy[m * 2 * H + j] = v;
+        dy[m * 2 * H + H + j] = v;
+    }
+}
+__global__ void make_pre_seq_kernel(const float* __restrict__ target, float* __restrict__ pre, int B, int T, int D, int n_pre) {
+    const long n = (long)B * T * (D + 1);
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % (D + 1));
+        const long bt = i / (D + 1);
+        const int t = (int)(bt % T);
+        pre[i] = t < n_pre ? (c < D ? target[bt * D + c] : 1.f) : 0.f;
+    }
+}
+__global__ void embed_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out, int n_idx, int D,
+                                    int n_rows) {
+    const long n = (long)n_idx * D;
+    GRID_STRIDE(i, n) {
+        const long r = i / D;
+        const int c = (int)(i - r * D);
+        const int64_t id = idx[r];
+        out[i] = (id >= 0 && id < n_rows) ? table[id * D + c] : 0.f;
+    }
+}
+// Dense embedding gradient.  The padded text input is mostly index 0: consecutive look-ups with the same
+// index are summed in registers and flushed with ONE atomic per run, so the hot PAD row sees n_idx/CHUNK atomics per
+// column instead of thousands.
+constexpr int SCATTER_CHUNK = 64;
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ dout, const int64_t* __restrict__ idx,
+                                                            float* __restrict__ dtable, int n_idx, int D, int n_rows) {
+    const int i0 = blockIdx.x * SCATTER_CHUNK;
+    const int i1 = min(n_idx, i0 + SCATTER_CHUNK);
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        int64_t cur = idx[i0];
+        float acc = 0.f;
+        for (int i = i0; i < i1; ++i) {
+            const int64_t id = idx[i];
+            if (id != cur) {
+                if (cur >= 0 && cur < n_rows) atomicAdd(&dtable[cur * D + c], acc);
+                acc = 0.f;
+                cur = id;
+            }
+            acc += dout[(long)i * D + c];
+        }
+        if (cur >= 0 && cur < n_rows) atomicAdd(&dtable[cur * D + c], acc);
+    }
+}
+__global__ void permute3_kernel(const float* __restrict__ in, float* __restrict__ out, int d0, int d1, int d2, int p0, int p1, int p2) {
+    const int d[3] = {d0, d1, d2};
+    const int o0 = d[p0], o1 = d[p1], o2 = d[p2];
+    const long n = (long)o0 * o1 * o2;
+    GRID_STRIDE(i, n) {
+        const int i2 = (int)(i % o2);
+        const long t = i / o2;
+        const int i1 = (int)(t % o1);
+        const int i0 = (int)(t / o1);
+        int x[3];
+        x[p0] = i0; x[p1] = i1; x[p2] = i2;
+        out[i] = in[((long)x[0] * d1 + x[1]) * d2 + x[2]];
+    }
+}
+
+__global__ void conv_dgrad_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Co, int Ci, int kw, int s, int J) {
+    const long n = (long)s * Ci * J * Co;
+    GRID_STRIDE(i, n) {
+        const int co = (int)(i % Co);
+        long t = i / Co;
+        const int j = (int)(t % J); t /= J;
+        const int ci = (int)(t % Ci);
+        const int r = (int)(t / Ci);
+        const int k = r + s * j;
+        out[i] = k < kw ? w[((long)co * Ci + ci) * kw + k] : 0.f;
+    }
+}
+
+// ---- weight norm -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sh[q];
+    __syncthreads();
+    return t;
+}
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ w,
+                                                              int Ci, int kw) {
+    __shared__ float sh[4];
+    const int co = blockIdx.x, n = Ci * kw;
+    const float* vr = v + (long)co * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += vr[i] * vr[i];
+    const float nrm = sqrtf(block_sum(s, sh));
+    const float sc = g[co] / nrm;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int ci = i / kw, kk = i - ci * kw;
+        w[(long)co * n + (long)kk * Ci + ci] = vr[i] * sc;
+    }
+}
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v, const float* __restrict__ g,
+                                                              float* __restrict__ dg, float* __restrict__ dv, int Ci, int kw) {
+    __shared__ float sh[4];
+    const int co = blockIdx.x, n = Ci * kw;
+    const float* vr = v + (long)co * n;
+    float s = 0.f, d = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int ci = i / kw, kk = i - ci * kw;
+        s += vr[i] * vr[i];
+        d += dw[(long)co * n + (long)kk * Ci + ci] * vr[i];
+    }
+    const float n2 = block_sum(s, sh);
+    const float dot = block_sum(d, sh);
+    const float nrm = sqrtf(n2);
+    if (threadIdx.x == 0) dg[co] += dot / nrm;
+    const float a = g[co] / nrm, bcoef = dot / n2;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int ci = i / kw, kk = i - ci * kw;
+        dv[(long)co * n + i] += a * (dw[(long)co * n + (long)kk * Ci + ci] - bcoef * vr[i]);
+    }
+}
+
+// ---- RNG -----------------------------------------------------------------------------------------------------------
+__global__ void rng_advance_kernel(uint64_t* st) { st[1] += 1; }
+__global__ void dropout_mask_kernel(float* __restrict__ mask, long n, float p, const uint64_t* __restrict__ st, uint32_t site) {
+    const uint64_t seed = st[0];
+    const uint32_t step = (uint32_t)st[1];
+    const float keep = 1.f / (1.f - p);
+    const long n4 = (n + 3) / 4;
+    GRID_STRIDE(i, n4) {
+        uint32_t r[4];
+        philox4x32(seed, (uint64_t)i, site, step, r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long e = i * 4 + q;
+            if (e < n) mask[e] = u01(r[q]) >= p ? keep : 0.f;
+        }
+    }
+}
+__global__ void normal_kernel(float* __restrict__ out, long n, const uint64_t* __restrict__ st, uint32_t site) {
+    const uint64_t seed = st[0];
+    const uint32_t step = (uint32_t)st[1];
+    const long n4 = (n + 3) / 4;
+    GRID_STRIDE(i, n4) {
+        uint32_t r[4];
+        philox4x32(seed, (uint64_t)i, site, step, r);
+        float z[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {   // Box-Muller
+            const float rad = sqrtf(-2.f * logf(u01(r[2 * q])));
+            const float ang = 6.283185307179586f * u01(r[2 * q + 1]);
+            z[2 * q] = rad * cosf(ang);
+            z[2 * q + 1] = rad * sinf(ang);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long e = i * 4 + q;
+            if (e < n) out[e] = z[q];
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void randperm_kernel(int64_t* __restrict__ out, int n, const uint64_t* __restrict__ st, uint32_t site) {
+    __shared__ uint64_t keys[1024];
+    const int i = threadIdx.x;
+    if (i < n) {
+        uint32_t r[4];
+        philox4x32(st[0], (uint64_t)i, site, (uint32_t)st[1], r);
+        keys[i] = ((uint64_t)r[0] << 32) | r[1];
+    }
+    __syncthreads();
+    if (i < n) {
+        const uint64_t k = keys[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (keys[j] < k) || (keys[j] == k && j < i);
+        out[rank] = i;
+    }
+}
+__global__ void gather_i64_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ perm, int64_t* __restrict__ out, int n) {
+    GRID_STRIDE(i, n) {
+        const int64_t p = perm[i];
+        out[i] = (p >= 0 && p < n) ? src[p] : 0;
+    }
+}
+
+// ---- speaker path ----------------------------------------------------------------------------------------------------
+__global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps, float* __restrict__ z, long n) {
+    GRID_STRIDE(i, n) z[i] = mu[i] + eps[i] * expf(0.5f * lv[i]);
+}
+__global__ void reparam_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ lv, const float* __restrict__ eps, float* __restrict__ dmu,
+                                   float* __restrict__ dlv, long n) {
+    GRID_STRIDE(i, n) {
+        dmu[i] += dz[i];
+        dlv[i] += dz[i] * eps[i] * 0.5f * expf(0.5f * lv[i]);
+    }
+}
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long n) {
+    GRID_STRIDE(i, n) dx[i] = dy[i] * y[i] * (1.f - y[i]);
+}
+__global__ void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, long n) { GRID_STRIDE(i, n) y[i] = sigmoidf_(x[i]); }
+
+// ---- Adam ------------------------------------------------------------------------------------------------------------
+__global__ void counter_inc_kernel(int32_t* c) { *c += 1; }
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   long n, float lr, float b1, float b2, float eps, const int32_t* __restrict__ step_dev) {
+    __shared__ float coef[2];
+    if (threadIdx.x == 0) {   // bias corrections in fp64, like the Python scalars torch.optim.Adam uses
+        const double t = (double)*step_dev;
+        const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+        coef[0] = (float)((double)lr / bc1);
+        coef[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float step_size = coef[0], bc2s = coef[1];
+    const long n4 = n / 4;
+    GRID_STRIDE(i, n4) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mv[q] = mv[q] + (gv[q] - mv[q]) * (1.f - b1);
+            vv[q] = vv[q] * b2 + gv[q] * gv[q] * (1.f - b2);
+            pv[q] -= step_size * mv[q] / (sqrtf(vv[q]) / bc2s + eps);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv; reinterpret_cast<f32x4*>(m)[i] = mv; reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // tail
+        const long i = n4 * 4 + threadIdx.x;
+        m[i] = m[i] + (g[i] - m[i]) * (1.f - b1);
+        v[i] = v[i] * b2 + g[i] * g[i] * (1.f - b2);
+        p[i] -= step_size * m[i] / (sqrtf(v[i]) / bc2s + eps);
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+#define ST ((hipStream_t)stream)
+#define EW(kernel, n, ...)                                                                      \
+    do {                                                                                        \
+        if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(ew_grid((n))), dim3(256), 0, ST, __VA_ARGS__); \
+    } while (0)
+
+extern "C" {
+
+int tg_add_relu(const float* a, const float* b, float* y, int64_t n, void* stream) {
+    TG_REQUIRE(a && b && y && n >= 0, "tg_add_relu: bad arguments");
+    EW(add_relu_kernel, n, a, b, y, (long)n);
+    return check_launch("tg_add_relu");
+}
+int tg_act_mask_bwd(const float* dy, const float* y, const float* mask, float slope, float* dx, int64_t n, void* stream) {
+    TG_REQUIRE(dy && y && dx && n >= 0, "tg_act_mask_bwd: bad arguments");
+    EW(act_mask_bwd_kernel, n, dy, y, mask, slope, dx, (long)n);
+    return check_launch("tg_act_mask_bwd");
+}
+int tg_mul(const float* x, const float* mask, float* y, int64_t n, void* stream) {
+    TG_REQUIRE(x && mask && y && n >= 0, "tg_mul: bad arguments");
+    EW(mul_kernel, n, x, mask, y, (long)n);
+    return check_launch("tg_mul");
+}
+int tg_axpy(const float* x, float* y, float alpha, int32_t accumulate, int64_t n, void* stream) {
+    TG_REQUIRE(x && y && n >= 0, "tg_axpy: bad arguments");
+    EW(axpy_kernel, n, x, y, alpha, accumulate, (long)n);
+    return check_launch("tg_axpy");
+}
+int tg_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows, int32_t cols, int32_t accumulate, void* stream) {
+    TG_REQUIRE(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "tg_copy2d: bad arguments");
+    EW(copy2d_kernel, (long)rows * cols, src, (long)lds, dst, (long)ldd, rows, cols, accumulate);
+    return check_launch("tg_copy2d");
+}
+int tg_repeat_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t B, int32_t T, int32_t cols, void* stream) {
+    TG_REQUIRE(src && dst && B > 0 && T > 0 && cols > 0 && lds >= cols && ldd >= cols, "tg_repeat_rows: bad arguments");
+    EW(repeat_rows_kernel, (long)B * T * cols, src, (long)lds, dst, (long)ldd, B, T, cols);
+    return check_launch("tg_repeat_rows");
+}
+int tg_sum_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t B, int32_t T, int32_t cols, int32_t accumulate, void* stream) {
+    TG_REQUIRE(src && dst && B > 0 && T > 0 && cols > 0 && lds >= cols && ldd >= cols, "tg_sum_rows: bad arguments");
+    EW(sum_rows_kernel, (long)B * cols, src, (long)lds, dst, (long)ldd, B, T, cols, accumulate);
+    return check_launch("tg_sum_rows");
+}
+int tg_add_halves(const float* y, float* o, int32_t M, int32_t H, void* stream) {
+    TG_REQUIRE(y && o && M > 0 && H > 0, "tg_add_halves: bad arguments");
+    EW(add_halves_kernel, (long)M * H, y, o, (long)M, H);
+    return check_launch("tg_add_halves");
+}
+int tg_dup_halves(const float* d_o, float* dy, int32_t M, int32_t H, void* stream) {
+    TG_REQUIRE(d_o && dy && M > 0 && H > 0, "tg_dup_halves: bad arguments");
+    EW(dup_halves_kernel, (long)M * H, d_o, dy, (long)M, H);
+    return check_launch("tg_dup_halves");
+}
+int tg_make_pre_seq(const float* target, float* pre, int32_t B, int32_t T, int32_t D, int32_t n_pre, void* stream) {
+    TG_REQUIRE(target && pre && B > 0 && T > 0 && D > 0 && n_pre >= 0 && n_pre <= T, "tg_make_pre_seq: bad arguments");
+    EW(make_pre_seq_kernel, (long)B * T * (D + 1), target, pre, B, T, D, n_pre);
+    return check_launch("tg_make_pre_seq");
+}
+int tg_embed_gather(const float* table, const int64_t* idx, float* out, int32_t n_idx, int32_t D, int32_t n_rows, void* stream) {
+    TG_REQUIRE(table && idx && out && n_idx > 0 && D > 0 && n_rows > 0, "tg_embed_gather: bad arguments");
+    EW(embed_gather_kernel, (long)n_idx * D, table, idx, out, n_idx, D, n_rows);
+    return check_launch("tg_embed_gather");
+}
+int tg_embed_scatter_add(const float* dout, const int64_t* idx, float* dtable, int32_t n_idx, int32_t D, int32_t n_rows, void* stream) {
+    TG_REQUIRE(dout && idx && dtable && n_idx > 0 && D > 0 && n_rows > 0, "tg_embed_scatter_add: bad arguments");
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(cdiv(n_idx, SCATTER_CHUNK)), dim3(256), 0, ST, dout, idx, dtable, n_idx, D, n_rows);
+    return check_launch("tg_embed_scatter_add");
+}
+int tg_permute3(const float* in, float* out, int32_t d0, int32_t d1, int32_t d2, int32_t p0, int32_t p1, int32_t p2, void* stream) {
+    TG_REQUIRE(in && out && d0 > 0 && d1 > 0 && d2 > 0, "tg_permute3: bad sizes");
+    TG_REQUIRE(p0 >= 0 && p0 < 3 && p1 >= 0 && p1 < 3 && p2 >= 0 && p2 < 3 && p0 != p1 && p0 != p2 && p1 != p2, "tg_permute3: bad permutation");
+    EW(permute3_kernel, (long)d0 * d1 * d2, in, out, d0, d1, d2, p0, p1, p2);
+    return check_launch("tg_permute3");
+}
+int tg_conv_dgrad_pack(const float* w, float* out, int32_t Co, int32_t Ci, int32_t kw, int32_t s, void* stream) {
+    TG_REQUIRE(w && out && Co > 0 && Ci > 0 && kw > 0 && s > 0, "tg_conv_dgrad_pack: bad arguments");
+    const int J = (kw + s - 1) / s;
+    EW(conv_dgrad_pack_kernel, (long)s * Ci * J * Co, w, out, Co, Ci, kw, s, J);
+    return check_launch("tg_conv_dgrad_pack");
+}
+int tg_weight_norm_fwd(const float* v, const float* g, float* w_packed, int32_t Co, int32_t Ci, int32_t kw, void* stream) {
+    TG_REQUIRE(v && g && w_packed && Co > 0 && Ci > 0 && kw > 0, "tg_weight_norm_fwd: bad arguments");
+    hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3(Co), dim3(256), 0, ST, v, g, w_packed, Ci, kw);
+    return check_launch("tg_weight_norm_fwd");
+}
+int tg_weight_norm_bwd(const float* dw_packed, const float* v, const float* g, float* dg, float* dv, int32_t Co, int32_t Ci, int32_t kw, void* stream) {
+    TG_REQUIRE(dw_packed && v && g && dg && dv && Co > 0 && Ci > 0 && kw > 0, "tg_weight_norm_bwd: bad arguments");
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(Co), dim3(256), 0, ST, dw_packed, v, g, dg, dv, Ci, kw);
+    return check_launch("tg_weight_norm_bwd");
+}
+int tg_rng_advance(uint64_t* rng_state, void* stream) {
+    TG_REQUIRE(rng_state, "tg_rng_advance: null");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, ST, rng_state);
+    return check_launch("tg_rng_advance");
+}
+int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream) {
+    TG_REQUIRE(mask && rng_state && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout_mask: bad arguments");
+    EW(dropout_mask_kernel, (n + 3) / 4, mask, (long)n, p, rng_state, site);
+    return check_launch("tg_dropout_mask");
+}
+int tg_normal(float* out, int64_t n, const uint64_t* rng_state, uint32_t site, void* stream) {
+    TG_REQUIRE(out && rng_state && n >= 0, "tg_normal: bad arguments");
+    EW(normal_kernel, (n + 3) / 4, out, (long)n, rng_state, site);
+    return check_launch("tg_normal");
+}
+int tg_randperm(int64_t* out, int32_t n, const uint64_t* rng_state, uint32_t site, void* stream) {
+    TG_REQUIRE(out && rng_state && n > 0 && n <= 1024, "tg_randperm: n=%d must be in [1,1024]", n);
+    hipLaunchKernelGGL(randperm_kernel, dim3(1), dim3(1024), 0, ST, out, n, rng_state, site);
+    return check_launch("tg_randperm");
+}
+int tg_gather_i64(const int64_t* src, const int64_t* perm, int64_t* out, int32_t n, void* stream) {
+    TG_REQUIRE(src && perm && out && n > 0, "tg_gather_i64: bad arguments");
+    EW(gather_i64_kernel, (long)n, src, perm, out, n);
+    return check_launch("tg_gather_i64");
+}
+int tg_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream) {
+    TG_REQUIRE(mu && logvar && eps && z && n >= 0, "tg_reparam_fwd: bad arguments");
+    EW(reparam_fwd_kernel, n, mu, logvar, eps, z, (long)n);
+    return check_launch("tg_reparam_fwd");
+}
+int tg_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu, float* dlogvar, int64_t n, void* stream) {
+    TG_REQUIRE(dz && logvar && eps && dmu && dlogvar && n >= 0, "tg_reparam_bwd: bad arguments");
+    EW(reparam_bwd_kernel, n, dz, logvar, eps, dmu, dlogvar, (long)n);
+    return check_launch("tg_reparam_bwd");
+}
+int tg_sigmoid(const float* x, float* y, int64_t n, void* stream) {
+    TG_REQUIRE(x && y && n >= 0, "tg_sigmoid: bad arguments");
+    EW(sigmoid_kernel, n, x, y, (long)n);
+    return check_launch("tg_sigmoid");
+}
+int tg_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    TG_REQUIRE(dy && y && dx && n >= 0, "tg_sigmoid_bwd: bad arguments");
+    EW(sigmoid_bwd_kernel, n, dy, y, dx, (long)n);
+    return check_launch("tg_sigmoid_bwd");
+}
+int tg_counter_inc(int32_t* counter, void* stream) {
+    TG_REQUIRE(counter, "tg_counter_inc: null");
+    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, ST, counter);
+    return check_launch("tg_counter_inc");
+}
+int tg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 const int32_t* step_dev, void* stream) {
+    TG_REQUIRE(p && g && m && v && step_dev && n > 0, "tg_adam_step: bad arguments");
+    TG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "tg_adam_step: slabs must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1, 256, 4)), dim3(256), 0, ST, p, g, m, v, (long)n, lr, beta1, beta2, eps, step_dev);
+    return check_launch("tg_adam_step");
+}
+
+}  // extern "C"

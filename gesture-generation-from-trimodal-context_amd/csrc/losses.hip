@@ -1,0 +1,191 @@
+// Loss kernels of the GAN step (train_eval/train_gan.py:41,53-89) and of the FGD autoencoder
+// (train_feature_extractor.py:64-72): forward value and analytic gradient in one pass, all on device so the
+// step never synchronises with the host (the reference's five .item() calls per iteration become one deferred read).
+#include "common.hpp"
+
+namespace tg {
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// sum over a 256-thread block; result valid in every thread
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ float sl1(float x) { const float a = fabsf(x); return a < 1.f ? 0.5f * x * x : a - 0.5f; }
+__device__ __forceinline__ float dsl1(float x) { return fabsf(x) < 1.f ? x : (x > 0.f ? 1.f : -1.f); }
+__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// dis_error = -mean(log(s_r + 1e-8) + log(1 - s_f + 1e-8))
+__global__ __launch_bounds__(256) void gan_d_loss_kernel(const float* __restrict__ lr, const float* __restrict__ lf, int B, float* __restrict__ out,
+                                                         float* __restrict__ dlr, float* __restrict__ dlf) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const float invB = 1.f / (float)B;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const float sr = sigmoidf_(lr[i]), sf = sigmoidf_(lf[i]);
+        s += logf(sr + 1e-8f) + logf(1.f - sf + 1e-8f);
+        dlr[i] = -invB * sr * (1.f - sr) / (sr + 1e-8f);
+        dlf[i] = invB * sf * (1.f - sf) / (1.f - sf + 1e-8f);
+    }
+    s = block_sum256(s, sh);
+    if (threadIdx.x == 0) out[0] = -s * invB;
+}
+
+// stage 1: one workgroup per clip -> ws[b] = P_b (pose smooth-L1 sum vs the shuffled-speaker output),
+// ws[B+b] = mean_c |z - z_rand|, ws[2B+b] = sum smooth-L1((out - target)/0.1)
+__global__ __launch_bounds__(256) void gan_g_stage1(const float* __restrict__ o, const float* __restrict__ t, const float* __restrict__ orand,
+                                                    const float* __restrict__ z, const float* __restrict__ zr, int B, int TD, int Z,
+                                                    float* __restrict__ ws) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    float p = 0.f, h = 0.f, zl = 0.f;
+    for (int i = threadIdx.x; i < TD; i += 256) {
+        const float ov = o[(long)b * TD + i];
+        p += sl1((ov - orand[(long)b * TD + i]) / 0.05f) * 0.05f;
+        h += sl1((ov - t[(long)b * TD + i]) / 0.1f);
+    }
+    for (int i = threadIdx.x; i < Z; i += 256) zl += fabsf(z[(long)b * Z + i] - zr[(long)b * Z + i]);
+    p = block_sum256(p, sh);
+    h = block_sum256(h, sh);
+    zl = block_sum256(zl, sh);
+    if (threadIdx.x == 0) { ws[b] = p; ws[B + b] = zl / (float)Z; ws[2 * B + b] = h; }
+}
+
+// stage 2 (one workgroup): scalars, per-clip div_reg coefficient (overwrites ws[b]), d_mu, d_logvar, d_logit
+__global__ __launch_bounds__(256) void gan_g_stage2(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ logit, int B,
+                                                    int TD, int Z, float w_h, float w_k, float w_d, float w_g, int use_gan,
+                                                    float* __restrict__ ws, float* __restrict__ sc, float* __restrict__ dmu, float* __restrict__ dlv,
+                                                    float* __restrict__ dlogit) {
+    __shared__ float sh[4];
+    float hub = 0.f, div = 0.f, gen = 0.f, kld = 0.f;
+    const float invB = 1.f / (float)B;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        hub += ws[2 * B + b];
+        const float den = ws[B + b] + 1.0e-5f;
+        const float v = -(ws[b] / den);
+        const bool clamped = v < -1000.f;
+        div += clamped ? -1000.f : v;
+        ws[b] = clamped ? 0.f : (-1.f / den) * w_d * invB;     // d(w_d * div_reg)/dP_b
+        const float s = sigmoidf_(logit[b]);
+        gen += logf(s + 1e-8f);
+        dlogit[b] = use_gan ? -w_g * invB * s * (1.f - s) / (s + 1e-8f) : 0.f;
+    }
+    const long nz = (long)B * Z;
+    const float invnz = 1.f / (float)nz;
+    for (long i = threadIdx.x; i < nz; i += 256) {
+        const float m = mu[i], l = lv[i], e = expf(l);
+        kld += 1.f + l - m * m - e;
+        dmu[i] = w_k * invnz * m;                         // d/dmu of -0.5*mean(1 + lv - mu^2 - e^lv)
+        dlv[i] = w_k * (-0.5f) * invnz * (1.f - e);
+    }
+    hub = block_sum256(hub, sh);
+    div = block_sum256(div, sh);
+    gen = block_sum256(gen, sh);
+    kld = block_sum256(kld, sh);
+    if (threadIdx.x == 0) {
+        const float huber = 0.1f * hub / ((float)B * (float)TD);
+        const float kl = -0.5f * kld * invnz;
+        const float dv = div * invB;
+        const float ge = -gen * invB;
+        sc[0] = huber; sc[1] = kl; sc[2] = dv; sc[3] = ge;
+        sc[4] = w_h * huber + w_k * kl + w_d * dv + (use_gan ? w_g * ge : 0.f);
+    }
+}
+
+// stage 3: d_out = w_h * sl1'((o-t)/0.1) / (B*TD) + coef_b * sl1'((o-orand)/0.05)
+__global__ void gan_g_stage3(const float* __restrict__ o, const float* __restrict__ t, const float* __restrict__ orand, const float* __restrict__ ws,
+                             int B, int TD, float w_h, float* __restrict__ d_out) {
+    const long n = (long)B * TD;
+    const float hn = w_h / (float)n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / TD);
+        const float ov = o[i];
+        d_out[i] = hn * dsl1((ov - t[i]) / 0.1f) + ws[b] * dsl1((ov - orand[i]) / 0.05f);
+    }
+}
+
+__global__ __launch_bounds__(256) void l1_mean_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += fabsf(a[i] - b[i]);
+    s = block_sum256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(out, s / (float)n);
+}
+
+// loss = sum_b [ mean_{t,d} |r - x| + mean_{t,d} |(r_t - r_{t-1}) - (x_t - x_{t-1})| ]
+__global__ __launch_bounds__(256) void ae_loss_kernel(const float* __restrict__ r, const float* __restrict__ x, int B, int T, int D, float* __restrict__ out,
+                                                      float* __restrict__ dr) {
+    __shared__ float sh[4];
+    const long n = (long)B * T * D;
+    const float w1 = 1.f / (float)(T * D), w2 = 1.f / (float)((T - 1) * D);
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int t = (int)((i / D) % T);
+        const float e = r[i] - x[i];
+        float g = sgn(e) * w1;
+        s += fabsf(e) * w1;
+        if (t >= 1) {
+            const float dlt = e - (r[i - D] - x[i - D]);
+            s += fabsf(dlt) * w2;
+            g += sgn(dlt) * w2;
+        }
+        if (t + 1 < T) {
+            const float dlt = (r[i + D] - x[i + D]) - e;
+            g -= sgn(dlt) * w2;
+        }
+        dr[i] = g;
+    }
+    s = block_sum256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+}  // namespace tg
+
+using namespace tg;
+#define ST ((hipStream_t)stream)
+
+extern "C" {
+
+int tg_gan_d_loss(const float* logit_real, const float* logit_fake, int32_t B, float* out, float* d_logit_real, float* d_logit_fake,
+                  void* stream) {
+    TG_REQUIRE(logit_real && logit_fake && out && d_logit_real && d_logit_fake && B > 0, "tg_gan_d_loss: bad arguments");
+    hipLaunchKernelGGL(gan_d_loss_kernel, dim3(1), dim3(256), 0, ST, logit_real, logit_fake, B, out, d_logit_real, d_logit_fake);
+    return check_launch("tg_gan_d_loss");
+}
+
+int tg_gan_g_loss(const float* out_pose, const float* target, const float* out_rand, const float* z, const float* z_rand,
+                  const float* mu, const float* logvar, const float* logit_out, int32_t B, int32_t TD, int32_t Z, float w_huber,
+                  float w_kld, float w_div, float w_gan, int32_t use_gan, float* ws, float* scalars, float* d_out, float* d_mu,
+                  float* d_logvar, float* d_logit_out, void* stream) {
+    TG_REQUIRE(out_pose && target && out_rand && z && z_rand && mu && logvar && logit_out && ws && scalars && d_out && d_mu &&
+                   d_logvar && d_logit_out, "tg_gan_g_loss: null pointer");
+    TG_REQUIRE(B > 0 && TD > 0 && Z > 0, "tg_gan_g_loss: bad sizes");
+    hipLaunchKernelGGL(gan_g_stage1, dim3(B), dim3(256), 0, ST, out_pose, target, out_rand, z, z_rand, B, TD, Z, ws);
+    hipLaunchKernelGGL(gan_g_stage2, dim3(1), dim3(256), 0, ST, mu, logvar, logit_out, B, TD, Z, w_huber, w_kld, w_div, w_gan, use_gan, ws,
+                       scalars, d_mu, d_logvar, d_logit_out);
+    hipLaunchKernelGGL(gan_g_stage3, dim3(ew_grid((long)B * TD)), dim3(256), 0, ST, out_pose, target, out_rand, ws, B, TD, w_huber, d_out);
+    return check_launch("tg_gan_g_loss");
+}
+
+int tg_l1_mean(const float* a, const float* b, int64_t n, float* out, void* stream) {
+    TG_REQUIRE(a && b && out && n > 0, "tg_l1_mean: bad arguments");
+    if (hipMemsetAsync(out, 0, sizeof(float), ST) != hipSuccess) { set_error("tg_l1_mean: memset"); return 1; }
+    hipLaunchKernelGGL(l1_mean_kernel, dim3(ew_grid(n, 256, 8)), dim3(256), 0, ST, a, b, (long)n, out);
+    return check_launch("tg_l1_mean");
+}
+
+int tg_ae_loss(const float* recon, const float* target, int32_t B, int32_t T, int32_t D, float* out, float* d_recon, void* stream) {
+    TG_REQUIRE(recon && target && out && d_recon && B > 0 && T > 1 && D > 0, "tg_ae_loss: bad arguments");
+    if (hipMemsetAsync(out, 0, sizeof(float), ST) != hipSuccess) { set_error("tg_ae_loss: memset"); return 1; }
+    hipLaunchKernelGGL(ae_loss_kernel, dim3(ew_grid((long)B * T * D, 256, 4)), dim3(256), 0, ST, recon, target, B, T, D, out, d_recon);
+    return check_launch("tg_ae_loss");
+}
+
+}  // extern "C"

@@ -1,0 +1,436 @@
+"""Network engines: hand-sequenced forward and backward passes over the HIP ops.
+
+Each engine owns the flat parameter slab of one drop-in nn.Module (modules.py) and runs the whole network as a fixed
+sequence of kernel launches on the current stream -- no autograd graph, no host synchronisation, so a complete
+training iteration can be captured into one hipGraph (train_gan.GraphedGanStep).
+
+Reference maths: model/multimodal_context_net.py (WavEncoder :9-28, TextEncoderTCN :31-61, PoseGenerator :64-160,
+ConvDiscriminator :207-252), model/tcn.py, model/embedding_net.py (pose-mode EmbeddingNet).
+"""
+import torch
+
+from . import layers as L
+from . import ops
+from .ops import Win
+from .params import ParamSlab
+
+WAV_CONVS = ((0, 16, 1, 5, 1600), (3, 32, 16, 6, 0), (6, 64, 32, 6, 0), (9, 32, 64, 6, 0))   # idx, Co, Ci, stride, pad
+WAV_KW = 15
+
+
+class DeviceRNG:
+    """Philox counter RNG state on the device: {seed, step}.  Every draw site gets a stable id."""
+
+    def __init__(self, seed, device):
+        self.state = ops.new_rng_state(seed, device)
+        self._sites = {}
+
+    def site(self, name):
+        return self._sites.setdefault(name, len(self._sites) + 1)
+
+    def advance(self):
+        ops.rng_advance(self.state)
+
+
+class _Engine:
+    def __init__(self, module, seed=0):
+        self.mod = module
+        self.slab = ParamSlab(module)
+        self._seed = seed
+        self._rng = None
+
+    @property
+    def rng(self):
+        dev = self.slab.flat.device
+        if self._rng is None or self._rng.state.device != dev:
+            self._rng = DeviceRNG(self._seed, dev)
+        return self._rng
+
+    def views(self):
+        self.slab.ensure()
+        P, G = self.slab.views()
+        Bf = dict(self.mod.named_buffers())
+        return P, G, Bf
+
+    def _mask(self, name, like, p, inject):
+        """Inverted-dropout scale mask for site `name`: injected (tests) or drawn on device."""
+        if inject is not None and name in inject:
+            m = inject[name]
+            assert m.shape == like.shape, (name, m.shape, like.shape)
+            return m.contiguous()
+        if p <= 0.0:
+            return None
+        return ops.dropout_mask(torch.empty_like(like), p, self.rng.state, self.rng.site(name))
+
+
+# ======================================================================================================= generator
+class GeneratorEngine(_Engine):
+    def __init__(self, module, seed=0):
+        super().__init__(module, seed)
+        self.H = module.hidden_size
+        self.n_layers = module.n_layers
+        self.p_drop = module.dropout_prob
+        self.pose_dim = module.pose_dim
+        self.T = module.pre_length + module.gen_length
+
+    # ---------------------------------------------------------------------------------------------- forward
+    def forward(self, pre_seq, in_text, in_audio, vid, *, training, groups=1, save=False, inject=None, tag="g"):
+        """Stacked forward: the batch may hold `groups` reference forward calls back to back (BatchNorm statistics are
+        per group).  Returns a dict with out/z/mu/logvar (+ the tape when save=True)."""
+        P, G, Bf = self.views()
+        Bs, T = in_text.shape
+        H, D = self.H, self.pose_dim
+        assert T == self.T and pre_seq.shape == (Bs, T, D + 1) and Bs % groups == 0
+        tp = {"Bs": Bs, "groups": groups, "training": training}
+        in_size = 32 + 32 + D + 1 + 16
+        in_data = L.empty(Bs, T, in_size, like=in_audio)
+
+        # ---- WavEncoder: 4 strided convs as window GEMMs, BN + LeakyReLU(0.3) between (:9-28)
+        # The stacked forward calls of one GAN iteration see the SAME audio and the encoder has no dropout, so when
+        # in_audio holds one group's rows the encoder runs once: identical batch statistics, running stats updated
+        # `groups` times (tg_bn_train_stats repeats), output replicated per group.
+        fe = "audio_encoder.feat_extractor"
+        Ba = in_audio.shape[0]
+        shared = Ba != Bs
+        assert Ba == Bs or Ba * groups == Bs, (Ba, Bs, groups)
+        x = in_audio.contiguous().view(Ba, -1, 1)
+        wav = []
+        for idx, Co, Ci, stride, pad in WAV_CONVS:
+            wp = L.pack_conv_weight(P[f"{fe}.{idx}.weight"])
+            last = idx == 9
+            out = in_data[:, :, D + 1:D + 33] if (last and not shared) else None
+            c = L.conv_fwd(x, wp, P[f"{fe}.{idx}.bias"], WAV_KW, stride=stride, pad=pad, out=out)
+            if last:
+                assert c.shape[1] == T, f"audio length gives {c.shape[1]} frames, expected {T}"
+                wav.append((x, None, None))
+                if shared:
+                    for g in range(groups):
+                        ops.copy2d(c.view(Ba * T, 32), in_data[g * Ba:(g + 1) * Ba].view(Ba * T, in_size)[:, D + 1:D + 33])
+                break
+            y, st = L.bn_fwd(c, P[f"{fe}.{idx + 1}.weight"], P[f"{fe}.{idx + 1}.bias"], Bf[f"{fe}.{idx + 1}.running_mean"],
+                             Bf[f"{fe}.{idx + 1}.running_var"], Bf[f"{fe}.{idx + 1}.num_batches_tracked"],
+                             training=training, groups=1 if shared else groups, act_slope=0.3,
+                             repeats=groups if shared else 1)
+            wav.append((x, st, c.shape[1]))
+            x = y
+        tp["wav"], tp["wav_shared"] = wav, shared
+
+        # ---- TextEncoderTCN (:31-61, model/tcn.py)
+        te = "text_encoder"
+        E = P[f"{te}.embedding.weight"].shape[1]
+        emb = ops.embed_gather(P[f"{te}.embedding.weight"], in_text.contiguous().view(-1), L.empty(Bs, T, E, like=in_audio))
+        emb_mask = self._mask(f"{tag}.emb_drop", emb, 0.1, inject) if training else None
+        cur = ops.mul(emb, emb_mask, torch.empty_like(emb)) if emb_mask is not None else emb
+        tcn = []
+        for i in range(self.n_layers):
+            d = 2 ** i
+            blk = {"x": cur, "d": d}
+            h = cur
+            for ci, name in enumerate(("conv1", "conv2")):
+                pre = f"{te}.tcn.network.{i}.{name}"
+                v = P[pre + ".weight_v"]
+                wp = ops.weight_norm_fwd(v, P[pre + ".weight_g"], L.empty(v.shape[0], 2 * v.shape[1], like=v))
+                c = L.conv_fwd(h, wp, P[pre + ".bias"], 2, pad=d, dil=d, rows_out=T, act_slope=0.0)   # causal: chomp
+                m = self._mask(f"{tag}.tcn{i}.drop{ci + 1}", c, self.p_drop, inject) if training else None
+                o = ops.mul(c, m, torch.empty_like(c)) if m is not None else c
+                blk[f"in{ci}"], blk[f"wp{ci}"], blk[f"o{ci}"], blk[f"m{ci}"] = h, wp, o, m
+                h = o
+            y = ops.add_relu(h, cur, torch.empty_like(cur))
+            blk["y"] = y
+            tcn.append(blk)
+            cur = y
+        tp["tcn"], tp["emb_mask"], tp["text_x"] = tcn, emb_mask, cur
+        L.linear_fwd(cur.view(Bs * T, -1), P[f"{te}.decoder.weight"], P[f"{te}.decoder.bias"],
+                     out=in_data.view(Bs * T, in_size)[:, D + 33:D + 65])
+
+        # ---- speaker embedding -> mu/logvar -> reparameterised z (:125-131; embedding_net.py:10-13)
+        se = ops.embed_gather(P["speaker_embedding.0.weight"], vid.contiguous(), L.empty(Bs, 16, like=in_audio))
+        zc = L.linear_fwd(se, P["speaker_embedding.1.weight"], P["speaker_embedding.1.bias"])
+        mu = L.linear_fwd(zc, P["speaker_mu.weight"], P["speaker_mu.bias"])
+        logvar = L.linear_fwd(zc, P["speaker_logvar.weight"], P["speaker_logvar.bias"])
+        if inject is not None and f"{tag}.eps" in inject:
+            eps = inject[f"{tag}.eps"].contiguous()
+        else:
+            eps = ops.normal(torch.empty_like(mu), self.rng.state, self.rng.site(f"{tag}.eps"))
+        z = ops.reparam_fwd(mu, logvar, eps, torch.empty_like(mu))
+        tp.update(se=se, zc=zc, mu=mu, logvar=logvar, eps=eps, vid=vid)
+
+        # ---- concat [pre_seq | audio | text | z repeated over time] (:139-153)
+        flat_in = in_data.view(Bs * T, in_size)
+        ops.copy2d(pre_seq.contiguous().view(Bs * T, D + 1), flat_in[:, :D + 1])
+        ops.repeat_rows(z, flat_in[:, D + 65:], Bs, T)
+
+        # ---- 4-layer bidirectional GRU, sum of directions, output MLP (:155-158)
+        y, gtape = L.gru_stack_fwd(in_data, P, "gru", self.n_layers, H, p_drop=self.p_drop, training=training, rng=self.rng,
+                                   save=save, inject=inject, tag=tag)
+        o = ops.add_halves(y, L.empty(Bs * T, H, like=y))
+        h1 = L.linear_fwd(o, P["out.0.weight"], P["out.0.bias"])            # LeakyReLU(True) == identity (README.md:122)
+        out = L.linear_fwd(h1, P["out.2.weight"], P["out.2.bias"]).view(Bs, T, D)
+        tp.update(in_text=in_text, gru=gtape, o=o, h1=h1, in_size=in_size)
+        return {"out": out, "z": z, "mu": mu, "logvar": logvar, "in_data": in_data, "tape": tp if save else None}
+
+    # ---------------------------------------------------------------------------------------------- backward
+    def backward(self, tp, d_out, d_mu=None, d_logvar=None, *, b0=0, nb=None, on_ready=None):
+        """Gradients of rows [b0, b0+nb) (one BatchNorm group) of a taped forward.  d_out: (nb, T, D);
+        d_mu/d_logvar: (nb, 16) direct gradients (KLD term) or None.  Accumulates into the gradient slab.
+        on_ready(prefixes): called as soon as the gradients of the named top-level parameter groups are final, in
+        backward order -- the data-parallel trainer starts that bucket's all-reduce while the rest still runs."""
+        ready = on_ready if on_ready is not None else (lambda names: None)
+        P, G, Bf = self.views()
+        Bs, T, H, D = tp["Bs"], self.T, self.H, self.pose_dim
+        nb = Bs - b0 if nb is None else nb
+        rows = slice(b0, b0 + nb)
+        grp = b0 // (Bs // tp["groups"])
+        assert nb == Bs // tp["groups"] and b0 % nb == 0, "backward runs on exactly one BatchNorm group"
+        M = nb * T
+        in_size = tp["in_size"]
+        d_out2 = d_out.contiguous().view(M, D)
+
+        # out MLP
+        dh1 = L.linear_bwd(d_out2, tp["h1"][b0 * T:b0 * T + M], P["out.2.weight"], G["out.2.weight"], G["out.2.bias"])
+        do = L.linear_bwd(dh1, tp["o"][b0 * T:b0 * T + M], P["out.0.weight"], G["out.0.weight"], G["out.0.bias"])
+        dy = ops.dup_halves(do, L.empty(nb, T, 2 * H, like=do))
+        d_in = L.gru_stack_bwd(dy, tp["gru"], P, G, "gru", self.n_layers, b0=b0, nb=nb)      # (nb, T, in_size)
+        d_in2 = d_in.view(M, in_size)
+        ready(("out", "gru"))
+
+        # speaker path
+        dz = ops.sum_rows(d_in2[:, D + 65:], L.empty(nb, 16, like=d_in), nb, T)
+        dmu = d_mu.clone() if d_mu is not None else torch.zeros_like(dz)
+        dlv = d_logvar.clone() if d_logvar is not None else torch.zeros_like(dz)
+        ops.reparam_bwd(dz, tp["logvar"][rows], tp["eps"][rows], dmu, dlv)
+        zc = tp["zc"][rows]
+        dzc = L.linear_bwd(dmu, zc, P["speaker_mu.weight"], G["speaker_mu.weight"], G["speaker_mu.bias"])
+        L.linear_bwd(dlv, zc, P["speaker_logvar.weight"], G["speaker_logvar.weight"], G["speaker_logvar.bias"],
+                     dx_out=dzc, accumulate_dx=True)
+        dse = L.linear_bwd(dzc, tp["se"][rows], P["speaker_embedding.1.weight"], G["speaker_embedding.1.weight"],
+                           G["speaker_embedding.1.bias"])
+        ops.embed_scatter_add(dse, tp["vid"][rows].contiguous(), G["speaker_embedding.0.weight"])
+
+        # text encoder
+        te = "text_encoder"
+        d_text = d_in2[:, D + 33:D + 65]
+        dcur = L.linear_bwd(d_text, tp["text_x"][rows].reshape(M, -1), P[f"{te}.decoder.weight"], G[f"{te}.decoder.weight"],
+                            G[f"{te}.decoder.bias"])
+        for i in range(self.n_layers - 1, -1, -1):
+            blk = tp["tcn"][i]
+            d = blk["d"]
+            Cc = dcur.shape[1]
+            dsum = ops.act_mask_bwd(dcur, blk["y"][rows].reshape(M, Cc), None, 0.0, torch.empty_like(dcur))   # relu(out + x)
+            dh = dsum
+            for ci, name in ((1, "conv2"), (0, "conv1")):
+                pre = f"{te}.tcn.network.{i}.{name}"
+                o = blk[f"o{ci}"][rows].reshape(M, -1)
+                m = blk[f"m{ci}"]
+                dc = ops.act_mask_bwd(dh, o, None if m is None else m[rows].reshape(M, -1), 0.0, torch.empty_like(o))
+                dc3 = dc.view(nb, T, -1)
+                xin = blk[f"in{ci}"][rows]
+                v = P[pre + ".weight_v"]
+                dwp = torch.zeros(v.shape[0], 2 * v.shape[1], device=v.device, dtype=v.dtype)
+                ops.gemm_tn(dc, Win.conv(xin, 2, pad=d, dil=d, rows_out=T), dwp)
+                ops.colsum(dc, G[pre + ".bias"])
+                ops.weight_norm_bwd(dwp, v, P[pre + ".weight_g"], G[pre + ".weight_g"], G[pre + ".weight_v"])
+                # dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0]  -> taps (t + d, t) with B = wp^T per tap
+                wT = L.empty(xin.shape[2], 2 * v.shape[0], like=v)
+                ops.permute3(blk[f"wp{ci}"].view(v.shape[0], 2, xin.shape[2]), wT, (2, 1, 0))
+                if ci == 1:
+                    dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, L.empty(M, xin.shape[2], like=dc))
+                else:   # first conv of the block: add into the residual branch gradient
+                    dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, dsum, accumulate=True)
+            dcur = dh
+        em = tp["emb_mask"]
+        demb = ops.mul(dcur, em[rows].reshape(M, -1), torch.empty_like(dcur)) if em is not None else dcur
+        ops.embed_scatter_add(demb, tp["in_text"][rows].contiguous().view(-1), G[f"{te}.embedding.weight"])
+        ready(("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder"))
+
+        # wav encoder
+        fe = "audio_encoder.feat_extractor"
+        dyw = d_in[:, :, D + 1:D + 33]                      # (nb, 34, 32) strided view
+        wrow0 = 0 if tp["wav_shared"] else b0              # shared audio: the encoder ran once on the group's rows
+        wgrp = 0 if tp["wav_shared"] else grp
+        wrows = slice(wrow0, wrow0 + nb)
+        for li in range(3, -1, -1):
+            idx, Co, Ci, stride, pad = WAV_CONVS[li]
+            x_in, st, _ = tp["wav"][li]                     # input of conv li (post BN+act of the previous block)
+            x_rows = x_in[wrows]
+            L.conv_wgrad(dyw, x_rows, G[f"{fe}.{idx}.weight"], G[f"{fe}.{idx}.bias"], WAV_KW, stride=stride, pad=pad)
+            if li == 0:
+                break
+            dxa = L.conv_dgrad(dyw, P[f"{fe}.{idx}.weight"], x_rows.shape[1], stride=stride)   # grad w.r.t. act(BN(c_prev))
+            pidx = WAV_CONVS[li - 1][0] + 1
+            _, st_prev, _ = tp["wav"][li - 1]
+            dyw = L.bn_bwd(dxa, st_prev, P[f"{fe}.{pidx}.weight"], P[f"{fe}.{pidx}.bias"], G[f"{fe}.{pidx}.weight"],
+                           G[f"{fe}.{pidx}.bias"], g0=wgrp, ng=1, row0=wrow0)
+        ready(("audio_encoder",))
+        return None
+
+
+# =================================================================================================== discriminator
+class DiscriminatorEngine(_Engine):
+    H = 64
+    CONVS = ((0, 16, 27), (3, 8, 16), (6, 8, 8))
+
+    def forward(self, poses, *, training, groups=1, save=False, inject=None, tag="d"):
+        """poses: (Bs, 34, 27).  Returns {'logit': (Bs,1) pre-sigmoid, 'prob': sigmoid, 'tape'}."""
+        P, G, Bf = self.views()
+        Bs, T0, D = poses.shape
+        tp = {"Bs": Bs, "groups": groups, "poses": poses.contiguous()}
+        x = tp["poses"]
+        convs = []
+        for idx, Co, Ci in self.CONVS:
+            wp = L.pack_conv_weight(P[f"pre_conv.{idx}.weight"])
+            c = L.conv_fwd(x, wp, P[f"pre_conv.{idx}.bias"], 3)
+            if idx == 6:
+                convs.append((x, None))
+                x = c
+                break
+            y, st = L.bn_fwd(c, P[f"pre_conv.{idx + 1}.weight"], P[f"pre_conv.{idx + 1}.bias"],
+                             Bf[f"pre_conv.{idx + 1}.running_mean"], Bf[f"pre_conv.{idx + 1}.running_var"],
+                             Bf[f"pre_conv.{idx + 1}.num_batches_tracked"], training=training, groups=groups, act_slope=1.0)
+            convs.append((x, st))
+            x = y
+        T = x.shape[1]
+        y, gtape = L.gru_stack_fwd(x, P, "gru", 4, self.H, p_drop=0.3, training=training, rng=self.rng, save=save,
+                                   inject=inject, tag=tag)
+        o = ops.add_halves(y, L.empty(Bs * T, self.H, like=y))
+        l1 = L.linear_fwd(o, P["out.weight"], P["out.bias"])                 # (Bs*T, 1)
+        logit = L.linear_fwd(l1.view(Bs, T), P["out2.weight"], P["out2.bias"])   # (Bs, 1)
+        prob = ops.sigmoid(logit, torch.empty_like(logit))
+        tp.update(convs=convs, gru=gtape, o=o, l1=l1, T=T)
+        return {"logit": logit, "prob": prob, "tape": tp if save else None}
+
+    def backward(self, tp, d_logit, *, b0=0, nb=None, param_grads=True, need_dposes=False):
+        """d_logit: (nb, 1) gradient w.r.t. the pre-sigmoid output for rows [b0, b0+nb): whole BatchNorm groups."""
+        P, G, Bf = self.views()
+        Bs, T, H = tp["Bs"], tp["T"], self.H
+        nb = Bs - b0 if nb is None else nb
+        rows = slice(b0, b0 + nb)
+        per = Bs // tp["groups"]
+        assert nb % per == 0 and b0 % per == 0
+        grp, ng = b0 // per, nb // per
+        M = nb * T
+        pg = param_grads
+        dl1 = L.linear_bwd(d_logit.contiguous().view(nb, 1), tp["l1"].view(Bs, T)[rows], P["out2.weight"],
+                           G["out2.weight"] if pg else None, G["out2.bias"] if pg else None)            # (nb, T)
+        do = L.linear_bwd(dl1.view(M, 1), tp["o"][b0 * T:b0 * T + M], P["out.weight"], G["out.weight"] if pg else None,
+                          G["out.bias"] if pg else None)
+        dy = ops.dup_halves(do, L.empty(nb, T, 2 * H, like=do))
+        dx = L.gru_stack_bwd(dy, tp["gru"], P, G, "gru", 4, b0=b0, nb=nb, param_grads=pg)              # (nb, 28, 8)
+        for li in (2, 1, 0):
+            idx, Co, Ci = self.CONVS[li]
+            x_in, _ = tp["convs"][li]
+            x_rows = x_in[rows]
+            if pg:
+                L.conv_wgrad(dx, x_rows, G[f"pre_conv.{idx}.weight"], G[f"pre_conv.{idx}.bias"], 3)
+            if li == 0 and not need_dposes:
+                return None
+            dxa = L.conv_dgrad(dx, P[f"pre_conv.{idx}.weight"], x_rows.shape[1])
+            if li == 0:
+                return dxa
+            pidx = self.CONVS[li - 1][0] + 1
+            _, st_prev = tp["convs"][li - 1]
+            dx = L.bn_bwd(dxa, st_prev, P[f"pre_conv.{pidx}.weight"], P[f"pre_conv.{pidx}.bias"],
+                          G[f"pre_conv.{pidx}.weight"] if pg else None, G[f"pre_conv.{pidx}.bias"] if pg else None,
+                          g0=grp, ng=ng, row0=b0)
+        return None
+
+
+# ===================================================================================================== autoencoder
+class AutoencoderEngine(_Engine):
+    """EmbeddingNet(mode='pose'): PoseEncoderConv + PoseDecoderConv, 34-frame branch (embedding_net.py:42-82,165-217)."""
+    ENC = (("net.0", 32, 27, 3, 1), ("net.1", 64, 32, 3, 1), ("net.2", 64, 64, 4, 2))
+
+    def _bn(self, P, Bf, pre, x, training, slope):
+        return L.bn_fwd(x, P[pre + ".weight"], P[pre + ".bias"], Bf[pre + ".running_mean"], Bf[pre + ".running_var"],
+                        Bf[pre + ".num_batches_tracked"], training=training, act_slope=slope)
+
+    def encode(self, poses, *, training, tape=None):
+        P, G, Bf = self.views()
+        e = "pose_encoder"
+        x = poses.contiguous()
+        B = x.shape[0]
+        rec = []
+        for name, Co, Ci, kw, stride in self.ENC:
+            c = L.conv_fwd(x, L.pack_conv_weight(P[f"{e}.{name}.0.weight"]), P[f"{e}.{name}.0.bias"], kw, stride=stride)
+            y, st = self._bn(P, Bf, f"{e}.{name}.1", c, training, 0.2)
+            rec.append((x, st))
+            x = y
+        c4 = L.conv_fwd(x, L.pack_conv_weight(P[f"{e}.net.3.weight"]), P[f"{e}.net.3.bias"], 3)     # (B, 12, 32)
+        # flatten(1) of the reference's (B, C=32, L=12) layout: channel-major -> permute our (B, L, C)
+        flat = ops.permute3(c4, L.empty(B, 32 * c4.shape[1], like=c4), (0, 2, 1))
+        f1 = L.linear_fwd(flat, P[f"{e}.out_net.0.weight"], P[f"{e}.out_net.0.bias"])
+        y1, st1 = self._bn(P, Bf, f"{e}.out_net.1", f1, training, 1.0)
+        f2 = L.linear_fwd(y1, P[f"{e}.out_net.3.weight"], P[f"{e}.out_net.3.bias"])
+        y2, st2 = self._bn(P, Bf, f"{e}.out_net.4", f2, training, 1.0)
+        f3 = L.linear_fwd(y2, P[f"{e}.out_net.6.weight"], P[f"{e}.out_net.6.bias"])
+        mu = L.linear_fwd(f3, P[f"{e}.fc_mu.weight"], P[f"{e}.fc_mu.bias"])
+        logvar = L.linear_fwd(f3, P[f"{e}.fc_logvar.weight"], P[f"{e}.fc_logvar.bias"])
+        if tape is not None:
+            tape.update(enc=rec, x4=x, c4=c4, flat=flat, st1=st1, y1=y1, st2=st2, y2=y2, f3=f3)
+        return mu, logvar
+
+    def decode(self, feat, *, training, tape=None):
+        P, G, Bf = self.views()
+        d = "decoder"
+        B = feat.shape[0]
+        p0 = L.linear_fwd(feat, P[f"{d}.pre_net.0.weight"], P[f"{d}.pre_net.0.bias"])
+        yp, stp = self._bn(P, Bf, f"{d}.pre_net.1", p0, training, 1.0)
+        p3 = L.linear_fwd(yp, P[f"{d}.pre_net.3.weight"], P[f"{d}.pre_net.3.bias"])                 # (B, 136) = (B, 4, 34)
+        x0 = ops.permute3(p3.view(B, 4, 34), L.empty(B, 34, 4, like=p3), (0, 2, 1))                # channel-last
+        t0 = L.conv_transpose_fwd(x0, P[f"{d}.net.0.weight"], P[f"{d}.net.0.bias"])                 # (B, 36, 32)
+        y0, s0 = self._bn(P, Bf, f"{d}.net.1", t0, training, 0.2)
+        t1 = L.conv_transpose_fwd(y0, P[f"{d}.net.3.weight"], P[f"{d}.net.3.bias"])                 # (B, 38, 32)
+        y1, s1 = self._bn(P, Bf, f"{d}.net.4", t1, training, 0.2)
+        c6 = L.conv_fwd(y1, L.pack_conv_weight(P[f"{d}.net.6.weight"]), P[f"{d}.net.6.bias"], 3)    # (B, 36, 32)
+        out = L.conv_fwd(c6, L.pack_conv_weight(P[f"{d}.net.7.weight"]), P[f"{d}.net.7.bias"], 3)   # (B, 34, 27)
+        if tape is not None:
+            tape.update(feat=feat, stp=stp, yp=yp, x0=x0, s0=s0, y0=y0, s1=s1, y1d=y1, c6=c6)
+        return out
+
+    def forward(self, poses, *, training, save=False):
+        tape = {} if save else None
+        mu, logvar = self.encode(poses, training=training, tape=tape)
+        recon = self.decode(mu, training=training, tape=tape)      # variational_encoding=False: z = mu
+        return {"feat": mu, "mu": mu, "logvar": logvar, "recon": recon, "tape": tape}
+
+    def backward(self, tp, d_recon):
+        """Gradients of the reconstruction loss (train_feature_extractor.py:54-97, z = mu so fc_logvar gets none)."""
+        P, G, Bf = self.views()
+        d, e = "decoder", "pose_encoder"
+        B = d_recon.shape[0]
+        dy = d_recon.contiguous()
+        # decoder
+        L.conv_wgrad(dy, tp["c6"], G[f"{d}.net.7.weight"], G[f"{d}.net.7.bias"], 3)
+        dy = L.conv_dgrad(dy, P[f"{d}.net.7.weight"], 36)
+        L.conv_wgrad(dy, tp["y1d"], G[f"{d}.net.6.weight"], G[f"{d}.net.6.bias"], 3)
+        dy = L.conv_dgrad(dy, P[f"{d}.net.6.weight"], 38)
+        dy = L.bn_bwd(dy, tp["s1"], P[f"{d}.net.4.weight"], P[f"{d}.net.4.bias"], G[f"{d}.net.4.weight"], G[f"{d}.net.4.bias"])
+        dy = L.conv_transpose_bwd(dy, tp["y0"], P[f"{d}.net.3.weight"], G[f"{d}.net.3.weight"], G[f"{d}.net.3.bias"])
+        dy = L.bn_bwd(dy, tp["s0"], P[f"{d}.net.1.weight"], P[f"{d}.net.1.bias"], G[f"{d}.net.1.weight"], G[f"{d}.net.1.bias"])
+        dx0 = L.conv_transpose_bwd(dy, tp["x0"], P[f"{d}.net.0.weight"], G[f"{d}.net.0.weight"], G[f"{d}.net.0.bias"])   # (B,34,4)
+        dp3 = ops.permute3(dx0, L.empty(B, 136, like=dx0), (0, 2, 1))
+        dyp = L.linear_bwd(dp3, tp["yp"], P[f"{d}.pre_net.3.weight"], G[f"{d}.pre_net.3.weight"], G[f"{d}.pre_net.3.bias"])
+        dp0 = L.bn_bwd(dyp, tp["stp"], P[f"{d}.pre_net.1.weight"], P[f"{d}.pre_net.1.bias"], G[f"{d}.pre_net.1.weight"],
+                       G[f"{d}.pre_net.1.bias"])
+        dmu = L.linear_bwd(dp0, tp["feat"], P[f"{d}.pre_net.0.weight"], G[f"{d}.pre_net.0.weight"], G[f"{d}.pre_net.0.bias"])
+        # encoder
+        df3 = L.linear_bwd(dmu, tp["f3"], P[f"{e}.fc_mu.weight"], G[f"{e}.fc_mu.weight"], G[f"{e}.fc_mu.bias"])
+        dy2 = L.linear_bwd(df3, tp["y2"], P[f"{e}.out_net.6.weight"], G[f"{e}.out_net.6.weight"], G[f"{e}.out_net.6.bias"])
+        df2 = L.bn_bwd(dy2, tp["st2"], P[f"{e}.out_net.4.weight"], P[f"{e}.out_net.4.bias"], G[f"{e}.out_net.4.weight"],
+                       G[f"{e}.out_net.4.bias"])
+        dy1 = L.linear_bwd(df2, tp["y1"], P[f"{e}.out_net.3.weight"], G[f"{e}.out_net.3.weight"], G[f"{e}.out_net.3.bias"])
+        df1 = L.bn_bwd(dy1, tp["st1"], P[f"{e}.out_net.1.weight"], P[f"{e}.out_net.1.bias"], G[f"{e}.out_net.1.weight"],
+                       G[f"{e}.out_net.1.bias"])
+        dflat = L.linear_bwd(df1, tp["flat"], P[f"{e}.out_net.0.weight"], G[f"{e}.out_net.0.weight"], G[f"{e}.out_net.0.bias"])
+        L4 = tp["c4"].shape[1]
+        dc4 = ops.permute3(dflat.view(B, 32, L4), L.empty(B, L4, 32, like=dflat), (0, 2, 1))
+        L.conv_wgrad(dc4, tp["x4"], G[f"{e}.net.3.weight"], G[f"{e}.net.3.bias"], 3)
+        dy = L.conv_dgrad(dc4, P[f"{e}.net.3.weight"], tp["x4"].shape[1])
+        for li in (2, 1, 0):
+            name, Co, Ci, kw, stride = self.ENC[li]
+            x_in, st = tp["enc"][li]
+            dc = L.bn_bwd(dy, st, P[f"{e}.{name}.1.weight"], P[f"{e}.{name}.1.bias"], G[f"{e}.{name}.1.weight"],
+                          G[f"{e}.{name}.1.bias"])
+            L.conv_wgrad(dc, x_in, G[f"{e}.{name}.0.weight"], G[f"{e}.{name}.0.bias"], kw, stride=stride)
+            if li > 0:
+                dy = L.conv_dgrad(dc, P[f"{e}.{name}.0.weight"], x_in.shape[1], stride=stride)

@@ -1,0 +1,247 @@
+"""Forward / backward building blocks composed from the HIP ops.
+
+Activations are channel-last (batch, time, channels) everywhere, so every Conv1d / ConvTranspose1d / Linear is a
+row-window GEMM (ops.Win) and im2col is never materialised.  Each backward routine accumulates parameter
+gradients straight into the caller's gradient views (which live in one flat slab per network, see params.py).
+"""
+import torch
+
+from . import ops
+from .ops import Win
+
+
+def empty(*shape, like=None, device=None, dtype=torch.float32):
+    return torch.empty(*shape, device=like.device if like is not None else device, dtype=dtype)
+
+
+def transpose2d(w):
+    """[N, K] -> [K, N] on device (weights are re-transposed after every optimiser step; they are small)."""
+    N, K = w.shape
+    out = empty(K, N, like=w)
+    ops.permute3(w.view(1, N, K), out, (0, 2, 1))
+    return out
+
+
+def pack_conv_weight(w):
+    """nn.Conv1d weight (Co, Ci, kw) -> tap-major [Co, kw*Ci], the B operand of the conv-as-GEMM."""
+    Co, Ci, kw = w.shape
+    if Ci == 1 or kw == 1:
+        return w.reshape(Co, Ci * kw)          # same memory order
+    out = empty(Co, kw * Ci, like=w)
+    ops.permute3(w, out, (0, 2, 1))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- linear
+def linear_fwd(x2d, W, b, out=None, act_slope=1.0):
+    if out is None:
+        out = empty(x2d.shape[0], W.shape[0], like=x2d)
+    return ops.gemm_nt(Win.plain(x2d), W, b, out, act_slope=act_slope)
+
+
+def linear_bwd(dy2d, x2d, W, dW, db, need_dx=True, dx_out=None, accumulate_dx=False):
+    """dW += dy^T x ; db += colsum(dy) ; dx = dy @ W (optional)."""
+    if dW is not None:
+        ops.gemm_tn(dy2d, Win.plain(x2d), dW)
+    if db is not None:
+        ops.colsum(dy2d, db, accumulate=True)
+    if not need_dx:
+        return None
+    if dx_out is None:
+        dx_out = empty(dy2d.shape[0], W.shape[1], like=dy2d)
+    return ops.gemm_nt(Win.plain(dy2d), transpose2d(W), None, dx_out, accumulate=accumulate_dx)
+
+
+# ----------------------------------------------------------------------------------------------- conv1d
+def conv_out_len(L, kw, stride=1, pad=0, dil=1):
+    return (L + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+
+
+def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=1.0, rows_out=None):
+    """x: (B, L, Ci) view; w_packed: [Co, kw*Ci]; out: (B, Lout, Co) view (may be a channel slice of a wider buffer)."""
+    B, L, _ = x.shape
+    Lo = conv_out_len(L, kw, stride, pad, dil) if rows_out is None else rows_out
+    Co = w_packed.shape[0]
+    if out is None:
+        out = empty(B, Lo, Co, like=x)
+    assert tuple(out.shape) == (B, Lo, Co) and out.stride(2) == 1
+    A = Win.conv(x, kw, stride=stride, pad=pad, dil=dil, rows_out=Lo)
+    ops.gemm_nt(A, w_packed, b, out, act_slope=act_slope, c_batch_stride=out.stride(0), c_row_stride=out.stride(1),
+                c_rows_out=Lo)
+    return out
+
+
+def conv_wgrad(dy, x, dW, db, kw, *, stride=1, pad=0, dil=1):
+    """dy: (B, Lout, Co) contiguous; x: (B, L, Ci) view; dW: (Co, Ci, kw) gradient view (accumulates)."""
+    B, Lo, Co = dy.shape
+    A = Win.conv(x, kw, stride=stride, pad=pad, dil=dil, rows_out=Lo)
+    dy2 = dy.reshape(B * Lo, Co)
+    if dW is not None:
+        ops.gemm_tn(dy2, A, dW.view(Co, -1), out_kw=kw if (kw > 1 and x.shape[2] > 1) else 0)
+    if db is not None:
+        ops.colsum(dy2, db, accumulate=True)
+
+
+def conv_dgrad(dy, w, L_in, *, stride=1):
+    """Input gradient of Conv1d(stride, no padding, dilation 1).  dy: (B, Lout, Co) view; w: (Co, Ci, kw).
+    One GEMM per phase r = p % stride: dx[b, stride*q + r] = sum_j dy[b, q - j] . Wr[:, j, :]  (zero taps outside)."""
+    B, Lo, Co = dy.shape
+    _, Ci, kw = w.shape
+    J = (kw + stride - 1) // stride
+    packed = empty(stride, Ci, J * Co, like=w)
+    ops.conv_dgrad_pack(w, packed, stride)
+    dx = empty(B, L_in, Ci, like=w)
+    for r in range(stride):
+        nq = (L_in - r + stride - 1) // stride
+        if nq <= 0:
+            continue
+        A = Win.taps(dy, J, shift=0, dil=-1, rows_out=nq)
+        ops.gemm_nt(A, packed[r], None, dx[:, r:, :], c_batch_stride=dx.stride(0), c_row_stride=stride * Ci, c_rows_out=nq)
+    return dx
+
+
+def conv_transpose_fwd(x, w, b, *, out=None):
+    """ConvTranspose1d(stride 1, no padding).  x: (B, L, Ci); w: (Ci, Co, kw) -> (B, L + kw - 1, Co).
+    Same arithmetic as conv_dgrad with the roles of the channel axes swapped."""
+    B, L, Ci = x.shape
+    _, Co, kw = w.shape
+    packed = empty(1, Co, kw * Ci, like=w)
+    ops.conv_dgrad_pack(w, packed, 1)            # (Ci, Co, kw) seen as a conv weight (Co'=Ci, Ci'=Co)
+    Lo = L + kw - 1
+    if out is None:
+        out = empty(B, Lo, Co, like=x)
+    A = Win.taps(x, kw, shift=0, dil=-1, rows_out=Lo)
+    ops.gemm_nt(A, packed[0], b, out, c_batch_stride=out.stride(0), c_row_stride=out.stride(1), c_rows_out=Lo)
+    return out
+
+
+def conv_transpose_bwd(dy, x, w, dW, db, need_dx=True):
+    """dy: (B, L+kw-1, Co); x: (B, L, Ci); w/dW: (Ci, Co, kw)."""
+    B, L, Ci = x.shape
+    _, Co, kw = w.shape
+    Lo = L + kw - 1
+    # dW[ci, co, k] = sum_{b,l} x[b,l,ci] * dy[b,l+k,co]
+    A = Win.conv(dy, kw, rows_out=L)
+    ops.gemm_tn(x.reshape(B * L, Ci), A, dW.view(Ci, -1), out_kw=kw)
+    ops.colsum(dy.reshape(B * Lo, Co), db, accumulate=True)
+    if not need_dx:
+        return None
+    # dx[b,l,ci] = sum_k sum_co dy[b,l+k,co] * w[ci,co,k]  == Conv1d with weight (Ci, Co, kw)
+    return conv_fwd(dy, pack_conv_weight(w), None, kw, rows_out=L)
+
+
+# ----------------------------------------------------------------------------------------------- batch norm
+class BNState:
+    """Per-call statistics of one BatchNorm1d (kept for the backward pass)."""
+    __slots__ = ("mean", "rstd", "groups", "x", "slope")
+
+
+def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, *, training, groups=1, act_slope=1.0, out=None, repeats=1):
+    """x: (..., C) contiguous channel-last.  Returns (y, BNState)."""
+    Cc = x.shape[-1]
+    x2 = x.view(-1, Cc)
+    st = BNState()
+    g = groups if training else 1
+    st.mean, st.rstd = empty(g, Cc, like=x), empty(g, Cc, like=x)
+    st.groups, st.x, st.slope = g, x, act_slope
+    if training:
+        ws = torch.empty(2 * g * Cc, device=x.device, dtype=torch.float64)
+        ops.bn_train_stats(x2, g, ws, st.mean, st.rstd, running_mean, running_var, nbt, repeats=repeats)
+    else:
+        ops.bn_eval_stats(running_mean, running_var, st.mean, st.rstd)
+    y = torch.empty_like(x) if out is None else out
+    ops.bn_apply(x2, y.view(-1, Cc), g, st.mean, st.rstd, gamma, beta, act_slope)
+    return y, st
+
+
+def bn_bwd(dy, st, gamma, beta, dgamma, dbeta, *, g0=0, ng=1, row0=0):
+    """Backward of act(BN(x)) for `ng` consecutive statistics groups starting at group g0.  dy: (nb, ..., C) holds
+    exactly those groups' batch rows; the matching rows of the taped input start at batch index row0."""
+    Cc = dy.shape[-1]
+    nb = dy.shape[0]
+    assert nb % ng == 0
+    per = nb // ng
+    dy = dy.contiguous()
+    dx = torch.empty_like(dy)
+    ws = torch.empty(2 * Cc, device=dy.device, dtype=torch.float64)
+    for g in range(ng):
+        sl = slice(g * per, (g + 1) * per)
+        x = st.x[row0 + g * per:row0 + (g + 1) * per]
+        ops.bn_backward(dy[sl].reshape(-1, Cc), x.reshape(-1, Cc), dx[sl].view(-1, Cc), st.mean[g0 + g], st.rstd[g0 + g],
+                        gamma, beta, st.slope, ws, dgamma, dbeta)
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------- GRU stack
+class GRUTape:
+    __slots__ = ("x", "y", "save", "masks", "B", "T", "H")
+
+
+def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save=False, inject=None, tag="g"):
+    """Multi-layer bidirectional GRU.  x: (B, T, Kin) contiguous.  P: name -> parameter tensor.
+    Returns (y_last (B,T,2H), tape)."""
+    B, T, _ = x.shape
+    tape = GRUTape()
+    tape.x, tape.y, tape.save, tape.masks = [], [], [], []
+    tape.B, tape.T, tape.H = B, T, H
+    cur = x
+    for l in range(n_layers):
+        Kin = cur.shape[2]
+        gi = empty(2, B, T, 3 * H, like=x)
+        for d, sfx in enumerate(("", "_reverse")):
+            ops.gemm_nt(Win.plain(cur.view(B * T, Kin)), P[f"{prefix}.weight_ih_l{l}{sfx}"], P[f"{prefix}.bias_ih_l{l}{sfx}"],
+                        gi[d].view(B * T, 3 * H))
+        y = empty(B, T, 2 * H, like=x)
+        sv = empty(2, B, T, 4 * H, like=x) if save else None
+        ops.gru_forward(gi, (P[f"{prefix}.weight_hh_l{l}"], P[f"{prefix}.weight_hh_l{l}_reverse"]),
+                        (P[f"{prefix}.bias_hh_l{l}"], P[f"{prefix}.bias_hh_l{l}_reverse"]), y, sv)
+        tape.x.append(cur); tape.y.append(y); tape.save.append(sv)
+        mask = None
+        if training and l < n_layers - 1:
+            name = f"{tag}.gru.drop{l}"
+            if inject is not None and name in inject:
+                mask = inject[name]
+            elif p_drop > 0:
+                mask = ops.dropout_mask(torch.empty_like(y), p_drop, rng.state, rng.site(name))
+            if mask is not None:
+                cur = ops.mul(y, mask, torch.empty_like(y))
+            else:
+                cur = y
+        else:
+            cur = y
+        tape.masks.append(mask)
+    return cur, tape
+
+
+def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=True, param_grads=True):
+    """dy: (nb, T, 2H) gradient w.r.t. the last layer's output for rows [b0, b0+nb) of the taped forward.
+    Accumulates into G[...] and returns dx (nb, T, Kin0)."""
+    B, T, H = tape.B, tape.T, tape.H
+    nb = B - b0 if nb is None else nb
+    rows = slice(b0, b0 + nb)
+    dh = empty(4 * nb * H, like=dy)
+    for l in range(n_layers - 1, -1, -1):
+        if tape.masks[l] is not None:
+            dy = ops.mul(dy, tape.masks[l][rows].contiguous(), torch.empty_like(dy))
+        wt = tuple(transpose2d(P[f"{prefix}.weight_hh_l{l}{s}"]) for s in ("", "_reverse"))
+        dgi, dgh = empty(2, nb, T, 3 * H, like=dy), empty(2, nb, T, 3 * H, like=dy)
+        ops.gru_backward(dy, tape.y[l], tape.save[l], wt, dgi, dgh, dh, b0=b0, nb=nb)
+        x_l = tape.x[l][rows]
+        Kin = x_l.shape[2]
+        y_l = tape.y[l][rows]
+        dx = None
+        for d, sfx in enumerate(("", "_reverse")):
+            gi2, gh2 = dgi[d].view(nb * T, 3 * H), dgh[d].view(nb * T, 3 * H)
+            if param_grads:
+                ops.gemm_tn(gi2, Win.plain(x_l.reshape(nb * T, Kin)), G[f"{prefix}.weight_ih_l{l}{sfx}"])
+                ops.colsum(gi2, G[f"{prefix}.bias_ih_l{l}{sfx}"])
+                # h_{t-1} of direction d is the layer output one step back (forward) / ahead (reverse), zero at the ends
+                hwin = Win.taps(y_l[:, :, d * H:(d + 1) * H], 1, shift=(1 if d else -1), dil=1, rows_out=T)
+                ops.gemm_tn(gh2, hwin, G[f"{prefix}.weight_hh_l{l}{sfx}"])
+                ops.colsum(gh2, G[f"{prefix}.bias_hh_l{l}{sfx}"])
+            if need_dx or l > 0:
+                if dx is None:
+                    dx = empty(nb * T, Kin, like=dy)
+                ops.gemm_nt(Win.plain(gi2), transpose2d(P[f"{prefix}.weight_ih_l{l}{sfx}"]), None, dx, accumulate=(d == 1))
+        dy = dx.view(nb, T, Kin) if dx is not None else None
+    return dy

@@ -1,0 +1,383 @@
+"""Checked Python wrappers over the C ABI: torch tensors in, raw device pointers out.
+
+PyTorch is plumbing here (device memory, streams); every arithmetic op below runs in libtrimodal_hip.so.
+Shape / dtype / bounds checks live in this layer so that a wrong call raises in Python instead of faulting on
+the GPU (kernels themselves only guard their own tile edges).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Window, call
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise TypeError(f"{name}: expected a CUDA float32 tensor, got {type(t).__name__} "
+                        f"{getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
+    return t
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _room(t):
+    """floats addressable from t.data_ptr() to the end of its storage"""
+    return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+
+
+def _flat(t, name):
+    _f32(t, name)
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+class Win:
+    """Row-window view (struct tg_window) over a channel-last buffer, with a bounds check against the storage."""
+
+    def __init__(self, t, *, batches, batch_stride, row_stride, rows_in, rows_out, cw, K, row_step=1, shift=0, dil=1):
+        _f32(t, "window base")
+        assert K > 0 and cw > 0 and K % cw == 0 and rows_in > 0 and rows_out > 0 and batches > 0
+        max_off = (batches - 1) * batch_stride + (rows_in - 1) * row_stride + cw - 1
+        if max_off >= _room(t) or batch_stride < 0 or row_stride < 0:
+            raise ValueError(f"window exceeds its tensor: max offset {max_off} >= {_room(t)}")
+        self.t, self.batches, self.rows_out, self.K = t, batches, rows_out, K
+        self.M = batches * rows_out
+        self.s = Window(t.data_ptr(), batch_stride, row_stride, rows_in, rows_out, row_step, shift, dil, cw, K)
+
+    @staticmethod
+    def plain(x):
+        """2-D matrix view [M, K] (unit inner stride; rows may be strided, e.g. a column slice)."""
+        assert x.dim() == 2 and x.stride(1) == 1, (x.shape, x.stride())
+        M, K = x.shape
+        return Win(x, batches=1, batch_stride=0, row_stride=x.stride(0), rows_in=M, rows_out=M, cw=K, K=K)
+
+    @staticmethod
+    def conv(x, kw, *, stride=1, pad=0, dil=1, rows_out=None):
+        """Conv1d window over x: (B, L, C) channel-last (unit channel stride).  rows_out defaults to the conv length."""
+        assert x.dim() == 3 and x.stride(2) == 1, (x.shape, x.stride())
+        B, L, Cc = x.shape
+        if rows_out is None:
+            rows_out = (L + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        return Win(x, batches=B, batch_stride=x.stride(0), row_stride=x.stride(1), rows_in=L, rows_out=rows_out,
+                   cw=Cc, K=kw * Cc, row_step=stride, shift=-pad, dil=dil)
+
+    @staticmethod
+    def taps(x, n_taps, *, shift, dil, rows_out):
+        """General tap window over x: (B, L, C): source row = r + shift + tap*dil (zero outside [0, L))."""
+        assert x.dim() == 3 and x.stride(2) == 1
+        B, L, Cc = x.shape
+        return Win(x, batches=B, batch_stride=x.stride(0), row_stride=x.stride(1), rows_in=L, rows_out=rows_out,
+                   cw=Cc, K=n_taps * Cc, row_step=1, shift=shift, dil=dil)
+
+
+def gemm_nt(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None,
+            c_rows_out=None, M=None):
+    """out(m, :) = act(A(m, :) @ W^T + bias) [+ out].  W: [N, K] (row stride may exceed K).
+    out: 2-D view [M, N] (unit inner stride) unless explicit C addressing is given."""
+    _f32(W, "W"); _f32(out, "out")
+    assert W.dim() == 2 and W.stride(1) == 1 and W.shape[1] == A.K, (W.shape, A.K)
+    N = W.shape[0]
+    M = A.M if M is None else M
+    if bias is not None:
+        _f32(bias, "bias"); assert bias.numel() == N and bias.is_contiguous()
+    if c_row_stride is None:
+        assert out.dim() == 2 and out.stride(1) == 1 and tuple(out.shape) == (M, N), (out.shape, M, N)
+        c_batch_stride, c_row_stride, c_rows_out = 0, out.stride(0), M
+    nb = (M + c_rows_out - 1) // c_rows_out
+    max_off = (nb - 1) * c_batch_stride + (c_rows_out - 1) * c_row_stride + N - 1
+    if max_off >= _room(out):
+        raise ValueError(f"gemm_nt: output exceeds its tensor ({max_off} >= {_room(out)})")
+    if (W.shape[0] - 1) * W.stride(0) + A.K - 1 >= _room(W):
+        raise ValueError("gemm_nt: W exceeds its tensor")
+    call("tg_gemm_nt", C.byref(A.s), _p(W), W.stride(0), _p(bias), _p(out), c_batch_stride, c_row_stride, c_rows_out,
+         M, N, float(act_slope), int(bool(accumulate)), _stream())
+    return out
+
+
+def gemm_tn(dY, A: Win, dW, *, out_kw=0):
+    """dW[n, perm(k)] += sum_m dY[m, n] * A(m, k).  dY: 2-D view [M, N]; dW: contiguous, N rows of K floats."""
+    _f32(dY, "dY"); _f32(dW, "dW")
+    assert dY.dim() == 2 and dY.stride(1) == 1 and dY.shape[0] == A.M, (dY.shape, A.M)
+    M, N = dY.shape
+    assert dW.is_contiguous() and dW.numel() == N * A.K and dW.shape[0] == N, (dW.shape, N, A.K)
+    if (M - 1) * dY.stride(0) + N - 1 >= _room(dY):
+        raise ValueError("gemm_tn: dY exceeds its tensor")
+    call("tg_gemm_tn", _p(dY), dY.stride(0), C.byref(A.s), _p(dW), A.K, M, N, int(out_kw), _stream())
+    return dW
+
+
+def colsum(X, out, *, accumulate=True):
+    _f32(X, "X"); _flat(out, "out")
+    assert X.dim() == 2 and X.stride(1) == 1 and out.numel() == X.shape[1]
+    if (X.shape[0] - 1) * X.stride(0) + X.shape[1] - 1 >= _room(X):
+        raise ValueError("colsum: X exceeds its tensor")
+    call("tg_colsum", _p(X), X.stride(0), X.shape[0], X.shape[1], _p(out), int(accumulate), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- GRU
+def gru_forward(gi, w_hh, b_hh, y, save):
+    """gi: [2, B, T, 3H] contiguous; w_hh/b_hh: (fwd, rev) pairs; y: [B, T, 2H]; save: [2, B, T, 4H] or None."""
+    _flat(gi, "gi"); _flat(y, "y")
+    _, B, T, H3 = gi.shape
+    H = H3 // 3
+    assert gi.shape[0] == 2 and tuple(y.shape) == (B, T, 2 * H)
+    for w, b in zip(w_hh, b_hh):
+        _flat(w, "w_hh"); _flat(b, "b_hh"); assert tuple(w.shape) == (3 * H, H) and b.numel() == 3 * H
+    if save is not None:
+        _flat(save, "save"); assert tuple(save.shape) == (2, B, T, 4 * H)
+    call("tg_gru_forward", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
+         B * T * 4 * H, B, T, H, _stream())
+    return y
+
+
+def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None):
+    """Backward through time for batch rows [b0, b0+nb) of a (possibly larger) stacked forward.
+    dy: [nb, T, 2H]; y: [B, T, 2H]; save: [2, B, T, 4H]; w_hh_t: (fwd, rev) each [H, 3H]; dgi/dgh: [2, nb, T, 3H]."""
+    _flat(dy, "dy"); _flat(y, "y"); _flat(save, "save"); _flat(dgi, "dgi"); _flat(dgh, "dgh"); _flat(dh_scratch, "dh")
+    B, T, H2 = y.shape
+    H = H2 // 2
+    nb = B - b0 if nb is None else nb
+    assert 0 <= b0 and b0 + nb <= B and tuple(dy.shape) == (nb, T, 2 * H)
+    assert tuple(save.shape) == (2, B, T, 4 * H) and tuple(dgi.shape) == (2, nb, T, 3 * H) == tuple(dgh.shape)
+    assert dh_scratch.numel() >= 4 * nb * H
+    for w in w_hh_t:
+        _flat(w, "w_hh_t"); assert tuple(w.shape) == (H, 3 * H)
+    ys, ss = y[b0:b0 + nb], save[:, b0:b0 + nb]
+    call("tg_gru_backward", _p(dy), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
+         _p(dgi), _p(dgh), nb * T * 3 * H, _p(dh_scratch), nb, T, H, _stream())
+
+
+# ------------------------------------------------------------------------------------------------- BatchNorm
+def bn_train_stats(x2d, groups, ws, mean, rstd, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, repeats=1):
+    _flat(x2d, "x"); rows, Cc = x2d.shape
+    assert ws.dtype == torch.float64 and ws.numel() >= 2 * groups * Cc and ws.is_cuda
+    assert mean.numel() == groups * Cc == rstd.numel()
+    assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda)
+    call("tg_bn_train_stats", _p(x2d), rows, Cc, groups, _p(ws), _p(_flat(mean, "mean")), _p(_flat(rstd, "rstd")),
+         _p(running_mean), _p(running_var), _p(nbt), float(eps), float(momentum), int(repeats), _stream())
+
+
+def bn_eval_stats(running_mean, running_var, mean, rstd, eps=1e-5):
+    Cc = running_mean.numel()
+    call("tg_bn_eval_stats", _p(_flat(running_mean, "rm")), _p(_flat(running_var, "rv")), Cc, float(eps),
+         _p(_flat(mean, "mean")), _p(_flat(rstd, "rstd")), _stream())
+
+
+def bn_apply(x2d, y2d, groups, mean, rstd, gamma, beta, act_slope):
+    _flat(x2d, "x"); _flat(y2d, "y"); rows, Cc = x2d.shape
+    assert y2d.shape == x2d.shape and mean.numel() == groups * Cc and gamma.numel() == Cc == beta.numel()
+    call("tg_bn_apply", _p(x2d), _p(y2d), rows, Cc, groups, _p(mean), _p(rstd), _p(_flat(gamma, "gamma")),
+         _p(_flat(beta, "beta")), float(act_slope), _stream())
+    return y2d
+
+
+def bn_backward(dy2d, x2d, dx2d, mean, rstd, gamma, beta, act_slope, ws, dgamma, dbeta):
+    _flat(dy2d, "dy"); _flat(x2d, "x"); _flat(dx2d, "dx"); rows, Cc = x2d.shape
+    assert dy2d.shape == x2d.shape == dx2d.shape and mean.numel() >= Cc and ws.dtype == torch.float64 and ws.numel() >= 2 * Cc
+    call("tg_bn_backward", _p(dy2d), _p(x2d), _p(dx2d), rows, Cc, _p(mean), _p(rstd), _p(gamma), _p(beta),
+         float(act_slope), _p(ws), _p(dgamma), _p(dbeta), _stream())
+    return dx2d
+
+
+# ------------------------------------------------------------------------------------------------- element-wise
+def _same(*ts):
+    n = ts[0].numel()
+    for t in ts:
+        _flat(t, "operand"); assert t.numel() == n, [tuple(x.shape) for x in ts]
+    return n
+
+
+def add_relu(a, b, y):
+    call("tg_add_relu", _p(a), _p(b), _p(y), _same(a, b, y), _stream()); return y
+
+
+def act_mask_bwd(dy, y, mask, slope, dx):
+    n = _same(dy, y, dx) if mask is None else _same(dy, y, mask, dx)
+    call("tg_act_mask_bwd", _p(dy), _p(y), _p(mask), float(slope), _p(dx), n, _stream()); return dx
+
+
+def mul(x, mask, y):
+    call("tg_mul", _p(x), _p(mask), _p(y), _same(x, mask, y), _stream()); return y
+
+
+def axpy(x, y, alpha=1.0, accumulate=True):
+    call("tg_axpy", _p(x), _p(y), float(alpha), int(accumulate), _same(x, y), _stream()); return y
+
+
+def _chk2d(t, rows, cols, name):
+    _f32(t, name)
+    assert t.dim() == 2 and t.stride(1) == 1 and t.shape[0] >= rows and t.shape[1] >= cols, (name, t.shape, rows, cols)
+    if (rows - 1) * t.stride(0) + cols - 1 >= _room(t):
+        raise ValueError(f"{name}: exceeds its tensor")
+
+
+def copy2d(src, dst, *, accumulate=False):
+    """dst[r, c] (+)= src[r, c] for 2-D views with unit inner stride."""
+    rows, cols = src.shape
+    _chk2d(src, rows, cols, "src"); _chk2d(dst, rows, cols, "dst"); assert tuple(dst.shape) == (rows, cols)
+    call("tg_copy2d", _p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, int(accumulate), _stream()); return dst
+
+
+def repeat_rows(src, dst, B, T):
+    """dst[(b*T + t), :] = src[b, :]; src [B, cols], dst 2-D view [B*T, cols]."""
+    cols = src.shape[1]
+    _chk2d(src, B, cols, "src"); _chk2d(dst, B * T, cols, "dst")
+    call("tg_repeat_rows", _p(src), src.stride(0), _p(dst), dst.stride(0), B, T, cols, _stream()); return dst
+
+
+def sum_rows(src, dst, B, T, *, accumulate=False):
+    cols = dst.shape[1]
+    _chk2d(src, B * T, cols, "src"); _chk2d(dst, B, cols, "dst")
+    call("tg_sum_rows", _p(src), src.stride(0), _p(dst), dst.stride(0), B, T, cols, int(accumulate), _stream()); return dst
+
+
+def add_halves(y, o):
+    _flat(y, "y"); _flat(o, "o"); H = o.shape[-1]; M = o.numel() // H
+    assert y.numel() == 2 * o.numel()
+    call("tg_add_halves", _p(y), _p(o), M, H, _stream()); return o
+
+
+def dup_halves(d_o, dy):
+    _flat(d_o, "do"); _flat(dy, "dy"); H = d_o.shape[-1]; M = d_o.numel() // H
+    assert dy.numel() == 2 * d_o.numel()
+    call("tg_dup_halves", _p(d_o), _p(dy), M, H, _stream()); return dy
+
+
+def _i64(t, name):
+    if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+        raise TypeError(f"{name}: expected a contiguous CUDA int64 tensor")
+    return t
+
+
+def make_pre_seq(target, pre, n_pre):
+    _flat(target, "target"); _flat(pre, "pre"); B, T, D = target.shape
+    assert tuple(pre.shape) == (B, T, D + 1)
+    call("tg_make_pre_seq", _p(target), _p(pre), B, T, D, int(n_pre), _stream()); return pre
+
+
+def embed_gather(table, idx, out):
+    _flat(table, "table"); _i64(idx, "idx"); _flat(out, "out")
+    n_rows, D = table.shape
+    assert out.numel() == idx.numel() * D
+    call("tg_embed_gather", _p(table), _p(idx), _p(out), idx.numel(), D, n_rows, _stream()); return out
+
+
+def embed_scatter_add(dout, idx, dtable):
+    _flat(dout, "dout"); _i64(idx, "idx"); _flat(dtable, "dtable")
+    n_rows, D = dtable.shape
+    assert dout.numel() == idx.numel() * D
+    call("tg_embed_scatter_add", _p(dout), _p(idx), _p(dtable), idx.numel(), D, n_rows, _stream()); return dtable
+
+
+def permute3(x, out, perm):
+    _flat(x, "in"); _flat(out, "out"); assert x.dim() == 3 and out.numel() == x.numel()
+    call("tg_permute3", _p(x), _p(out), *x.shape, *perm, _stream()); return out
+
+
+def conv_dgrad_pack(w, out, stride):
+    _flat(w, "w"); _flat(out, "out"); Co, Ci, kw = w.shape
+    J = (kw + stride - 1) // stride
+    assert out.numel() == stride * Ci * J * Co
+    call("tg_conv_dgrad_pack", _p(w), _p(out), Co, Ci, kw, stride, _stream()); return out
+
+
+def weight_norm_fwd(v, g, w_packed):
+    _flat(v, "v"); _flat(g, "g"); _flat(w_packed, "w"); Co, Ci, kw = v.shape
+    assert g.numel() == Co and w_packed.numel() == v.numel()
+    call("tg_weight_norm_fwd", _p(v), _p(g), _p(w_packed), Co, Ci, kw, _stream()); return w_packed
+
+
+def weight_norm_bwd(dw_packed, v, g, dg, dv):
+    Co, Ci, kw = v.shape
+    assert _same(dw_packed, v, dv) and dg.numel() == Co == g.numel()
+    call("tg_weight_norm_bwd", _p(dw_packed), _p(v), _p(g), _p(_flat(dg, "dg")), _p(dv), Co, Ci, kw, _stream())
+
+
+# ------------------------------------------------------------------------------------------------- RNG
+def new_rng_state(seed, device):
+    return torch.tensor([int(seed) & (2 ** 63 - 1), 0], dtype=torch.int64, device=device)
+
+
+def rng_advance(state):
+    call("tg_rng_advance", _p(_i64(state, "rng_state")), _stream())
+
+
+def dropout_mask(mask, p, state, site):
+    call("tg_dropout_mask", _p(_flat(mask, "mask")), mask.numel(), float(p), _p(_i64(state, "rng_state")), int(site), _stream())
+    return mask
+
+
+def normal(out, state, site):
+    call("tg_normal", _p(_flat(out, "out")), out.numel(), _p(_i64(state, "rng_state")), int(site), _stream()); return out
+
+
+def randperm(out, state, site):
+    call("tg_randperm", _p(_i64(out, "out")), out.numel(), _p(_i64(state, "rng_state")), int(site), _stream()); return out
+
+
+def gather_i64(src, perm, out):
+    _i64(src, "src"); _i64(perm, "perm"); _i64(out, "out"); assert src.numel() == perm.numel() == out.numel()
+    call("tg_gather_i64", _p(src), _p(perm), _p(out), src.numel(), _stream()); return out
+
+
+# ------------------------------------------------------------------------------------------------- speaker path / losses
+def reparam_fwd(mu, logvar, eps, z):
+    call("tg_reparam_fwd", _p(mu), _p(logvar), _p(eps), _p(z), _same(mu, logvar, eps, z), _stream()); return z
+
+
+def reparam_bwd(dz, logvar, eps, dmu, dlogvar):
+    call("tg_reparam_bwd", _p(dz), _p(logvar), _p(eps), _p(dmu), _p(dlogvar), _same(dz, logvar, eps, dmu, dlogvar), _stream())
+
+
+def gan_d_loss(logit_real, logit_fake, out, d_real, d_fake):
+    B = _same(logit_real, logit_fake, d_real, d_fake); _flat(out, "out")
+    call("tg_gan_d_loss", _p(logit_real), _p(logit_fake), B, _p(out), _p(d_real), _p(d_fake), _stream())
+
+
+def gan_g_loss(out_pose, target, out_rand, z, z_rand, mu, logvar, logit_out, weights, use_gan, ws, scalars, d_out, d_mu,
+               d_logvar, d_logit):
+    B = out_pose.shape[0]
+    TD = _same(out_pose, target, out_rand, d_out) // B
+    Z = _same(z, z_rand, mu, logvar, d_mu, d_logvar) // B
+    assert _same(logit_out, d_logit) == B and ws.numel() >= 3 * B and scalars.numel() >= 5
+    call("tg_gan_g_loss", _p(out_pose), _p(target), _p(out_rand), _p(z), _p(z_rand), _p(mu), _p(logvar), _p(logit_out),
+         B, TD, Z, *[float(w) for w in weights], int(bool(use_gan)), _p(_flat(ws, "ws")), _p(_flat(scalars, "scalars")),
+         _p(d_out), _p(d_mu), _p(d_logvar), _p(d_logit), _stream())
+
+
+def l1_mean(a, b, out):
+    call("tg_l1_mean", _p(a), _p(b), _same(a, b), _p(_flat(out, "out")), _stream()); return out
+
+
+def sigmoid(x, y):
+    call("tg_sigmoid", _p(x), _p(y), _same(x, y), _stream()); return y
+
+
+def sigmoid_bwd(dy, y, dx):
+    call("tg_sigmoid_bwd", _p(dy), _p(y), _p(dx), _same(dy, y, dx), _stream()); return dx
+
+
+def ae_loss(recon, target, out, d_recon):
+    B, T, D = recon.shape; _same(recon, target, d_recon)
+    call("tg_ae_loss", _p(recon), _p(target), B, T, D, _p(_flat(out, "out")), _p(d_recon), _stream())
+
+
+# ------------------------------------------------------------------------------------------------- optimiser
+def counter_inc(counter):
+    assert counter.is_cuda and counter.dtype == torch.int32
+    call("tg_counter_inc", _p(counter), _stream())
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step_dev):
+    n = _same(p, g, m, v)
+    assert step_dev.is_cuda and step_dev.dtype == torch.int32
+    call("tg_adam_step", _p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps), _p(step_dev), _stream())

@@ -1,0 +1,36 @@
+"""Fused Adam over a flat parameter slab (torch.optim.Adam semantics, train.py:104-109)."""
+import torch
+
+from . import ops
+
+
+class FusedAdam:
+    """One launch per step for the whole network.  Same maths as torch.optim.Adam(lr, betas, eps=1e-8) without weight
+    decay / amsgrad; the step counter lives on the device so a captured hipGraph replays correctly."""
+
+    def __init__(self, module_or_engine, lr, betas=(0.5, 0.999), eps=1e-8):
+        eng = getattr(module_or_engine, "engine", module_or_engine)
+        self.engine = eng
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+
+    @property
+    def slab(self):
+        return self.engine.slab.ensure()
+
+    def zero_grad(self, set_to_none=False):
+        self.slab.zero_grad()
+
+    def step(self):
+        s = self.slab
+        ops.counter_inc(s.step)
+        ops.adam_step(s.flat, s.grad, s.m, s.v, self.lr, self.betas[0], self.betas[1], self.eps, s.step)
+
+    def state_dict(self):
+        s = self.slab
+        return {"step": int(s.step.item()), "exp_avg": s.m.clone(), "exp_avg_sq": s.v.clone(), "lr": self.lr,
+                "betas": self.betas, "eps": self.eps, "names": list(s.names), "offsets": list(s.offsets)}
+
+    def load_state_dict(self, sd):
+        s = self.slab
+        s.m.copy_(sd["exp_avg"]); s.v.copy_(sd["exp_avg_sq"])
+        s.step.fill_(int(sd["step"]))

@@ -1,0 +1,179 @@
+"""One GAN training iteration on the HIP engines: the role of train_eval/train_gan.py:train_iter_gan (:13-103).
+
+Same order of operations and the same losses as the reference; what changes is the schedule:
+  * the generator forwards of one iteration (G fwd #1 for the D step, #2 for the G step, #3 with shuffled speakers)
+    share weights and inputs, so they run as ONE stacked forward with per-call BatchNorm statistics and independent
+    dropout / reparameterisation draws; only call #2 is taped and back-propagated (the other two are detached in the
+    reference, train_gan.py:39,69);
+  * D(real) and D(fake) of the discriminator step run as one stacked forward/backward;
+  * the discriminator gradients produced by the generator step are never formed (the reference discards them);
+  * nothing reads a loss back to the host inside the iteration; the five .item() calls of :94-102 become one
+    deferred read (StepLosses.to_dict()).
+With static shapes the whole iteration is captured into a hipGraph (GraphedGanStep).
+"""
+import torch
+
+from . import ops
+from .optim import FusedAdam
+
+
+class StepLosses:
+    """Device-resident loss scalars of one iteration; to_dict() reproduces the reference's return value."""
+
+    def __init__(self, g_scalars, d_scalar, hp, post_warmup):
+        self.g, self.d, self.hp, self.post = g_scalars, d_scalar, hp, post_warmup
+
+    def to_dict(self):
+        g = self.g.tolist()       # one device->host read
+        hp = self.hp
+        ret = {"loss": hp["loss_regression_weight"] * g[0]}
+        if g[1]:
+            ret["KLD"] = hp["loss_kld_weight"] * g[1]
+        if g[2]:
+            ret["DIV_REG"] = hp["loss_reg_weight"] * g[2]
+        if self.post:
+            ret["gen"] = hp["loss_gan_weight"] * g[3]
+            ret["dis"] = float(self.d.item())
+        return ret
+
+
+def hyper_params(args):
+    keys = ("n_pre_poses", "loss_warmup", "loss_gan_weight", "loss_regression_weight", "loss_kld_weight", "loss_reg_weight",
+            "learning_rate", "discriminator_lr_weight")
+    return {k: getattr(args, k) for k in keys}
+
+
+def _stack_inject(inject, tags, prefix):
+    """Per-call injected draws ('g1.x', 'g2.x', ...) -> stacked draws ('<prefix>.x') in call order."""
+    if inject is None:
+        return None
+    out = {}
+    suffixes = {k.split(".", 1)[1] for k in inject if "." in k and k.split(".", 1)[0] in tags}
+    for sfx in suffixes:
+        parts = [inject.get(f"{t}.{sfx}") for t in tags]
+        if all(p is not None for p in parts):
+            out[f"{prefix}.{sfx}"] = torch.cat(parts, dim=0).contiguous()
+    return out
+
+
+class GanTrainer:
+    def __init__(self, generator, discriminator, args, grad_sync=None):
+        self.gen, self.dis = generator, discriminator
+        self.G, self.D = generator.engine, discriminator.engine
+        self.hp = hyper_params(args)
+        self.g_opt = FusedAdam(self.G, lr=self.hp["learning_rate"], betas=(0.5, 0.999))
+        self.d_opt = FusedAdam(self.D, lr=self.hp["learning_rate"] * self.hp["discriminator_lr_weight"], betas=(0.5, 0.999))
+        self.grad_sync = grad_sync          # ddp.GradSync or None
+
+    # -------------------------------------------------------------------------------------------------------
+    def train_iter(self, epoch, in_text, in_audio, target, vid, inject=None):
+        """in_text (B,34) int64, in_audio (B,A) f32, target (B,34,27) f32, vid (B,) int64, all on the GPU.
+        `inject` (tests only) replays recorded random draws; names follow oracle.ref_model.Rand."""
+        hp = self.hp
+        post = epoch > hp["loss_warmup"] and hp["loss_gan_weight"] > 0.0
+        st = self.phase_forward(post, in_text, in_audio, target, vid, inject)
+        if post:
+            self.phase_d_step(st, inject)
+        self.phase_g_backward(st, post, inject)
+        self.phase_g_update()
+        return StepLosses(st["g_scalars"], st.get("d_scalar"), hp, post)
+
+    # ---- phase 1: stacked generator forward (train_gan.py:30,50,67)
+    def phase_forward(self, post, in_text, in_audio, target, vid, inject):
+        G, D = self.G, self.D
+        B = target.shape[0]
+        dev = target.device
+        G.rng.advance(); D.rng.advance()
+        target = target.contiguous().float()
+        pre = ops.make_pre_seq(target, torch.empty(B, target.shape[1], target.shape[2] + 1, device=dev), self.hp["n_pre_poses"])
+        if inject is not None and "perm" in inject:
+            perm = inject["perm"].to(dev).long().contiguous()
+        else:
+            perm = ops.randperm(torch.empty(B, dtype=torch.int64, device=dev), G.rng.state, G.rng.site("perm"))
+        vid = vid.contiguous()
+        vid_r = ops.gather_i64(vid, perm, torch.empty_like(vid))
+        tags = ["g1", "g2", "g3"] if post else ["g2", "g3"]
+        ng, i2 = len(tags), tags.index("g2")
+        pre_s = pre.repeat(ng, 1, 1)                                   # data movement only
+        text_s = in_text.contiguous().repeat(ng, 1)
+        vid_s = torch.cat([vid] * (ng - 1) + [vid_r])
+        res = G.forward(pre_s, text_s, in_audio.float(), vid_s, training=True, groups=ng, save=True,
+                        inject=_stack_inject(inject, tags, "g"), tag="g")
+        sl = lambda t, i: t[i * B:(i + 1) * B]
+        st = dict(B=B, target=target, res=res, i2=i2, ng=ng, out2=sl(res["out"], i2), out3=sl(res["out"], ng - 1),
+                  z2=sl(res["z"], i2), z3=sl(res["z"], ng - 1), mu2=sl(res["mu"], i2), lv2=sl(res["logvar"], i2))
+        if post:
+            st["out1"] = sl(res["out"], 0)
+        return st
+
+    # ---- phase 2: discriminator step (train_gan.py:27-43)
+    def phase_d_step(self, st, inject):
+        D, B = self.D, st["B"]
+        D.slab.ensure().zero_grad()
+        both = torch.cat([st["target"], st["out1"]])                   # D(real) first, then D(fake.detach())
+        dres = D.forward(both, training=True, groups=2, save=True, inject=_stack_inject(inject, ["d_real", "d_fake"], "d"), tag="d")
+        logit = dres["logit"].view(-1)
+        d_logit = torch.empty_like(logit)
+        st["d_scalar"] = torch.empty(1, device=logit.device)
+        ops.gan_d_loss(logit[:B], logit[B:], st["d_scalar"], d_logit[:B], d_logit[B:])
+        D.backward(dres["tape"], d_logit.view(-1, 1), b0=0, nb=2 * B, param_grads=True)
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce(D.slab.grad)
+        self.d_opt.step()
+
+    # ---- phase 3: generator losses and backward (train_gan.py:47-91)
+    def phase_g_backward(self, st, post, inject):
+        G, D, B, hp = self.G, self.D, st["B"], self.hp
+        dev = st["target"].device
+        G.slab.ensure().zero_grad()
+        out2 = st["out2"].contiguous()
+        dres = D.forward(out2, training=True, groups=1, save=post, inject=inject, tag="d_out")   # runs in warm-up too (:55)
+        d_out = torch.empty_like(out2)
+        d_mu, d_lv = torch.empty_like(st["mu2"]), torch.empty_like(st["mu2"])
+        d_logit = torch.empty(B, device=dev)
+        st["g_scalars"] = torch.empty(5, device=dev)
+        ops.gan_g_loss(out2, st["target"], st["out3"].contiguous(), st["z2"].contiguous(), st["z3"].contiguous(),
+                       st["mu2"].contiguous(), st["lv2"].contiguous(), dres["logit"].view(-1),
+                       (hp["loss_regression_weight"], hp["loss_kld_weight"], hp["loss_reg_weight"], hp["loss_gan_weight"]),
+                       post, torch.empty(3 * B, device=dev), st["g_scalars"], d_out, d_mu, d_lv, d_logit)
+        if post:
+            d_poses = D.backward(dres["tape"], d_logit.view(B, 1), param_grads=False, need_dposes=True)
+            ops.axpy(d_poses, d_out, 1.0, accumulate=True)
+        on_ready = self.grad_sync.bucket_hook(G.slab) if self.grad_sync is not None else None
+        G.backward(st["res"]["tape"], d_out, d_mu, d_lv, b0=st["i2"] * B, nb=B, on_ready=on_ready)
+
+    # ---- phase 4: generator update (train_gan.py:92)
+    def phase_g_update(self):
+        if self.grad_sync is not None:
+            self.grad_sync.wait()
+        self.g_opt.step()
+
+
+class GraphedGanStep:
+    """Captures GanTrainer.train_iter for fixed shapes into a hipGraph and replays it.
+
+    Inputs are copied into static buffers; every intermediate lives in the graph's private memory pool; random draws
+    advance through the device-side Philox step counter, Adam through its device-side step counter, so every replay is a
+    new, correct training iteration.  Only single-process training is captured (collectives stay outside graphs)."""
+
+    def __init__(self, trainer: GanTrainer, epoch, in_text, in_audio, target, vid, warmup_iters=2):
+        assert trainer.grad_sync is None, "graph capture covers the single-GPU step; use GanTrainer.train_iter under DDP"
+        self.trainer, self.epoch = trainer, epoch
+        self.static = [t.clone() for t in (in_text, in_audio, target, vid)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                   # warm-up outside capture (allocator, lazy init)
+            for _ in range(warmup_iters):
+                trainer.train_iter(epoch, *self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.losses = trainer.train_iter(epoch, *self.static)
+
+    def __call__(self, in_text=None, in_audio=None, target=None, vid=None):
+        for dst, src in zip(self.static, (in_text, in_audio, target, vid)):
+            if src is not None and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.losses

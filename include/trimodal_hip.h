@@ -1,0 +1,216 @@
+/*
+ * trimodal_hip.h -- C ABI of libtrimodal_hip.so (gfx950 / MI355X kernels for the trimodal gesture GAN path).
+ *
+ * The reference (ai4r/Gesture-Generation-from-Trimodal-Context) has no FFI: its hot path is PyTorch
+ * nn.Modules whose arithmetic runs in ATen.  Each entry point below replaces the ATen
+ * kernel behind one reference call site; the call site is cited per function as file:line relative to
+ * /root/reference/scripts/.  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a hipStream_t passed as void*.
+ *   - every function returns 0 on success, non-zero on error; tg_last_error() gives the message
+ *     (thread-local).  No C++ exception crosses the ABI.
+ *   - all device memory is owned by the caller.  Functions never allocate, never synchronise the device
+ *     and are safe to call during hipGraph stream capture.
+ *   - all tensors are fp32, row-major, "channel-last" for sequences: (batch, time, channels).
+ *   - functions documented "accumulates" add into their output; the caller zeroes it when needed.
+ */
+#ifndef TRIMODAL_HIP_H
+#define TRIMODAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_ABI_VERSION 1
+
+int tg_version(void);
+const char* tg_last_error(void);
+
+/*
+ * A "row window" view of a channel-last activation buffer: the A operand of every GEMM-shaped op.
+ * Logical matrix element (m, k), m in [0, M), k in [0, K):
+ *     b  = m / rows_out,  r = m % rows_out            (clip b, output row r inside the clip)
+ *     kk = k / cw,        c = k % cw                  (tap kk, channel c)
+ *     sr = r * row_step + shift + kk * dil            (source row inside the clip)
+ *     value = (0 <= sr < rows_in) ? ptr[b * batch_stride + sr * row_stride + c] : 0
+ * A plain matrix is {rows_out = rows_in = M, row_step = 1, shift = 0, cw = K}.  A Conv1d(kernel kw, stride s,
+ * padding p, dilation d) over (B, L, C) is {cw = C, K = kw*C, row_step = s, shift = -p, dil = d}: im2col is never
+ * materialised.
+ */
+typedef struct tg_window {
+    const float* ptr;
+    int64_t batch_stride;
+    int64_t row_stride;
+    int32_t rows_in;
+    int32_t rows_out;
+    int32_t row_step;
+    int32_t shift;
+    int32_t dil;
+    int32_t cw;
+    int32_t K;
+} tg_window;
+
+/* ---- GEMM-shaped ops (f32 MFMA v_mfma_f32_16x16x4_f32, exact fp32 accumulate) ------------------------------
+ * tg_gemm_nt: C(m, n) = act( sum_k A(m,k) * Bw[n*ldb + k] + bias[n] ) (+ C(m,n) when accumulate != 0)
+ *   act(x) = x >= 0 ? x : act_slope * x   (1.0 = identity, 0.0 = ReLU, 0.3/0.2 = LeakyReLU)
+ *   C row m is stored at C + (m / c_rows_out) * c_batch_stride + (m % c_rows_out) * c_row_stride.
+ *   Replaces nn.Linear / nn.Conv1d / nn.ConvTranspose1d forward and their input-gradients:
+ *   model/multimodal_context_net.py:13-22,51,89-93,100-104,214-220,225-226; model/tcn.py:19,25;
+ *   the x @ W_ih^T half of nn.GRU (:98,223); model/embedding_net.py:24,48-62,187-206. */
+int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bias, float* C,
+               int64_t c_batch_stride, int64_t c_row_stride, int32_t c_rows_out, int32_t M, int32_t N,
+               float act_slope, int32_t accumulate, void* stream);
+
+/* tg_gemm_tn (weight gradient, accumulates): dW[n*ldw + perm(k)] += sum_m dY[m*ldy + n] * A(m, k).
+ *   out_kw == 0: perm(k) = k.  out_kw == K/cw: perm(k) = (k % cw) * out_kw + k / cw, i.e. the gradient lands in
+ *   the (Cout, Cin, kw) layout of nn.Conv1d weights.
+ *   Replaces the weight-gradient half of aten::convolution_backward / addmm backward for the same call sites. */
+int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,
+               int32_t out_kw, void* stream);
+
+/* tg_colsum (bias gradient): out[n] (+)= sum_m X[m*ldx + n]. */
+int tg_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream);
+
+/* ---- GRU recurrence (nn.GRU, batch_first, bidirectional; model/multimodal_context_net.py:98-99,155,223-224,241)
+ * gi   : [2][B][T][3H] input projections x@W_ih^T + b_ih per direction (dir stride in floats given explicitly)
+ * y    : [B][T][2H]    layer output; direction d writes columns [d*H, (d+1)*H); also the recurrent state store
+ * save : [2][B][T][4H] r, z, n, (W_hn h + b_hn) per step for the backward pass, or NULL (inference / no-grad)
+ * Gate order and maths are PyTorch's: r,z = sigmoid, n = tanh(gi_n + r*(W_hn h + b_hn)), h' = (1-z) n + z h.
+ * One launch per time step (both directions, all batch rows); the launch boundary is the grid-wide dependency. */
+int tg_gru_forward(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
+                   const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
+                   int32_t B, int32_t T, int32_t H, void* stream);
+
+/* Backward through time.  dy: [B][T][2H] gradient w.r.t. y.  w_hh_t_*: TRANSPOSED recurrent weights [H][3H].
+ * Outputs dgi, dgh: [2][B][T][3H] gradients w.r.t. the input-side and hidden-side gate pre-activations
+ * (feed tg_gemm_tn / tg_gemm_nt / tg_colsum for dW_ih, dW_hh, dx, db).  dh_scratch: 4*B*H floats. */
+int tg_gru_backward(const float* dy, const float* y, const float* save, int64_t save_dir_stride,
+                    const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
+                    float* dh_scratch, int32_t B, int32_t T, int32_t H, void* stream);
+
+/* ---- BatchNorm1d, channel-last [rows][C] (model/multimodal_context_net.py:14,17,20,215,218) -------------
+ * Training statistics per group: the rows are split into `groups` equal consecutive slabs, each normalised with
+ * its own batch statistics (several reference forward calls stacked into one launch); running stats are updated
+ * once per group in order (momentum 0.1, unbiased variance), num_batches_tracked += groups * repeats.
+ * repeats >= 1: the running update of each group is applied that many times (the same batch seen by `repeats`
+ * identical reference forward calls: the three generator forwards of one GAN iteration share their audio input).
+ * ws: 2*groups*C doubles of scratch.  mean/rstd: [groups][C] outputs. */
+int tg_bn_train_stats(const float* x, int32_t rows, int32_t C, int32_t groups, double* ws, float* mean, float* rstd,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
+                      float momentum, int32_t repeats, void* stream);
+/* eval mode: mean/rstd from running stats. */
+int tg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
+                     float* rstd, void* stream);
+/* y = act((x - mean[g]) * rstd[g] * gamma + beta). */
+int tg_bn_apply(const float* x, float* y, int32_t rows, int32_t C, int32_t groups, const float* mean,
+                const float* rstd, const float* gamma, const float* beta, float act_slope, void* stream);
+/* backward of act(BN(x)) for one group: dx, and dgamma/dbeta (accumulate).  ws: 2*C doubles.
+ * mean==NULL selects eval-mode backward is not supported (training only). */
+int tg_bn_backward(const float* dy, const float* x, float* dx, int32_t rows, int32_t C, const float* mean,
+                   const float* rstd, const float* gamma, const float* beta, float act_slope, double* ws,
+                   float* dgamma, float* dbeta, void* stream);
+
+/* ---- element-wise / data movement ------------------------------------------------------------------- */
+/* y = max(a + b, 0)  (model/tcn.py:46);  dx = dy * (y > 0). */
+int tg_add_relu(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* dx = dy * mask * (y > 0 ? 1 : slope); mask may be NULL (=1).  Backward of act() followed by dropout. */
+int tg_act_mask_bwd(const float* dy, const float* y, const float* mask, float slope, float* dx, int64_t n,
+                    void* stream);
+/* y = x * mask  (nn.Dropout with a materialised inverted-dropout mask: 0 or 1/(1-p)). */
+int tg_mul(const float* x, const float* mask, float* y, int64_t n, void* stream);
+/* y (+)= alpha * x. */
+int tg_axpy(const float* x, float* y, float alpha, int32_t accumulate, int64_t n, void* stream);
+/* dst[r*ldd + c] (+)= src[r*lds + c], r < rows, c < cols. */
+int tg_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows, int32_t cols,
+              int32_t accumulate, void* stream);
+/* dst[(b*T + t)*ldd + c] = src[b*lds + c]  (z repeated over time, multimodal_context_net.py:151-153). */
+int tg_repeat_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t B, int32_t T, int32_t cols,
+                   void* stream);
+/* dst[b*ldd + c] (+)= sum_t src[(b*T + t)*lds + c]. */
+int tg_sum_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t B, int32_t T, int32_t cols,
+                int32_t accumulate, void* stream);
+/* o[m*H + j] = y[m*2H + j] + y[m*2H + H + j]  (multimodal_context_net.py:156,242). */
+int tg_add_halves(const float* y, float* o, int32_t M, int32_t H, void* stream);
+/* dy[m*2H + j] = dy[m*2H + H + j] = do[m*H + j]. */
+int tg_dup_halves(const float* d_o, float* dy, int32_t M, int32_t H, void* stream);
+/* pre[b][t][:D] = t < n_pre ? target[b][t][:] : 0 ; pre[b][t][D] = t < n_pre  (train_eval/train_gan.py:20-22). */
+int tg_make_pre_seq(const float* target, float* pre, int32_t B, int32_t T, int32_t D, int32_t n_pre, void* stream);
+/* out[i*D + :] = table[idx[i]*D + :]  (nn.Embedding, multimodal_context_net.py:40,89). */
+int tg_embed_gather(const float* table, const int64_t* idx, float* out, int32_t n_idx, int32_t D, int32_t n_rows,
+                    void* stream);
+/* dtable[idx[i]*D + :] += dout[i*D + :]  (dense embedding gradient; accumulates). */
+int tg_embed_scatter_add(const float* dout, const int64_t* idx, float* dtable, int32_t n_idx, int32_t D,
+                         int32_t n_rows, void* stream);
+/* out[perm-ed] = in: generic 3-D permute, out[i0][i1][i2] with out dims (d[p0], d[p1], d[p2]) of in dims d. */
+int tg_permute3(const float* in, float* out, int32_t d0, int32_t d1, int32_t d2, int32_t p0, int32_t p1,
+                int32_t p2, void* stream);
+
+/* Weight pack for the input-gradient of Conv1d(stride s) (= forward of ConvTranspose1d):
+ * w: [Co][Ci][kw] -> out: [s][Ci][J][Co], J = ceil(kw/s), out[r][ci][j][co] = (r + s*j < kw) ? w[co][ci][r + s*j] : 0.
+ * Phase r serves the input positions p with (p % s) == r:  dx[6q + r] = sum_j dy[q - j] . out[r][:, j, :]. */
+int tg_conv_dgrad_pack(const float* w, float* out, int32_t Co, int32_t Ci, int32_t kw, int32_t s, void* stream);
+
+/* ---- weight norm (torch.nn.utils.weight_norm dim=0; model/tcn.py:19,25) ------------------------------
+ * v: [Co][Ci][kw], g: [Co].  w_packed: [Co][kw][Ci] = g * v / ||v||  (tap-major, the layout tg_gemm_nt wants). */
+int tg_weight_norm_fwd(const float* v, const float* g, float* w_packed, int32_t Co, int32_t Ci, int32_t kw,
+                       void* stream);
+/* dw_packed: [Co][kw][Ci] -> dg[Co], dv[Co][Ci][kw] (both accumulate). */
+int tg_weight_norm_bwd(const float* dw_packed, const float* v, const float* g, float* dg, float* dv, int32_t Co,
+                       int32_t Ci, int32_t kw, void* stream);
+
+/* ---- randomness: Philox4x32-10 counter RNG, graph-replay safe -----------------------------------------
+ * rng_state: device uint64[2] = {seed, step}.  tg_rng_advance bumps step by one (launch once per iteration).
+ * Every draw site passes its own `site` id so streams never collide. */
+int tg_rng_advance(uint64_t* rng_state, void* stream);
+int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream);
+int tg_normal(float* out, int64_t n, const uint64_t* rng_state, uint32_t site, void* stream);
+/* out = random permutation of [0, n), n <= 1024 (torch.randperm at train_eval/train_gan.py:62). */
+int tg_randperm(int64_t* out, int32_t n, const uint64_t* rng_state, uint32_t site, void* stream);
+/* out[i] = src[perm[i]] for int64 vectors (vid_indices[rand_idx], train_gan.py:63). */
+int tg_gather_i64(const int64_t* src, const int64_t* perm, int64_t* out, int32_t n, void* stream);
+
+/* ---- speaker path (multimodal_context_net.py:128-131; model/embedding_net.py:10-13) -------------------- */
+/* z = mu + eps * exp(0.5 * logvar) */
+int tg_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);
+/* dmu += dz ; dlogvar += dz * eps * 0.5 * exp(0.5*logvar) */
+int tg_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu, float* dlogvar, int64_t n,
+                   void* stream);
+
+/* ---- losses (train_eval/train_gan.py:41,53-89) ----------------------------------------------------------
+ * Discriminator step.  logit_*: pre-sigmoid outputs [B].  out[0] = dis_error; d_logit_* = d dis_error / d logit. */
+int tg_gan_d_loss(const float* logit_real, const float* logit_fake, int32_t B, float* out, float* d_logit_real,
+                  float* d_logit_fake, void* stream);
+/* Generator step.  out_pose/target/out_rand: [B][T*D]; z, z_rand, mu, logvar: [B][Z]; logit_out: [B] (pre-sigmoid
+ * D(out)).  scalars[0..4] = huber, kld, div_reg, gen_error, total loss (unweighted terms; total is weighted).
+ * Gradients of the TOTAL loss: d_out [B][T*D], d_mu, d_logvar [B][Z] (written), d_logit_out [B] (0 when
+ * use_gan == 0).  ws: 3*B floats. */
+int tg_gan_g_loss(const float* out_pose, const float* target, const float* out_rand, const float* z,
+                  const float* z_rand, const float* mu, const float* logvar, const float* logit_out, int32_t B,
+                  int32_t TD, int32_t Z, float w_huber, float w_kld, float w_div, float w_gan, int32_t use_gan,
+                  float* ws, float* scalars, float* d_out, float* d_mu, float* d_logvar, float* d_logit_out,
+                  void* stream);
+/* out[0] = mean |a - b| over n elements (F.l1_loss, train.py:282). */
+int tg_l1_mean(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* y = 1 / (1 + exp(-x)) */
+int tg_sigmoid(const float* x, float* y, int64_t n, void* stream);
+/* dx = dy * y * (1 - y), y = sigmoid(x)  (torch.sigmoid backward, multimodal_context_net.py:250). */
+int tg_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+
+/* FGD autoencoder loss (train_feature_extractor.py:64-72): loss = sum_b [mean|r-t| + mean|dr-dt|];
+ * out[0] = loss, d_recon = d loss / d recon. */
+int tg_ae_loss(const float* recon, const float* target, int32_t B, int32_t T, int32_t D, float* out, float* d_recon,
+               void* stream);
+
+/* ---- optimiser (torch.optim.Adam, train.py:104-109): one fused launch over a flat parameter slab ------
+ * step_dev: device int32 step counter, incremented by tg_counter_inc BEFORE the update (graph-replay safe). */
+int tg_counter_inc(int32_t* counter, void* stream);
+int tg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, const int32_t* step_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRIMODAL_HIP_H */

@@ -1,0 +1,84 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every declared symbol, the host
+mirror has the reference's state_dict key set, and the product package never touches oracle/ or /root/reference."""
+import ctypes
+import os
+import re
+
+import torch
+
+from conftest import ROOT
+
+
+def _build_if_needed():
+    lib = os.path.join(ROOT, "gesture-generation-from-trimodal-context_amd", "libtrimodal_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+        g.build()
+    return lib
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib_path = _build_if_needed()
+    header = open(os.path.join(ROOT, "include", "trimodal_hip.h")).read()
+    declared = set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", header))
+    declared.discard("tg_window")
+    lib = ctypes.CDLL(lib_path)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    bound = set(pkg._lib.SIGNATURES) | {"tg_version", "tg_last_error"}
+    assert declared == bound, declared ^ bound
+    lib.tg_version.restype = ctypes.c_int
+    assert lib.tg_version() == pkg._lib.ABI_VERSION
+
+
+def test_argument_checks_fail_loudly_without_gpu(pkg):
+    """Entry points validate arguments on the host before any launch: callable here, no GPU needed."""
+    lib = pkg._lib.load()
+    rc = lib.tg_adam_step(None, None, None, None, 0, 0.1, 0.5, 0.999, 1e-8, None, None)
+    assert rc != 0 and b"tg_adam_step" in lib.tg_last_error()
+    rc = lib.tg_gru_forward(None, 0, None, None, None, None, None, None, 0, 1, 1, 4, None)
+    assert rc != 0
+
+
+def test_state_dict_keys_match_reference(pkg):
+    import argparse
+    from oracle import ref_model as O
+    a = argparse.Namespace(n_pre_poses=4, n_poses=34, input_context="both", hidden_size=300, n_layers=4, dropout_prob=0.3,
+                           freeze_wordembed=False)
+    g = pkg.PoseGenerator(a, 27, 512, 300, None, pkg.Vocab.speakers(17))
+    d = pkg.ConvDiscriminator(27)
+    ae = pkg.EmbeddingNet(a, 27, 34)
+    gs, ds, as_ = O.make_generator_state(0), O.make_discriminator_state(1), O.make_autoencoder_state(2)
+    for mod, st, n in ((g, gs, 117), (d, ds, 52), (ae, as_, 70)):
+        sd = mod.state_dict()
+        assert len(sd) == n and set(sd) == set(st)
+        for k in sd:
+            assert tuple(sd[k].shape) == tuple(st[k].shape) and sd[k].dtype == st[k].dtype, k
+        mod.load_state_dict(st, strict=True)
+    # the TCN's duplicated registration shares storage, like the reference
+    sd = g.state_dict()
+    assert sd["text_encoder.tcn.network.0.conv1.weight_v"].data_ptr() == sd["text_encoder.tcn.network.0.net.0.weight_v"].data_ptr()
+    assert sum(p.numel() for p in g.parameters()) == 13_204_939 - (20000 - 512) * 300 - (1371 - 17) * 16
+    assert sum(p.numel() for p in d.parameters()) == 253_950 and sum(p.numel() for p in ae.parameters()) == 190_691
+
+
+def test_product_never_imports_oracle_or_reference():
+    pdir = os.path.join(ROOT, "gesture-generation-from-trimodal-context_amd")
+    for dirpath, _, files in os.walk(pdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "sys.path" not in src or f == "__init__.py", f
+                assert "/root/reference" not in src, f
+
+
+def test_missing_library_fails_loudly(pkg, monkeypatch):
+    monkeypatch.setattr(pkg._lib, "_lib", None)
+    monkeypatch.setattr(pkg._lib, "LIB_PATH", "/nonexistent/libtrimodal_hip.so")
+    try:
+        pkg._lib.load()
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("load() must raise when the HIP library is missing")

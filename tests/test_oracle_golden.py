@@ -1,0 +1,141 @@
+"""Pins oracle/ref_model.py to golden vectors produced by the REAL reference (tests/golden/make_golden.py).
+CPU only.  The weights are regenerated from seeds (same torch build on both machines) and cross-checked by checksum."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+from oracle import ref_model as O
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def sample_idx(numel, n=2048, seed=7):
+    if numel <= n:
+        return np.arange(numel)
+    return np.sort(np.random.RandomState(seed + numel % 9973).choice(numel, n, replace=False))
+
+
+def unpack_masks(g, tags, p_tcn=0.3):
+    """Recorded keep-masks (packed bits, reference layout (B,T,300) for the embedding and (B,300,T) for the TCN)."""
+    shape_emb = tuple(g["mask_shape"])
+    names = ["emb_drop"] + [f"tcn{i}.drop{j}" for i in range(4) for j in (1, 2)]
+    n = int(np.prod(shape_emb))
+    bits = np.unpackbits(g["masks"], axis=1)[:, :n]
+    inj, k = {}, 0
+    B = shape_emb[0]
+    for tag in tags:
+        for name in names:
+            p = 0.1 if name == "emb_drop" else p_tcn
+            keep = torch.from_numpy(bits[k].astype(np.float32))
+            shp = shape_emb if name == "emb_drop" else (B, shape_emb[2], shape_emb[1])
+            inj[f"{tag}.{name}"] = keep.view(shp) / (1.0 - p)
+            k += 1
+    return inj
+
+
+def test_report_is_tight():
+    rep = json.load(open(os.path.join(GOLDEN, "golden_report.json")))
+    assert rep["torch"] == torch.__version__
+    assert max(rep["G1"].values()) < 2e-6
+    for k in ("G2_warmup", "G2_gan"):
+        assert rep[k]["g_grad_max"] < 2e-5 and max(rep[k]["loss"].values()) < 1e-6
+    assert rep["G3"]["g_grad_max"] < 2e-5 and rep["G5"]["fgd_rel"] < 1e-9
+
+
+def test_g1_eval_forward_matches_reference():
+    g = load("g1_eval_forward.npz")
+    gst, dst = O.make_generator_state(int(g["g_seed"]), int(g["n_words"]), int(g["n_speakers"])), O.make_discriminator_state(int(g["d_seed"]))
+    chk = np.array([float(v.double().abs().sum()) for v in gst.values() if v.is_floating_point()])
+    assert np.allclose(chk, g["w_checksum"], rtol=1e-12), "seeded weights differ from the ones the golden run used"
+    text, audio, vid, poses = O.make_batch(int(g["batch_seed"]), 4, int(g["n_words"]), int(g["n_speakers"]))
+    assert np.array_equal(text.numpy(), g["text"]) and np.array_equal(audio.numpy(), g["audio"])
+    pre = O.make_pre_seq(poses, 4)
+    out, z, mu, lv, parts = O.generator_forward(gst, pre, text, audio, vid, training=False,
+                                                rand=O.Rand(inject={"g.eps": torch.from_numpy(g["eps"])}), return_parts=True)
+    assert rel(out, g["out"]) < 2e-6 and rel(z, g["z"]) < 1e-6 and rel(mu, g["mu"]) < 1e-6 and rel(lv, g["logvar"]) < 1e-6
+    assert rel(parts["audio_feat"], g["wav_feat"]) < 2e-6 and rel(parts["text_feat"], g["text_feat"]) < 2e-6
+    d = O.discriminator_forward(dst, poses, training=False, rand=O.Rand())
+    assert rel(d, g["d_out"]) < 1e-6
+
+
+def _run_g2(label):
+    g = load(f"g2_train_{label}.npz")
+    epoch = int(g["epoch"])
+    V, S = int(g["n_words"]), int(g["n_speakers"])
+    gst, dst = O.make_generator_state(int(g["g_seed"]), V, S), O.make_discriminator_state(int(g["d_seed"]))
+    text, audio, vid, poses = O.make_batch(int(g["batch_seed"]), 4, V, S)
+    tags = ["g1", "g2", "g3"] if epoch > 10 else ["g2", "g3"]
+    inj = unpack_masks(g, tags)
+    for t, e in zip(tags, g["eps"]):
+        inj[f"{t}.eps"] = torch.from_numpy(e)
+    inj["perm"] = torch.from_numpy(g["perm"])
+    for t in tags:
+        for l in range(3):
+            inj[f"{t}.gru.drop{l}"] = torch.ones(4, 34, 600)
+    for t in ("d_real", "d_fake", "d_out"):
+        for l in range(3):
+            inj[f"{t}.gru.drop{l}"] = torch.ones(4, 28, 128)
+    ret, extra = O.train_iter_gan(gst, dst, {}, {}, epoch, text, audio, poses, vid, O.Rand(inject=inj), want_grads=True)
+    return g, ret, extra, gst, dst
+
+
+def test_g2_train_steps_match_reference():
+    for label in ("warmup", "gan"):
+        g, ret, extra, gst, dst = _run_g2(label)
+        assert sorted(ret) == list(g["loss_keys"])
+        for k, v in zip(g["loss_keys"], g["loss_vals"]):
+            assert abs(ret[k] - v) <= 1e-6 * max(1.0, abs(v)), (label, k, ret[k], v)
+        worst = 0.0
+        for k, gr in extra["g_grads"].items():
+            ref = g["gg/" + k]
+            mine = gr.reshape(-1).numpy()[sample_idx(gr.numel())]
+            if float(np.abs(ref).max()) < 1e-5:      # zero-by-construction gradients (bias in front of BatchNorm)
+                assert float(np.abs(mine).max()) < 1e-4
+                continue
+            worst = max(worst, rel(mine, ref))
+        assert worst < 2e-5, (label, worst)
+        for k in gst:
+            if k.endswith("num_batches_tracked"):
+                assert int(gst[k]) == int(g["gp/" + k]), k
+
+
+def test_g5_fgd_matches_reference():
+    g = load("g5_fgd.npz")
+    ast = O.make_autoencoder_state(int(g["ae_seed"]))
+    gp = torch.Generator().manual_seed(int(g["pose_seed"]))
+    real = 0.1 * torch.randn(256, 34, 27, generator=gp)
+    fake = real + 0.05 * torch.randn(256, 34, 27, generator=gp)
+    fr, _, _, _ = O.ae_forward(O.clone_state(ast), real, False)
+    fk, _, _, _ = O.ae_forward(O.clone_state(ast), fake, False)
+    assert rel(fr, g["feat_real"]) < 2e-6 and rel(fk, g["feat_fake"]) < 2e-6
+    fd, feat_dist = O.fgd_scores(g["feat_fake"], g["feat_real"])
+    assert abs(fd - float(g["fgd"])) <= 1e-9 * abs(float(g["fgd"]))
+    fd8, _ = O.fgd_scores(g["feat_fake"][:8], g["feat_real"][:8])
+    assert abs(fd8 - float(g["fgd8"])) <= 1e-6 * max(1.0, abs(float(g["fgd8"])))
+    ret, _ = O.ae_train_iter(O.clone_state(ast), {}, real[:32])
+    assert abs(ret["loss"] - float(g["train_loss"])) < 1e-5 * float(g["train_loss"])
+
+
+def test_window_blend_and_count_hand_computed():
+    """synthesize.py:57-63,142-160 restated; values worked out by hand."""
+    assert O.num_windows(1.0) == 1 and O.num_windows(34 / 15) == 1 and O.num_windows(34 / 15 + 0.01) == 2 and O.num_windows(10.0) == 5
+    a, b = np.zeros((34, 2), np.float32), np.ones((34, 2), np.float32)
+    out = O.blend_windows([a, b])
+    assert out.shape == (64, 2)
+    assert np.allclose(out[30:34, 0], [1 / 5, 2 / 5, 3 / 5, 4 / 5]) and np.all(out[:30] == 0) and np.all(out[34:] == 1)
+
+
+def test_dir_vec_to_pose_hand_computed():
+    v = np.zeros((1, 1, 27)); v[0, 0, 0:3] = [0, 1, 0]; v[0, 0, 3:6] = [1, 0, 0]
+    p = O.dir_vec_to_pose(v)
+    assert np.allclose(p[0, 0, 1], [0, 0.26, 0]) and np.allclose(p[0, 0, 2], [0.18, 0.26, 0]) and np.allclose(p[0, 0, 4], [0, 0.26, 0])
