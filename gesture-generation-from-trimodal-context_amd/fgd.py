@@ -1,0 +1,107 @@
+"""Frechet Gesture Distance on the HIP autoencoder (model/embedding_space_evaluator.py:15-156) and the autoencoder's
+training step (train_feature_extractor.py:54-97).  Feature extraction runs on the GPU; the 32x32 statistics are fp64
+host maths exactly as in the reference (numpy mean / cov(rowvar=False) / matrix square root)."""
+import numpy as np
+import torch
+
+from . import ops
+from .optim import FusedAdam
+
+
+def _sqrtm(a):
+    """Principal matrix square root of a (possibly non-symmetric) real matrix, complex if needed."""
+    try:
+        from scipy import linalg
+        r = linalg.sqrtm(a)
+        return r[0] if isinstance(r, tuple) else r
+    except ImportError:            # eigen-decomposition fallback (host maths only, not a kernel fallback)
+        w, v = np.linalg.eig(a)
+        return (v * np.sqrt(w.astype(complex))) @ np.linalg.inv(v)
+
+
+def frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
+    """||mu1-mu2||^2 + Tr(S1) + Tr(S2) - 2 Tr sqrt(S1 S2)  (embedding_space_evaluator.py:103-156)."""
+    mu1, mu2 = np.atleast_1d(mu1).astype(np.float64), np.atleast_1d(mu2).astype(np.float64)
+    sigma1, sigma2 = np.atleast_2d(sigma1).astype(np.float64), np.atleast_2d(sigma2).astype(np.float64)
+    assert mu1.shape == mu2.shape and sigma1.shape == sigma2.shape
+    diff = mu1 - mu2
+    covmean = _sqrtm(sigma1.dot(sigma2))
+    if not np.isfinite(covmean).all():                                  # singular product: offset the diagonals (:139-144)
+        off = np.eye(sigma1.shape[0]) * eps
+        covmean = _sqrtm((sigma1 + off).dot(sigma2 + off))
+    if np.iscomplexobj(covmean):                                        # (:147-151)
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+            raise ValueError("Imaginary component {}".format(np.max(np.abs(covmean.imag))))
+        covmean = covmean.real
+    return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean))
+
+
+def fgd_scores(generated_feats, real_feats):
+    """(FGD, mean L1 distance of paired latents): EmbeddingSpaceEvaluator.get_scores (:74-101)."""
+    g, r = np.asarray(generated_feats), np.asarray(real_feats)
+    try:
+        fd = frechet_distance(np.mean(g, axis=0), np.cov(g, rowvar=False), np.mean(r, axis=0), np.cov(r, rowvar=False))
+    except ValueError:
+        fd = 1e10
+    return fd, float(np.mean(np.sum(np.abs(r - g), axis=1)))
+
+
+class EmbeddingSpaceEvaluator:
+    """Same surface as the reference class (reset / push_samples / get_no_of_samples / get_scores), built around an
+    already constructed HIP EmbeddingNet instead of a checkpoint path (pass `net`) or a checkpoint dict."""
+
+    def __init__(self, net, n_pre_poses=4):
+        self.net = net
+        self.net.train(False)
+        self.n_pre_poses = n_pre_poses
+        self.reset()
+
+    @classmethod
+    def from_checkpoint(cls, args, ckpt, device):
+        from .modules import EmbeddingNet
+        net = EmbeddingNet(args, ckpt["pose_dim"], args.n_poses, None, None, None, mode="pose").to(device)
+        net.load_state_dict(ckpt["gen_dict"])
+        return cls(net, args.n_pre_poses)
+
+    def reset(self):
+        self.real_feat_list, self.generated_feat_list, self.recon_err_diff = [], [], []
+
+    def get_no_of_samples(self):
+        return len(self.real_feat_list)
+
+    def push_samples(self, context_text, context_spec, generated_poses, real_poses):
+        eng = self.net.engine
+        with torch.no_grad():
+            r = eng.forward(real_poses.float(), training=False)
+            g = eng.forward(generated_poses.float(), training=False)
+            err = torch.empty(2, device=real_poses.device)
+            ops.l1_mean(real_poses.float().contiguous(), r["recon"], err[0:1])
+            ops.l1_mean(generated_poses.float().contiguous(), g["recon"], err[1:2])
+        self.real_feat_list.append(r["feat"].cpu().numpy())
+        self.generated_feat_list.append(g["feat"].cpu().numpy())
+        e = err.tolist()
+        self.recon_err_diff.append(e[1] - e[0])
+
+    def get_scores(self):
+        return fgd_scores(np.vstack(self.generated_feat_list), np.vstack(self.real_feat_list))
+
+
+class AutoencoderTrainer:
+    """train_feature_extractor.py:train_iter with variational_encoding=False: reconstruction L1 + L1 of frame differences,
+    summed over the batch; Adam(lr 5e-4, betas (0.5, 0.999))."""
+
+    def __init__(self, net, lr=5e-4):
+        self.net, self.E = net, net.engine
+        self.opt = FusedAdam(self.E, lr=lr, betas=(0.5, 0.999))
+
+    def train_iter(self, target):
+        E = self.E
+        E.slab.ensure().zero_grad()
+        target = target.float().contiguous()
+        res = E.forward(target, training=True, save=True)
+        loss = torch.empty(1, device=target.device)
+        d_recon = torch.empty_like(target)
+        ops.ae_loss(res["recon"], target, loss, d_recon)
+        E.backward(res["tape"], d_recon)
+        self.opt.step()
+        return loss

@@ -62,7 +62,7 @@ class Win:
     @staticmethod
     def conv(x, kw, *, stride=1, pad=0, dil=1, rows_out=None):
         """Conv1d window over x: (B, L, C) channel-last (unit channel stride).  rows_out defaults to the conv length."""
-        assert x.dim() == 3 and x.stride(2) == 1, (x.shape, x.stride())
+        assert x.dim() == 3 and (x.stride(2) == 1 or x.shape[2] == 1), (x.shape, x.stride())
         B, L, Cc = x.shape
         if rows_out is None:
             rows_out = (L + 2 * pad - dil * (kw - 1) - 1) // stride + 1
@@ -72,7 +72,7 @@ class Win:
     @staticmethod
     def taps(x, n_taps, *, shift, dil, rows_out):
         """General tap window over x: (B, L, C): source row = r + shift + tap*dil (zero outside [0, L))."""
-        assert x.dim() == 3 and x.stride(2) == 1
+        assert x.dim() == 3 and (x.stride(2) == 1 or x.shape[2] == 1)
         B, L, Cc = x.shape
         return Win(x, batches=B, batch_stride=x.stride(0), row_stride=x.stride(1), rows_in=L, rows_out=rows_out,
                    cw=Cc, K=n_taps * Cc, row_step=1, shift=shift, dil=dil)

@@ -1,0 +1,131 @@
+"""Shared parity harness (tests, __graft_entry__.smoke, bench cpu_baseline): builds the HIP-backed modules from the
+oracle's deterministic weights, replays the oracle's recorded random draws on the GPU path and compares."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import ref_model as O  # noqa: E402
+
+# parameters whose true gradient is exactly zero (they feed a train-mode BatchNorm through linear maps only):
+# both sides hold rounding noise there, and Adam turns noise into +-lr steps
+ZERO_GRAD_KEYS = {"audio_encoder.feat_extractor.0.bias", "audio_encoder.feat_extractor.3.bias", "audio_encoder.feat_extractor.6.bias",
+                  "pre_conv.0.bias", "pre_conv.3.bias", "pre_conv.1.bias", "pose_encoder.net.0.0.bias", "pose_encoder.net.1.0.bias",
+                  "pose_encoder.net.2.0.bias", "pose_encoder.out_net.0.bias", "pose_encoder.out_net.3.bias", "decoder.pre_net.0.bias",
+                  "decoder.net.0.bias", "decoder.net.3.bias", "pose_encoder.net.3.bias", "pose_encoder.out_net.1.bias",
+                  "pose_encoder.out_net.4.bias", "pose_encoder.out_net.6.bias", "pose_encoder.fc_mu.bias"}
+
+
+def make_args(**over):
+    a = dict(n_pre_poses=4, n_poses=34, input_context="both", hidden_size=300, n_layers=4, dropout_prob=0.3, freeze_wordembed=False,
+             z_type="speaker", loss_warmup=10, loss_gan_weight=5.0, loss_regression_weight=500.0, loss_kld_weight=0.1,
+             loss_reg_weight=0.05, learning_rate=0.0005, discriminator_lr_weight=0.2, wordembed_dim=300)
+    a.update(over)
+    return argparse.Namespace(**a)
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def build_models(pkg, dev, gst, dst, n_words, n_speakers, args=None):
+    args = args or make_args()
+    G = pkg.PoseGenerator(args, 27, n_words, 300, None, pkg.Vocab.speakers(n_speakers))
+    D = pkg.ConvDiscriminator(27)
+    G.load_state_dict(O.clone_state(gst, torch.float32), strict=True)
+    D.load_state_dict(O.clone_state(dst, torch.float32), strict=True)
+    return args, G.to(dev), D.to(dev)
+
+
+def to_device_inject(rec, dev):
+    """Oracle-recorded draws -> GPU-path layout: TCN masks are (B, C, T) in the oracle, (B, T, C) here."""
+    inj = {}
+    for k, v in rec.items():
+        if k == "perm":
+            inj[k] = v.to(dev)
+        elif ".tcn" in k:
+            inj[k] = v.float().transpose(1, 2).contiguous().to(dev)
+        else:
+            inj[k] = v.float().contiguous().to(dev)
+    return inj
+
+
+def grad_errors(mine, ref):
+    """(worst normalised error over real gradients, worst |grad| over zero-by-construction ones, worst key)"""
+    worst, wkey, zmax = 0.0, None, 0.0
+    for k, r in ref.items():
+        if r is None:
+            continue
+        if k in ZERO_GRAD_KEYS:
+            zmax = max(zmax, float(mine[k].abs().max()))
+            continue
+        e = rel(mine[k], r)
+        if e > worst:
+            worst, wkey = e, k
+    return worst, zmax, wkey
+
+
+def run_train_parity(pkg, dev, batch=4, epochs=(0, 11), n_words=512, n_speakers=17, seed=77, verbose=False, dropout=True):
+    """Oracle (fp64, CPU) and HIP path on identical weights, inputs and random draws, one iteration per epoch value,
+    fresh models each.  Returns the worst normalised error over losses, gradients, BN buffers and updated parameters."""
+    worst = 0.0
+    gst0, dst0 = O.make_generator_state(3, n_words, n_speakers), O.make_discriminator_state(4)
+    text, audio, vid, poses = O.make_batch(seed, batch, n_words, n_speakers)
+    for epoch in epochs:
+        og, od = O.clone_state(gst0, torch.float64), O.clone_state(dst0, torch.float64)
+        hp = dict(O.HP)
+        if not dropout:
+            hp["dropout_prob"] = 0.0
+        rand = O.Rand(seed=1000 + epoch) if dropout else _NoDrop(seed=1000 + epoch)
+        oret, extra = O.train_iter_gan(og, od, {}, {}, epoch, text, audio.double(), poses.double(), vid, rand, hp, want_grads=True)
+        args, G, D = build_models(pkg, dev, gst0, dst0, n_words, n_speakers)
+        tr = pkg.GanTrainer(G, D, args)
+        losses = tr.train_iter(epoch, text.to(dev), audio.to(dev), poses.to(dev), vid.to(dev), inject=to_device_inject(rand.rec, dev))
+        ret = losses.to_dict()
+        assert sorted(ret) == sorted(oret), (ret, oret)
+        e_loss = max(abs(ret[k] - oret[k]) / max(abs(oret[k]), 1e-6) for k in oret)
+        _, Gg, _ = tr.G.views()
+        e_g, z_g, k_g = grad_errors(Gg, extra["g_grads"])
+        e_d, z_d, k_d = (0.0, 0.0, None)
+        if epoch > 10:
+            _, Dg, _ = tr.D.views()
+            e_d, z_d, k_d = grad_errors(Dg, extra["d_grads"])
+        gsd, dsd = G.state_dict(), D.state_dict()
+        e_bn = max(rel(sd[k], o[k]) for sd, o in ((gsd, og), (dsd, od)) for k in o if "running_var" in k)
+        # running_mean inherits the +-lr noise step of the zero-gradient biases in front of it: compare loosely
+        e_bnm = max(float((sd[k].double().cpu() - o[k]).abs().max()) for sd, o in ((gsd, og), (dsd, od)) for k in o if "running_mean" in k)
+        for sd, o in ((gsd, og), (dsd, od)):
+            for k in o:
+                if k.endswith("num_batches_tracked"):
+                    assert int(sd[k]) == int(o[k]), (k, int(sd[k]), int(o[k]))
+        e_step = 0.0
+        for sd, o, lr in ((gsd, og, 5e-4), (dsd, od, 1e-4)):
+            for k in o:
+                if o[k].is_floating_point() and "running" not in k and k not in ZERO_GRAD_KEYS and not O.is_tcn_alias(k):
+                    e_step = max(e_step, float((sd[k].double().cpu() - o[k]).abs().max()) / lr)
+        if verbose:
+            print(f"epoch {epoch}: loss {e_loss:.2e} g_grad {e_g:.2e} ({k_g}) zero-grad |g| {z_g:.1e} d_grad {e_d:.2e} ({k_d}) "
+                  f"bn_var {e_bn:.2e} bn_mean_abs {e_bnm:.1e} step/lr {e_step:.2e}")
+        assert e_bnm < 5e-4 and e_step < 0.6, (e_bnm, e_step)     # Adam's first step is lr*sign(g): only ~0-gradient entries may flip
+        worst = max(worst, e_loss, e_g, e_d, e_bn)
+    return worst
+
+
+class _NoDrop(O.Rand):
+    def keep_mask(self, name, shape, p, dtype=torch.float32):
+        m = torch.ones(shape, dtype=dtype)
+        self.rec[name] = m
+        return m
+
+
+def sample_idx(numel, n=2048, seed=7):
+    if numel <= n:
+        return np.arange(numel)
+    return np.sort(np.random.RandomState(seed + numel % 9973).choice(numel, n, replace=False))

@@ -1,0 +1,227 @@
+"""Network-level parity on the GPU, through the C ABI: HIP path vs (a) golden vectors from the real reference and
+(b) the fp64 oracle on the same weights / inputs / random draws.  Tolerances: forward 1e-5, gradients 1e-4
+normalised max error."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from harness import O, ZERO_GRAD_KEYS, build_models, grad_errors, make_args, rel, run_train_parity, sample_idx, to_device_inject
+
+pytestmark = pytest.mark.gpu
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def test_eval_forward_matches_reference_golden(pkg, dev):
+    g = load("g1_eval_forward.npz")
+    V, S = int(g["n_words"]), int(g["n_speakers"])
+    gst, dst = O.make_generator_state(int(g["g_seed"]), V, S), O.make_discriminator_state(int(g["d_seed"]))
+    args, G, D = build_models(pkg, dev, gst, dst, V, S)
+    G.eval(); D.eval()
+    t = lambda k, dt=torch.float32: torch.from_numpy(g[k]).to(dev).to(dt)
+    poses = t("poses")
+    pre = O.make_pre_seq(poses.cpu(), 4).to(dev)
+    with torch.no_grad():
+        res = G.engine.forward(pre, t("text", torch.int64), t("audio"), t("vid", torch.int64), training=False,
+                               inject={"g.eps": t("eps")})
+        d = D(poses)
+    assert rel(res["out"], g["out"]) < 1e-5 and rel(res["z"], g["z"]) < 1e-5
+    assert rel(res["mu"], g["mu"]) < 1e-5 and rel(res["logvar"], g["logvar"]) < 1e-5
+    assert rel(res["in_data"][:, :, 28:60], g["wav_feat"]) < 1e-5 and rel(res["in_data"][:, :, 60:92], g["text_feat"]) < 1e-5
+    assert rel(d, g["d_out"]) < 1e-5
+    # module API: same call signature / return arity as the reference, eval mode draws its own eps
+    with torch.no_grad():
+        out, z, mu, lv = G(pre, t("text", torch.int64), t("audio"), t("vid", torch.int64))
+    assert out.shape == (4, 34, 27) and z.shape == mu.shape == lv.shape == (4, 16) and rel(mu, g["mu"]) < 1e-5
+
+
+def test_train_iter_matches_fp64_oracle_with_dropout(pkg, dev):
+    worst = run_train_parity(pkg, dev, batch=4, epochs=(0, 11), verbose=True)
+    assert worst < 1e-4, worst
+
+
+def test_train_iter_matches_reference_golden(pkg, dev):
+    """Replays the dropout masks / eps / permutation recorded from the reference's own train_iter_gan run."""
+    from test_oracle_golden import unpack_masks
+    for label in ("warmup", "gan"):
+        g = load(f"g2_train_{label}.npz")
+        epoch, V, S = int(g["epoch"]), int(g["n_words"]), int(g["n_speakers"])
+        gst, dst = O.make_generator_state(int(g["g_seed"]), V, S), O.make_discriminator_state(int(g["d_seed"]))
+        text, audio, vid, poses = O.make_batch(int(g["batch_seed"]), 4, V, S)
+        tags = ["g1", "g2", "g3"] if epoch > 10 else ["g2", "g3"]
+        rec = unpack_masks(g, tags)
+        for tg, e in zip(tags, g["eps"]):
+            rec[f"{tg}.eps"] = torch.from_numpy(e)
+        rec["perm"] = torch.from_numpy(g["perm"])
+        args, G, D = build_models(pkg, dev, gst, dst, V, S)
+        G.engine.p_drop = 0.3
+        tr = pkg.GanTrainer(G, D, args)
+        inj = to_device_inject(rec, dev)
+        ones = lambda *s: torch.ones(*s, device=dev)
+        for tg in tags:                                   # the golden run had nn.GRU's internal dropout switched off
+            for l in range(3):
+                inj[f"{tg}.gru.drop{l}"] = ones(4, 34, 600)
+        for tg in ("d_real", "d_fake", "d_out"):
+            for l in range(3):
+                inj[f"{tg}.gru.drop{l}"] = ones(4, 28, 128)
+        ret = tr.train_iter(epoch, text.to(dev), audio.to(dev), poses.to(dev), vid.to(dev), inject=inj).to_dict()
+        assert sorted(ret) == list(g["loss_keys"])
+        for k, v in zip(g["loss_keys"], g["loss_vals"]):
+            assert abs(ret[k] - v) <= 2e-5 * max(1.0, abs(v)), (label, k, ret[k], v)
+        _, Gg, _ = tr.G.views()
+        for k, gr in Gg.items():
+            ref = g["gg/" + k]
+            mine = gr.reshape(-1).cpu().numpy()[sample_idx(gr.numel())]
+            if k in ZERO_GRAD_KEYS:
+                assert float(np.abs(mine).max()) < 1e-4
+                continue
+            assert rel(mine, ref) < 1e-4, (label, k)
+        if epoch > 10:
+            _, Dg, _ = tr.D.views()
+            for k, gr in Dg.items():
+                if k in ZERO_GRAD_KEYS:
+                    continue
+                assert rel(gr.reshape(-1).cpu().numpy()[sample_idx(gr.numel())], g["dg/" + k]) < 1e-4, (label, k)
+        for sd, pre in ((G.state_dict(), "gp/"), (D.state_dict(), "dp/")):
+            for k, v in sd.items():
+                if k.endswith("num_batches_tracked"):
+                    assert int(v) == int(g[pre + k]), k            # Q2: G (2,1)/(3,..) and D 1/3 updates per iteration
+
+
+def test_full_size_step_matches_reference_golden_b128(pkg, dev):
+    g = load("g3_train_b128.npz")
+    V, S, B = int(g["n_words"]), int(g["n_speakers"]), int(g["batch"])
+    gst, dst = O.make_generator_state(int(g["g_seed"]), V, S), O.make_discriminator_state(int(g["d_seed"]))
+    text, audio, vid, poses = O.make_batch(int(g["batch_seed"]), B, V, S)
+    args, G, D = build_models(pkg, dev, gst, dst, V, S, make_args(dropout_prob=0.0))
+    D.engine  # built lazily
+    tr = pkg.GanTrainer(G, D, args)
+    inj = {f"{t}.eps": torch.from_numpy(e).to(dev) for t, e in zip(("g1", "g2", "g3"), g["eps"])}
+    inj["perm"] = torch.from_numpy(g["perm"]).to(dev)
+    for t in ("g1", "g2", "g3"):                          # golden run: every dropout off
+        inj[f"{t}.emb_drop"] = torch.ones(B, 34, 300, device=dev)
+        for l in range(3):
+            inj[f"{t}.gru.drop{l}"] = torch.ones(B, 34, 600, device=dev)
+    for t in ("d_real", "d_fake", "d_out"):
+        for l in range(3):
+            inj[f"{t}.gru.drop{l}"] = torch.ones(B, 28, 128, device=dev)
+    ret = tr.train_iter(11, text.to(dev), audio.to(dev), poses.to(dev), vid.to(dev), inject=inj).to_dict()
+    for k, v in zip(g["loss_keys"], g["loss_vals"]):
+        assert abs(ret[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, ret[k], v)
+    _, Gg, _ = tr.G.views()
+    for k, gr in Gg.items():
+        if k in ZERO_GRAD_KEYS:
+            continue
+        nrm = float(gr.double().norm())
+        assert abs(nrm - float(g["ggn/" + k])) <= 1e-4 * float(g["ggn/" + k]) + 1e-12, (k, nrm, float(g["ggn/" + k]))
+        scale = float(gr.abs().max())
+        mine = gr.reshape(-1).cpu().numpy()[sample_idx(gr.numel(), 64)]
+        assert float(np.abs(mine - g["gg/" + k]).max()) <= 1e-4 * scale, k
+    for sd, pre in ((G.state_dict(), "gp/"), (D.state_dict(), "dp/")):
+        for k, v in sd.items():
+            if "running_var" in k:
+                assert rel(v, g[pre + k]) < 1e-5, k
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == int(g[pre + k])
+
+
+def test_module_api_autograd_bridge(pkg, dev):
+    """The reference's own loop style: module(...) calls + torch losses + loss.backward() + torch.optim.Adam."""
+    V, S, B = 64, 9, 4
+    gst, dst = O.make_generator_state(5, V, S), O.make_discriminator_state(6)
+    text, audio, vid, poses = O.make_batch(9, B, V, S)
+    args, G, D = build_models(pkg, dev, gst, dst, V, S, make_args(dropout_prob=0.0))
+    G.train(); D.train()
+    G.engine.p_drop = 0.0
+    # oracle with matching draws: emb dropout (p=0.1) is fixed in the reference -> inject ones on both sides via eval of masks
+    pre = O.make_pre_seq(poses, 4)
+    og, od = O.clone_state(gst, torch.float64), O.clone_state(dst, torch.float64)
+    ps = O.unique_params(og)
+    for p in ps.values():
+        p.requires_grad_(True)
+    rand = O.Rand(seed=5)
+    out, z, mu, lv = O.generator_forward(og, pre.double(), text, audio.double(), vid, training=True, rand=rand, tag="g", p_drop=0.0)
+    dprob = O.discriminator_forward(od, out, training=True, rand=rand, tag="d")
+    loss = (out - poses.double()).abs().mean() + 0.1 * (mu ** 2).mean() + 0.05 * lv.exp().mean() - torch.log(dprob + 1e-8).mean()
+    gr = torch.autograd.grad(loss, list(ps.values()), allow_unused=True)
+    ref_grads = dict(zip(ps.keys(), gr))
+    inj = to_device_inject(rand.rec, dev)
+    G.engine.forward_inject = inj
+    # drive through the nn.Module API with injected draws (engine-level hook used by tests only)
+    opt = torch.optim.Adam(G.parameters(), lr=5e-4, betas=(0.5, 0.999))
+    opt.zero_grad(set_to_none=False)
+    eng_fwd = G.engine.forward
+    G.engine.forward = lambda *a, **k: eng_fwd(*a, **{**k, "inject": inj, "tag": "g"})
+    d_fwd = D.engine.forward
+    D.engine.forward = lambda *a, **k: d_fwd(*a, **{**k, "inject": inj, "tag": "d"})
+    o2, z2, mu2, lv2 = G(pre.to(dev), text.to(dev), audio.to(dev), vid.to(dev))
+    dp = D(o2)
+    l2 = (o2 - poses.to(dev)).abs().mean() + 0.1 * (mu2 ** 2).mean() + 0.05 * lv2.exp().mean() - torch.log(dp + 1e-8).mean()
+    l2.backward()
+    assert abs(float(l2) - float(loss)) < 1e-5 * abs(float(loss))
+    mine = {k: p.grad for k, p in G.named_parameters()}
+    e, zmax, key = grad_errors(mine, ref_grads)
+    assert e < 1e-4, (e, key)
+    before = G.out[2].bias.detach().clone()
+    opt.step()
+    assert not torch.equal(before, G.out[2].bias.detach())          # torch.optim works on the slab views
+
+
+def test_autoencoder_and_fgd(pkg, dev):
+    g = load("g5_fgd.npz")
+    ast = O.make_autoencoder_state(int(g["ae_seed"]))
+    gp = torch.Generator().manual_seed(int(g["pose_seed"]))
+    real = 0.1 * torch.randn(256, 34, 27, generator=gp)
+    fake = real + 0.05 * torch.randn(256, 34, 27, generator=gp)
+    AE = pkg.EmbeddingNet(make_args(), 27, 34).to(dev)
+    AE.load_state_dict(O.clone_state(ast), strict=True)
+    AE.eval()
+    with torch.no_grad():
+        _, _, _, fr, _, _, rec = AE(None, None, None, real.to(dev), "pose", variational_encoding=False)
+        _, _, _, fk, _, _, _ = AE(None, None, None, fake.to(dev), "pose", variational_encoding=False)
+    assert rel(fr, g["feat_real"]) < 1e-5 and rel(fk, g["feat_fake"]) < 1e-5
+    assert rel(rec.reshape(-1).cpu().numpy()[sample_idx(rec.numel())], g["recon_real"]) < 1e-5
+    from importlib import import_module
+    fgd = import_module(pkg.__name__ + ".fgd")
+    fd, fdist = fgd.fgd_scores(fk.cpu().numpy(), fr.cpu().numpy())
+    assert abs(fd - float(g["fgd"])) <= 1e-4 * abs(float(g["fgd"])) and abs(fdist - float(g["feat_dist"])) < 1e-4 * float(g["feat_dist"])
+    # one training step of the autoencoder (config 5) vs the fp64 oracle
+    AE.train()
+    oast = O.clone_state(ast, torch.float64)
+    oret, ogr = O.ae_train_iter(oast, {}, real[:32].double())
+    tr = fgd.AutoencoderTrainer(AE, lr=5e-4)
+    ret = tr.train_iter(real[:32].to(dev))
+    assert abs(ret.item() - oret["loss"]) < 1e-5 * oret["loss"]
+    _, Gg, _ = AE.engine.views()
+    e, zmax, key = grad_errors(Gg, {k: v for k, v in ogr.items() if v is not None})
+    assert e < 1e-4, (e, key)
+    assert float(Gg["pose_encoder.fc_logvar.weight"].abs().max()) == 0           # z = mu: no gradient, Adam must skip it
+    sd = AE.state_dict()
+    assert torch.equal(sd["pose_encoder.fc_logvar.weight"].cpu(), ast["pose_encoder.fc_logvar.weight"])
+
+
+def test_graphed_step_equals_eager(pkg, dev):
+    V, S, B = 64, 9, 8
+    gst, dst = O.make_generator_state(7, V, S), O.make_discriminator_state(8)
+    text, audio, vid, poses = (t.to(dev) for t in O.make_batch(11, B, V, S))
+    runs = []
+    for graphed in (False, True):
+        args, G, D = build_models(pkg, dev, gst, dst, V, S)
+        tr = pkg.GanTrainer(G, D, args)
+        if graphed:
+            step = pkg.GraphedGanStep(tr, 11, text, audio, poses, vid, warmup_iters=2)
+            out = [step().to_dict() for _ in range(2)]            # iterations 3, 4
+        else:
+            for _ in range(2):
+                tr.train_iter(11, text, audio, poses, vid)
+            out = [tr.train_iter(11, text, audio, poses, vid).to_dict() for _ in range(2)]
+        runs.append((out, {k: v.detach().clone() for k, v in G.state_dict().items() if v.is_floating_point()}))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-4 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    assert all(np.isfinite(list(d.values())).all() for d in runs[1][0])

@@ -1,0 +1,314 @@
+"""Op-level parity: every C-ABI kernel against a plain torch fp64 CPU reference of the same op (GPU only).
+Tolerances: fp32 kernels, max|err| / max|ref| <= 1e-5 forward, 1e-4 for long reductions (stated per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def cl(x):   # (B, C, L) -> channel-last (B, L, C)
+    return x.transpose(1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM family
+@pytest.mark.parametrize("M,N,K", [(200, 70, 108), (37, 27, 150), (4352, 900, 600), (5, 1, 28), (130, 33, 8)])
+def test_gemm_nt_plain(pkg, dev, M, N, K):
+    ops, Win = pkg.ops, pkg.ops.Win
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    ref = F.leaky_relu(x.double() @ w.double().t() + b.double(), 0.3)
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_nt(Win.plain(x.to(dev)), w.to(dev), b.to(dev), out, act_slope=0.3)
+    assert rel(out, ref) < 1e-5
+    ops.gemm_nt(Win.plain(x.to(dev)), w.to(dev), None, out, accumulate=True)
+    assert rel(out, ref + x.double() @ w.double().t()) < 1e-5
+
+
+def test_gemm_nt_strided_views(pkg, dev):
+    ops, Win = pkg.ops, pkg.ops.Win
+    big = rnd(50, 108, seed=4).to(dev)
+    w = rnd(12, 32, seed=5).to(dev)
+    outbig = torch.zeros(50, 40, device=dev)
+    ops.gemm_nt(Win.plain(big[:, 60:92]), w, None, outbig[:, 8:20])
+    ref = big[:, 60:92].double().cpu() @ w.double().cpu().t()
+    assert rel(outbig[:, 8:20], ref) < 1e-5 and float(outbig[:, :8].abs().max()) == 0 and float(outbig[:, 20:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("Ci,Co,kw,stride,pad,dil,L", [(16, 32, 15, 6, 0, 1, 211), (1, 16, 15, 5, 40, 1, 333), (27, 16, 3, 1, 0, 1, 34),
+                                                      (300, 300, 2, 1, 4, 4, 34), (64, 64, 4, 2, 0, 1, 30)])
+def test_conv_forward_wgrad_dgrad(pkg, dev, Ci, Co, kw, stride, pad, dil, L):
+    Lm = pkg.layers
+    B = 3
+    x = rnd(B, Ci, L, seed=6).double().requires_grad_(True)
+    w = rnd(Co, Ci, kw, seed=7, scale=0.2).double().requires_grad_(True)
+    b = rnd(Co, seed=8).double().requires_grad_(True)
+    y = F.conv1d(x, w, b, stride=stride, padding=pad, dilation=dil)
+    causal = pad == dil * (kw - 1) and pad > 0
+    if causal:
+        y = y[:, :, :L]                          # Chomp1d
+    dy = rnd(*y.shape, seed=9).double()
+    y.backward(dy)
+    xg, wg = cl(x.detach().float()).to(dev), w.detach().float().to(dev)
+    out = Lm.conv_fwd(xg, Lm.pack_conv_weight(wg), b.detach().float().to(dev), kw, stride=stride, pad=pad, dil=dil,
+                      rows_out=L if causal else None)
+    assert rel(out, cl(y)) < 1e-5
+    dW, db = torch.zeros_like(wg), torch.zeros(Co, device=dev)
+    dyg = cl(dy.float()).to(dev)
+    Lm.conv_wgrad(dyg, xg, dW, db, kw, stride=stride, pad=pad, dil=dil)
+    assert rel(dW, w.grad) < 1e-5 and rel(db, b.grad) < 1e-5
+    if pad == 0 and dil == 1:
+        dx = Lm.conv_dgrad(dyg, wg, L, stride=stride)
+        assert rel(dx, cl(x.grad)) < 1e-5
+
+
+def test_conv_transpose_fwd_bwd(pkg, dev):
+    Lm = pkg.layers
+    B, Ci, Co, kw, L = 5, 4, 32, 3, 34
+    x = rnd(B, Ci, L, seed=10).double().requires_grad_(True)
+    w = rnd(Ci, Co, kw, seed=11, scale=0.3).double().requires_grad_(True)
+    b = rnd(Co, seed=12).double().requires_grad_(True)
+    y = F.conv_transpose1d(x, w, b)
+    dy = rnd(*y.shape, seed=13).double()
+    y.backward(dy)
+    xg, wg = cl(x.detach().float()).to(dev), w.detach().float().to(dev)
+    out = Lm.conv_transpose_fwd(xg, wg, b.detach().float().to(dev))
+    assert rel(out, cl(y)) < 1e-5
+    dW, db = torch.zeros_like(wg), torch.zeros(Co, device=dev)
+    dx = Lm.conv_transpose_bwd(cl(dy.float()).to(dev), xg, wg, dW, db)
+    assert rel(dW, w.grad) < 1e-5 and rel(db, b.grad) < 1e-5 and rel(dx, cl(x.grad)) < 1e-5
+
+
+def test_linear_bwd_and_colsum(pkg, dev):
+    Lm = pkg.layers
+    M, N, K = 4352, 150, 300
+    x, w, dy = rnd(M, K, seed=14), rnd(N, K, seed=15, scale=0.1), rnd(M, N, seed=16)
+    dW, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    dx = Lm.linear_bwd(dy.to(dev), x.to(dev), w.to(dev), dW, db)
+    assert rel(dW, dy.double().t() @ x.double()) < 1e-5
+    assert rel(db, dy.double().sum(0)) < 1e-5 and rel(dx, dy.double() @ w.double()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ GRU
+@pytest.mark.parametrize("B,T,H,Kin", [(37, 9, 300, 108), (70, 28, 64, 8), (4, 34, 300, 600)])
+def test_gru_layer_fwd_bwd(pkg, dev, B, T, H, Kin):
+    Lm, ops = pkg.layers, pkg.ops
+    gru = torch.nn.GRU(Kin, H, num_layers=1, batch_first=True, bidirectional=True).double()
+    x = rnd(B, T, Kin, seed=17).double().requires_grad_(True)
+    y, _ = gru(x)
+    dy = rnd(B, T, 2 * H, seed=18).double()
+    y.backward(dy)
+    P = {f"gru.{k}": v.detach().float().to(dev).contiguous() for k, v in gru.named_parameters()}
+    G = {k: torch.zeros_like(v) for k, v in P.items()}
+    yg, tape = Lm.gru_stack_fwd(x.detach().float().to(dev), P, "gru", 1, H, p_drop=0.0, training=True, save=True)
+    assert rel(yg, y) < 1e-5
+    dx = Lm.gru_stack_bwd(dy.float().to(dev), tape, P, G, "gru", 1)
+    assert rel(dx, x.grad) < 1e-4
+    for k, v in gru.named_parameters():
+        assert rel(G[f"gru.{k}"], v.grad) < 1e-4, k
+    # sub-batch backward of a larger taped forward (the stacked-forward schedule of the GAN step)
+    if B >= 8:
+        b0, nb = 2, B // 2
+        G2 = {k: torch.zeros_like(v) for k, v in P.items()}
+        x2 = x.detach().clone().requires_grad_(True)
+        y2, _ = gru(x2[b0:b0 + nb])
+        gru.zero_grad()
+        y2.backward(dy[b0:b0 + nb])
+        dx2 = Lm.gru_stack_bwd(dy[b0:b0 + nb].float().to(dev).contiguous(), tape, P, G2, "gru", 1, b0=b0, nb=nb)
+        assert rel(dx2, x2.grad[b0:b0 + nb]) < 1e-4
+        for k, v in gru.named_parameters():
+            assert rel(G2[f"gru.{k}"], v.grad) < 1e-4, k
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm
+@pytest.mark.parametrize("rows,C,groups,slope", [(3 * 500, 16, 3, 0.3), (64, 256, 1, 1.0), (2 * 96, 8, 2, 1.0)])
+def test_batchnorm_train_eval_backward(pkg, dev, rows, C, groups, slope):
+    Lm = pkg.layers
+    x = (rnd(rows, C, seed=19) * 2 + 0.5)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=20), 0.1 * rnd(C, seed=21)
+    rm, rv = 0.05 * rnd(C, seed=22), 1 + 0.1 * rnd(C, seed=23).abs()
+    per = rows // groups
+    # reference: `groups` separate nn.BatchNorm1d calls
+    bn = torch.nn.BatchNorm1d(C).double()
+    bn.weight.data, bn.bias.data = gamma.double().clone(), beta.double().clone()
+    bn.running_mean.data, bn.running_var.data = rm.double().clone(), rv.double().clone()
+    xs = x.double().requires_grad_(True)
+    ys = torch.cat([F.leaky_relu(bn(xs[g * per:(g + 1) * per]), slope) for g in range(groups)])
+    dy = rnd(rows, C, seed=24).double()
+    g_sel = groups - 1
+    ys[g_sel * per:(g_sel + 1) * per].backward(dy[g_sel * per:(g_sel + 1) * per])
+    rmg, rvg, nbt = rm.to(dev).clone(), rv.to(dev).clone(), torch.zeros((), dtype=torch.int64, device=dev)
+    y, st = Lm.bn_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rmg, rvg, nbt, training=True, groups=groups, act_slope=slope)
+    assert rel(y, ys) < 1e-5 and rel(rmg, bn.running_mean) < 1e-5 and rel(rvg, bn.running_var) < 1e-5 and int(nbt) == groups
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx = Lm.bn_bwd(dy[g_sel * per:(g_sel + 1) * per].float().to(dev), st, gamma.to(dev), beta.to(dev), dg, db, g0=g_sel, ng=1,
+                   row0=g_sel * per)
+    assert rel(dx, xs.grad[g_sel * per:(g_sel + 1) * per]) < 1e-4 and rel(dg, bn.weight.grad) < 1e-4 and rel(db, bn.bias.grad) < 1e-4
+    bn.eval()
+    ye, _ = Lm.bn_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rmg, rvg, nbt, training=False, act_slope=slope)
+    assert rel(ye, F.leaky_relu(bn(x.double()), slope)) < 1e-5
+    # repeats: the same batch normalised by three identical calls
+    rm3, rv3, nbt3 = rm.to(dev).clone(), rv.to(dev).clone(), torch.zeros((), dtype=torch.int64, device=dev)
+    bn3 = torch.nn.BatchNorm1d(C).double(); bn3.running_mean.data, bn3.running_var.data = rm.double().clone(), rv.double().clone()
+    for _ in range(3):
+        bn3(x[:per].double())
+    Lm.bn_fwd(x[:per].to(dev).contiguous(), gamma.to(dev), beta.to(dev), rm3, rv3, nbt3, training=True, repeats=3)
+    assert rel(rm3, bn3.running_mean) < 1e-5 and rel(rv3, bn3.running_var) < 1e-5 and int(nbt3) == 3
+
+
+# ------------------------------------------------------------------------------------------------ element-wise & co
+def test_elementwise_family(pkg, dev):
+    ops = pkg.ops
+    a, b = rnd(1000, seed=25).to(dev), rnd(1000, seed=26).to(dev)
+    assert rel(ops.add_relu(a, b, torch.empty_like(a)), torch.relu(a.cpu() + b.cpu())) == 0
+    y = torch.relu(a)
+    m = (rnd(1000, seed=27) > 0).float().to(dev) * 1.25
+    assert rel(ops.act_mask_bwd(b, y, m, 0.0, torch.empty_like(a)), b.cpu() * m.cpu() * (y.cpu() > 0)) == 0
+    assert rel(ops.mul(a, m, torch.empty_like(a)), a.cpu() * m.cpu()) == 0
+    c = b.clone(); ops.axpy(a, c, 0.5, accumulate=True); assert rel(c, b.cpu() + 0.5 * a.cpu()) < 1e-6
+    src = rnd(20, 7, seed=28).to(dev); dst = torch.zeros(20, 11, device=dev)
+    ops.copy2d(src, dst[:, 2:9]); assert torch.equal(dst[:, 2:9].cpu(), src.cpu()) and float(dst[:, 9:].abs().max()) == 0
+    z = rnd(5, 16, seed=29).to(dev); big = torch.zeros(5 * 6, 20, device=dev)
+    ops.repeat_rows(z, big[:, 4:], 5, 6)
+    assert torch.equal(big.view(5, 6, 20)[:, :, 4:].cpu(), z.cpu()[:, None, :].expand(5, 6, 16))
+    s = ops.sum_rows(big[:, 4:], torch.empty(5, 16, device=dev), 5, 6); assert rel(s, 6 * z.cpu()) < 1e-6
+    yy = rnd(12, 10, seed=30).to(dev)
+    assert rel(ops.add_halves(yy, torch.empty(12, 5, device=dev)), yy.cpu()[:, :5] + yy.cpu()[:, 5:]) == 0
+    dd = ops.dup_halves(yy[:, :5].contiguous(), torch.empty(12, 10, device=dev))
+    assert torch.equal(dd[:, :5].cpu(), dd[:, 5:].cpu()) and torch.equal(dd[:, :5].cpu(), yy[:, :5].cpu())
+    t = rnd(3, 5, 7, seed=31).to(dev)
+    for perm in ((0, 2, 1), (2, 1, 0), (1, 2, 0)):
+        assert torch.equal(ops.permute3(t, torch.empty(t.numel(), device=dev), perm).view([t.shape[p] for p in perm]).cpu(),
+                           t.cpu().permute(*perm).contiguous())
+    tg = rnd(6, 34, 27, seed=32).to(dev)
+    pre = ops.make_pre_seq(tg, torch.empty(6, 34, 28, device=dev), 4).cpu()
+    assert torch.equal(pre[:, :4, :27], tg.cpu()[:, :4]) and float(pre[:, 4:].abs().max()) == 0 and torch.all(pre[:, :4, 27] == 1)
+    sg = ops.sigmoid(a, torch.empty_like(a)); assert rel(sg, torch.sigmoid(a.cpu().double())) < 1e-6
+    assert rel(ops.sigmoid_bwd(b, sg, torch.empty_like(a)), b.cpu().double() * sg.cpu().double() * (1 - sg.cpu().double())) < 1e-6
+
+
+def test_embedding_gather_scatter(pkg, dev):
+    ops = pkg.ops
+    V, D, n = 50, 300, 4 * 34
+    table = rnd(V, D, seed=33)
+    idx = torch.zeros(n, dtype=torch.int64); idx[::7] = torch.randint(4, V, (len(idx[::7]),), generator=torch.Generator().manual_seed(1))
+    out = ops.embed_gather(table.to(dev), idx.to(dev), torch.empty(n, D, device=dev))
+    assert torch.equal(out.cpu(), table[idx])
+    dout = rnd(n, D, seed=34)
+    dt = ops.embed_scatter_add(dout.to(dev), idx.to(dev), torch.zeros(V, D, device=dev))
+    ref = torch.zeros(V, D, dtype=torch.float64).index_add_(0, idx, dout.double())
+    assert rel(dt, ref) < 1e-5
+
+
+def test_weight_norm_and_dgrad_pack(pkg, dev):
+    ops = pkg.ops
+    Co, Ci, kw = 300, 300, 2
+    v = rnd(Co, Ci, kw, seed=35, scale=0.05).double().requires_grad_(True)
+    g = (1 + 0.1 * rnd(Co, 1, 1, seed=36)).double().requires_grad_(True)
+    w = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+    dw = rnd(Co, Ci, kw, seed=37).double()
+    w.backward(dw)
+    vg, gg = v.detach().float().to(dev), g.detach().float().view(-1).to(dev)
+    wp = ops.weight_norm_fwd(vg, gg, torch.empty(Co, kw * Ci, device=dev))
+    assert rel(wp.view(Co, kw, Ci), w.detach().permute(0, 2, 1)) < 1e-6
+    dg, dv = torch.zeros(Co, device=dev), torch.zeros_like(vg)
+    ops.weight_norm_bwd(dw.permute(0, 2, 1).contiguous().float().to(dev).view(Co, kw * Ci), vg, gg, dg, dv)
+    assert rel(dg, g.grad.view(-1)) < 1e-5 and rel(dv, v.grad) < 1e-5
+    w2 = rnd(8, 5, 15, seed=38).to(dev)
+    packed = ops.conv_dgrad_pack(w2, torch.empty(6, 5, 3 * 8, device=dev), 6).cpu().view(6, 5, 3, 8)
+    for r in range(6):
+        for j in range(3):
+            k = r + 6 * j
+            exp = w2.cpu()[:, :, k].t() if k < 15 else torch.zeros(5, 8)
+            assert torch.equal(packed[r, :, j, :], exp)
+
+
+def test_rng_ops(pkg, dev):
+    ops = pkg.ops
+    st = ops.new_rng_state(1234, dev)
+    m = ops.dropout_mask(torch.empty(1 << 20, device=dev), 0.3, st, 1)
+    keep = float((m > 0).float().mean())
+    assert abs(keep - 0.7) < 3e-3 and abs(float(m.max()) - 1 / 0.7) < 1e-6 and float(m.min()) == 0
+    m2 = ops.dropout_mask(torch.empty(1 << 20, device=dev), 0.3, st, 1)
+    assert torch.equal(m, m2)                                     # same (seed, step, site) -> same draw
+    ops.rng_advance(st)
+    m3 = ops.dropout_mask(torch.empty(1 << 20, device=dev), 0.3, st, 1)
+    assert not torch.equal(m, m3) and int(st[1]) == 1
+    m4 = ops.dropout_mask(torch.empty(1 << 20, device=dev), 0.3, st, 2)
+    assert abs(float(((m3 > 0) == (m4 > 0)).float().mean()) - (0.49 + 0.09)) < 5e-3     # sites are independent
+    e = ops.normal(torch.empty(1 << 20, device=dev), st, 3)
+    assert abs(float(e.mean())) < 5e-3 and abs(float(e.std()) - 1) < 5e-3 and abs(float((e ** 4).mean()) - 3) < 0.1
+    p = ops.randperm(torch.empty(128, dtype=torch.int64, device=dev), st, 4).cpu()
+    assert sorted(p.tolist()) == list(range(128)) and p.tolist() != list(range(128))
+    src = torch.arange(100, 228, device=dev)
+    assert torch.equal(ops.gather_i64(src, p.to(dev), torch.empty_like(src)).cpu(), src.cpu()[p])
+
+
+def test_reparam_losses_adam_vs_oracle(pkg, dev):
+    from oracle import ref_model as O
+    ops = pkg.ops
+    B, T, D, Z = 6, 34, 27, 16
+    mu, lv, eps = rnd(B, Z, seed=40).double().requires_grad_(True), (0.3 * rnd(B, Z, seed=41)).double().requires_grad_(True), rnd(B, Z, seed=42).double()
+    z = mu + eps * torch.exp(0.5 * lv)
+    zg = ops.reparam_fwd(mu.detach().float().to(dev), lv.detach().float().to(dev), eps.float().to(dev), torch.empty(B, Z, device=dev))
+    assert rel(zg, z) < 1e-6
+    out = (0.2 * rnd(B, T, D, seed=43)).double().requires_grad_(True)
+    tgt, outr = 0.2 * rnd(B, T, D, seed=44).double(), 0.2 * rnd(B, T, D, seed=45).double()
+    zr = rnd(B, Z, seed=46).double()
+    zr[0] = z.detach()[0] + 1e-9                                   # forces the clamp(min=-1000) branch for clip 0
+    logit = rnd(B, 1, seed=47).double().requires_grad_(True)
+    for epoch in (0, 11):
+        for t in (mu, lv, out, logit):
+            t.grad = None
+        loss, parts = O.gan_losses_g(out, tgt, torch.sigmoid(logit), outr, z, zr, mu, lv, epoch)
+        # z enters the loss only detached (train_gan.py:71); mu/logvar via KLD
+        loss.backward()
+        f = lambda t: t.detach().float().to(dev).contiguous()
+        sc, d_out, d_mu, d_lv, d_lg = (torch.empty(5, device=dev), torch.empty(B, T, D, device=dev), torch.empty(B, Z, device=dev),
+                                       torch.empty(B, Z, device=dev), torch.empty(B, device=dev))
+        ops.gan_g_loss(f(out), f(tgt), f(outr), f(z), f(zr), f(mu), f(lv), f(logit).view(-1), (500.0, 0.1, 0.05, 5.0), epoch > 10,
+                       torch.empty(3 * B, device=dev), sc, d_out, d_mu, d_lv, d_lg)
+        ref_sc = torch.stack([parts["huber"], parts["kld"], parts["div_reg"], parts["gen"], loss]).detach()
+        assert rel(sc, ref_sc) < 2e-5, (sc.cpu(), ref_sc)
+        assert float(parts["div_reg"]) < -100          # clamp branch really hit
+        assert rel(d_out, out.grad) < 2e-5 and rel(d_mu, mu.grad) < 2e-5 and rel(d_lv, lv.grad) < 2e-5
+        if epoch > 10:
+            assert rel(d_lg, logit.grad.view(-1)) < 2e-5
+        else:
+            assert float(d_lg.abs().max()) == 0
+    lr_, lf_ = rnd(B, seed=48).double().requires_grad_(True), rnd(B, seed=49).double().requires_grad_(True)
+    dis = torch.sum(-torch.mean(torch.log(torch.sigmoid(lr_) + 1e-8) + torch.log(1 - torch.sigmoid(lf_) + 1e-8)))
+    dis.backward()
+    o, d1, d2 = torch.empty(1, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
+    ops.gan_d_loss(lr_.detach().float().to(dev), lf_.detach().float().to(dev), o, d1, d2)
+    assert rel(o, dis.detach().view(1)) < 1e-5 and rel(d1, lr_.grad) < 1e-5 and rel(d2, lf_.grad) < 1e-5
+    # AE loss
+    rc = (0.3 * rnd(B, T, D, seed=50)).double().requires_grad_(True)
+    l = O.ae_loss(rc, tgt); l.backward()
+    o2, drc = torch.empty(1, device=dev), torch.empty(B, T, D, device=dev)
+    ops.ae_loss(rc.detach().float().to(dev), tgt.float().to(dev), o2, drc)
+    assert rel(o2, l.detach().view(1)) < 1e-5 and rel(drc, rc.grad) < 1e-5
+    assert rel(ops.l1_mean(zg, zg * 0 + 1, torch.empty(1, device=dev)), (z.detach() - 1).abs().mean().view(1)) < 1e-5
+    # Adam: three steps against the oracle's restatement of torch.optim.Adam
+    n = 1003
+    p = {"w": rnd(n, seed=51).double()}
+    pg, mg, vg, step = p["w"].float().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros((), dtype=torch.int32, device=dev)
+    pg = torch.cat([pg, torch.zeros(1, device=dev)])[:n]          # any 16-byte aligned slab start
+    state = {}
+    for it in range(3):
+        g = rnd(n, seed=60 + it).double()
+        O.adam_step(p, {"w": g}, state, 5e-4)
+        ops.counter_inc(step)
+        ops.adam_step(pg, g.float().to(dev), mg, vg, 5e-4, 0.5, 0.999, 1e-8, step)
+    assert rel(pg, p["w"]) < 1e-6 and int(step) == 3
