@@ -22,7 +22,7 @@ WP = C.POINTER(Window)
 # name -> argtypes (all return int); mirrors include/trimodal_hip.h one to one
 SIGNATURES = {
     "tg_gemm_nt": [WP, P, I64, P, P, I64, I64, I32, I32, I32, F32, I32, P],
-    "tg_gemm_tn": [P, I64, WP, P, I64, I32, I32, I32, P],
+    "tg_gemm_tn": [P, I64, WP, P, I64, I32, I32, I32, P, I64, P],
     "tg_colsum": [P, I64, I32, I32, P, I32, P],
     "tg_gru_forward": [P, I64, P, P, P, P, P, P, I64, I32, I32, I32, P],
     "tg_gru_backward": [P, P, P, I64, P, P, P, P, I64, P, I32, I32, I32, P],
@@ -79,6 +79,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.tg_version.restype = C.c_int
     lib.tg_last_error.restype = C.c_char_p
+    lib.tg_gemm_tn_ws_floats.restype = C.c_int64
+    lib.tg_gemm_tn_ws_floats.argtypes = [I32, I32, I32]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: intended
         fn.argtypes = argtypes

@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Win A, const float* __rest
 // dW[n][k] += sum_m dY[m][n] * A(m,k).  Workgroup = 4 waves as 2 (n) x 2 (k), each 32x32 of dW; the m range is
 // split over blockIdx.z and partial tiles are combined with f32 atomics (one global_atomic_add_f32 per element).
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, long ldy, Win A, float* __restrict__ dW,
-                                                      long ldw, int M, int N, int rows_per_split, int out_kw) {
+                                                      long ldw, int M, int N, int rows_per_split, int out_kw,
+                                                      float* __restrict__ partial) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r16 = lane & 15, mq = lane >> 4;
@@ -223,13 +224,28 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             for (int i = 0; i < 4; ++i) {
                 const int n = n_base + nt * 16 + mq * 4 + i;
                 const int kc = k_base + kt * 16 + r16;
-                if (n < N && kc < K) {
+                if (n < N && kc < K && partial) {
+                    partial[((long)blockIdx.z * N + n) * K + kc] = acc[nt][kt][i];     // combined in fp64 by tn_reduce_kernel
+                } else if (n < N && kc < K) {
                     // out_kw > 0: k = (tap, channel) is stored channel-major, tap-minor: the (Co, Ci, kw) layout of
                     // nn.Conv1d / ConvTranspose1d weights, so conv weight gradients need no separate permute pass
                     const long off = out_kw > 0 ? (long)(kc % A.cw) * out_kw + kc / A.cw : (long)kc;
                     atomicAdd(&dW[(long)n * ldw + off], acc[nt][kt][i]);
                 }
             }
+}
+
+// Deterministic combine of the split-M partial tiles: fp64 sum in split order, one rounding, then += into dW.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int splits, int N, int K, int cw, int out_kw,
+                                                        float* __restrict__ dW, long ldw) {
+    const long total = (long)N * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int q = 0; q < splits; ++q) s += (double)partial[(long)q * total + i];
+        const int n = (int)(i / K), kc = (int)(i - (long)n * K);
+        const long off = out_kw > 0 ? (long)(kc % cw) * out_kw + kc / cw : (long)kc;
+        dW[(long)n * ldw + off] += (float)s;
+    }
 }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ldx, int M, int N, float* __restrict__ out,
@@ -280,23 +296,44 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
     return check_launch("tg_gemm_nt");
 }
 
-extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,
-                          int32_t out_kw, void* stream) {
-    if (int e = check_window(A, "tg_gemm_tn")) return e;
-    TG_REQUIRE(dY && dW && M > 0 && N > 0 && ldy >= N && ldw >= A->K, "tg_gemm_tn: bad arguments");
-    TG_REQUIRE(out_kw == 0 || out_kw * A->cw == A->K, "tg_gemm_tn: out_kw=%d must be 0 or K/cw", out_kw);
-    Win w = to_win(A);
-    const int tiles = cdiv(N, 64) * cdiv(w.K, 64);
+static void tn_plan(int M, int N, int K, bool two_pass, int* splits_out, int* rows_out) {
+    const int tiles = cdiv(N, 64) * cdiv(K, 64);
     int splits = 1024 / tiles;
+    if (two_pass) {                       // short fp32 chains per split: at most 512 rows, fp64 across splits
+        const int by_len = cdiv(M, 512);
+        if (splits < by_len) splits = by_len;
+    }
     const int max_splits = cdiv(M, 64);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
-    int rows_per_split = cdiv(M, splits);
-    rows_per_split = ((rows_per_split + 15) / 16) * 16;
-    splits = cdiv(M, rows_per_split);
+    int rows = cdiv(M, splits);
+    rows = ((rows + 15) / 16) * 16;
+    *rows_out = rows;
+    *splits_out = cdiv(M, rows);
+}
+
+extern "C" int64_t tg_gemm_tn_ws_floats(int32_t M, int32_t N, int32_t K) {
+    int splits, rows;
+    tn_plan(M, N, K, true, &splits, &rows);
+    return (int64_t)splits * N * K;
+}
+
+extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,
+                          int32_t out_kw, float* ws, int64_t ws_floats, void* stream) {
+    if (int e = check_window(A, "tg_gemm_tn")) return e;
+    TG_REQUIRE(dY && dW && M > 0 && N > 0 && ldy >= N && ldw >= A->K, "tg_gemm_tn: bad arguments");
+    TG_REQUIRE(out_kw == 0 || out_kw * A->cw == A->K, "tg_gemm_tn: out_kw=%d must be 0 or K/cw", out_kw);
+    Win w = to_win(A);
+    int splits, rows_per_split;
+    tn_plan(M, N, w.K, ws != nullptr, &splits, &rows_per_split);
+    TG_REQUIRE(ws == nullptr || ws_floats >= (int64_t)splits * N * w.K, "tg_gemm_tn: workspace too small (%ld < %ld floats)",
+               (long)ws_floats, (long)splits * N * w.K);
     dim3 grid(cdiv(N, 64), cdiv(w.K, 64), splits);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N, rows_per_split, out_kw);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N, rows_per_split, out_kw, ws);
+    if (ws)
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(ew_grid((long)N * w.K, 256, 1)), dim3(256), 0, (hipStream_t)stream, ws, splits, N, w.K, w.cw,
+                           out_kw, dW, (long)ldw);
     return check_launch("tg_gemm_tn");
 }
 

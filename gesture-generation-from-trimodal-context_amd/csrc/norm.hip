@@ -142,8 +142,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float xh = (x[e] - mean[c]) * rs;
         const float z = xh * ga + beta[c];
         const float dz = dy[e] * (z >= 0.f ? 1.f : slope);
-        const float m1 = (float)(ws[c] * inv_n), m2 = (float)(ws[C + c] * inv_n);
-        dx[e] = ga * rs * (dz - m1 - xh * m2);
+        // the two batch means are subtracted in fp64: rounding them to fp32 first would shift every element of the
+        // channel by the same amount, and the next layer's weight-gradient sum over ~1e6 rows amplifies that coherently
+        const double m1 = ws[c] * inv_n, m2 = ws[C + c] * inv_n;
+        dx[e] = (float)((double)(ga * rs) * ((double)dz - m1 - (double)xh * m2));
     }
 }
 

@@ -110,7 +110,9 @@ def gemm_tn(dY, A: Win, dW, *, out_kw=0):
     assert dW.is_contiguous() and dW.numel() == N * A.K and dW.shape[0] == N, (dW.shape, N, A.K)
     if (M - 1) * dY.stride(0) + N - 1 >= _room(dY):
         raise ValueError("gemm_tn: dY exceeds its tensor")
-    call("tg_gemm_tn", _p(dY), dY.stride(0), C.byref(A.s), _p(dW), A.K, M, N, int(out_kw), _stream())
+    nws = _lib.load().tg_gemm_tn_ws_floats(M, N, A.K)      # deterministic fp64 cross-split combine (no atomics)
+    ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
+    call("tg_gemm_tn", _p(dY), dY.stride(0), C.byref(A.s), _p(dW), A.K, M, N, int(out_kw), _p(ws), nws, _stream())
     return dW
 
 

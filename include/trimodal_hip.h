@@ -67,9 +67,13 @@ int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bi
 /* tg_gemm_tn (weight gradient, accumulates): dW[n*ldw + perm(k)] += sum_m dY[m*ldy + n] * A(m, k).
  *   out_kw == 0: perm(k) = k.  out_kw == K/cw: perm(k) = (k % cw) * out_kw + k / cw, i.e. the gradient lands in
  *   the (Cout, Cin, kw) layout of nn.Conv1d weights.
+ *   The sum over m is split across workgroups.  ws == NULL: partial tiles are combined with f32 atomics (order
+ *   varies run to run).  ws != NULL (>= tg_gemm_tn_ws_floats(M, N, K) floats): partials of <= 512 rows go to ws and are
+ *   combined in split order in fp64 -- bitwise reproducible, and accurate for the ~1e6-row sums of the audio encoder.
  *   Replaces the weight-gradient half of aten::convolution_backward / addmm backward for the same call sites. */
+int64_t tg_gemm_tn_ws_floats(int32_t M, int32_t N, int32_t K);
 int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,
-               int32_t out_kw, void* stream);
+               int32_t out_kw, float* ws, int64_t ws_floats, void* stream);
 
 /* tg_colsum (bias gradient): out[n] (+)= sum_m X[m*ldx + n]. */
 int tg_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream);

@@ -114,14 +114,18 @@ def test_full_size_step_matches_reference_golden_b128(pkg, dev):
     for k, v in zip(g["loss_keys"], g["loss_vals"]):
         assert abs(ret[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, ret[k], v)
     _, Gg, _ = tr.G.views()
+    bad = []
     for k, gr in Gg.items():
         if k in ZERO_GRAD_KEYS:
             continue
         nrm = float(gr.double().norm())
-        assert abs(nrm - float(g["ggn/" + k])) <= 1e-4 * float(g["ggn/" + k]) + 1e-12, (k, nrm, float(g["ggn/" + k]))
+        e_n = abs(nrm - float(g["ggn/" + k])) / (float(g["ggn/" + k]) + 1e-30)
         scale = float(gr.abs().max())
         mine = gr.reshape(-1).cpu().numpy()[sample_idx(gr.numel(), 64)]
-        assert float(np.abs(mine - g["gg/" + k]).max()) <= 1e-4 * scale, k
+        e_s = float(np.abs(mine - g["gg/" + k]).max()) / scale
+        if e_n > 1e-4 or e_s > 1e-4:
+            bad.append((k, e_n, e_s))
+    assert not bad, bad
     for sd, pre in ((G.state_dict(), "gp/"), (D.state_dict(), "dp/")):
         for k, v in sd.items():
             if "running_var" in k:
