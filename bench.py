@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Training-throughput benchmark of the trimodal gesture GAN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): config/multimodal_context.yml -- PoseGenerator + ConvDiscriminator, post-warm-up GAN
+iteration (3 G forwards, 1 G backward, 3 D forwards, D backward passes, both Adam steps), batch 128 clips of 34 frames x 27
+dims per GPU, 36 267 audio samples per clip, synthetic data (V = 20 000 words, 1 370 speakers), random-init weights, fp32.
+A "step" is one full iteration; inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "gesture-generation-from-trimodal-context_amd"
+
+V, S, T, D, A = 20000, 1371, 34, 27, 36267
+# algorithmic work per clip of one post-warm-up iteration: 5 G-forward-equivalents + 9 D-forward-equivalents
+FLOP_PER_CLIP = 2.735e9
+PEAK_F32_MFMA = 157.3e12          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def make_args():
+    return argparse.Namespace(n_pre_poses=4, n_poses=34, input_context="both", hidden_size=300, n_layers=4, dropout_prob=0.3,
+                              freeze_wordembed=False, z_type="speaker", loss_warmup=10, loss_gan_weight=5.0,
+                              loss_regression_weight=500.0, loss_kld_weight=0.1, loss_reg_weight=0.05, learning_rate=0.0005,
+                              discriminator_lr_weight=0.2, wordembed_dim=300)
+
+
+def synthetic_batch(batch, seed, device):
+    """sparse-onset word ids (4..12 word onsets per clip, rest PAD=0), N(0, 0.1^2) audio and poses."""
+    g = torch.Generator().manual_seed(seed)
+    text = torch.zeros(batch, T, dtype=torch.int64)
+    for b in range(batch):
+        k = int(torch.randint(4, 13, (1,), generator=g))
+        frames = torch.randperm(T, generator=g)[:k]
+        text[b, frames] = torch.randint(4, V, (k,), generator=g)
+    audio = (0.1 * torch.randn(batch, A, generator=g)).clamp_(-1, 1)
+    vid = torch.randint(1, S, (batch,), generator=g)
+    poses = 0.1 * torch.randn(batch, T, D, generator=g)
+    return text.to(device), audio.to(device), poses.to(device), vid.to(device)
+
+
+def build(pkg, device, seed=0):
+    torch.manual_seed(seed)
+    args = make_args()
+    emb = (torch.randn(V, 300) / 300 ** 0.5).numpy()            # vocab.py:74-75 initialisation scale
+    G = pkg.PoseGenerator(args, D, V, 300, emb, pkg.Vocab.speakers(S)).to(device)
+    Dn = pkg.ConvDiscriminator(D).to(device)
+    return args, G, Dn
+
+
+def time_kernel(fn, iters=50, warm=5):
+    """Average duration (s) of one launch sequence `fn`, HIP events on the stream the kernels are launched on
+    (the ops launch on torch's current stream)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def dominant_kernel_roofline(pkg, device, batch):
+    """The kernel with the largest share of the step (profiles/): the per-time-step launch of the generator's GRU forward
+    over the 3 stacked forwards (gru_fwd_step_kernel at B = 3*batch, H = 300).
+    Algorithmic FLOPs per launch: 2 directions x B x H x 3H x 2 (the h_{t-1} @ W_hh^T product; gate maths excluded)."""
+    ops = pkg.ops
+    Bs, H = 3 * batch, 300
+    gi = torch.randn(2, Bs, T, 3 * H, device=device) * 0.1
+    w = [torch.randn(3 * H, H, device=device) * 0.05 for _ in range(2)]
+    b = [torch.randn(3 * H, device=device) * 0.05 for _ in range(2)]
+    y = torch.empty(Bs, T, 2 * H, device=device)
+    sv = torch.empty(2, Bs, T, 4 * H, device=device)
+    dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, sv), iters=20) / T        # T launches per call
+    flops = 2 * Bs * H * 3 * H * 2
+    return {"kernel": "gru_fwd_step_kernel", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": None, "launch_us": dt * 1e6,
+            "flop_per_launch": flops}
+
+
+def cpu_baseline(batch, steps=2):
+    """The oracle (a CPU port of the reference path, verified against the reference's own outputs) on the host cores,
+    ATen native kernels (FAST), fp32, same workload shape; bounded sample of `steps` iterations after one warm-up."""
+    from oracle import ref_model as O
+    O.FAST = True
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gst, dst = O.make_generator_state(0, V, S), O.make_discriminator_state(1)
+    g = torch.Generator().manual_seed(5)
+    text = torch.zeros(batch, T, dtype=torch.int64)
+    text[:, ::4] = torch.randint(4, V, (batch, len(range(0, T, 4))), generator=g)
+    audio, poses = 0.1 * torch.randn(batch, A, generator=g), 0.1 * torch.randn(batch, T, D, generator=g)
+    vid = torch.randint(1, S, (batch,), generator=g)
+    ga, da = {}, {}
+    O.train_iter_gan(gst, dst, ga, da, 11, text, audio, poses, vid, O.Rand(seed=1), fast_gru=True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        O.train_iter_gan(gst, dst, ga, da, 11, text, audio, poses, vid, O.Rand(seed=2 + i), fast_gru=True)
+    dt = (time.perf_counter() - t0) / steps
+    O.FAST = False
+    return {"value": batch / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} post-warm-up GAN iterations at batch {batch} after 1 warm-up, fp32 ATen kernels, {dt:.2f} s/iter"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="clips per GPU")
+    ap.add_argument("--epoch", type=int, default=11, help="> loss_warmup (10) = full GAN iteration")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    pkg = importlib.import_module(PKG)
+    pkg._lib.load()
+
+    grad_sync = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        ddp = importlib.import_module(PKG + ".ddp")
+        grad_sync = ddp.GradSync()
+
+    args, G, Dn = build(pkg, device, seed=0)                 # same seed on every rank: identical replicas
+    trainer = pkg.GanTrainer(G, Dn, args, grad_sync=grad_sync)
+    if world > 1:
+        ddp.broadcast_parameters([trainer.G.slab.ensure(), trainer.D.slab.ensure()])
+    text, audio, poses, vid = synthetic_batch(a.batch, 1234 + rank, device)
+
+    if a.no_graph:
+        step = lambda: trainer.train_iter(a.epoch, text, audio, poses, vid)
+    else:
+        step = pkg.GraphedGanStep(trainer, a.epoch, text, audio, poses, vid, warmup_iters=2)
+    for _ in range(a.warmup):
+        losses = step()
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_dict = losses.to_dict()
+    assert all(v == v and abs(v) < 1e6 for v in loss_dict.values()), loss_dict     # finite
+
+    if rank == 0:
+        clips_per_s = world * a.batch * a.steps / dt
+        out = {
+            "metric": "training clips/sec (34-frame, 27-dim pose), post-warm-up GAN iteration",
+            "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "multimodal_context GAN training iteration (BASELINE.json configs[1]), epoch > loss_warmup",
+                       "batch_per_gpu": a.batch, "global_batch": world * a.batch, "frames": T, "pose_dim": D,
+                       "audio_samples": A, "n_words": V, "n_speakers": S - 1, "hipgraph": not a.no_graph,
+                       "parallelism": f"dp{world}"},
+            "step_roofline": {"bound": "mfma", "achieved": clips_per_s / world * FLOP_PER_CLIP / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+                              "unit": "TFLOP/s", "frac": clips_per_s / world * FLOP_PER_CLIP / PEAK_F32_MFMA,
+                              "note": "whole iteration, algorithmic 2.735 GFLOP/clip, per GPU"},
+            "losses": loss_dict,
+        }
+        out["roofline"] = dominant_kernel_roofline(pkg, device, a.batch)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.batch)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

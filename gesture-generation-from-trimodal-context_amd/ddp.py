@@ -1,0 +1,73 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL over xGMI (torch.distributed backend "nccl").
+
+Replaces nn.DataParallel (scripts/train.py:93-96).  Clips are independent, BatchNorm statistics stay per replica (as
+DataParallel's own per-chunk statistics do), so the only exchange is the gradient mean: the discriminator slab (1 MB)
+after its backward, the generator slab in three buckets that become final in backward order -- {out, gru} (22 MB),
+{text encoder, speaker path} (up to 30 MB with the word embedding), {audio encoder} (0.3 MB).  Each bucket is a single
+contiguous range of the flat gradient slab, all-reduced asynchronously on RCCL's stream while the rest of the backward
+keeps the compute stream busy; the optimiser step waits on the outstanding work.  xGMI is point-to-point (7 links per
+GPU): few large messages keep every link busy without per-tensor launch overhead.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, group=None, chunk_floats=8 * 1024 * 1024):
+        assert dist.is_initialized(), "init_process_group first"
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.chunk = int(chunk_floats)
+        self.pending = []
+        self._avg = dist.get_backend(group) == "nccl"
+
+    # ---- primitive: mean all-reduce of one contiguous gradient range, asynchronous
+    def _launch(self, flat):
+        for s in range(0, flat.numel(), self.chunk):
+            piece = flat[s:s + self.chunk]
+            if self._avg:
+                w = dist.all_reduce(piece, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                self.pending.append((w, None))
+            else:                                   # gloo (CPU tests): SUM then scale
+                w = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.pending.append((w, piece))
+
+    def wait(self):
+        for w, piece in self.pending:
+            w.wait()
+            if piece is not None:
+                piece.div_(self.world)
+        self.pending = []
+
+    @staticmethod
+    def bucket_range(slab, prefixes):
+        """Contiguous [start, end) of the slab covered by the parameters under the given top-level names."""
+        lo, hi = None, None
+        for name, p, off in zip(slab.names, slab.params, slab.offsets):
+            if name.split(".", 1)[0] in prefixes:
+                lo = off if lo is None else min(lo, off)
+                hi = off + p.numel() if hi is None else max(hi, off + p.numel())
+        assert lo is not None, prefixes
+        for name, p, off in zip(slab.names, slab.params, slab.offsets):       # the range must not swallow other groups
+            assert not (lo <= off < hi) or name.split(".", 1)[0] in prefixes, (name, prefixes)
+        return lo, hi
+
+    # ---- actions issued by the trainer at its synchronisation points
+    def run(self, action):
+        kind = action[0]
+        if kind == "all":                      # whole slab, finished before returning control to the optimiser
+            self._launch(action[1].grad)
+            self.wait()
+        elif kind == "bucket":                 # one backward-order bucket, left in flight
+            lo, hi = self.bucket_range(action[1], action[2])
+            self._launch(action[1].grad[lo:hi])
+        elif kind == "wait":
+            self.wait()
+        else:
+            raise ValueError(kind)
+
+
+def broadcast_parameters(slabs, src=0, group=None):
+    """Make every replica start from rank `src`'s weights (what DataParallel's per-forward replicate guarantees)."""
+    for s in slabs:
+        dist.broadcast(s.flat, src=src, group=group)

@@ -64,6 +64,17 @@ class GanTrainer:
         self.g_opt = FusedAdam(self.G, lr=self.hp["learning_rate"], betas=(0.5, 0.999))
         self.d_opt = FusedAdam(self.D, lr=self.hp["learning_rate"] * self.hp["discriminator_lr_weight"], betas=(0.5, 0.999))
         self.grad_sync = grad_sync          # ddp.GradSync or None
+        self._cut = None                    # set by GraphedGanStep while capturing: cuts the graph at sync points
+
+    def _sync(self, *action):
+        """A gradient-exchange point.  Eager: run the collective now.  Capturing: end the current graph segment here and
+        let the replay loop issue the collective between segments (collectives stay outside hipGraphs)."""
+        if self.grad_sync is None:
+            return
+        if self._cut is not None:
+            self._cut(action)
+        else:
+            self.grad_sync.run(action)
 
     # -------------------------------------------------------------------------------------------------------
     def train_iter(self, epoch, in_text, in_audio, target, vid, inject=None):
@@ -117,8 +128,7 @@ class GanTrainer:
         st["d_scalar"] = torch.empty(1, device=logit.device)
         ops.gan_d_loss(logit[:B], logit[B:], st["d_scalar"], d_logit[:B], d_logit[B:])
         D.backward(dres["tape"], d_logit.view(-1, 1), b0=0, nb=2 * B, param_grads=True)
-        if self.grad_sync is not None:
-            self.grad_sync.all_reduce(D.slab.grad)
+        self._sync("all", D.slab)
         self.d_opt.step()
 
     # ---- phase 3: generator losses and backward (train_gan.py:47-91)
@@ -139,25 +149,25 @@ class GanTrainer:
         if post:
             d_poses = D.backward(dres["tape"], d_logit.view(B, 1), param_grads=False, need_dposes=True)
             ops.axpy(d_poses, d_out, 1.0, accumulate=True)
-        on_ready = self.grad_sync.bucket_hook(G.slab) if self.grad_sync is not None else None
+        on_ready = (lambda prefixes: self._sync("bucket", G.slab, prefixes)) if self.grad_sync is not None else None
         G.backward(st["res"]["tape"], d_out, d_mu, d_lv, b0=st["i2"] * B, nb=B, on_ready=on_ready)
 
     # ---- phase 4: generator update (train_gan.py:92)
     def phase_g_update(self):
-        if self.grad_sync is not None:
-            self.grad_sync.wait()
+        self._sync("wait")
         self.g_opt.step()
 
 
 class GraphedGanStep:
     """Captures GanTrainer.train_iter for fixed shapes into a hipGraph and replays it.
 
-    Inputs are copied into static buffers; every intermediate lives in the graph's private memory pool; random draws
+    Inputs are copied into static buffers; every intermediate lives in the graphs' private memory pool; random draws
     advance through the device-side Philox step counter, Adam through its device-side step counter, so every replay is a
-    new, correct training iteration.  Only single-process training is captured (collectives stay outside graphs)."""
+    new, correct training iteration.  Under data parallelism the iteration is captured as several graph SEGMENTS cut at the
+    gradient-exchange points: the replay loop launches each segment and issues the RCCL all-reduce of the bucket that just
+    became final, asynchronously, so it overlaps the next segment (the rest of the backward)."""
 
     def __init__(self, trainer: GanTrainer, epoch, in_text, in_audio, target, vid, warmup_iters=2):
-        assert trainer.grad_sync is None, "graph capture covers the single-GPU step; use GanTrainer.train_iter under DDP"
         self.trainer, self.epoch = trainer, epoch
         self.static = [t.clone() for t in (in_text, in_audio, target, vid)]
         side = torch.cuda.Stream()
@@ -167,13 +177,34 @@ class GraphedGanStep:
                 trainer.train_iter(epoch, *self.static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.losses = trainer.train_iter(epoch, *self.static)
+        self.segments = []                   # [(graph, action to run after it or None)]
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            state = {"g": torch.cuda.CUDAGraph()}
+            state["g"].capture_begin(pool=pool)
+
+            def cut(action):
+                state["g"].capture_end()
+                self.segments.append((state["g"], action))
+                state["g"] = torch.cuda.CUDAGraph()
+                state["g"].capture_begin(pool=pool)
+            trainer._cut = cut
+            try:
+                self.losses = trainer.train_iter(epoch, *self.static)
+            finally:
+                trainer._cut = None
+                state["g"].capture_end()
+            self.segments.append((state["g"], None))
+        torch.cuda.current_stream().wait_stream(cap)
 
     def __call__(self, in_text=None, in_audio=None, target=None, vid=None):
         for dst, src in zip(self.static, (in_text, in_audio, target, vid)):
             if src is not None and src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
-        self.graph.replay()
+        for graph, action in self.segments:
+            graph.replay()
+            if action is not None:
+                self.trainer.grad_sync.run(action)
         return self.losses
