@@ -22,7 +22,7 @@ WP = C.POINTER(Window)
 # name -> argtypes (all return int); mirrors include/trimodal_hip.h one to one
 SIGNATURES = {
     "tg_gemm_nt": [WP, P, I64, P, P, I64, I64, I32, I32, I32, F32, I32, P],
-    "tg_gemm_tn": [P, I64, WP, P, I64, I32, I32, I32, P, I64, P],
+    "tg_gemm_tn": [P, I64, WP, P, I64, I32, I32, I32, P, P, I64, P],
     "tg_colsum": [P, I64, I32, I32, P, I32, P],
     "tg_gru_forward": [P, I64, P, P, P, P, P, P, I64, I32, I32, I32, P],
     "tg_gru_backward": [P, P, P, I64, P, P, P, P, I64, P, I32, I32, I32, P],

@@ -3,10 +3,13 @@
 // Conv1d / ConvTranspose1d of the path (channel-last, im2col never materialised) and the shifted h_{t-1} view the
 // GRU weight gradient needs.
 //
-// Operand staging: no LDS.  The MFMA k index is permuted so that lane group kq = lane>>4 owns k = 16u + 4kq + {0..3}
+// tg_gemm_nt: no LDS.  The MFMA k index is permuted so that lane group kq = lane>>4 owns k = 16u + 4kq + {0..3}
 // of every 16-deep super-step: each lane then feeds four MFMAs from ONE contiguous 16-byte global load per operand
 // (both operands use the same permutation, so the sum over k is unchanged).  Operands of this path are L2-resident
 // (weights <= 2 MB, activations a few MB per layer); L1/L2 serve the 2x intra-workgroup reuse.
+//
+// tg_gemm_tn (weight gradients): the reduction runs over ROWS, so MFMA fragments are column-strided; tiles of 16 rows
+// are staged through LDS with coalesced 16-byte loads, double-buffered, one barrier per tile.
 #include "common.hpp"
 
 namespace tg {
@@ -147,83 +150,121 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Win A, const float* __rest
     }
 }
 
-// dW[n][k] += sum_m dY[m][n] * A(m,k).  Workgroup = 4 waves as 2 (n) x 2 (k), each 32x32 of dW; the m range is
-// split over blockIdx.z and partial tiles are combined with f32 atomics (one global_atomic_add_f32 per element).
+// dW[n][k] += sum_m dY[m][n] * A(m,k)  (and dbias[n] += sum_m dY[m][n] when asked).
+// Workgroup = 4 waves as 2 (n) x 2 (k), each 32x32 of dW, i.e. a 64 x 64 tile of dW per workgroup; the m range is split
+// over blockIdx.z.  Per 16-row tile every thread fetches one 16-byte piece of dY and one of A (coalesced rows), the
+// pieces go to LDS ([row][col], row stride 68 floats: the column-strided MFMA fragment reads are conflict-free), the
+// next tile's global loads are in flight while the current tile's 16 MFMAs per wave run.
+constexpr int TN_LD = 68;
+
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, long ldy, Win A, float* __restrict__ dW,
                                                       long ldw, int M, int N, int rows_per_split, int out_kw,
-                                                      float* __restrict__ partial) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+                                                      float* __restrict__ partial, float* __restrict__ dbias, int vec_y, int vec_a) {
+    __shared__ __attribute__((aligned(16))) float ys[2][16][TN_LD];
+    __shared__ __attribute__((aligned(16))) float xs[2][16][TN_LD];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
     const int r16 = lane & 15, mq = lane >> 4;
-    const int n_base = blockIdx.x * 64 + (wave >> 1) * 32;
-    const int k_base = blockIdx.y * 64 + (wave & 1) * 32;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
     const int K = A.K;
-    if (n_base >= N || k_base >= K) return;
     const int m_begin = blockIdx.z * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
-    if (m_begin >= m_end) return;
 
-    int n_idx[2], k_col[2], k_roff[2], k_ch[2];
-    bool n_ok[2], k_ok[2];
+    // staging role of this thread: row (t>>4) of the 16-row tile, 4 consecutive columns starting at 4*(t&15)
+    const int srow = t >> 4, scol = 4 * (t & 15);
+    const int yn = n0 + scol;                 // first dY column of this thread's piece
+    const int ak = k0 + scol;                 // first k of this thread's piece
+    int a_roff[4], a_ch[4];
+    bool a_kok[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        n_idx[t] = n_base + t * 16 + r16;
-        n_ok[t] = n_idx[t] < N;
-        k_col[t] = k_base + t * 16 + r16;
-        k_ok[t] = k_col[t] < K;
-        const int kc = k_ok[t] ? k_col[t] : 0;
+    for (int q = 0; q < 4; ++q) {
+        a_kok[q] = ak + q < K;
+        const int kc = a_kok[q] ? ak + q : 0;
         const int kk = kc / A.cw;
-        k_roff[t] = kk * A.dil;
-        k_ch[t] = kc - kk * A.cw;
+        a_roff[q] = kk * A.dil;
+        a_ch[q] = kc - kk * A.cw;
     }
-    // (clip, row) of the four m values this lane owns per 16-row super-step, advanced incrementally
-    int mb[4], mr[4];
+    int mb = 0, mr = 0;                       // (clip, row in clip) of this thread's staging row, advanced incrementally
+    {
+        const int m = m_begin + srow;
+        mb = m / A.rows_out;
+        mr = m - mb * A.rows_out;
+    }
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bias = dbias != nullptr && blockIdx.y == 0;
+
+    auto fetch = [&](int m0, f32x4& yv, f32x4& xv) {
+        const int m = m0 + srow;
+        const bool ok = m < m_end;
+        yv = f32x4{0.f, 0.f, 0.f, 0.f};
+        xv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const float* yp = dY + (long)m * ldy + yn;
+            if (vec_y && yn + 3 < N) {
+                yv = *reinterpret_cast<const f32x4*>(yp);
+            } else {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int m = m_begin + 4 * mq + v;
-        mb[v] = m / A.rows_out;
-        mr[v] = m - mb[v] * A.rows_out;
-    }
+                for (int q = 0; q < 4; ++q) yv[q] = (yn + q < N) ? yp[q] : 0.f;
+            }
+            const long base = (long)mb * A.bs;
+            const int sr0 = mr * A.step + A.shift;
+            if (vec_a && a_kok[3]) {            // cw % 4 == 0: the four k share one tap
+                const int sr = sr0 + a_roff[0];
+                if (sr >= 0 && sr < A.rows_in) xv = *reinterpret_cast<const f32x4*>(A.ptr + base + (long)sr * A.rs + a_ch[0]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sr = sr0 + a_roff[q];
+                    xv[q] = (a_kok[q] && sr >= 0 && sr < A.rows_in) ? A.ptr[base + (long)sr * A.rs + a_ch[q]] : 0.f;
+                }
+            }
+        }
+        mr += 16;
+        while (mr >= A.rows_out) { mr -= A.rows_out; ++mb; }
+    };
+
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    f32x4 yv, xv;
+    fetch(m_begin, yv, xv);
+    int buf = 0;
     for (int m0 = m_begin; m0 < m_end; m0 += 16) {
-        f32x4 ya[2], xa[2];
+        *reinterpret_cast<f32x4*>(&ys[buf][srow][scol]) = yv;
+        *reinterpret_cast<f32x4*>(&xs[buf][srow][scol]) = xv;
+        if (want_bias) bsum += yv;
+        __syncthreads();                                   // tile `buf` complete; the other buffer is free again
+        if (m0 + 16 < m_end) fetch(m0 + 16, yv, xv);       // next tile's loads fly during the MFMAs
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int m = m0 + 4 * mq + v;
-            const bool ok = m < m_end;
-            const long base = (long)mb[v] * A.bs;
-            const int sr0 = mr[v] * A.step + A.shift;
+            const int ml = 4 * mq + v;
+            float ya[2], xa[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                ya[t][v] = (ok && n_ok[t]) ? dY[(long)m * ldy + n_idx[t]] : 0.f;
-                const int sr = sr0 + k_roff[t];
-                const bool okk = ok && k_ok[t] && sr >= 0 && sr < A.rows_in;
-                xa[t][v] = okk ? A.ptr[base + (long)sr * A.rs + k_ch[t]] : 0.f;
+            for (int q = 0; q < 2; ++q) {
+                ya[q] = ys[buf][ml][wn * 32 + q * 16 + r16];
+                xa[q] = xs[buf][ml][wk * 32 + q * 16 + r16];
             }
-            mr[v] += 16;
-            while (mr[v] >= A.rows_out) { mr[v] -= A.rows_out; ++mb[v]; }
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
-                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[nt][v], xa[kt][v], acc[nt][kt], 0, 0, 0);
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[nt], xa[kt], acc[nt][kt], 0, 0, 0);
+        }
+        buf ^= 1;
     }
+
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int n = n_base + nt * 16 + mq * 4 + i;
-                const int kc = k_base + kt * 16 + r16;
+                const int n = n0 + wn * 32 + nt * 16 + mq * 4 + i;
+                const int kc = k0 + wk * 32 + kt * 16 + r16;
                 if (n < N && kc < K && partial) {
                     partial[((long)blockIdx.z * N + n) * K + kc] = acc[nt][kt][i];     // combined in fp64 by tn_reduce_kernel
                 } else if (n < N && kc < K) {
@@ -233,18 +274,43 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                     atomicAdd(&dW[(long)n * ldw + off], acc[nt][kt][i]);
                 }
             }
+    if (want_bias) {       // column sums of dY over this split: 16 staging rows -> one value per column
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&ys[0][srow][scol]) = bsum;
+        __syncthreads();
+        if (t < 64 && n0 + t < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += ys[0][r][t];
+            atomicAdd(&dbias[n0 + t], s);
+        }
+    }
 }
 
-// Deterministic combine of the split-M partial tiles: fp64 sum in split order, one rounding, then += into dW.
+// Deterministic combine of the split-M partial tiles: fp64 sum over the splits in a fixed order, one rounding, += into dW.
+// One (n, k) entry per 16 threads: the split axis is strided over them, then summed in lane order.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int splits, int N, int K, int cw, int out_kw,
                                                         float* __restrict__ dW, long ldw) {
+    __shared__ double sh[256];
     const long total = (long)N * K;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int sub = threadIdx.x & 15;
+    const long n_iter = (total + 15) / 16;          // every thread of a workgroup runs the same number of iterations
+    for (long it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const long i = it * 16 + (threadIdx.x >> 4);
         double s = 0.0;
-        for (int q = 0; q < splits; ++q) s += (double)partial[(long)q * total + i];
-        const int n = (int)(i / K), kc = (int)(i - (long)n * K);
-        const long off = out_kw > 0 ? (long)(kc % cw) * out_kw + kc / cw : (long)kc;
-        dW[(long)n * ldw + off] += (float)s;
+        if (i < total)
+            for (int q = sub; q < splits; q += 16) s += (double)partial[(long)q * total + i];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (sub == 0 && i < total) {
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += sh[threadIdx.x + q];
+            const int n = (int)(i / K), kc = (int)(i - (long)n * K);
+            const long off = out_kw > 0 ? (long)(kc % cw) * out_kw + kc / cw : (long)kc;
+            dW[(long)n * ldw + off] += (float)tot;
+        }
+        __syncthreads();
     }
 }
 
@@ -320,7 +386,7 @@ extern "C" int64_t tg_gemm_tn_ws_floats(int32_t M, int32_t N, int32_t K) {
 }
 
 extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,
-                          int32_t out_kw, float* ws, int64_t ws_floats, void* stream) {
+                          int32_t out_kw, float* dbias, float* ws, int64_t ws_floats, void* stream) {
     if (int e = check_window(A, "tg_gemm_tn")) return e;
     TG_REQUIRE(dY && dW && M > 0 && N > 0 && ldy >= N && ldw >= A->K, "tg_gemm_tn: bad arguments");
     TG_REQUIRE(out_kw == 0 || out_kw * A->cw == A->K, "tg_gemm_tn: out_kw=%d must be 0 or K/cw", out_kw);
@@ -329,11 +395,16 @@ extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, floa
     tn_plan(M, N, w.K, ws != nullptr, &splits, &rows_per_split);
     TG_REQUIRE(ws == nullptr || ws_floats >= (int64_t)splits * N * w.K, "tg_gemm_tn: workspace too small (%ld < %ld floats)",
                (long)ws_floats, (long)splits * N * w.K);
+    const int vec_y = (ldy % 4 == 0) && aligned16(dY);
+    const int vec_a = (w.cw % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr);
     dim3 grid(cdiv(N, 64), cdiv(w.K, 64), splits);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N, rows_per_split, out_kw, ws);
-    if (ws)
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(ew_grid((long)N * w.K, 256, 1)), dim3(256), 0, (hipStream_t)stream, ws, splits, N, w.K, w.cw,
-                           out_kw, dW, (long)ldw);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N, rows_per_split, out_kw,
+                       ws, dbias, vec_y, vec_a);
+    if (ws) {
+        int blocks = cdiv((long)N * w.K, 16);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, splits, N, w.K, w.cw, out_kw, dW, (long)ldw);
+    }
     return check_launch("tg_gemm_tn");
 }
 

@@ -1,21 +1,28 @@
 // Bidirectional GRU recurrence (nn.GRU semantics) on the f32 matrix cores.
 //
-// The recurrence is a chain of T dependent skinny GEMMs h_{t-1}[B,H] x W_hh^T[H,3H].  Each time step is ONE launch
-// that covers both directions, every batch tile and every 16-wide slice of hidden units; the launch boundary is the
-// grid-wide dependency (a kernel boundary costs ~1.5 us on MI355X, an in-kernel grid barrier 4-7 us), so there is no
-// spin-wait anywhere and nothing that can dead-lock.  A workgroup owns [32 batch rows] x [16 hidden units, all three
-// gates]: 8 waves = 2 row tiles x 4 K-slices, partial sums combined through LDS, then the gate maths is fused in the
-// epilogue (sigmoid/tanh, h' = (1-z) n + z h) and h_t goes straight into the layer output y, which doubles as the
-// state store.  Operands stream from L2 as 16-byte fragments (k-permuted MFMA feed, see gemm.hip).
+// Two regimes, both without any in-kernel inter-workgroup synchronisation (nothing can dead-lock):
+//
+//  * H = 300 (generator): the recurrent product h_{t-1}[B,H] x W_hh^T[H,3H] is too large for one CU's LDS + registers
+//    (W_hh fp32 = 1.08 MB per direction), so each time step is ONE launch covering both directions, every batch tile
+//    and every 16-wide slice of hidden units; the launch boundary (~1.5 us) is the grid-wide dependency, cheaper than
+//    an in-kernel grid barrier (4-7 us on 256 CUs).  A workgroup owns [32 batch rows] x [16 hidden units, all three
+//    gates]: 8 waves = 2 row tiles x 4 K-slices.  Every wave first issues the loads of its gate-epilogue operands and
+//    of ALL its K fragments (16-byte k-permuted MFMA feed, see gemm.hip), then runs its MFMAs, partial sums meet in LDS
+//    and all eight waves share the fused gate epilogue (sigmoid/tanh, h' = (1-z) n + z h), writing h_t straight into the
+//    layer output y, which doubles as the state store.
+//
+//  * H = 64 (discriminator): W_hh (48 KB per direction) lives in REGISTERS as MFMA B-fragments for the whole sequence;
+//    a workgroup owns 16 batch rows of one direction and walks all T steps in one launch, exchanging h_t between its
+//    four waves through 4 KB of LDS.  T x 4 layers x 6 passes of ~6 us launches become 24 launches of ~20 us.
 #include "common.hpp"
 
 namespace tg {
 
 constexpr int GRU_MT = 2;   // 16-row tiles per workgroup
 constexpr int GRU_KS = 4;   // K slices per workgroup
+constexpr int GRU_PF = 5;   // K fragments in flight per wave (covers H <= 320 in one batch of loads)
 constexpr int GRU_THREADS = 64 * GRU_MT * GRU_KS;
 
-// One MFMA operand fragment: 4 consecutive floats of a row, or zeros.
 __device__ __forceinline__ f32x4 ld4(const float* p, bool ok) {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return ok ? *reinterpret_cast<const f32x4*>(p) : z;
@@ -37,10 +44,22 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_step_kernel(
     const int r16 = lane & 15, kq = lane >> 4;
     const int j0 = blockIdx.x * 16, b0 = blockIdx.y * (GRU_MT * 16);
 
+    // gate epilogue ownership: wave (mt, ks) finalises accumulator row i = ks of m-tile mt.  Its operands do not
+    // depend on the product, so their loads go out first.
+    const int erow = b0 + mt * 16 + kq * 4 + ks;
+    const int ej = j0 + r16;
+    const bool e_ok = erow < B && ej < H;
+    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, hp = 0.f, bh_r = 0.f, bh_z = 0.f, bh_n = 0.f;
+    if (e_ok) {
+        const float* gip = gi + dir * gi_ds + ((long)erow * T + tau) * (3 * H);
+        gi_r = gip[ej]; gi_z = gip[H + ej]; gi_n = gip[2 * H + ej];
+        bh_r = bhh[ej]; bh_z = bhh[H + ej]; bh_n = bhh[2 * H + ej];
+        if (has_prev) hp = Y[((long)erow * T + tau_prev) * (2 * H) + dir * H + ej];
+    }
+
     f32x4 acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     if (has_prev) {
         const int b = b0 + mt * 16 + r16;
         const bool b_ok = b < B;
@@ -50,17 +69,25 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_step_kernel(
         const float* wrow[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) wrow[g] = whh + (long)(g * H + (j_ok ? j : 0)) * H;
-        for (int k0 = ks * 16; k0 < H; k0 += GRU_KS * 16) {
-            const int k = k0 + 4 * kq;
-            const bool inb = k < H;   // H % 4 == 0 (checked on the host)
-            const f32x4 a = ld4(hrow + k, b_ok && inb);
-            f32x4 w[3];
+        for (int kbase = ks * 16; kbase < H; kbase += GRU_KS * 16 * GRU_PF) {
+            f32x4 a[GRU_PF], w[3][GRU_PF];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) w[g] = ld4(wrow[g] + k, j_ok && inb);
+            for (int p = 0; p < GRU_PF; ++p) {
+                const int k = kbase + p * (GRU_KS * 16) + 4 * kq;
+                const bool inb = k < H;   // H % 4 == 0 (checked on the host)
+                a[p] = ld4(hrow + k, b_ok && inb);
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+                for (int g = 0; g < 3; ++g) w[g][p] = ld4(wrow[g] + k, j_ok && inb);
+            }
 #pragma unroll
-                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v], w[g][v], acc[g], 0, 0, 0);
+            for (int p = 0; p < GRU_PF; ++p) {
+                if (kbase + p * (GRU_KS * 16) < H) {      // wave-uniform
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][v], w[g][p][v], acc[g], 0, 0, 0);
+                }
+            }
         }
     }
 #pragma unroll
@@ -68,35 +95,24 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_step_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[ks][mt][g][i][lane] = acc[g][i];
     __syncthreads();
-    if (ks != 0) return;
-
-    const int j = j0 + r16;
-    if (j >= H) return;
-    const float bh_r = bhh[j], bh_z = bhh[H + j], bh_n = bhh[2 * H + j];
+    if (!e_ok) return;
+    float gh[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = b0 + mt * 16 + kq * 4 + i;
-        if (row >= B) continue;
-        float gh[3];
+    for (int g = 0; g < 3; ++g) {
+        float s = red[0][mt][g][ks][lane];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            float s = red[0][mt][g][i][lane];
-#pragma unroll
-            for (int q = 1; q < GRU_KS; ++q) s += red[q][mt][g][i][lane];
-            gh[g] = s;
-        }
-        const float* gip = gi + dir * gi_ds + ((long)row * T + tau) * (3 * H);
-        const float hp = has_prev ? Y[((long)row * T + tau_prev) * (2 * H) + dir * H + j] : 0.f;
-        const float hn = gh[2] + bh_n;
-        const float r = sigmoidf_(gip[j] + gh[0] + bh_r);
-        const float z = sigmoidf_(gip[H + j] + gh[1] + bh_z);
-        const float n = tanhf(gip[2 * H + j] + r * hn);
-        const float h = (1.f - z) * n + z * hp;
-        Y[((long)row * T + tau) * (2 * H) + dir * H + j] = h;
-        if (save) {
-            float* sp = save + dir * save_ds + ((long)row * T + tau) * (4 * H);
-            sp[j] = r; sp[H + j] = z; sp[2 * H + j] = n; sp[3 * H + j] = hn;
-        }
+        for (int q = 1; q < GRU_KS; ++q) s += red[q][mt][g][ks][lane];
+        gh[g] = s;
+    }
+    const float hn = gh[2] + bh_n;
+    const float r = sigmoidf_(gi_r + gh[0] + bh_r);
+    const float z = sigmoidf_(gi_z + gh[1] + bh_z);
+    const float n = tanhf(gi_n + r * hn);
+    const float h = (1.f - z) * n + z * hp;
+    Y[((long)erow * T + tau) * (2 * H) + dir * H + ej] = h;
+    if (save) {
+        float* sp = save + dir * save_ds + ((long)erow * T + tau) * (4 * H);
+        sp[ej] = r; sp[H + ej] = z; sp[2 * H + ej] = n; sp[3 * H + ej] = hn;
     }
 }
 
@@ -124,7 +140,25 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_step_kernel(
     const int j0 = blockIdx.x * 16, b0 = blockIdx.y * (GRU_MT * 16);
     const int H3 = 3 * H;
 
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // epilogue operands of accumulator row i = ks (independent of the product): issue their loads first
+    const int erow = b0 + mt * 16 + kq * 4 + ks;
+    const int ej = j0 + r16;
+    const bool e_ok = erow < B && ej < H;
+    float dy = 0.f, r = 0.f, z = 0.f, n = 0.f, hn = 0.f, hp = 0.f, z_next = 0.f, dh_next = 0.f;
+    float* dh_w = dhbuf + ((long)(step & 1) * 2 + dir) * (long)B * H;
+    const float* dh_r = dhbuf + ((long)((step & 1) ^ 1) * 2 + dir) * (long)B * H;
+    if (e_ok) {
+        dy = dY[((long)erow * T + tau) * (2 * H) + dir * H + ej];
+        const float* sp = save + dir * save_ds + ((long)erow * T + tau) * (4 * H);
+        r = sp[ej]; z = sp[H + ej]; n = sp[2 * H + ej]; hn = sp[3 * H + ej];
+        if (has_prev) hp = Y[((long)erow * T + tau_prev) * (2 * H) + dir * H + ej];
+        if (has_next) {
+            z_next = save[dir * save_ds + ((long)erow * T + tau_next) * (4 * H) + H + ej];
+            dh_next = dh_r[(long)erow * H + ej];
+        }
+    }
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (has_next) {
         const int b = b0 + mt * 16 + r16;
         const bool b_ok = b < B;
@@ -132,47 +166,204 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_step_kernel(
         const int j = j0 + r16;
         const bool j_ok = j < H;
         const float* wrow = wt + (long)(j_ok ? j : 0) * H3;
-        for (int k0 = ks * 16; k0 < H3; k0 += GRU_KS * 16) {
-            const int k = k0 + 4 * kq;
-            const bool inb = k < H3;
-            const f32x4 a = ld4(arow + k, b_ok && inb);
-            const f32x4 w = ld4(wrow + k, j_ok && inb);
+        for (int kbase = ks * 16; kbase < H3; kbase += GRU_KS * 16 * GRU_PF) {
+            f32x4 a[GRU_PF], w[GRU_PF];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v], w[v], acc, 0, 0, 0);
+            for (int p = 0; p < GRU_PF; ++p) {
+                const int k = kbase + p * (GRU_KS * 16) + 4 * kq;
+                const bool inb = k < H3;
+                a[p] = ld4(arow + k, b_ok && inb);
+                w[p] = ld4(wrow + k, j_ok && inb);
+            }
+#pragma unroll
+            for (int p = 0; p < GRU_PF; ++p) {
+                if (kbase + p * (GRU_KS * 16) < H3) {
+                    // two accumulators: the dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (40 cycles) exceeds
+                    // its issue interval (32)
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][0], w[p][0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][1], w[p][1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][2], w[p][2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][3], w[p][3], acc1, 0, 0, 0);
+                }
+            }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[ks][mt][i][lane] = acc[i];
+    for (int i = 0; i < 4; ++i) red[ks][mt][i][lane] = acc0[i] + acc1[i];
     __syncthreads();
-    if (ks != 0) return;
+    if (!e_ok) return;
+    float dh = dy;
+    if (has_next) {
+        float s = red[0][mt][ks][lane];
+#pragma unroll
+        for (int q = 1; q < GRU_KS; ++q) s += red[q][mt][ks][lane];
+        dh += s + dh_next * z_next;
+    }
+    const float dn = dh * (1.f - z) * (1.f - n * n);
+    const float dz = dh * (hp - n) * z * (1.f - z);
+    const float dr = dn * hn * r * (1.f - r);
+    float* gi_o = dgi + dir * dg_ds + ((long)erow * T + tau) * H3;
+    float* gh_o = dgh + dir * dg_ds + ((long)erow * T + tau) * H3;
+    gi_o[ej] = dr; gi_o[H + ej] = dz; gi_o[2 * H + ej] = dn;
+    gh_o[ej] = dr; gh_o[H + ej] = dz; gh_o[2 * H + ej] = dn * r;
+    dh_w[(long)erow * H + ej] = dh;
+}
 
-    const int j = j0 + r16;
-    if (j >= H) return;
-    float* dh_w = dhbuf + ((long)(step & 1) * 2 + dir) * (long)B * H;
-    const float* dh_r = dhbuf + ((long)((step & 1) ^ 1) * 2 + dir) * (long)B * H;
+// ---------------------------------------------------------------------------------------------- H = 64, persistent
+// One workgroup = 16 batch rows of one direction, 4 waves; wave w owns hidden units [16w, 16w+16) of all three gates
+// and keeps its 48 rows of W_hh as 12 float4 MFMA B-fragments in registers for the whole sequence.
+constexpr int HS = 64;
+constexpr int HS_LD = HS + 4;     // LDS row stride (floats): keeps float4 alignment, spreads banks
+
+__global__ __launch_bounds__(256) void gru_seq_fwd_h64_kernel(
+    const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
+    const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save,
+    long save_ds, int B, int T) {
+    __shared__ __attribute__((aligned(16))) float hs[16][HS_LD];
+    const int dir = blockIdx.y;
+    const float* whh = dir ? whh1 : whh0;
+    const float* bhh = dir ? bhh1 : bhh0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int j = wave * 16 + r16;                 // hidden unit of this lane's accumulator column
+    const int b0 = blockIdx.x * 16;
+
+    f32x4 wf[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wf[g][u] = *reinterpret_cast<const f32x4*>(whh + (long)(g * HS + j) * HS + 16 * u + 4 * kq);
+    const float bh_r = bhh[j], bh_z = bhh[HS + j], bh_n = bhh[2 * HS + j];
+    float hp[4] = {0.f, 0.f, 0.f, 0.f};
+    bool row_ok[4];
+    long row_base[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = b0 + mt * 16 + kq * 4 + i;
-        if (row >= B) continue;
-        float dh = dY[((long)row * T + tau) * (2 * H) + dir * H + j];
-        if (has_next) {
-            float s = red[0][mt][i][lane];
+        const int row = b0 + kq * 4 + i;
+        row_ok[i] = row < B;
+        row_base[i] = (long)(row_ok[i] ? row : 0) * T;
+    }
+    for (int e = threadIdx.x; e < 16 * HS_LD; e += 256) (&hs[0][0])[e] = 0.f;
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int tau = dir ? T - 1 - step : step;
+        float g_r[4], g_z[4], g_n[4];
 #pragma unroll
-            for (int q = 1; q < GRU_KS; ++q) s += red[q][mt][i][lane];
-            const float z_next = save[dir * save_ds + ((long)row * T + tau_next) * (4 * H) + H + j];
-            dh += s + dh_r[(long)row * H + j] * z_next;
+        for (int i = 0; i < 4; ++i) {               // independent of the recurrence: in flight during the MFMAs
+            const float* gip = gi + dir * gi_ds + (row_base[i] + tau) * (3 * HS);
+            g_r[i] = row_ok[i] ? gip[j] : 0.f;
+            g_z[i] = row_ok[i] ? gip[HS + j] : 0.f;
+            g_n[i] = row_ok[i] ? gip[2 * HS + j] : 0.f;
         }
-        const float* sp = save + dir * save_ds + ((long)row * T + tau) * (4 * H);
-        const float r = sp[j], z = sp[H + j], n = sp[2 * H + j], hn = sp[3 * H + j];
-        const float hp = has_prev ? Y[((long)row * T + tau_prev) * (2 * H) + dir * H + j] : 0.f;
-        const float dn = dh * (1.f - z) * (1.f - n * n);
-        const float dz = dh * (hp - n) * z * (1.f - z);
-        const float dr = dn * hn * r * (1.f - r);
-        float* gi_o = dgi + dir * dg_ds + ((long)row * T + tau) * H3;
-        float* gh_o = dgh + dir * dg_ds + ((long)row * T + tau) * H3;
-        gi_o[j] = dr; gi_o[H + j] = dz; gi_o[2 * H + j] = dn;
-        gh_o[j] = dr; gh_o[H + j] = dz; gh_o[2 * H + j] = dn * r;
-        dh_w[(long)row * H + j] = dh;
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&hs[r16][16 * u + 4 * kq]);
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v], wf[g][u][v], acc[g], 0, 0, 0);
+            }
+        }
+        __syncthreads();                            // every wave has read h_{t-1}
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float hn = acc[2][i] + bh_n;
+            const float r = sigmoidf_(g_r[i] + acc[0][i] + bh_r);
+            const float z = sigmoidf_(g_z[i] + acc[1][i] + bh_z);
+            const float n = tanhf(g_n[i] + r * hn);
+            const float h = (1.f - z) * n + z * hp[i];
+            hp[i] = h;
+            hs[kq * 4 + i][j] = h;
+            if (row_ok[i]) {
+                Y[(row_base[i] + tau) * (2 * HS) + dir * HS + j] = h;
+                if (save) {
+                    float* sp = save + dir * save_ds + (row_base[i] + tau) * (4 * HS);
+                    sp[j] = r; sp[HS + j] = z; sp[2 * HS + j] = n; sp[3 * HS + j] = hn;
+                }
+            }
+        }
+        __syncthreads();                            // h_t complete in LDS
+    }
+}
+
+// Backward through time, same ownership; W_hh^T rows [16w, 16w+16) x 192 live in registers as 12 float4 fragments;
+// the gate gradients of the step just processed sit in LDS (16 x 192) as the next step's MFMA A operand.
+constexpr int DG_LD = 3 * HS + 4;
+
+__global__ __launch_bounds__(256) void gru_seq_bwd_h64_kernel(
+    const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ save, long save_ds,
+    const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh, long dg_ds,
+    int B, int T) {
+    __shared__ __attribute__((aligned(16))) float dgs[16][DG_LD];
+    const int dir = blockIdx.y;
+    const float* wt = dir ? wt1 : wt0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int j = wave * 16 + r16;
+    const int b0 = blockIdx.x * 16;
+
+    f32x4 wf[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) wf[u] = *reinterpret_cast<const f32x4*>(wt + (long)j * (3 * HS) + 16 * u + 4 * kq);
+    bool row_ok[4];
+    long row_base[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = b0 + kq * 4 + i;
+        row_ok[i] = row < B;
+        row_base[i] = (long)(row_ok[i] ? row : 0) * T;
+    }
+    float dh_c[4] = {0.f, 0.f, 0.f, 0.f}, z_c[4] = {0.f, 0.f, 0.f, 0.f};   // dh and z of the step processed before
+    for (int e = threadIdx.x; e < 16 * DG_LD; e += 256) (&dgs[0][0])[e] = 0.f;
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int tau = dir ? step : T - 1 - step;
+        const int tau_prev = dir ? tau + 1 : tau - 1;
+        const bool has_prev = dir ? (tau < T - 1) : (tau > 0);
+        float dy[4], r[4], z[4], n[4], hn[4], hp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = row_ok[i];
+            const float* sp = save + dir * save_ds + (row_base[i] + tau) * (4 * HS);
+            dy[i] = ok ? dY[(row_base[i] + tau) * (2 * HS) + dir * HS + j] : 0.f;
+            r[i] = ok ? sp[j] : 0.f; z[i] = ok ? sp[HS + j] : 0.f; n[i] = ok ? sp[2 * HS + j] : 0.f; hn[i] = ok ? sp[3 * HS + j] : 0.f;
+            hp[i] = (ok && has_prev) ? Y[(row_base[i] + tau_prev) * (2 * HS) + dir * HS + j] : 0.f;
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&dgs[r16][16 * u + 4 * kq]);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], wf[u][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], wf[u][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], wf[u][2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], wf[u][3], acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();                            // every wave has read the previous step's gate gradients
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dh = dy[i] + (step > 0 ? acc0[i] + acc1[i] + dh_c[i] * z_c[i] : 0.f);
+            const float dn = dh * (1.f - z[i]) * (1.f - n[i] * n[i]);
+            const float dz = dh * (hp[i] - n[i]) * z[i] * (1.f - z[i]);
+            const float dr = dn * hn[i] * r[i] * (1.f - r[i]);
+            dh_c[i] = dh; z_c[i] = z[i];
+            float* row = dgs[kq * 4 + i];
+            row[j] = dr; row[HS + j] = dz; row[2 * HS + j] = dn * r[i];
+            if (row_ok[i]) {
+                float* gi_o = dgi + dir * dg_ds + (row_base[i] + tau) * (3 * HS);
+                float* gh_o = dgh + dir * dg_ds + (row_base[i] + tau) * (3 * HS);
+                gi_o[j] = dr; gi_o[HS + j] = dz; gi_o[2 * HS + j] = dn;
+                gh_o[j] = dr; gh_o[HS + j] = dz; gh_o[2 * HS + j] = dn * r[i];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -186,9 +377,15 @@ extern "C" int tg_gru_forward(const float* gi, int64_t gi_dir_stride, const floa
     TG_REQUIRE(gi && w_hh_fwd && w_hh_rev && b_hh_fwd && b_hh_rev && y, "tg_gru_forward: null pointer");
     TG_REQUIRE(B > 0 && T > 0 && H > 0 && H % 4 == 0, "tg_gru_forward: need H %% 4 == 0 (H=%d)", H);
     TG_REQUIRE(aligned16(w_hh_fwd) && aligned16(w_hh_rev) && aligned16(y), "tg_gru_forward: w_hh / y must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (H == HS) {
+        hipLaunchKernelGGL(gru_seq_fwd_h64_kernel, dim3(cdiv(B, 16), 2), dim3(256), 0, s, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev,
+                           b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, B, T);
+        return check_launch("tg_gru_forward(h64)");
+    }
     dim3 grid(cdiv(H, 16), cdiv(B, GRU_MT * 16), 2);
     for (int step = 0; step < T; ++step)
-        hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(GRU_THREADS), 0, (hipStream_t)stream, gi, (long)gi_dir_stride, w_hh_fwd,
+        hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(GRU_THREADS), 0, s, gi, (long)gi_dir_stride, w_hh_fwd,
                            w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, B, T, H, step);
     return check_launch("tg_gru_forward");
 }
@@ -200,9 +397,15 @@ extern "C" int tg_gru_backward(const float* dy, const float* y, const float* sav
     TG_REQUIRE(B > 0 && T > 0 && H > 0 && H % 4 == 0, "tg_gru_backward: need H %% 4 == 0 (H=%d)", H);
     TG_REQUIRE(aligned16(w_hh_t_fwd) && aligned16(w_hh_t_rev) && aligned16(dgh) && (dg_dir_stride % 4 == 0),
                "tg_gru_backward: w_hh_t / dgh must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (H == HS) {
+        hipLaunchKernelGGL(gru_seq_bwd_h64_kernel, dim3(cdiv(B, 16), 2), dim3(256), 0, s, dy, y, save, (long)save_dir_stride, w_hh_t_fwd,
+                           w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T);
+        return check_launch("tg_gru_backward(h64)");
+    }
     dim3 grid(cdiv(H, 16), cdiv(B, GRU_MT * 16), 2);
     for (int step = 0; step < T; ++step)
-        hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(GRU_THREADS), 0, (hipStream_t)stream, dy, y, save, (long)save_dir_stride,
+        hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(GRU_THREADS), 0, s, dy, y, save, (long)save_dir_stride,
                            w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, dh_scratch, B, T, H, step);
     return check_launch("tg_gru_backward");
 }

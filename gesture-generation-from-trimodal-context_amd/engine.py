@@ -227,8 +227,7 @@ class GeneratorEngine(_Engine):
                 xin = blk[f"in{ci}"][rows]
                 v = P[pre + ".weight_v"]
                 dwp = torch.zeros(v.shape[0], 2 * v.shape[1], device=v.device, dtype=v.dtype)
-                ops.gemm_tn(dc, Win.conv(xin, 2, pad=d, dil=d, rows_out=T), dwp)
-                ops.colsum(dc, G[pre + ".bias"])
+                ops.gemm_tn(dc, Win.conv(xin, 2, pad=d, dil=d, rows_out=T), dwp, dbias=G[pre + ".bias"])
                 ops.weight_norm_bwd(dwp, v, P[pre + ".weight_g"], G[pre + ".weight_g"], G[pre + ".weight_v"])
                 # dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0]  -> taps (t + d, t) with B = wp^T per tap
                 wT = L.empty(xin.shape[2], 2 * v.shape[0], like=v)

@@ -42,8 +42,8 @@ def linear_fwd(x2d, W, b, out=None, act_slope=1.0):
 def linear_bwd(dy2d, x2d, W, dW, db, need_dx=True, dx_out=None, accumulate_dx=False):
     """dW += dy^T x ; db += colsum(dy) ; dx = dy @ W (optional)."""
     if dW is not None:
-        ops.gemm_tn(dy2d, Win.plain(x2d), dW)
-    if db is not None:
+        ops.gemm_tn(dy2d, Win.plain(x2d), dW, dbias=db)
+    elif db is not None:
         ops.colsum(dy2d, db, accumulate=True)
     if not need_dx:
         return None
@@ -77,8 +77,8 @@ def conv_wgrad(dy, x, dW, db, kw, *, stride=1, pad=0, dil=1):
     A = Win.conv(x, kw, stride=stride, pad=pad, dil=dil, rows_out=Lo)
     dy2 = dy.reshape(B * Lo, Co)
     if dW is not None:
-        ops.gemm_tn(dy2, A, dW.view(Co, -1), out_kw=kw if (kw > 1 and x.shape[2] > 1) else 0)
-    if db is not None:
+        ops.gemm_tn(dy2, A, dW.view(Co, -1), out_kw=kw, dbias=db)
+    elif db is not None:
         ops.colsum(dy2, db, accumulate=True)
 
 
@@ -233,12 +233,11 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
         for d, sfx in enumerate(("", "_reverse")):
             gi2, gh2 = dgi[d].view(nb * T, 3 * H), dgh[d].view(nb * T, 3 * H)
             if param_grads:
-                ops.gemm_tn(gi2, Win.plain(x_l.reshape(nb * T, Kin)), G[f"{prefix}.weight_ih_l{l}{sfx}"])
-                ops.colsum(gi2, G[f"{prefix}.bias_ih_l{l}{sfx}"])
+                ops.gemm_tn(gi2, Win.plain(x_l.reshape(nb * T, Kin)), G[f"{prefix}.weight_ih_l{l}{sfx}"],
+                            dbias=G[f"{prefix}.bias_ih_l{l}{sfx}"])
                 # h_{t-1} of direction d is the layer output one step back (forward) / ahead (reverse), zero at the ends
                 hwin = Win.taps(y_l[:, :, d * H:(d + 1) * H], 1, shift=(1 if d else -1), dil=1, rows_out=T)
-                ops.gemm_tn(gh2, hwin, G[f"{prefix}.weight_hh_l{l}{sfx}"])
-                ops.colsum(gh2, G[f"{prefix}.bias_hh_l{l}{sfx}"])
+                ops.gemm_tn(gh2, hwin, G[f"{prefix}.weight_hh_l{l}{sfx}"], dbias=G[f"{prefix}.bias_hh_l{l}{sfx}"])
             if need_dx or l > 0:
                 if dx is None:
                     dx = empty(nb * T, Kin, like=dy)

@@ -102,17 +102,25 @@ def gemm_nt(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_st
     return out
 
 
-def gemm_tn(dY, A: Win, dW, *, out_kw=0):
-    """dW[n, perm(k)] += sum_m dY[m, n] * A(m, k).  dY: 2-D view [M, N]; dW: contiguous, N rows of K floats."""
+TN_TWO_PASS_ROWS = 32768     # reductions at least this long combine their partials in fp64 (deterministic) instead of atomics
+
+
+def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
+    """dW[n, perm(k)] += sum_m dY[m, n] * A(m, k); dbias[n] += sum_m dY[m, n] when given.
+    dY: 2-D view [M, N]; dW: contiguous, N rows of K floats."""
     _f32(dY, "dY"); _f32(dW, "dW")
     assert dY.dim() == 2 and dY.stride(1) == 1 and dY.shape[0] == A.M, (dY.shape, A.M)
     M, N = dY.shape
     assert dW.is_contiguous() and dW.numel() == N * A.K and dW.shape[0] == N, (dW.shape, N, A.K)
+    if dbias is not None:
+        _flat(dbias, "dbias"); assert dbias.numel() == N
     if (M - 1) * dY.stride(0) + N - 1 >= _room(dY):
         raise ValueError("gemm_tn: dY exceeds its tensor")
-    nws = _lib.load().tg_gemm_tn_ws_floats(M, N, A.K)      # deterministic fp64 cross-split combine (no atomics)
-    ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
-    call("tg_gemm_tn", _p(dY), dY.stride(0), C.byref(A.s), _p(dW), A.K, M, N, int(out_kw), _p(ws), nws, _stream())
+    ws, nws = None, 0
+    if M >= TN_TWO_PASS_ROWS:
+        nws = _lib.load().tg_gemm_tn_ws_floats(M, N, A.K)
+        ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
+    call("tg_gemm_tn", _p(dY), dY.stride(0), C.byref(A.s), _p(dW), A.K, M, N, int(out_kw), _p(dbias), _p(ws), nws, _stream())
     return dW
 
 

@@ -72,8 +72,9 @@ int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bi
  *   combined in split order in fp64 -- bitwise reproducible, and accurate for the ~1e6-row sums of the audio encoder.
  *   Replaces the weight-gradient half of aten::convolution_backward / addmm backward for the same call sites. */
 int64_t tg_gemm_tn_ws_floats(int32_t M, int32_t N, int32_t K);
+/*   dbias != NULL: also dbias[n] += sum_m dY[m*ldy + n] (the bias gradient rides along; no separate pass over dY). */
 int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,
-               int32_t out_kw, float* ws, int64_t ws_floats, void* stream);
+               int32_t out_kw, float* dbias, float* ws, int64_t ws_floats, void* stream);
 
 /* tg_colsum (bias gradient): out[n] (+)= sum_m X[m*ldx + n]. */
 int tg_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream);
@@ -83,7 +84,8 @@ int tg_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, int
  * y    : [B][T][2H]    layer output; direction d writes columns [d*H, (d+1)*H); also the recurrent state store
  * save : [2][B][T][4H] r, z, n, (W_hn h + b_hn) per step for the backward pass, or NULL (inference / no-grad)
  * Gate order and maths are PyTorch's: r,z = sigmoid, n = tanh(gi_n + r*(W_hn h + b_hn)), h' = (1-z) n + z h.
- * One launch per time step (both directions, all batch rows); the launch boundary is the grid-wide dependency. */
+ * H != 64: one launch per time step (both directions, all batch rows); the launch boundary is the grid-wide dependency.
+ * H == 64: one persistent launch for the whole sequence (W_hh held in registers as MFMA fragments). */
 int tg_gru_forward(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
                    const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
                    int32_t B, int32_t T, int32_t H, void* stream);
