@@ -56,6 +56,16 @@ inline Win to_win(const tg_window* w) {
     return d;
 }
 
+// XCD-aware workgroup order.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with a private
+// 4 MB L2), so neighbours in id space -- which here share a weight slice or an activation panel -- land on eight
+// different L2s and every one of them re-fetches the shared operand from Infinity Cache / HBM.  This bijection hands each
+// XCD one CONTIGUOUS chunk of the logical id space instead (guide T1, non-divisible-safe form).  Speed only: any
+// placement gives the same results.
+__device__ __forceinline__ int xcd_chunked_id(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+}
+
 __device__ __forceinline__ float act_fn(float x, float slope) { return x >= 0.f ? x : x * slope; }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 

@@ -56,13 +56,15 @@ __device__ __forceinline__ void load_nt_frags(const Win& A, const long (&a_off)[
 template <bool VEC, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(Win A, const float* __restrict__ Bw, long ldb,
                                                       const float* __restrict__ bias, float* __restrict__ C, long cbs,
-                                                      long crs, int cR, int M, int N, float slope, int accumulate) {
+                                                      long crs, int cR, int M, int N, float slope, int accumulate, int n_nt) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int m_base = blockIdx.x * (WM * 32) + wm * 32;
-    const int n_base = blockIdx.y * (WN * 32) + wn * 32;
+    // logical order: output-column tile fastest -> the workgroups that re-read one A row panel sit on ONE XCD's L2
+    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int m_base = (lid / n_nt) * (WM * 32) + wm * 32;
+    const int n_base = (lid % n_nt) * (WN * 32) + wn * 32;
     if (m_base >= M || n_base >= N) return;   // no LDS, no barriers: a whole wave may leave
     const int K = A.K;
 
@@ -159,16 +161,20 @@ constexpr int TN_LD = 68;
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, long ldy, Win A, float* __restrict__ dW,
                                                       long ldw, int M, int N, int rows_per_split, int out_kw,
-                                                      float* __restrict__ partial, float* __restrict__ dbias, int vec_y, int vec_a) {
+                                                      float* __restrict__ partial, float* __restrict__ dbias, int vec_y, int vec_a,
+                                                      int n_nt, int n_kt) {
     __shared__ __attribute__((aligned(16))) float ys[2][16][TN_LD];
     __shared__ __attribute__((aligned(16))) float xs[2][16][TN_LD];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int r16 = lane & 15, mq = lane >> 4;
     const int wn = wave >> 1, wk = wave & 1;
-    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    // logical order: (n tile, k tile) fastest, split slowest -> the tiles that re-read one chunk of rows share an XCD
+    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int tn_n = lid % n_nt, tn_k = (lid / n_nt) % n_kt, tn_s = lid / (n_nt * n_kt);
+    const int n0 = tn_n * 64, k0 = tn_k * 64;
     const int K = A.K;
-    const int m_begin = blockIdx.z * rows_per_split;
+    const int m_begin = tn_s * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
 
     // staging role of this thread: row (t>>4) of the 16-row tile, 4 consecutive columns starting at 4*(t&15)
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         mr = m - mb * A.rows_out;
     }
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    const bool want_bias = dbias != nullptr && blockIdx.y == 0;
+    const bool want_bias = dbias != nullptr && tn_k == 0;
 
     auto fetch = [&](int m0, f32x4& yv, f32x4& xv) {
         const int m = m0 + srow;
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 const int n = n0 + wn * 32 + nt * 16 + mq * 4 + i;
                 const int kc = k0 + wk * 32 + kt * 16 + r16;
                 if (n < N && kc < K && partial) {
-                    partial[((long)blockIdx.z * N + n) * K + kc] = acc[nt][kt][i];     // combined in fp64 by tn_reduce_kernel
+                    partial[((long)tn_s * N + n) * K + kc] = acc[nt][kt][i];     // combined in fp64 by tn_reduce_kernel
                 } else if (n < N && kc < K) {
                     // out_kw > 0: k = (tap, channel) is stored channel-major, tap-minor: the (Co, Ci, kw) layout of
                     // nn.Conv1d / ConvTranspose1d weights, so conv weight gradients need no separate permute pass
@@ -351,13 +357,15 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
                      (ldb % 4 == 0) && aligned16(Bw);
     hipStream_t s = (hipStream_t)stream;
     if (N <= 32) {
-        dim3 grid(cdiv(M, 128), cdiv(N, 32));
-        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate);
-        else     hipLaunchKernelGGL((gemm_nt_kernel<false, 4, 1>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate);
+        const int n_nt = cdiv(N, 32);
+        dim3 grid(cdiv(M, 128) * n_nt);
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
+        else     hipLaunchKernelGGL((gemm_nt_kernel<false, 4, 1>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
     } else {
-        dim3 grid(cdiv(M, 64), cdiv(N, 64));
-        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 2, 2>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate);
-        else     hipLaunchKernelGGL((gemm_nt_kernel<false, 2, 2>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate);
+        const int n_nt = cdiv(N, 64);
+        dim3 grid(cdiv(M, 64) * n_nt);
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 2, 2>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
+        else     hipLaunchKernelGGL((gemm_nt_kernel<false, 2, 2>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
     }
     return check_launch("tg_gemm_nt");
 }
@@ -397,9 +405,10 @@ extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, floa
                (long)ws_floats, (long)splits * N * w.K);
     const int vec_y = (ldy % 4 == 0) && aligned16(dY);
     const int vec_a = (w.cw % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr);
-    dim3 grid(cdiv(N, 64), cdiv(w.K, 64), splits);
+    const int n_nt = cdiv(N, 64), n_kt = cdiv(w.K, 64);
+    dim3 grid(n_nt * n_kt * splits);
     hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N, rows_per_split, out_kw,
-                       ws, dbias, vec_y, vec_a);
+                       ws, dbias, vec_y, vec_a, n_nt, n_kt);
     if (ws) {
         int blocks = cdiv((long)N * w.K, 16);
         if (blocks > 4096) blocks = 4096;

@@ -31,9 +31,13 @@ __device__ __forceinline__ f32x4 ld4(const float* p, bool ok) {
 __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_step_kernel(
     const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save,
-    long save_ds, int B, int T, int H, int step) {
+    long save_ds, int B, int T, int H, int step, int n_jt, int n_bt) {
     __shared__ float red[GRU_KS][GRU_MT][3][4][64];
-    const int dir = blockIdx.z;
+    // logical order: batch tile fastest, then hidden-unit slice, then direction -> an XCD's chunk holds few W_hh slices
+    // (57.6 KB each) for ALL batch tiles, and one direction's h_{t-1}
+    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int bt = lid % n_bt, jt = (lid / n_bt) % n_jt;
+    const int dir = lid / (n_bt * n_jt);
     const int tau = dir ? T - 1 - step : step;
     const int tau_prev = dir ? tau + 1 : tau - 1;
     const bool has_prev = step > 0;
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_step_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mt = wave % GRU_MT, ks = wave / GRU_MT;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * (GRU_MT * 16);
+    const int j0 = jt * 16, b0 = bt * (GRU_MT * 16);
 
     // gate epilogue ownership: wave (mt, ks) finalises accumulator row i = ks of m-tile mt.  Its operands do not
     // depend on the product, so their loads go out first.
@@ -125,9 +129,11 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_step_kernel(
 __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_step_kernel(
     const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ save, long save_ds,
     const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh, long dg_ds,
-    float* __restrict__ dhbuf, int B, int T, int H, int step) {
+    float* __restrict__ dhbuf, int B, int T, int H, int step, int n_jt, int n_bt) {
     __shared__ float red[GRU_KS][GRU_MT][4][64];
-    const int dir = blockIdx.z;
+    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int bt = lid % n_bt, jt = (lid / n_bt) % n_jt;
+    const int dir = lid / (n_bt * n_jt);
     const int tau = dir ? step : T - 1 - step;
     const int tau_next = dir ? tau - 1 : tau + 1;   // consumer of h_tau in forward order
     const int tau_prev = dir ? tau + 1 : tau - 1;   // producer of h_prev for this cell
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_step_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mt = wave % GRU_MT, ks = wave / GRU_MT;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * (GRU_MT * 16);
+    const int j0 = jt * 16, b0 = bt * (GRU_MT * 16);
     const int H3 = 3 * H;
 
     // epilogue operands of accumulator row i = ks (independent of the product): issue their loads first
@@ -383,10 +389,11 @@ extern "C" int tg_gru_forward(const float* gi, int64_t gi_dir_stride, const floa
                            b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, B, T);
         return check_launch("tg_gru_forward(h64)");
     }
-    dim3 grid(cdiv(H, 16), cdiv(B, GRU_MT * 16), 2);
+    const int n_jt = cdiv(H, 16), n_bt = cdiv(B, GRU_MT * 16);
+    dim3 grid(n_jt * n_bt * 2);
     for (int step = 0; step < T; ++step)
         hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(GRU_THREADS), 0, s, gi, (long)gi_dir_stride, w_hh_fwd,
-                           w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, B, T, H, step);
+                           w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, B, T, H, step, n_jt, n_bt);
     return check_launch("tg_gru_forward");
 }
 
@@ -403,9 +410,10 @@ extern "C" int tg_gru_backward(const float* dy, const float* y, const float* sav
                            w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T);
         return check_launch("tg_gru_backward(h64)");
     }
-    dim3 grid(cdiv(H, 16), cdiv(B, GRU_MT * 16), 2);
+    const int n_jt = cdiv(H, 16), n_bt = cdiv(B, GRU_MT * 16);
+    dim3 grid(n_jt * n_bt * 2);
     for (int step = 0; step < T; ++step)
         hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(GRU_THREADS), 0, s, dy, y, save, (long)save_dir_stride,
-                           w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, dh_scratch, B, T, H, step);
+                           w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, dh_scratch, B, T, H, step, n_jt, n_bt);
     return check_launch("tg_gru_backward");
 }
