@@ -152,6 +152,128 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Win A, const float* __rest
     }
 }
 
+// Large-tile path of tg_gemm_nt for the big products of the step (GRU input projections, TCN convs, their input
+// gradients): workgroup tile 128 x (32*TN), 4 waves as 2 x 2, each wave 64 x (16*TN) = 4 x TN MFMA tiles, so every
+// operand fragment read from LDS feeds 4 (B) or TN (A) MFMAs instead of 2.  16-deep K slabs of A and B are staged through
+// LDS with coalesced 16-byte global loads ([row][16 k] rows padded to 20 floats: the k-permuted 16-byte fragment reads
+// stay 16-byte aligned and spread over the banks), double-buffered: the next slab's global loads are in flight while
+// the current slab's 16*TN MFMAs per wave run.  Needs the vectorisable layout (cw % 4 == 0 etc., checked on the host).
+constexpr int BG_LD = 20;
+
+template <int TN>
+__global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __restrict__ Bw, long ldb,
+                                                          const float* __restrict__ bias, float* __restrict__ C, long cbs,
+                                                          long crs, int cR, int M, int N, float slope, int accumulate, int n_nt) {
+    constexpr int BN = 32 * TN;                       // workgroup tile width
+    constexpr int BROWS = BN / 64;                    // B rows staged per thread (1 or 2)
+    __shared__ __attribute__((aligned(16))) float as[2][128][BG_LD];
+    __shared__ __attribute__((aligned(16))) float bs[2][BN][BG_LD];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int m0 = (lid / n_nt) * 128, n0 = (lid % n_nt) * BN;
+    const int K = A.K;
+
+    // staging role: row (t >> 2) [+64], 16-byte piece (t & 3) of the 16-deep slab
+    const int srow = t >> 2, sk = 4 * (t & 3);
+    long a_off[2];
+    int a_r[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + srow + 64 * i;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        const int b = mm / A.rows_out;
+        const int r = mm - b * A.rows_out;
+        a_off[i] = (long)b * A.bs;
+        a_r[i] = r * A.step + A.shift;
+    }
+    const float* b_ptr[BROWS];
+    bool b_ok[BROWS];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+        const int n = n0 + srow + 64 * i;
+        b_ok[i] = n < N;
+        b_ptr[i] = Bw + (long)(b_ok[i] ? n : 0) * ldb;
+    }
+    int kk = sk / A.cw, c = sk - (sk / A.cw) * A.cw;   // tap / channel of this thread's piece, advanced by 16 per slab
+
+    f32x4 ga[2], gb[BROWS];
+    auto fetch = [&](int k0) {
+        const int k = k0 + sk;
+        const bool inb = k < K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sr = a_r[i] + kk * A.dil;
+            const bool ok = a_ok[i] && inb && sr >= 0 && sr < A.rows_in;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ga[i] = ok ? *reinterpret_cast<const f32x4*>(A.ptr + a_off[i] + (long)sr * A.rs + c) : z;
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            gb[i] = (b_ok[i] && inb) ? *reinterpret_cast<const f32x4*>(b_ptr[i] + k) : z;
+        }
+        c += 16;
+        while (c >= A.cw) { c -= A.cw; ++kk; }
+    };
+
+    f32x4 acc[4][TN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&as[buf][srow + 64 * i][sk]) = ga[i];
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<f32x4*>(&bs[buf][srow + 64 * i][sk]) = gb[i];
+        __syncthreads();
+        if (k0 + 16 < K) fetch(k0 + 16);
+        f32x4 fa[4], fb[TN];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&as[buf][wm * 64 + i * 16 + r16][4 * kq]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&bs[buf][wn * (16 * TN) + j * 16 + r16][4 * kq]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][v], fb[j][v], acc[i][j], 0, 0, 0);
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = m0 + wm * 64 + i * 16 + kq * 4 + q;
+            if (row >= M) continue;
+            const int cb = row / cR;
+            const int cr = row - cb * cR;
+            float* crow = C + (long)cb * cbs + (long)cr * crs;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (16 * TN) + j * 16 + r16;
+                if (col >= N) continue;
+                float v = acc[i][j][q];
+                if (bias) v += bias[col];
+                v = act_fn(v, slope);
+                if (accumulate) v += crow[col];
+                crow[col] = v;
+            }
+        }
+    }
+}
+
 // dW[n][k] += sum_m dY[m][n] * A(m,k)  (and dbias[n] += sum_m dY[m][n] when asked).
 // Workgroup = 4 waves as 2 (n) x 2 (k), each 32x32 of dW, i.e. a 64 x 64 tile of dW per workgroup; the m range is split
 // over blockIdx.z.  Per 16-row tile every thread fetches one 16-byte piece of dY and one of A (coalesced rows), the
@@ -356,7 +478,19 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
     const bool vec = (w.cw % 4 == 0) && (w.K % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr) &&
                      (ldb % 4 == 0) && aligned16(Bw);
     hipStream_t s = (hipStream_t)stream;
-    if (N <= 32) {
+    if (vec && N >= 96 && M >= 1024 && w.K >= 64) {
+        // big products: 128-row tiles; 128 columns per tile unless that leaves the last column tile mostly empty or
+        // too few workgroups to fill 256 CUs, then 64
+        const int waste128 = cdiv(N, 128) * 128 - N, waste64 = cdiv(N, 64) * 64 - N;
+        const bool wide = (waste128 <= waste64 + 32) && ((long)cdiv(M, 128) * cdiv(N, 128) >= 384);
+        if (wide) {
+            const int n_nt = cdiv(N, 128);
+            hipLaunchKernelGGL((gemm_nt_big_kernel<4>), dim3(cdiv(M, 128) * n_nt), dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
+        } else {
+            const int n_nt = cdiv(N, 64);
+            hipLaunchKernelGGL((gemm_nt_big_kernel<2>), dim3(cdiv(M, 128) * n_nt), dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
+        }
+    } else if (N <= 32) {
         const int n_nt = cdiv(N, 32);
         dim3 grid(cdiv(M, 128) * n_nt);
         if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);

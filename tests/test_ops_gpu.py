@@ -312,3 +312,22 @@ def test_reparam_losses_adam_vs_oracle(pkg, dev):
         ops.counter_inc(step)
         ops.adam_step(pg, g.float().to(dev), mg, vg, 5e-4, 0.5, 0.999, 1e-8, step)
     assert rel(pg, p["w"]) < 1e-6 and int(step) == 3
+
+
+def test_gemm_nt_big_tile_path_with_conv_window(pkg, dev):
+    """Large-tile kernel (M >= 1024, N >= 96): dilated causal conv window, strided output slice, bias + ReLU, accumulate."""
+    Lm = pkg.layers
+    B, T, Cc, d = 40, 34, 300, 2
+    x = rnd(B, Cc, T, seed=70).double()
+    w = rnd(Cc, Cc, 2, seed=71, scale=0.05).double()
+    b = rnd(Cc, seed=72).double()
+    y = torch.relu(F.conv1d(x, w, b, padding=d, dilation=d)[:, :, :T])
+    out = Lm.conv_fwd(cl(x.float()).to(dev), Lm.pack_conv_weight(w.float().to(dev)), b.float().to(dev), 2, pad=d, dil=d, rows_out=T,
+                      act_slope=0.0)
+    assert rel(out, cl(y)) < 1e-5
+    M, N, K = 2000, 130, 600
+    xa, wa = rnd(M, K, seed=73), rnd(N, K, seed=74, scale=0.1)
+    big = torch.zeros(M, 200, device=dev)
+    pkg.ops.gemm_nt(pkg.ops.Win.plain(xa.to(dev)), wa.to(dev), None, big[:, 30:160])
+    pkg.ops.gemm_nt(pkg.ops.Win.plain(xa.to(dev)), wa.to(dev), None, big[:, 30:160], accumulate=True)
+    assert rel(big[:, 30:160], 2 * (xa.double() @ wa.double().t())) < 1e-5 and float(big[:, :30].abs().max()) == 0
