@@ -1,0 +1,112 @@
+"""Data-parallel gradient exchange on CPU: world_size 2, gloo backend.  Covers ddp.GradSync (bucket ranges in backward
+order, asynchronous launch + wait, mean semantics), parameter broadcast and the trainer's sync-point routing, without
+any HIP call (ParamSlab and GradSync are device-agnostic)."""
+import importlib
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+PKG = "gesture-generation-from-trimodal-context_amd"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_generator(pkg):
+    import argparse
+    a = argparse.Namespace(n_pre_poses=4, n_poses=34, input_context="both", hidden_size=300, n_layers=4, dropout_prob=0.3,
+                           freeze_wordembed=False)
+    torch.manual_seed(0)
+    return pkg.PoseGenerator(a, 27, 64, 300, None, pkg.Vocab.speakers(9))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module(PKG)
+        ddp = importlib.import_module(PKG + ".ddp")
+        params = importlib.import_module(PKG + ".params")
+        G = _make_generator(pkg)
+        slab = params.ParamSlab(G)
+        # replicas start different, broadcast makes them rank 0's
+        if rank == 1:
+            slab.flat.add_(1.0)
+        ddp.broadcast_parameters([slab])
+        ref = _make_generator(pkg)
+        ok = all(torch.equal(p.detach(), q.detach()) for p, q in zip(G.parameters(), ref.parameters()))
+        # rank-dependent gradients; buckets in the backward order the trainer uses
+        g = torch.Generator().manual_seed(100 + rank)
+        slab.grad.copy_(torch.randn(slab.numel, generator=g))
+        mine = slab.grad.clone()
+        sync = ddp.GradSync(chunk_floats=1 << 18)
+        buckets = (("out", "gru"), ("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder"), ("audio_encoder",))
+        covered = torch.zeros(slab.numel, dtype=torch.bool)
+        for b in buckets:
+            lo, hi = sync.bucket_range(slab, b)
+            assert not covered[lo:hi].any()
+            covered[lo:hi] = True
+            sync.run(("bucket", slab, b))
+        sync.run(("wait",))
+        # every parameter element is in exactly one bucket (only alignment padding is left out)
+        for p, off in zip(slab.params, slab.offsets):
+            assert covered[off:off + p.numel()].all()
+        other = torch.randn(slab.numel, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+        expect = (mine + other) / 2
+        err = float((slab.grad - expect)[covered].abs().max())
+        # whole-slab form (discriminator step)
+        slab.grad.copy_(mine)
+        sync.run(("all", slab))
+        err2 = float((slab.grad - expect).abs().max())
+        # the nn.Parameter .grad views see the reduced values (they alias the slab)
+        p0 = slab.params[0]
+        view_ok = torch.equal(p0.grad.reshape(-1), slab.grad[slab.offsets[0]:slab.offsets[0] + p0.numel()])
+        out.put((rank, ok, err, err2, view_ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_sync_world2_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, err, err2, view_ok in res:
+        assert ok and view_ok, (rank, ok, view_ok)
+        assert err < 1e-6 and err2 < 1e-6, (rank, err, err2)
+
+
+def test_trainer_routes_sync_points(pkg, monkeypatch):
+    """GanTrainer._sync: eager -> GradSync.run(action); capturing -> the cut callback gets the action instead."""
+    tg = importlib.import_module(PKG + ".train_gan")
+
+    class FakeSync:
+        def __init__(self): self.seen = []
+        def run(self, action): self.seen.append(action[0])
+
+    tr = tg.GanTrainer.__new__(tg.GanTrainer)
+    tr.grad_sync, tr._cut = FakeSync(), None
+    tr._sync("all", "slab"); tr._sync("bucket", "slab", ("gru",)); tr._sync("wait")
+    assert tr.grad_sync.seen == ["all", "bucket", "wait"]
+    cuts = []
+    tr._cut = cuts.append
+    tr._sync("bucket", "slab", ("out", "gru"))
+    assert cuts == [("bucket", "slab", ("out", "gru"))] and tr.grad_sync.seen == ["all", "bucket", "wait"]
+    tr.grad_sync = None
+    tr._sync("wait")            # single GPU: no-op
