@@ -85,8 +85,11 @@ def dominant_kernel_roofline(pkg, device, batch):
     sv = torch.empty(2, Bs, T, 4 * H, device=device)
     dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, sv), iters=20) / T        # T launches per call
     flops = 2 * Bs * H * 3 * H * 2
+    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape (profiles/r1_b_pmc_gru_fwd_step.txt):
+    # FETCH_SIZE 5193.7 KB x 2 (gfx950 wide-read correction) + WRITE_SIZE 4977.0 KB.  Only valid for batch 128 (B_s = 384).
+    traffic = (2 * 5193.7 + 4977.0) * 1024 if batch == 128 else None
     return {"kernel": "gru_fwd_step_kernel", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-            "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": None, "launch_us": dt * 1e6,
+            "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": traffic, "launch_us": dt * 1e6,
             "flop_per_launch": flops}
 
 
