@@ -33,6 +33,8 @@ class DeviceRNG:
 
 
 class _Engine:
+    use_side_stream = True       # overlap independent work on a second HIP stream (layers.Fork)
+
     def __init__(self, module, seed=0):
         self.mod = module
         self.slab = ParamSlab(module)
@@ -95,6 +97,9 @@ class GeneratorEngine(_Engine):
         assert Ba == Bs or Ba * groups == Bs, (Ba, Bs, groups)
         x = in_audio.contiguous().view(Ba, -1, 1)
         wav = []
+        fork = L.Fork(in_audio.device, enabled=self.use_side_stream)
+        fork.keep(x, in_data)
+        fork.__enter__()                 # audio encoder on the side stream, text encoder + speaker path on the main one
         for idx, Co, Ci, stride, pad in WAV_CONVS:
             wp = L.pack_conv_weight(P[f"{fe}.{idx}.weight"])
             last = idx == 9
@@ -113,6 +118,7 @@ class GeneratorEngine(_Engine):
                              repeats=groups if shared else 1)
             wav.append((x, st, c.shape[1]))
             x = y
+        fork.__exit__(None, None, None)
         tp["wav"], tp["wav_shared"] = wav, shared
 
         # ---- TextEncoderTCN (:31-61, model/tcn.py)
@@ -156,6 +162,7 @@ class GeneratorEngine(_Engine):
         tp.update(se=se, zc=zc, mu=mu, logvar=logvar, eps=eps, vid=vid)
 
         # ---- concat [pre_seq | audio | text | z repeated over time] (:139-153)
+        fork.join()
         flat_in = in_data.view(Bs * T, in_size)
         ops.copy2d(pre_seq.contiguous().view(Bs * T, D + 1), flat_in[:, :D + 1])
         ops.repeat_rows(z, flat_in[:, D + 65:], Bs, T)
@@ -190,9 +197,9 @@ class GeneratorEngine(_Engine):
         dh1 = L.linear_bwd(d_out2, tp["h1"][b0 * T:b0 * T + M], P["out.2.weight"], G["out.2.weight"], G["out.2.bias"])
         do = L.linear_bwd(dh1, tp["o"][b0 * T:b0 * T + M], P["out.0.weight"], G["out.0.weight"], G["out.0.bias"])
         dy = ops.dup_halves(do, L.empty(nb, T, 2 * H, like=do))
-        d_in = L.gru_stack_bwd(dy, tp["gru"], P, G, "gru", self.n_layers, b0=b0, nb=nb)      # (nb, T, in_size)
+        fork = L.Fork(dy.device, enabled=self.use_side_stream)
+        d_in = L.gru_stack_bwd(dy, tp["gru"], P, G, "gru", self.n_layers, b0=b0, nb=nb, fork=fork)      # (nb, T, in_size)
         d_in2 = d_in.view(M, in_size)
-        ready(("out", "gru"))
 
         # speaker path
         dz = ops.sum_rows(d_in2[:, D + 65:], L.empty(nb, 16, like=d_in), nb, T)
@@ -240,6 +247,8 @@ class GeneratorEngine(_Engine):
         em = tp["emb_mask"]
         demb = ops.mul(dcur, em[rows].reshape(M, -1), torch.empty_like(dcur)) if em is not None else dcur
         ops.embed_scatter_add(demb, tp["in_text"][rows].contiguous().view(-1), G[f"{te}.embedding.weight"])
+        fork.join()        # the GRU weight gradients ran beside the recurrences and the text-encoder backward
+        ready(("out", "gru"))
         ready(("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder"))
 
         # wav encoder

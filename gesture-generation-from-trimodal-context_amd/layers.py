@@ -213,13 +213,63 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     return cur, tape
 
 
-def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=True, param_grads=True):
+class Fork:
+    """Second HIP stream for work that is independent of the main dependency chain (weight-gradient GEMMs while the next
+    layer's recurrence runs, the audio encoder beside the text encoder).  Works under hipGraph capture: the side stream
+    joins the capture through the wait on the main stream and is joined back before the captured region ends.
+
+        with fork:            # launches inside go to the side stream, ordered after everything queued on the main stream
+            ...
+        fork.join()           # main stream waits for the side stream
+
+    Buffers read by side-stream work must stay referenced until join(): pass them to keep()."""
+    _streams = {}
+
+    def __init__(self, device, enabled=True):
+        self.enabled = enabled and device.type == "cuda"
+        self.side = None
+        self._ctx = None
+        self._keep = []
+        self.dirty = False
+        if self.enabled:
+            key = (device.type, device.index)
+            if key not in Fork._streams:
+                Fork._streams[key] = torch.cuda.Stream(device=device)
+            self.side = Fork._streams[key]
+
+    def keep(self, *tensors):
+        self._keep.extend(tensors)
+
+    def __enter__(self):
+        if self.enabled:
+            self.side.wait_stream(torch.cuda.current_stream())
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+            self.dirty = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self._ctx.__exit__(*exc)
+            self._ctx = None
+        return False
+
+    def join(self):
+        if self.enabled and self.dirty:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.dirty = False
+        self._keep = []
+
+
+def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=True, param_grads=True, fork=None):
     """dy: (nb, T, 2H) gradient w.r.t. the last layer's output for rows [b0, b0+nb) of the taped forward.
-    Accumulates into G[...] and returns dx (nb, T, Kin0)."""
+    Accumulates into G[...] and returns dx (nb, T, Kin0).  With `fork`, each layer's weight-gradient GEMMs run on the side
+    stream while the main stream goes on with dx and the next layer's recurrence; the caller joins."""
     B, T, H = tape.B, tape.T, tape.H
     nb = B - b0 if nb is None else nb
     rows = slice(b0, b0 + nb)
     dh = empty(4 * nb * H, like=dy)
+    fk = fork if fork is not None else Fork(dy.device, enabled=False)
     for l in range(n_layers - 1, -1, -1):
         if tape.masks[l] is not None:
             dy = ops.mul(dy, tape.masks[l][rows].contiguous(), torch.empty_like(dy))
@@ -229,18 +279,23 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
         x_l = tape.x[l][rows]
         Kin = x_l.shape[2]
         y_l = tape.y[l][rows]
+        if param_grads:
+            fk.keep(dgi, dgh, x_l, y_l)
+            with fk:
+                for d, sfx in enumerate(("", "_reverse")):
+                    gi2, gh2 = dgi[d].view(nb * T, 3 * H), dgh[d].view(nb * T, 3 * H)
+                    ops.gemm_tn(gi2, Win.plain(x_l.reshape(nb * T, Kin)), G[f"{prefix}.weight_ih_l{l}{sfx}"],
+                                dbias=G[f"{prefix}.bias_ih_l{l}{sfx}"])
+                    # h_{t-1} of direction d is the layer output one step back (forward) / ahead (reverse), zero at the ends
+                    hwin = Win.taps(y_l[:, :, d * H:(d + 1) * H], 1, shift=(1 if d else -1), dil=1, rows_out=T)
+                    ops.gemm_tn(gh2, hwin, G[f"{prefix}.weight_hh_l{l}{sfx}"], dbias=G[f"{prefix}.bias_hh_l{l}{sfx}"])
         dx = None
-        for d, sfx in enumerate(("", "_reverse")):
-            gi2, gh2 = dgi[d].view(nb * T, 3 * H), dgh[d].view(nb * T, 3 * H)
-            if param_grads:
-                ops.gemm_tn(gi2, Win.plain(x_l.reshape(nb * T, Kin)), G[f"{prefix}.weight_ih_l{l}{sfx}"],
-                            dbias=G[f"{prefix}.bias_ih_l{l}{sfx}"])
-                # h_{t-1} of direction d is the layer output one step back (forward) / ahead (reverse), zero at the ends
-                hwin = Win.taps(y_l[:, :, d * H:(d + 1) * H], 1, shift=(1 if d else -1), dil=1, rows_out=T)
-                ops.gemm_tn(gh2, hwin, G[f"{prefix}.weight_hh_l{l}{sfx}"], dbias=G[f"{prefix}.bias_hh_l{l}{sfx}"])
-            if need_dx or l > 0:
-                if dx is None:
-                    dx = empty(nb * T, Kin, like=dy)
-                ops.gemm_nt(Win.plain(gi2), transpose2d(P[f"{prefix}.weight_ih_l{l}{sfx}"]), None, dx, accumulate=(d == 1))
+        if need_dx or l > 0:
+            dx = empty(nb * T, Kin, like=dy)
+            for d, sfx in enumerate(("", "_reverse")):
+                ops.gemm_nt(Win.plain(dgi[d].view(nb * T, 3 * H)), transpose2d(P[f"{prefix}.weight_ih_l{l}{sfx}"]), None, dx,
+                            accumulate=(d == 1))
         dy = dx.view(nb, T, Kin) if dx is not None else None
+    if fork is None:
+        fk.join()
     return dy
