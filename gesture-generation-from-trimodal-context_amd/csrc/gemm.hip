@@ -461,6 +461,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 
 using namespace tg;
 
+// bf16-operand tier (gemm_bf16.hip), selected by tg_set_math_mode(1)
+extern "C" int tg_get_math_mode(void);
+int tg_gemm_nt_bf16_launch(const Win& w, const float* Bw, long ldb, const float* bias, float* C, long cbs, long crs, int cR, int M,
+                           int N, float slope, int accumulate, hipStream_t s);
+int tg_gemm_tn_bf16_launch(const float* dY, long ldy, const Win& w, float* dW, long ldw, int M, int N, int out_kw, float* dbias,
+                           void* ws, int64_t ws_bytes, hipStream_t s);
+
 static int check_window(const tg_window* w, const char* who) {
     TG_REQUIRE(w && w->ptr, "%s: null window", who);
     TG_REQUIRE(w->K > 0 && w->cw > 0 && w->K % w->cw == 0, "%s: K=%d must be a positive multiple of cw=%d", who, w->K, w->cw);
@@ -478,6 +485,9 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
     const bool vec = (w.cw % 4 == 0) && (w.K % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr) &&
                      (ldb % 4 == 0) && aligned16(Bw);
     hipStream_t s = (hipStream_t)stream;
+    if (tg_get_math_mode() == 1 && vec && M >= 256 && N >= 32 && w.K >= 32)
+        return tg_gemm_nt_bf16_launch(w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope,
+                                      accumulate, s);
     if (vec && N >= 96 && M >= 1024 && w.K >= 64) {
         // big products: 128-row tiles; 128 columns per tile unless that leaves the last column tile mostly empty or
         // too few workgroups to fill 256 CUs, then 64
@@ -533,6 +543,8 @@ extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, floa
     TG_REQUIRE(dY && dW && M > 0 && N > 0 && ldy >= N && ldw >= A->K, "tg_gemm_tn: bad arguments");
     TG_REQUIRE(out_kw == 0 || out_kw * A->cw == A->K, "tg_gemm_tn: out_kw=%d must be 0 or K/cw", out_kw);
     Win w = to_win(A);
+    if (tg_get_math_mode() == 1 && ws != nullptr)      // math mode 1: ws is the byte workspace of tg_gemm_tn_bf16_ws_bytes()
+        return tg_gemm_tn_bf16_launch(dY, (long)ldy, w, dW, (long)ldw, M, N, out_kw, dbias, ws, ws_floats * 4, (hipStream_t)stream);
     int splits, rows_per_split;
     tn_plan(M, N, w.K, ws != nullptr, &splits, &rows_per_split);
     TG_REQUIRE(ws == nullptr || ws_floats >= (int64_t)splits * N * w.K, "tg_gemm_tn: workspace too small (%ld < %ld floats)",

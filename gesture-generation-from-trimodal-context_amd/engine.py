@@ -7,6 +7,8 @@ training iteration can be captured into one hipGraph (train_gan.GraphedGanStep).
 Reference maths: model/multimodal_context_net.py (WavEncoder :9-28, TextEncoderTCN :31-61, PoseGenerator :64-160,
 ConvDiscriminator :207-252), model/tcn.py, model/embedding_net.py (pose-mode EmbeddingNet).
 """
+import os
+
 import torch
 
 from . import layers as L
@@ -33,7 +35,8 @@ class DeviceRNG:
 
 
 class _Engine:
-    use_side_stream = True       # overlap independent work on a second HIP stream (layers.Fork)
+    # overlap independent work on a second HIP stream (layers.Fork); off by default: measured 3 % slower under hipGraph replay on MI355X (12.39 vs 12.00 ms); TG_SIDE_STREAM=1 enables
+    use_side_stream = os.environ.get("TG_SIDE_STREAM", "0") != "0"
 
     def __init__(self, module, seed=0):
         self.mod = module

@@ -102,6 +102,17 @@ def gemm_nt(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_st
     return out
 
 
+def set_math_mode(mode):
+    """'f32' (exact fp32 matrix cores, default) or 'bf16' (bf16 operands, fp32 accumulate) for the GEMM-shaped kernels."""
+    m = {"f32": 0, "fp32": 0, 0: 0, "bf16": 1, 1: 1}[mode]
+    if _lib.load().tg_set_math_mode(m) != 0:
+        raise RuntimeError(_lib.load().tg_last_error().decode())
+
+
+def get_math_mode():
+    return "bf16" if _lib.load().tg_get_math_mode() == 1 else "f32"
+
+
 TN_TWO_PASS_ROWS = 32768     # reductions at least this long combine their partials in fp64 (deterministic) instead of atomics
 
 
@@ -117,7 +128,10 @@ def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
     if (M - 1) * dY.stride(0) + N - 1 >= _room(dY):
         raise ValueError("gemm_tn: dY exceeds its tensor")
     ws, nws = None, 0
-    if M >= TN_TWO_PASS_ROWS:
+    if _lib.load().tg_get_math_mode() == 1 and M >= 256:
+        nws = (_lib.load().tg_gemm_tn_bf16_ws_bytes(M, N, A.K) + 3) // 4
+        ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
+    elif M >= TN_TWO_PASS_ROWS:
         nws = _lib.load().tg_gemm_tn_ws_floats(M, N, A.K)
         ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
     call("tg_gemm_tn", _p(dY), dY.stride(0), C.byref(A.s), _p(dW), A.K, M, N, int(out_kw), _p(dbias), _p(ws), nws, _stream())
