@@ -124,6 +124,50 @@ def cpu_baseline(batch, budget_s=20.0, max_steps=3):
             "sample": f"{steps} post-warm-up GAN iterations at batch {batch} after 1 warm-up, fp32 ATen kernels, {dt:.2f} s/iter"}
 
 
+def decode_bench(pkg, a, args, G, device, world, rank):
+    """Inference path (synthesize.py:82-160): every step is one 34-frame window for a.batch utterances in lock-step
+    (seed hand-over + cross-fade on device, hipGraph replay).  Replicas only under --gpus N: no collective."""
+    syn = importlib.import_module(PKG + ".synthesize")
+    args.motion_resampling_framerate = 15
+    dec = syn.WindowDecoder(args, G, a.batch, device, graph=not a.no_graph)
+    g = torch.Generator().manual_seed(77 + rank)
+    text = torch.zeros(a.batch, T, dtype=torch.int64)
+    text[:, ::5] = torch.randint(4, V, (a.batch, len(range(0, T, 5))), generator=g)
+    audio = (0.1 * torch.randn(a.batch, dec.audio_len, generator=g)).to(device)
+    text, vid = text.to(device), torch.randint(1, S, (a.batch,), generator=g).to(device)
+    dec.seed(None)
+    dec.window(text, audio, vid, first=True)
+    for _ in range(max(a.warmup, 1)):
+        dec.window(text, audio, vid, first=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = dec.window(text, audio, vid, first=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert bool(torch.isfinite(out).all())
+    if rank == 0:
+        fps = world * a.batch * T * a.steps / dt
+        print(json.dumps({
+            "metric": "inference pose-frames/sec (batched 34-frame synthesis windows)", "value": fps, "unit": "pose-frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthesize.py window loop (BASELINE.json configs[3]): PoseGenerator eval forward + seed hand-over + cross-fade",
+                       "utterances_per_gpu": a.batch, "frames": T, "hipgraph": not a.no_graph, "parallelism": f"replicas x{world}"},
+            "step_roofline": {"bound": "mfma", "achieved": fps / world / T * 0.5217e9 / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                              "frac": fps / world / T * 0.5217e9 / PEAK_F32_MFMA, "note": "0.5217 GFLOP per window (SURVEY 8d)"}}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +175,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="clips per GPU")
     ap.add_argument("--epoch", type=int, default=11, help="> loss_warmup (10) = full GAN iteration")
+    ap.add_argument("--mode", choices=("train", "decode"), default="train",
+                    help="train: GAN training iteration (headline metric); decode: BASELINE.json configs[3], batched 34-frame "
+                         "synthesis windows with device-side seed hand-over / cross-fade, pose-frames/sec")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -154,6 +201,8 @@ def main():
         grad_sync = ddp.GradSync()
 
     args, G, Dn = build(pkg, device, seed=0)                 # same seed on every rank: identical replicas
+    if a.mode == "decode":
+        return decode_bench(pkg, a, args, G, device, world, rank)
     trainer = pkg.GanTrainer(G, Dn, args, grad_sync=grad_sync)
     if world > 1:
         ddp.broadcast_parameters([trainer.G.slab.ensure(), trainer.D.slab.ensure()])

@@ -58,6 +58,8 @@ SIGNATURES = {
     "tg_l1_mean": [P, P, I64, P, P],
     "tg_sigmoid": [P, P, I64, P],
     "tg_sigmoid_bwd": [P, P, P, I64, P],
+    "tg_window_blend": [P, P, I32, I32, I32, I32, P],
+    "tg_pose_metrics": [P, P, P, I32, I32, I32, P, P],
     "tg_ae_loss": [P, P, I32, I32, I32, P, P, P],
     "tg_counter_inc": [P, P],
     "tg_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, P, P],

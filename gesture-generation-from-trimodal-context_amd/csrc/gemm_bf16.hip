@@ -37,41 +37,56 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(Win A, const float* _
     const int m0 = (lid / n_nt) * 128, n0 = (lid % n_nt) * BN;
     const int K = A.K;
 
-    // A staging: row t>>1, 16 consecutive k starting at 16*(t&1): four 16-byte pieces
-    const int arow = t >> 1, ak = 16 * (t & 1);
-    long a_off;
-    int a_r;
-    bool a_ok;
-    {
-        const int m = m0 + arow;
-        a_ok = m < M;
-        const int mm = a_ok ? m : 0;
+    // staging map: 8 consecutive lanes cover one 128-byte row of the slab (32 fp32), so every load instruction reads whole
+    // cache lines (8 rows x 128 B); thread t owns piece (t & 7) of rows (t >> 3) + 32 q
+    const int sp = 4 * (t & 7), sr0 = t >> 3;
+    long a_off[4];
+    int a_r[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + sr0 + 32 * q;
+        a_ok[q] = m < M;
+        const int mm = a_ok[q] ? m : 0;
         const int b = mm / A.rows_out;
-        a_off = (long)b * A.bs;
-        a_r = (mm - b * A.rows_out) * A.step + A.shift;
+        a_off[q] = (long)b * A.bs;
+        a_r[q] = (mm - b * A.rows_out) * A.step + A.shift;
     }
-    // B staging: BN rows x 8 pieces = BN*8 pieces over 256 threads: row (t*BQ)/8, pieces (t*BQ)%8 .. +BQ-1
-    const int brow = (t * BQ) >> 3, bk = 4 * ((t * BQ) & 7);
-    const bool b_ok = n0 + brow < N;
-    const float* b_ptr = Bw + (long)(b_ok ? n0 + brow : 0) * ldb;
+    const float* b_ptr[BQ];
+    bool b_ok[BQ];
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+        const int n = n0 + sr0 + 32 * q;
+        b_ok[q] = n < N;
+        b_ptr[q] = Bw + (long)(b_ok[q] ? n : 0) * ldb;
+    }
 
-    f32x4 ga[4], gb[BQ];
-    auto fetch = [&](int k0) {
+    // two register sets: the loads of slab s+2 are issued while slab s is multiplied, so a slab's global-load latency
+    // (~2 us under load) is covered by two full iterations instead of the few hundred cycles of one slab's MFMAs
+    f32x4 ga[2][4], gb[2][BQ];
+    auto fetch = [&](int k0, f32x4 (&ra)[4], f32x4 (&rb)[BQ]) {
+        // loads are issued UNCONDITIONALLY from an always-valid address and zeroed afterwards: a predicated load makes the
+        // number of outstanding loads dynamic and hipcc then drains everything (vmcnt(0)) at the next use
+        const int k = k0 + sp;
+        const bool inb = k < K;
+        const int kc = inb ? k : 0;
+        const int kk = kc / A.cw;
+        const int c = kc - kk * A.cw;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int k = k0 + ak + 4 * q;
-            const int kk = k / A.cw;
-            const int c = k - kk * A.cw;
-            const int sr = a_r + kk * A.dil;
-            const bool ok = a_ok && k < K && sr >= 0 && sr < A.rows_in;
+            const int sr = a_r[q] + kk * A.dil;
+            const bool ok = a_ok[q] && inb && sr >= 0 && sr < A.rows_in;
+            const float* src = ok ? A.ptr + a_off[q] + (long)sr * A.rs + c : A.ptr;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ga[q] = ok ? *reinterpret_cast<const f32x4*>(A.ptr + a_off + (long)sr * A.rs + c) : z;
+            ra[q] = ok ? v : z;
         }
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {
-            const int k = k0 + bk + 4 * q;
+            const bool ok = b_ok[q] && inb;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? b_ptr[q] + kc : Bw);
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            gb[q] = (b_ok && k < K) ? *reinterpret_cast<const f32x4*>(b_ptr + k) : z;
+            rb[q] = ok ? v : z;
         }
     };
 
@@ -81,15 +96,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(Win A, const float* _
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    auto stage_and_multiply = [&](int buf, int k_next, f32x4 (&ra)[4], f32x4 (&rb)[BQ]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(&as[buf][arow][ak + 4 * q]) = cvt4(ga[q]);
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(&as[buf][sr0 + 32 * q][sp]) = cvt4(ra[q]);
 #pragma unroll
-        for (int q = 0; q < BQ; ++q) *reinterpret_cast<bf16x4*>(&bs[buf][brow][bk + 4 * q]) = cvt4(gb[q]);
+        for (int q = 0; q < BQ; ++q) *reinterpret_cast<bf16x4*>(&bs[buf][sr0 + 32 * q][sp]) = cvt4(rb[q]);
         __syncthreads();
-        if (k0 + 32 < K) fetch(k0 + 32);
+        fetch(k_next, ra, rb);
         bf16x8 fa[4], fb[TN];
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&as[buf][wm * 64 + i * 16 + r16][8 * kq]);
@@ -99,7 +112,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(Win A, const float* _
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        buf ^= 1;
+    };
+
+    fetch(0, ga[0], gb[0]);
+    fetch(32, ga[1], gb[1]);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        stage_and_multiply(0, k0 + 64, ga[0], gb[0]);
+        if (k0 + 32 < K) stage_and_multiply(1, k0 + 96, ga[1], gb[1]);
     }
 
 #pragma unroll

@@ -146,6 +146,68 @@ __global__ __launch_bounds__(256) void ae_loss_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
+// Cross-fade of consecutive synthesis windows (synthesize.py:145-153): the first n frames of the new window become
+// prev_tail[j] * (n - j)/(n + 1) + next[j] * (j + 1)/(n + 1).  next: [B][T][D] (in place), prev_tail: [B][n][D].
+__global__ void window_blend_kernel(const float* __restrict__ prev_tail, float* __restrict__ next, int B, int T, int D, int n) {
+    const long total = (long)B * n * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int j = (int)((i / D) % n);
+        const long b = i / ((long)D * n);
+        float* p = next + (b * T + j) * D + d;
+        *p = prev_tail[i] * (float)(n - j) / (float)(n + 1) + *p * (float)(j + 1) / (float)(n + 1);
+    }
+}
+
+// evaluate_testset metrics (train.py:282-310): direction vectors (+ mean) -> 10 joint positions by walking the 9 bones
+// (utils/data_utils.py:14-15,77-98); sums of |joint error| over frames >= n_pre, of |second-difference error| and of the plain
+// L1 error.  One thread per (clip, frame); sums[0..2] in fp64.
+__constant__ int c_bone_from[9] = {0, 1, 2, 1, 4, 5, 1, 7, 8};
+__constant__ int c_bone_to[9] = {1, 2, 3, 4, 5, 6, 7, 8, 9};
+__constant__ float c_bone_len[9] = {0.26f, 0.18f, 0.14f, 0.22f, 0.36f, 0.33f, 0.22f, 0.36f, 0.33f};
+
+__device__ __forceinline__ void joints_of(const float* __restrict__ v, const float* __restrict__ mean, float (&jp)[30]) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) jp[q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) jp[c_bone_to[j] * 3 + q] = jp[c_bone_from[j] * 3 + q] + c_bone_len[j] * (v[j * 3 + q] + mean[j * 3 + q]);
+}
+
+__global__ __launch_bounds__(256) void pose_metrics_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                           const float* __restrict__ mean, int B, int T, int n_pre, double* __restrict__ sums) {
+    __shared__ float sh[4];
+    float s_mae = 0.f, s_acc = 0.f, s_l1 = 0.f;
+    const long total = (long)B * T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % T);
+        const float* o = out + i * 27;
+        const float* g = tgt + i * 27;
+        for (int q = 0; q < 27; ++q) s_l1 += fabsf(o[q] - g[q]);
+        float jo[30], jg[30];
+        joints_of(o, mean, jo);
+        joints_of(g, mean, jg);
+        if (t >= n_pre)
+            for (int q = 0; q < 30; ++q) s_mae += fabsf(jo[q] - jg[q]);
+        if (t + 2 < T) {      // np.diff(n=2): x[t+2] - 2 x[t+1] + x[t]
+            float jo1[30], jg1[30], jo2[30], jg2[30];
+            joints_of(o + 27, mean, jo1); joints_of(g + 27, mean, jg1);
+            joints_of(o + 54, mean, jo2); joints_of(g + 54, mean, jg2);
+            for (int q = 0; q < 30; ++q)
+                s_acc += fabsf((jg2[q] - 2.f * jg1[q] + jg[q]) - (jo2[q] - 2.f * jo1[q] + jo[q]));
+        }
+    }
+    s_mae = block_sum256(s_mae, sh);
+    s_acc = block_sum256(s_acc, sh);
+    s_l1 = block_sum256(s_l1, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], (double)s_mae);
+        atomicAdd(&sums[1], (double)s_acc);
+        atomicAdd(&sums[2], (double)s_l1);
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -179,6 +241,21 @@ int tg_l1_mean(const float* a, const float* b, int64_t n, float* out, void* stre
     if (hipMemsetAsync(out, 0, sizeof(float), ST) != hipSuccess) { set_error("tg_l1_mean: memset"); return 1; }
     hipLaunchKernelGGL(l1_mean_kernel, dim3(ew_grid(n, 256, 8)), dim3(256), 0, ST, a, b, (long)n, out);
     return check_launch("tg_l1_mean");
+}
+
+int tg_window_blend(const float* prev_tail, float* next, int32_t B, int32_t T, int32_t D, int32_t n, void* stream) {
+    TG_REQUIRE(prev_tail && next && B > 0 && T > 0 && D > 0 && n > 0 && n <= T, "tg_window_blend: bad arguments");
+    hipLaunchKernelGGL(window_blend_kernel, dim3(ew_grid((long)B * n * D)), dim3(256), 0, ST, prev_tail, next, B, T, D, n);
+    return check_launch("tg_window_blend");
+}
+
+int tg_pose_metrics(const float* out_dir_vec, const float* target_dir_vec, const float* mean_dir_vec, int32_t B, int32_t T,
+                    int32_t n_pre, double* sums, void* stream) {
+    TG_REQUIRE(out_dir_vec && target_dir_vec && mean_dir_vec && sums && B > 0 && T > 2 && n_pre >= 0 && n_pre < T, "tg_pose_metrics: bad arguments");
+    if (hipMemsetAsync(sums, 0, 3 * sizeof(double), ST) != hipSuccess) { set_error("tg_pose_metrics: memset"); return 1; }
+    hipLaunchKernelGGL(pose_metrics_kernel, dim3(ew_grid((long)B * T, 256, 1)), dim3(256), 0, ST, out_dir_vec, target_dir_vec, mean_dir_vec, B, T,
+                       n_pre, sums);
+    return check_launch("tg_pose_metrics");
 }
 
 int tg_ae_loss(const float* recon, const float* target, int32_t B, int32_t T, int32_t D, float* out, float* d_recon, void* stream) {

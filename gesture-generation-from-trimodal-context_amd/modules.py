@@ -125,6 +125,7 @@ class PoseGenerator(nn.Module):
     def forward(self, pre_seq, in_text, in_audio, vid_indices=None):
         assert vid_indices is not None
         eng = self.engine
+        eng.rng.advance()            # every call draws fresh dropout masks / eps (the trainer advances once per iteration itself)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
         def runner():
@@ -173,6 +174,7 @@ class ConvDiscriminator(nn.Module):
 
     def forward(self, poses, in_text=None):
         eng = self.engine
+        eng.rng.advance()
         params_need = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         need_grad = params_need or (torch.is_grad_enabled() and poses.requires_grad)
 

@@ -390,6 +390,20 @@ def sigmoid_bwd(dy, y, dx):
     call("tg_sigmoid_bwd", _p(dy), _p(y), _p(dx), _same(dy, y, dx), _stream()); return dx
 
 
+def window_blend(prev_tail, nxt):
+    """nxt (B,T,D) in place: first n frames cross-faded with prev_tail (B,n,D)."""
+    _flat(prev_tail, "prev_tail"); _flat(nxt, "next")
+    B, n, D = prev_tail.shape
+    assert nxt.shape[0] == B and nxt.shape[2] == D and n <= nxt.shape[1]
+    call("tg_window_blend", _p(prev_tail), _p(nxt), B, nxt.shape[1], D, n, _stream()); return nxt
+
+
+def pose_metrics(out, target, mean_dir_vec, n_pre, sums):
+    _same(out, target); _flat(mean_dir_vec, "mean"); B, T, D = out.shape
+    assert D == 27 and mean_dir_vec.numel() == 27 and sums.dtype == torch.float64 and sums.numel() >= 3 and sums.is_cuda
+    call("tg_pose_metrics", _p(out), _p(target), _p(mean_dir_vec), B, T, int(n_pre), _p(sums), _stream()); return sums
+
+
 def ae_loss(recon, target, out, d_recon):
     B, T, D = recon.shape; _same(recon, target, d_recon)
     call("tg_ae_loss", _p(recon), _p(target), B, T, D, _p(_flat(out, "out")), _p(d_recon), _stream())

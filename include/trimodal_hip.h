@@ -215,6 +215,16 @@ int tg_sigmoid(const float* x, float* y, int64_t n, void* stream);
 /* dx = dy * y * (1 - y), y = sigmoid(x)  (torch.sigmoid backward, multimodal_context_net.py:250). */
 int tg_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 
+/* Cross-fade of consecutive synthesis windows (synthesize.py:145-153), in place on the new window:
+ * next[b][j][:] = prev_tail[b][j][:] * (n-j)/(n+1) + next[b][j][:] * (j+1)/(n+1), j < n.  next: [B][T][D], prev_tail: [B][n][D]. */
+int tg_window_blend(const float* prev_tail, float* next, int32_t B, int32_t T, int32_t D, int32_t n, void* stream);
+
+/* evaluate_testset metrics of one batch (train.py:282-310; utils/data_utils.py:77-98): out/target direction vectors [B][T][27],
+ * mean_dir_vec [27].  sums[0] = sum |joint error| over frames >= n_pre and 10x3 joints, sums[1] = sum |second-difference error| over
+ * T-2 frames, sums[2] = sum |out - target|.  (joint_mae = sums[0]/(B*(T-n_pre)*30), accel = sums[1]/(B*(T-2)*30), l1 = sums[2]/(B*T*27).) */
+int tg_pose_metrics(const float* out_dir_vec, const float* target_dir_vec, const float* mean_dir_vec, int32_t B, int32_t T,
+                    int32_t n_pre, double* sums, void* stream);
+
 /* FGD autoencoder loss (train_feature_extractor.py:64-72): loss = sum_b [mean|r-t| + mean|dr-dt|];
  * out[0] = loss, d_recon = d loss / d recon. */
 int tg_ae_loss(const float* recon, const float* target, int32_t B, int32_t T, int32_t D, float* out, float* d_recon,

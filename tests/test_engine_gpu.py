@@ -235,3 +235,70 @@ def test_graphed_step_equals_eager(pkg, dev):
         for k in a:
             assert abs(a[k] - b[k]) <= 1e-4 * max(1.0, abs(a[k])), (k, a[k], b[k])
     assert all(np.isfinite(list(d.values())).all() for d in runs[1][0])
+
+
+def test_eval_metrics_match_oracle(pkg, dev):
+    """train.py:282-310 (restated in the oracle) vs tg_pose_metrics."""
+    from importlib import import_module
+    em = import_module(pkg.__name__ + ".eval_metrics")
+    g = torch.Generator().manual_seed(3)
+    out, tgt = 0.3 * torch.randn(12, 34, 27, generator=g), 0.3 * torch.randn(12, 34, 27, generator=g)
+    mean = [0.0154009, -0.9690125, -0.0884354, -0.0022264, -0.8655276, 0.4342174, -0.0035145, -0.8755367, -0.4121039, -0.9236511,
+            0.3061306, -0.0012415, -0.5155854, 0.8129665, 0.0871897, 0.2348464, 0.1846561, 0.8091402, 0.9271948, 0.2960011, -0.013189,
+            0.5233978, 0.8092403, 0.0725451, -0.2037076, 0.1924306, 0.8196916]                    # config/multimodal_context.yml:16
+    l1, mae, acc = em.batch_metrics(out.to(dev), tgt.to(dev), mean, 4)
+    ol1, omae, oacc = O.eval_metrics(out.numpy(), tgt.numpy(), mean, 4)
+    assert abs(l1 - ol1) < 1e-6 * ol1 and abs(mae - omae) < 1e-5 * omae and abs(acc - oacc) < 1e-5 * oacc
+
+
+def test_window_synthesis_matches_oracle_blend(pkg, dev):
+    """generate_gestures (synthesize.py:36-209): window count, audio slicing, seed hand-over and cross-fade, against the
+    oracle's restatement driven window by window with the same eps."""
+    from importlib import import_module
+    syn = import_module(pkg.__name__ + ".synthesize")
+    V, S = 64, 9
+    gst = O.make_generator_state(5, V, S)
+    args, G, D = build_models(pkg, dev, gst, O.make_discriminator_state(6), V, S)
+    args.motion_resampling_framerate = 15
+    G.eval()
+
+    class Lang:
+        def get_word_index(self, w): return 4 + (sum(map(ord, w)) % (V - 4))
+    gen = torch.Generator().manual_seed(21)
+    sr = 16000
+    audio = (0.1 * torch.randn(int(6.9 * sr), generator=gen)).numpy()         # 6.9 s -> ceil((6.9-2.2667)/2)+1 = 4 windows
+    words = [["hello", 0.3, 0.6], ["there", 1.1, 1.5], ["general", 2.6, 3.0], ["kenobi", 4.05, 4.6], ["bold", 6.0, 6.4]]
+    assert syn.num_windows(len(audio) / sr) == O.num_windows(len(audio) / sr) == 4
+    # window inputs: slicing arithmetic of synthesize.py:96-119
+    a3, ids3, pad3 = syn.window_inputs(args, Lang(), audio, words, 3, sr)
+    assert len(a3) == 36266 and pad3 == 36266 - (len(audio) - int(np.floor(6.0 / 6.9 * len(audio)))) and ids3[0] == Lang().get_word_index("bold")
+    # run the HIP window loop with recorded eps: wrap the engine's normal draw to record it
+    eng = G.engine
+    eps_rec = []
+    orig_normal = pkg.ops.normal
+    def rec_normal(out, state, site):
+        r = orig_normal(out, state, site); eps_rec.append(r.clone()); return r
+    pkg.ops.normal = rec_normal
+    import importlib as _il
+    _il.import_module(pkg.__name__ + ".engine").ops.normal = rec_normal
+    try:
+        res = syn.generate_gestures_batch(args, G, Lang(), [audio], [words], vids=[3], graph=False)[0]
+    finally:
+        pkg.ops.normal = orig_normal
+        _il.import_module(pkg.__name__ + ".engine").ops.normal = orig_normal
+    assert res.shape == (4 * 30 + 4, 27) and len(eps_rec) == 4
+    # oracle: same windows, same eps, python blend
+    ost = O.clone_state(gst, torch.float64)
+    outs, pre = [], torch.zeros(1, 34, 28, dtype=torch.float64)
+    for i in range(4):
+        a, ids, _ = syn.window_inputs(args, Lang(), audio, words, i, sr)
+        o, *_ = O.generator_forward(ost, pre, torch.from_numpy(ids)[None], torch.from_numpy(a)[None].double(), torch.tensor([3]),
+                                    training=False, rand=O.Rand(inject={"g.eps": eps_rec[i].cpu().double()}))
+        outs.append(o[0].numpy())
+        blended = O.blend_windows(outs)                                    # what the reference has accumulated so far
+        pre = torch.zeros(1, 34, 28, dtype=torch.float64)
+        pre[0, :4, :27] = torch.from_numpy(outs[-1][-4:]) if i == 0 else torch.from_numpy(outs[-1][-4:])
+        pre[0, :4, 27] = 1
+        # the reference seeds window i+1 with the RAW last 4 frames of window i (out_dir_vec, before blending): synthesize.py:122-124
+    ref = O.blend_windows(outs)
+    assert rel(res, ref) < 1e-5
