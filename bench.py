@@ -180,6 +180,7 @@ def main():
                          "synthesis windows with device-side seed hand-over / cross-fade, pose-frames/sec")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path (graph segments + RCCL) even with one rank")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,9 +194,11 @@ def main():
     pkg._lib.load()
 
     grad_sync = None
-    if world > 1:
+    if world > 1 or a.force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
         ddp = importlib.import_module(PKG + ".ddp")
         grad_sync = ddp.GradSync()
@@ -204,7 +207,7 @@ def main():
     if a.mode == "decode":
         return decode_bench(pkg, a, args, G, device, world, rank)
     trainer = pkg.GanTrainer(G, Dn, args, grad_sync=grad_sync)
-    if world > 1:
+    if grad_sync is not None:
         ddp.broadcast_parameters([trainer.G.slab.ensure(), trainer.D.slab.ensure()])
     text, audio, poses, vid = synthetic_batch(a.batch, 1234 + rank, device)
 
