@@ -255,7 +255,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.batch)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or a.force_ddp:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

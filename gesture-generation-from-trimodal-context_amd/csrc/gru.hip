@@ -252,16 +252,25 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_h64_kernel(
     for (int e = threadIdx.x; e < 16 * HS_LD; e += 256) (&hs[0][0])[e] = 0.f;
     __syncthreads();
 
+    // input-side gate pre-activations are independent of the recurrence: software-pipelined one step ahead, so their
+    // (HBM/L2) latency hides behind a whole step instead of behind 48 MFMAs
+    float nx_r[4], nx_z[4], nx_n[4];
+    auto load_gi = [&](int tau_l) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* gip = gi + dir * gi_ds + (row_base[i] + tau_l) * (3 * HS);
+            nx_r[i] = row_ok[i] ? gip[j] : 0.f;
+            nx_z[i] = row_ok[i] ? gip[HS + j] : 0.f;
+            nx_n[i] = row_ok[i] ? gip[2 * HS + j] : 0.f;
+        }
+    };
+    load_gi(dir ? T - 1 : 0);
     for (int step = 0; step < T; ++step) {
         const int tau = dir ? T - 1 - step : step;
         float g_r[4], g_z[4], g_n[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {               // independent of the recurrence: in flight during the MFMAs
-            const float* gip = gi + dir * gi_ds + (row_base[i] + tau) * (3 * HS);
-            g_r[i] = row_ok[i] ? gip[j] : 0.f;
-            g_z[i] = row_ok[i] ? gip[HS + j] : 0.f;
-            g_n[i] = row_ok[i] ? gip[2 * HS + j] : 0.f;
-        }
+        for (int i = 0; i < 4; ++i) { g_r[i] = nx_r[i]; g_z[i] = nx_z[i]; g_n[i] = nx_n[i]; }
+        if (step + 1 < T) load_gi(dir ? tau - 1 : tau + 1);
         f32x4 acc[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -328,19 +337,27 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_h64_kernel(
     for (int e = threadIdx.x; e < 16 * DG_LD; e += 256) (&dgs[0][0])[e] = 0.f;
     __syncthreads();
 
-    for (int step = 0; step < T; ++step) {
-        const int tau = dir ? step : T - 1 - step;
-        const int tau_prev = dir ? tau + 1 : tau - 1;
-        const bool has_prev = dir ? (tau < T - 1) : (tau > 0);
-        float dy[4], r[4], z[4], n[4], hn[4], hp[4];
+    // the per-step operands (dy, saved gates, h_prev) do not depend on the recurrence: loaded one step ahead
+    float n_dy[4], n_r[4], n_z[4], n_n[4], n_hn[4], n_hp[4];
+    auto load_step = [&](int tau_l) {
+        const int tp = dir ? tau_l + 1 : tau_l - 1;
+        const bool hasp = dir ? (tau_l < T - 1) : (tau_l > 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = row_ok[i];
-            const float* sp = save + dir * save_ds + (row_base[i] + tau) * (4 * HS);
-            dy[i] = ok ? dY[(row_base[i] + tau) * (2 * HS) + dir * HS + j] : 0.f;
-            r[i] = ok ? sp[j] : 0.f; z[i] = ok ? sp[HS + j] : 0.f; n[i] = ok ? sp[2 * HS + j] : 0.f; hn[i] = ok ? sp[3 * HS + j] : 0.f;
-            hp[i] = (ok && has_prev) ? Y[(row_base[i] + tau_prev) * (2 * HS) + dir * HS + j] : 0.f;
+            const float* sp = save + dir * save_ds + (row_base[i] + tau_l) * (4 * HS);
+            n_dy[i] = ok ? dY[(row_base[i] + tau_l) * (2 * HS) + dir * HS + j] : 0.f;
+            n_r[i] = ok ? sp[j] : 0.f; n_z[i] = ok ? sp[HS + j] : 0.f; n_n[i] = ok ? sp[2 * HS + j] : 0.f; n_hn[i] = ok ? sp[3 * HS + j] : 0.f;
+            n_hp[i] = (ok && hasp) ? Y[(row_base[i] + tp) * (2 * HS) + dir * HS + j] : 0.f;
         }
+    };
+    load_step(dir ? 0 : T - 1);
+    for (int step = 0; step < T; ++step) {
+        const int tau = dir ? step : T - 1 - step;
+        float dy[4], r[4], z[4], n[4], hn[4], hp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dy[i] = n_dy[i]; r[i] = n_r[i]; z[i] = n_z[i]; n[i] = n_n[i]; hn[i] = n_hn[i]; hp[i] = n_hp[i]; }
+        if (step + 1 < T) load_step(dir ? tau + 1 : tau - 1);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
 #pragma unroll
