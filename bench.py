@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--mode", choices=("train", "decode"), default="train",
                     help="train: GAN training iteration (headline metric); decode: BASELINE.json configs[3], batched 34-frame "
                          "synthesis windows with device-side seed hand-over / cross-fade, pose-frames/sec")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32: exact fp32 matrix cores (parity ~1e-6). bf16: forward / input-gradient GEMMs feed the matrix cores "
+                         "with bf16 operands, fp32 accumulate, fp32 everywhere else (tolerance 2e-2 / 5e-2)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path (graph segments + RCCL) even with one rank")
@@ -192,6 +195,7 @@ def main():
     device = torch.device("cuda", local)
     pkg = importlib.import_module(PKG)
     pkg._lib.load()
+    pkg.ops.set_math_mode(a.dtype)
 
     grad_sync = None
     if world > 1 or a.force_ddp:
@@ -241,7 +245,7 @@ def main():
             "metric": "training clips/sec (34-frame, 27-dim pose), post-warm-up GAN iteration",
             "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "multimodal_context GAN training iteration (BASELINE.json configs[1]), epoch > loss_warmup",
                        "batch_per_gpu": a.batch, "global_batch": world * a.batch, "frames": T, "pose_dim": D,
                        "audio_samples": A, "n_words": V, "n_speakers": S - 1, "hipgraph": not a.no_graph,

@@ -113,6 +113,9 @@ def get_math_mode():
     return "bf16" if _lib.load().tg_get_math_mode() == 1 else "f32"
 
 
+# In bf16 math mode the weight gradients stay on the fp32 path by default: the transposing bf16 variant is slower at the
+# shapes of this model (tools/gemm_probe.py) and fp32 weight gradients keep the optimiser input exact.
+BF16_WGRAD = False
 TN_TWO_PASS_ROWS = 32768     # reductions at least this long combine their partials in fp64 (deterministic) instead of atomics
 
 
@@ -128,7 +131,7 @@ def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
     if (M - 1) * dY.stride(0) + N - 1 >= _room(dY):
         raise ValueError("gemm_tn: dY exceeds its tensor")
     ws, nws = None, 0
-    if _lib.load().tg_get_math_mode() == 1 and M >= 256:
+    if BF16_WGRAD and _lib.load().tg_get_math_mode() == 1 and M >= 256:
         nws = (_lib.load().tg_gemm_tn_bf16_ws_bytes(M, N, A.K) + 3) // 4
         ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
     elif M >= TN_TWO_PASS_ROWS:
