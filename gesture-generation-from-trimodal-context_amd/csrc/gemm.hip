@@ -485,7 +485,7 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
     const bool vec = (w.cw % 4 == 0) && (w.K % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr) &&
                      (ldb % 4 == 0) && aligned16(Bw);
     hipStream_t s = (hipStream_t)stream;
-    if (tg_get_math_mode() == 1 && vec && M >= 256 && N >= 32 && w.K >= 32)
+    if (tg_get_math_mode() >= 1 && vec && M >= 256 && N >= 32 && w.K >= 32)
         return tg_gemm_nt_bf16_launch(w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope,
                                       accumulate, s);
     if (vec && N >= 96 && M >= 1024 && w.K >= 64) {
@@ -543,7 +543,7 @@ extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, floa
     TG_REQUIRE(dY && dW && M > 0 && N > 0 && ldy >= N && ldw >= A->K, "tg_gemm_tn: bad arguments");
     TG_REQUIRE(out_kw == 0 || out_kw * A->cw == A->K, "tg_gemm_tn: out_kw=%d must be 0 or K/cw", out_kw);
     Win w = to_win(A);
-    if (tg_get_math_mode() == 1 && ws != nullptr)      // math mode 1: ws is the byte workspace of tg_gemm_tn_bf16_ws_bytes()
+    if (tg_get_math_mode() == 2 && ws != nullptr)      // math mode 2: ws is the byte workspace of tg_gemm_tn_bf16_ws_bytes()
         return tg_gemm_tn_bf16_launch(dY, (long)ldy, w, dW, (long)ldw, M, N, out_kw, dbias, ws, ws_floats * 4, (hipStream_t)stream);
     int splits, rows_per_split;
     tn_plan(M, N, w.K, ws != nullptr, &splits, &rows_per_split);

@@ -277,7 +277,7 @@ static int g_math_mode = 0;
 using namespace tg;
 
 extern "C" int tg_set_math_mode(int32_t mode) {
-    TG_REQUIRE(mode == 0 || mode == 1, "tg_set_math_mode: 0 = fp32 matrix cores (exact fp32), 1 = bf16 operands / fp32 accumulate");
+    TG_REQUIRE(mode >= 0 && mode <= 2, "tg_set_math_mode: 0 = fp32 matrix cores (exact fp32), 1 = bf16 operands for forward / input-gradient products, 2 = also for weight gradients");
     g_math_mode = mode;
     return 0;
 }

@@ -104,18 +104,17 @@ def gemm_nt(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_st
 
 def set_math_mode(mode):
     """'f32' (exact fp32 matrix cores, default) or 'bf16' (bf16 operands, fp32 accumulate) for the GEMM-shaped kernels."""
-    m = {"f32": 0, "fp32": 0, 0: 0, "bf16": 1, 1: 1}[mode]
+    m = {"f32": 0, "fp32": 0, 0: 0, "bf16": 1, 1: 1, "bf16_all": 2, 2: 2}[mode]
     if _lib.load().tg_set_math_mode(m) != 0:
         raise RuntimeError(_lib.load().tg_last_error().decode())
 
 
 def get_math_mode():
-    return "bf16" if _lib.load().tg_get_math_mode() == 1 else "f32"
+    return ("f32", "bf16", "bf16_all")[_lib.load().tg_get_math_mode()]
 
 
-# In bf16 math mode the weight gradients stay on the fp32 path by default: the transposing bf16 variant is slower at the
+# Math mode "bf16" leaves the weight gradients on the fp32 path: the transposing bf16 variant ("bf16_all") is slower at the
 # shapes of this model (tools/gemm_probe.py) and fp32 weight gradients keep the optimiser input exact.
-BF16_WGRAD = False
 TN_TWO_PASS_ROWS = 32768     # reductions at least this long combine their partials in fp64 (deterministic) instead of atomics
 
 
@@ -131,7 +130,7 @@ def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
     if (M - 1) * dY.stride(0) + N - 1 >= _room(dY):
         raise ValueError("gemm_tn: dY exceeds its tensor")
     ws, nws = None, 0
-    if BF16_WGRAD and _lib.load().tg_get_math_mode() == 1 and M >= 256:
+    if _lib.load().tg_get_math_mode() == 2 and M >= 256:
         nws = (_lib.load().tg_gemm_tn_bf16_ws_bytes(M, N, A.K) + 3) // 4
         ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
     elif M >= TN_TWO_PASS_ROWS:

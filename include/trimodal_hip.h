@@ -31,8 +31,10 @@ const char* tg_last_error(void);
 
 /* Math mode of the GEMM-shaped kernels (process-wide, like cublasSetMathMode):
  *   0 (default): fp32 operands on the f32 matrix cores -- exact fp32 fma chains, parity with the reference to ~1e-6.
- *   1: operands rounded to bf16 (RNE) at the matrix-core feed, fp32 accumulate (v_mfma_f32_16x16x32_bf16); everything in
- *      HBM stays fp32.  The precision BASELINE.json configs[1] names; tolerance 2e-2 forward / 5e-2 gradients. */
+ *   1: forward and input-gradient products (tg_gemm_nt) round their operands to bf16 (RNE) at the matrix-core feed, fp32
+ *      accumulate (v_mfma_f32_16x16x32_bf16); everything in HBM stays fp32, weight gradients stay fp32.  The precision
+ *      BASELINE.json configs[1] names; tolerance 2e-2 forward / 5e-2 gradients.
+ *   2: as 1, and tg_gemm_tn (weight gradients) too when given the bf16 workspace. */
 int tg_set_math_mode(int32_t mode);
 int tg_get_math_mode(void);
 
