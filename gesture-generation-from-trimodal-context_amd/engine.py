@@ -77,6 +77,17 @@ class GeneratorEngine(_Engine):
         self.p_drop = module.dropout_prob
         self.pose_dim = module.pose_dim
         self.T = module.pre_length + module.gen_length
+        # input_context / z variants (multimodal_context_net.py:71-97): columns of the GRU input are
+        # [pre_seq (D+1) | audio 32 | text 32 | z 16] with the absent blocks removed
+        ctx = module.input_context
+        assert ctx in ("both", "audio", "text", "none"), ctx
+        self.use_audio, self.use_text = ctx in ("both", "audio"), ctx in ("both", "text")
+        self.z_mode = None if not module.z_obj else ("speaker" if module.speaker_embedding is not None else "random")
+        D = self.pose_dim
+        self.c_audio = D + 1
+        self.c_text = self.c_audio + 32 * self.use_audio
+        self.c_z = self.c_text + 32 * self.use_text
+        self.in_size = self.c_z + (16 if self.z_mode else 0)
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, pre_seq, in_text, in_audio, vid, *, training, groups=1, save=False, inject=None, tag="g"):
@@ -87,33 +98,80 @@ class GeneratorEngine(_Engine):
         H, D = self.H, self.pose_dim
         assert T == self.T and pre_seq.shape == (Bs, T, D + 1) and Bs % groups == 0
         tp = {"Bs": Bs, "groups": groups, "training": training}
-        in_size = 32 + 32 + D + 1 + 16
-        in_data = L.empty(Bs, T, in_size, like=in_audio)
+        in_size = self.in_size
+        in_data = L.empty(Bs, T, in_size, like=pre_seq)
+        fork = L.Fork(pre_seq.device, enabled=self.use_side_stream and self.use_audio)
+        # The reference evaluates BOTH encoders for 'audio' and 'text' (:117-123) and discards one.  The discarded text encoder
+        # has no state, so it is skipped; the discarded audio encoder moves its BatchNorm running statistics in train mode, so
+        # for 'text' it still runs (forward only, into a scratch buffer) to keep the state_dict identical after training.
+        if self.use_audio:
+            self._audio_fwd(P, Bf, in_audio, in_data, self.c_audio, tp, fork, training, groups)
+        elif training and self.use_text:
+            self._audio_fwd(P, Bf, in_audio, L.empty(Bs, T, 32, like=pre_seq), 0, {}, fork, training, groups)
+        if self.use_text:
+            self._text_fwd(P, in_text, in_data, tp, training, inject, tag)
+        mu = logvar = z = None
+        if self.z_mode == "speaker":
+            # ---- speaker embedding -> mu/logvar -> reparameterised z (:125-131; embedding_net.py:10-13)
+            assert vid is not None
+            se = ops.embed_gather(P["speaker_embedding.0.weight"], vid.contiguous(), L.empty(Bs, 16, like=pre_seq))
+            zc = L.linear_fwd(se, P["speaker_embedding.1.weight"], P["speaker_embedding.1.bias"])
+            mu = L.linear_fwd(zc, P["speaker_mu.weight"], P["speaker_mu.bias"])
+            logvar = L.linear_fwd(zc, P["speaker_logvar.weight"], P["speaker_logvar.bias"])
+            if inject is not None and f"{tag}.eps" in inject:
+                eps = inject[f"{tag}.eps"].contiguous()
+            else:
+                eps = ops.normal(torch.empty_like(mu), self.rng.state, self.rng.site(f"{tag}.eps"))
+            z = ops.reparam_fwd(mu, logvar, eps, torch.empty_like(mu))
+            tp.update(se=se, zc=zc, mu=mu, logvar=logvar, eps=eps, vid=vid)
+        elif self.z_mode == "random":
+            # ---- plain noise vector (:132-134)
+            if inject is not None and f"{tag}.z" in inject:
+                z = inject[f"{tag}.z"].contiguous()
+            else:
+                z = ops.normal(L.empty(Bs, 16, like=pre_seq), self.rng.state, self.rng.site(f"{tag}.z"))
 
-        # ---- WavEncoder: 4 strided convs as window GEMMs, BN + LeakyReLU(0.3) between (:9-28)
-        # The stacked forward calls of one GAN iteration see the SAME audio and the encoder has no dropout, so when
-        # in_audio holds one group's rows the encoder runs once: identical batch statistics, running stats updated
-        # `groups` times (tg_bn_train_stats repeats), output replicated per group.
+        # ---- concat [pre_seq | audio | text | z repeated over time] (:139-153)
+        fork.join()
+        flat_in = in_data.view(Bs * T, in_size)
+        ops.copy2d(pre_seq.contiguous().view(Bs * T, D + 1), flat_in[:, :D + 1])
+        if z is not None:
+            ops.repeat_rows(z, flat_in[:, self.c_z:], Bs, T)
+
+        # ---- 4-layer bidirectional GRU, sum of directions, output MLP (:155-158)
+        y, gtape = L.gru_stack_fwd(in_data, P, "gru", self.n_layers, H, p_drop=self.p_drop, training=training, rng=self.rng,
+                                   save=save, inject=inject, tag=tag)
+        o = ops.add_halves(y, L.empty(Bs * T, H, like=y))
+        h1 = L.linear_fwd(o, P["out.0.weight"], P["out.0.bias"])            # LeakyReLU(True) == identity (README.md:122)
+        out = L.linear_fwd(h1, P["out.2.weight"], P["out.2.bias"]).view(Bs, T, D)
+        tp.update(in_text=in_text, gru=gtape, o=o, h1=h1, in_size=in_size)
+        return {"out": out, "z": z, "mu": mu, "logvar": logvar, "in_data": in_data, "tape": tp if save else None}
+
+    def _audio_fwd(self, P, Bf, in_audio, in_data, ca, tp, fork, training, groups):
+        """WavEncoder: 4 strided convs as window GEMMs, BN + LeakyReLU(0.3) between (:9-28) -> in_data[:, :, audio columns].
+        The stacked forward calls of one GAN iteration see the SAME audio and the encoder has no dropout, so when
+        in_audio holds one group's rows the encoder runs once: identical batch statistics, running stats updated
+        `groups` times (tg_bn_train_stats repeats), output replicated per group."""
+        Bs, T, in_size = in_data.shape
         fe = "audio_encoder.feat_extractor"
         Ba = in_audio.shape[0]
         shared = Ba != Bs
         assert Ba == Bs or Ba * groups == Bs, (Ba, Bs, groups)
         x = in_audio.contiguous().view(Ba, -1, 1)
         wav = []
-        fork = L.Fork(in_audio.device, enabled=self.use_side_stream)
         fork.keep(x, in_data)
         fork.__enter__()                 # audio encoder on the side stream, text encoder + speaker path on the main one
         for idx, Co, Ci, stride, pad in WAV_CONVS:
             wp = L.pack_conv_weight(P[f"{fe}.{idx}.weight"])
             last = idx == 9
-            out = in_data[:, :, D + 1:D + 33] if (last and not shared) else None
+            out = in_data[:, :, ca:ca + 32] if (last and not shared) else None
             c = L.conv_fwd(x, wp, P[f"{fe}.{idx}.bias"], WAV_KW, stride=stride, pad=pad, out=out)
             if last:
                 assert c.shape[1] == T, f"audio length gives {c.shape[1]} frames, expected {T}"
                 wav.append((x, None, None))
                 if shared:
                     for g in range(groups):
-                        ops.copy2d(c.view(Ba * T, 32), in_data[g * Ba:(g + 1) * Ba].view(Ba * T, in_size)[:, D + 1:D + 33])
+                        ops.copy2d(c.view(Ba * T, 32), in_data[g * Ba:(g + 1) * Ba].view(Ba * T, in_size)[:, ca:ca + 32])
                 break
             y, st = L.bn_fwd(c, P[f"{fe}.{idx + 1}.weight"], P[f"{fe}.{idx + 1}.bias"], Bf[f"{fe}.{idx + 1}.running_mean"],
                              Bf[f"{fe}.{idx + 1}.running_var"], Bf[f"{fe}.{idx + 1}.num_batches_tracked"],
@@ -124,10 +182,12 @@ class GeneratorEngine(_Engine):
         fork.__exit__(None, None, None)
         tp["wav"], tp["wav_shared"] = wav, shared
 
-        # ---- TextEncoderTCN (:31-61, model/tcn.py)
+    def _text_fwd(self, P, in_text, in_data, tp, training, inject, tag):
+        """TextEncoderTCN (:31-61, model/tcn.py) -> in_data[:, :, text columns]."""
+        Bs, T, in_size = in_data.shape
         te = "text_encoder"
         E = P[f"{te}.embedding.weight"].shape[1]
-        emb = ops.embed_gather(P[f"{te}.embedding.weight"], in_text.contiguous().view(-1), L.empty(Bs, T, E, like=in_audio))
+        emb = ops.embed_gather(P[f"{te}.embedding.weight"], in_text.contiguous().view(-1), L.empty(Bs, T, E, like=in_data))
         emb_mask = self._mask(f"{tag}.emb_drop", emb, 0.1, inject) if training else None
         cur = ops.mul(emb, emb_mask, torch.empty_like(emb)) if emb_mask is not None else emb
         tcn = []
@@ -150,34 +210,7 @@ class GeneratorEngine(_Engine):
             cur = y
         tp["tcn"], tp["emb_mask"], tp["text_x"] = tcn, emb_mask, cur
         L.linear_fwd(cur.view(Bs * T, -1), P[f"{te}.decoder.weight"], P[f"{te}.decoder.bias"],
-                     out=in_data.view(Bs * T, in_size)[:, D + 33:D + 65])
-
-        # ---- speaker embedding -> mu/logvar -> reparameterised z (:125-131; embedding_net.py:10-13)
-        se = ops.embed_gather(P["speaker_embedding.0.weight"], vid.contiguous(), L.empty(Bs, 16, like=in_audio))
-        zc = L.linear_fwd(se, P["speaker_embedding.1.weight"], P["speaker_embedding.1.bias"])
-        mu = L.linear_fwd(zc, P["speaker_mu.weight"], P["speaker_mu.bias"])
-        logvar = L.linear_fwd(zc, P["speaker_logvar.weight"], P["speaker_logvar.bias"])
-        if inject is not None and f"{tag}.eps" in inject:
-            eps = inject[f"{tag}.eps"].contiguous()
-        else:
-            eps = ops.normal(torch.empty_like(mu), self.rng.state, self.rng.site(f"{tag}.eps"))
-        z = ops.reparam_fwd(mu, logvar, eps, torch.empty_like(mu))
-        tp.update(se=se, zc=zc, mu=mu, logvar=logvar, eps=eps, vid=vid)
-
-        # ---- concat [pre_seq | audio | text | z repeated over time] (:139-153)
-        fork.join()
-        flat_in = in_data.view(Bs * T, in_size)
-        ops.copy2d(pre_seq.contiguous().view(Bs * T, D + 1), flat_in[:, :D + 1])
-        ops.repeat_rows(z, flat_in[:, D + 65:], Bs, T)
-
-        # ---- 4-layer bidirectional GRU, sum of directions, output MLP (:155-158)
-        y, gtape = L.gru_stack_fwd(in_data, P, "gru", self.n_layers, H, p_drop=self.p_drop, training=training, rng=self.rng,
-                                   save=save, inject=inject, tag=tag)
-        o = ops.add_halves(y, L.empty(Bs * T, H, like=y))
-        h1 = L.linear_fwd(o, P["out.0.weight"], P["out.0.bias"])            # LeakyReLU(True) == identity (README.md:122)
-        out = L.linear_fwd(h1, P["out.2.weight"], P["out.2.bias"]).view(Bs, T, D)
-        tp.update(in_text=in_text, gru=gtape, o=o, h1=h1, in_size=in_size)
-        return {"out": out, "z": z, "mu": mu, "logvar": logvar, "in_data": in_data, "tape": tp if save else None}
+                     out=in_data.view(Bs * T, in_size)[:, self.c_text:self.c_text + 32])
 
     # ---------------------------------------------------------------------------------------------- backward
     def backward(self, tp, d_out, d_mu=None, d_logvar=None, *, b0=0, nb=None, on_ready=None):
@@ -204,59 +237,64 @@ class GeneratorEngine(_Engine):
         d_in = L.gru_stack_bwd(dy, tp["gru"], P, G, "gru", self.n_layers, b0=b0, nb=nb, fork=fork)      # (nb, T, in_size)
         d_in2 = d_in.view(M, in_size)
 
-        # speaker path
-        dz = ops.sum_rows(d_in2[:, D + 65:], L.empty(nb, 16, like=d_in), nb, T)
-        dmu = d_mu.clone() if d_mu is not None else torch.zeros_like(dz)
-        dlv = d_logvar.clone() if d_logvar is not None else torch.zeros_like(dz)
-        ops.reparam_bwd(dz, tp["logvar"][rows], tp["eps"][rows], dmu, dlv)
-        zc = tp["zc"][rows]
-        dzc = L.linear_bwd(dmu, zc, P["speaker_mu.weight"], G["speaker_mu.weight"], G["speaker_mu.bias"])
-        L.linear_bwd(dlv, zc, P["speaker_logvar.weight"], G["speaker_logvar.weight"], G["speaker_logvar.bias"],
-                     dx_out=dzc, accumulate_dx=True)
-        dse = L.linear_bwd(dzc, tp["se"][rows], P["speaker_embedding.1.weight"], G["speaker_embedding.1.weight"],
-                           G["speaker_embedding.1.bias"])
-        ops.embed_scatter_add(dse, tp["vid"][rows].contiguous(), G["speaker_embedding.0.weight"])
+        if self.z_mode == "speaker":
+            # speaker path
+            dz = ops.sum_rows(d_in2[:, self.c_z:], L.empty(nb, 16, like=d_in), nb, T)
+            dmu = d_mu.clone() if d_mu is not None else torch.zeros_like(dz)
+            dlv = d_logvar.clone() if d_logvar is not None else torch.zeros_like(dz)
+            ops.reparam_bwd(dz, tp["logvar"][rows], tp["eps"][rows], dmu, dlv)
+            zc = tp["zc"][rows]
+            dzc = L.linear_bwd(dmu, zc, P["speaker_mu.weight"], G["speaker_mu.weight"], G["speaker_mu.bias"])
+            L.linear_bwd(dlv, zc, P["speaker_logvar.weight"], G["speaker_logvar.weight"], G["speaker_logvar.bias"],
+                         dx_out=dzc, accumulate_dx=True)
+            dse = L.linear_bwd(dzc, tp["se"][rows], P["speaker_embedding.1.weight"], G["speaker_embedding.1.weight"],
+                               G["speaker_embedding.1.bias"])
+            ops.embed_scatter_add(dse, tp["vid"][rows].contiguous(), G["speaker_embedding.0.weight"])
 
-        # text encoder
-        te = "text_encoder"
-        d_text = d_in2[:, D + 33:D + 65]
-        dcur = L.linear_bwd(d_text, tp["text_x"][rows].reshape(M, -1), P[f"{te}.decoder.weight"], G[f"{te}.decoder.weight"],
-                            G[f"{te}.decoder.bias"])
-        for i in range(self.n_layers - 1, -1, -1):
-            blk = tp["tcn"][i]
-            d = blk["d"]
-            Cc = dcur.shape[1]
-            dsum = ops.act_mask_bwd(dcur, blk["y"][rows].reshape(M, Cc), None, 0.0, torch.empty_like(dcur))   # relu(out + x)
-            dh = dsum
-            for ci, name in ((1, "conv2"), (0, "conv1")):
-                pre = f"{te}.tcn.network.{i}.{name}"
-                o = blk[f"o{ci}"][rows].reshape(M, -1)
-                m = blk[f"m{ci}"]
-                dc = ops.act_mask_bwd(dh, o, None if m is None else m[rows].reshape(M, -1), 0.0, torch.empty_like(o))
-                dc3 = dc.view(nb, T, -1)
-                xin = blk[f"in{ci}"][rows]
-                v = P[pre + ".weight_v"]
-                dwp = torch.zeros(v.shape[0], 2 * v.shape[1], device=v.device, dtype=v.dtype)
-                ops.gemm_tn(dc, Win.conv(xin, 2, pad=d, dil=d, rows_out=T), dwp, dbias=G[pre + ".bias"])
-                ops.weight_norm_bwd(dwp, v, P[pre + ".weight_g"], G[pre + ".weight_g"], G[pre + ".weight_v"])
-                # dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0]  -> taps (t + d, t) with B = wp^T per tap
-                wT = L.empty(xin.shape[2], 2 * v.shape[0], like=v)
-                ops.permute3(blk[f"wp{ci}"].view(v.shape[0], 2, xin.shape[2]), wT, (2, 1, 0))
-                if ci == 1:
-                    dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, L.empty(M, xin.shape[2], like=dc))
-                else:   # first conv of the block: add into the residual branch gradient
-                    dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, dsum, accumulate=True)
-            dcur = dh
-        em = tp["emb_mask"]
-        demb = ops.mul(dcur, em[rows].reshape(M, -1), torch.empty_like(dcur)) if em is not None else dcur
-        ops.embed_scatter_add(demb, tp["in_text"][rows].contiguous().view(-1), G[f"{te}.embedding.weight"])
+        if self.use_text:
+            # text encoder
+            te = "text_encoder"
+            d_text = d_in2[:, self.c_text:self.c_text + 32]
+            dcur = L.linear_bwd(d_text, tp["text_x"][rows].reshape(M, -1), P[f"{te}.decoder.weight"], G[f"{te}.decoder.weight"],
+                                G[f"{te}.decoder.bias"])
+            for i in range(self.n_layers - 1, -1, -1):
+                blk = tp["tcn"][i]
+                d = blk["d"]
+                Cc = dcur.shape[1]
+                dsum = ops.act_mask_bwd(dcur, blk["y"][rows].reshape(M, Cc), None, 0.0, torch.empty_like(dcur))   # relu(out + x)
+                dh = dsum
+                for ci, name in ((1, "conv2"), (0, "conv1")):
+                    pre = f"{te}.tcn.network.{i}.{name}"
+                    o = blk[f"o{ci}"][rows].reshape(M, -1)
+                    m = blk[f"m{ci}"]
+                    dc = ops.act_mask_bwd(dh, o, None if m is None else m[rows].reshape(M, -1), 0.0, torch.empty_like(o))
+                    dc3 = dc.view(nb, T, -1)
+                    xin = blk[f"in{ci}"][rows]
+                    v = P[pre + ".weight_v"]
+                    dwp = torch.zeros(v.shape[0], 2 * v.shape[1], device=v.device, dtype=v.dtype)
+                    ops.gemm_tn(dc, Win.conv(xin, 2, pad=d, dil=d, rows_out=T), dwp, dbias=G[pre + ".bias"])
+                    ops.weight_norm_bwd(dwp, v, P[pre + ".weight_g"], G[pre + ".weight_g"], G[pre + ".weight_v"])
+                    # dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0]  -> taps (t + d, t) with B = wp^T per tap
+                    wT = L.empty(xin.shape[2], 2 * v.shape[0], like=v)
+                    ops.permute3(blk[f"wp{ci}"].view(v.shape[0], 2, xin.shape[2]), wT, (2, 1, 0))
+                    if ci == 1:
+                        dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, L.empty(M, xin.shape[2], like=dc))
+                    else:   # first conv of the block: add into the residual branch gradient
+                        dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, dsum, accumulate=True)
+                dcur = dh
+            em = tp["emb_mask"]
+            demb = ops.mul(dcur, em[rows].reshape(M, -1), torch.empty_like(dcur)) if em is not None else dcur
+            ops.embed_scatter_add(demb, tp["in_text"][rows].contiguous().view(-1), G[f"{te}.embedding.weight"])
         fork.join()        # the GRU weight gradients ran beside the recurrences and the text-encoder backward
         ready(("out", "gru"))
         ready(("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder"))
 
+        if not self.use_audio:
+            ready(("audio_encoder",))
+            return None
         # wav encoder
         fe = "audio_encoder.feat_extractor"
-        dyw = d_in[:, :, D + 1:D + 33]                      # (nb, 34, 32) strided view
+        dyw = d_in[:, :, self.c_audio:self.c_audio + 32]                      # (nb, 34, 32) strided view
         wrow0 = 0 if tp["wav_shared"] else b0              # shared audio: the encoder ran once on the group's rows
         wgrp = 0 if tp["wav_shared"] else grp
         wrows = slice(wrow0, wrow0 + nb)

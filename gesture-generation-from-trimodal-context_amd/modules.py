@@ -94,17 +94,26 @@ class PoseGenerator(nn.Module):
         self.gen_length = args.n_poses - args.n_pre_poses
         self.z_obj = z_obj
         self.input_context = args.input_context
-        if self.input_context != "both" or not isinstance(z_obj, vocab.Vocab):
-            raise NotImplementedError("HIP path implements input_context='both' with a speaker Vocab as z_obj "
-                                      "(config/multimodal_context.yml); other variants are not built yet")
-        self.in_size = 32 + 32 + pose_dim + 1
+        if self.input_context == "both":
+            self.in_size = 32 + 32 + pose_dim + 1          # audio_feat + text_feat + last pose + constraint bit
+        elif self.input_context == "none":
+            self.in_size = pose_dim + 1
+        elif self.input_context in ("audio", "text"):
+            self.in_size = 32 + pose_dim + 1
+        else:
+            raise ValueError(f"input_context {self.input_context!r}")
         self.audio_encoder = _WavEncoderParams()
         self.text_encoder = _TextEncoderParams(args, n_words, word_embed_size, word_embeddings, args.dropout_prob)
-        self.z_size = 16
-        self.in_size += self.z_size
-        self.speaker_embedding = nn.Sequential(nn.Embedding(z_obj.n_words, self.z_size), nn.Linear(self.z_size, self.z_size))
-        self.speaker_mu = nn.Linear(self.z_size, self.z_size)
-        self.speaker_logvar = nn.Linear(self.z_size, self.z_size)
+        self.speaker_embedding = None
+        if self.z_obj:
+            self.z_size = 16
+            self.in_size += self.z_size
+            if isinstance(self.z_obj, vocab.Vocab):
+                self.speaker_embedding = nn.Sequential(nn.Embedding(z_obj.n_words, self.z_size),
+                                                       nn.Linear(self.z_size, self.z_size))
+                self.speaker_mu = nn.Linear(self.z_size, self.z_size)
+                self.speaker_logvar = nn.Linear(self.z_size, self.z_size)
+            # else: z is a plain random vector (multimodal_context_net.py:95-96)
         self.hidden_size = args.hidden_size
         self.n_layers = args.n_layers
         self.dropout_prob = args.dropout_prob
@@ -123,7 +132,7 @@ class PoseGenerator(nn.Module):
         return self._engine
 
     def forward(self, pre_seq, in_text, in_audio, vid_indices=None):
-        assert vid_indices is not None
+        assert vid_indices is not None or self.speaker_embedding is None
         eng = self.engine
         eng.rng.advance()            # every call draws fresh dropout masks / eps (the trainer advances once per iteration itself)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
@@ -137,7 +146,7 @@ class PoseGenerator(nn.Module):
                 tp = res["tape"]
                 dm = d_mu if d_mu is not None else None
                 dl = d_lv if d_lv is not None else None
-                if d_z is not None:
+                if d_z is not None and tp.get("eps") is not None:
                     from . import ops
                     dm = torch.zeros_like(res["mu"]) if dm is None else dm.contiguous().clone()
                     dl = torch.zeros_like(res["mu"]) if dl is None else dl.contiguous().clone()

@@ -61,6 +61,11 @@ class GanTrainer:
         self.gen, self.dis = generator, discriminator
         self.G, self.D = generator.engine, discriminator.engine
         self.hp = hyper_params(args)
+        # z_type variants (train_gan.py:59-84): 'speaker' = shuffled-speaker forward + div_reg + KLD, 'random' = second noise
+        # forward + div_reg, anything else (or loss_reg_weight == 0) = regression (+ GAN) loss only
+        self.z_type = getattr(args, "z_type", "speaker")
+        assert (self.G.z_mode == "speaker") == (self.z_type == "speaker"), "args.z_type does not match the generator's z_obj"
+        self.use_reg = self.z_type in ("speaker", "random") and self.hp["loss_reg_weight"] > 0.0 and self.G.z_mode is not None
         self.g_opt = FusedAdam(self.G, lr=self.hp["learning_rate"], betas=(0.5, 0.999))
         self.d_opt = FusedAdam(self.D, lr=self.hp["learning_rate"] * self.hp["discriminator_lr_weight"], betas=(0.5, 0.999))
         self.grad_sync = grad_sync          # ddp.GradSync or None
@@ -97,20 +102,25 @@ class GanTrainer:
         G.rng.advance(); D.rng.advance()
         target = target.contiguous().float()
         pre = ops.make_pre_seq(target, torch.empty(B, target.shape[1], target.shape[2] + 1, device=dev), self.hp["n_pre_poses"])
-        if inject is not None and "perm" in inject:
-            perm = inject["perm"].to(dev).long().contiguous()
-        else:
-            perm = ops.randperm(torch.empty(B, dtype=torch.int64, device=dev), G.rng.state, G.rng.site("perm"))
-        vid = vid.contiguous()
-        vid_r = ops.gather_i64(vid, perm, torch.empty_like(vid))
-        tags = ["g1", "g2", "g3"] if post else ["g2", "g3"]
+        speaker = self.G.z_mode == "speaker"
+        tags = (["g1"] if post else []) + ["g2"] + (["g3"] if self.use_reg else [])
         ng, i2 = len(tags), tags.index("g2")
-        pre_s = pre.repeat(ng, 1, 1)                                   # data movement only
-        text_s = in_text.contiguous().repeat(ng, 1)
-        vid_s = torch.cat([vid] * (ng - 1) + [vid_r])
+        vid_s = None
+        if speaker:
+            vid = vid.contiguous()
+            parts = [vid] * (ng - 1 if self.use_reg else ng)
+            if self.use_reg:
+                if inject is not None and "perm" in inject:
+                    perm = inject["perm"].to(dev).long().contiguous()
+                else:
+                    perm = ops.randperm(torch.empty(B, dtype=torch.int64, device=dev), G.rng.state, G.rng.site("perm"))
+                parts.append(ops.gather_i64(vid, perm, torch.empty_like(vid)))
+            vid_s = torch.cat(parts) if len(parts) > 1 else parts[0]
+        pre_s = pre.repeat(ng, 1, 1) if ng > 1 else pre                # data movement only
+        text_s = in_text.contiguous().repeat(ng, 1) if ng > 1 else in_text.contiguous()
         res = G.forward(pre_s, text_s, in_audio.float(), vid_s, training=True, groups=ng, save=True,
                         inject=_stack_inject(inject, tags, "g"), tag="g")
-        sl = lambda t, i: t[i * B:(i + 1) * B]
+        sl = lambda t, i: None if t is None else t[i * B:(i + 1) * B]
         st = dict(B=B, target=target, res=res, i2=i2, ng=ng, out2=sl(res["out"], i2), out3=sl(res["out"], ng - 1),
                   z2=sl(res["z"], i2), z3=sl(res["z"], ng - 1), mu2=sl(res["mu"], i2), lv2=sl(res["logvar"], i2))
         if post:
@@ -139,13 +149,22 @@ class GanTrainer:
         out2 = st["out2"].contiguous()
         dres = D.forward(out2, training=True, groups=1, save=post, inject=inject, tag="d_out")   # runs in warm-up too (:55)
         d_out = torch.empty_like(out2)
-        d_mu, d_lv = torch.empty_like(st["mu2"]), torch.empty_like(st["mu2"])
         d_logit = torch.empty(B, device=dev)
         st["g_scalars"] = torch.empty(5, device=dev)
-        ops.gan_g_loss(out2, st["target"], st["out3"].contiguous(), st["z2"].contiguous(), st["z3"].contiguous(),
-                       st["mu2"].contiguous(), st["lv2"].contiguous(), dres["logit"].view(-1),
-                       (hp["loss_regression_weight"], hp["loss_kld_weight"], hp["loss_reg_weight"], hp["loss_gan_weight"]),
+        # the fused loss kernel covers every z_type through its weights: terms the reference leaves out (:59-84) get weight 0
+        # and neutral operands (out_rand = out, z_rand = z, mu = logvar = 0)
+        speaker_terms = self.G.z_mode == "speaker" and self.use_reg
+        zero_z = torch.zeros(B, 16, device=dev)
+        mu2, lv2 = (st["mu2"].contiguous(), st["lv2"].contiguous()) if speaker_terms else (zero_z, zero_z)
+        z2, z3 = (st["z2"].contiguous(), st["z3"].contiguous()) if self.use_reg else (zero_z, zero_z)
+        out3 = st["out3"].contiguous() if self.use_reg else out2
+        d_mu, d_lv = torch.empty_like(zero_z), torch.empty_like(zero_z)
+        ops.gan_g_loss(out2, st["target"], out3, z2, z3, mu2, lv2, dres["logit"].view(-1),
+                       (hp["loss_regression_weight"], hp["loss_kld_weight"] if speaker_terms else 0.0,
+                        hp["loss_reg_weight"] if self.use_reg else 0.0, hp["loss_gan_weight"]),
                        post, torch.empty(3 * B, device=dev), st["g_scalars"], d_out, d_mu, d_lv, d_logit)
+        if not speaker_terms:
+            d_mu = d_lv = None
         if post:
             d_poses = D.backward(dres["tape"], d_logit.view(B, 1), param_grads=False, need_dposes=True)
             ops.axpy(d_poses, d_out, 1.0, accumulate=True)

@@ -207,20 +207,31 @@ def linear(st, prefix, x):
 
 
 def generator_forward(st, pre_seq, in_text, in_audio, vid, *, training, rand: Rand, tag="g",
-                      n_layers=4, hidden=300, p_drop=0.3, fast_gru=False, return_parts=False):
-    """PoseGenerator.forward, input_context='both', z_obj=speaker Vocab
-    (multimodal_context_net.py:110-160).  Returns (out, z, mu, logvar)."""
-    audio_feat = wav_encoder(st, in_audio, training)
-    text_feat = text_encoder(st, in_text, n_layers, p_drop, training, rand, tag)
-    assert audio_feat.shape[1] == text_feat.shape[1]
-    zc = linear(st, "speaker_embedding.1", st["speaker_embedding.0.weight"][vid])
-    mu = linear(st, "speaker_mu", zc)
-    logvar = linear(st, "speaker_logvar", zc)
-    std = torch.exp(0.5 * logvar)                       # embedding_net.py:10-13 (no train/eval switch)
-    eps = rand.normal(f"{tag}.eps", tuple(std.shape), std.dtype)
-    z = mu + eps * std
-    in_data = torch.cat((pre_seq, audio_feat, text_feat), dim=2)
-    in_data = torch.cat((in_data, z.unsqueeze(1).repeat(1, in_data.shape[1], 1)), dim=2)
+                      n_layers=4, hidden=300, p_drop=0.3, fast_gru=False, return_parts=False,
+                      input_context="both", z_mode="speaker"):
+    """PoseGenerator.forward (multimodal_context_net.py:110-160).  input_context 'both' | 'audio' | 'text' | 'none'
+    (:71-76, :139-148); z_mode 'speaker' (z_obj = speaker Vocab) | 'random' (plain noise, :132-134) | None.
+    Returns (out, z, mu, logvar)."""
+    audio_feat = text_feat = None
+    if input_context != "none":                 # both encoders are evaluated for 'audio' and 'text' too (:117-123); the unused
+        audio_feat = wav_encoder(st, in_audio, training)        # audio encoder still moves its BatchNorm running statistics
+        if input_context == "text":
+            audio_feat = None
+    if input_context in ("both", "text"):       # (an unused text encoder has no state: only its dropout draws are skipped)
+        text_feat = text_encoder(st, in_text, n_layers, p_drop, training, rand, tag)
+    mu = logvar = z = None
+    if z_mode == "speaker":
+        zc = linear(st, "speaker_embedding.1", st["speaker_embedding.0.weight"][vid])
+        mu = linear(st, "speaker_mu", zc)
+        logvar = linear(st, "speaker_logvar", zc)
+        std = torch.exp(0.5 * logvar)                       # embedding_net.py:10-13 (no train/eval switch)
+        eps = rand.normal(f"{tag}.eps", tuple(std.shape), std.dtype)
+        z = mu + eps * std
+    elif z_mode == "random":
+        z = rand.normal(f"{tag}.z", (in_text.shape[0], 16), pre_seq.dtype)
+    in_data = torch.cat([t for t in (pre_seq, audio_feat, text_feat) if t is not None], dim=2)
+    if z is not None:
+        in_data = torch.cat((in_data, z.unsqueeze(1).repeat(1, in_data.shape[1], 1)), dim=2)
     g = gru_stack(in_data, st, "gru", n_layers, p_drop, training, rand, tag, fast=fast_gru)
     g = g[:, :, :hidden] + g[:, :, hidden:]
     o = linear(st, "out.0", g.reshape(-1, hidden))      # LeakyReLU(True) == identity between the two
@@ -304,29 +315,38 @@ def sync_aliases(st):
 
 
 def gan_losses_g(out, target, d_out, out_rand, z, z_rand, mu, logvar, epoch, hp=HP):
-    """Generator-side losses, train_eval/train_gan.py:53-89.  Returns (loss, parts)."""
+    """Generator-side losses, train_eval/train_gan.py:53-89.  out_rand None = no diversity term (z_type neither 'speaker'
+    nor 'random', or loss_reg_weight == 0); mu None = no KLD (z_type != 'speaker').  Returns (loss, parts)."""
     beta = 0.1
     huber = F.smooth_l1_loss(out / beta, target / beta) * beta
     gen_error = -torch.mean(torch.log(d_out + 1e-8))
-    beta = 0.05
-    pose_l1 = F.smooth_l1_loss(out / beta, out_rand.detach() / beta, reduction="none") * beta
-    pose_l1 = pose_l1.sum(dim=1).sum(dim=1)
-    z_l1 = (z.detach() - z_rand.detach()).abs().mean(1)
-    div_reg = -(pose_l1 / (z_l1 + 1.0e-5))
-    div_reg = torch.clamp(div_reg, min=-1000).mean()
-    kld = -0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
-    loss = hp["loss_regression_weight"] * huber + hp["loss_kld_weight"] * kld + hp["loss_reg_weight"] * div_reg
+    loss = hp["loss_regression_weight"] * huber
+    div_reg = kld = torch.zeros(())
+    if out_rand is not None:
+        beta = 0.05
+        pose_l1 = F.smooth_l1_loss(out / beta, out_rand.detach() / beta, reduction="none") * beta
+        pose_l1 = pose_l1.sum(dim=1).sum(dim=1)
+        z_l1 = (z.detach() - z_rand.detach()).abs().mean(1)
+        div_reg = -(pose_l1 / (z_l1 + 1.0e-5))
+        div_reg = torch.clamp(div_reg, min=-1000).mean()
+        loss = loss + hp["loss_reg_weight"] * div_reg
+        if mu is not None:
+            kld = -0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
+            loss = loss + hp["loss_kld_weight"] * kld
     if epoch > hp["loss_warmup"]:
         loss = loss + hp["loss_gan_weight"] * gen_error
     return loss, dict(huber=huber, gen=gen_error, div_reg=div_reg, kld=kld)
 
 
 def train_iter_gan(gst, dst, g_opt, d_opt, epoch, in_text, in_audio, target, vid, rand: Rand, hp=HP,
-                   fast_gru=False, want_grads=False):
+                   fast_gru=False, want_grads=False, input_context="both", z_type="speaker"):
     """One GAN iteration, same order of operations as train_eval/train_gan.py:13-103.
+    z_type 'speaker' | 'random' | anything else ('none'): train.py:82-87 picks the generator's z_obj from it.
     ``gst``/``dst`` are state dicts (modified in place: params, BN buffers); ``g_opt``/``d_opt`` are
     Adam state dicts.  Returns the reference's loss dict (plus grads when asked)."""
-    kw = dict(n_layers=hp["n_layers"], hidden=hp["hidden_size"], p_drop=hp["dropout_prob"], fast_gru=fast_gru)
+    z_mode = z_type if z_type in ("speaker", "random") else None
+    kw = dict(n_layers=hp["n_layers"], hidden=hp["hidden_size"], p_drop=hp["dropout_prob"], fast_gru=fast_gru,
+              input_context=input_context, z_mode=z_mode)
     gp, dp = unique_params(gst), unique_params(dst)
     for p in list(gp.values()) + list(dp.values()):
         p.requires_grad_(True)
@@ -349,9 +369,11 @@ def train_iter_gan(gst, dst, g_opt, d_opt, epoch, in_text, in_audio, target, vid
 
     out, z, mu, logvar = generator_forward(gst, pre_seq, in_text, in_audio, vid, training=True, rand=rand, tag="g2", **kw)
     d_out = discriminator_forward(dst, out, training=True, rand=rand, tag="d_out", fast_gru=fast_gru)   # :55 always
-    rand_idx = rand.perm("perm", vid.shape[0])                           # :62-63
-    out_r, z_r, _, _ = generator_forward(gst, pre_seq, in_text, in_audio, vid[rand_idx], training=True, rand=rand,
-                                         tag="g3", **kw)
+    out_r = z_r = None
+    if z_mode is not None and hp["loss_reg_weight"] > 0.0:               # :59-70
+        rand_vids = vid[rand.perm("perm", vid.shape[0])] if z_mode == "speaker" else None
+        out_r, z_r, _, _ = generator_forward(gst, pre_seq, in_text, in_audio, rand_vids, training=True, rand=rand,
+                                             tag="g3", **kw)
     loss, parts = gan_losses_g(out, target, d_out, out_r, z, z_r, mu, logvar, epoch, hp)
     ggr = torch.autograd.grad(loss, list(gp.values()), allow_unused=True)
     if want_grads:
@@ -560,9 +582,11 @@ def _gru(st, prefix, n_in, hidden, layers, gen):
             st[f"{prefix}.bias_hh_l{l}{sfx}"] = _u(gen, (3 * hidden,), bound)
 
 
-def make_generator_state(seed=0, n_words=512, n_speakers=17, hidden=300, layers=4, pose_dim=27, embed=300):
+def make_generator_state(seed=0, n_words=512, n_speakers=17, hidden=300, layers=4, pose_dim=27, embed=300,
+                         input_context="both", z_mode="speaker"):
     """Deterministic PoseGenerator state_dict with the reference's exact key set (117 keys
-    at 4 layers).  Distributions follow torch defaults in scale; values are this build's own."""
+    at 4 layers).  Distributions follow torch defaults in scale; values are this build's own.
+    Both encoders are always present (multimodal_context_net.py:78-80); the speaker layers only for z_mode 'speaker'."""
     g = torch.Generator().manual_seed(seed)
     st = OrderedDict()
     fe = "audio_encoder.feat_extractor"
@@ -586,11 +610,13 @@ def make_generator_state(seed=0, n_words=512, n_speakers=17, hidden=300, layers=
                 st[a + s] = st[p + s]
     st["text_encoder.decoder.weight"] = 0.01 * torch.randn(32, hidden, generator=g)
     st["text_encoder.decoder.bias"] = torch.zeros(32)
-    st["speaker_embedding.0.weight"] = torch.randn(n_speakers, 16, generator=g)
-    _lin(st, "speaker_embedding.1", 16, 16, g)
-    _lin(st, "speaker_mu", 16, 16, g)
-    _lin(st, "speaker_logvar", 16, 16, g)
-    _gru(st, "gru", 32 + 32 + pose_dim + 1 + 16, hidden, layers, g)
+    if z_mode == "speaker":
+        st["speaker_embedding.0.weight"] = torch.randn(n_speakers, 16, generator=g)
+        _lin(st, "speaker_embedding.1", 16, 16, g)
+        _lin(st, "speaker_mu", 16, 16, g)
+        _lin(st, "speaker_logvar", 16, 16, g)
+    n_ctx = {"both": 64, "audio": 32, "text": 32, "none": 0}[input_context]
+    _gru(st, "gru", n_ctx + pose_dim + 1 + (16 if z_mode else 0), hidden, layers, g)
     _lin(st, "out.0", hidden // 2, hidden, g)
     _lin(st, "out.2", pose_dim, hidden // 2, g)
     return st

@@ -45,6 +45,37 @@ def test_train_iter_matches_fp64_oracle_with_dropout(pkg, dev):
     assert worst < 1e-4, worst
 
 
+@pytest.mark.parametrize("ctx,zt", [("audio", "random"), ("text", "none"), ("none", "speaker"), ("text", "speaker"), ("both", "random"),
+                                    ("none", "none")])
+def test_generator_variants_match_fp64_oracle(pkg, dev, ctx, zt):
+    """The other input_context / z_type configurations (multimodal_context_net.py:71-97, train_gan.py:59-84); the oracle's
+    variants are pinned to the real reference by tests/test_oracle_golden.py::test_g6_generator_variants_match_reference.
+    Includes the unused audio encoder's BatchNorm buffers moving for input_context='text' (compared inside the harness)."""
+    worst = run_train_parity(pkg, dev, batch=4, epochs=(0, 11), input_context=ctx, z_type=zt, verbose=True)
+    assert worst < 1e-4, worst
+
+
+def test_variant_module_api_shapes(pkg, dev):
+    """forward() return arity follows the reference: z/mu/logvar are None where the reference returns None (:132-137)."""
+    V, S, B = 64, 9, 3
+    text, audio, vid, poses = O.make_batch(9, B, V, S)
+    pre = O.make_pre_seq(poses, 4).to(dev)
+    for ctx, zt, in_size in (("audio", "random", 28 + 32 + 16), ("text", "none", 28 + 32), ("none", "speaker", 28 + 16)):
+        z_mode = zt if zt != "none" else None
+        gst = O.make_generator_state(5, V, S, input_context=ctx, z_mode=z_mode)
+        args, G, D = build_models(pkg, dev, gst, O.make_discriminator_state(6), V, S, make_args(input_context=ctx, z_type=zt))
+        assert G.in_size == in_size == G.gru.weight_ih_l0.shape[1]
+        G.eval()
+        with torch.no_grad():
+            out, z, mu, lv = G(pre, text.to(dev), audio.to(dev), vid.to(dev) if zt == "speaker" else None)
+        assert out.shape == (B, 34, 27) and bool(torch.isfinite(out).all())
+        assert (z is None) == (zt == "none") and (mu is None) == (zt != "speaker") and (lv is None) == (zt != "speaker")
+        G.train()
+        out, z, mu, lv = G(pre, text.to(dev), audio.to(dev), vid.to(dev) if zt == "speaker" else None)
+        out.square().mean().backward()
+        assert float(G.gru.weight_hh_l0.grad.abs().max()) > 0
+
+
 def test_train_iter_matches_reference_golden(pkg, dev):
     """Replays the dropout masks / eps / permutation recorded from the reference's own train_iter_gan run."""
     from test_oracle_golden import unpack_masks

@@ -109,6 +109,59 @@ def test_g2_train_steps_match_reference():
                 assert int(gst[k]) == int(g["gp/" + k]), k
 
 
+def test_g6_generator_variants_match_reference():
+    """input_context 'audio' | 'text' | 'none' and z_type 'random' | 'none' (multimodal_context_net.py:71-97, train_gan.py:59-84):
+    one reference train_iter_gan per variant, draws replayed into the oracle."""
+    g = load("g6_variants.npz")
+    V, S, epoch = int(g["n_words"]), int(g["n_speakers"]), int(g["epoch"])
+    text, audio, vid, poses = O.make_batch(int(g["batch_seed"]), 4, V, S)
+    sidx = lambda n: sample_idx(n, 256)
+    for var in g["variants"]:
+        ctx, zt = str(var).split("/")
+        key = f"{ctx}_{zt}"
+        z_mode = zt if zt in ("speaker", "random") else None
+        gst = O.make_generator_state(int(g["g_seed"]), V, S, input_context=ctx, z_mode=z_mode)
+        dst = O.make_discriminator_state(int(g["d_seed"]))
+        tags = ["g1", "g2"] + (["g3"] if z_mode else [])
+        inj = {}
+        if g[f"{key}/masks"].size:
+            inj.update(unpack_masks({"mask_shape": g[f"{key}/mask_shape"], "masks": g[f"{key}/masks"]}, tags))
+        for t, e in zip(tags, g[f"{key}/eps"] if zt == "speaker" else []):
+            inj[f"{t}.eps"] = torch.from_numpy(e)
+        for t, z in zip(tags, g[f"{key}/z"] if zt == "random" else []):
+            inj[f"{t}.z"] = torch.from_numpy(z)
+        if g[f"{key}/perm"].size:
+            inj["perm"] = torch.from_numpy(g[f"{key}/perm"])
+        for t in tags:
+            for l in range(3):
+                inj[f"{t}.gru.drop{l}"] = torch.ones(4, 34, 600)
+        for t in ("d_real", "d_fake", "d_out"):
+            for l in range(3):
+                inj[f"{t}.gru.drop{l}"] = torch.ones(4, 28, 128)
+        ret, extra = O.train_iter_gan(gst, dst, {}, {}, epoch, text, audio, poses, vid, O.Rand(inject=inj), want_grads=True,
+                                      input_context=ctx, z_type=zt)
+        assert sorted(ret) == list(g[f"{key}/loss_keys"]), (key, ret)
+        for k, v in zip(g[f"{key}/loss_keys"], g[f"{key}/loss_vals"]):
+            assert abs(ret[k] - v) <= 1e-6 * max(1.0, abs(v)), (key, k, ret[k], v)
+        grad_keys = list(g[f"{key}/grad_keys"])
+        # parameters the reference leaves without a gradient (unused encoder / absent z) have none here either
+        assert sorted(k for k, gr in extra["g_grads"].items() if gr is not None) == grad_keys, key
+        worst = 0.0
+        for k in grad_keys:
+            gr, ref = extra["g_grads"][k], g[f"{key}/gg/{k}"]
+            mine = gr.reshape(-1).numpy()[sidx(gr.numel())]
+            if float(np.abs(ref).max()) < 1e-5:
+                assert float(np.abs(mine).max()) < 1e-4
+                continue
+            worst = max(worst, rel(mine, ref))
+        assert worst < 2e-5, (key, worst)
+        for k in gst:                       # incl. the UNUSED audio encoder's BatchNorm buffers for input_context='text'
+            if "running" in k:
+                assert rel(gst[k], g[f"{key}/gp/{k}"]) < 1e-6, (key, k)
+            elif k.endswith("num_batches_tracked"):
+                assert int(gst[k]) == int(g[f"{key}/gp/{k}"]), (key, k)
+
+
 def test_g5_fgd_matches_reference():
     g = load("g5_fgd.npz")
     ast = O.make_autoencoder_state(int(g["ae_seed"]))
