@@ -168,6 +168,58 @@ def decode_bench(pkg, a, args, G, device, world, rank):
         torch.distributed.destroy_process_group()
 
 
+def ae_bench(pkg, a, args, device, world, rank):
+    """FGD autoencoder training (BASELINE.json configs[4], train_feature_extractor.py:54-97): one step = one Adam iteration
+    of the pose-mode EmbeddingNet on a.batch synthetic clips.  1.04 M MAC/clip forward: launch/latency bound, clips/s only.
+    Replicas only under --gpus N."""
+    fgd = importlib.import_module(PKG + ".fgd")
+    torch.manual_seed(0)
+    net = pkg.EmbeddingNet(args, D, T, None, None, None, mode="pose").to(device)
+    net.train()
+    tr = fgd.AutoencoderTrainer(net)
+    g = torch.Generator().manual_seed(4321 + rank)
+    poses = (0.1 * torch.randn(a.batch, T, D, generator=g)).to(device)
+    graph = None
+    if not a.no_graph:
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                tr.train_iter(poses)
+        torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = tr.train_iter(poses)
+    step = graph.replay if graph is not None else (lambda: tr.train_iter(poses))
+    for _ in range(max(a.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    lv = float((loss if graph is not None else r).item())
+    assert lv == lv and lv < 1e6
+    if rank == 0:
+        print(json.dumps({
+            "metric": "FGD autoencoder training clips/sec", "value": world * a.batch * a.steps / dt, "unit": "clips/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "gesture_autoencoder training iteration (BASELINE.json configs[4]): pose-mode EmbeddingNet fwd+bwd+Adam",
+                       "batch_per_gpu": a.batch, "frames": T, "pose_dim": D, "hipgraph": not a.no_graph, "parallelism": f"replicas x{world}"},
+            "loss": lv}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,7 +227,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="clips per GPU")
     ap.add_argument("--epoch", type=int, default=11, help="> loss_warmup (10) = full GAN iteration")
-    ap.add_argument("--mode", choices=("train", "decode"), default="train",
+    ap.add_argument("--mode", choices=("train", "decode", "ae"), default="train",
                     help="train: GAN training iteration (headline metric); decode: BASELINE.json configs[3], batched 34-frame "
                          "synthesis windows with device-side seed hand-over / cross-fade, pose-frames/sec")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
@@ -210,6 +262,8 @@ def main():
     args, G, Dn = build(pkg, device, seed=0)                 # same seed on every rank: identical replicas
     if a.mode == "decode":
         return decode_bench(pkg, a, args, G, device, world, rank)
+    if a.mode == "ae":
+        return ae_bench(pkg, a, args, device, world, rank)
     trainer = pkg.GanTrainer(G, Dn, args, grad_sync=grad_sync)
     if grad_sync is not None:
         ddp.broadcast_parameters([trainer.G.slab.ensure(), trainer.D.slab.ensure()])

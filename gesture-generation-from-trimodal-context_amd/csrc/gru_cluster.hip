@@ -1,0 +1,251 @@
+// Persistent, cluster-synchronised GRU recurrence for the generator (H <= 320): ONE launch walks all T steps of both
+// directions, replacing T per-step launches (gru.hip) whose ~14 us were mostly dispatch, cold-miss and drain latency.
+//
+// The recurrence of one (direction, batch tile) never needs another tile's data, so there is no grid-wide barrier: the
+// CW = ceil(H / 32) workgroups that share a batch tile form a CLUSTER.  Workgroup m of a cluster owns hidden units
+// [32m, 32m + 32) of all three gates and keeps its 96 rows of W_hh in REGISTERS as MFMA B-fragments for the whole
+// sequence (8 waves = 2 unit tiles x 4 K-slices, 15 float4 per lane).  Per step it
+//   1. waits until every member of its cluster has published h_{t-1}                      (one wave polls CW flag words),
+//   2. loads the h_{t-1} tile [16*MT rows][H] as MFMA A-fragments straight from the exchange buffer (sc1 loads),
+//   3. 60*MT MFMAs per wave, K-slice partials meet in LDS,
+//   4. fused gate epilogue on 4 consecutive hidden units per thread, h_t -> exchange buffer with 16-byte write-through
+//      (sc1) stores, every wave drains its stores, barrier, ONE lane publishes flag = step + 1,
+//   5. y / saved gates go out as plain stores behind the publish (off the critical path).
+// Hand-off protocol: write-through payload + drained flag, sc1 loads on the consumer (MI355X_MICROARCH.md, inter-workgroup
+// visibility, table row 1; cdna_hip_programming.md Guideline 16 R1).  The exchange buffer is double-buffered by step parity and
+// laid out so that every 128-byte line is written whole by one store instruction of one wave.
+// Residency: 512-thread workgroups with > 128 VGPRs -> one per CU; the host launches at most 256 of them (all co-resident on
+// an otherwise in-order stream).  Every spin is bounded: on a timeout the workgroup sets the timeout word, stops waiting for
+// the rest of the sequence and runs to completion (results are then garbage and the host raises on the timeout word).
+#include "common.hpp"
+
+namespace tg {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+constexpr int GC_UNITS = 32;          // hidden units per workgroup
+constexpr int GC_HX = 320;            // exchange-buffer row stride (floats): 10 x 128-byte lines
+constexpr int GC_FLAG_STRIDE = 16;    // flag words per cluster (one 64-byte line)
+constexpr int GC_KS = 4;
+constexpr int GC_PF = 5;              // K chunks (of 16) per wave: covers H <= 320
+constexpr unsigned GC_SPIN_LIMIT = 400000u;
+constexpr unsigned GC_RSRC3 = 0x00020000u;   // gfx9 raw buffer descriptor word 3 (32-bit data format)
+
+__device__ __forceinline__ f32x4 as_f32x4(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+__device__ __forceinline__ u32x4 as_u32x4(f32x4 v) { return __builtin_bit_cast(u32x4, v); }
+
+// flags[cluster * 16 + member] = number of steps that member has published; word 0 of `tmo` = timeout marker
+template <int MT>
+__global__ __launch_bounds__(512) void gru_seq_fwd_cluster_kernel(
+    const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
+    const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
+    float* hx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int CW, int b_pad) {
+    __shared__ __attribute__((aligned(16))) float red[GC_KS][2][MT][3][4][64];
+    const int n_cl = 2 * n_bt;
+    int cl, m;
+    if (n_cl % 8 == 0) {        // members of one cluster on block ids of one residue mod 8: same XCD as observed (speed only)
+        cl = (blockIdx.x % 8) + 8 * ((blockIdx.x / 8) / CW);
+        m = (blockIdx.x / 8) % CW;
+    } else {
+        cl = blockIdx.x / CW;
+        m = blockIdx.x % CW;
+    }
+    const int dir = cl / n_bt, bt = cl % n_bt;
+    const float* whh = dir ? whh1 : whh0;
+    const float* bhh = dir ? bhh1 : bhh0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ut = wave & 1, ks = wave >> 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int b0 = bt * (16 * MT);
+
+    // ---- W_hh slice -> registers (B operand: lane (r16, kq) holds W[g*H + j][16c + 4kq + v])
+    f32x4 w[3][GC_PF];
+    {
+        const int j = m * GC_UNITS + ut * 16 + r16;
+#pragma unroll
+        for (int p = 0; p < GC_PF; ++p) {
+            const int k = 16 * (ks + GC_KS * p) + 4 * kq;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                w[g][p] = (j < H && k < H) ? *reinterpret_cast<const f32x4*>(whh + (long)(g * H + j) * H + k) : z;
+            }
+        }
+    }
+    // ---- epilogue role: thread e < 128*MT finalises row (e / 8) of the tile, hidden units 4*(e % 8) .. +3 of the slice
+    const int e = threadIdx.x;
+    const bool epi = e < 128 * MT;
+    const int row_l = e >> 3, ug = e & 7;
+    const int e_mt = (row_l >> 4) % MT, e_lane = ((row_l & 15) >> 2) * 16 + 4 * (ug & 3), e_i = row_l & 3, e_ut = ug >> 2;
+    const int row = b0 + row_l;
+    const int unit0 = m * GC_UNITS + 4 * ug;
+    const bool e_ok = epi && row < B && unit0 < H;           // H % 4 == 0: the four units are valid together
+    f32x4 bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        bh[g] = (epi && unit0 < H) ? *reinterpret_cast<const f32x4*>(bhh + g * H + unit0) : z;
+    }
+    f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+
+    const long slot_floats = (long)b_pad * GC_HX;
+    __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx, 0, (int)(4 * slot_floats * 4), GC_RSRC3);
+    gu32* my_flag = (gu32*)(flags + cl * GC_FLAG_STRIDE + m);
+    gu32* cl_flags = (gu32*)(flags + cl * GC_FLAG_STRIDE);
+    bool aborted = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int tau = dir ? T - 1 - step : step;
+        // input-side pre-activations do not depend on the recurrence: issue their loads before the wait
+        f32x4 gv[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            gv[g] = e_ok ? *reinterpret_cast<const f32x4*>(gi + dir * gi_ds + ((long)row * T + tau) * (3 * H) + g * H + unit0) : z;
+        }
+        f32x4 acc[MT][3];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (step > 0) {
+            if (wave == 0 && !aborted) {           // ONE wave polls the cluster's flag words, relaxed, bounded
+                unsigned spins = 0;
+                for (;;) {
+                    const unsigned v = lane < CW ? __hip_atomic_load(cl_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    if (__all(v >= (unsigned)step)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > GC_SPIN_LIMIT) {
+                        if (lane == 0) __hip_atomic_store((gu32*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        aborted = true;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();                        // the other waves load only behind the polling wave's barrier
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // compiler ordering only; every load below is sc1
+            const int rslot = (step - 1) & 1;
+            const int off0 = (int)(((long)(dir * 2 + rslot) * slot_floats) * 4);
+            f32x4 a[MT][GC_PF];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int p = 0; p < GC_PF; ++p) {
+                    const int k = 16 * (ks + GC_KS * p) + 4 * kq;          // < 320 = GC_HX always
+                    const int off = off0 + ((b0 + i * 16 + r16) * GC_HX + k) * 4;
+                    a[i][p] = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off, 0, 16));   // aux 16 = sc1
+                }
+#pragma unroll
+            for (int p = 0; p < GC_PF; ++p)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g)
+                            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][p][v], w[g][p][v], acc[i][g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[ks][ut][i][g][q][lane] = acc[i][g][q];
+        __syncthreads();
+
+        f32x4 h = {0.f, 0.f, 0.f, 0.f}, r4, z4, n4, hn4;
+        if (epi) {
+            f32x4 gh[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                f32x4 s = *reinterpret_cast<const f32x4*>(&red[0][e_ut][e_mt][g][e_i][e_lane]);
+#pragma unroll
+                for (int q = 1; q < GC_KS; ++q) s += *reinterpret_cast<const f32x4*>(&red[q][e_ut][e_mt][g][e_i][e_lane]);
+                gh[g] = s;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float hn = gh[2][q] + bh[2][q];
+                const float r = sigmoidf_(gv[0][q] + gh[0][q] + bh[0][q]);
+                const float z = sigmoidf_(gv[1][q] + gh[1][q] + bh[1][q]);
+                const float n = tanhf(gv[2][q] + r * hn);
+                h[q] = (1.f - z) * n + z * hp[q];
+                r4[q] = r; z4[q] = z; n4[q] = n; hn4[q] = hn;
+            }
+            hp = h;
+            // publish h_t: 16-byte write-through store; 8 consecutive lanes write one whole 128-byte line
+            const int woff = (int)((((long)(dir * 2 + (step & 1)) * slot_floats) + (long)row * GC_HX + unit0) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(h), hx_rsrc, woff, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY wave drains its stores before the flag
+        __syncthreads();                                       // (also: `red` is free again)
+        if (threadIdx.x == 0) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e_ok) {                                            // outputs for later kernels: plain stores, off the critical path
+            *reinterpret_cast<f32x4*>(Y + ((long)row * T + tau) * (2 * H) + dir * H + unit0) = h;
+            if (save) {
+                float* sp = save + dir * save_ds + ((long)row * T + tau) * (4 * H) + unit0;
+                *reinterpret_cast<f32x4*>(sp) = r4;
+                *reinterpret_cast<f32x4*>(sp + H) = z4;
+                *reinterpret_cast<f32x4*>(sp + 2 * H) = n4;
+                *reinterpret_cast<f32x4*>(sp + 3 * H) = hn4;
+            }
+        }
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+static void cluster_plan(int B, int H, int* mt, int* n_bt, int* cw) {
+    *cw = cdiv(H, GC_UNITS);
+    *mt = (2 * cdiv(B, 16) * *cw <= 256) ? 1 : 2;
+    *n_bt = cdiv(B, 16 * *mt);
+}
+
+extern "C" int32_t tg_gru_cluster_supported(int32_t B, int32_t H) {
+    if (H > GC_HX || H % 4 != 0 || B <= 0) return 0;
+    int mt, n_bt, cw;
+    cluster_plan(B, H, &mt, &n_bt, &cw);
+    return 2 * n_bt * cw <= 256 && cw <= GC_FLAG_STRIDE;
+}
+
+// workspace: [flag block: 2*n_bt clusters x 16 words + 16 words (timeout word first) ...] [exchange buffer 2 dirs x 2 slots]
+extern "C" int64_t tg_gru_cluster_ws_bytes(int32_t B, int32_t H) {
+    int mt, n_bt, cw;
+    cluster_plan(B, H, &mt, &n_bt, &cw);
+    const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
+    const int64_t b_pad = (int64_t)n_bt * 16 * mt;
+    return flag_words * 4 + 4 * b_pad * GC_HX * 4;
+}
+
+extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
+                                      const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
+                                      void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream) {
+    TG_REQUIRE(gi && w_hh_fwd && w_hh_rev && b_hh_fwd && b_hh_rev && y && ws, "tg_gru_forward_cluster: null pointer");
+    TG_REQUIRE(T > 0 && tg_gru_cluster_supported(B, H), "tg_gru_forward_cluster: unsupported shape B=%d H=%d", B, H);
+    TG_REQUIRE(ws_bytes >= tg_gru_cluster_ws_bytes(B, H), "tg_gru_forward_cluster: workspace too small");
+    TG_REQUIRE(aligned16(gi) && aligned16(w_hh_fwd) && aligned16(w_hh_rev) && aligned16(b_hh_fwd) && aligned16(b_hh_rev) && aligned16(y) &&
+               aligned16(ws) && (save == nullptr || aligned16(save)) && gi_dir_stride % 4 == 0 && save_dir_stride % 4 == 0,
+               "tg_gru_forward_cluster: operands must be 16-byte aligned");
+    int mt, n_bt, cw;
+    cluster_plan(B, H, &mt, &n_bt, &cw);
+    const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
+    hipStream_t s = (hipStream_t)stream;
+    // every polled word is zeroed on the stream before every launch (a memset node under graph capture)
+    if (hipMemsetAsync(ws, 0, (size_t)flag_words * 4, s) != hipSuccess) { set_error("tg_gru_forward_cluster: memset failed"); return 1; }
+    unsigned* tmo = (unsigned*)ws;
+    unsigned* flags = tmo + GC_FLAG_STRIDE;
+    float* hx = (float*)(tmo + flag_words);
+    const int b_pad = n_bt * 16 * mt;
+    dim3 grid(2 * n_bt * cw);
+    if (mt == 1)
+        hipLaunchKernelGGL(gru_seq_fwd_cluster_kernel<1>, grid, dim3(512), 0, s, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd,
+                           b_hh_rev, y, save, (long)save_dir_stride, hx, flags, tmo, B, T, H, n_bt, cw, b_pad);
+    else
+        hipLaunchKernelGGL(gru_seq_fwd_cluster_kernel<2>, grid, dim3(512), 0, s, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd,
+                           b_hh_rev, y, save, (long)save_dir_stride, hx, flags, tmo, B, T, H, n_bt, cw, b_pad);
+    return check_launch("tg_gru_forward_cluster");
+}

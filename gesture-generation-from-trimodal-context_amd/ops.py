@@ -5,6 +5,7 @@ Shape / dtype / bounds checks live in this layer so that a wrong call raises in 
 the GPU (kernels themselves only guard their own tile edges).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -150,6 +151,30 @@ def colsum(X, out, *, accumulate=True):
 
 
 # ------------------------------------------------------------------------------------------------- GRU
+# persistent cluster-synchronised recurrence (csrc/gru_cluster.hip): on by default where it fits; TG_GRU_CLUSTER=0 keeps the
+# per-step launches.  One workspace per (device, B, H): flag words + exchange buffer; its first word is the timeout marker.
+GRU_CLUSTER = os.environ.get("TG_GRU_CLUSTER", "1") != "0"
+_gru_ws = {}
+
+
+def _gru_cluster_ws(dev, B, H):
+    key = (dev, B, H)
+    ws = _gru_ws.get(key)
+    if ws is None:
+        nbytes = _lib.load().tg_gru_cluster_ws_bytes(B, H)
+        ws = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev)
+        _gru_ws[key] = ws
+    return ws
+
+
+def check_async_errors():
+    """Raise if a bounded spin of a persistent kernel timed out since the last check (synchronises; tests, bench, loss read-out)."""
+    for key, ws in _gru_ws.items():
+        if int(ws[0].item()) != 0:
+            ws[0] = 0
+            raise RuntimeError(f"persistent GRU kernel timed out waiting for a cluster member (device, B, H) = {key}; results are invalid")
+
+
 def gru_forward(gi, w_hh, b_hh, y, save):
     """gi: [2, B, T, 3H] contiguous; w_hh/b_hh: (fwd, rev) pairs; y: [B, T, 2H]; save: [2, B, T, 4H] or None."""
     _flat(gi, "gi"); _flat(y, "y")
@@ -160,6 +185,11 @@ def gru_forward(gi, w_hh, b_hh, y, save):
         _flat(w, "w_hh"); _flat(b, "b_hh"); assert tuple(w.shape) == (3 * H, H) and b.numel() == 3 * H
     if save is not None:
         _flat(save, "save"); assert tuple(save.shape) == (2, B, T, 4 * H)
+    if GRU_CLUSTER and H > 64 and _lib.load().tg_gru_cluster_supported(B, H):
+        ws = _gru_cluster_ws(gi.device, B, H)
+        call("tg_gru_forward_cluster", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
+             B * T * 4 * H, C.c_void_p(ws.data_ptr()), ws.numel() * 4, B, T, H, _stream())
+        return y
     call("tg_gru_forward", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
          B * T * 4 * H, B, T, H, _stream())
     return y

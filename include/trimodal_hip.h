@@ -109,6 +109,18 @@ int tg_gru_backward(const float* dy, const float* y, const float* save, int64_t 
                     const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
                     float* dh_scratch, int32_t B, int32_t T, int32_t H, void* stream);
 
+/* Persistent, cluster-synchronised variant of tg_gru_forward for H <= 320 (the generator): ONE launch walks all T
+ * steps of both directions; the workgroups that share a batch tile exchange h_t through `ws` with write-through stores and
+ * per-workgroup flag words, no grid-wide barrier (csrc/gru_cluster.hip).  Same arguments and results as tg_gru_forward.
+ * ws: tg_gru_cluster_ws_bytes(B, H) bytes of device scratch, 16-byte aligned; its first word is a sticky TIMEOUT marker the
+ * kernel sets if a bounded spin expires (results are then invalid): the call zeroes it, read it back after synchronising.
+ * tg_gru_cluster_supported(B, H) != 0 iff the launch fits co-resident on the 256 CUs (B <= 384 at H = 300). */
+int32_t tg_gru_cluster_supported(int32_t B, int32_t H);
+int64_t tg_gru_cluster_ws_bytes(int32_t B, int32_t H);
+int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
+                           const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
+                           void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream);
+
 /* ---- BatchNorm1d, channel-last [rows][C] (model/multimodal_context_net.py:14,17,20,215,218) -------------
  * Training statistics per group: the rows are split into `groups` equal consecutive slabs, each normalised with
  * its own batch statistics (several reference forward calls stacked into one launch); running stats are updated
