@@ -27,6 +27,7 @@ SIGNATURES = {
     "tg_gru_forward": [P, I64, P, P, P, P, P, P, I64, I32, I32, I32, P],
     "tg_gru_backward": [P, P, P, I64, P, P, P, P, I64, P, I32, I32, I32, P],
     "tg_gru_forward_cluster": [P, I64, P, P, P, P, P, P, I64, P, I64, I32, I32, I32, P],
+    "tg_gru_backward_cluster": [P, P, P, I64, P, P, P, P, I64, P, I64, I32, I32, I32, P],
     "tg_bn_train_stats": [P, I32, I32, I32, P, P, P, P, P, P, F32, F32, I32, P],
     "tg_bn_eval_stats": [P, P, I32, F32, P, P, P],
     "tg_bn_apply": [P, P, I32, I32, I32, P, P, P, P, F32, P],
@@ -93,6 +94,10 @@ def load():
     lib.tg_gru_cluster_supported.argtypes = [I32, I32]
     lib.tg_gru_cluster_ws_bytes.restype = C.c_int64
     lib.tg_gru_cluster_ws_bytes.argtypes = [I32, I32]
+    lib.tg_gru_cluster_bwd_supported.restype = C.c_int32
+    lib.tg_gru_cluster_bwd_supported.argtypes = [I32, I32]
+    lib.tg_gru_cluster_bwd_ws_bytes.restype = C.c_int64
+    lib.tg_gru_cluster_bwd_ws_bytes.argtypes = [I32, I32]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: intended
         fn.argtypes = argtypes

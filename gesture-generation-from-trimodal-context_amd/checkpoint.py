@@ -26,8 +26,8 @@ class _RefUnpickler(pickle.Unpickler):
         return super().find_class(module, name)
 
 
-# pickle_module for torch.load: the stdlib pickle with the Unpickler above, so model.vocab.Vocab resolves without the reference
-# on sys.path
+# pickle_module for torch.load: the stdlib pickle with the Unpickler above, so model.vocab.Vocab resolves without the
+# reference being importable
 _ref_pickle = types.ModuleType("trimodal_ref_pickle")
 _ref_pickle.__dict__.update({k: getattr(pickle, k) for k in dir(pickle) if not k.startswith("__")})
 _ref_pickle.Unpickler = _RefUnpickler

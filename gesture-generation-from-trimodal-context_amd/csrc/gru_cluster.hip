@@ -195,6 +195,163 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------ backward
+// Reverse-time walk with the same cluster structure.  Workgroup m owns hidden units [32m, 32m + 32):
+//     dh_tau = dy_tau + dh_next * z_next + dgh_next @ W_hh            (contraction over the 3H gate rows)
+//     dn = dh (1-z)(1-n^2),  dz = dh (h_prev - n) z (1-z),  dr = dn * hn * r (1-r);  dgi = [dr, dz, dn], dgh = [dr, dz, dn r]
+// W_hh^T slice [32 units][3H] lives in registers (15 float4 per lane: 8 waves = 2 unit tiles x 4 K-slices of the 57 chunks);
+// the hand-off payload is the step's dgh tile, exchanged gate-major ([row][gate][320]) so that every 128-byte line is
+// written by one workgroup.  dh_next and z_next belong to the thread that produced them and stay in registers.
+constexpr int GC_PFB = 15;            // K chunks per wave in the backward product: 4 x 15 x 16 >= 3 x 320
+
+template <int MT>
+__global__ __launch_bounds__(512) void gru_seq_bwd_cluster_kernel(
+    const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ save, long save_ds,
+    const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh, long dg_ds,
+    float* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int CW, int b_pad) {
+    __shared__ __attribute__((aligned(16))) float red[GC_KS][2][MT][4][64];
+    const int n_cl = 2 * n_bt;
+    int cl, m;
+    if (n_cl % 8 == 0) {
+        cl = (blockIdx.x % 8) + 8 * ((blockIdx.x / 8) / CW);
+        m = (blockIdx.x / 8) % CW;
+    } else {
+        cl = blockIdx.x / CW;
+        m = blockIdx.x % CW;
+    }
+    const int dir = cl / n_bt, bt = cl % n_bt;
+    const float* wt = dir ? wt1 : wt0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ut = wave & 1, ks = wave >> 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int b0 = bt * (16 * MT);
+    const int H3 = 3 * H;
+
+    // ---- W_hh^T slice -> registers (B operand: lane (r16, kq) holds W_hh[k][j] = wt[j][k], k = 16c + 4kq + v), and the
+    // exchange-buffer offset of the same k (gate-major, padded rows)
+    f32x4 w[GC_PFB];
+    int koff[GC_PFB];
+    {
+        const int j = m * GC_UNITS + ut * 16 + r16;
+#pragma unroll
+        for (int p = 0; p < GC_PFB; ++p) {
+            const int k = 16 * (ks + GC_KS * p) + 4 * kq;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            w[p] = (j < H && k < H3) ? *reinterpret_cast<const f32x4*>(wt + (long)j * H3 + k) : z;
+            const int kc = k < H3 ? k : 0;                 // beyond 3H the weight fragment is zero: any finite operand will do
+            koff[p] = (kc / H) * GC_HX + (kc % H);
+        }
+    }
+    const int e = threadIdx.x;
+    const bool epi = e < 128 * MT;
+    const int row_l = e >> 3, ug = e & 7;
+    const int e_mt = (row_l >> 4) % MT, e_lane = ((row_l & 15) >> 2) * 16 + 4 * (ug & 3), e_i = row_l & 3, e_ut = ug >> 2;
+    const int row = b0 + row_l;
+    const int unit0 = m * GC_UNITS + 4 * ug;
+    const bool e_ok = epi && row < B && unit0 < H;
+    f32x4 dh_c = {0.f, 0.f, 0.f, 0.f}, z_c = {0.f, 0.f, 0.f, 0.f};
+
+    const long slot_floats = (long)b_pad * 3 * GC_HX;
+    __amdgpu_buffer_rsrc_t gx_rsrc = __builtin_amdgcn_make_buffer_rsrc(gx, 0, (int)(4 * slot_floats * 4), GC_RSRC3);
+    gu32* my_flag = (gu32*)(flags + cl * GC_FLAG_STRIDE + m);
+    gu32* cl_flags = (gu32*)(flags + cl * GC_FLAG_STRIDE);
+    bool aborted = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int tau = dir ? step : T - 1 - step;
+        const int tau_prev = dir ? tau + 1 : tau - 1;           // producer of h_prev for this cell
+        const bool has_prev = dir ? (tau < T - 1) : (tau > 0);
+        // operands of the gate gradients do not depend on the recurrence: issue their loads before the wait
+        f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 dy = zero, r = zero, z = zero, n = zero, hn = zero, hp = zero;
+        if (e_ok) {
+            dy = *reinterpret_cast<const f32x4*>(dY + ((long)row * T + tau) * (2 * H) + dir * H + unit0);
+            const float* sp = save + dir * save_ds + ((long)row * T + tau) * (4 * H) + unit0;
+            r = *reinterpret_cast<const f32x4*>(sp);
+            z = *reinterpret_cast<const f32x4*>(sp + H);
+            n = *reinterpret_cast<const f32x4*>(sp + 2 * H);
+            hn = *reinterpret_cast<const f32x4*>(sp + 3 * H);
+            if (has_prev) hp = *reinterpret_cast<const f32x4*>(Y + ((long)row * T + tau_prev) * (2 * H) + dir * H + unit0);
+        }
+        f32x4 acc[MT][2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][0] = acc[i][1] = zero;
+
+        if (step > 0) {
+            if (wave == 0 && !aborted) {
+                unsigned spins = 0;
+                for (;;) {
+                    const unsigned v = lane < CW ? __hip_atomic_load(cl_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    if (__all(v >= (unsigned)step)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > GC_SPIN_LIMIT) {
+                        if (lane == 0) __hip_atomic_store((gu32*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        aborted = true;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int rslot = (step - 1) & 1;
+            const int off0 = (int)(((long)(dir * 2 + rslot) * slot_floats) * 4);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                f32x4 a[GC_PFB];
+                const int rbase = off0 + (b0 + i * 16 + r16) * (3 * GC_HX) * 4;
+#pragma unroll
+                for (int p = 0; p < GC_PFB; ++p)
+                    a[p] = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(gx_rsrc, rbase + koff[p] * 4, 0, 16));
+                // two accumulators: the dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (40 cycles) exceeds its issue
+                // interval (32)
+#pragma unroll
+                for (int p = 0; p < GC_PFB; ++p) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][0], w[p][0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][1], w[p][1], acc[i][1], 0, 0, 0);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][2], w[p][2], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][3], w[p][3], acc[i][1], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[ks][ut][i][q][lane] = acc[i][0][q] + acc[i][1][q];
+        __syncthreads();
+
+        f32x4 g_r = zero, g_z = zero, g_n = zero, g_nr = zero;
+        if (epi) {
+            f32x4 s = *reinterpret_cast<const f32x4*>(&red[0][e_ut][e_mt][e_i][e_lane]);
+#pragma unroll
+            for (int q = 1; q < GC_KS; ++q) s += *reinterpret_cast<const f32x4*>(&red[q][e_ut][e_mt][e_i][e_lane]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dh = dy[q] + (step > 0 ? s[q] + dh_c[q] * z_c[q] : 0.f);
+                const float dn = dh * (1.f - z[q]) * (1.f - n[q] * n[q]);
+                const float dz = dh * (hp[q] - n[q]) * z[q] * (1.f - z[q]);
+                const float dr = dn * hn[q] * r[q] * (1.f - r[q]);
+                dh_c[q] = dh; z_c[q] = z[q];
+                g_r[q] = dr; g_z[q] = dz; g_n[q] = dn; g_nr[q] = dn * r[q];
+            }
+            // publish this step's dgh tile (gate-major rows of the exchange buffer), 16-byte write-through stores
+            const int woff = (int)((((long)(dir * 2 + (step & 1)) * slot_floats) + (long)row * (3 * GC_HX) + unit0) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_r), gx_rsrc, woff, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_z), gx_rsrc, woff + GC_HX * 4, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_nr), gx_rsrc, woff + 2 * GC_HX * 4, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e_ok) {
+            float* gi_o = dgi + dir * dg_ds + ((long)row * T + tau) * H3 + unit0;
+            float* gh_o = dgh + dir * dg_ds + ((long)row * T + tau) * H3 + unit0;
+            *reinterpret_cast<f32x4*>(gi_o) = g_r; *reinterpret_cast<f32x4*>(gi_o + H) = g_z; *reinterpret_cast<f32x4*>(gi_o + 2 * H) = g_n;
+            *reinterpret_cast<f32x4*>(gh_o) = g_r; *reinterpret_cast<f32x4*>(gh_o + H) = g_z; *reinterpret_cast<f32x4*>(gh_o + 2 * H) = g_nr;
+        }
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -248,4 +405,46 @@ extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, co
         hipLaunchKernelGGL(gru_seq_fwd_cluster_kernel<2>, grid, dim3(512), 0, s, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd,
                            b_hh_rev, y, save, (long)save_dir_stride, hx, flags, tmo, B, T, H, n_bt, cw, b_pad);
     return check_launch("tg_gru_forward_cluster");
+}
+
+// ---- backward
+static void cluster_plan_bwd(int B, int H, int* n_bt, int* cw) {
+    *cw = cdiv(H, GC_UNITS);
+    *n_bt = cdiv(B, 16);
+}
+
+extern "C" int32_t tg_gru_cluster_bwd_supported(int32_t B, int32_t H) {
+    if (H > GC_HX || H % 4 != 0 || B <= 0) return 0;
+    int n_bt, cw;
+    cluster_plan_bwd(B, H, &n_bt, &cw);
+    return 2 * n_bt * cw <= 256 && cw <= GC_FLAG_STRIDE;
+}
+
+extern "C" int64_t tg_gru_cluster_bwd_ws_bytes(int32_t B, int32_t H) {
+    int n_bt, cw;
+    cluster_plan_bwd(B, H, &n_bt, &cw);
+    const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
+    return flag_words * 4 + 4 * (int64_t)n_bt * 16 * 3 * GC_HX * 4;
+}
+
+extern "C" int tg_gru_backward_cluster(const float* dy, const float* y, const float* save, int64_t save_dir_stride,
+                                       const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
+                                       void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream) {
+    TG_REQUIRE(dy && y && save && w_hh_t_fwd && w_hh_t_rev && dgi && dgh && ws, "tg_gru_backward_cluster: null pointer");
+    TG_REQUIRE(T > 0 && tg_gru_cluster_bwd_supported(B, H), "tg_gru_backward_cluster: unsupported shape B=%d H=%d", B, H);
+    TG_REQUIRE(ws_bytes >= tg_gru_cluster_bwd_ws_bytes(B, H), "tg_gru_backward_cluster: workspace too small");
+    TG_REQUIRE(aligned16(dy) && aligned16(y) && aligned16(save) && aligned16(w_hh_t_fwd) && aligned16(w_hh_t_rev) && aligned16(dgi) &&
+               aligned16(dgh) && aligned16(ws) && save_dir_stride % 4 == 0 && dg_dir_stride % 4 == 0,
+               "tg_gru_backward_cluster: operands must be 16-byte aligned");
+    int n_bt, cw;
+    cluster_plan_bwd(B, H, &n_bt, &cw);
+    const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, (size_t)flag_words * 4, s) != hipSuccess) { set_error("tg_gru_backward_cluster: memset failed"); return 1; }
+    unsigned* tmo = (unsigned*)ws;
+    unsigned* flags = tmo + GC_FLAG_STRIDE;
+    float* gx = (float*)(tmo + flag_words);
+    hipLaunchKernelGGL(gru_seq_bwd_cluster_kernel<1>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, y, save, (long)save_dir_stride, w_hh_t_fwd,
+                       w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, gx, flags, tmo, B, T, H, n_bt, cw, n_bt * 16);
+    return check_launch("tg_gru_backward_cluster");
 }

@@ -157,11 +157,12 @@ GRU_CLUSTER = os.environ.get("TG_GRU_CLUSTER", "1") != "0"
 _gru_ws = {}
 
 
-def _gru_cluster_ws(dev, B, H):
-    key = (dev, B, H)
+def _gru_cluster_ws(dev, B, H, bwd=False):
+    key = (dev, B, H, bwd)
     ws = _gru_ws.get(key)
     if ws is None:
-        nbytes = _lib.load().tg_gru_cluster_ws_bytes(B, H)
+        lib = _lib.load()
+        nbytes = lib.tg_gru_cluster_bwd_ws_bytes(B, H) if bwd else lib.tg_gru_cluster_ws_bytes(B, H)
         ws = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev)
         _gru_ws[key] = ws
     return ws
@@ -208,6 +209,11 @@ def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None):
     for w in w_hh_t:
         _flat(w, "w_hh_t"); assert tuple(w.shape) == (H, 3 * H)
     ys, ss = y[b0:b0 + nb], save[:, b0:b0 + nb]
+    if GRU_CLUSTER and H > 64 and _lib.load().tg_gru_cluster_bwd_supported(nb, H):
+        ws = _gru_cluster_ws(dy.device, nb, H, bwd=True)
+        call("tg_gru_backward_cluster", _p(dy), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
+             _p(dgi), _p(dgh), nb * T * 3 * H, C.c_void_p(ws.data_ptr()), ws.numel() * 4, nb, T, H, _stream())
+        return
     call("tg_gru_backward", _p(dy), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
          _p(dgi), _p(dgh), nb * T * 3 * H, _p(dh_scratch), nb, T, H, _stream())
 

@@ -25,6 +25,7 @@ class StepLosses:
 
     def to_dict(self):
         g = self.g.tolist()       # one device->host read
+        ops.check_async_errors()  # raises if a persistent kernel's bounded spin timed out (results invalid)
         hp = self.hp
         ret = {"loss": hp["loss_regression_weight"] * g[0]}
         if g[1]:

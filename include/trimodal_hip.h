@@ -121,6 +121,14 @@ int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, const float* 
                            const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
                            void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream);
 
+/* Persistent cluster-synchronised variant of tg_gru_backward (B <= 192 at H = 300; no dh_scratch: the carried dh stays in
+ * registers).  Same workspace / timeout-word convention as tg_gru_forward_cluster. */
+int32_t tg_gru_cluster_bwd_supported(int32_t B, int32_t H);
+int64_t tg_gru_cluster_bwd_ws_bytes(int32_t B, int32_t H);
+int tg_gru_backward_cluster(const float* dy, const float* y, const float* save, int64_t save_dir_stride,
+                            const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
+                            void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream);
+
 /* ---- BatchNorm1d, channel-last [rows][C] (model/multimodal_context_net.py:14,17,20,215,218) -------------
  * Training statistics per group: the rows are split into `groups` equal consecutive slabs, each normalised with
  * its own batch statistics (several reference forward calls stacked into one launch); running stats are updated

@@ -131,6 +131,42 @@ def test_gru_layer_fwd_bwd(pkg, dev, B, T, H, Kin):
             assert rel(G2[f"gru.{k}"], v.grad) < 1e-4, k
 
 
+@pytest.mark.parametrize("B", [3, 37, 128, 384])
+def test_gru_cluster_kernels_match_step_launches(pkg, dev, B):
+    """The persistent cluster-synchronised recurrence (csrc/gru_cluster.hip) against the per-step launches (csrc/gru.hip): same
+    K-slicing and summation order, so they agree to rounding; a stale inter-workgroup hand-off would show as an O(1e-2) error.
+    Repeated on the same buffers (the L2s then hold the previous run's lines of the exchange buffer)."""
+    ops = pkg.ops
+    T, H = 34, 300
+    g = torch.Generator().manual_seed(B)
+    w = [(torch.randn(3 * H, H, generator=g) * 0.08).to(dev) for _ in range(2)]
+    b = [(torch.randn(3 * H, generator=g) * 0.05).to(dev) for _ in range(2)]
+    wt = [x.t().contiguous() for x in w]
+    prev = ops.GRU_CLUSTER
+    try:
+        for rep in range(4):
+            gi = (torch.randn(2, B, T, 3 * H, generator=g) * 0.5).to(dev)
+            dy = torch.randn(B, T, 2 * H, generator=g).to(dev)
+            out = {}
+            for cluster in (False, True):
+                ops.GRU_CLUSTER = cluster
+                y = torch.full((B, T, 2 * H), float("nan"), device=dev)
+                sv = torch.full((2, B, T, 4 * H), float("nan"), device=dev)
+                ops.gru_forward(gi, w, b, y, sv)
+                nb = min(B, 128)                                   # backward of one 128-row group of the stacked forward
+                b0 = (B - nb) // 2
+                dgi = torch.full((2, nb, T, 3 * H), float("nan"), device=dev)
+                dgh = torch.full((2, nb, T, 3 * H), float("nan"), device=dev)
+                ops.gru_backward(dy[b0:b0 + nb].contiguous(), y, sv, wt, dgi, dgh, torch.zeros(4 * nb * H, device=dev), b0=b0, nb=nb)
+                out[cluster] = (y, sv, dgi, dgh)
+            ops.check_async_errors()
+            for a, c in zip(out[False], out[True]):
+                assert bool(torch.isfinite(c).all())
+                assert float((a - c).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), (B, rep)
+    finally:
+        ops.GRU_CLUSTER = prev
+
+
 # ------------------------------------------------------------------------------------------------ BatchNorm
 @pytest.mark.parametrize("rows,C,groups,slope", [(3 * 500, 16, 3, 0.3), (64, 256, 1, 1.0), (2 * 96, 8, 2, 1.0)])
 def test_batchnorm_train_eval_backward(pkg, dev, rows, C, groups, slope):

@@ -56,3 +56,42 @@ ops.check_async_errors()
 print("total mismatches", bad)
 for B in (128, 256, 384):
     print(f"B={B:4d}  step-launch {timeit(B, False):7.2f} us/step   cluster {timeit(B, True):7.2f} us/step")
+
+# ---- backward: cluster vs step launches on the same taped forward
+def bwd(B, cluster, seed):
+    gi, w, b = data(B, seed)
+    ops.GRU_CLUSTER = False
+    y = torch.empty(B, T, 2 * H, device=dev); sv = torch.empty(2, B, T, 4 * H, device=dev)
+    ops.gru_forward(gi, w, b, y, sv)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    dy = torch.randn(B, T, 2 * H, generator=g).to(dev)
+    wt = [x.t().contiguous() for x in w]
+    ops.GRU_CLUSTER = cluster
+    dgi = torch.full((2, B, T, 3 * H), float("nan"), device=dev); dgh = torch.full((2, B, T, 3 * H), float("nan"), device=dev)
+    scratch = torch.zeros(4 * B * H, device=dev)
+    ops.gru_backward(dy, y, sv, wt, dgi, dgh, scratch)
+    torch.cuda.synchronize()
+    return dgi, dgh, (dy, y, sv, wt, scratch)
+bad = 0
+for B in (4, 37, 128, 192):
+    for rep in range(6):
+        a0, b0_, _ = bwd(B, False, 1000 * B + rep)
+        a1, b1_, _ = bwd(B, True, 1000 * B + rep)
+        ops.check_async_errors()
+        sc = float(a0.abs().max())
+        e = max(float((a0 - a1).abs().nan_to_num(1e9).max()), float((b0_ - b1_).abs().nan_to_num(1e9).max())) / sc
+        if not e < 2e-5:
+            bad += 1; print(f"bwd B={B} rep={rep}: MISMATCH rel {e:.3e}")
+    print(f"bwd B={B}: mismatches so far {bad}")
+def timeb(B, cluster, iters=10):
+    dgi, dgh, (dy, y, sv, wt, scratch) = bwd(B, cluster, 5)
+    ops.GRU_CLUSTER = cluster
+    for _ in range(3): ops.gru_backward(dy, y, sv, wt, dgi, dgh, scratch)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): ops.gru_backward(dy, y, sv, wt, dgi, dgh, scratch)
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters / T
+for B in (64, 128, 192):
+    print(f"bwd B={B:4d}  step-launch {timeb(B, False):7.2f} us/step   cluster {timeb(B, True):7.2f} us/step")
+ops.GRU_CLUSTER = True
