@@ -73,9 +73,11 @@ def time_kernel(fn, iters=50, warm=5):
 
 
 def dominant_kernel_roofline(pkg, device, batch):
-    """The kernel with the largest share of the step (profiles/): the per-time-step launch of the generator's GRU forward
-    over the 3 stacked forwards (gru_fwd_step_kernel at B = 3*batch, H = 300).
-    Algorithmic FLOPs per launch: 2 directions x B x H x 3H x 2 (the h_{t-1} @ W_hh^T product; gate maths excluded)."""
+    """The single kernel with the largest share of the iteration (profiles/r1_c_by_shape.txt): the persistent cluster-synchronised
+    GRU recurrence of the generator's stacked forward, gru_seq_fwd_cluster_kernel<2> at B = 3*batch, H = 300, T = 34 -- one launch
+    per layer walks all 34 steps of both directions (csrc/gru_cluster.hip).
+    Algorithmic FLOPs per launch: (T-1) steps x 2 directions x B x 3H x H x 2 (the h_{t-1} @ W_hh^T products; gate maths excluded).
+    The kernel is bound by the per-step inter-workgroup hand-off latency, not by MFMA issue or HBM: the fraction says how far."""
     ops = pkg.ops
     Bs, H = 3 * batch, 300
     gi = torch.randn(2, Bs, T, 3 * H, device=device) * 0.1
@@ -83,14 +85,15 @@ def dominant_kernel_roofline(pkg, device, batch):
     b = [torch.randn(3 * H, device=device) * 0.05 for _ in range(2)]
     y = torch.empty(Bs, T, 2 * H, device=device)
     sv = torch.empty(2, Bs, T, 4 * H, device=device)
-    dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, sv), iters=20) / T        # T launches per call
-    flops = 2 * Bs * H * 3 * H * 2
-    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape (profiles/r1_b_pmc_gru_fwd_step.txt):
-    # FETCH_SIZE 5193.7 KB x 2 (gfx950 wide-read correction) + WRITE_SIZE 4977.0 KB.  Only valid for batch 128 (B_s = 384).
-    traffic = (2 * 5193.7 + 4977.0) * 1024 if batch == 128 else None
-    return {"kernel": "gru_fwd_step_kernel", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+    dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, sv), iters=20)
+    ops.check_async_errors()
+    flops = (T - 1) * 2 * Bs * H * 3 * H * 2
+    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape (profiles/r1_c_pmc_gru_fwd_cluster.txt):
+    # FETCH_SIZE 70695.5 KB x 2 (gfx950 wide-read correction) + WRITE_SIZE 186359.5 KB.  Only valid for batch 128 (B_s = 384).
+    traffic = (2 * 70695.5 + 186359.5) * 1024 if batch == 128 else None
+    return {"kernel": "gru_seq_fwd_cluster_kernel<2>", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": traffic, "launch_us": dt * 1e6,
-            "flop_per_launch": flops}
+            "flop_per_launch": flops, "us_per_step": dt * 1e6 / T}
 
 
 def cpu_baseline(batch, budget_s=20.0, max_steps=3):

@@ -14,7 +14,7 @@ __device__ __forceinline__ int xcd_chunked_id(int bid, int nwg) {
     return x * per + (x < rem ? x : rem) + q;
 }
 
-template <int MF, int BK, int PAD, int SWZ>
+template <int MF, int BK, int PAD, int SWZ, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                    int M, int N, int K, int n_nt) {
     constexpr int LD = BK + PAD;
@@ -63,21 +63,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 
     fetch(0);
     int buf = 0;
+    f32x4 fa[NT], fb[NT];
+    if (ABL & 4) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { fa[i] = ga[0] + (float)i; fb[i] = gb[0] + (float)i; }
+    }
     for (int k0 = 0; k0 < K; k0 += BK) {
+        if (!(ABL & 8)) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             *reinterpret_cast<f32x4*>(&as[buf][srow[i]][sk[i]]) = ga[i];
             *reinterpret_cast<f32x4*>(&bs[buf][srow[i]][sk[i]]) = gb[i];
         }
-        __syncthreads();
-        if (k0 + BK < K) fetch(k0 + BK);
+        }
+        if (!(ABL & 2)) __syncthreads();
+        if (!(ABL & 1) && k0 + BK < K) fetch(k0 + BK);
 #pragma unroll
         for (int u = 0; u < BK / KG; ++u) {
-            f32x4 fa[NT], fb[NT];
+            if (!(ABL & 4)) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&as[buf][wm * 64 + i * TS + rr][KG * u + 4 * kq]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&bs[buf][wn * 64 + j * TS + rr][KG * u + 4 * kq]);
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #pragma unroll
@@ -102,12 +110,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
             }
 }
 
-template <int MF, int BK, int PAD, int SWZ>
+template <int MF, int BK, int PAD, int SWZ, int ABL = 0>
 double run(const char* name, const float* A, const float* B, float* C, int M, int N, int K, const std::vector<float>& hA,
            const std::vector<float>& hB) {
     const int n_nt = (N + 127) / 128, grid = ((M + 127) / 128) * n_nt;
     hipMemset(C, 0, sizeof(float) * (size_t)M * N);
-    hipLaunchKernelGGL((gemm_kernel<MF, BK, PAD, SWZ>), dim3(grid), dim3(256), 0, 0, A, B, C, M, N, K, n_nt);
+    hipLaunchKernelGGL((gemm_kernel<MF, BK, PAD, SWZ, ABL>), dim3(grid), dim3(256), 0, 0, A, B, C, M, N, K, n_nt);
     hipDeviceSynchronize();
     // spot check
     std::vector<float> hC((size_t)M * N);
@@ -128,7 +136,7 @@ double run(const char* name, const float* A, const float* B, float* C, int M, in
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20;
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_kernel<MF, BK, PAD, SWZ>), dim3(grid), dim3(256), 0, 0, A, B, C, M, N, K, n_nt);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_kernel<MF, BK, PAD, SWZ, ABL>), dim3(grid), dim3(256), 0, 0, A, B, C, M, N, K, n_nt);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / us / 1e6;
@@ -165,7 +173,7 @@ int main_old() {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // tile menu: 4 waves (2x2), wave tile (16*WTM) x (16*WTN) of 16x16x4 MFMAs, workgroup tile BM = 32*WTM, BN = 32*WTN
-template <int WTM, int WTN, int BK>
+template <int WTM, int WTN, int BK, int ABL = 0>   // ABL bit0: no global fetch in the loop, bit1: no barrier, bit2: no LDS fragment reads, bit3: no LDS writes
 __global__ __launch_bounds__(256) void gemm_menu(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                  int M, int N, int K, int n_nt) {
     constexpr int BM = 32 * WTM, BN = 32 * WTN, LD = BK + 4, PPR = BK / 4;
@@ -207,20 +215,30 @@ __global__ __launch_bounds__(256) void gemm_menu(const float* __restrict__ A, co
     const int r16 = lane & 15, kq = lane >> 4;
     fetch(0);
     int buf = 0;
+    f32x4 fa[WTM], fb[WTN];
+    if (ABL & 4) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) fa[i] = ga[0] + (float)i;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) fb[j] = gb[0] + (float)j;
+    }
     for (int k0 = 0; k0 < K; k0 += BK) {
+        if (!(ABL & 8)) {
 #pragma unroll
         for (int i = 0; i < NPA; ++i) if (ar[i] < BM) *reinterpret_cast<f32x4*>(&as[buf][ar[i]][ak[i]]) = ga[i];
 #pragma unroll
         for (int i = 0; i < NPB; ++i) if (br[i] < BN) *reinterpret_cast<f32x4*>(&bs[buf][br[i]][bk[i]]) = gb[i];
-        __syncthreads();
-        if (k0 + BK < K) fetch(k0 + BK);
+        }
+        if (!(ABL & 2)) __syncthreads();
+        if (!(ABL & 1) && k0 + BK < K) fetch(k0 + BK);
 #pragma unroll
         for (int u = 0; u < BK / 16; ++u) {
-            f32x4 fa[WTM], fb[WTN];
+            if (!(ABL & 4)) {
 #pragma unroll
             for (int i = 0; i < WTM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&as[buf][wm * 16 * WTM + i * 16 + r16][16 * u + 4 * kq]);
 #pragma unroll
             for (int j = 0; j < WTN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&bs[buf][wn * 16 * WTN + j * 16 + r16][16 * u + 4 * kq]);
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #pragma unroll
@@ -242,12 +260,12 @@ __global__ __launch_bounds__(256) void gemm_menu(const float* __restrict__ A, co
             }
 }
 
-template <int WTM, int WTN, int BK>
+template <int WTM, int WTN, int BK, int ABL = 0>
 void run_menu(const float* A, const float* B, float* C, int M, int N, int K, const std::vector<float>& hA, const std::vector<float>& hB) {
     constexpr int BM = 32 * WTM, BN = 32 * WTN;
     const int n_nt = (N + BN - 1) / BN, grid = ((M + BM - 1) / BM) * n_nt;
     hipMemset(C, 0, sizeof(float) * (size_t)M * N);
-    hipLaunchKernelGGL((gemm_menu<WTM, WTN, BK>), dim3(grid), dim3(256), 0, 0, A, B, C, M, N, K, n_nt);
+    hipLaunchKernelGGL((gemm_menu<WTM, WTN, BK, ABL>), dim3(grid), dim3(256), 0, 0, A, B, C, M, N, K, n_nt);
     hipDeviceSynchronize();
     std::vector<float> hC((size_t)M * N);
     hipMemcpy(hC.data(), C, sizeof(float) * hC.size(), hipMemcpyDeviceToHost);
@@ -261,14 +279,14 @@ void run_menu(const float* A, const float* B, float* C, int M, int N, int K, con
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20;
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_menu<WTM, WTN, BK>), dim3(grid), dim3(256), 0, 0, A, B, C, M, N, K, n_nt);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_menu<WTM, WTN, BK, ABL>), dim3(grid), dim3(256), 0, 0, A, B, C, M, N, K, n_nt);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters;
-    printf("  %3dx%3d BK%2d  wgs %5d  %8.1f us %6.1f TF  err %.1e\n", BM, BN, BK, grid, us, 2.0 * M * N * K / us / 1e6, worst);
+    printf("  %3dx%3d BK%2d abl %2d wgs %5d  %8.1f us %6.1f TF  err %.1e\n", BM, BN, BK, ABL, grid, us, 2.0 * M * N * K / us / 1e6, worst);
 }
 
-int main() {
+int main_menu() {
     const int shapes[][3] = {{13056, 900, 600}, {13056, 900, 108}, {13056, 300, 600}, {4352, 600, 900}, {4352, 300, 600}, {4352, 108, 900},
                              {13056, 150, 300}, {4352, 300, 150}, {27776, 64, 480}, {168064, 32, 240}};
     for (auto& sh : shapes) {
@@ -298,6 +316,44 @@ int main() {
         run_menu<1, 2, 16>(A, B, C, M, N, K, hA, hB);
         run_menu<4, 1, 16>(A, B, C, M, N, K, hA, hB);
         run_menu<2, 1, 16>(A, B, C, M, N, K, hA, hB);
+        hipFree(A); hipFree(B); hipFree(C);
+    }
+    return 0;
+}
+
+int main() {
+    const int shapes[][3] = {{13056, 1800, 600}, {13056, 900, 600}};
+    for (auto& sh : shapes) {
+        const int M = sh[0], N = sh[1], K = sh[2];
+        printf("M=%d N=%d K=%d\n", M, N, K);
+        std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+        unsigned s = 12345;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+        for (auto& v : hA) v = rnd();
+        for (auto& v : hB) v = rnd() * 0.1f;
+        float *A, *B, *C;
+        hipMalloc(&A, hA.size() * 4); hipMalloc(&B, hB.size() * 4); hipMalloc(&C, (size_t)M * N * 4);
+        hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+        run<1, 16, 4, 1, 0>("32x32x2 abl0", A, B, C, M, N, K, hA, hB);
+        run<1, 16, 4, 1, 1>("32x32x2 abl1 (no fetch)", A, B, C, M, N, K, hA, hB);
+        run<1, 16, 4, 1, 4>("32x32x2 abl4 (no lds read)", A, B, C, M, N, K, hA, hB);
+        run<1, 16, 4, 1, 5>("32x32x2 abl5", A, B, C, M, N, K, hA, hB);
+        run<1, 16, 4, 1, 15>("32x32x2 abl15 (mfma only)", A, B, C, M, N, K, hA, hB);
+        run<0, 16, 4, 1, 15>("16x16x4 abl15 (mfma only)", A, B, C, M, N, K, hA, hB);
+        run_menu<4, 4, 16, 0>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 4, 16, 1>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 4, 16, 2>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 4, 16, 3>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 4, 16, 4>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 4, 16, 5>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 4, 16, 7>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 4, 16, 15>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 2, 16, 0>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 2, 16, 1>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 2, 16, 2>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 2, 16, 4>(A, B, C, M, N, K, hA, hB);
+        run_menu<4, 2, 16, 15>(A, B, C, M, N, K, hA, hB);
         hipFree(A); hipFree(B); hipFree(C);
     }
     return 0;
