@@ -10,6 +10,7 @@
 //
 // tg_gemm_tn (weight gradients): the reduction runs over ROWS, so MFMA fragments are column-strided; tiles of 16 rows
 // are staged through LDS with coalesced 16-byte loads, double-buffered, one barrier per tile.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace tg {
@@ -152,68 +153,71 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Win A, const float* __rest
     }
 }
 
-// Large-tile path of tg_gemm_nt for the big products of the step (GRU input projections, TCN convs, their input
-// gradients): workgroup tile 128 x (32*TN), 4 waves as 2 x 2, each wave 64 x (16*TN) = 4 x TN MFMA tiles, so every
-// operand fragment read from LDS feeds 4 (B) or TN (A) MFMAs instead of 2.  16-deep K slabs of A and B are staged through
+// LDS-staged path of tg_gemm_nt for the big products of the step (GRU input projections, TCN convs, their input
+// gradients): workgroup tile (32*TM) x (32*TN), 4 waves as 2 x 2, each wave (16*TM) x (16*TN) = TM x TN MFMA tiles, so every
+// operand fragment read from LDS feeds TM (B) or TN (A) MFMAs.  16-deep K slabs of A and B are staged through
 // LDS with coalesced 16-byte global loads ([row][16 k] rows padded to 20 floats: the k-permuted 16-byte fragment reads
 // stay 16-byte aligned and spread over the banks), double-buffered: the next slab's global loads are in flight while
-// the current slab's 16*TN MFMAs per wave run.  Needs the vectorisable layout (cw % 4 == 0 etc., checked on the host).
+// the current slab's 4*TM*TN MFMAs per wave run.  Needs the vectorisable layout (cw % 4 == 0 etc., checked on the host).
+// The tile is chosen per shape by nt_pick_tile(): the f32 pipe sustains ~100 TFLOP/s on real data whatever the tile
+// (tools/gemm_lab.hip), so what matters is tile quantisation and filling 256 CUs x 3 workgroups.
 constexpr int BG_LD = 20;
 
-template <int TN>
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __restrict__ Bw, long ldb,
                                                           const float* __restrict__ bias, float* __restrict__ C, long cbs,
                                                           long crs, int cR, int M, int N, float slope, int accumulate, int n_nt) {
-    constexpr int BN = 32 * TN;                       // workgroup tile width
-    constexpr int BROWS = BN / 64;                    // B rows staged per thread (1 or 2)
-    __shared__ __attribute__((aligned(16))) float as[2][128][BG_LD];
+    constexpr int BM = 32 * TM, BN = 32 * TN;         // workgroup tile
+    constexpr int NPA = (BM * 4 + 255) / 256;         // 16-byte pieces staged per thread (4 per 16-deep row)
+    constexpr int NPB = (BN * 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float as[2][BM][BG_LD];
     __shared__ __attribute__((aligned(16))) float bs[2][BN][BG_LD];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, kq = lane >> 4;
     const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
-    const int m0 = (lid / n_nt) * 128, n0 = (lid % n_nt) * BN;
+    const int m0 = (lid / n_nt) * BM, n0 = (lid % n_nt) * BN;
     const int K = A.K;
 
-    // staging role: row (t >> 2) [+64], 16-byte piece (t & 3) of the 16-deep slab
+    // staging role: row (t >> 2) [+64 per extra piece], 16-byte piece (t & 3) of the 16-deep slab
     const int srow = t >> 2, sk = 4 * (t & 3);
-    long a_off[2];
-    int a_r[2];
-    bool a_ok[2];
+    long a_off[NPA];
+    int a_r[NPA];
+    bool a_ok[NPA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NPA; ++i) {
         const int m = m0 + srow + 64 * i;
-        a_ok[i] = m < M;
+        a_ok[i] = (srow + 64 * i < BM) && m < M;
         const int mm = a_ok[i] ? m : 0;
         const int b = mm / A.rows_out;
         const int r = mm - b * A.rows_out;
         a_off[i] = (long)b * A.bs;
         a_r[i] = r * A.step + A.shift;
     }
-    const float* b_ptr[BROWS];
-    bool b_ok[BROWS];
+    const float* b_ptr[NPB];
+    bool b_ok[NPB];
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) {
+    for (int i = 0; i < NPB; ++i) {
         const int n = n0 + srow + 64 * i;
-        b_ok[i] = n < N;
+        b_ok[i] = (srow + 64 * i < BN) && n < N;
         b_ptr[i] = Bw + (long)(b_ok[i] ? n : 0) * ldb;
     }
     int kk = sk / A.cw, c = sk - (sk / A.cw) * A.cw;   // tap / channel of this thread's piece, advanced by 16 per slab
 
-    f32x4 ga[2], gb[BROWS];
+    f32x4 ga[NPA], gb[NPB];
     auto fetch = [&](int k0) {
         const int k = k0 + sk;
         const bool inb = k < K;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NPA; ++i) {
             const int sr = a_r[i] + kk * A.dil;
             const bool ok = a_ok[i] && inb && sr >= 0 && sr < A.rows_in;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             ga[i] = ok ? *reinterpret_cast<const f32x4*>(A.ptr + a_off[i] + (long)sr * A.rs + c) : z;
         }
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) {
+        for (int i = 0; i < NPB; ++i) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             gb[i] = (b_ok[i] && inb) ? *reinterpret_cast<const f32x4*>(b_ptr[i] + k) : z;
         }
@@ -221,9 +225,9 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
         while (c >= A.cw) { c -= A.cw; ++kk; }
     };
 
-    f32x4 acc[4][TN];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -231,20 +235,22 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
     int buf = 0;
     for (int k0 = 0; k0 < K; k0 += 16) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&as[buf][srow + 64 * i][sk]) = ga[i];
+        for (int i = 0; i < NPA; ++i)
+            if (BM % 64 == 0 || srow + 64 * i < BM) *reinterpret_cast<f32x4*>(&as[buf][srow + 64 * i][sk]) = ga[i];
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<f32x4*>(&bs[buf][srow + 64 * i][sk]) = gb[i];
+        for (int i = 0; i < NPB; ++i)
+            if (BN % 64 == 0 || srow + 64 * i < BN) *reinterpret_cast<f32x4*>(&bs[buf][srow + 64 * i][sk]) = gb[i];
         __syncthreads();
         if (k0 + 16 < K) fetch(k0 + 16);
-        f32x4 fa[4], fb[TN];
+        f32x4 fa[TM], fb[TN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&as[buf][wm * 64 + i * 16 + r16][4 * kq]);
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&as[buf][wm * (16 * TM) + i * 16 + r16][4 * kq]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&bs[buf][wn * (16 * TN) + j * 16 + r16][4 * kq]);
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][v], fb[j][v], acc[i][j], 0, 0, 0);
@@ -252,10 +258,10 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
     }
 
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int row = m0 + wm * 64 + i * 16 + kq * 4 + q;
+            const int row = m0 + wm * (16 * TM) + i * 16 + kq * 4 + q;
             if (row >= M) continue;
             const int cb = row / cR;
             const int cr = row - cb * cR;
@@ -274,19 +280,39 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
     }
 }
 
-// dW[n][k] += sum_m dY[m][n] * A(m,k)  (and dbias[n] += sum_m dY[m][n] when asked).
-// Workgroup = 4 waves as 2 (n) x 2 (k), each 32x32 of dW, i.e. a 64 x 64 tile of dW per workgroup; the m range is split
-// over blockIdx.z.  Per 16-row tile every thread fetches one 16-byte piece of dY and one of A (coalesced rows), the
-// pieces go to LDS ([row][col], row stride 68 floats: the column-strided MFMA fragment reads are conflict-free), the
-// next tile's global loads are in flight while the current tile's 16 MFMAs per wave run.
-constexpr int TN_LD = 68;
+// Tile menu of the LDS-staged path.  Rules read off tools/gemm_lab.hip runs on the shapes of the training step (the f32 pipe
+// sustains ~100 TFLOP/s on real data whatever the tile; what matters is tile quantisation and having >= 2-3 workgroups per CU
+// in flight): take the largest tile that still yields enough workgroups, smaller tiles below that.
+struct NtTile { int tm, tn; };
+static NtTile nt_pick_tile(int M, int N) {
+    auto wgs = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(N, bn); };
+    auto waste = [&](int bn) { return cdiv(N, bn) * bn - N; };
+    if (wgs(128, 128) >= 1400 && waste(128) <= waste(64) + 32) return {4, 4};
+    if (wgs(128, 96) >= 700 && waste(96) <= waste(64) + 16) return {4, 3};
+    if (wgs(128, 64) >= 500) return {4, 2};
+    if (wgs(64, 64) >= 640) return {2, 2};
+    return {2, 1};
+}
 
+// dW[n][k] += sum_m dY[m][n] * A(m,k)  (and dbias[n] += sum_m dY[m][n] when asked).
+// Workgroup = 4 waves as 2 (n) x 2 (k), each (16*WTN) x (16*WTK) of dW, i.e. a (32*WTN) x (32*WTK) tile of dW per workgroup;
+// the m range is split over workgroups.  Per MR-row slab every thread fetches 16-byte pieces of dY and of A (coalesced rows),
+// the pieces go to LDS ([row][col], row stride = width + 4 floats: 4 * stride % 32 == 16, so the column-strided ds_read_b32
+// MFMA fragment reads of the two row groups of a 32-lane half hit disjoint banks), the next slab's global loads are in
+// flight while the current slab's MR/4 * WTN * WTK MFMAs per wave run: one barrier per slab.  <4, 2, 32> (128 x 64 tile, 64
+// MFMAs per wave per barrier, 6 LDS reads per 8 MFMAs) is the large-shape configuration, <2, 2, 16> the small one.
+template <int WTN, int WTK, int MR>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, long ldy, Win A, float* __restrict__ dW,
                                                       long ldw, int M, int N, int rows_per_split, int out_kw,
                                                       float* __restrict__ partial, float* __restrict__ dbias, int vec_y, int vec_a,
                                                       int n_nt, int n_kt) {
-    __shared__ __attribute__((aligned(16))) float ys[2][16][TN_LD];
-    __shared__ __attribute__((aligned(16))) float xs[2][16][TN_LD];
+    constexpr int BN = 32 * WTN, BC = 32 * WTK;            // tile of dW: BN rows (n) x BC columns (k)
+    constexpr int LDY = BN + 4, LDX = BC + 4;
+    constexpr int PY = BN / 4, PX = BC / 4;                // 16-byte pieces per slab row
+    constexpr int NY = MR * PY / 256, NX = MR * PX / 256;  // pieces per thread
+    static_assert(MR * PY % 256 == 0 && MR * PX % 256 == 0 && 256 % PY == 0 && 256 % PX == 0, "staging map");
+    __shared__ __attribute__((aligned(16))) float ys[2][MR][LDY];
+    __shared__ __attribute__((aligned(16))) float xs[2][MR][LDX];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int r16 = lane & 15, mq = lane >> 4;
@@ -294,15 +320,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     // logical order: (n tile, k tile) fastest, split slowest -> the tiles that re-read one chunk of rows share an XCD
     const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
     const int tn_n = lid % n_nt, tn_k = (lid / n_nt) % n_kt, tn_s = lid / (n_nt * n_kt);
-    const int n0 = tn_n * 64, k0 = tn_k * 64;
+    const int n0 = tn_n * BN, k0 = tn_k * BC;
     const int K = A.K;
     const int m_begin = tn_s * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
 
-    // staging role of this thread: row (t>>4) of the 16-row tile, 4 consecutive columns starting at 4*(t&15)
-    const int srow = t >> 4, scol = 4 * (t & 15);
-    const int yn = n0 + scol;                 // first dY column of this thread's piece
-    const int ak = k0 + scol;                 // first k of this thread's piece
+    // staging roles: dY piece i = row (t / PY) + i * (256 / PY), columns 4 * (t % PY) .. +3; A piece likewise with PX
+    const int yrow = t / PY, ycol = 4 * (t % PY);
+    const int xrow = t / PX, xcol = 4 * (t % PX);
+    const int yn = n0 + ycol;                 // first dY column of this thread's pieces
+    const int ak = k0 + xcol;                 // first k of this thread's pieces
     int a_roff[4], a_ch[4];
     bool a_kok[4];
 #pragma unroll
@@ -313,86 +340,100 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         a_roff[q] = kk * A.dil;
         a_ch[q] = kc - kk * A.cw;
     }
-    int mb = 0, mr = 0;                       // (clip, row in clip) of this thread's staging row, advanced incrementally
-    {
-        const int m = m_begin + srow;
-        mb = m / A.rows_out;
-        mr = m - mb * A.rows_out;
+    int mb[NX], mr[NX];                       // (clip, row in clip) of each A staging row, advanced incrementally
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int m = m_begin + xrow + i * (256 / PX);
+        mb[i] = m / A.rows_out;
+        mr[i] = m - mb[i] * A.rows_out;
     }
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const bool want_bias = dbias != nullptr && tn_k == 0;
 
-    auto fetch = [&](int m0, f32x4& yv, f32x4& xv) {
-        const int m = m0 + srow;
-        const bool ok = m < m_end;
-        yv = f32x4{0.f, 0.f, 0.f, 0.f};
-        xv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-            const float* yp = dY + (long)m * ldy + yn;
-            if (vec_y && yn + 3 < N) {
-                yv = *reinterpret_cast<const f32x4*>(yp);
-            } else {
+    f32x4 yv[NY], xv[NX];
+    auto fetch = [&](int m0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) yv[q] = (yn + q < N) ? yp[q] : 0.f;
-            }
-            const long base = (long)mb * A.bs;
-            const int sr0 = mr * A.step + A.shift;
-            if (vec_a && a_kok[3]) {            // cw % 4 == 0: the four k share one tap
-                const int sr = sr0 + a_roff[0];
-                if (sr >= 0 && sr < A.rows_in) xv = *reinterpret_cast<const f32x4*>(A.ptr + base + (long)sr * A.rs + a_ch[0]);
-            } else {
+        for (int i = 0; i < NY; ++i) {
+            const int m = m0 + yrow + i * (256 / PY);
+            yv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                const float* yp = dY + (long)m * ldy + yn;
+                if (vec_y && yn + 3 < N) {
+                    yv[i] = *reinterpret_cast<const f32x4*>(yp);
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int sr = sr0 + a_roff[q];
-                    xv[q] = (a_kok[q] && sr >= 0 && sr < A.rows_in) ? A.ptr[base + (long)sr * A.rs + a_ch[q]] : 0.f;
+                    for (int q = 0; q < 4; ++q) yv[i][q] = (yn + q < N) ? yp[q] : 0.f;
                 }
             }
         }
-        mr += 16;
-        while (mr >= A.rows_out) { mr -= A.rows_out; ++mb; }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int m = m0 + xrow + i * (256 / PX);
+            xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                const long base = (long)mb[i] * A.bs;
+                const int sr0 = mr[i] * A.step + A.shift;
+                if (vec_a && a_kok[3]) {            // cw % 4 == 0: the four k share one tap
+                    const int sr = sr0 + a_roff[0];
+                    if (sr >= 0 && sr < A.rows_in) xv[i] = *reinterpret_cast<const f32x4*>(A.ptr + base + (long)sr * A.rs + a_ch[0]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int sr = sr0 + a_roff[q];
+                        xv[i][q] = (a_kok[q] && sr >= 0 && sr < A.rows_in) ? A.ptr[base + (long)sr * A.rs + a_ch[q]] : 0.f;
+                    }
+                }
+            }
+            mr[i] += MR;
+            while (mr[i] >= A.rows_out) { mr[i] -= A.rows_out; ++mb[i]; }
+        }
     };
 
-    f32x4 acc[2][2];
+    f32x4 acc[WTN][WTK];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WTN; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WTK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 yv, xv;
-    fetch(m_begin, yv, xv);
+    fetch(m_begin);
     int buf = 0;
-    for (int m0 = m_begin; m0 < m_end; m0 += 16) {
-        *reinterpret_cast<f32x4*>(&ys[buf][srow][scol]) = yv;
-        *reinterpret_cast<f32x4*>(&xs[buf][srow][scol]) = xv;
-        if (want_bias) bsum += yv;
-        __syncthreads();                                   // tile `buf` complete; the other buffer is free again
-        if (m0 + 16 < m_end) fetch(m0 + 16, yv, xv);       // next tile's loads fly during the MFMAs
+    for (int m0 = m_begin; m0 < m_end; m0 += MR) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int ml = 4 * mq + v;
-            float ya[2], xa[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                ya[q] = ys[buf][ml][wn * 32 + q * 16 + r16];
-                xa[q] = xs[buf][ml][wk * 32 + q * 16 + r16];
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[nt], xa[kt], acc[nt][kt], 0, 0, 0);
+        for (int i = 0; i < NY; ++i) {
+            *reinterpret_cast<f32x4*>(&ys[buf][yrow + i * (256 / PY)][ycol]) = yv[i];
+            if (want_bias) bsum += yv[i];
         }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(&xs[buf][xrow + i * (256 / PX)][xcol]) = xv[i];
+        __syncthreads();                                   // slab `buf` complete; the other buffer is free again
+        if (m0 + MR < m_end) fetch(m0 + MR);               // next slab's loads fly during the MFMAs
+#pragma unroll
+        for (int u = 0; u < MR / 16; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ml = 16 * u + 4 * mq + v;
+                float ya[WTN], xa[WTK];
+#pragma unroll
+                for (int q = 0; q < WTN; ++q) ya[q] = ys[buf][ml][wn * 16 * WTN + q * 16 + r16];
+#pragma unroll
+                for (int q = 0; q < WTK; ++q) xa[q] = xs[buf][ml][wk * 16 * WTK + q * 16 + r16];
+#pragma unroll
+                for (int nt = 0; nt < WTN; ++nt)
+#pragma unroll
+                    for (int kt = 0; kt < WTK; ++kt)
+                        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[nt], xa[kt], acc[nt][kt], 0, 0, 0);
+            }
         buf ^= 1;
     }
 
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < WTN; ++nt)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < WTK; ++kt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int n = n0 + wn * 32 + nt * 16 + mq * 4 + i;
-                const int kc = k0 + wk * 32 + kt * 16 + r16;
+                const int n = n0 + wn * 16 * WTN + nt * 16 + mq * 4 + i;
+                const int kc = k0 + wk * 16 * WTK + kt * 16 + r16;
                 if (n < N && kc < K && partial) {
                     partial[((long)tn_s * N + n) * K + kc] = acc[nt][kt][i];     // combined in fp64 by tn_reduce_kernel
                 } else if (n < N && kc < K) {
@@ -402,14 +443,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                     atomicAdd(&dW[(long)n * ldw + off], acc[nt][kt][i]);
                 }
             }
-    if (want_bias) {       // column sums of dY over this split: 16 staging rows -> one value per column
+    if (want_bias) {       // column sums of dY over this split: 256 / PY staging rows -> one value per column
         __syncthreads();
-        *reinterpret_cast<f32x4*>(&ys[0][srow][scol]) = bsum;
+        *reinterpret_cast<f32x4*>(&ys[0][yrow][ycol]) = bsum;
         __syncthreads();
-        if (t < 64 && n0 + t < N) {
+        if (t < BN && n0 + t < N) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += ys[0][r][t];
+            for (int r = 0; r < 256 / PY; ++r) s += ys[0][r][t];
             atomicAdd(&dbias[n0 + t], s);
         }
     }
@@ -488,18 +529,18 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
     if (tg_get_math_mode() >= 1 && vec && M >= 256 && N >= 32 && w.K >= 32)
         return tg_gemm_nt_bf16_launch(w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope,
                                       accumulate, s);
-    if (vec && N >= 96 && M >= 1024 && w.K >= 64) {
-        // big products: 128-row tiles; 128 columns per tile unless that leaves the last column tile mostly empty or
-        // too few workgroups to fill 256 CUs, then 64
-        const int waste128 = cdiv(N, 128) * 128 - N, waste64 = cdiv(N, 64) * 64 - N;
-        const bool wide = (waste128 <= waste64 + 32) && ((long)cdiv(M, 128) * cdiv(N, 128) >= 384);
-        if (wide) {
-            const int n_nt = cdiv(N, 128);
-            hipLaunchKernelGGL((gemm_nt_big_kernel<4>), dim3(cdiv(M, 128) * n_nt), dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
-        } else {
-            const int n_nt = cdiv(N, 64);
-            hipLaunchKernelGGL((gemm_nt_big_kernel<2>), dim3(cdiv(M, 128) * n_nt), dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
-        }
+    if (vec && N >= 48 && M >= 1024 && w.K >= 64) {
+        const NtTile tl = nt_pick_tile(M, N);
+        const int n_nt = cdiv(N, 32 * tl.tn);
+        const dim3 grid(cdiv(M, 32 * tl.tm) * n_nt);
+#define TG_NT_BIG(TM_, TN_) hipLaunchKernelGGL((gemm_nt_big_kernel<TM_, TN_>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, \
+                                               (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt)
+        if (tl.tm == 4 && tl.tn == 4) TG_NT_BIG(4, 4);
+        else if (tl.tm == 4 && tl.tn == 3) TG_NT_BIG(4, 3);
+        else if (tl.tm == 4 && tl.tn == 2) TG_NT_BIG(4, 2);
+        else if (tl.tm == 2 && tl.tn == 2) TG_NT_BIG(2, 2);
+        else TG_NT_BIG(2, 1);
+#undef TG_NT_BIG
     } else if (N <= 32) {
         const int n_nt = cdiv(N, 32);
         dim3 grid(cdiv(M, 128) * n_nt);
@@ -514,19 +555,24 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
     return check_launch("tg_gemm_nt");
 }
 
+// tile of dW for a weight-gradient shape: 128 x 64 where the n dimension fills it, else 64 x 64
+static bool tn_wide(int N, int K) { return N >= 96 && K >= 48 && (cdiv(N, 128) * 128 - N) <= (cdiv(N, 64) * 64 - N) + 32; }
+
 static void tn_plan(int M, int N, int K, bool two_pass, int* splits_out, int* rows_out) {
-    const int tiles = cdiv(N, 64) * cdiv(K, 64);
+    const bool wide = tn_wide(N, K);
+    const int tiles = cdiv(N, wide ? 128 : 64) * cdiv(K, 64);
     int splits = 1024 / tiles;
+    if (const char* e = getenv("TG_TN_SPLITS")) splits = atoi(e);       // experiment knob
     if (two_pass) {                       // short fp32 chains per split: at most 512 rows, fp64 across splits
         const int by_len = cdiv(M, 512);
         if (splits < by_len) splits = by_len;
     }
-    const int max_splits = cdiv(M, 64);
+    const int max_splits = cdiv(M, wide ? 128 : 64);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
     int rows = cdiv(M, splits);
-    rows = ((rows + 15) / 16) * 16;
+    rows = ((rows + 31) / 32) * 32;
     *rows_out = rows;
     *splits_out = cdiv(M, rows);
 }
@@ -551,10 +597,15 @@ extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, floa
                (long)ws_floats, (long)splits * N * w.K);
     const int vec_y = (ldy % 4 == 0) && aligned16(dY);
     const int vec_a = (w.cw % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr);
-    const int n_nt = cdiv(N, 64), n_kt = cdiv(w.K, 64);
+    const bool wide = tn_wide(N, w.K);
+    const int n_nt = cdiv(N, wide ? 128 : 64), n_kt = cdiv(w.K, 64);
     dim3 grid(n_nt * n_kt * splits);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N, rows_per_split, out_kw,
-                       ws, dbias, vec_y, vec_a, n_nt, n_kt);
+    if (wide)
+        hipLaunchKernelGGL((gemm_tn_kernel<4, 2, 32>), grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N,
+                           rows_per_split, out_kw, ws, dbias, vec_y, vec_a, n_nt, n_kt);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 16>), grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N,
+                           rows_per_split, out_kw, ws, dbias, vec_y, vec_a, n_nt, n_kt);
     if (ws) {
         int blocks = cdiv((long)N * w.K, 16);
         if (blocks > 4096) blocks = 4096;

@@ -134,7 +134,10 @@ def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
     if _lib.load().tg_get_math_mode() == 2 and M >= 256:
         nws = (_lib.load().tg_gemm_tn_bf16_ws_bytes(M, N, A.K) + 3) // 4
         ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
-    elif M >= TN_TWO_PASS_ROWS:
+    elif M >= TN_TWO_PASS_ROWS or (out_kw > 0 and M >= 1024):
+        # two-pass (partial tiles + fp64 combine): long reductions for accuracy, and every conv-layout output (out_kw > 0):
+        # the permuted (Co, Ci, kw) scatter makes the one-pass float atomics uncoalesced (measured 224 -> 39 us on the audio
+        # conv3 weight gradient), the combine kernel writes that layout from contiguous partials instead
         nws = _lib.load().tg_gemm_tn_ws_floats(M, N, A.K)
         ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
     call("tg_gemm_tn", _p(dY), dY.stride(0), C.byref(A.s), _p(dW), A.K, M, N, int(out_kw), _p(dbias), _p(ws), nws, _stream())
