@@ -556,12 +556,19 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
 }
 
 // tile of dW for a weight-gradient shape: 128 x 64 where the n dimension fills it, else 64 x 64
-static bool tn_wide(int N, int K) { return N >= 96 && K >= 48 && (cdiv(N, 128) * 128 - N) <= (cdiv(N, 64) * 64 - N) + 32; }
+static bool tn_wide(int N, int K) {
+    if (const char* e = getenv("TG_TN_WIDE")) return atoi(e) != 0;       // experiment knob
+    (void)N; (void)K;
+    return false;     // the 128 x 64 / 32-row-slab configuration measured slower than 64 x 64 / 16 on every shape of the step
+}
 
 static void tn_plan(int M, int N, int K, bool two_pass, int* splits_out, int* rows_out) {
     const bool wide = tn_wide(N, K);
     const int tiles = cdiv(N, wide ? 128 : 64) * cdiv(K, 64);
-    int splits = 1024 / tiles;
+    // ~320 rows per workgroup (20 slabs: enough to amortise the prologue and the atomic epilogue), but at least ~640 workgroups
+    // (measured optimum on the M = 4352 weight gradients of the step: 10-16 splits whatever the tile count, tools/tn_probe.py)
+    int splits = cdiv(M, 320);
+    if (splits < cdiv(640, tiles)) splits = cdiv(640, tiles);
     if (const char* e = getenv("TG_TN_SPLITS")) splits = atoi(e);       // experiment knob
     if (two_pass) {                       // short fp32 chains per split: at most 512 rows, fp64 across splits
         const int by_len = cdiv(M, 512);

@@ -10,15 +10,14 @@ def t(fn, iters=20):
     for _ in range(iters): fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) * 1e3 / iters
-for (M, N, K) in ((4352, 900, 600), (4352, 900, 300), (4352, 300, 600), (27776, 64, 480), (4352, 32, 960), (7168, 192, 128), (7168, 192, 64), (4352, 150, 300), (168064, 32, 240)):
+for (M, N, K) in ((4352, 900, 600), (4352, 900, 300), (4352, 300, 600), (4352, 900, 108), (7168, 192, 128)):
     dy, x = torch.randn(M, N, device=dev), torch.randn(M, K, device=dev)
     dW, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
-    res = []
-    for two_pass in (False, True):
-        ops.TN_TWO_PASS_ROWS = 1 if two_pass else 1 << 30
-        for sp in ("", "4", "8", "16", "32", "64"):
-            if sp: os.environ["TG_TN_SPLITS"] = sp
-            else: os.environ.pop("TG_TN_SPLITS", None)
+    for wide in ("0", "1"):
+        os.environ["TG_TN_WIDE"] = wide
+        res = []
+        for sp in ("4", "6", "8", "10", "12", "14", "16", "20", "24", "32"):
+            os.environ["TG_TN_SPLITS"] = sp
             us = t(lambda: ops.gemm_tn(dy, Win.plain(x), dW, dbias=db))
-            res.append(f"{'2p' if two_pass else 'at'}{sp or 'def'}:{us:6.1f}")
-    print(f"tn M={M} N={N} K={K}  " + " ".join(res))
+            res.append(f"{sp}:{us:6.1f}")
+        print(f"tn M={M} N={N} K={K} wide={wide}  " + " ".join(res))
