@@ -237,6 +237,9 @@ def main():
                     help="f32: exact fp32 matrix cores (parity ~1e-6). bf16: forward / input-gradient GEMMs feed the matrix cores "
                          "with bf16 operands, fp32 accumulate, fp32 everywhere else (tolerance 2e-2 / 5e-2)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--host-input", action="store_true",
+                    help="feed every iteration from host memory through data.DeviceBatchFeeder (PCIe-inclusive rate for DESIGN.md; "
+                         "never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path (graph segments + RCCL) even with one rank")
     a = ap.parse_args()
@@ -276,6 +279,21 @@ def main():
         step = lambda: trainer.train_iter(a.epoch, text, audio, poses, vid)
     else:
         step = pkg.GraphedGanStep(trainer, a.epoch, text, audio, poses, vid, warmup_iters=2)
+    feeder = None
+    if a.host_input:
+        assert not a.no_graph, "--host-input drives the captured step"
+        data = importlib.import_module(PKG + ".data")
+        feeder = data.DeviceBatchFeeder(*step.static)
+        pool = [tuple(t.cpu() for t in synthetic_batch(a.batch, 4321 + 17 * i + rank, device)) for i in range(4)]
+        pool = [(t, p_, au, v) for (t, au, p_, v) in pool]          # feeder.put(text, vec, audio, vid)
+        feeder.put(*pool[0])
+        plain_step = step
+
+        def step(_k=[0]):
+            feeder.ready()
+            _k[0] += 1
+            feeder.put(*pool[_k[0] % len(pool)])                    # next batch's host->device copy overlaps this iteration
+            return plain_step()
     for _ in range(a.warmup):
         losses = step()
 
@@ -299,7 +317,7 @@ def main():
     if rank == 0:
         clips_per_s = world * a.batch * a.steps / dt
         out = {
-            "metric": "training clips/sec (34-frame, 27-dim pose), post-warm-up GAN iteration",
+            "metric": "training clips/sec (34-frame, 27-dim pose), post-warm-up GAN iteration" + (" [host-fed, PCIe-inclusive]" if a.host_input else ""),
             "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",

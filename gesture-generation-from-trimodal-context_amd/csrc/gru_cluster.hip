@@ -29,7 +29,11 @@ constexpr int GC_HX = 320;            // exchange-buffer row stride (floats): 10
 constexpr int GC_FLAG_STRIDE = 16;    // flag words per cluster (one 64-byte line)
 constexpr int GC_KS = 4;
 constexpr int GC_PF = 5;              // K chunks (of 16) per wave: covers H <= 320
-constexpr unsigned GC_SPIN_LIMIT = 400000u;
+// Bound of every spin: 2^26 polls (>= 20 ns each: 1.3 s or more).  A wait is normally < 10 us; it gets long only when another
+// queue's kernels (e.g. a blit copy on a copy stream) keep some cluster members from becoming resident for a while -- that is a
+// delay, not a dead-lock, and must not invalidate the results (a 2^19-poll bound, ~8 ms, did trip beside a slow host-to-device
+// copy); only a member that can never run trips this one.
+constexpr unsigned GC_SPIN_LIMIT = 1u << 26;
 constexpr unsigned GC_RSRC3 = 0x00020000u;   // gfx9 raw buffer descriptor word 3 (32-bit data format)
 
 __device__ __forceinline__ f32x4 as_f32x4(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
@@ -117,7 +121,12 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_kernel(
                     const unsigned v = lane < CW ? __hip_atomic_load(cl_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
                     if (__all(v >= (unsigned)step)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > GC_SPIN_LIMIT) {
+                    if (++spins > GC_SPIN_LIMIT) {                    // wave-uniform
+                        if (lane == 0) {      // who / when (words 1, 2) and the flag words it saw (4..): diagnostics for the host
+                            __hip_atomic_store((gu32*)tmo + 1, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store((gu32*)tmo + 2, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (lane < CW) __hip_atomic_store((gu32*)tmo + 4 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (lane == 0) __hip_atomic_store((gu32*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         aborted = true;
                         break;
@@ -285,7 +294,12 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_kernel(
                     const unsigned v = lane < CW ? __hip_atomic_load(cl_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
                     if (__all(v >= (unsigned)step)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > GC_SPIN_LIMIT) {
+                    if (++spins > GC_SPIN_LIMIT) {                    // wave-uniform
+                        if (lane == 0) {      // who / when (words 1, 2) and the flag words it saw (4..): diagnostics for the host
+                            __hip_atomic_store((gu32*)tmo + 1, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store((gu32*)tmo + 2, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (lane < CW) __hip_atomic_store((gu32*)tmo + 4 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (lane == 0) __hip_atomic_store((gu32*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         aborted = true;
                         break;

@@ -1,0 +1,165 @@
+"""Input-pipeline stand-in: sample -> training tensors -> device batch (data_loader/lmdb_data_loader.py:107-171, :43-53;
+utils/data_utils.py:68-74; train.py:169-183).
+
+The reference reads pyarrow-0.14-serialised samples from LMDB (neither is available here); what follows that read
+is restated: a *sample* is the tuple the reference deserialises, `(word_seq, pose_seq, vec_seq, audio, spectrogram, aux_info)`
+with word_seq = [[word, start_s, end_s], ...] and aux_info = {'vid', 'start_time', 'end_time', ...}.  `sample_to_tensors` is
+`SpeechMotionDataset.__getitem__` after the read; `collate` is `default_collate_fn` restricted to what the multimodal model
+consumes; `DeviceBatchFeeder` replaces the `.to(device)` calls of the training loop with pinned staging buffers and asynchronous
+copies into static device tensors on a copy stream, double-buffered, so that the host-to-device transfer of batch i+1 overlaps
+iteration i of a hipGraph-replayed step (GraphedGanStep reads the same static tensors every replay).
+"""
+import numpy as np
+import torch
+
+
+def make_audio_fixed_length(audio, expected_audio_length):
+    """utils/data_utils.py:68-74: symmetric padding or truncation."""
+    n_padding = expected_audio_length - len(audio)
+    if n_padding > 0:
+        return np.pad(audio, (0, n_padding), mode="symmetric")
+    return audio[0:expected_audio_length]
+
+
+def extend_word_seq(lang, words, start_time, end_time, n_frames, remove_word_timing=False):
+    """lmdb_data_loader.py:115-140: one vocabulary index per pose frame at each word's onset frame, 0 (PAD) elsewhere."""
+    frame_duration = (end_time - start_time) / n_frames
+    out = np.zeros(n_frames, dtype=np.int64)
+    if remove_word_timing:
+        n_words = 0
+        for word in words:
+            idx = max(0, int(np.floor((word[1] - start_time) / frame_duration)))
+            if idx < n_frames:
+                n_words += 1
+        space = int(n_frames / (n_words + 1))
+        for i in range(n_words):
+            out[(i + 1) * space] = lang.get_word_index(words[i][0])
+    else:
+        for word in words:
+            idx = max(0, int(np.floor((word[1] - start_time) / frame_duration)))
+            if idx < n_frames:
+                out[idx] = lang.get_word_index(word[0])
+    return out
+
+
+def words_to_tensor(lang, words, end_time=None):
+    """lmdb_data_loader.py:142-149: [SOS, w..., EOS] (used by the seq2seq baseline; kept for the collate's return arity)."""
+    indexes = [lang.SOS_token]
+    for word in words:
+        if end_time is not None and word[1] > end_time:
+            break
+        indexes.append(lang.get_word_index(word[0]))
+    indexes.append(lang.EOS_token)
+    return np.asarray(indexes, dtype=np.int64)
+
+
+def sample_to_tensors(sample, lang_model, n_poses, pose_resampling_fps, remove_word_timing=False):
+    """SpeechMotionDataset.__getitem__ after the LMDB read (:151-171).  Returns
+    (word_seq (L,) int64, extended_word_seq (n_poses,) int64, pose_seq (n_poses, 30) f32, vec_seq (n_poses, 27) f32,
+    audio (expected_audio_length,) f32, aux_info)."""
+    word_seq, pose_seq, vec_seq, audio, _spectrogram, aux_info = sample
+    expected_audio_length = int(round(n_poses / pose_resampling_fps * 16000))
+    duration = aux_info["end_time"] - aux_info["start_time"]
+    sample_end_time = aux_info["start_time"] + duration * n_poses / vec_seq.shape[0]
+    audio = make_audio_fixed_length(np.asarray(audio), expected_audio_length)
+    vec_seq = np.asarray(vec_seq)[0:n_poses]
+    pose_seq = np.asarray(pose_seq)[0:n_poses]
+    words = words_to_tensor(lang_model, word_seq, sample_end_time)
+    ext = extend_word_seq(lang_model, word_seq, aux_info["start_time"], sample_end_time, n_poses, remove_word_timing)
+    return (torch.from_numpy(words), torch.from_numpy(ext), torch.from_numpy(pose_seq.reshape(pose_seq.shape[0], -1)).float(),
+            torch.from_numpy(vec_seq.reshape(vec_seq.shape[0], -1)).float(), torch.from_numpy(np.ascontiguousarray(audio)).float(), aux_info)
+
+
+def collate(items, speaker_model=None):
+    """default_collate_fn (:43-53) for the multimodal model + the speaker lookup of train.py:178-183.
+    Returns (in_text_padded (B, T) int64, target_vec (B, T, 27) f32, in_audio (B, A) f32, vid_indices (B,) int64 or None)."""
+    text = torch.stack([it[1] for it in items])
+    vec = torch.stack([it[3] for it in items])
+    audio = torch.stack([it[4] for it in items])
+    vid = None
+    if speaker_model is not None and hasattr(speaker_model, "word2index"):
+        vid = torch.tensor([speaker_model.word2index[it[5]["vid"]] for it in items], dtype=torch.int64)
+    return text, vec, audio, vid
+
+
+class SyntheticSpeechMotionDataset(torch.utils.data.Dataset):
+    """Samples in the reference's stored format, generated deterministically: random-walk direction vectors, band-limited noise
+    audio with a random (slightly wrong) length, 4-12 words with onset times inside the clip, one of `n_speakers - 1` videos."""
+
+    def __init__(self, n_samples, lang_model, speaker_model, n_poses=34, fps=15, seed=0, mean_dir_vec=None):
+        self.n, self.lang, self.spk = n_samples, lang_model, speaker_model
+        self.n_poses, self.fps, self.seed = n_poses, fps, seed
+        self.words = [w for w in lang_model.word2index]
+        self.vids = list(speaker_model.word2index)
+
+    def __len__(self):
+        return self.n
+
+    def raw(self, idx):
+        r = np.random.RandomState(self.seed * 1000003 + idx)
+        n_ext = int(round(self.n_poses * 1.25))                        # the preprocessor stores 25 % margin (:84)
+        vec = np.cumsum(r.randn(n_ext, 9, 3).astype(np.float32) * 0.02, axis=0)
+        vec /= np.maximum(np.linalg.norm(vec, axis=-1, keepdims=True), 1e-6)
+        vec = (vec - vec.mean(0, keepdims=True)).astype(np.float32)
+        pose = np.cumsum(r.randn(n_ext, 10, 3).astype(np.float32) * 0.01, axis=0)
+        start = float(r.uniform(0, 100))
+        dur = n_ext / self.fps
+        n_audio = int(dur * 16000) + int(r.randint(-200, 200))
+        audio = (0.1 * r.randn(n_audio)).astype(np.float32)
+        n_words = int(r.randint(4, 13))
+        onsets = np.sort(r.uniform(start, start + dur, n_words))
+        words = [[self.words[int(r.randint(len(self.words)))], float(t0), float(t0 + 0.2)] for t0 in onsets]
+        aux = {"vid": self.vids[int(r.randint(len(self.vids)))], "start_time": start, "end_time": start + dur,
+               "start_frame_no": 0, "end_frame_no": n_ext}
+        return words, pose, vec, audio, np.zeros((128, 1), np.float32), aux
+
+    def __getitem__(self, idx):
+        return sample_to_tensors(self.raw(idx), self.lang, self.n_poses, self.fps)
+
+
+class DeviceBatchFeeder:
+    """Double-buffered host->device staging for a static-shape training step.
+
+    `static` are the device tensors a GraphedGanStep was captured on (GraphedGanStep.static).  put(batch) copies a collated batch
+    into a free pinned host slot and enqueues its asynchronous copy into a device staging slot on a copy stream -- this overlaps
+    the iteration that is running; ready() makes the compute stream wait for that copy and moves staging -> static with
+    device-to-device copies (19 MB at B = 128: ~10 us), after which the step can be replayed."""
+
+    def __init__(self, static_text, static_audio, static_target, static_vid):
+        self.static = (static_text, static_audio, static_target, static_vid)
+        self.dev = static_text.device
+        self.pinned = [tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in self.static) for _ in range(2)]
+        self.staging = [tuple(torch.empty_like(t) for t in self.static) for _ in range(2)]
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.h2d_done = [None, None]          # per slot: host -> staging copy finished (pinned slot reusable, staging valid)
+        self.d2d_done = [None, None]          # per slot: staging -> static copy finished (staging slot reusable)
+        self.i = 0
+        self.pending = None
+
+    def put(self, text, vec, audio, vid):
+        slot = self.i
+        self.i ^= 1
+        if self.h2d_done[slot] is not None:
+            self.h2d_done[slot].synchronize()                 # never overwrite pinned memory a copy may still be reading
+        for dst, src in zip(self.pinned[slot], (text, audio, vec, vid)):
+            dst.copy_(src)
+        with torch.cuda.stream(self.stream):
+            if self.d2d_done[slot] is not None:
+                self.stream.wait_event(self.d2d_done[slot])   # the staging slot has been drained into the static tensors
+            for dst, src in zip(self.staging[slot], self.pinned[slot]):
+                dst.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.h2d_done[slot] = ev
+        self.pending = slot
+
+    def ready(self):
+        """Compute stream: wait for the newest batch and move it into the step's static input tensors."""
+        slot = self.pending
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(self.h2d_done[slot])
+        for dst, src in zip(self.static, self.staging[slot]):
+            dst.copy_(src, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.d2d_done[slot] = ev

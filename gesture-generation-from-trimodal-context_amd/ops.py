@@ -175,8 +175,10 @@ def check_async_errors():
     """Raise if a bounded spin of a persistent kernel timed out since the last check (synchronises; tests, bench, loss read-out)."""
     for key, ws in _gru_ws.items():
         if int(ws[0].item()) != 0:
+            info = ws[:14].tolist()
             ws[0] = 0
-            raise RuntimeError(f"persistent GRU kernel timed out waiting for a cluster member (device, B, H) = {key}; results are invalid")
+            raise RuntimeError(f"persistent GRU kernel timed out waiting for a cluster member (device, B, H, bwd) = {key}: step {info[1]}, "
+                               f"workgroup {info[2]}, flag words seen {info[4:14]}; results are invalid")
 
 
 def gru_forward(gi, w_hh, b_hh, y, save):

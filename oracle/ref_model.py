@@ -689,3 +689,39 @@ def make_batch(seed, batch, n_words=512, n_speakers=17, n_frames=34, pose_dim=27
     vid = torch.randint(1, n_speakers, (batch,), generator=g)
     poses = 0.1 * torch.randn(batch, n_frames, pose_dim, generator=g)
     return text, audio, vid, poses
+
+
+# --------------------------------------------------------------------------- input pipeline (after the LMDB read)
+def data_make_audio_fixed_length(audio, expected_audio_length):
+    """utils/data_utils.py:68-74."""
+    n_padding = expected_audio_length - len(audio)
+    if n_padding > 0:
+        audio = np.pad(audio, (0, n_padding), mode="symmetric")
+    else:
+        audio = audio[0:expected_audio_length]
+    return audio
+
+
+def data_getitem(sample, word_index, n_poses=34, fps=15, remove_word_timing=False):
+    """SpeechMotionDataset.__getitem__ (data_loader/lmdb_data_loader.py:107-171) after `pyarrow.deserialize`; `word_index`
+    maps a word to its vocabulary id (lang_model.get_word_index).  Returns (extended_word_seq, vec_seq, audio) as numpy.
+    parity unpinned: lmdb_data_loader.py needs lmdb / pyarrow 0.14 and cannot be imported; checked against
+    hand-computed values in tests/test_data_cpu.py."""
+    word_seq, pose_seq, vec_seq, audio, spectrogram, aux_info = sample
+    duration = aux_info["end_time"] - aux_info["start_time"]
+    sample_end_time = aux_info["start_time"] + duration * n_poses / vec_seq.shape[0]          # :153
+    audio = data_make_audio_fixed_length(audio, int(round(n_poses / fps * 16000)))            # :154, :62
+    vec_seq = vec_seq[0:n_poses]
+    frame_duration = (sample_end_time - aux_info["start_time"]) / n_poses                     # :119
+    ext = np.zeros(n_poses)
+    onset_frames = [max(0, int(np.floor((w[1] - aux_info["start_time"]) / frame_duration))) for w in word_seq]
+    if remove_word_timing:                                                                     # :122-131
+        n_words = sum(1 for f in onset_frames if f < n_poses)
+        space = int(n_poses / (n_words + 1))
+        for i in range(n_words):
+            ext[(i + 1) * space] = word_index(word_seq[i][0])
+    else:                                                                                      # :132-139
+        for w, f in zip(word_seq, onset_frames):
+            if f < n_poses:
+                ext[f] = word_index(w[0])
+    return ext.astype(np.int64), vec_seq.reshape(vec_seq.shape[0], -1).astype(np.float32), np.asarray(audio, dtype=np.float32)

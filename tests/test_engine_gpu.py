@@ -333,3 +333,44 @@ def test_window_synthesis_matches_oracle_blend(pkg, dev):
         # the reference seeds window i+1 with the RAW last 4 frames of window i (out_dir_vec, before blending): synthesize.py:122-124
     ref = O.blend_windows(outs)
     assert rel(res, ref) < 1e-5
+
+
+def test_device_batch_feeder_drives_graphed_step(pkg, dev):
+    """data.DeviceBatchFeeder: collated host batches -> pinned -> staging (copy stream) -> the static tensors of a captured step.
+    Same losses as handing the same batches to the step directly (same seeds, same iteration order)."""
+    import importlib
+    D = importlib.import_module(pkg.__name__ + ".data")
+    V, S, B = 64, 9, 8
+    lang = pkg.Vocab("words")
+    for i in range(V - 4):
+        lang.index_word(f"w{i}")
+    spk = pkg.Vocab.speakers(S)
+    ds = D.SyntheticSpeechMotionDataset(3 * B, lang, spk, seed=11)
+    batches = [D.collate([ds[i] for i in range(k * B, (k + 1) * B)], spk) for k in range(3)]
+    out = []
+    for use_feeder in (False, True):
+        gst, dst = O.make_generator_state(5, V, S), O.make_discriminator_state(6)
+        args, G, Dn = build_models(pkg, dev, gst, dst, V, S)
+        G.train(); Dn.train()
+        tr = pkg.GanTrainer(G, Dn, args)
+        text, vec, audio, vid = (t.to(dev) for t in batches[0])
+        step = pkg.GraphedGanStep(tr, 11, text, audio, vec, vid, warmup_iters=1)
+        losses = []
+        if use_feeder:
+            feeder = D.DeviceBatchFeeder(*step.static)
+            feeder.put(*batches[0])
+            for k in range(3):
+                feeder.ready()
+                if k + 1 < 3:
+                    feeder.put(*batches[k + 1])              # overlaps the replay below
+                losses.append(step().to_dict())
+                assert torch.equal(step.static[0].cpu(), batches[k][0]) and torch.equal(step.static[2].cpu(), batches[k][1])
+        else:
+            for k in range(3):
+                text, vec, audio, vid = (t.to(dev) for t in batches[k])
+                losses.append(step(text, audio, vec, vid).to_dict())
+        out.append(losses)
+    for a, b in zip(*out):
+        assert sorted(a) == sorted(b)
+        for k in a:       # float atomics in the weight gradients make two runs differ at the 1e-5 level after a few Adam steps
+            assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
