@@ -34,6 +34,12 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Zero `bytes` (a multiple of 4) at p with a kernel of this library.  Used instead of hipMemsetAsync everywhere: a memset
+// captured into a hipGraph replays as a runtime fill kernel that reads its pattern from a staging area of the runtime, and on
+// ROCm 7.2 that area is reused by eager blit copies issued between replays -- the "zero" fill then wrote copy arguments
+// (source / destination pointers) over the flag words of the persistent GRU kernels (tools/feeder_probe2.py).
+int zero_async(void* p, size_t bytes, hipStream_t s);
+
 // grid for a grid-stride element-wise kernel: enough blocks to fill 256 CUs, capped (guide: Guideline 11)
 inline int ew_grid(int64_t n, int block = 256, int per_thread = 4) {
     int64_t b = (n + (int64_t)block * per_thread - 1) / ((int64_t)block * per_thread);

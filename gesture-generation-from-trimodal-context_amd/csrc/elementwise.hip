@@ -6,6 +6,27 @@ namespace tg {
 
 #define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
+__global__ void zero_kernel(unsigned* __restrict__ p, long n_words) {
+    const long n4 = n_words >> 2;                       // 16-byte stores where the pointer allows (checked by the launcher)
+    GRID_STRIDE(i, n4) reinterpret_cast<uint4*>(p)[i] = uint4{0u, 0u, 0u, 0u};
+    GRID_STRIDE(i, n_words - 4 * n4) p[4 * n4 + i] = 0u;
+}
+__global__ void zero_kernel_unaligned(unsigned* __restrict__ p, long n_words) {
+    GRID_STRIDE(i, n_words) p[i] = 0u;
+}
+
+int zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return 0;
+    if (p == nullptr || (bytes & 3u) || (reinterpret_cast<uintptr_t>(p) & 3u)) { set_error("zero_async: bad pointer / size"); return 1; }
+    const long n_words = (long)(bytes >> 2);
+    long blocks = (n_words / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    if (aligned16(p)) hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned*)p, n_words);
+    else hipLaunchKernelGGL(zero_kernel_unaligned, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned*)p, n_words);
+    return check_launch("zero_async");
+}
+
 __global__ void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
     GRID_STRIDE(i, n) { const float v = a[i] + b[i]; y[i] = v > 0.f ? v : 0.f; }
 }
@@ -318,6 +339,10 @@ int tg_act_mask_bwd(const float* dy, const float* y, const float* mask, float sl
     TG_REQUIRE(dy && y && dx && n >= 0, "tg_act_mask_bwd: bad arguments");
     EW(act_mask_bwd_kernel, n, dy, y, mask, slope, dx, (long)n);
     return check_launch("tg_act_mask_bwd");
+}
+int tg_zero(void* p, int64_t bytes, void* stream) {
+    TG_REQUIRE(bytes >= 0, "tg_zero: bad size");
+    return zero_async(p, (size_t)bytes, (hipStream_t)stream);
 }
 int tg_mul(const float* x, const float* mask, float* y, int64_t n, void* stream) {
     TG_REQUIRE(x && mask && y && n >= 0, "tg_mul: bad arguments");

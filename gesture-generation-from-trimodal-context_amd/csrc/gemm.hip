@@ -625,7 +625,7 @@ extern "C" int tg_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, floa
     TG_REQUIRE(X && out && M > 0 && N > 0 && ldx >= N, "tg_colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) {
-        if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) { set_error("tg_colsum: memset failed"); return 1; }
+        if (zero_async(out, sizeof(float) * (size_t)N, s)) return 1;
     }
     int splits = 512 / cdiv(N, 64);
     const int max_splits = cdiv(M, 64);

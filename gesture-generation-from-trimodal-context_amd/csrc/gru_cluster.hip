@@ -406,7 +406,7 @@ extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, co
     const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
     hipStream_t s = (hipStream_t)stream;
     // every polled word is zeroed on the stream before every launch (a memset node under graph capture)
-    if (hipMemsetAsync(ws, 0, (size_t)flag_words * 4, s) != hipSuccess) { set_error("tg_gru_forward_cluster: memset failed"); return 1; }
+    if (zero_async(ws, (size_t)flag_words * 4, s)) return 1;
     unsigned* tmo = (unsigned*)ws;
     unsigned* flags = tmo + GC_FLAG_STRIDE;
     float* hx = (float*)(tmo + flag_words);
@@ -454,7 +454,7 @@ extern "C" int tg_gru_backward_cluster(const float* dy, const float* y, const fl
     cluster_plan_bwd(B, H, &n_bt, &cw);
     const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, (size_t)flag_words * 4, s) != hipSuccess) { set_error("tg_gru_backward_cluster: memset failed"); return 1; }
+    if (zero_async(ws, (size_t)flag_words * 4, s)) return 1;
     unsigned* tmo = (unsigned*)ws;
     unsigned* flags = tmo + GC_FLAG_STRIDE;
     float* gx = (float*)(tmo + flag_words);

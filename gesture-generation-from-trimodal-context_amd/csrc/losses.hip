@@ -238,7 +238,7 @@ int tg_gan_g_loss(const float* out_pose, const float* target, const float* out_r
 
 int tg_l1_mean(const float* a, const float* b, int64_t n, float* out, void* stream) {
     TG_REQUIRE(a && b && out && n > 0, "tg_l1_mean: bad arguments");
-    if (hipMemsetAsync(out, 0, sizeof(float), ST) != hipSuccess) { set_error("tg_l1_mean: memset"); return 1; }
+    if (zero_async(out, sizeof(float), ST)) return 1;
     hipLaunchKernelGGL(l1_mean_kernel, dim3(ew_grid(n, 256, 8)), dim3(256), 0, ST, a, b, (long)n, out);
     return check_launch("tg_l1_mean");
 }
@@ -252,7 +252,7 @@ int tg_window_blend(const float* prev_tail, float* next, int32_t B, int32_t T, i
 int tg_pose_metrics(const float* out_dir_vec, const float* target_dir_vec, const float* mean_dir_vec, int32_t B, int32_t T,
                     int32_t n_pre, double* sums, void* stream) {
     TG_REQUIRE(out_dir_vec && target_dir_vec && mean_dir_vec && sums && B > 0 && T > 2 && n_pre >= 0 && n_pre < T, "tg_pose_metrics: bad arguments");
-    if (hipMemsetAsync(sums, 0, 3 * sizeof(double), ST) != hipSuccess) { set_error("tg_pose_metrics: memset"); return 1; }
+    if (zero_async(sums, 3 * sizeof(double), ST)) return 1;
     hipLaunchKernelGGL(pose_metrics_kernel, dim3(ew_grid((long)B * T, 256, 1)), dim3(256), 0, ST, out_dir_vec, target_dir_vec, mean_dir_vec, B, T,
                        n_pre, sums);
     return check_launch("tg_pose_metrics");
@@ -260,7 +260,7 @@ int tg_pose_metrics(const float* out_dir_vec, const float* target_dir_vec, const
 
 int tg_ae_loss(const float* recon, const float* target, int32_t B, int32_t T, int32_t D, float* out, float* d_recon, void* stream) {
     TG_REQUIRE(recon && target && out && d_recon && B > 0 && T > 1 && D > 0, "tg_ae_loss: bad arguments");
-    if (hipMemsetAsync(out, 0, sizeof(float), ST) != hipSuccess) { set_error("tg_ae_loss: memset"); return 1; }
+    if (zero_async(out, sizeof(float), ST)) return 1;
     hipLaunchKernelGGL(ae_loss_kernel, dim3(ew_grid((long)B * T * D, 256, 4)), dim3(256), 0, ST, recon, target, B, T, D, out, d_recon);
     return check_launch("tg_ae_loss");
 }

@@ -159,7 +159,7 @@ extern "C" int tg_bn_train_stats(const float* x, int32_t rows, int32_t C, int32_
     TG_REQUIRE(x && ws && mean && rstd && repeats >= 1, "tg_bn_train_stats: null pointer / repeats < 1");
     TG_REQUIRE(C > 0 && C <= 256 && groups > 0 && rows > 0 && rows % groups == 0, "tg_bn_train_stats: C=%d (<=256), rows=%d, groups=%d", C, rows, groups);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)groups * C, s) != hipSuccess) { set_error("tg_bn_train_stats: memset"); return 1; }
+    if (zero_async(ws, sizeof(double) * 2 * (size_t)groups * C, s)) return 1;
     const int rpg = rows / groups;
     const int rpi = 256 / C;
     int blocks = cdiv(rpg, rpi * 16);
@@ -195,7 +195,7 @@ extern "C" int tg_bn_backward(const float* dy, const float* x, float* dx, int32_
     TG_REQUIRE(dy && x && dx && mean && rstd && gamma && beta && ws, "tg_bn_backward: null pointer");
     TG_REQUIRE(rows > 0 && C > 0 && C <= 256, "tg_bn_backward: C=%d must be <= 256", C);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) { set_error("tg_bn_backward: memset"); return 1; }
+    if (zero_async(ws, sizeof(double) * 2 * (size_t)C, s)) return 1;
     const int rpi = 256 / C;
     int blocks = cdiv(rows, rpi * 16);
     if (blocks > 1024) blocks = 1024;

@@ -118,23 +118,30 @@ class SyntheticSpeechMotionDataset(torch.utils.data.Dataset):
 
 
 class DeviceBatchFeeder:
-    """Double-buffered host->device staging for a static-shape training step.
+    """Host -> device staging for a static-shape training step (the `.to(device)` calls of train.py:172-183).
 
     `static` are the device tensors a GraphedGanStep was captured on (GraphedGanStep.static).  put(batch) copies a collated batch
-    into a free pinned host slot and enqueues its asynchronous copy into a device staging slot on a copy stream -- this overlaps
-    the iteration that is running; ready() makes the compute stream wait for that copy and moves staging -> static with
-    device-to-device copies (19 MB at B = 128: ~10 us), after which the step can be replayed."""
+    into a free pinned host slot (two slots) and enqueues its asynchronous host-to-device copy; ready() makes the batch the
+    step's input.  Two modes:
+      * overlap=False (default): the copy goes straight into the static tensors on the compute stream, stream-ordered behind the
+        previous replay: +0.4 ms per iteration at B = 128 (19 MB at ~50 GiB/s), nothing else on the GPU is disturbed;
+      * overlap=True: the copy goes into a device staging slot on a separate copy stream while the current iteration runs, and
+        ready() moves staging -> static with device-to-device copies.  Measured on MI355X / ROCm 7.2: 10.06 vs 10.03 ms per
+        iteration -- no gain (the copy beside a replay of chip-filling kernels stretches the replay by what it saves), kept as
+        an option."""
 
-    def __init__(self, static_text, static_audio, static_target, static_vid):
+    def __init__(self, static_text, static_audio, static_target, static_vid, overlap=False):
         self.static = (static_text, static_audio, static_target, static_vid)
         self.dev = static_text.device
+        self.overlap = overlap
         self.pinned = [tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in self.static) for _ in range(2)]
-        self.staging = [tuple(torch.empty_like(t) for t in self.static) for _ in range(2)]
-        self.stream = torch.cuda.Stream(device=self.dev)
-        self.h2d_done = [None, None]          # per slot: host -> staging copy finished (pinned slot reusable, staging valid)
-        self.d2d_done = [None, None]          # per slot: staging -> static copy finished (staging slot reusable)
+        self.h2d_done = [None, None]          # per slot: host -> device copy finished (pinned slot reusable)
         self.i = 0
         self.pending = None
+        if overlap:
+            self.staging = [tuple(torch.empty_like(t) for t in self.static) for _ in range(2)]
+            self.stream = torch.cuda.Stream(device=self.dev)
+            self.d2d_done = [None, None]      # per slot: staging -> static copy finished (staging slot reusable)
 
     def put(self, text, vec, audio, vid):
         slot = self.i
@@ -142,24 +149,33 @@ class DeviceBatchFeeder:
         if self.h2d_done[slot] is not None:
             self.h2d_done[slot].synchronize()                 # never overwrite pinned memory a copy may still be reading
         for dst, src in zip(self.pinned[slot], (text, audio, vec, vid)):
-            dst.copy_(src)
-        with torch.cuda.stream(self.stream):
-            if self.d2d_done[slot] is not None:
-                self.stream.wait_event(self.d2d_done[slot])   # the staging slot has been drained into the static tensors
-            for dst, src in zip(self.staging[slot], self.pinned[slot]):
-                dst.copy_(src, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            self.h2d_done[slot] = ev
+            # plain single-threaded memcpy: torch's multi-threaded CPU copy stalled for tens of ms now and then on a many-core host
+            np.copyto(dst.numpy(), src.numpy() if isinstance(src, torch.Tensor) else np.asarray(src))
+        if self.overlap:
+            with torch.cuda.stream(self.stream):
+                if self.d2d_done[slot] is not None:
+                    self.stream.wait_event(self.d2d_done[slot])   # the staging slot has been drained into the static tensors
+                for dst, src in zip(self.staging[slot], self.pinned[slot]):
+                    dst.copy_(src, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                self.h2d_done[slot] = ev
         self.pending = slot
 
     def ready(self):
-        """Compute stream: wait for the newest batch and move it into the step's static input tensors."""
+        """Compute stream: make the newest batch the step's input (call right before replaying the step)."""
         slot = self.pending
         cur = torch.cuda.current_stream(self.dev)
-        cur.wait_event(self.h2d_done[slot])
-        for dst, src in zip(self.static, self.staging[slot]):
-            dst.copy_(src, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        self.d2d_done[slot] = ev
+        if self.overlap:
+            cur.wait_event(self.h2d_done[slot])
+            for dst, src in zip(self.static, self.staging[slot]):
+                dst.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.d2d_done[slot] = ev
+        else:
+            for dst, src in zip(self.static, self.pinned[slot]):
+                dst.copy_(src, non_blocking=True)              # stream-ordered behind the previous replay's reads
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.h2d_done[slot] = ev

@@ -240,8 +240,8 @@ class GeneratorEngine(_Engine):
         if self.z_mode == "speaker":
             # speaker path
             dz = ops.sum_rows(d_in2[:, self.c_z:], L.empty(nb, 16, like=d_in), nb, T)
-            dmu = d_mu.clone() if d_mu is not None else torch.zeros_like(dz)
-            dlv = d_logvar.clone() if d_logvar is not None else torch.zeros_like(dz)
+            dmu = d_mu.clone() if d_mu is not None else ops.zeros_like(dz)
+            dlv = d_logvar.clone() if d_logvar is not None else ops.zeros_like(dz)
             ops.reparam_bwd(dz, tp["logvar"][rows], tp["eps"][rows], dmu, dlv)
             zc = tp["zc"][rows]
             dzc = L.linear_bwd(dmu, zc, P["speaker_mu.weight"], G["speaker_mu.weight"], G["speaker_mu.bias"])
@@ -271,7 +271,7 @@ class GeneratorEngine(_Engine):
                     dc3 = dc.view(nb, T, -1)
                     xin = blk[f"in{ci}"][rows]
                     v = P[pre + ".weight_v"]
-                    dwp = torch.zeros(v.shape[0], 2 * v.shape[1], device=v.device, dtype=v.dtype)
+                    dwp = ops.zeros(v.shape[0], 2 * v.shape[1], device=v.device, dtype=v.dtype)
                     ops.gemm_tn(dc, Win.conv(xin, 2, pad=d, dil=d, rows_out=T), dwp, dbias=G[pre + ".bias"])
                     ops.weight_norm_bwd(dwp, v, P[pre + ".weight_g"], G[pre + ".weight_g"], G[pre + ".weight_v"])
                     # dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0]  -> taps (t + d, t) with B = wp^T per tap

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import vocab
+from . import ops
 from .engine import AutoencoderEngine, DiscriminatorEngine, GeneratorEngine
 
 
@@ -148,10 +149,10 @@ class PoseGenerator(nn.Module):
                 dl = d_lv if d_lv is not None else None
                 if d_z is not None and tp.get("eps") is not None:
                     from . import ops
-                    dm = torch.zeros_like(res["mu"]) if dm is None else dm.contiguous().clone()
-                    dl = torch.zeros_like(res["mu"]) if dl is None else dl.contiguous().clone()
+                    dm = ops.zeros_like(res["mu"]) if dm is None else dm.contiguous().clone()
+                    dl = ops.zeros_like(res["mu"]) if dl is None else dl.contiguous().clone()
                     ops.reparam_bwd(d_z.contiguous(), tp["logvar"], tp["eps"], dm, dl)
-                eng.backward(tp, d_out if d_out is not None else torch.zeros_like(res["out"]), dm, dl)
+                eng.backward(tp, d_out if d_out is not None else ops.zeros_like(res["out"]), dm, dl)
                 return ()
             return (res["out"], res["z"], res["mu"], res["logvar"]), back
 

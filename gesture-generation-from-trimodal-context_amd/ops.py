@@ -103,6 +103,23 @@ def gemm_nt(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_st
     return out
 
 
+def zero_(t):
+    """In-place zero fill by a kernel of the library (never a memset: see csrc/common.hpp zero_async)."""
+    if not t.is_contiguous() or (t.numel() * t.element_size()) % 4:
+        raise ValueError("zero_: needs a contiguous tensor of a multiple of 4 bytes")
+    if t.numel():
+        call("tg_zero", C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), _stream())
+    return t
+
+
+def zeros(*shape, device, dtype=torch.float32):
+    return zero_(torch.empty(*shape, device=device, dtype=dtype))
+
+
+def zeros_like(t):
+    return zero_(torch.empty(t.shape, device=t.device, dtype=t.dtype))
+
+
 def set_math_mode(mode):
     """'f32' (exact fp32 matrix cores, default) or 'bf16' (bf16 operands, fp32 accumulate) for the GEMM-shaped kernels."""
     m = {"f32": 0, "fp32": 0, 0: 0, "bf16": 1, 1: 1, "bf16_all": 2, 2: 2}[mode]

@@ -9,6 +9,8 @@ from collections import OrderedDict
 
 import torch
 
+from . import ops
+
 ALIGN = 4   # floats: every tensor starts 16-byte aligned so vectorised kernels can take any parameter directly
 
 
@@ -68,4 +70,4 @@ class ParamSlab:
         return P, G
 
     def zero_grad(self):
-        self.grad.zero_()
+        ops.zero_(self.grad)

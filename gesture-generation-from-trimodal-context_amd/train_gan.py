@@ -155,7 +155,7 @@ class GanTrainer:
         # the fused loss kernel covers every z_type through its weights: terms the reference leaves out (:59-84) get weight 0
         # and neutral operands (out_rand = out, z_rand = z, mu = logvar = 0)
         speaker_terms = self.G.z_mode == "speaker" and self.use_reg
-        zero_z = torch.zeros(B, 16, device=dev)
+        zero_z = ops.zeros(B, 16, device=dev)
         mu2, lv2 = (st["mu2"].contiguous(), st["lv2"].contiguous()) if speaker_terms else (zero_z, zero_z)
         z2, z3 = (st["z2"].contiguous(), st["z3"].contiguous()) if self.use_reg else (zero_z, zero_z)
         out3 = st["out3"].contiguous() if self.use_reg else out2

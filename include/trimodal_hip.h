@@ -160,6 +160,9 @@ int tg_act_mask_bwd(const float* dy, const float* y, const float* mask, float sl
 /* y = x * mask  (nn.Dropout with a materialised inverted-dropout mask: 0 or 1/(1-p)). */
 int tg_mul(const float* x, const float* mask, float* y, int64_t n, void* stream);
 /* y (+)= alpha * x. */
+/* Zero `bytes` (multiple of 4) at p with a kernel of this library (graph-capture safe; the library never uses hipMemsetAsync:
+ * captured memset nodes were observed to replay with a clobbered fill pattern on ROCm 7.2, see csrc/common.hpp). */
+int tg_zero(void* p, int64_t bytes, void* stream);
 int tg_axpy(const float* x, float* y, float alpha, int32_t accumulate, int64_t n, void* stream);
 /* dst[r*ldd + c] (+)= src[r*lds + c], r < rows, c < cols. */
 int tg_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows, int32_t cols,

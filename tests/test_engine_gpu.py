@@ -348,7 +348,7 @@ def test_device_batch_feeder_drives_graphed_step(pkg, dev):
     ds = D.SyntheticSpeechMotionDataset(3 * B, lang, spk, seed=11)
     batches = [D.collate([ds[i] for i in range(k * B, (k + 1) * B)], spk) for k in range(3)]
     out = []
-    for use_feeder in (False, True):
+    for use_feeder in (False, True, "overlap"):
         gst, dst = O.make_generator_state(5, V, S), O.make_discriminator_state(6)
         args, G, Dn = build_models(pkg, dev, gst, dst, V, S)
         G.train(); Dn.train()
@@ -357,7 +357,7 @@ def test_device_batch_feeder_drives_graphed_step(pkg, dev):
         step = pkg.GraphedGanStep(tr, 11, text, audio, vec, vid, warmup_iters=1)
         losses = []
         if use_feeder:
-            feeder = D.DeviceBatchFeeder(*step.static)
+            feeder = D.DeviceBatchFeeder(*step.static, overlap=(use_feeder == "overlap"))
             feeder.put(*batches[0])
             for k in range(3):
                 feeder.ready()
@@ -370,7 +370,7 @@ def test_device_batch_feeder_drives_graphed_step(pkg, dev):
                 text, vec, audio, vid = (t.to(dev) for t in batches[k])
                 losses.append(step(text, audio, vec, vid).to_dict())
         out.append(losses)
-    for a, b in zip(*out):
+    for a, b in list(zip(out[0], out[1])) + list(zip(out[0], out[2])):
         assert sorted(a) == sorted(b)
         for k in a:       # float atomics in the weight gradients make two runs differ at the 1e-5 level after a few Adam steps
             assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
