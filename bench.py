@@ -58,6 +58,22 @@ def build(pkg, device, seed=0):
     return args, G, Dn
 
 
+def finish(line, dist_on):
+    """Tear the process group down, flush what native libraries buffered on C stdout (RCCL prints a version banner there), then
+    print the ONE JSON line (rank 0) as the last line of stdout."""
+    if dist_on:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if line is not None:
+        print(line, flush=True)
+
+
 def time_kernel(fn, iters=50, warm=5):
     """Average duration (s) of one launch sequence `fn`, HIP events on the stream the kernels are launched on
     (the ops launch on torch's current stream)."""
@@ -157,9 +173,10 @@ def decode_bench(pkg, a, args, G, device, world, rank):
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     assert bool(torch.isfinite(out).all())
+    line = None
     if rank == 0:
         fps = world * a.batch * T * a.steps / dt
-        print(json.dumps({
+        line = (json.dumps({
             "metric": "inference pose-frames/sec (batched 34-frame synthesis windows)", "value": fps, "unit": "pose-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -167,8 +184,7 @@ def decode_bench(pkg, a, args, G, device, world, rank):
                        "utterances_per_gpu": a.batch, "frames": T, "hipgraph": not a.no_graph, "parallelism": f"replicas x{world}"},
             "step_roofline": {"bound": "mfma", "achieved": fps / world / T * 0.5217e9 / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                               "frac": fps / world / T * 0.5217e9 / PEAK_F32_MFMA, "note": "0.5217 GFLOP per window (SURVEY 8d)"}}))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    finish(line, world > 1)
 
 
 def ae_bench(pkg, a, args, device, world, rank):
@@ -211,16 +227,16 @@ def ae_bench(pkg, a, args, device, world, rank):
         dt = float(tmax.item())
     lv = float((loss if graph is not None else r).item())
     assert lv == lv and lv < 1e6
+    line = None
     if rank == 0:
-        print(json.dumps({
+        line = (json.dumps({
             "metric": "FGD autoencoder training clips/sec", "value": world * a.batch * a.steps / dt, "unit": "clips/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "gesture_autoencoder training iteration (BASELINE.json configs[4]): pose-mode EmbeddingNet fwd+bwd+Adam",
                        "batch_per_gpu": a.batch, "frames": T, "pose_dim": D, "hipgraph": not a.no_graph, "parallelism": f"replicas x{world}"},
             "loss": lv}))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    finish(line, world > 1)
 
 
 def main():
@@ -314,6 +330,7 @@ def main():
     loss_dict = losses.to_dict()
     assert all(v == v and abs(v) < 1e6 for v in loss_dict.values()), loss_dict     # finite
 
+    line = None
     if rank == 0:
         clips_per_s = world * a.batch * a.steps / dt
         out = {
@@ -333,10 +350,8 @@ def main():
         out["roofline"] = dominant_kernel_roofline(pkg, device, a.batch)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.batch)
-        print(json.dumps(out))
-    if world > 1 or a.force_ddp:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        line = json.dumps(out)
+    finish(line, world > 1 or a.force_ddp)
 
 
 if __name__ == "__main__":

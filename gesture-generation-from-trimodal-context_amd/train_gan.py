@@ -203,13 +203,16 @@ class GraphedGanStep:
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
             state = {"g": torch.cuda.CUDAGraph()}
-            state["g"].capture_begin(pool=pool)
+            # thread-local capture mode: other threads (the RCCL watchdog polls its events with hipEventQuery) must not invalidate
+            # the capture; everything this thread issues between begin and end is still checked
+            mode = "thread_local" if trainer.grad_sync is not None else "global"
+            state["g"].capture_begin(pool=pool, capture_error_mode=mode)
 
             def cut(action):
                 state["g"].capture_end()
                 self.segments.append((state["g"], action))
                 state["g"] = torch.cuda.CUDAGraph()
-                state["g"].capture_begin(pool=pool)
+                state["g"].capture_begin(pool=pool, capture_error_mode=mode)
             trainer._cut = cut
             try:
                 self.losses = trainer.train_iter(epoch, *self.static)

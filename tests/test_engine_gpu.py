@@ -374,3 +374,35 @@ def test_device_batch_feeder_drives_graphed_step(pkg, dev):
         assert sorted(a) == sorted(b)
         for k in a:       # float atomics in the weight gradients make two runs differ at the 1e-5 level after a few Adam steps
             assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
+
+
+def test_data_parallel_graph_segments_single_rank(pkg, dev, tmp_path):
+    """The data-parallel code path on one rank: RCCL process group (world size 1), gradient buckets, hipGraph captured in segments cut at
+    the all-reduce points (thread-local capture mode: the RCCL watchdog thread polls events while we capture).  Same losses as the
+    plain captured step."""
+    import importlib
+    import torch.distributed as dist
+    ddp = importlib.import_module(pkg.__name__ + ".ddp")
+    V, S, B = 64, 9, 8
+    text, audio, vid, poses = O.make_batch(21, B, V, S)
+    text, audio, vid, poses = text.to(dev), audio.to(dev), vid.to(dev), poses.to(dev)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=dev)
+    try:
+        out = []
+        for use_ddp in (False, True):
+            gst, dst = O.make_generator_state(5, V, S), O.make_discriminator_state(6)
+            args, G, Dn = build_models(pkg, dev, gst, dst, V, S)
+            G.train(); Dn.train()
+            sync = ddp.GradSync() if use_ddp else None
+            tr = pkg.GanTrainer(G, Dn, args, grad_sync=sync)
+            if use_ddp:
+                ddp.broadcast_parameters([tr.G.slab.ensure(), tr.D.slab.ensure()])
+            step = pkg.GraphedGanStep(tr, 11, text, audio, poses, vid, warmup_iters=1)
+            assert (len(step.segments) > 1) == use_ddp
+            losses = [step().to_dict() for _ in range(3)]
+            out.append(losses)
+        for a, b in zip(*out):
+            for k in a:
+                assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    finally:
+        dist.destroy_process_group()
