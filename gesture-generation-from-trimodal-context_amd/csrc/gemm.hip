@@ -10,7 +10,6 @@
 //
 // tg_gemm_tn (weight gradients): the reduction runs over ROWS, so MFMA fragments are column-strided; tiles of 16 rows
 // are staged through LDS with coalesced 16-byte loads, double-buffered, one barrier per tile.
-#include <cstdlib>
 #include "common.hpp"
 
 namespace tg {
@@ -299,8 +298,8 @@ static NtTile nt_pick_tile(int M, int N) {
 // the m range is split over workgroups.  Per MR-row slab every thread fetches 16-byte pieces of dY and of A (coalesced rows),
 // the pieces go to LDS ([row][col], row stride = width + 4 floats: 4 * stride % 32 == 16, so the column-strided ds_read_b32
 // MFMA fragment reads of the two row groups of a 32-lane half hit disjoint banks), the next slab's global loads are in
-// flight while the current slab's MR/4 * WTN * WTK MFMAs per wave run: one barrier per slab.  <4, 2, 32> (128 x 64 tile, 64
-// MFMAs per wave per barrier, 6 LDS reads per 8 MFMAs) is the large-shape configuration, <2, 2, 16> the small one.
+// flight while the current slab's MR/4 * WTN * WTK MFMAs per wave run: one barrier per slab.  <2, 2, 16> (64 x 64 tile) is the
+// configuration in use; larger ones (<4, 2, 32>: 128 x 64, 64 MFMAs per wave per barrier) compile but measured slower here.
 template <int WTN, int WTK, int MR>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, long ldy, Win A, float* __restrict__ dW,
                                                       long ldw, int M, int N, int rows_per_split, int out_kw,
@@ -555,26 +554,19 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
     return check_launch("tg_gemm_nt");
 }
 
-// tile of dW for a weight-gradient shape: 128 x 64 where the n dimension fills it, else 64 x 64
-static bool tn_wide(int N, int K) {
-    if (const char* e = getenv("TG_TN_WIDE")) return atoi(e) != 0;       // experiment knob
-    (void)N; (void)K;
-    return false;     // the 128 x 64 / 32-row-slab configuration measured slower than 64 x 64 / 16 on every shape of the step
-}
-
+// Split plan of a weight gradient: 64 x 64 tiles of dW (the 128 x 64 / 32-row-slab configuration <4, 2, 32> of the kernel measured
+// slower on every shape of the training step, tools/tn_probe.py), the m range cut into ~320-row pieces (20 slabs: enough to
+// amortise the prologue and the atomic epilogue) but at least ~640 workgroups; measured optimum on the M = 4352 weight
+// gradients: 10-16 splits whatever the tile count.
 static void tn_plan(int M, int N, int K, bool two_pass, int* splits_out, int* rows_out) {
-    const bool wide = tn_wide(N, K);
-    const int tiles = cdiv(N, wide ? 128 : 64) * cdiv(K, 64);
-    // ~320 rows per workgroup (20 slabs: enough to amortise the prologue and the atomic epilogue), but at least ~640 workgroups
-    // (measured optimum on the M = 4352 weight gradients of the step: 10-16 splits whatever the tile count, tools/tn_probe.py)
+    const int tiles = cdiv(N, 64) * cdiv(K, 64);
     int splits = cdiv(M, 320);
     if (splits < cdiv(640, tiles)) splits = cdiv(640, tiles);
-    if (const char* e = getenv("TG_TN_SPLITS")) splits = atoi(e);       // experiment knob
     if (two_pass) {                       // short fp32 chains per split: at most 512 rows, fp64 across splits
         const int by_len = cdiv(M, 512);
         if (splits < by_len) splits = by_len;
     }
-    const int max_splits = cdiv(M, wide ? 128 : 64);
+    const int max_splits = cdiv(M, 64);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
@@ -604,15 +596,10 @@ extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, floa
                (long)ws_floats, (long)splits * N * w.K);
     const int vec_y = (ldy % 4 == 0) && aligned16(dY);
     const int vec_a = (w.cw % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr);
-    const bool wide = tn_wide(N, w.K);
-    const int n_nt = cdiv(N, wide ? 128 : 64), n_kt = cdiv(w.K, 64);
+    const int n_nt = cdiv(N, 64), n_kt = cdiv(w.K, 64);
     dim3 grid(n_nt * n_kt * splits);
-    if (wide)
-        hipLaunchKernelGGL((gemm_tn_kernel<4, 2, 32>), grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N,
-                           rows_per_split, out_kw, ws, dbias, vec_y, vec_a, n_nt, n_kt);
-    else
-        hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 16>), grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N,
-                           rows_per_split, out_kw, ws, dbias, vec_y, vec_a, n_nt, n_kt);
+    hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 16>), grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N,
+                       rows_per_split, out_kw, ws, dbias, vec_y, vec_a, n_nt, n_kt);
     if (ws) {
         int blocks = cdiv((long)N * w.K, 16);
         if (blocks > 4096) blocks = 4096;

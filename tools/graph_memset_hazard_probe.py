@@ -1,3 +1,7 @@
+"""Watches the flag / timeout words of the persistent GRU workspaces while a captured training step is replayed with eager copies
+between replays (data.DeviceBatchFeeder).  With hipMemsetAsync in the captured region (the library up to commit \"Persistent cluster
+GRU backward\") every replay filled the flag block with the source / destination pointers of the preceding 1 KB copy instead of zeros
+(ROCm 7.2, MI355X); with the library's own zero kernel (csrc/common.hpp zero_async) the words stay clean.  N_ITERS / SYNC env vars."""
 import importlib, sys, time, torch
 sys.path.insert(0, '/root/repo')
 import bench

@@ -1,3 +1,5 @@
+"""Weight-gradient GEMM timing vs number of m-splits / tile variant.  Used with two temporary environment knobs (TG_TN_SPLITS,
+TG_TN_WIDE) that existed in csrc/gemm.hip while tuning tn_plan(); the knobs are gone, the measured table is quoted there."""
 import importlib, os, sys, torch
 sys.path.insert(0, '/root/repo')
 pkg = importlib.import_module("gesture-generation-from-trimodal-context_amd")
