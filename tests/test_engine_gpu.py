@@ -406,3 +406,29 @@ def test_data_parallel_graph_segments_single_rank(pkg, dev, tmp_path):
                 assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
     finally:
         dist.destroy_process_group()
+
+
+def test_reference_checkpoint_runs_on_gpu(pkg, dev):
+    """The checkpoint written by the reference's own classes (tests/golden/g7_reference_checkpoint.bin: hidden_size 8, 1 layer,
+    13 words, 5 speakers) loads through checkpoint.load_checkpoint_and_model and its eval forward matches the oracle run on the
+    same state dict: the generic-size paths (H = 8 recurrence, 8-channel TCN, 1 layer) of the kernels."""
+    import importlib
+    ck = importlib.import_module(pkg.__name__ + ".checkpoint")
+    path = os.path.join(GOLDEN, "g7_reference_checkpoint.bin")
+    args, G, _, lang, spk, pose_dim = ck.load_checkpoint_and_model(path, dev)
+    raw = ck.load_checkpoint(path)
+    assert G.hidden_size == 8 and G.n_layers == 1 and pose_dim == 27 and not G.training
+    B = 5
+    g = torch.Generator().manual_seed(3)
+    text = torch.randint(0, lang.n_words, (B, 34), generator=g)
+    audio = 0.1 * torch.randn(B, 36267, generator=g)
+    vid = torch.randint(0, spk.n_words, (B,), generator=g)
+    poses = 0.1 * torch.randn(B, 34, 27, generator=g)
+    pre = O.make_pre_seq(poses, 4)
+    eps = torch.randn(B, 16, generator=g)
+    st = {k: v.double() if v.is_floating_point() else v for k, v in raw["gen_dict"].items()}
+    want = O.generator_forward(st, pre.double(), text, audio.double(), vid, training=False, rand=O.Rand(inject={"g.eps": eps.double()}),
+                               n_layers=1, hidden=8, p_drop=args.dropout_prob)
+    with torch.no_grad():
+        res = G.engine.forward(pre.to(dev), text.to(dev), audio.to(dev), vid.to(dev), training=False, inject={"g.eps": eps.to(dev)})
+    assert rel(res["out"], want[0]) < 1e-5 and rel(res["mu"], want[2]) < 1e-5 and rel(res["logvar"], want[3]) < 1e-5
