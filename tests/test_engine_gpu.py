@@ -192,7 +192,6 @@ def test_module_api_autograd_bridge(pkg, dev):
     gr = torch.autograd.grad(loss, list(ps.values()), allow_unused=True)
     ref_grads = dict(zip(ps.keys(), gr))
     inj = to_device_inject(rand.rec, dev)
-    G.engine.forward_inject = inj
     # drive through the nn.Module API with injected draws (engine-level hook used by tests only)
     opt = torch.optim.Adam(G.parameters(), lr=5e-4, betas=(0.5, 0.999))
     opt.zero_grad(set_to_none=False)
