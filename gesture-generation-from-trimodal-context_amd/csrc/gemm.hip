@@ -10,7 +10,6 @@
 //
 // tg_gemm_tn (weight gradients): the reduction runs over ROWS, so MFMA fragments are column-strided; tiles of 16 rows
 // are staged through LDS with coalesced 16-byte loads, double-buffered, one barrier per tile.
-#include <cstdlib>
 #include "common.hpp"
 
 namespace tg {
@@ -340,71 +339,52 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         a_roff[q] = kk * A.dil;
         a_ch[q] = kc - kk * A.cw;
     }
-    // Every staging row keeps a running pointer instead of re-deriving its address per slab (the address arithmetic was a quarter
-    // of the kernel's time: 16 MFMAs per wave per slab do not hide 50 VALU instructions): xp[i] = address of (row, tap 0,
-    // channel 0) of the row's source position, advanced by MR rows per slab with a jump at clip boundaries; mr[i] = row in clip
-    // (for the zero-padding test); yp[i] likewise for dY.
-    int mr[NX], m_x[NX];
-    const float* xp[NX];
-    const long x_row_adv = (long)A.step * A.rs;                       // one output row further
-    const long x_clip_jump = A.bs - (long)A.rows_out * x_row_adv;       // ... across a clip boundary
+    int mb[NX], mr[NX];                       // (clip, row in clip) of each A staging row, advanced incrementally
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const int m = m_begin + xrow + i * (256 / PX);
-        const int b = m / A.rows_out;
-        mr[i] = m - b * A.rows_out;
-        m_x[i] = m;
-        xp[i] = A.ptr + (long)b * A.bs + ((long)mr[i] * A.step + A.shift) * A.rs;
+        mb[i] = m / A.rows_out;
+        mr[i] = m - mb[i] * A.rows_out;
     }
-    int m_y[NY];
-    const float* yp[NY];
-#pragma unroll
-    for (int i = 0; i < NY; ++i) {
-        m_y[i] = m_begin + yrow + i * (256 / PY);
-        yp[i] = dY + (long)m_y[i] * ldy + yn;
-    }
-    const bool y_vec = vec_y && yn + 3 < N;
-    const bool x_vec = vec_a && a_kok[3];           // cw % 4 == 0: the four k share one tap
-    const long x_off0 = (long)a_roff[0] * A.rs + a_ch[0];
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const bool want_bias = dbias != nullptr && tn_k == 0;
 
-    f32x4 yv[NY], xv[NX], yv2[NY], xv2[NX];         // two slabs in flight: a single one did not cover the L2 / HBM latency
-    auto fetch = [&](f32x4 (&yv)[NY], f32x4 (&xv)[NX]) {   // loads the slab the running pointers stand on, then advances them
+    f32x4 yv[NY], xv[NX];
+    auto fetch = [&](int m0) {
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
+            const int m = m0 + yrow + i * (256 / PY);
             yv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m_y[i] < m_end) {
-                if (y_vec) {
-                    yv[i] = *reinterpret_cast<const f32x4*>(yp[i]);
+            if (m < m_end) {
+                const float* yp = dY + (long)m * ldy + yn;
+                if (vec_y && yn + 3 < N) {
+                    yv[i] = *reinterpret_cast<const f32x4*>(yp);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) yv[i][q] = (yn + q < N) ? yp[i][q] : 0.f;
+                    for (int q = 0; q < 4; ++q) yv[i][q] = (yn + q < N) ? yp[q] : 0.f;
                 }
             }
-            m_y[i] += MR;
-            yp[i] += (long)MR * ldy;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
+            const int m = m0 + xrow + i * (256 / PX);
             xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m_x[i] < m_end) {
+            if (m < m_end) {
+                const long base = (long)mb[i] * A.bs;
                 const int sr0 = mr[i] * A.step + A.shift;
-                if (x_vec) {
+                if (vec_a && a_kok[3]) {            // cw % 4 == 0: the four k share one tap
                     const int sr = sr0 + a_roff[0];
-                    if (sr >= 0 && sr < A.rows_in) xv[i] = *reinterpret_cast<const f32x4*>(xp[i] + x_off0);
+                    if (sr >= 0 && sr < A.rows_in) xv[i] = *reinterpret_cast<const f32x4*>(A.ptr + base + (long)sr * A.rs + a_ch[0]);
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int sr = sr0 + a_roff[q];
-                        xv[i][q] = (a_kok[q] && sr >= 0 && sr < A.rows_in) ? xp[i][(long)a_roff[q] * A.rs + a_ch[q]] : 0.f;
+                        xv[i][q] = (a_kok[q] && sr >= 0 && sr < A.rows_in) ? A.ptr[base + (long)sr * A.rs + a_ch[q]] : 0.f;
                     }
                 }
             }
-            m_x[i] += MR;
             mr[i] += MR;
-            xp[i] += (long)MR * x_row_adv;
-            while (mr[i] >= A.rows_out) { mr[i] -= A.rows_out; xp[i] += x_clip_jump; }
+            while (mr[i] >= A.rows_out) { mr[i] -= A.rows_out; ++mb[i]; }
         }
     };
 
@@ -414,8 +394,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < WTK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    fetch(yv, xv);
-    fetch(yv2, xv2);
+    fetch(m_begin);
     int buf = 0;
     for (int m0 = m_begin; m0 < m_end; m0 += MR) {
 #pragma unroll
@@ -426,11 +405,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(&xs[buf][xrow + i * (256 / PX)][xcol]) = xv[i];
         __syncthreads();                                   // slab `buf` complete; the other buffer is free again
-#pragma unroll
-        for (int i = 0; i < NY; ++i) yv[i] = yv2[i];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xv[i] = xv2[i];
-        fetch(yv2, xv2);                                   // the slab after next: its loads fly during two slabs of MFMAs
+        if (m0 + MR < m_end) fetch(m0 + MR);               // next slab's loads fly during the MFMAs
 #pragma unroll
         for (int u = 0; u < MR / 16; ++u)
 #pragma unroll
@@ -583,10 +558,8 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
 // slower on every shape of the training step, tools/tn_probe.py), the m range cut into ~320-row pieces (20 slabs: enough to
 // amortise the prologue and the atomic epilogue) but at least ~640 workgroups; measured optimum on the M = 4352 weight
 // gradients: 10-16 splits whatever the tile count.
-static int tn_cfg() { const char* e = getenv("TG_TN_CFG"); return e ? atoi(e) : 0; }   // experiment knob: 0 = 64x64, 1 = 128x64, 2 = 128x128
 static void tn_plan(int M, int N, int K, bool two_pass, int* splits_out, int* rows_out) {
-    const int cfg = tn_cfg();
-    const int tiles = cdiv(N, cfg ? 128 : 64) * cdiv(K, cfg == 2 ? 128 : 64);
+    const int tiles = cdiv(N, 64) * cdiv(K, 64);
     int splits = cdiv(M, 320);
     if (splits < cdiv(640, tiles)) splits = cdiv(640, tiles);
     if (two_pass) {                       // short fp32 chains per split: at most 512 rows, fp64 across splits
@@ -623,17 +596,9 @@ extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, floa
                (long)ws_floats, (long)splits * N * w.K);
     const int vec_y = (ldy % 4 == 0) && aligned16(dY);
     const int vec_a = (w.cw % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr);
-    const int cfg = tn_cfg();
-    const int n_nt = cdiv(N, cfg ? 128 : 64), n_kt = cdiv(w.K, cfg == 2 ? 128 : 64);
+    const int n_nt = cdiv(N, 64), n_kt = cdiv(w.K, 64);
     dim3 grid(n_nt * n_kt * splits);
-    if (cfg == 0)
     hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 16>), grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N,
-                       rows_per_split, out_kw, ws, dbias, vec_y, vec_a, n_nt, n_kt);
-    else if (cfg == 1)
-    hipLaunchKernelGGL((gemm_tn_kernel<4, 2, 16>), grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N,
-                       rows_per_split, out_kw, ws, dbias, vec_y, vec_a, n_nt, n_kt);
-    else
-    hipLaunchKernelGGL((gemm_tn_kernel<4, 4, 16>), grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N,
                        rows_per_split, out_kw, ws, dbias, vec_y, vec_a, n_nt, n_kt);
     if (ws) {
         int blocks = cdiv((long)N * w.K, 16);
