@@ -242,8 +242,8 @@ def ae_bench(pkg, a, args, device, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128, help="clips per GPU")
     ap.add_argument("--epoch", type=int, default=11, help="> loss_warmup (10) = full GAN iteration")
     ap.add_argument("--mode", choices=("train", "decode", "ae"), default="train",
