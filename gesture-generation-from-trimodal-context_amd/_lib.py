@@ -33,6 +33,7 @@ SIGNATURES = {
     "tg_bn_apply": [P, P, I32, I32, I32, P, P, P, P, F32, P],
     "tg_bn_backward": [P, P, P, I32, I32, P, P, P, P, F32, P, P, P, P],
     "tg_zero": [P, I64, P],
+    "tg_permute3_batch": [P, I32, I32, P],
     "tg_add_relu": [P, P, P, I64, P],
     "tg_act_mask_bwd": [P, P, P, F32, P, I64, P],
     "tg_mul": [P, P, P, I64, P],

@@ -148,6 +148,32 @@ __global__ void permute3_kernel(const float* __restrict__ in, float* __restrict_
     }
 }
 
+// Batched permute3: one launch for a table of independent (src, dst, dims, perm) jobs -- all weight transposes / conv packs of a
+// network after an optimiser step (layers.WeightPrep).  Table entry = 10 int64: src, dst, d0, d1, d2, p0, p1, p2, first workgroup,
+// workgroup count; a workgroup finds its job by scanning the (short) table, then grid-strides inside the job.
+__global__ __launch_bounds__(256) void permute3_batch_kernel(const long* __restrict__ desc, int n_jobs) {
+    int job = 0;
+    for (int j = 1; j < n_jobs; ++j)
+        if ((long)blockIdx.x >= desc[10 * j + 8]) job = j;
+    const long* e = desc + 10 * job;
+    const float* in = reinterpret_cast<const float*>(e[0]);
+    float* out = reinterpret_cast<float*>(e[1]);
+    const int d[3] = {(int)e[2], (int)e[3], (int)e[4]};
+    const int p0 = (int)e[5], p1 = (int)e[6], p2 = (int)e[7];
+    const long wg0 = e[8], nwg = e[9];
+    const int o1 = d[p1], o2 = d[p2];
+    const long n = (long)d[0] * d[1] * d[2];
+    for (long i = ((long)blockIdx.x - wg0) * 256 + threadIdx.x; i < n; i += nwg * 256) {
+        const int i2 = (int)(i % o2);
+        const long t = i / o2;
+        const int i1 = (int)(t % o1);
+        const int i0 = (int)(t / o1);
+        int x[3];
+        x[p0] = i0; x[p1] = i1; x[p2] = i2;
+        out[i] = in[((long)x[0] * d[1] + x[1]) * d[2] + x[2]];
+    }
+}
+
 __global__ void conv_dgrad_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Co, int Ci, int kw, int s, int J) {
     const long n = (long)s * Ci * J * Co;
     GRID_STRIDE(i, n) {
@@ -399,6 +425,11 @@ int tg_permute3(const float* in, float* out, int32_t d0, int32_t d1, int32_t d2,
     TG_REQUIRE(p0 >= 0 && p0 < 3 && p1 >= 0 && p1 < 3 && p2 >= 0 && p2 < 3 && p0 != p1 && p0 != p2 && p1 != p2, "tg_permute3: bad permutation");
     EW(permute3_kernel, (long)d0 * d1 * d2, in, out, d0, d1, d2, p0, p1, p2);
     return check_launch("tg_permute3");
+}
+int tg_permute3_batch(const int64_t* desc, int32_t n_jobs, int32_t total_workgroups, void* stream) {
+    TG_REQUIRE(desc && n_jobs > 0 && total_workgroups > 0, "tg_permute3_batch: bad arguments");
+    hipLaunchKernelGGL(permute3_batch_kernel, dim3(total_workgroups), dim3(256), 0, ST, reinterpret_cast<const long*>(desc), n_jobs);
+    return check_launch("tg_permute3_batch");
 }
 int tg_conv_dgrad_pack(const float* w, float* out, int32_t Co, int32_t Ci, int32_t kw, int32_t s, void* stream) {
     TG_REQUIRE(w && out && Co > 0 && Ci > 0 && kw > 0 && s > 0, "tg_conv_dgrad_pack: bad arguments");

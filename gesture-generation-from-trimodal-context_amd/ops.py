@@ -367,6 +367,12 @@ def permute3(x, out, perm):
     call("tg_permute3", _p(x), _p(out), *x.shape, *perm, _stream()); return out
 
 
+def permute3_batch(desc, n_jobs, total_workgroups):
+    """desc: int64 device tensor [n_jobs, 10] built by layers.WeightPrep (pointers of live tensors it owns / was given)."""
+    assert desc.dtype == torch.int64 and desc.is_cuda and desc.is_contiguous() and tuple(desc.shape) == (n_jobs, 10)
+    call("tg_permute3_batch", C.c_void_p(desc.data_ptr()), int(n_jobs), int(total_workgroups), _stream())
+
+
 def conv_dgrad_pack(w, out, stride):
     _flat(w, "w"); _flat(out, "out"); Co, Ci, kw = w.shape
     J = (kw + stride - 1) // stride

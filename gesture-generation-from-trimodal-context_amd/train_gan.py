@@ -13,6 +13,7 @@ With static shapes the whole iteration is captured into a hipGraph (GraphedGanSt
 """
 import torch
 
+from . import layers as L
 from . import ops
 from .optim import FusedAdam
 
@@ -70,6 +71,7 @@ class GanTrainer:
         self.g_opt = FusedAdam(self.G, lr=self.hp["learning_rate"], betas=(0.5, 0.999))
         self.d_opt = FusedAdam(self.D, lr=self.hp["learning_rate"] * self.hp["discriminator_lr_weight"], betas=(0.5, 0.999))
         self.grad_sync = grad_sync          # ddp.GradSync or None
+        self.prep = L.WeightPrep()          # transposed / packed weight operands, refreshed once per optimiser step
         self._cut = None                    # set by GraphedGanStep while capturing: cuts the graph at sync points
 
     def _sync(self, *action):
@@ -88,11 +90,18 @@ class GanTrainer:
         `inject` (tests only) replays recorded random draws; names follow oracle.ref_model.Rand."""
         hp = self.hp
         post = epoch > hp["loss_warmup"] and hp["loss_gan_weight"] > 0.0
-        st = self.phase_forward(post, in_text, in_audio, target, vid, inject)
-        if post:
-            self.phase_d_step(st, inject)
-        self.phase_g_backward(st, post, inject)
-        self.phase_g_update()
+        self.prep.add_slab("G", self.G.slab.ensure().flat)
+        self.prep.add_slab("D", self.D.slab.ensure().flat)
+        with self.prep.active():
+            # both networks may have been changed since the last call (optimiser steps, load_state_dict): one batched launch each
+            self.prep.refresh("G")
+            self.prep.refresh("D")
+            st = self.phase_forward(post, in_text, in_audio, target, vid, inject)
+            if post:
+                self.phase_d_step(st, inject)
+                self.prep.refresh("D")                     # the discriminator's weights moved (train_gan.py:43)
+            self.phase_g_backward(st, post, inject)
+            self.phase_g_update()
         return StepLosses(st["g_scalars"], st.get("d_scalar"), hp, post)
 
     # ---- phase 1: stacked generator forward (train_gan.py:30,50,67)

@@ -189,6 +189,10 @@ int tg_embed_scatter_add(const float* dout, const int64_t* idx, float* dtable, i
 int tg_permute3(const float* in, float* out, int32_t d0, int32_t d1, int32_t d2, int32_t p0, int32_t p1,
                 int32_t p2, void* stream);
 
+/* One launch for a table of independent tg_permute3 jobs (all weight transposes / conv packs of a network after an optimiser
+ * step).  desc: device array of n_jobs x 10 int64 = {src, dst, d0, d1, d2, p0, p1, p2, first_workgroup, workgroup_count}; jobs
+ * sorted by first_workgroup, total_workgroups = sum of the counts.  Same element mapping as tg_permute3. */
+int tg_permute3_batch(const int64_t* desc, int32_t n_jobs, int32_t total_workgroups, void* stream);
 /* Weight pack for the input-gradient of Conv1d(stride s) (= forward of ConvTranspose1d):
  * w: [Co][Ci][kw] -> out: [s][Ci][J][Co], J = ceil(kw/s), out[r][ci][j][co] = (r + s*j < kw) ? w[co][ci][r + s*j] : 0.
  * Phase r serves the input positions p with (p % s) == r:  dx[6q + r] = sum_j dy[q - j] . out[r][:, j, :]. */
