@@ -52,6 +52,7 @@ SIGNATURES = {
     "tg_weight_norm_bwd": [P, P, P, P, P, I32, I32, I32, P],
     "tg_rng_advance": [P, P],
     "tg_dropout_mask": [P, I64, F32, P, U32, P],
+    "tg_dropout_apply": [P, P, P, I64, F32, P, U32, P],
     "tg_normal": [P, I64, P, U32, P],
     "tg_randperm": [P, I32, P, U32, P],
     "tg_gather_i64": [P, P, P, I32, P],

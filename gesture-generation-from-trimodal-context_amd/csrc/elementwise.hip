@@ -251,6 +251,27 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, long n, float p, c
         }
     }
 }
+// draw the mask and apply it in one pass: y = x * mask (same draws as dropout_mask_kernel for the same state / site)
+__global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, long n, float p,
+                                     const uint64_t* __restrict__ st, uint32_t site) {
+    const uint64_t seed = st[0];
+    const uint32_t step = (uint32_t)st[1];
+    const float keep = 1.f / (1.f - p);
+    const long n4 = (n + 3) / 4;
+    GRID_STRIDE(i, n4) {
+        uint32_t r[4];
+        philox4x32(seed, (uint64_t)i, site, step, r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long e = i * 4 + q;
+            if (e < n) {
+                const float m = u01(r[q]) >= p ? keep : 0.f;
+                mask[e] = m;
+                y[e] = x[e] * m;
+            }
+        }
+    }
+}
 __global__ void normal_kernel(float* __restrict__ out, long n, const uint64_t* __restrict__ st, uint32_t site) {
     const uint64_t seed = st[0];
     const uint32_t step = (uint32_t)st[1];
@@ -456,6 +477,11 @@ int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, 
     TG_REQUIRE(mask && rng_state && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout_mask: bad arguments");
     EW(dropout_mask_kernel, (n + 3) / 4, mask, (long)n, p, rng_state, site);
     return check_launch("tg_dropout_mask");
+}
+int tg_dropout_apply(const float* x, float* y, float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream) {
+    TG_REQUIRE(x && y && mask && rng_state && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout_apply: bad arguments");
+    EW(dropout_apply_kernel, (n + 3) / 4, x, y, mask, (long)n, p, rng_state, site);
+    return check_launch("tg_dropout_apply");
 }
 int tg_normal(float* out, int64_t n, const uint64_t* rng_state, uint32_t site, void* stream) {
     TG_REQUIRE(out && rng_state && n >= 0, "tg_normal: bad arguments");

@@ -57,6 +57,17 @@ class _Engine:
         Bf = dict(self.mod.named_buffers())
         return P, G, Bf
 
+    def _drop(self, name, x, p, inject):
+        """F.dropout(x, p) in train mode -> (y, scale mask or None): injected mask (tests) or one fused draw-and-apply pass."""
+        if inject is not None and name in inject:
+            m = inject[name]
+            assert m.shape == x.shape, (name, m.shape, x.shape)
+            m = m.contiguous()
+            return ops.mul(x, m, torch.empty_like(x)), m
+        if p <= 0.0:
+            return x, None
+        return ops.dropout_apply(x.contiguous(), p, self.rng.state, self.rng.site(name))
+
     def _mask(self, name, like, p, inject):
         """Inverted-dropout scale mask for site `name`: injected (tests) or drawn on device."""
         if inject is not None and name in inject:
@@ -188,8 +199,7 @@ class GeneratorEngine(_Engine):
         te = "text_encoder"
         E = P[f"{te}.embedding.weight"].shape[1]
         emb = ops.embed_gather(P[f"{te}.embedding.weight"], in_text.contiguous().view(-1), L.empty(Bs, T, E, like=in_data))
-        emb_mask = self._mask(f"{tag}.emb_drop", emb, 0.1, inject) if training else None
-        cur = ops.mul(emb, emb_mask, torch.empty_like(emb)) if emb_mask is not None else emb
+        cur, emb_mask = self._drop(f"{tag}.emb_drop", emb, 0.1, inject) if training else (emb, None)
         tcn = []
         for i in range(self.n_layers):
             d = 2 ** i
@@ -200,8 +210,7 @@ class GeneratorEngine(_Engine):
                 v = P[pre + ".weight_v"]
                 wp = ops.weight_norm_fwd(v, P[pre + ".weight_g"], L.empty(v.shape[0], 2 * v.shape[1], like=v))
                 c = L.conv_fwd(h, wp, P[pre + ".bias"], 2, pad=d, dil=d, rows_out=T, act_slope=0.0)   # causal: chomp
-                m = self._mask(f"{tag}.tcn{i}.drop{ci + 1}", c, self.p_drop, inject) if training else None
-                o = ops.mul(c, m, torch.empty_like(c)) if m is not None else c
+                o, m = self._drop(f"{tag}.tcn{i}.drop{ci + 1}", c, self.p_drop, inject) if training else (c, None)
                 blk[f"in{ci}"], blk[f"wp{ci}"], blk[f"o{ci}"], blk[f"m{ci}"] = h, wp, o, m
                 h = o
             y = ops.add_relu(h, cur, torch.empty_like(cur))

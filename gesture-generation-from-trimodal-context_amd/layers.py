@@ -290,10 +290,9 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
             name = f"{tag}.gru.drop{l}"
             if inject is not None and name in inject:
                 mask = inject[name]
-            elif p_drop > 0:
-                mask = ops.dropout_mask(torch.empty_like(y), p_drop, rng.state, rng.site(name))
-            if mask is not None:
                 cur = ops.mul(y, mask, torch.empty_like(y))
+            elif p_drop > 0:
+                cur, mask = ops.dropout_apply(y, p_drop, rng.state, rng.site(name))     # draw + apply in one pass
             else:
                 cur = y
         else:

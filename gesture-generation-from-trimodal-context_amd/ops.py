@@ -406,6 +406,14 @@ def dropout_mask(mask, p, state, site):
     return mask
 
 
+def dropout_apply(x, p, state, site):
+    """(y, mask) with mask drawn as dropout_mask does and y = x * mask, one pass."""
+    _flat(x, "x")
+    y, mask = torch.empty_like(x), torch.empty_like(x)
+    call("tg_dropout_apply", _p(x), _p(y), _p(mask), x.numel(), float(p), _p(_i64(state, "rng_state")), int(site), _stream())
+    return y, mask
+
+
 def normal(out, state, site):
     call("tg_normal", _p(_flat(out, "out")), out.numel(), _p(_i64(state, "rng_state")), int(site), _stream()); return out
 

@@ -211,6 +211,9 @@ int tg_weight_norm_bwd(const float* dw_packed, const float* v, const float* g, f
  * Every draw site passes its own `site` id so streams never collide. */
 int tg_rng_advance(uint64_t* rng_state, void* stream);
 int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream);
+/* Draw the same mask and apply it in one pass: mask as tg_dropout_mask, y[i] = x[i] * mask[i] (F.dropout, train mode). */
+int tg_dropout_apply(const float* x, float* y, float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site,
+                     void* stream);
 int tg_normal(float* out, int64_t n, const uint64_t* rng_state, uint32_t site, void* stream);
 /* out = random permutation of [0, n), n <= 1024 (torch.randperm at train_eval/train_gan.py:62). */
 int tg_randperm(int64_t* out, int32_t n, const uint64_t* rng_state, uint32_t site, void* stream);

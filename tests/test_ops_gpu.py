@@ -283,6 +283,10 @@ def test_rng_ops(pkg, dev):
     assert not torch.equal(m, m3) and int(st[1]) == 1
     m4 = ops.dropout_mask(torch.empty(1 << 20, device=dev), 0.3, st, 2)
     assert abs(float(((m3 > 0) == (m4 > 0)).float().mean()) - (0.49 + 0.09)) < 5e-3     # sites are independent
+    x = torch.randn(1000003, device=dev)                          # fused draw + apply == separate draw, then multiply
+    y5, m5 = ops.dropout_apply(x, 0.3, st, 1)
+    assert torch.equal(m5, ops.dropout_mask(torch.empty_like(x), 0.3, st, 1)) and torch.equal(y5, x * m5)
+    assert torch.equal(m5, m3[:1000003])                          # draws do not depend on the tensor length
     e = ops.normal(torch.empty(1 << 20, device=dev), st, 3)
     assert abs(float(e.mean())) < 5e-3 and abs(float(e.std()) - 1) < 5e-3 and abs(float((e ** 4).mean()) - 3) < 0.1
     p = ops.randperm(torch.empty(128, dtype=torch.int64, device=dev), st, 4).cpu()
