@@ -431,3 +431,38 @@ def test_reference_checkpoint_runs_on_gpu(pkg, dev):
     with torch.no_grad():
         res = G.engine.forward(pre.to(dev), text.to(dev), audio.to(dev), vid.to(dev), training=False, inject={"g.eps": eps.to(dev)})
     assert rel(res["out"], want[0]) < 1e-5 and rel(res["mu"], want[2]) < 1e-5 and rel(res["logvar"], want[3]) < 1e-5
+
+
+def test_weight_prep_follows_external_weight_changes(pkg, dev):
+    """layers.WeightPrep caches transposed / packed weights across iterations and refreshes them with one batched launch per network:
+    weights changed behind the trainer's back (load_state_dict between iterations) must be picked up at the next iteration."""
+    V, S, B = 64, 9, 4
+    text, audio, vid, poses = O.make_batch(31, B, V, S)
+    text, audio, vid, poses = text.to(dev), audio.to(dev), vid.to(dev), poses.to(dev)
+    gst_a, dst_a = O.make_generator_state(5, V, S), O.make_discriminator_state(6)
+    gst_b, dst_b = O.make_generator_state(15, V, S), O.make_discriminator_state(16)
+
+    def make(gst, dst):
+        args, G, Dn = build_models(pkg, dev, gst, dst, V, S, make_args(dropout_prob=0.0))
+        G.train(); Dn.train()
+        G.engine.p_drop = 0.0
+        return G, Dn, pkg.GanTrainer(G, Dn, args)
+
+    G1, D1, tr1 = make(gst_a, dst_a)
+    tr1.train_iter(11, text, audio, poses, vid)                      # fills the cache with operands of weights A (then A')
+    assert len(tr1.prep.by_key) > 10
+    G1.load_state_dict(O.clone_state(gst_b, torch.float32)); D1.load_state_dict(O.clone_state(dst_b, torch.float32))
+    for opt in (tr1.g_opt, tr1.d_opt):                               # fresh optimiser state, like the comparison trainer
+        opt.slab.m.zero_(); opt.slab.v.zero_(); opt.slab.step.zero_()
+    G2, D2, tr2 = make(gst_b, dst_b)
+    inj = {"perm": torch.arange(B), **{f"g{i}.eps": torch.zeros(B, 16) for i in (1, 2, 3)},
+           **{f"g{i}.emb_drop": torch.ones(B, 34, 300) for i in (1, 2, 3)},
+           **{f"{t}.gru.drop{l}": torch.ones(B, 28, 128) for t in ("d_real", "d_fake", "d_out") for l in range(3)}}
+    inj = {k: v.to(dev) for k, v in inj.items()}
+    l1 = tr1.train_iter(11, text, audio, poses, vid, inject=inj).to_dict()
+    l2 = tr2.train_iter(11, text, audio, poses, vid, inject=inj).to_dict()
+    for k in l2:
+        assert abs(l1[k] - l2[k]) <= 1e-4 * max(1.0, abs(l2[k])), (k, l1[k], l2[k])
+    _, g1, _ = tr1.G.views(); _, g2, _ = tr2.G.views()
+    for k in ("gru.weight_ih_l1", "gru.weight_hh_l0_reverse", "audio_encoder.feat_extractor.3.weight", "out.0.weight"):
+        assert rel(g1[k], g2[k]) < 1e-3, k
