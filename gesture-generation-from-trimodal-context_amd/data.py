@@ -82,6 +82,14 @@ def collate(items, speaker_model=None):
     return text, vec, audio, vid
 
 
+def collate_reference(items):
+    """default_collate_fn (:43-53) with the reference's return arity, for code written against its DataLoader (evaluate_testset):
+    (word_seq placeholder, lengths placeholder, text_padded, pose_seq, vec_seq, audio, spectrogram placeholder, aux_info)."""
+    aux = {k: [it[5][k] for it in items] for k in items[0][5]}
+    return (torch.tensor([0]), torch.tensor([0]), torch.stack([it[1] for it in items]), torch.stack([it[2] for it in items]),
+            torch.stack([it[3] for it in items]), torch.stack([it[4] for it in items]), torch.zeros(len(items), 1), aux)
+
+
 class SyntheticSpeechMotionDataset(torch.utils.data.Dataset):
     """Samples in the reference's stored format, generated deterministically: random-walk direction vectors, band-limited noise
     audio with a random (slightly wrong) length, 4-12 words with onset times inside the clip, one of `n_speakers - 1` videos."""
