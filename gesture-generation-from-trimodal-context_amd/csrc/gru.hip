@@ -109,9 +109,9 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_step_kernel(
         gh[g] = s;
     }
     const float hn = gh[2] + bh_n;
-    const float r = sigmoidf_(gi_r + gh[0] + bh_r);
-    const float z = sigmoidf_(gi_z + gh[1] + bh_z);
-    const float n = tanhf(gi_n + r * hn);
+    const float r = gate_sigmoid(gi_r + gh[0] + bh_r);
+    const float z = gate_sigmoid(gi_z + gh[1] + bh_z);
+    const float n = gate_tanh(gi_n + r * hn);
     const float h = (1.f - z) * n + z * hp;
     Y[((long)erow * T + tau) * (2 * H) + dir * H + ej] = h;
     if (save) {
@@ -288,9 +288,9 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_h64_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float hn = acc[2][i] + bh_n;
-            const float r = sigmoidf_(g_r[i] + acc[0][i] + bh_r);
-            const float z = sigmoidf_(g_z[i] + acc[1][i] + bh_z);
-            const float n = tanhf(g_n[i] + r * hn);
+            const float r = gate_sigmoid(g_r[i] + acc[0][i] + bh_r);
+            const float z = gate_sigmoid(g_z[i] + acc[1][i] + bh_z);
+            const float n = gate_tanh(g_n[i] + r * hn);
             const float h = (1.f - z) * n + z * hp[i];
             hp[i] = h;
             hs[kq * 4 + i][j] = h;

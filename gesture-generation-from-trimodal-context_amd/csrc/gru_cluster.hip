@@ -177,9 +177,9 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_kernel(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float hn = gh[2][q] + bh[2][q];
-                const float r = sigmoidf_(gv[0][q] + gh[0][q] + bh[0][q]);
-                const float z = sigmoidf_(gv[1][q] + gh[1][q] + bh[1][q]);
-                const float n = tanhf(gv[2][q] + r * hn);
+                const float r = gate_sigmoid(gv[0][q] + gh[0][q] + bh[0][q]);
+                const float z = gate_sigmoid(gv[1][q] + gh[1][q] + bh[1][q]);
+                const float n = gate_tanh(gv[2][q] + r * hn);
                 h[q] = (1.f - z) * n + z * hp[q];
                 r4[q] = r; z4[q] = z; n4[q] = n; hn4[q] = hn;
             }
