@@ -89,13 +89,13 @@ def time_kernel(fn, iters=50, warm=5):
 
 
 def dominant_kernel_roofline(pkg, device, batch):
-    """The single kernel with the largest share of the iteration (profiles/r1_f_by_shape.txt): the persistent cluster-synchronised
+    """The single kernel with the largest share of the iteration (profiles/r1_g_by_shape.txt): the persistent cluster-synchronised
     GRU recurrence of the generator's stacked forward, gru_seq_fwd_cluster_kernel<2> at B = 3*batch, H = 300, T = 34 -- one launch
     per layer walks all 34 steps of both directions (csrc/gru_cluster.hip).
     Algorithmic FLOPs per launch: (T-1) steps x 2 directions x B x 3H x H x 2 (the h_{t-1} @ W_hh^T products; gate maths excluded).
     The kernel is bound by the per-step inter-workgroup hand-off latency, not by MFMA issue or HBM: the fraction says how far.
     The timed call is tg_gru_forward_cluster = the 1.6 KB flag-zeroing kernel + the persistent kernel: HIP events see both
-    (~254 us), rocprofv3's per-kernel average is the persistent kernel alone (~245 us, profiles/r1_f_kernel_stats.csv)."""
+    (~249 us), rocprofv3's per-kernel average is the persistent kernel alone (~239 us, profiles/r1_g_kernel_stats.csv)."""
     ops = pkg.ops
     Bs, H = 3 * batch, 300
     gi = torch.randn(2, Bs, T, 3 * H, device=device) * 0.1
@@ -106,9 +106,9 @@ def dominant_kernel_roofline(pkg, device, batch):
     dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, sv), iters=20)
     ops.check_async_errors()
     flops = (T - 1) * 2 * Bs * H * 3 * H * 2
-    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape (profiles/r1_f_pmc_gru_fwd_cluster.txt):
-    # FETCH_SIZE 70617.0 KB x 2 (gfx950 wide-read correction) + WRITE_SIZE 186404.0 KB.  Only valid for batch 128 (B_s = 384).
-    traffic = (2 * 70617.0 + 186404.0) * 1024 if batch == 128 else None
+    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape (profiles/r1_g_pmc_gru_fwd_cluster.txt):
+    # FETCH_SIZE 70635.7 KB x 2 (gfx950 wide-read correction) + WRITE_SIZE 186401.1 KB.  Only valid for batch 128 (B_s = 384).
+    traffic = (2 * 70635.7 + 186401.1) * 1024 if batch == 128 else None
     return {"kernel": "gru_seq_fwd_cluster_kernel<2>", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": traffic, "launch_us": dt * 1e6,
             "flop_per_launch": flops, "us_per_step": dt * 1e6 / T}
