@@ -76,6 +76,14 @@ def test_variant_module_api_shapes(pkg, dev):
         assert float(G.gru.weight_hh_l0.grad.abs().max()) > 0
 
 
+@pytest.mark.parametrize("batch", [1, 3, 21])
+def test_train_iter_odd_batch_sizes(pkg, dev, batch):
+    """Batch sizes that are not multiples of the 16-row MFMA tile (and the degenerate batch of one clip: BatchNorm statistics over a
+    single clip's frames, randperm of one element): every kernel's edge handling, against the fp64 oracle."""
+    worst = run_train_parity(pkg, dev, batch=batch, epochs=(11,), seed=90 + batch, rand_seed=2000 + batch, verbose=True)
+    assert worst < 1e-4, worst
+
+
 def test_train_iter_matches_reference_golden(pkg, dev):
     """Replays the dropout masks / eps / permutation recorded from the reference's own train_iter_gan run."""
     from test_oracle_golden import unpack_masks
