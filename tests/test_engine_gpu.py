@@ -474,3 +474,33 @@ def test_weight_prep_follows_external_weight_changes(pkg, dev):
     _, g1, _ = tr1.G.views(); _, g2, _ = tr2.G.views()
     for k in ("gru.weight_ih_l1", "gru.weight_hh_l0_reverse", "audio_encoder.feat_extractor.3.weight", "out.0.weight"):
         assert rel(g1[k], g2[k]) < 1e-3, k
+
+
+def test_ragged_batch_synthesis(pkg, dev):
+    """generate_gestures_batch with utterances of different lengths in lock-step (1, 2 and 4 windows; shorter ones idle on their last
+    window), hipGraph replay for the non-first windows: lengths follow synthesize.py:57-63, results are finite, and the window loop
+    is reproducible (same RNG seed -> same frames) and independent of the graph capture (eager == replayed)."""
+    from importlib import import_module
+    syn = import_module(pkg.__name__ + ".synthesize")
+    V, S = 64, 9
+    gst = O.make_generator_state(5, V, S)
+
+    class Lang:
+        def get_word_index(self, w): return 4 + (sum(map(ord, w)) % (V - 4))
+    gen = torch.Generator().manual_seed(5)
+    sr = 16000
+    audios = [(0.1 * torch.randn(int(sec * sr), generator=gen)).numpy() for sec in (1.5, 3.9, 7.3)]
+    words = [[["a", 0.2, 0.4]], [["b", 0.5, 0.9], ["c", 2.5, 2.9]], [["d", 0.1, 0.3], ["e", 3.3, 3.8], ["f", 6.6, 7.0]]]
+    outs = []
+    for graph in (True, True, False):
+        args, G, D = build_models(pkg, dev, gst, O.make_discriminator_state(6), V, S)      # fresh module: RNG state restarts
+        args.motion_resampling_framerate = 15
+        G.eval()
+        outs.append(syn.generate_gestures_batch(args, G, Lang(), audios, words, vids=[1, 2, 3], graph=graph))
+    n_win = [syn.num_windows(len(a) / sr) for a in audios]
+    assert n_win == [1, 2, 4]
+    for r, n in zip(outs[0], n_win):
+        assert r.shape == (n * 30 + 4, 27) and np.isfinite(r).all()
+    for a, b, c in zip(*outs):
+        assert np.array_equal(a, b)                                   # reproducible
+        assert np.abs(a - c).max() <= 1e-5 * max(1.0, np.abs(c).max())   # replayed graph == eager launches
