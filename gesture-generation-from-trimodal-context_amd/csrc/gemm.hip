@@ -158,19 +158,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Win A, const float* __rest
 // LDS with coalesced 16-byte global loads ([row][16 k] rows padded to 20 floats: the k-permuted 16-byte fragment reads
 // stay 16-byte aligned and spread over the banks), double-buffered: the next slab's global loads are in flight while
 // the current slab's 4*TM*TN MFMAs per wave run.  Needs the vectorisable layout (cw % 4 == 0 etc., checked on the host).
+// BK (slab depth) is a template parameter; 64-deep slabs were tried for the short-K discriminator products (K = 128 / 192: 2-3
+// slabs instead of 8-12) and measured within +-8 % of BK = 16 under graph replay (tools/nt_small_probe.py), so only 16 is used.
 // The tile is chosen per shape by nt_pick_tile(): the f32 pipe sustains ~100 TFLOP/s on real data whatever the tile
 // (tools/gemm_lab.hip), so what matters is tile quantisation and filling 256 CUs x 3 workgroups.
 constexpr int BG_LD = 20;
 
-template <int TM, int TN>
+template <int TM, int TN, int BK = 16>
 __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __restrict__ Bw, long ldb,
                                                           const float* __restrict__ bias, float* __restrict__ C, long cbs,
                                                           long crs, int cR, int M, int N, float slope, int accumulate, int n_nt) {
     constexpr int BM = 32 * TM, BN = 32 * TN;         // workgroup tile
-    constexpr int NPA = (BM * 4 + 255) / 256;         // 16-byte pieces staged per thread (4 per 16-deep row)
-    constexpr int NPB = (BN * 4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float as[2][BM][BG_LD];
-    __shared__ __attribute__((aligned(16))) float bs[2][BN][BG_LD];
+    constexpr int PPR = BK / 4;                       // 16-byte pieces per slab row
+    constexpr int RPP = 256 / PPR;                    // slab rows staged per pass of the 256 threads
+    constexpr int NPA = (BM + RPP - 1) / RPP;         // pieces staged per thread
+    constexpr int NPB = (BN + RPP - 1) / RPP;
+    constexpr int LD = BK + 4;                        // padded slab row (BG_LD for BK = 16)
+    __shared__ __attribute__((aligned(16))) float as[2][BM][LD];
+    __shared__ __attribute__((aligned(16))) float bs[2][BN][LD];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -179,15 +184,15 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
     const int m0 = (lid / n_nt) * BM, n0 = (lid % n_nt) * BN;
     const int K = A.K;
 
-    // staging role: row (t >> 2) [+64 per extra piece], 16-byte piece (t & 3) of the 16-deep slab
-    const int srow = t >> 2, sk = 4 * (t & 3);
+    // staging role: row (t / PPR) [+RPP per extra piece], 16-byte piece (t % PPR) of the BK-deep slab
+    const int srow = t / PPR, sk = 4 * (t % PPR);
     long a_off[NPA];
     int a_r[NPA];
     bool a_ok[NPA];
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
-        const int m = m0 + srow + 64 * i;
-        a_ok[i] = (srow + 64 * i < BM) && m < M;
+        const int m = m0 + srow + RPP * i;
+        a_ok[i] = (srow + RPP * i < BM) && m < M;
         const int mm = a_ok[i] ? m : 0;
         const int b = mm / A.rows_out;
         const int r = mm - b * A.rows_out;
@@ -198,11 +203,11 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
     bool b_ok[NPB];
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
-        const int n = n0 + srow + 64 * i;
-        b_ok[i] = (srow + 64 * i < BN) && n < N;
+        const int n = n0 + srow + RPP * i;
+        b_ok[i] = (srow + RPP * i < BN) && n < N;
         b_ptr[i] = Bw + (long)(b_ok[i] ? n : 0) * ldb;
     }
-    int kk = sk / A.cw, c = sk - (sk / A.cw) * A.cw;   // tap / channel of this thread's piece, advanced by 16 per slab
+    int kk = sk / A.cw, c = sk - (sk / A.cw) * A.cw;   // tap / channel of this thread's piece, advanced by BK per slab
 
     f32x4 ga[NPA], gb[NPB];
     auto fetch = [&](int k0) {
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             gb[i] = (b_ok[i] && inb) ? *reinterpret_cast<const f32x4*>(b_ptr[i] + k) : z;
         }
-        c += 16;
+        c += BK;
         while (c >= A.cw) { c -= A.cw; ++kk; }
     };
 
@@ -232,27 +237,30 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
 
     fetch(0);
     int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int k0 = 0; k0 < K; k0 += BK) {
 #pragma unroll
         for (int i = 0; i < NPA; ++i)
-            if (BM % 64 == 0 || srow + 64 * i < BM) *reinterpret_cast<f32x4*>(&as[buf][srow + 64 * i][sk]) = ga[i];
+            if (BM % RPP == 0 || srow + RPP * i < BM) *reinterpret_cast<f32x4*>(&as[buf][srow + RPP * i][sk]) = ga[i];
 #pragma unroll
         for (int i = 0; i < NPB; ++i)
-            if (BN % 64 == 0 || srow + 64 * i < BN) *reinterpret_cast<f32x4*>(&bs[buf][srow + 64 * i][sk]) = gb[i];
+            if (BN % RPP == 0 || srow + RPP * i < BN) *reinterpret_cast<f32x4*>(&bs[buf][srow + RPP * i][sk]) = gb[i];
         __syncthreads();
-        if (k0 + 16 < K) fetch(k0 + 16);
-        f32x4 fa[TM], fb[TN];
+        if (k0 + BK < K) fetch(k0 + BK);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&as[buf][wm * (16 * TM) + i * 16 + r16][4 * kq]);
+        for (int u = 0; u < BK / 16; ++u) {
+            f32x4 fa[TM], fb[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&bs[buf][wn * (16 * TN) + j * 16 + r16][4 * kq]);
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&as[buf][wm * (16 * TM) + i * 16 + r16][16 * u + 4 * kq]);
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&bs[buf][wn * (16 * TN) + j * 16 + r16][16 * u + 4 * kq]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][v], fb[j][v], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][v], fb[j][v], acc[i][j], 0, 0, 0);
+        }
         buf ^= 1;
     }
 
