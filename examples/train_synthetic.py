@@ -53,7 +53,7 @@ def main():
     generator, discriminator, _ = ckpt.init_model(args, lang, spk, args.pose_dim, dev)              # train.py:36-62
     trainer = hip.GanTrainer(generator, discriminator, args)
     ae = hip.EmbeddingNet(args, args.pose_dim, args.n_poses, None, None, None, mode="pose").to(dev)  # stands in for the trained FGD net
-    evaluator = fgd.EmbeddingSpaceEvaluator(ae, args.n_pre_poses)
+    evaluator = fgd.EmbeddingSpaceEvaluator.from_net(ae, args.n_pre_poses)
     args.mean_dir_vec = np.zeros(27, dtype=np.float32)
     val_loader = torch.utils.data.DataLoader(val_set, batch_size=a.batch, collate_fn=data.collate_reference)
 
@@ -74,9 +74,9 @@ def main():
         losses = last.to_dict()                   # the only host read of the epoch
         torch.cuda.synchronize()
         rate = a.iters_per_epoch * a.batch / (time.time() - t0)
-        val = metrics.evaluate_testset(val_loader, generator, evaluator, args)                      # train.py:234-329
+        val = metrics.evaluate_testset(val_loader, generator, None, evaluator, args)                # train.py:234-329 (same signature)
         print(f"epoch {epoch:3d}  {rate:8.0f} clips/s  " + "  ".join(f"{k} {v:.4f}" for k, v in losses.items()) +
-              "  | val " + "  ".join(f"{k} {v:.4f}" for k, v in val.items() if isinstance(v, float)), flush=True)
+              "  | val " + "  ".join(f"{k} {v:.4f}" for k, v in val.items()) + f"  accel {val.accel:.4f}", flush=True)
     if a.out:
         os.makedirs(a.out, exist_ok=True)
         path = os.path.join(a.out, "synthetic_checkpoint_best.bin")

@@ -51,6 +51,18 @@ def init_model(args, lang_model, speaker_model, pose_dim, _device):
     return generator, discriminator, loss_fn
 
 
+def get_speaker_model(net):
+    """utils/train_utils.py:152-164: the generator's speaker Vocab (through a DataParallel-style `.module` wrapper too), or None when
+    z_obj is not a Vocab (z_type 'random' keeps the integer 1 there, 'none' keeps None)."""
+    try:
+        speaker_model = net.module.z_obj if hasattr(net, "module") else net.z_obj
+    except AttributeError:
+        speaker_model = None
+    if not isinstance(speaker_model, _vocab.Vocab):
+        speaker_model = None
+    return speaker_model
+
+
 def load_checkpoint(checkpoint_path, _device="cpu"):
     """torch.load of a reference-format checkpoint (a full pickle: weights_only=False, as the reference's torch.load)."""
     return torch.load(checkpoint_path, map_location=_device, weights_only=False, pickle_module=_ref_pickle)

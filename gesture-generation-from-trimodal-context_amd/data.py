@@ -53,41 +53,77 @@ def words_to_tensor(lang, words, end_time=None):
     return np.asarray(indexes, dtype=np.int64)
 
 
+def calc_spectrogram_length_from_motion_length(n_frames, fps):
+    """utils/data_utils.py:44-46."""
+    return int(round((n_frames / fps * 16000 - 1024) / 512 + 1))
+
+
 def sample_to_tensors(sample, lang_model, n_poses, pose_resampling_fps, remove_word_timing=False):
-    """SpeechMotionDataset.__getitem__ after the LMDB read (:151-171).  Returns
+    """SpeechMotionDataset.__getitem__ after the LMDB read (:151-171).  Returns the reference's tuple
     (word_seq (L,) int64, extended_word_seq (n_poses,) int64, pose_seq (n_poses, 30) f32, vec_seq (n_poses, 27) f32,
-    audio (expected_audio_length,) f32, aux_info)."""
-    word_seq, pose_seq, vec_seq, audio, _spectrogram, aux_info = sample
+    audio (expected_audio_length,) f32, spectrogram (mels, expected_spectrogram_length), aux_info)."""
+    word_seq, pose_seq, vec_seq, audio, spectrogram, aux_info = sample
     expected_audio_length = int(round(n_poses / pose_resampling_fps * 16000))
     duration = aux_info["end_time"] - aux_info["start_time"]
     sample_end_time = aux_info["start_time"] + duration * n_poses / vec_seq.shape[0]
     audio = make_audio_fixed_length(np.asarray(audio), expected_audio_length)
+    spectrogram = np.asarray(spectrogram)[:, 0:calc_spectrogram_length_from_motion_length(n_poses, pose_resampling_fps)]
     vec_seq = np.asarray(vec_seq)[0:n_poses]
     pose_seq = np.asarray(pose_seq)[0:n_poses]
     words = words_to_tensor(lang_model, word_seq, sample_end_time)
     ext = extend_word_seq(lang_model, word_seq, aux_info["start_time"], sample_end_time, n_poses, remove_word_timing)
     return (torch.from_numpy(words), torch.from_numpy(ext), torch.from_numpy(pose_seq.reshape(pose_seq.shape[0], -1)).float(),
-            torch.from_numpy(vec_seq.reshape(vec_seq.shape[0], -1)).float(), torch.from_numpy(np.ascontiguousarray(audio)).float(), aux_info)
+            torch.from_numpy(vec_seq.reshape(vec_seq.shape[0], -1)).float(), torch.from_numpy(np.ascontiguousarray(audio)).float(),
+            torch.from_numpy(np.ascontiguousarray(spectrogram)), aux_info)
 
 
 def collate(items, speaker_model=None):
-    """default_collate_fn (:43-53) for the multimodal model + the speaker lookup of train.py:178-183.
+    """default_collate_fn (:43-53) restricted to what the multimodal model consumes + the speaker lookup of train.py:178-183.
     Returns (in_text_padded (B, T) int64, target_vec (B, T, 27) f32, in_audio (B, A) f32, vid_indices (B,) int64 or None)."""
     text = torch.stack([it[1] for it in items])
     vec = torch.stack([it[3] for it in items])
     audio = torch.stack([it[4] for it in items])
     vid = None
     if speaker_model is not None and hasattr(speaker_model, "word2index"):
-        vid = torch.tensor([speaker_model.word2index[it[5]["vid"]] for it in items], dtype=torch.int64)
+        vid = torch.tensor([speaker_model.word2index[it[6]["vid"]] for it in items], dtype=torch.int64)
     return text, vec, audio, vid
 
 
-def collate_reference(items):
-    """default_collate_fn (:43-53) with the reference's return arity, for code written against its DataLoader (evaluate_testset):
-    (word_seq placeholder, lengths placeholder, text_padded, pose_seq, vec_seq, audio, spectrogram placeholder, aux_info)."""
-    aux = {k: [it[5][k] for it in items] for k in items[0][5]}
-    return (torch.tensor([0]), torch.tensor([0]), torch.stack([it[1] for it in items]), torch.stack([it[2] for it in items]),
-            torch.stack([it[3] for it in items]), torch.stack([it[4] for it in items]), torch.zeros(len(items), 1), aux)
+def default_collate_fn(data):
+    """lmdb_data_loader.py:43-53 with the reference's return arity, for code written against its DataLoader (evaluate_testset):
+    (word_seq placeholder, lengths placeholder, text_padded, pose_seq, vec_seq, audio, spectrogram, aux_info)."""
+    from torch.utils.data.dataloader import default_collate
+    _, text_padded, pose_seq, vec_seq, audio, spectrogram, aux_info = zip(*data)
+    aux_info = {key: default_collate([d[key] for d in aux_info]) for key in aux_info[0]}
+    return (torch.tensor([0]), torch.tensor([0]), default_collate(text_padded), default_collate(pose_seq), default_collate(vec_seq),
+            default_collate(audio), default_collate(spectrogram), aux_info)
+
+
+collate_reference = default_collate_fn
+
+
+class SpeechMotionDataset(torch.utils.data.Dataset):
+    """SpeechMotionDataset (lmdb_data_loader.py:56-171) over samples already read into memory, in the stored format
+    [word_seq, pose_seq, vec_seq, audio, spectrogram, aux_info] (data_preprocessor.py:160-164).  The LMDB / pyarrow-0.14 read
+    itself is out of scope (neither library exists in this image)."""
+
+    def __init__(self, samples, n_poses, subdivision_stride, pose_resampling_fps, mean_pose=None, mean_dir_vec=None,
+                 speaker_model=None, remove_word_timing=False):
+        self.samples, self.n_poses, self.subdivision_stride = samples, n_poses, subdivision_stride
+        self.skeleton_resampling_fps, self.mean_dir_vec, self.remove_word_timing = pose_resampling_fps, mean_dir_vec, remove_word_timing
+        self.expected_audio_length = int(round(n_poses / pose_resampling_fps * 16000))
+        self.expected_spectrogram_length = calc_spectrogram_length_from_motion_length(n_poses, pose_resampling_fps)
+        self.lang_model, self.speaker_model = None, speaker_model
+        self.n_samples = len(samples)
+
+    def __len__(self):
+        return self.n_samples
+
+    def set_lang_model(self, lang_model):
+        self.lang_model = lang_model
+
+    def __getitem__(self, idx):
+        return sample_to_tensors(self.samples[idx], self.lang_model, self.n_poses, self.skeleton_resampling_fps, self.remove_word_timing)
 
 
 class SyntheticSpeechMotionDataset(torch.utils.data.Dataset):

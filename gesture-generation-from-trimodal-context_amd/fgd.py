@@ -47,24 +47,41 @@ def fgd_scores(generated_feats, real_feats):
 
 
 class EmbeddingSpaceEvaluator:
-    """Same surface as the reference class (reset / push_samples / get_no_of_samples / get_scores), built around an
-    already constructed HIP EmbeddingNet instead of a checkpoint path (pass `net`) or a checkpoint dict."""
+    """model/embedding_space_evaluator.py:15-101 with the reference's constructor `(args, embed_net_path, lang_model, device)`
+    (train.py:99-101 calls it unchanged): the checkpoint at embed_net_path is the autoencoder trainer's
+    {'args', 'epoch', 'pose_dim', 'gen_dict'} (train_feature_extractor.py:155-157).  from_net() wraps an already built network."""
 
-    def __init__(self, net, n_pre_poses=4):
-        self.net = net
+    def __init__(self, args, embed_net_path, lang_model, device):
+        from .checkpoint import load_checkpoint
+        from .modules import EmbeddingNet
+        self.n_pre_poses = args.n_pre_poses
+        ckpt = load_checkpoint(embed_net_path, device)
+        self.pose_dim = ckpt["pose_dim"]
+        word_embeddings = getattr(lang_model, "word_embedding_weights", None)
+        self.net = EmbeddingNet(args, self.pose_dim, args.n_poses, getattr(lang_model, "n_words", None),
+                                getattr(args, "wordembed_dim", None), word_embeddings, "pose").to(device)
+        self.net.load_state_dict(ckpt["gen_dict"])
         self.net.train(False)
-        self.n_pre_poses = n_pre_poses
         self.reset()
 
     @classmethod
+    def from_net(cls, net, n_pre_poses=4):
+        self = cls.__new__(cls)
+        self.net, self.n_pre_poses, self.pose_dim = net, n_pre_poses, net.pose_dim
+        self.net.train(False)
+        self.reset()
+        return self
+
+    @classmethod
     def from_checkpoint(cls, args, ckpt, device):
+        """From an already loaded autoencoder checkpoint dict."""
         from .modules import EmbeddingNet
         net = EmbeddingNet(args, ckpt["pose_dim"], args.n_poses, None, None, None, mode="pose").to(device)
         net.load_state_dict(ckpt["gen_dict"])
-        return cls(net, args.n_pre_poses)
+        return cls.from_net(net, args.n_pre_poses)
 
     def reset(self):
-        self.real_feat_list, self.generated_feat_list, self.recon_err_diff = [], [], []
+        self.context_feat_list, self.real_feat_list, self.generated_feat_list, self.recon_err_diff = [], [], [], []
 
     def get_no_of_samples(self):
         return len(self.real_feat_list)
@@ -84,6 +101,44 @@ class EmbeddingSpaceEvaluator:
 
     def get_scores(self):
         return fgd_scores(np.vstack(self.generated_feat_list), np.vstack(self.real_feat_list))
+
+
+def eval_embed(in_text, in_audio, pre_poses, target_poses, net, mode=None):
+    """train_eval/train_joint_embed.py:54-62 for the pose-mode network: (mean over clips of the per-clip mean L1 between
+    reconstruction and target, reconstruction).  The loss stays a device scalar (the caller's .item() is the one host read)."""
+    _, _, _, _, _, _, recon_poses = net(in_text, in_audio, pre_poses, target_poses, mode, variational_encoding=False)
+    target = target_poses.float().contiguous()
+    loss = ops.l1_mean(recon_poses.detach().contiguous(), target, torch.empty(1, device=target.device))   # clips have equal size: mean of means
+    return loss.view(()), recon_poses
+
+
+def evaluate_testset(test_data_loader, generator):
+    """scripts/train_feature_extractor.py:26-51: average reconstruction L1 of the autoencoder over a loader that yields
+    (target_poses, target_vec) like data_loader/h36m_loader.py; leaves the network in train mode like the reference."""
+    device = next(generator.parameters()).device
+    generator.train(False)
+    s, n = 0.0, 0
+    with torch.no_grad():
+        for target_poses, target_vec in test_data_loader:
+            loss, _ = eval_embed(None, None, None, target_vec.to(device), generator)
+            s += float(loss) * target_vec.size(0)
+            n += target_vec.size(0)
+    generator.train(True)
+    return {"loss": s / n}
+
+
+def train_iter(args, epoch, target_data, net, optim):
+    """scripts/train_feature_extractor.py:54-97 with variational_encoding=False; `optim` is a FusedAdam over `net`."""
+    E = net.engine
+    E.slab.ensure().zero_grad()
+    target = target_data.float().contiguous()
+    res = E.forward(target, training=True, save=True)
+    loss = torch.empty(1, device=target.device)
+    d_recon = torch.empty_like(target)
+    ops.ae_loss(res["recon"], target, loss, d_recon)
+    E.backward(res["tape"], d_recon)
+    optim.step()
+    return {"loss": float(loss)}
 
 
 class AutoencoderTrainer:

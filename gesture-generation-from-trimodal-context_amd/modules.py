@@ -125,6 +125,7 @@ class PoseGenerator(nn.Module):
                                  nn.Linear(self.hidden_size // 2, pose_dim))
         self.do_flatten_parameters = False
         self._engine = None
+        self._replay_draws = []      # parity tests: queue of {'g.eps' | 'g.z' | mask name: tensor}, one entry consumed per forward call
 
     @property
     def engine(self) -> GeneratorEngine:
@@ -138,8 +139,11 @@ class PoseGenerator(nn.Module):
         eng.rng.advance()            # every call draws fresh dropout masks / eps (the trainer advances once per iteration itself)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
+        inject = self._replay_draws.pop(0) if self._replay_draws else None
+
         def runner():
-            res = eng.forward(pre_seq.float(), in_text, in_audio.float(), vid_indices, training=self.training, save=need_grad)
+            res = eng.forward(pre_seq.float(), in_text, in_audio.float(), vid_indices, training=self.training, save=need_grad,
+                              inject=inject)
 
             def back(d_out, d_z, d_mu, d_lv):
                 # z = mu + eps*std: a gradient on z folds into mu/logvar inside engine.backward via the GRU input path;
@@ -239,6 +243,7 @@ class EmbeddingNet(nn.Module):
         if mode != "pose" or n_frames != 34:
             raise NotImplementedError("HIP path implements mode='pose' with 34-frame clips (config/gesture_autoencoder.yml)")
         self.context_encoder = None
+        self.pose_dim = pose_dim
         self.pose_encoder = _PoseEncoderParams(pose_dim)
         self.decoder = _PoseDecoderParams(pose_dim)
         self.mode = mode

@@ -64,8 +64,11 @@ def window_inputs(args, lang_model, audio, words, i, audio_sr=16000):
 class WindowDecoder:
     """Batched window forward with device-side seed hand-over and cross-fade; optional hipGraph capture."""
 
-    def __init__(self, args, pose_decoder, batch, device, graph=True):
+    def __init__(self, args, pose_decoder, batch, device, graph=True, replay_draws=False):
         self.args, self.gen, self.B, self.dev = args, pose_decoder, batch, device
+        # replay_draws (parity tests): the per-window eps / random z comes from self.draw (B, 16), filled by the caller before each
+        # window, instead of the device RNG -- a static buffer, so a captured window replays with new contents
+        self.draw = torch.zeros(batch, 16, device=device) if replay_draws else None
         self.T, self.n_pre = args.n_poses, args.n_pre_poses
         self.D = pose_decoder.pose_dim
         self.audio_len = int(self.T / args.motion_resampling_framerate * 16000)
@@ -88,8 +91,11 @@ class WindowDecoder:
             self.pre_seq[:, :self.n_pre, -1] = 1
 
     def _forward(self, first):
-        self.gen.engine.rng.advance()          # reparameterize() draws a fresh eps per window, also at inference
-        res = self.gen.engine.forward(self.pre_seq, self.text, self.audio, self.vid, training=False)
+        eng = self.gen.engine
+        eng.rng.advance()                      # reparameterize() draws a fresh eps per window, also at inference
+        inject = None if self.draw is None else {"g.eps": self.draw, "g.z": self.draw}
+        vid = self.vid if eng.z_mode == "speaker" else None            # synthesize.py:67-74: no speaker input otherwise
+        res = eng.forward(self.pre_seq, self.text, self.audio, vid, training=False, inject=inject)
         ops.copy2d(res["out"].view(self.B * self.T, self.D), self.out.view(self.B * self.T, self.D))
         if not first:                                            # cross-fade with the previous window's last frames
             ops.window_blend(self.tail, self.out)
@@ -98,12 +104,15 @@ class WindowDecoder:
         self.seedwin[:, :self.n_pre, :].copy_(self.tail)
         ops.make_pre_seq(self.seedwin, self.pre_seq, self.n_pre)          # frames < n_pre + constraint bit, zeros elsewhere
 
-    def window(self, in_text, in_audio, vid, first):
+    def window(self, in_text, in_audio, vid, first, draw=None):
         """One window for the whole batch.  Inputs may be CPU or GPU tensors; returns the (B, T, D) output buffer (device,
         overwritten by the next call)."""
         self.text.copy_(in_text, non_blocking=True)
         self.audio.copy_(in_audio, non_blocking=True)
-        self.vid.copy_(vid, non_blocking=True)
+        if vid is not None:
+            self.vid.copy_(vid, non_blocking=True)
+        if draw is not None:
+            self.draw.copy_(draw, non_blocking=True)
         with torch.no_grad():
             if not self.use_graph or first:
                 self._forward(first)
@@ -121,17 +130,23 @@ class WindowDecoder:
 
 
 def generate_gestures_batch(args, pose_decoder, lang_model, audios, words_list, vids=None, seed_seqs=None, audio_sr=16000,
-                            graph=True):
+                            graph=True, _draws=None):
     """Lock-step synthesis of several utterances.  Returns a list of (n_i * 30 + 4, D) numpy arrays (mean-subtracted direction
-    vectors, like the reference's return value without fade-out)."""
+    vectors, like the reference's return value without fade-out).  vids: one speaker id per utterance, or None / a falsy entry to
+    draw it like the reference (synthesize.py:67-74; ignored unless args.z_type == 'speaker').  _draws (parity tests): per window,
+    the (B, 16) eps / z to replay instead of the device RNG."""
     dev = next(pose_decoder.parameters()).device
     B = len(audios)
     n_win = [num_windows(len(a) / audio_sr, args.n_poses, args.n_pre_poses, args.motion_resampling_framerate) for a in audios]
-    dec = WindowDecoder(args, pose_decoder, B, dev, graph=graph)
+    dec = WindowDecoder(args, pose_decoder, B, dev, graph=graph, replay_draws=_draws is not None)
     dec.seed(None if seed_seqs is None else np.stack([np.asarray(s)[:args.n_pre_poses] for s in seed_seqs]))
-    if vids is None:
-        vids = [random.randrange(pose_decoder.z_obj.n_words) for _ in range(B)]        # synthesize.py:70-72
-    vid = torch.as_tensor(vids, dtype=torch.int64)
+    vid = None
+    if args.z_type == "speaker":                                                       # synthesize.py:67-74
+        vids = [None] * B if vids is None else list(vids)
+        for b in range(B):
+            if not vids[b]:
+                vids[b] = random.randrange(pose_decoder.z_obj.n_words)
+        vid = torch.as_tensor(vids, dtype=torch.int64)
     stride = args.n_poses - args.n_pre_poses
     total = torch.zeros(B, max(n_win) * stride + args.n_pre_poses, dec.D, device=dev)
     for i in range(max(n_win)):
@@ -140,7 +155,8 @@ def generate_gestures_batch(args, pose_decoder, lang_model, audios, words_list, 
             j = min(i, n_win[b] - 1)                               # finished utterances idle on their last window
             a, ids, _ = window_inputs(args, lang_model, audios[b], words_list[b], j, audio_sr)
             a_np.append(a); t_np.append(ids)
-        out = dec.window(torch.from_numpy(np.stack(t_np)), torch.from_numpy(np.stack(a_np)), vid, first=(i == 0))
+        out = dec.window(torch.from_numpy(np.stack(t_np)), torch.from_numpy(np.stack(a_np)), vid, first=(i == 0),
+                         draw=None if _draws is None else _draws[i])
         # out_list[-1][:-n_pre] + blended window == write the whole window at frame i*stride (its first n_pre frames overwrite
         # the previous window's last n_pre frames with the cross-faded values)
         total[:, i * stride:i * stride + args.n_poses, :].copy_(out)
@@ -148,24 +164,31 @@ def generate_gestures_batch(args, pose_decoder, lang_model, audios, words_list, 
     return [res[b, :n_win[b] * stride + args.n_pre_poses] for b in range(B)]
 
 
-def generate_gestures(args, pose_decoder, lang_model, audio, words, audio_sr=16000, vid=None, seed_seq=None, fade_out=False):
-    """Single-utterance API of the reference (multimodal_context model)."""
-    out = generate_gestures_batch(args, pose_decoder, lang_model, [audio], [words], None if vid is None else [vid],
-                                  None if seed_seq is None else [seed_seq], audio_sr, graph=True)[0]
-    if not fade_out:
-        return out
-    # fade out to the mean pose (synthesize.py:188-207), host maths on the last few frames
+def fade_out_to_mean(out_dir_vec, end_padding_samples, args, audio_sr=16000):
+    """synthesize.py:188-207: fade out to the mean pose over 2 * n_pre_poses frames starting where the real audio ended --
+    frames after the fade are zeroed (mean pose), the transition is a weighted quadratic fit per dimension.  Host maths on a
+    handful of frames."""
     n_smooth = args.n_pre_poses
-    n_win = num_windows(len(audio) / audio_sr, args.n_poses, args.n_pre_poses, args.motion_resampling_framerate)
-    _, _, end_padding = window_inputs(args, lang_model, audio, words, n_win - 1, audio_sr)
-    start_frame = len(out) - int(end_padding / audio_sr * args.motion_resampling_framerate)
+    start_frame = len(out_dir_vec) - int(end_padding_samples / audio_sr * args.motion_resampling_framerate)
     end_frame = start_frame + n_smooth * 2
-    if len(out) < end_frame:
-        out = np.pad(out, [(0, end_frame - len(out)), (0, 0)], mode="constant")
-    out[end_frame - n_smooth:] = 0
-    y = out[start_frame:end_frame]
+    if len(out_dir_vec) < end_frame:
+        out_dir_vec = np.pad(out_dir_vec, [(0, end_frame - len(out_dir_vec)), (0, 0)], mode="constant")
+    out_dir_vec[end_frame - n_smooth:] = 0
+    y = out_dir_vec[start_frame:end_frame]
     x = np.arange(y.shape[0])
     w = np.ones(len(y)); w[0] = 5; w[-1] = 5
     coeffs = np.polyfit(x, y, 2, w=w)
-    out[start_frame:end_frame] = np.stack([np.poly1d(coeffs[:, k])(x) for k in range(y.shape[1])], axis=1)
-    return out
+    out_dir_vec[start_frame:end_frame] = np.stack([np.poly1d(coeffs[:, k])(x) for k in range(y.shape[1])], axis=1)
+    return out_dir_vec
+
+
+def generate_gestures(args, pose_decoder, lang_model, audio, words, audio_sr=16000, vid=None, seed_seq=None, fade_out=False,
+                      _draws=None):
+    """Single-utterance API of the reference (synthesize.py:36-209, multimodal_context model)."""
+    out = generate_gestures_batch(args, pose_decoder, lang_model, [audio], [words], [vid], None if seed_seq is None else [seed_seq],
+                                  audio_sr, graph=True, _draws=_draws)[0]
+    if not fade_out:
+        return out
+    n_win = num_windows(len(audio) / audio_sr, args.n_poses, args.n_pre_poses, args.motion_resampling_framerate)
+    _, _, end_padding = window_inputs(args, lang_model, audio, words, n_win - 1, audio_sr)
+    return fade_out_to_mean(out, end_padding, args, audio_sr)

@@ -702,16 +702,30 @@ def data_make_audio_fixed_length(audio, expected_audio_length):
     return audio
 
 
-def data_getitem(sample, word_index, n_poses=34, fps=15, remove_word_timing=False):
+def data_words_to_tensor(word_seq, word_index, end_time=None, sos=1, eos=2):
+    """lmdb_data_loader.py:142-149: [SOS, ids of the words that start no later than end_time, EOS]."""
+    idx = [sos]
+    for w in word_seq:
+        if end_time is not None and w[1] > end_time:
+            break
+        idx.append(word_index(w[0]))
+    idx.append(eos)
+    return np.asarray(idx, dtype=np.int64)
+
+
+def data_getitem(sample, word_index, n_poses=34, fps=15, remove_word_timing=False, full=False):
     """SpeechMotionDataset.__getitem__ (data_loader/lmdb_data_loader.py:107-171) after `pyarrow.deserialize`; `word_index`
-    maps a word to its vocabulary id (lang_model.get_word_index).  Returns (extended_word_seq, vec_seq, audio) as numpy.
-    parity unpinned: lmdb_data_loader.py needs lmdb / pyarrow 0.14 and cannot be imported; checked against
-    hand-computed values in tests/test_data_cpu.py."""
+    maps a word to its vocabulary id (lang_model.get_word_index).  Returns (extended_word_seq, vec_seq, audio) as numpy, or with
+    full=True the reference's whole tuple (word_seq_tensor, extended_word_seq, pose_seq, vec_seq, audio, spectrogram, aux_info).
+    Pinned by tests/golden/g10_dataset.npz (SpeechMotionDataset.__getitem__ of the imported reference, make_golden_eval.py)."""
     word_seq, pose_seq, vec_seq, audio, spectrogram, aux_info = sample
     duration = aux_info["end_time"] - aux_info["start_time"]
     sample_end_time = aux_info["start_time"] + duration * n_poses / vec_seq.shape[0]          # :153
     audio = data_make_audio_fixed_length(audio, int(round(n_poses / fps * 16000)))            # :154, :62
+    spec_len = int(round((n_poses / fps * 16000 - 1024) / 512 + 1))                            # utils/data_utils.py:44-46
+    spectrogram = np.asarray(spectrogram)[:, 0:spec_len]                                       # :155
     vec_seq = vec_seq[0:n_poses]
+    pose_seq = pose_seq[0:n_poses]
     frame_duration = (sample_end_time - aux_info["start_time"]) / n_poses                     # :119
     ext = np.zeros(n_poses)
     onset_frames = [max(0, int(np.floor((w[1] - aux_info["start_time"]) / frame_duration))) for w in word_seq]
@@ -724,4 +738,159 @@ def data_getitem(sample, word_index, n_poses=34, fps=15, remove_word_timing=Fals
         for w, f in zip(word_seq, onset_frames):
             if f < n_poses:
                 ext[f] = word_index(w[0])
-    return ext.astype(np.int64), vec_seq.reshape(vec_seq.shape[0], -1).astype(np.float32), np.asarray(audio, dtype=np.float32)
+    ext = ext.astype(np.int64)
+    vec = vec_seq.reshape(vec_seq.shape[0], -1).astype(np.float32)
+    audio = np.asarray(audio, dtype=np.float32)
+    if not full:
+        return ext, vec, audio
+    return (data_words_to_tensor(word_seq, word_index, sample_end_time), ext, pose_seq.reshape(pose_seq.shape[0], -1).astype(np.float32),
+            vec, audio, spectrogram, aux_info)
+
+
+def pose_seq_to_dir_vec(pose):
+    """utils/data_utils.py:101-121: joint positions (T,10,3) | (B,T,10,3) -> unit bone direction vectors (..., 9, 3).
+    sklearn's normalize leaves an all-zero row at zero."""
+    pose = np.asarray(pose)
+    if pose.shape[-1] != 3:
+        pose = pose.reshape(pose.shape[:-1] + (-1, 3))
+    out = np.zeros(pose.shape[:-2] + (len(DIR_VEC_PAIRS), 3))
+    for i, (a, b, _) in enumerate(DIR_VEC_PAIRS):
+        d = pose[..., b, :] - pose[..., a, :]
+        n = np.sqrt((d * d).sum(-1, keepdims=True))
+        out[..., i, :] = d / np.where(n == 0, 1.0, n)
+    return out
+
+
+# --------------------------------------------------------------------------- evaluation loops
+def evaluate_testset(gst, batches, mean_dir_vec, rand: Rand, *, n_pre=4, ast=None, vids=None, input_context="both",
+                     z_mode="speaker", dtype=torch.float32):
+    """scripts/train.py:234-329, multimodal_context branch.  `batches`: list of (in_text_padded, target_vec, in_audio) torch
+    tensors; `vids`: per-batch speaker ids (the reference draws them with random.choice :257-260; None when the generator has
+    no speaker Vocab, utils/train_utils.py:152-164).  Draw names: 'e{i}.eps' / 'e{i}.z'.  Returns the reference's dict plus
+    'accel' (computed at :308-310 but only logged) and the per-batch outputs."""
+    tot = {"loss": 0.0, "joint_mae": 0.0, "accel": 0.0}
+    count = 0
+    outs, real_feats, gen_feats = [], [], []
+    mean = np.asarray(mean_dir_vec).squeeze()
+    for i, (text, target, audio) in enumerate(batches):
+        B = target.shape[0]
+        target_t = target.to(dtype)
+        pre_seq = make_pre_seq(target_t, n_pre)                                        # :262-265
+        vid = None if (vids is None or z_mode != "speaker") else vids[i]
+        out, *_ = generator_forward(gst, pre_seq, text, audio.to(dtype), vid, training=False, rand=rand, tag=f"e{i}",
+                                    input_context=input_context, z_mode=z_mode)
+        loss = float((out - target_t).abs().mean())                                   # F.l1_loss :282
+        if ast is not None:                                                            # push_samples, evaluator :46-64
+            real_feats.append(ae_forward(ast, target_t.to(torch.float32), False)[0].numpy())
+            gen_feats.append(ae_forward(ast, out.to(torch.float32), False)[0].numpy())
+        o = out.detach().to(torch.float32).numpy() + mean                              # :293-298 (float32 + float64 -> float64)
+        t = target.to(torch.float32).numpy() + mean
+        oj, tj = dir_vec_to_pose(o), dir_vec_to_pose(t)
+        mae = float(np.mean(np.absolute(oj[:, n_pre:] - tj[:, n_pre:])))               # :300-305
+        acc = float(np.mean(np.abs(np.diff(tj, n=2, axis=1) - np.diff(oj, n=2, axis=1))))   # :308-310
+        tot["loss"] += loss * B; tot["joint_mae"] += mae * B; tot["accel"] += acc * B
+        count += B
+        outs.append(out.detach())
+    ret = {k: v / count for k, v in tot.items()}
+    if ast is not None and real_feats:
+        ret["frechet"], ret["feat_dist"] = fgd_scores(np.vstack(gen_feats), np.vstack(real_feats))
+    return ret, outs
+
+
+def eval_embed(ast, target_poses):
+    """train_eval/train_joint_embed.py:54-62 for the pose-mode network: (mean over clips of the per-clip mean L1, recon)."""
+    _, _, _, recon = ae_forward(ast, target_poses, False)
+    return float((recon - target_poses).abs().mean(dim=(1, 2)).mean()), recon
+
+
+def ae_evaluate_testset(ast, batches):
+    """scripts/train_feature_extractor.py:26-51: batch-size weighted average of eval_embed's loss over (B,34,27) batches."""
+    s, n = 0.0, 0
+    for target in batches:
+        loss, _ = eval_embed(ast, target)
+        s += loss * target.shape[0]
+        n += target.shape[0]
+    return {"loss": s / n}
+
+
+# --------------------------------------------------------------------------- long-utterance synthesis
+def words_in_time_range(word_list, start_time, end_time):
+    """data_loader/data_preprocessor.py:174-188."""
+    out = []
+    for w in word_list:
+        if w[1] >= end_time:
+            break
+        if w[2] <= start_time:
+            continue
+        out.append(w)
+    return out
+
+
+def window_inputs(audio, words, i, word_index, *, n_poses=34, n_pre=4, fps=15, audio_sr=16000):
+    """synthesize.py:82-119 for window i: (in_audio (L,) float32 zero-padded, in_text_padded (n_poses,) int64, padding samples)."""
+    unit_time, stride_time = n_poses / fps, (n_poses - n_pre) / fps
+    clip_length = len(audio) / audio_sr
+    audio_sample_length = int(unit_time * audio_sr)
+    start_time = i * stride_time
+    end_time = start_time + unit_time
+    a0 = math.floor(start_time / clip_length * len(audio))
+    piece = np.asarray(audio[a0:a0 + audio_sample_length])
+    pad = 0
+    if len(piece) < audio_sample_length:
+        pad = audio_sample_length - len(piece)
+        piece = np.pad(piece, (0, pad), "constant")
+    ids = np.zeros(n_poses)
+    frame_duration = (end_time - start_time) / n_poses
+    for w in words_in_time_range(words, start_time, end_time):
+        ids[max(0, int(np.floor((w[1] - start_time) / frame_duration)))] = word_index(w[0])
+    return piece.astype(np.float32), ids.astype(np.int64), pad
+
+
+def fade_out_tail(out_dir_vec, end_padding_samples, *, n_pre=4, fps=15, audio_sr=16000):
+    """synthesize.py:188-207: pad if needed, zero the frames after the fade, weighted quadratic fit over 2*n_pre frames."""
+    out = np.array(out_dir_vec, copy=True)
+    n_smooth = n_pre
+    start_frame = len(out) - int(end_padding_samples / audio_sr * fps)
+    end_frame = start_frame + n_smooth * 2
+    if len(out) < end_frame:
+        out = np.pad(out, [(0, end_frame - len(out)), (0, 0)], mode="constant")
+    out[end_frame - n_smooth:] = 0
+    y = out[start_frame:end_frame]
+    x = np.arange(y.shape[0])
+    w = np.ones(len(y)); w[0] = 5; w[-1] = 5
+    coeffs = np.polyfit(x, y, 2, w=w)
+    out[start_frame:end_frame] = np.stack([np.poly1d(coeffs[:, k])(x) for k in range(y.shape[1])], axis=1)
+    return out
+
+
+def generate_gestures(gst, audio, words, word_index, rand: Rand, *, vid=None, seed_seq=None, fade_out=False, n_poses=34,
+                      n_pre=4, fps=15, audio_sr=16000, pose_dim=27, input_context="both", z_mode="speaker", windows=None):
+    """scripts/synthesize.py:36-209, multimodal_context model.  vid: speaker id (already drawn: the reference's
+    random.randrange at :69-71 is the caller's business) or None for z_mode != 'speaker'.  Draw names 'w{i}.eps' / 'w{i}.z'.
+    `windows` (list) receives each window's (pre_seq, in_text_padded, in_audio) when given."""
+    clip_length = len(audio) / audio_sr
+    n_sub = num_windows(clip_length, n_poses, n_pre, fps)
+    pre_seq = torch.zeros(1, n_poses, pose_dim + 1)
+    if seed_seq is not None:
+        pre_seq[0, :n_pre, :-1] = torch.as_tensor(np.asarray(seed_seq)[:n_pre], dtype=torch.float32)
+        pre_seq[0, :n_pre, -1] = 1
+    vid_t = torch.tensor([int(vid)], dtype=torch.int64) if (z_mode == "speaker") else None
+    out_list, end_pad, out = [], 0, None
+    for i in range(n_sub):
+        a, ids, pad = window_inputs(audio, words, i, word_index, n_poses=n_poses, n_pre=n_pre, fps=fps, audio_sr=audio_sr)
+        if i == n_sub - 1:
+            end_pad = pad
+        if i > 0:
+            pre_seq = pre_seq.clone()
+            pre_seq[0, :n_pre, :-1] = out[0, -n_pre:]
+            pre_seq[0, :n_pre, -1] = 1
+        in_audio, in_text = torch.from_numpy(a).unsqueeze(0), torch.from_numpy(ids).unsqueeze(0)
+        if windows is not None:
+            windows.append((pre_seq.clone(), in_text.clone(), in_audio.clone()))
+        out, *_ = generator_forward(gst, pre_seq, in_text, in_audio, vid_t, training=False, rand=rand, tag=f"w{i}",
+                                    input_context=input_context, z_mode=z_mode)
+        out_list.append(out[0].detach().numpy().copy())
+    res = blend_windows(out_list, n_pre)
+    if fade_out:
+        res = fade_out_tail(res, end_pad, n_pre=n_pre, fps=fps, audio_sr=audio_sr)
+    return res

@@ -145,3 +145,70 @@ def sample_idx(numel, n=2048, seed=7):
     if numel <= n:
         return np.arange(numel)
     return np.sort(np.random.RandomState(seed + numel % 9973).choice(numel, n, replace=False))
+
+
+# --------------------------------------------------------------------------- fixtures generated by tests/golden/make_golden_eval.py
+MEAN_DIR_VEC_KEY = "mean_dir_vec"
+FIXTURE_WORDS = ("so what i want to talk about today is how we move our hands when we speak and why it matters for the people who listen "
+                 "because gesture carries meaning that words alone do not").split()
+
+
+def fixture_lang(vocab_cls, n_words):
+    """The word Vocab make_golden_eval.py built with the reference's class: the fixture's words, then fillers up to n_words."""
+    lang = vocab_cls("words")
+    for w in FIXTURE_WORDS:
+        lang.index_word(w)
+    i = 0
+    while lang.n_words < n_words:
+        lang.index_word(f"filler{i}")
+        i += 1
+    lang.word_embedding_weights = None
+    return lang
+
+
+class OracleLang:
+    """get_word_index of that Vocab without any product / reference class (oracle side of the tests)."""
+
+    def __init__(self, n_words):
+        self.index = {}
+        n = 4
+        for w in FIXTURE_WORDS:
+            if w not in self.index:
+                self.index[w] = n
+                n += 1
+        self.n_words = n_words
+
+    def get_word_index(self, w):
+        return self.index.get(w, 3)
+
+
+def synth_case(g, name):
+    """One generate_gestures case of g9_generate_gestures.npz -> dict of python / numpy inputs and expected outputs."""
+    words = [[str(w), float(t[0]), float(t[1])] for w, t in zip(g[f"{name}/words"], g[f"{name}/word_times"])]
+    seed = g[f"{name}/seed_seq"]
+    zt = str(g[f"{name}/z_type"])
+    draws = g[f"{name}/eps"] if zt == "speaker" else g[f"{name}/z"]
+    return dict(z_type=zt, audio=g[f"{name}/audio"].astype(np.float32), words=words, fade_out=bool(g[f"{name}/fade_out"]),
+                vid_arg=None if int(g[f"{name}/vid_arg"]) < 0 else int(g[f"{name}/vid_arg"]),
+                vid_used=None if int(g[f"{name}/vid_used"]) < 0 else int(g[f"{name}/vid_used"]),
+                seed_seq=seed if seed.shape[0] else None, draws=draws, out=g[f"{name}/out"], win_pre_seq=g[f"{name}/win_pre_seq"],
+                win_text=g[f"{name}/win_text"], win_audio_head=g[f"{name}/win_audio_head"], win_audio_tail=g[f"{name}/win_audio_tail"],
+                win_audio_abs_sum=g[f"{name}/win_audio_abs_sum"])
+
+
+def check_window_audio(case, i, audio_window):
+    a = np.asarray(audio_window, dtype=np.float32)
+    assert np.array_equal(a[:64], case["win_audio_head"][i]) and np.array_equal(a[-3000:], case["win_audio_tail"][i]), i
+    assert abs(float(np.abs(a.astype(np.float64)).sum()) - float(case["win_audio_abs_sum"][i])) < 1e-9, i
+
+
+def dataset_samples(g):
+    """The raw samples of g10_dataset.npz in the preprocessor's stored format."""
+    out = []
+    for i in range(int(g["n_samples"])):
+        words = [[str(w), float(t[0]), float(t[1])] for w, t in zip(g[f"raw{i}/words"], g[f"raw{i}/word_times"])]
+        aux = g[f"raw{i}/aux"]
+        out.append([words, g[f"raw{i}/pose"], g[f"raw{i}/vec"], g[f"raw{i}/audio"].astype(np.float32), g[f"raw{i}/spec"],
+                    {"vid": str(g[f"raw{i}/vid"]), "start_frame_no": int(aux[0]), "end_frame_no": int(aux[1]), "start_time": float(aux[2]),
+                     "end_time": float(aux[3])}])
+    return out

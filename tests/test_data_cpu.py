@@ -1,12 +1,20 @@
-"""Input-pipeline stand-in (data.py) against the oracle's restatement of SpeechMotionDataset.__getitem__ and hand-computed values.
-The reference's data loader cannot be imported here (needs lmdb / pyarrow 0.14): parity for this part is unpinned and rests on the
-hand-computed cases below."""
+"""Host logic either side of the hot path -- the input pipeline (data.py), window slicing / fade-out (synthesize.py), bone integration
+and speaker-model lookup -- against fixtures the REAL reference produced (tests/golden/make_golden_eval.py: SpeechMotionDataset.__getitem__,
+default_collate_fn, generate_gestures, convert_dir_vec_to_pose) and against the oracle pinned by the same fixtures."""
+import argparse
 import importlib
+import os
 
 import numpy as np
 import torch
 
+from conftest import GOLDEN
 from oracle import ref_model as O
+from tests.harness import check_window_audio, dataset_samples, fixture_lang, synth_case
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
 def _mods(pkg):
@@ -58,8 +66,84 @@ def test_getitem_matches_oracle_and_collate(pkg):
         assert it[1].dtype == torch.int64 and np.array_equal(it[1].numpy(), ext)
         assert np.array_equal(it[3].numpy(), vec) and np.array_equal(it[4].numpy(), audio)
         assert it[3].shape == (34, 27) and it[4].shape == (36267,) and it[2].shape == (34, 30)     # expected_audio_length :62
-        assert int((it[1] > 0).sum()) >= 1 and it[0][0] == 1 and it[0][-1] == 2
+        assert int((it[1] > 0).sum()) >= 1 and it[0][0] == 1 and it[0][-1] == 2 and len(it) == 7
     text, vec, audio, vid = D.collate(items[:8], spk)
     assert text.shape == (8, 34) and vec.shape == (8, 34, 27) and audio.shape == (8, 36267) and vid.shape == (8,)
     assert vid.dtype == torch.int64 and int(vid.min()) >= 1 and int(vid.max()) < spk.n_words
     assert D.collate(items[:2], None)[3] is None and D.collate(items[:2], 1)[3] is None          # z_type random / none
+
+
+def test_dataset_items_and_collate_match_reference_golden(pkg):
+    """data.SpeechMotionDataset / sample_to_tensors / default_collate_fn == the reference's (lmdb_data_loader.py:43-53,107-171), bit for
+    bit, on the raw samples the reference itself was run on."""
+    D = _mods(pkg)
+    g = load("g10_dataset.npz")
+    lang = fixture_lang(pkg.Vocab, int(g["vocab_size"]))
+    samples = dataset_samples(g)
+    for tag, rwt in (("timed", False), ("rwt", True)):
+        ds = D.SpeechMotionDataset(samples, 34, 10, 15, remove_word_timing=rwt)
+        ds.set_lang_model(lang)
+        assert len(ds) == len(samples) and ds.expected_audio_length == 36267 and ds.expected_spectrogram_length == 70
+        items = [ds[i] for i in range(len(ds))]
+        for i, (words, ext, pose, vec, audio, spec, aux) in enumerate(items):
+            assert words.dtype == torch.int64 and ext.dtype == torch.int64 and vec.dtype == torch.float32 and audio.dtype == torch.float32
+            assert np.array_equal(words.numpy(), g[f"{tag}{i}/words"]) and np.array_equal(ext.numpy(), g[f"{tag}{i}/ext"]), (tag, i)
+            assert np.array_equal(pose.numpy(), g[f"item{i}/pose"]) and np.array_equal(vec.numpy(), g[f"item{i}/vec"])
+            a = audio.numpy()
+            assert a.shape[0] == int(g[f"item{i}/audio_len"])
+            assert np.array_equal(a[:64], g[f"item{i}/audio_head"]) and np.array_equal(a[-1500:], g[f"item{i}/audio_tail"])
+            assert abs(float(np.abs(a.astype(np.float64)).sum()) - float(g[f"item{i}/audio_abs_sum"])) < 1e-9
+            assert list(spec.shape) == list(g[f"item{i}/spec_shape"]) and aux is samples[i][5]
+        if not rwt:
+            col = D.default_collate_fn(items[:4])
+            assert len(col) == 8 and np.array_equal(col[0].numpy(), g["collate/word_seq"]) and np.array_equal(col[1].numpy(), g["collate/lengths"])
+            assert np.array_equal(col[2].numpy(), g["collate/text"]) and np.array_equal(col[3].numpy(), g["collate/pose"])
+            assert np.array_equal(col[4].numpy(), g["collate/vec"]) and list(col[5].shape) == list(g["collate/audio_shape"])
+            assert torch.equal(col[5], torch.stack([it[4] for it in items[:4]])) and list(col[6].shape) == list(g["collate/spec_shape"])
+            assert sorted(col[7]) == [str(k) for k in g["collate/aux_keys"]] and list(col[7]["vid"]) == [str(v) for v in g["collate/aux_vid"]]
+            assert np.array_equal(col[7]["start_time"].numpy(), g["collate/aux_start_time"])
+    a = g["fixlen/in"]
+    for n, key in ((1500, "longer"), (700, "shorter"), (1000, "same")):
+        assert np.array_equal(D.make_audio_fixed_length(a, n), g["fixlen/" + key])
+
+
+def test_window_inputs_and_fade_out_match_reference_golden(pkg):
+    """synthesize.window_inputs / num_windows / fade_out_to_mean == what scripts/synthesize.py:generate_gestures fed its model and
+    did to its output (recorded window inputs; fade-out applied to the reference's own un-faded result)."""
+    syn = importlib.import_module(pkg.__name__ + ".synthesize")
+    g = load("g9_generate_gestures.npz")
+    lang = fixture_lang(pkg.Vocab, int(g["n_words"]))
+    args = argparse.Namespace(n_poses=34, n_pre_poses=4, motion_resampling_framerate=15)
+    cases = {str(c): synth_case(g, str(c)) for c in g["cases"]}
+    for name, c in cases.items():
+        n = c["win_text"].shape[0]
+        assert syn.num_windows(len(c["audio"]) / 16000, 34, 4, 15) == n, name
+        pad = 0
+        for i in range(n):
+            a, ids, pad = syn.window_inputs(args, lang, c["audio"], c["words"], i)
+            assert ids.dtype == np.int64 and np.array_equal(ids, c["win_text"][i]), (name, i)
+            check_window_audio(c, i, a)
+        twin = cases.get(name[:-5]) if name.endswith("_fade") else None
+        if twin is not None and (twin["seed_seq"] is None) == (c["seed_seq"] is None):
+            plain = twin["out"]                            # same utterance, seed poses and draws without fade-out
+            faded = syn.fade_out_to_mean(plain.copy(), pad, args)
+            assert faded.shape == c["out"].shape and float(np.abs(faded - c["out"]).max()) < 1e-6, name
+    c = cases["w2_exact"]                                  # no padding in the last window: the fade-out appends 2 * n_pre frames
+    assert c["win_text"].shape[0] == 2 and c["out"].shape[0] == 2 * 30 + 4 + 8 and np.all(c["out"][-4:] == 0)
+    assert syn.words_in_time_range([["a", 0.0, 0.5], ["b", 0.4, 1.0], ["c", 2.0, 3.0]], 0.5, 2.0) == [["b", 0.4, 1.0]]
+
+
+def test_convert_dir_vec_to_pose_and_speaker_lookup(pkg):
+    M = importlib.import_module(pkg.__name__ + ".eval_metrics")
+    C = importlib.import_module(pkg.__name__ + ".checkpoint")
+    g = load("g8_evaluate_testset.npz")
+    v = g["dir_vec/in"]
+    for x, key in ((v, "pose_b_t"), (v[0], "pose_t"), (v[0, 0], "pose_single")):
+        p = M.convert_dir_vec_to_pose(x)
+        assert p.shape == g["dir_vec/" + key].shape and float(np.abs(p - g["dir_vec/" + key]).max()) < 1e-12
+    # utils/train_utils.py:152-164: Vocab -> itself; 1 (z_type random) / None -> None; DataParallel-style .module unwrap
+    spk = pkg.Vocab.speakers(5)
+    holder = argparse.Namespace
+    assert C.get_speaker_model(holder(z_obj=spk)) is spk and C.get_speaker_model(holder(module=holder(z_obj=spk))) is spk
+    assert C.get_speaker_model(holder(z_obj=1)) is None and C.get_speaker_model(holder(z_obj=None)) is None
+    assert C.get_speaker_model(holder()) is None

@@ -275,71 +275,163 @@ def test_graphed_step_equals_eager(pkg, dev):
     assert all(np.isfinite(list(d.values())).all() for d in runs[1][0])
 
 
-def test_eval_metrics_match_oracle(pkg, dev):
-    """train.py:282-310 (restated in the oracle) vs tg_pose_metrics."""
+def _ae_checkpoint(pkg, tmp_path, ae_seed):
+    """An FGD autoencoder checkpoint file in the reference's format (train_feature_extractor.py:155-157)."""
+    from importlib import import_module
+    ck = import_module(pkg.__name__ + ".checkpoint")
+    path = os.path.join(str(tmp_path), "ae_checkpoint.bin")
+    ck.save_checkpoint({"args": make_args(), "epoch": 1, "pose_dim": 27, "gen_dict": O.clone_state(O.make_autoencoder_state(ae_seed))}, path)
+    return path
+
+
+def _eval_loader(g, V, S):
+    sizes = [int(x) for x in g["sizes"]]
+    out = []
+    for i, b in enumerate(sizes):
+        text, audio, _, poses = O.make_batch(int(g["batch_seed0"]) + i, b, V, S)
+        # the 8-tuple of default_collate_fn (lmdb_data_loader.py:43-53)
+        out.append((torch.tensor([0]), torch.tensor([0]), text, torch.zeros(b, 34, 30), poses, audio, torch.zeros(b, 1), {}))
+    return sizes, out
+
+
+@pytest.mark.parametrize("zt", ["speaker", "random", "none"])
+def test_evaluate_testset_matches_reference_golden(pkg, dev, tmp_path, zt):
+    """eval_metrics.evaluate_testset called with the reference's signature == scripts/train.py:evaluate_testset (:234-329) run by the
+    reference itself (g8 fixture): loss / joint MAE / accel / FGD / feature distance, speaker ids drawn the reference's way, for every
+    z_type; the evaluator is built through the reference's constructor from a checkpoint file."""
+    import random
     from importlib import import_module
     em = import_module(pkg.__name__ + ".eval_metrics")
-    g = torch.Generator().manual_seed(3)
-    out, tgt = 0.3 * torch.randn(12, 34, 27, generator=g), 0.3 * torch.randn(12, 34, 27, generator=g)
-    mean = [0.0154009, -0.9690125, -0.0884354, -0.0022264, -0.8655276, 0.4342174, -0.0035145, -0.8755367, -0.4121039, -0.9236511,
-            0.3061306, -0.0012415, -0.5155854, 0.8129665, 0.0871897, 0.2348464, 0.1846561, 0.8091402, 0.9271948, 0.2960011, -0.013189,
-            0.5233978, 0.8092403, 0.0725451, -0.2037076, 0.1924306, 0.8196916]                    # config/multimodal_context.yml:16
-    l1, mae, acc = em.batch_metrics(out.to(dev), tgt.to(dev), mean, 4)
-    ol1, omae, oacc = O.eval_metrics(out.numpy(), tgt.numpy(), mean, 4)
+    fgd = import_module(pkg.__name__ + ".fgd")
+    from harness import fixture_lang
+    g = load("g8_evaluate_testset.npz")
+    V, S = int(g["n_words"]), int(g["n_speakers"])
+    z_mode = zt if zt != "none" else None
+    gst = O.make_generator_state(int(g["g_seed"]), V, S, z_mode=z_mode)
+    args = make_args(z_type=zt, model="multimodal_context", mean_dir_vec=[float(x) for x in g["mean_dir_vec"]])
+    z_obj = pkg.Vocab("vid", insert_default_tokens=False) if zt == "speaker" else (1 if zt == "random" else None)
+    if zt == "speaker":
+        for i in range(S - 1):
+            z_obj.index_word(f"spk{i}")                       # the names (and so the dict order random.choice sees) of the fixture run
+    G = pkg.PoseGenerator(args, 27, V, 300, None, z_obj).to(dev)
+    G.load_state_dict(O.clone_state(gst), strict=True)
+    evaluator = fgd.EmbeddingSpaceEvaluator(args, _ae_checkpoint(pkg, tmp_path, int(g["ae_seed"])), fixture_lang(pkg.Vocab, V), dev)
+    sizes, loader = _eval_loader(g, V, S)
+    offs = np.cumsum([0] + sizes)
+    key = {"speaker": "eps", "random": "z"}.get(zt)
+    if key:
+        G._replay_draws = [{f"g.{key}": torch.from_numpy(g[f"{zt}/{key}"][offs[i]:offs[i + 1]]).to(dev)} for i in range(len(sizes))]
+    vids_seen = []
+    fwd = G.forward
+
+    def spy(pre_seq, in_text, in_audio, vid_indices=None):
+        vids_seen.append(vid_indices)
+        return fwd(pre_seq, in_text, in_audio, vid_indices)
+    G.forward = spy
+    G.train(True)
+    random.seed(1234)                                          # the seed of the fixture run: same Vocab -> same random.choice draws
+    ret = em.evaluate_testset(loader, G, None, evaluator, args)
+    assert G.training and not G._replay_draws
+    if zt == "speaker":
+        assert np.array_equal(torch.cat(vids_seen).cpu().numpy(), g[f"{zt}/vids"])
+    else:
+        assert all(v is None for v in vids_seen)               # utils/train_utils.py:152-164
+    want = dict(zip([str(k) for k in g[f"{zt}/ret_keys"]], g[f"{zt}/ret_vals"]))
+    assert sorted(ret) == sorted(want)
+    for k, v in want.items():
+        tol = 1e-3 if k == "frechet" else 1e-4                 # FGD amplifies 1e-6 feature differences through the matrix square root
+        assert abs(ret[k] - v) <= tol * abs(v), (zt, k, ret[k], v)
+    assert abs(ret.accel - float(g[f"{zt}/accel"])) <= 1e-4 * float(g[f"{zt}/accel"])
+
+
+def test_pose_metrics_kernel_matches_reference_outputs(pkg, dev):
+    """tg_pose_metrics on the reference's own generator outputs of the g8 fixture vs the pinned oracle metrics (train.py:282-310)."""
+    from importlib import import_module
+    em = import_module(pkg.__name__ + ".eval_metrics")
+    g = load("g8_evaluate_testset.npz")
+    V, S = int(g["n_words"]), int(g["n_speakers"])
+    sizes, loader = _eval_loader(g, V, S)
+    out = torch.from_numpy(g["speaker/out"])
+    tgt = torch.cat([b[4] for b in loader])
+    l1, mae, acc = em.batch_metrics(out.to(dev), tgt.to(dev), g["mean_dir_vec"], 4)
+    ol1, omae, oacc = O.eval_metrics(out.numpy(), tgt.numpy(), g["mean_dir_vec"], 4)
     assert abs(l1 - ol1) < 1e-6 * ol1 and abs(mae - omae) < 1e-5 * omae and abs(acc - oacc) < 1e-5 * oacc
 
 
-def test_window_synthesis_matches_oracle_blend(pkg, dev):
-    """generate_gestures (synthesize.py:36-209): window count, audio slicing, seed hand-over and cross-fade, against the
-    oracle's restatement driven window by window with the same eps."""
+def test_generate_gestures_matches_reference_golden(pkg, dev):
+    """synthesize.generate_gestures with the reference's signature == scripts/synthesize.py:generate_gestures (:36-209) run by the
+    reference itself (g9 fixture): 1 / 2 / 3 / 4 windows, fade_out False and True, seed poses, given and randomly drawn speaker ids,
+    z_type speaker / random / none.  The windows the HIP path was fed are compared with the ones the reference fed its model."""
+    import random
     from importlib import import_module
     syn = import_module(pkg.__name__ + ".synthesize")
-    V, S = 64, 9
-    gst = O.make_generator_state(5, V, S)
-    args, G, D = build_models(pkg, dev, gst, O.make_discriminator_state(6), V, S)
-    args.motion_resampling_framerate = 15
-    G.eval()
+    from harness import check_window_audio, fixture_lang, synth_case
+    g = load("g9_generate_gestures.npz")
+    V, S = int(g["n_words"]), int(g["n_speakers"])
+    lang = fixture_lang(pkg.Vocab, V)
+    models, seeds = {}, dict(zip([str(c) for c in g["cases"]], (1, 1, 2, 2, 3, 3, 4, 5, 6)))
+    fades = set()
+    for name in [str(c) for c in g["cases"]]:
+        c = synth_case(g, name)
+        zt = c["z_type"]
+        if zt not in models:
+            z_mode = zt if zt != "none" else None
+            args = make_args(z_type=zt, model="multimodal_context", motion_resampling_framerate=15,
+                             mean_dir_vec=[0.0] * 27)
+            z_obj = pkg.Vocab.speakers(S) if zt == "speaker" else (1 if zt == "random" else None)
+            G = pkg.PoseGenerator(args, 27, V, 300, None, z_obj).to(dev)
+            G.load_state_dict(O.clone_state(O.make_generator_state(int(g["g_seed"]), V, S, z_mode=z_mode)), strict=True)
+            G.eval()
+            models[zt] = (args, G)
+        args, G = models[zt]
+        n = c["win_text"].shape[0]
+        draws = None if zt == "none" else [torch.from_numpy(c["draws"][i:i + 1]) for i in range(n)]
+        fed = []
+        orig = syn.WindowDecoder.window
 
-    class Lang:
-        def get_word_index(self, w): return 4 + (sum(map(ord, w)) % (V - 4))
-    gen = torch.Generator().manual_seed(21)
-    sr = 16000
-    audio = (0.1 * torch.randn(int(6.9 * sr), generator=gen)).numpy()         # 6.9 s -> ceil((6.9-2.2667)/2)+1 = 4 windows
-    words = [["hello", 0.3, 0.6], ["there", 1.1, 1.5], ["general", 2.6, 3.0], ["kenobi", 4.05, 4.6], ["bold", 6.0, 6.4]]
-    assert syn.num_windows(len(audio) / sr) == O.num_windows(len(audio) / sr) == 4
-    # window inputs: slicing arithmetic of synthesize.py:96-119
-    a3, ids3, pad3 = syn.window_inputs(args, Lang(), audio, words, 3, sr)
-    assert len(a3) == 36266 and pad3 == 36266 - (len(audio) - int(np.floor(6.0 / 6.9 * len(audio)))) and ids3[0] == Lang().get_word_index("bold")
-    # run the HIP window loop with recorded eps: wrap the engine's normal draw to record it
-    eng = G.engine
-    eps_rec = []
-    orig_normal = pkg.ops.normal
-    def rec_normal(out, state, site):
-        r = orig_normal(out, state, site); eps_rec.append(r.clone()); return r
-    pkg.ops.normal = rec_normal
-    import importlib as _il
-    _il.import_module(pkg.__name__ + ".engine").ops.normal = rec_normal
-    try:
-        res = syn.generate_gestures_batch(args, G, Lang(), [audio], [words], vids=[3], graph=False)[0]
-    finally:
-        pkg.ops.normal = orig_normal
-        _il.import_module(pkg.__name__ + ".engine").ops.normal = orig_normal
-    assert res.shape == (4 * 30 + 4, 27) and len(eps_rec) == 4
-    # oracle: same windows, same eps, python blend
-    ost = O.clone_state(gst, torch.float64)
-    outs, pre = [], torch.zeros(1, 34, 28, dtype=torch.float64)
-    for i in range(4):
-        a, ids, _ = syn.window_inputs(args, Lang(), audio, words, i, sr)
-        o, *_ = O.generator_forward(ost, pre, torch.from_numpy(ids)[None], torch.from_numpy(a)[None].double(), torch.tensor([3]),
-                                    training=False, rand=O.Rand(inject={"g.eps": eps_rec[i].cpu().double()}))
-        outs.append(o[0].numpy())
-        blended = O.blend_windows(outs)                                    # what the reference has accumulated so far
-        pre = torch.zeros(1, 34, 28, dtype=torch.float64)
-        pre[0, :4, :27] = torch.from_numpy(outs[-1][-4:]) if i == 0 else torch.from_numpy(outs[-1][-4:])
-        pre[0, :4, 27] = 1
-        # the reference seeds window i+1 with the RAW last 4 frames of window i (out_dir_vec, before blending): synthesize.py:122-124
-    ref = O.blend_windows(outs)
-    assert rel(res, ref) < 1e-5
+        def spy(self, in_text, in_audio, vid, first, draw=None, _orig=orig, _fed=fed):
+            _fed.append((self.pre_seq.detach().cpu().clone(), in_text.clone(), in_audio.clone(), None if vid is None else vid.clone()))
+            return _orig(self, in_text, in_audio, vid, first, draw=draw)
+        syn.WindowDecoder.window = spy
+        random.seed(4321 + seeds[name])                        # the seed of the fixture run (random.randrange for vid=None, :69-71)
+        try:
+            out = syn.generate_gestures(args, G, lang, c["audio"], c["words"], vid=c["vid_arg"], seed_seq=c["seed_seq"],
+                                        fade_out=c["fade_out"], _draws=draws)
+        finally:
+            syn.WindowDecoder.window = orig
+        assert len(fed) == n
+        for i, (pre, text, audio, vid) in enumerate(fed):
+            assert np.array_equal(text.numpy(), c["win_text"][i:i + 1]), (name, i)
+            check_window_audio(c, i, audio.numpy()[0])
+            assert float(np.abs(pre.numpy() - c["win_pre_seq"][i:i + 1]).max()) < 2e-5, (name, i)     # window i-1's output frames
+            assert (vid is None) == (zt != "speaker") and (vid is None or int(vid[0]) == c["vid_used"]), (name, vid)
+        assert out.shape == c["out"].shape and rel(out, c["out"]) < 1e-5, (name, out.shape, rel(out, c["out"]))
+        fades.add(c["fade_out"])
+    assert fades == {True, False}
+
+
+def test_autoencoder_eval_matches_reference_golden(pkg, dev):
+    """fgd.eval_embed / fgd.evaluate_testset == train_joint_embed.py:54-62 / train_feature_extractor.py:26-51 run by the reference
+    (g11 fixture), and evaluate_testset's gesture_autoencoder branch (train.py:270-271)."""
+    from importlib import import_module
+    fgd = import_module(pkg.__name__ + ".fgd")
+    em = import_module(pkg.__name__ + ".eval_metrics")
+    g = load("g11_ae_eval.npz")
+    AE = pkg.EmbeddingNet(make_args(), 27, 34).to(dev)
+    AE.load_state_dict(O.clone_state(O.make_autoencoder_state(int(g["ae_seed"]))), strict=True)
+    gen = torch.Generator().manual_seed(int(g["pose_seed"]))
+    batches = [0.1 * torch.randn(int(b), 34, 27, generator=gen) for b in g["sizes"]]
+    AE.train(False)
+    with torch.no_grad():
+        loss, recon = fgd.eval_embed(None, None, None, batches[0].to(dev), AE)
+    assert abs(float(loss) - float(g["eval_embed_loss"])) < 1e-5 * float(g["eval_embed_loss"]) and rel(recon, g["recon"]) < 1e-5
+    ret = fgd.evaluate_testset([(torch.zeros(b.shape[0], 34, 30), b) for b in batches], AE)
+    assert AE.training and abs(ret["loss"] - float(g["evaluate_testset_loss"])) < 1e-5 * float(g["evaluate_testset_loss"])
+    loader = [(torch.tensor([0]), torch.tensor([0]), torch.zeros(b.shape[0], 34, dtype=torch.int64), torch.zeros(b.shape[0], 34, 30), b,
+               torch.zeros(b.shape[0], 8), torch.zeros(b.shape[0], 1), {}) for b in batches]
+    ret2 = em.evaluate_testset(loader, AE, None, None, make_args(model="gesture_autoencoder"))
+    assert sorted(ret2) == ["joint_mae", "loss"] and ret2["joint_mae"] == 0
+    assert abs(ret2["loss"] - float(g["evaluate_testset_loss"])) < 1e-5 * float(g["evaluate_testset_loss"])
 
 
 def test_device_batch_feeder_drives_graphed_step(pkg, dev):

@@ -43,6 +43,22 @@ def unpack_masks(g, tags, p_tcn=0.3):
     return inj
 
 
+def test_eval_report_is_tight():
+    """golden_report_eval.json: oracle-vs-reference errors recorded while the g8-g11 fixtures were generated."""
+    with open(os.path.join(GOLDEN, "golden_report_eval.json")) as f:
+        rep = json.load(f)
+    for zt in ("speaker", "random", "none"):
+        r = rep["evaluate_testset_" + zt]
+        assert max(r["loss"], r["joint_mae"], r["accel"], r["out"]) < 2e-6 and max(r["frechet"], r["feat_dist"]) < 2e-5, r
+    assert rep["dir_vec_to_pose"] < 1e-7 and rep["pose_seq_to_dir_vec"] < 1e-12
+    cases = [k for k in rep if k.startswith("generate_gestures_")]
+    assert len(cases) == 9
+    for k in cases:
+        assert rep[k]["out"] < 2e-6 and rep[k]["pre_seq"] < 1e-6 and rep[k]["text_equal"] and rep[k]["audio_equal"], (k, rep[k])
+    assert all(all(v.values()) if isinstance(v, dict) else v for v in rep["dataset"].values())
+    assert max(rep["ae_eval"].values()) < 2e-6
+
+
 def test_report_is_tight():
     rep = json.load(open(os.path.join(GOLDEN, "golden_report.json")))
     assert rep["torch"] == torch.__version__
@@ -177,6 +193,104 @@ def test_g5_fgd_matches_reference():
     assert abs(fd8 - float(g["fgd8"])) <= 1e-6 * max(1.0, abs(float(g["fgd8"])))
     ret, _ = O.ae_train_iter(O.clone_state(ast), {}, real[:32])
     assert abs(ret["loss"] - float(g["train_loss"])) < 1e-5 * float(g["train_loss"])
+
+
+def test_g8_evaluate_testset_matches_reference():
+    """oracle evaluate_testset == scripts/train.py:evaluate_testset (:234-329) incl. FGD, for every z_type; bone integration."""
+    g = load("g8_evaluate_testset.npz")
+    V, S = int(g["n_words"]), int(g["n_speakers"])
+    ast = O.make_autoencoder_state(int(g["ae_seed"]))
+    sizes = [int(x) for x in g["sizes"]]
+    for zt in ("speaker", "random", "none"):
+        z_mode = zt if zt != "none" else None
+        gst = O.make_generator_state(int(g["g_seed"]), V, S, z_mode=z_mode)
+        batches = []
+        for i, b in enumerate(sizes):
+            text, audio, _, poses = O.make_batch(int(g["batch_seed0"]) + i, b, V, S)
+            batches.append((text, poses, audio))
+        offs = np.cumsum([0] + sizes)
+        inj, vids = {}, None
+        for i in range(len(sizes)):
+            if zt == "speaker":
+                inj[f"e{i}.eps"] = torch.from_numpy(g[f"{zt}/eps"][offs[i]:offs[i + 1]])
+            elif zt == "random":
+                inj[f"e{i}.z"] = torch.from_numpy(g[f"{zt}/z"][offs[i]:offs[i + 1]])
+        if zt == "speaker":
+            vids = [torch.from_numpy(g[f"{zt}/vids"][offs[i]:offs[i + 1]]) for i in range(len(sizes))]
+        ret, outs = O.evaluate_testset(O.clone_state(gst), batches, g["mean_dir_vec"], O.Rand(inject=inj), ast=O.clone_state(ast),
+                                       vids=vids, z_mode=z_mode)
+        want = dict(zip([str(k) for k in g[f"{zt}/ret_keys"]], g[f"{zt}/ret_vals"]))
+        assert sorted(want) == ["feat_dist", "frechet", "joint_mae", "loss"]          # the reference's return keys (:316-325)
+        for k, v in want.items():
+            assert abs(ret[k] - v) <= 2e-5 * abs(v), (zt, k, ret[k], v)
+        assert abs(ret["accel"] - float(g[f"{zt}/accel"])) <= 1e-6 * float(g[f"{zt}/accel"])
+        assert rel(torch.cat(outs), g[f"{zt}/out"]) < 2e-6
+    v = g["dir_vec/in"]
+    assert rel(O.dir_vec_to_pose(v), g["dir_vec/pose_b_t"]) < 1e-7 and rel(O.dir_vec_to_pose(v[0]), g["dir_vec/pose_t"]) < 1e-7
+    assert rel(O.dir_vec_to_pose(v[0, 0]), g["dir_vec/pose_single"]) < 1e-7
+    assert rel(O.pose_seq_to_dir_vec(g["dir_vec/pose_in"]), g["dir_vec/vec_from_pose"]) < 1e-12
+    assert rel(O.pose_seq_to_dir_vec(g["dir_vec/pose_in"][1]), g["dir_vec/vec_from_pose_t"]) < 1e-12
+
+
+def test_g9_generate_gestures_matches_reference():
+    """oracle generate_gestures == scripts/synthesize.py:generate_gestures (:36-209): window slicing, seed hand-over, cross-fade,
+    fade-out, speaker-id handling, for 1 / 2 / 3 / 4 windows and every z_type."""
+    from tests.harness import OracleLang, check_window_audio, synth_case
+    g = load("g9_generate_gestures.npz")
+    V, S = int(g["n_words"]), int(g["n_speakers"])
+    lang = OracleLang(V)
+    seen_fade = set()
+    for name in [str(c) for c in g["cases"]]:
+        c = synth_case(g, name)
+        z_mode = c["z_type"] if c["z_type"] != "none" else None
+        gst = O.make_generator_state(int(g["g_seed"]), V, S, z_mode=z_mode)
+        n = c["win_text"].shape[0]
+        key = "eps" if c["z_type"] == "speaker" else "z"
+        inj = {f"w{i}.{key}": torch.from_numpy(c["draws"][i:i + 1]) for i in range(c["draws"].shape[0])}
+        wins = []
+        out = O.generate_gestures(O.clone_state(gst), c["audio"], c["words"], lang.get_word_index, O.Rand(inject=inj), vid=c["vid_used"],
+                                  seed_seq=c["seed_seq"], fade_out=c["fade_out"], z_mode=z_mode, windows=wins)
+        assert out.shape == c["out"].shape and rel(out, c["out"]) < 5e-6, (name, out.shape, c["out"].shape)
+        assert len(wins) == n == O.num_windows(len(c["audio"]) / 16000)
+        for i, (pre, text, audio) in enumerate(wins):
+            assert np.array_equal(text.numpy(), c["win_text"][i:i + 1])
+            assert float(np.abs(pre.numpy() - c["win_pre_seq"][i:i + 1]).max()) < 1e-6
+            check_window_audio(c, i, audio.numpy()[0])
+        seen_fade.add(c["fade_out"])
+    assert seen_fade == {True, False}
+
+
+def test_g10_dataset_matches_reference():
+    """oracle data_getitem == SpeechMotionDataset.__getitem__ (lmdb_data_loader.py:107-171), bit for bit, both word-timing modes."""
+    from tests.harness import OracleLang, dataset_samples
+    g = load("g10_dataset.npz")
+    lang = OracleLang(int(g["vocab_size"]))
+    samples = dataset_samples(g)
+    for i, s in enumerate(samples):
+        for tag, rwt in (("timed", False), ("rwt", True)):
+            words, ext, pose, vec, audio, spec, aux = O.data_getitem(s, lang.get_word_index, remove_word_timing=rwt, full=True)
+            assert np.array_equal(words, g[f"{tag}{i}/words"]) and np.array_equal(ext, g[f"{tag}{i}/ext"]), (tag, i)
+        assert np.array_equal(pose, g[f"item{i}/pose"]) and np.array_equal(vec, g[f"item{i}/vec"])
+        assert audio.shape[0] == int(g[f"item{i}/audio_len"]) == 36267
+        assert np.array_equal(audio[:64], g[f"item{i}/audio_head"]) and np.array_equal(audio[-1500:], g[f"item{i}/audio_tail"])
+        assert abs(float(np.abs(audio.astype(np.float64)).sum()) - float(g[f"item{i}/audio_abs_sum"])) < 1e-9
+        assert list(spec.shape) == list(g[f"item{i}/spec_shape"])
+    a = g["fixlen/in"]
+    assert np.array_equal(O.data_make_audio_fixed_length(a, 1500), g["fixlen/longer"])
+    assert np.array_equal(O.data_make_audio_fixed_length(a, 700), g["fixlen/shorter"])
+    assert np.array_equal(O.data_make_audio_fixed_length(a, 1000), g["fixlen/same"])
+
+
+def test_g11_autoencoder_eval_matches_reference():
+    """oracle eval_embed / ae_evaluate_testset == train_joint_embed.py:54-62 / train_feature_extractor.py:26-51."""
+    g = load("g11_ae_eval.npz")
+    ast = O.make_autoencoder_state(int(g["ae_seed"]))
+    gen = torch.Generator().manual_seed(int(g["pose_seed"]))
+    batches = [0.1 * torch.randn(int(b), 34, 27, generator=gen) for b in g["sizes"]]
+    loss, recon = O.eval_embed(O.clone_state(ast), batches[0])
+    assert abs(loss - float(g["eval_embed_loss"])) < 1e-6 * float(g["eval_embed_loss"]) and rel(recon, g["recon"]) < 2e-6
+    ret = O.ae_evaluate_testset(O.clone_state(ast), batches)
+    assert abs(ret["loss"] - float(g["evaluate_testset_loss"])) < 1e-6 * float(g["evaluate_testset_loss"])
 
 
 def test_window_blend_and_count_hand_computed():
