@@ -144,7 +144,9 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_kernel(
                 for (int p = 0; p < GC_PF; ++p) {
                     const int k = 16 * (ks + GC_KS * p) + 4 * kq;          // < 320 = GC_HX always
                     const int off = off0 + ((b0 + i * 16 + r16) * GC_HX + k) * 4;
-                    a[i][p] = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off, 0, 16));   // aux 16 = sc1
+                    // columns >= 32 * CW are written by nobody (H <= 288): never feed scratch bit patterns (NaN * 0) to the MFMA
+                    const f32x4 ld = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off, 0, 16));   // aux 16 = sc1
+                    a[i][p] = (k < GC_UNITS * CW) ? ld : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
             for (int p = 0; p < GC_PF; ++p)
@@ -370,6 +372,21 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_kernel(
 
 using namespace tg;
 
+// Workgroups that can be co-resident at one per CU: the device's CU count (256 on a whole MI355X; fewer under CPX/DPX partitioning
+// or CU masking, where the cluster kernels must not be used: a member that can never become resident stalls its cluster until
+// the spin bound).  0 when no device is usable (the caller then falls back to the per-step launches).
+static int resident_cus() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 0; }
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        cached[dev] = n > 0 ? n : -1;
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
+}
+
 static void cluster_plan(int B, int H, int* mt, int* n_bt, int* cw) {
     *cw = cdiv(H, GC_UNITS);
     *mt = (2 * cdiv(B, 16) * *cw <= 256) ? 1 : 2;
@@ -380,7 +397,8 @@ extern "C" int32_t tg_gru_cluster_supported(int32_t B, int32_t H) {
     if (H > GC_HX || H % 4 != 0 || B <= 0) return 0;
     int mt, n_bt, cw;
     cluster_plan(B, H, &mt, &n_bt, &cw);
-    return 2 * n_bt * cw <= 256 && cw <= GC_FLAG_STRIDE;
+    const int cus = resident_cus();
+    return 2 * n_bt * cw <= (cus < 256 ? cus : 256) && cw <= GC_FLAG_STRIDE;
 }
 
 // workspace: [flag block: 2*n_bt clusters x 16 words + 16 words (timeout word first) ...] [exchange buffer 2 dirs x 2 slots]
@@ -405,10 +423,12 @@ extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, co
     cluster_plan(B, H, &mt, &n_bt, &cw);
     const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
     hipStream_t s = (hipStream_t)stream;
-    // every polled word is zeroed on the stream before every launch (a memset node under graph capture)
-    if (zero_async(ws, (size_t)flag_words * 4, s)) return 1;
+    // every polled word is zeroed on the stream before every launch (a kernel node under graph capture).  The first 16 words (the
+    // timeout marker and its diagnostics) are NOT touched here: they are sticky until the host reads and clears them
+    // (ops.check_async_errors), so a timeout in any launch that shares this workspace survives the launches after it.
     unsigned* tmo = (unsigned*)ws;
     unsigned* flags = tmo + GC_FLAG_STRIDE;
+    if (zero_async(flags, (size_t)(flag_words - GC_FLAG_STRIDE) * 4, s)) return 1;
     float* hx = (float*)(tmo + flag_words);
     const int b_pad = n_bt * 16 * mt;
     dim3 grid(2 * n_bt * cw);
@@ -431,7 +451,8 @@ extern "C" int32_t tg_gru_cluster_bwd_supported(int32_t B, int32_t H) {
     if (H > GC_HX || H % 4 != 0 || B <= 0) return 0;
     int n_bt, cw;
     cluster_plan_bwd(B, H, &n_bt, &cw);
-    return 2 * n_bt * cw <= 256 && cw <= GC_FLAG_STRIDE;
+    const int cus = resident_cus();
+    return 2 * n_bt * cw <= (cus < 256 ? cus : 256) && cw <= GC_FLAG_STRIDE;
 }
 
 extern "C" int64_t tg_gru_cluster_bwd_ws_bytes(int32_t B, int32_t H) {
@@ -454,9 +475,9 @@ extern "C" int tg_gru_backward_cluster(const float* dy, const float* y, const fl
     cluster_plan_bwd(B, H, &n_bt, &cw);
     const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
     hipStream_t s = (hipStream_t)stream;
-    if (zero_async(ws, (size_t)flag_words * 4, s)) return 1;
-    unsigned* tmo = (unsigned*)ws;
+    unsigned* tmo = (unsigned*)ws;              // sticky timeout block: cleared by the host only (see the forward entry point)
     unsigned* flags = tmo + GC_FLAG_STRIDE;
+    if (zero_async(flags, (size_t)(flag_words - GC_FLAG_STRIDE) * 4, s)) return 1;
     float* gx = (float*)(tmo + flag_words);
     hipLaunchKernelGGL(gru_seq_bwd_cluster_kernel<1>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, y, save, (long)save_dir_stride, w_hh_t_fwd,
                        w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, gx, flags, tmo, B, T, H, n_bt, cw, n_bt * 16);

@@ -43,20 +43,21 @@ class GradSync:
     def bucket_range(slab, prefixes):
         """Contiguous [start, end) of the slab covered by the parameters under the given top-level names."""
         lo, hi = None, None
-        for name, p, off in zip(slab.names, slab.params, slab.offsets):
+        live = [(n, p, o) for n, p, o in zip(slab.names, slab.params, slab.offsets) if n not in slab.frozen]   # frozen: no gradient
+        for name, p, off in live:
             if name.split(".", 1)[0] in prefixes:
                 lo = off if lo is None else min(lo, off)
                 hi = off + p.numel() if hi is None else max(hi, off + p.numel())
         assert lo is not None, prefixes
-        for name, p, off in zip(slab.names, slab.params, slab.offsets):       # the range must not swallow other groups
+        for name, p, off in live:                                             # the range must not swallow other groups
             assert not (lo <= off < hi) or name.split(".", 1)[0] in prefixes, (name, prefixes)
         return lo, hi
 
     # ---- actions issued by the trainer at its synchronisation points
     def run(self, action):
         kind = action[0]
-        if kind == "all":                      # whole slab, finished before returning control to the optimiser
-            self._launch(action[1].grad)
+        if kind == "all":                      # whole (trainable) slab, finished before returning control to the optimiser
+            self._launch(action[1].grad[:action[1].n_train])
             self.wait()
         elif kind == "bucket":                 # one backward-order bucket, left in flight
             lo, hi = self.bucket_range(action[1], action[2])

@@ -293,7 +293,8 @@ class GeneratorEngine(_Engine):
                 dcur = dh
             em = tp["emb_mask"]
             demb = ops.mul(dcur, em[rows].reshape(M, -1), torch.empty_like(dcur)) if em is not None else dcur
-            ops.embed_scatter_add(demb, tp["in_text"][rows].contiguous().view(-1), G[f"{te}.embedding.weight"])
+            if f"{te}.embedding.weight" not in self.slab.frozen:           # freeze_wordembed (:40-41): no gradient, never stepped
+                ops.embed_scatter_add(demb, tp["in_text"][rows].contiguous().view(-1), G[f"{te}.embedding.weight"])
         fork.join()        # the GRU weight gradients ran beside the recurrences and the text-encoder backward
         ready(("out", "gru"))
         ready(("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder"))

@@ -189,11 +189,12 @@ def _gru_cluster_ws(dev, B, H, bwd=False):
 
 
 def check_async_errors():
-    """Raise if a bounded spin of a persistent kernel timed out since the last check (synchronises; tests, bench, loss read-out)."""
+    """Raise if a bounded spin of a persistent kernel timed out since the last check (synchronises; tests, bench, loss read-out,
+    every CHECK_EVERY replays of a captured step).  The timeout word is sticky on the device: only this function clears it."""
     for key, ws in _gru_ws.items():
         if int(ws[0].item()) != 0:
             info = ws[:14].tolist()
-            ws[0] = 0
+            ws[:16] = 0
             raise RuntimeError(f"persistent GRU kernel timed out waiting for a cluster member (device, B, H, bwd) = {key}: step {info[1]}, "
                                f"workgroup {info[2]}, flag words seen {info[4:14]}; results are invalid")
 

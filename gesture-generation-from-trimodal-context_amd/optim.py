@@ -22,8 +22,9 @@ class FusedAdam:
 
     def step(self):
         s = self.slab
+        n = s.n_train                                  # frozen parameters sit behind the trainable prefix and are never stepped
         ops.counter_inc(s.step)
-        ops.adam_step(s.flat, s.grad, s.m, s.v, self.lr, self.betas[0], self.betas[1], self.eps, s.step)
+        ops.adam_step(s.flat[:n], s.grad[:n], s.m[:n], s.v[:n], self.lr, self.betas[0], self.betas[1], self.eps, s.step)
 
     def state_dict(self):
         s = self.slab

@@ -19,17 +19,26 @@ class ParamSlab:
         self.module = module
         self.names, self.params = [], []
         seen = set()
+        named = []
         for name, p in module.named_parameters():      # named_parameters() already de-duplicates shared tensors
             if id(p) in seen:
                 continue
             seen.add(id(p))
-            self.names.append(name)
-            self.params.append(p)
+            named.append((name, p))
+        # frozen parameters (requires_grad=False, e.g. freeze_wordembed: multimodal_context_net.py:40-41) go to the END of the slab:
+        # the optimiser and the gradient exchange work on the trainable prefix [0, n_train) only, like optim.Adam(parameters())
+        # which skips parameters without a gradient
+        named.sort(key=lambda np_: not np_[1].requires_grad)          # stable: module order within each class
+        self.names, self.params = [n for n, _ in named], [p for _, p in named]
         self.offsets, off = [], 0
+        self.n_train = 0
         for p in self.params:
             self.offsets.append(off)
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            if p.requires_grad:
+                self.n_train = off
         self.numel = off
+        self.frozen = {n for n, p in named if not p.requires_grad}
         self.flat = self.grad = self.m = self.v = None
         self.step = None
         self._ptr = None
@@ -46,7 +55,7 @@ class ParamSlab:
                 view = flat[off:off + p.numel()].view(p.shape)
                 view.copy_(p.detach().to(torch.float32))
                 p.data = view
-                p.grad = grad[off:off + p.numel()].view(p.shape)
+                p.grad = grad[off:off + p.numel()].view(p.shape) if p.requires_grad else None
         self.flat, self.grad = flat, grad
         self.m = torch.zeros_like(flat) if old_m is None else old_m.to(dev)
         self.v = torch.zeros_like(flat) if old_v is None else old_v.to(dev)
@@ -57,7 +66,7 @@ class ParamSlab:
         """Module.to()/cuda() replaces .data and breaks the views: detect and rebuild."""
         p0 = self.params[0]
         if p0.data_ptr() != self._ptr or p0.device != self.flat.device or any(
-                p.grad is None or p.grad.device != self.flat.device for p in self.params[:2]):
+                p.requires_grad and (p.grad is None or p.grad.device != self.flat.device) for p in self.params[:2]):
             self.rebuild()
         return self
 
@@ -70,4 +79,5 @@ class ParamSlab:
         return P, G
 
     def zero_grad(self):
-        ops.zero_(self.grad)
+        if self.n_train:
+            ops.zero_(self.grad[:self.n_train])

@@ -231,7 +231,12 @@ class GraphedGanStep:
             self.segments.append((state["g"], None))
         torch.cuda.current_stream().wait_stream(cap)
 
+    CHECK_EVERY = 64      # replays between two reads of the persistent kernels' sticky timeout word (one host sync each)
+
     def __call__(self, in_text=None, in_audio=None, target=None, vid=None):
+        self._n_replays = getattr(self, "_n_replays", 0) + 1
+        if self._n_replays % self.CHECK_EVERY == 0:
+            ops.check_async_errors()       # a timed-out recurrence must not train on garbage until somebody reads the losses
         for dst, src in zip(self.static, (in_text, in_audio, target, vid)):
             if src is not None and src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)

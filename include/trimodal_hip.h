@@ -112,9 +112,12 @@ int tg_gru_backward(const float* dy, const float* y, const float* save, int64_t 
 /* Persistent, cluster-synchronised variant of tg_gru_forward for H <= 320 (the generator): ONE launch walks all T
  * steps of both directions; the workgroups that share a batch tile exchange h_t through `ws` with write-through stores and
  * per-workgroup flag words, no grid-wide barrier (csrc/gru_cluster.hip).  Same arguments and results as tg_gru_forward.
- * ws: tg_gru_cluster_ws_bytes(B, H) bytes of device scratch, 16-byte aligned; its first word is a sticky TIMEOUT marker the
- * kernel sets if a bounded spin expires (results are then invalid): the call zeroes it, read it back after synchronising.
- * tg_gru_cluster_supported(B, H) != 0 iff the launch fits co-resident on the 256 CUs (B <= 384 at H = 300). */
+ * ws: tg_gru_cluster_ws_bytes(B, H) bytes of device memory, 16-byte aligned, ZERO-FILLED ONCE by the caller when allocated.  Its
+ * first 16 words are a sticky TIMEOUT block: word 0 is set by the kernel if a bounded spin expires (results are then invalid),
+ * words 1.. hold diagnostics.  No launch ever clears them -- a timeout in any launch sharing the workspace stays visible until
+ * the caller reads word 0 back (after synchronising) and clears it itself.
+ * tg_gru_cluster_supported(B, H) != 0 iff the launch fits co-resident at one workgroup per CU on the current device (its CU
+ * count is queried: B <= 384 at H = 300 on the 256 CUs of an unpartitioned MI355X; 0 under CPX/DPX partitions that are too small). */
 int32_t tg_gru_cluster_supported(int32_t B, int32_t H);
 int64_t tg_gru_cluster_ws_bytes(int32_t B, int32_t H);
 int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,

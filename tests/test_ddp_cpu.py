@@ -110,3 +110,25 @@ def test_trainer_routes_sync_points(pkg, monkeypatch):
     assert cuts == [("bucket", "slab", ("out", "gru"))] and tr.grad_sync.seen == ["all", "bucket", "wait"]
     tr.grad_sync = None
     tr._sync("wait")            # single GPU: no-op
+
+
+def test_frozen_word_embedding_leaves_optimiser_and_buckets(pkg):
+    """args.freeze_wordembed=True (multimodal_context_net.py:40-41): the embedding has requires_grad=False, so the reference's
+    optim.Adam(generator.parameters()) never steps it.  Here it sits behind the trainable prefix of the slab: outside the Adam range,
+    outside every gradient bucket, no .grad."""
+    import numpy as np
+    from tests.harness import make_args
+    ddp = importlib.import_module(pkg.__name__ + ".ddp")
+    emb = np.random.RandomState(0).randn(40, 300).astype(np.float32)
+    for freeze in (False, True):
+        G = pkg.PoseGenerator(make_args(freeze_wordembed=freeze), 27, 40, 300, emb, pkg.Vocab.speakers(5))
+        slab = G.engine.slab
+        name = "text_encoder.embedding.weight"
+        if not freeze:
+            assert not slab.frozen and slab.n_train == slab.numel
+            continue
+        assert slab.frozen == {name} and slab.names[-1] == name and slab.n_train == slab.offsets[-1] == slab.numel - 40 * 300
+        assert G.text_encoder.embedding.weight.grad is None and G.gru.weight_hh_l0.grad is not None
+        lo, hi = ddp.GradSync.bucket_range(slab, ("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder"))
+        assert hi <= slab.n_train                                  # the 48 KB word table is not exchanged
+        assert sorted(G.state_dict()) == sorted(pkg.PoseGenerator(make_args(), 27, 40, 300, emb, pkg.Vocab.speakers(5)).state_dict())

@@ -596,3 +596,48 @@ def test_ragged_batch_synthesis(pkg, dev):
     for a, b, c in zip(*outs):
         assert np.array_equal(a, b)                                   # reproducible
         assert np.abs(a - c).max() <= 1e-5 * max(1.0, np.abs(c).max())   # replayed graph == eager launches
+
+
+def test_freeze_wordembed_keeps_the_embedding_fixed(pkg, dev):
+    """args.freeze_wordembed=True (multimodal_context_net.py:40-41, train.py:104: optim.Adam(generator.parameters()) skips parameters
+    without gradient): the word table must stay bit-identical through a GAN iteration and every other parameter must move exactly as in
+    the unfrozen run with the same draws."""
+    V, S, B = 64, 9, 4
+    gst, dst = O.make_generator_state(7, V, S), O.make_discriminator_state(8)
+    text, audio, vid, poses = (t.to(dev) for t in O.make_batch(11, B, V, S))
+    emb = gst["text_encoder.embedding.weight"].numpy()
+    after = {}
+    for freeze in (False, True):
+        args = make_args(freeze_wordembed=freeze)
+        G = pkg.PoseGenerator(args, 27, V, 300, emb, pkg.Vocab.speakers(S))
+        D = pkg.ConvDiscriminator(27)
+        G.load_state_dict(O.clone_state(gst, torch.float32), strict=True)
+        D.load_state_dict(O.clone_state(dst, torch.float32), strict=True)
+        G, D = G.to(dev), D.to(dev)
+        assert G.text_encoder.embedding.weight.requires_grad == (not freeze)
+        tr = pkg.GanTrainer(G, D, args)
+        tr.G.rng.state[0] = 5; tr.D.rng.state[0] = 6            # same device RNG seeds in both runs: identical dropout / eps draws
+        tr.train_iter(11, text, audio, poses, vid).to_dict()
+        after[freeze] = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    k_emb = "text_encoder.embedding.weight"
+    assert torch.equal(after[True][k_emb], gst[k_emb]) and not torch.equal(after[False][k_emb], gst[k_emb])
+    for k, v in after[False].items():
+        if k != k_emb and v.is_floating_point():
+            assert rel(after[True][k], v) < 2e-5, k                # float atomics in the weight gradients: not bitwise
+
+
+def test_persistent_kernel_timeout_word_is_sticky(pkg, dev):
+    """A timeout marker raised by ANY launch that shares a cluster workspace must survive the later launches of the iteration (4 GRU
+    layers use the same workspace) until the host reads it: to_dict() raises, and clears it."""
+    V, S, B = 64, 9, 8
+    args, G, D = build_models(pkg, dev, O.make_generator_state(7, V, S), O.make_discriminator_state(8), V, S)
+    text, audio, vid, poses = (t.to(dev) for t in O.make_batch(11, B, V, S))
+    tr = pkg.GanTrainer(G, D, args)
+    tr.train_iter(11, text, audio, poses, vid).to_dict()           # creates the workspaces
+    ws = [w for key, w in pkg.ops._gru_ws.items() if key[0] == dev or str(key[0]) == str(dev)]
+    assert ws, "the cluster kernels did not run"
+    ws[0][0] = 1                                                   # what a timed-out workgroup of the first layer stores
+    losses = tr.train_iter(11, text, audio, poses, vid)            # 4 forward + 4 backward launches on the same workspaces follow
+    with pytest.raises(RuntimeError, match="timed out"):
+        losses.to_dict()
+    tr.train_iter(11, text, audio, poses, vid).to_dict()           # cleared by the host read: the next iteration is clean
