@@ -29,10 +29,8 @@ PEAK_F32_MFMA = 157.3e12          # /opt/skills/guides/MI355X_MICROARCH.md, "Pea
 
 
 def make_args():
-    return argparse.Namespace(n_pre_poses=4, n_poses=34, input_context="both", hidden_size=300, n_layers=4, dropout_prob=0.3,
-                              freeze_wordembed=False, z_type="speaker", loss_warmup=10, loss_gan_weight=5.0,
-                              loss_regression_weight=500.0, loss_kld_weight=0.1, loss_reg_weight=0.05, learning_rate=0.0005,
-                              discriminator_lr_weight=0.2, wordembed_dim=300)
+    """config/multimodal_context.yml through the package's parse_args mirror (hidden 300, 4 layers, z_type speaker, batch 128 ...)."""
+    return importlib.import_module(PKG + ".config").load_config("multimodal_context")
 
 
 def synthetic_batch(batch, seed, device):

@@ -35,11 +35,7 @@ def main():
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    # config/multimodal_context.yml
-    args = argparse.Namespace(model="multimodal_context", name="synthetic", n_pre_poses=4, n_poses=34, input_context="both", hidden_size=300,
-                              n_layers=4, dropout_prob=0.3, freeze_wordembed=False, z_type="speaker", loss_warmup=10, loss_gan_weight=5.0,
-                              loss_regression_weight=500.0, loss_kld_weight=0.1, loss_reg_weight=0.05, learning_rate=0.0005,
-                              discriminator_lr_weight=0.2, wordembed_dim=300, motion_resampling_framerate=15, pose_dim=27)
+    args = importlib.import_module(hip.__name__ + ".config").load_config("multimodal_context", name="synthetic", pose_dim=27)
     lang = hip.Vocab("words")
     for i in range(a.n_words - 4):
         lang.index_word(f"w{i}")

@@ -88,8 +88,6 @@ def load():
     lib.tg_last_error.restype = C.c_char_p
     lib.tg_gemm_tn_ws_floats.restype = C.c_int64
     lib.tg_gemm_tn_ws_floats.argtypes = [I32, I32, I32]
-    lib.tg_gemm_tn_bf16_ws_bytes.restype = C.c_int64
-    lib.tg_gemm_tn_bf16_ws_bytes.argtypes = [I32, I32, I32]
     lib.tg_set_math_mode.restype = C.c_int
     lib.tg_set_math_mode.argtypes = [I32]
     lib.tg_get_math_mode.restype = C.c_int

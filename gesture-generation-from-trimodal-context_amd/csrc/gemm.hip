@@ -10,6 +10,8 @@
 //
 // tg_gemm_tn (weight gradients): the reduction runs over ROWS, so MFMA fragments are column-strided; tiles of 16 rows
 // are staged through LDS with coalesced 16-byte loads, double-buffered, one barrier per tile.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace tg {
@@ -162,8 +164,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Win A, const float* __rest
 // slabs instead of 8-12) and measured within +-8 % of BK = 16 under graph replay (tools/nt_small_probe.py), so only 16 is used.
 // The tile is chosen per shape by nt_pick_tile(): the f32 pipe sustains ~100 TFLOP/s on real data whatever the tile
 // (tools/gemm_lab.hip), so what matters is tile quantisation and filling 256 CUs x 3 workgroups.
-constexpr int BG_LD = 20;
-
 template <int TM, int TN, int BK = 16>
 __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __restrict__ Bw, long ldb,
                                                           const float* __restrict__ bias, float* __restrict__ C, long cbs,
@@ -509,12 +509,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 
 using namespace tg;
 
-// bf16-operand tier (gemm_bf16.hip), selected by tg_set_math_mode(1)
+// bf16 matrix-core path of the big products (gemm_split.hip): three-way operand split at fp32 accuracy (math mode 0, default) or
+// plain bf16 operands (math mode 1).  TG_GEMM_X3=0 in the environment keeps math mode 0 on the f32-MFMA kernels below.
 extern "C" int tg_get_math_mode(void);
-int tg_gemm_nt_bf16_launch(const Win& w, const float* Bw, long ldb, const float* bias, float* C, long cbs, long crs, int cR, int M,
-                           int N, float slope, int accumulate, hipStream_t s);
-int tg_gemm_tn_bf16_launch(const float* dY, long ldy, const Win& w, float* dW, long ldw, int M, int N, int out_kw, float* dbias,
-                           void* ws, int64_t ws_bytes, hipStream_t s);
+int tg_gemm_nt_split_launch(const Win& w, const float* Bw, long ldb, const float* bias, float* C, long cbs, long crs, int cR, int M,
+                            int N, float slope, int accumulate, hipStream_t s);
+static bool use_split_path() {
+    static int x3 = -1;
+    if (x3 < 0) {
+        const char* e = getenv("TG_GEMM_X3");
+        x3 = (e && e[0] == '0') ? 0 : 1;
+    }
+    return x3 == 1 || tg_get_math_mode() == 1;
+}
 
 static int check_window(const tg_window* w, const char* who) {
     TG_REQUIRE(w && w->ptr, "%s: null window", who);
@@ -533,9 +540,9 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
     const bool vec = (w.cw % 4 == 0) && (w.K % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr) &&
                      (ldb % 4 == 0) && aligned16(Bw);
     hipStream_t s = (hipStream_t)stream;
-    if (tg_get_math_mode() >= 1 && vec && M >= 256 && N >= 32 && w.K >= 32)
-        return tg_gemm_nt_bf16_launch(w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope,
-                                      accumulate, s);
+    if (vec && N >= 48 && M >= 1024 && w.K >= 64 && use_split_path())
+        return tg_gemm_nt_split_launch(w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope,
+                                       accumulate, s);
     if (vec && N >= 48 && M >= 1024 && w.K >= 64) {
         const NtTile tl = nt_pick_tile(M, N);
         const int n_nt = cdiv(N, 32 * tl.tn);
@@ -596,8 +603,6 @@ extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, floa
     TG_REQUIRE(dY && dW && M > 0 && N > 0 && ldy >= N && ldw >= A->K, "tg_gemm_tn: bad arguments");
     TG_REQUIRE(out_kw == 0 || out_kw * A->cw == A->K, "tg_gemm_tn: out_kw=%d must be 0 or K/cw", out_kw);
     Win w = to_win(A);
-    if (tg_get_math_mode() == 2 && ws != nullptr)      // math mode 2: ws is the byte workspace of tg_gemm_tn_bf16_ws_bytes()
-        return tg_gemm_tn_bf16_launch(dY, (long)ldy, w, dW, (long)ldw, M, N, out_kw, dbias, ws, ws_floats * 4, (hipStream_t)stream);
     int splits, rows_per_split;
     tn_plan(M, N, w.K, ws != nullptr, &splits, &rows_per_split);
     TG_REQUIRE(ws == nullptr || ws_floats >= (int64_t)splits * N * w.K, "tg_gemm_tn: workspace too small (%ld < %ld floats)",

@@ -1,0 +1,247 @@
+// tg_gemm_nt on the bf16 matrix cores at fp32 accuracy: operand splitting ("bf16 x 3").
+//
+// gfx950 has no TF32-style fast path for fp32 GEMMs: v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate, 1/16 of the bf16 MFMA
+// rate.  Here every fp32 operand x is split EXACTLY into three bf16 terms while its 32-deep K slab is staged into LDS,
+//     x = hi + mid + lo        hi = top 8 significand bits of x (truncation), mid = top 8 bits of x - hi, lo = the rest (<= 8 bits),
+// and the product keeps the six partial products whose weight is >= 2^-16 of the leading one,
+//     a.b ~= hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi            (dropped: mid.lo, lo.mid, lo.lo <= 2^-23 |a.b|),
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  Six bf16 MFMAs replace sixteen f32-MFMA
+// issue slots of the same tile (2.67x the matrix rate); measured error vs fp64 is the f32 MFMA path's (max 6e-7 of max|C| at
+// K = 600, tools/gemm_split_lab.hip) -- the only roundings are fp32 accumulations, as there.  Measured 1.15-1.85x faster than the
+// f32-MFMA kernel on the shapes of the training step (the VALU split work and the LDS traffic of three planes eat the rest).
+//
+// SPLITS = 1 is the plain bf16-operand tier (math mode 1): operands rounded to nearest even, one MFMA per product, fp32 accumulate.
+//
+// Workgroup tile (32*TM) x (32*TN), 4 waves as 2 x 2, wave tile (16*TM) x (16*TN) of 16x16x32 MFMAs.  LDS rows hold 32 bf16
+// (64 B) padded to 80 B so a lane's fragment -- A[row l&15][k = 8*(l>>4) .. +7] -- is one conflict-light 16-byte ds_read.  The
+// next slab's global loads are in flight (registers) while the current slab is split, stored and multiplied.  DB = 0 keeps ONE
+// LDS buffer (two barriers per slab, <= 54 KB: two workgroups per CU, the better choice when the grid has >= 2 workgroups per
+// CU); DB = 1 double-buffers (one barrier per slab, one workgroup per CU: better for the small grids of the backward shapes).
+#include "common.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace tg {
+
+constexpr int SP_LD = 40;     // bf16 elements per LDS row (32 + 8 pad)
+
+// upper halves of two fp32 words -> one dword holding two bf16 (first element in the low half)
+__device__ __forceinline__ unsigned pack_hi16(unsigned first, unsigned second) { return __builtin_amdgcn_perm(second, first, 0x07060302u); }
+
+template <int SPLITS>
+__device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
+    if constexpr (SPLITS == 1) {          // plain bf16 tier: round to nearest even (v_cvt_pk_bf16_f32)
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 r;
+        r[0] = (__bf16)v[0]; r[1] = (__bf16)v[1]; r[2] = (__bf16)v[2]; r[3] = (__bf16)v[3];
+        out[0] = __builtin_bit_cast(u32x2, r);
+    } else {
+        static_assert(SPLITS == 3, "1 or 3 terms");
+        unsigned t[4], u[4], s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // (__builtin_bit_cast(unsigned, v[i]) on an ext_vector ELEMENT is miscompiled by hipcc 7.2 -- every i reads element 0:
+            // copy the element to a scalar first)
+            const float xf = v[i];
+            t[i] = __float_as_uint(xf) & 0xffff0000u;                 // hi: exact prefix of the significand
+            const float r = xf - __uint_as_float(t[i]);               // exact
+            u[i] = __float_as_uint(r) & 0xffff0000u;                  // mid
+            s[i] = __float_as_uint(r - __uint_as_float(u[i]));        // lo: <= 8 significant bits left, exact in bf16
+        }
+        out[0] = u32x2{pack_hi16(t[0], t[1]), pack_hi16(t[2], t[3])};
+        out[1] = u32x2{pack_hi16(u[0], u[1]), pack_hi16(u[2], u[3])};
+        out[2] = u32x2{pack_hi16(s[0], s[1]), pack_hi16(s[2], s[3])};
+    }
+}
+
+// C(m, n) = act(sum_k A(m,k) * Bw[n][k] + bias[n]) (+ C).  A: fp32 row window (vectorisable layout: checked by the caller),
+// Bw: fp32 [N][ldb].  Same contract as gemm_nt_big_kernel (gemm.hip).
+template <int TM, int TN, int SPLITS, int DB>
+__global__ __launch_bounds__(256) void gemm_nt_split_kernel(Win A, const float* __restrict__ Bw, long ldb,
+                                                            const float* __restrict__ bias, float* __restrict__ C, long cbs,
+                                                            long crs, int cR, int M, int N, float slope, int accumulate, int n_nt) {
+    constexpr int BM = 32 * TM, BN = 32 * TN;
+    constexpr int NPA = BM / 32, NPB = BN / 32;               // f32x4 pieces per thread per slab (8 pieces per 32-deep row)
+    constexpr int NS = SPLITS;
+    constexpr int NB = DB ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NB][NS][BM + BN][SP_LD];      // ONE array (A rows first, then B rows)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int m0 = (lid / n_nt) * BM, n0 = (lid % n_nt) * BN;
+    const int K = A.K;
+
+    // staging map: 8 consecutive lanes cover one 128-byte row piece of the slab (32 fp32): whole cache lines per load instruction;
+    // thread t owns piece (t & 7) of rows (t >> 3) + 32 q
+    const int sp = 4 * (t & 7), sr0 = t >> 3;
+    long a_off[NPA];
+    int a_r[NPA];
+    bool a_ok[NPA];
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) {
+        const int m = m0 + sr0 + 32 * q;
+        a_ok[q] = m < M;
+        const int mm = a_ok[q] ? m : 0;
+        const int b = mm / A.rows_out;
+        a_off[q] = (long)b * A.bs;
+        a_r[q] = (mm - b * A.rows_out) * A.step + A.shift;
+    }
+    const float* b_ptr[NPB];
+    bool b_ok[NPB];
+#pragma unroll
+    for (int q = 0; q < NPB; ++q) {
+        const int n = n0 + sr0 + 32 * q;
+        b_ok[q] = n < N;
+        b_ptr[q] = Bw + (long)(b_ok[q] ? n : 0) * ldb;
+    }
+    int kk = sp / A.cw, c = sp - (sp / A.cw) * A.cw;          // tap / channel of this thread's piece, advanced by 32 per slab
+
+    f32x4 ga[NPA], gb[NPB];
+    auto fetch = [&](int k0) {
+        // loads are issued UNCONDITIONALLY from an always-valid address and zeroed afterwards: a predicated load makes the number
+        // of outstanding loads dynamic and hipcc then drains everything (vmcnt(0)) at the next use
+        const int k = k0 + sp;
+        const bool inb = k < K;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) {
+            const int sr = a_r[q] + kk * A.dil;
+            const bool ok = a_ok[q] && inb && sr >= 0 && sr < A.rows_in;
+            const float* src = ok ? A.ptr + a_off[q] + (long)sr * A.rs + c : A.ptr;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+            ga[q] = ok ? v : z;
+        }
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) {
+            const bool ok = b_ok[q] && inb;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? b_ptr[q] + k : Bw);
+            gb[q] = ok ? v : z;
+        }
+        c += 32;
+        while (c >= A.cw) { c -= A.cw; ++kk; }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        if (!DB && k0 > 0) __syncthreads();                     // single buffer: everybody has read the previous slab
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) {
+            u32x2 o[NS];
+            split4<SPLITS>(ga[q], o);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][sr0 + 32 * q][sp]) = o[s];
+        }
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) {
+            u32x2 o[NS];
+            split4<SPLITS>(gb[q], o);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][BM + sr0 + 32 * q][sp]) = o[s];
+        }
+        __syncthreads();
+        if (k0 + 32 < K) fetch(k0 + 32);
+        bf16x8 fa[NS][TM], fb[NS][TN];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(&lds[buf][s][wm * (16 * TM) + i * 16 + r16][8 * kq]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(&lds[buf][s][BM + wn * (16 * TN) + j * 16 + r16][8 * kq]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 cc = acc[i][j];
+                if constexpr (SPLITS == 3) {           // smallest terms first
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][i], fb[0][j], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[2][j], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[0][j], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[1][j], cc, 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], cc, 0, 0, 0);
+            }
+        if (DB) buf ^= 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = m0 + wm * (16 * TM) + i * 16 + kq * 4 + q;
+            if (row >= M) continue;
+            const int cb = row / cR;
+            const int cr = row - cb * cR;
+            float* crow = C + (long)cb * cbs + (long)cr * crs;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (16 * TN) + j * 16 + r16;
+                if (col >= N) continue;
+                float v = acc[i][j][q];
+                if (bias) v += bias[col];
+                v = act_fn(v, slope);
+                if (accumulate) v += crow[col];
+                crow[col] = v;
+            }
+        }
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+static int g_math_mode = 0;
+
+extern "C" int tg_set_math_mode(int32_t mode) {
+    TG_REQUIRE(mode == 0 || mode == 1, "tg_set_math_mode: mode must be 0 (fp32-accurate) or 1 (bf16 operands)");
+    g_math_mode = mode;
+    return 0;
+}
+
+extern "C" int tg_get_math_mode(void) { return g_math_mode; }
+
+// Tile menu (tools/gemm_split_lab.hip on the shapes of the training step).  Single-buffered tiles run two workgroups per CU and win
+// when the grid has at least ~2 workgroups per CU; the double-buffered ones win on the small grids of the backward shapes.
+struct SplitTile { int tm, tn, db; };
+static SplitTile split_pick_tile(int M, int N) {
+    auto wgs = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(N, bn); };
+    auto waste = [&](int bn) { return cdiv(N, bn) * bn - N; };
+    if (wgs(128, 96) >= 512 && waste(96) <= waste(64) + 32) return {4, 3, 0};
+    if (wgs(128, 64) >= 384) return {4, 2, 0};
+    if (wgs(128, 96) >= 160 && waste(96) <= waste(64) + 32) return {4, 3, 1};
+    if (wgs(128, 64) >= 160) return {4, 2, 1};
+    return {2, 2, 1};
+}
+
+int tg_gemm_nt_split_launch(const Win& w, const float* Bw, long ldb, const float* bias, float* C, long cbs, long crs, int cR, int M,
+                            int N, float slope, int accumulate, hipStream_t s) {
+    const SplitTile tl = split_pick_tile(M, N);
+    const int n_nt = cdiv(N, 32 * tl.tn);
+    const dim3 grid(cdiv(M, 32 * tl.tm) * n_nt);
+#define TG_SPLIT(TM_, TN_, SP_, DB_) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_>), grid, dim3(256), 0, s, w, Bw, ldb, bias, C, \
+                                                        cbs, crs, cR, M, N, slope, accumulate, n_nt)
+#define TG_SPLIT_MENU(SP_)                                              \
+    do {                                                                \
+        if (tl.tm == 4 && tl.tn == 3 && !tl.db) TG_SPLIT(4, 3, SP_, 0); \
+        else if (tl.tm == 4 && tl.tn == 3) TG_SPLIT(4, 3, SP_, 1);      \
+        else if (tl.tm == 4 && tl.tn == 2 && !tl.db) TG_SPLIT(4, 2, SP_, 0); \
+        else if (tl.tm == 4 && tl.tn == 2) TG_SPLIT(4, 2, SP_, 1);      \
+        else TG_SPLIT(2, 2, SP_, 1);                                    \
+    } while (0)
+    if (g_math_mode == 1) TG_SPLIT_MENU(1);
+    else TG_SPLIT_MENU(3);
+#undef TG_SPLIT_MENU
+#undef TG_SPLIT
+    return check_launch("tg_gemm_nt(split)");
+}

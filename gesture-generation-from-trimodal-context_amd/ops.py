@@ -121,18 +121,16 @@ def zeros_like(t):
 
 
 def set_math_mode(mode):
-    """'f32' (exact fp32 matrix cores, default) or 'bf16' (bf16 operands, fp32 accumulate) for the GEMM-shaped kernels."""
-    m = {"f32": 0, "fp32": 0, 0: 0, "bf16": 1, 1: 1, "bf16_all": 2, 2: 2}[mode]
+    """'f32' (fp32-accurate, default) or 'bf16' (bf16 operands, fp32 accumulate) for the big forward / input-gradient GEMMs."""
+    m = {"f32": 0, "fp32": 0, 0: 0, "bf16": 1, 1: 1}[mode]
     if _lib.load().tg_set_math_mode(m) != 0:
         raise RuntimeError(_lib.load().tg_last_error().decode())
 
 
 def get_math_mode():
-    return ("f32", "bf16", "bf16_all")[_lib.load().tg_get_math_mode()]
+    return ("f32", "bf16")[_lib.load().tg_get_math_mode()]
 
 
-# Math mode "bf16" leaves the weight gradients on the fp32 path: the transposing bf16 variant ("bf16_all") is slower at the
-# shapes of this model (tools/gemm_probe.py) and fp32 weight gradients keep the optimiser input exact.
 TN_TWO_PASS_ROWS = 32768     # reductions at least this long combine their partials in fp64 (deterministic) instead of atomics
 
 
@@ -148,10 +146,7 @@ def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
     if (M - 1) * dY.stride(0) + N - 1 >= _room(dY):
         raise ValueError("gemm_tn: dY exceeds its tensor")
     ws, nws = None, 0
-    if _lib.load().tg_get_math_mode() == 2 and M >= 256:
-        nws = (_lib.load().tg_gemm_tn_bf16_ws_bytes(M, N, A.K) + 3) // 4
-        ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
-    elif M >= TN_TWO_PASS_ROWS or (out_kw > 0 and M >= 1024):
+    if M >= TN_TWO_PASS_ROWS or (out_kw > 0 and M >= 1024):
         # two-pass (partial tiles + fp64 combine): long reductions for accuracy, and every conv-layout output (out_kw > 0):
         # the permuted (Co, Ci, kw) scatter makes the one-pass float atomics uncoalesced (measured 224 -> 39 us on the audio
         # conv3 weight gradient), the combine kernel writes that layout from contiguous partials instead

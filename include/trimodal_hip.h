@@ -30,11 +30,14 @@ int tg_version(void);
 const char* tg_last_error(void);
 
 /* Math mode of the GEMM-shaped kernels (process-wide, like cublasSetMathMode):
- *   0 (default): fp32 operands on the f32 matrix cores -- exact fp32 fma chains, parity with the reference to ~1e-6.
- *   1: forward and input-gradient products (tg_gemm_nt) round their operands to bf16 (RNE) at the matrix-core feed, fp32
- *      accumulate (v_mfma_f32_16x16x32_bf16); everything in HBM stays fp32, weight gradients stay fp32.  The precision
- *      BASELINE.json configs[1] names; tolerance 2e-2 forward / 5e-2 gradients.
- *   2: as 1, and tg_gemm_tn (weight gradients) too when given the bf16 workspace. */
+ *   0 (default): fp32-accurate products, parity with the reference to ~1e-6.  Small products run on the f32 matrix cores
+ *      (v_mfma_f32_16x16x4_f32, exact fp32 fma chains); the big forward / input-gradient products (tg_gemm_nt, M >= 1024) split
+ *      each fp32 operand exactly into three bf16 terms and accumulate the six significant partial products in fp32 on the
+ *      bf16 matrix cores (csrc/gemm_split.hip): same error as the f32 path, 1.2-1.8x its speed.  Environment TG_GEMM_X3=0
+ *      keeps everything on the f32 matrix cores.
+ *   1: those big products round their operands to bf16 (RNE) instead, one MFMA per product, fp32 accumulate; everything in HBM
+ *      stays fp32, weight gradients and the recurrences stay fp32.  The precision BASELINE.json configs[1] names; tolerance
+ *      2e-2 forward / 5e-2 gradients. */
 int tg_set_math_mode(int32_t mode);
 int tg_get_math_mode(void);
 
@@ -81,9 +84,6 @@ int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bi
  *   combined in split order in fp64 -- bitwise reproducible, and accurate for the ~1e6-row sums of the audio encoder.
  *   Replaces the weight-gradient half of aten::convolution_backward / addmm backward for the same call sites. */
 int64_t tg_gemm_tn_ws_floats(int32_t M, int32_t N, int32_t K);
-/*   math mode 1: ws must hold tg_gemm_tn_bf16_ws_bytes(M, N, K) bytes (transposed bf16 copies of both operands);
- *   ws_floats = that size / 4 rounded up. */
-int64_t tg_gemm_tn_bf16_ws_bytes(int32_t M, int32_t N, int32_t K);
 /*   dbias != NULL: also dbias[n] += sum_m dY[m*ldy + n] (the bias gradient rides along; no separate pass over dY). */
 int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,
                int32_t out_kw, float* dbias, float* ws, int64_t ws_floats, void* stream);

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = ctypes.CDLL(lib_path)
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, missing
-    bound = set(pkg._lib.SIGNATURES) | {"tg_version", "tg_last_error", "tg_gemm_tn_ws_floats", "tg_gemm_tn_bf16_ws_bytes", "tg_set_math_mode", "tg_get_math_mode",
+    bound = set(pkg._lib.SIGNATURES) | {"tg_version", "tg_last_error", "tg_gemm_tn_ws_floats", "tg_set_math_mode", "tg_get_math_mode",
                                          "tg_gru_cluster_supported", "tg_gru_cluster_ws_bytes", "tg_gru_cluster_bwd_supported",
                                          "tg_gru_cluster_bwd_ws_bytes"}
     assert declared == bound, declared ^ bound

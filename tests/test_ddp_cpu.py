@@ -22,9 +22,8 @@ def _free_port():
 
 
 def _make_generator(pkg):
-    import argparse
-    a = argparse.Namespace(n_pre_poses=4, n_poses=34, input_context="both", hidden_size=300, n_layers=4, dropout_prob=0.3,
-                           freeze_wordembed=False)
+    from tests.harness import make_args
+    a = make_args()
     torch.manual_seed(0)
     return pkg.PoseGenerator(a, 27, 64, 300, None, pkg.Vocab.speakers(9))
 

@@ -371,3 +371,51 @@ def test_gemm_nt_big_tile_path_with_conv_window(pkg, dev):
     pkg.ops.gemm_nt(pkg.ops.Win.plain(xa.to(dev)), wa.to(dev), None, big[:, 30:160])
     pkg.ops.gemm_nt(pkg.ops.Win.plain(xa.to(dev)), wa.to(dev), None, big[:, 30:160], accumulate=True)
     assert rel(big[:, 30:160], 2 * (xa.double() @ wa.double().t())) < 1e-5 and float(big[:, :30].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(13056, 300, 600), (4352, 600, 900), (1030, 49, 68), (2049, 97, 108), (1500, 161, 1024), (1024, 48, 64)])
+def test_gemm_nt_split_bf16x3_path_is_fp32_accurate(pkg, dev, M, N, K):
+    """The big-product path (csrc/gemm_split.hip: fp32 operands split exactly into three bf16 terms, six partial products on the bf16
+    matrix cores) against fp64 at the fp32 tolerance, every tile of its menu, ragged edges in M, N and K, bias + activation,
+    accumulate, strided output -- and full-range operands (8 decades of magnitude) so that lost low-order terms would show."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * torch.pow(10.0, torch.randint(-4, 4, (M, 1), generator=g).float())
+    w = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    ref = F.leaky_relu(x.double() @ w.double().t() + b.double(), 0.3)
+    out = torch.full((M, N + 7), float("nan"), device=dev)
+    ops.gemm_nt(Win.plain(x.to(dev)), w.to(dev), b.to(dev), out[:, 3:3 + N], act_slope=0.3)
+    row_scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)                 # per-row normalisation: rows span 8 decades
+    assert float(((out[:, 3:3 + N].double().cpu() - ref).abs() / row_scale).max()) < 1e-5
+    assert bool(torch.isnan(out[:, :3]).all()) and bool(torch.isnan(out[:, 3 + N:]).all())
+    ops.gemm_nt(Win.plain(x.to(dev)), w.to(dev), None, out[:, 3:3 + N], accumulate=True)
+    ref2 = ref + x.double() @ w.double().t()
+    assert float(((out[:, 3:3 + N].double().cpu() - ref2).abs() / ref2.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)).max()) < 1e-5
+
+
+def test_bf16_math_mode_tier(pkg, dev):
+    """tg_set_math_mode(1): the big forward / input-gradient products take bf16 operands (one MFMA per product, fp32 accumulate).
+    Op-level error at the bf16 level (and clearly different from the fp32 result: the mode really switches), and one full GAN
+    iteration at B = 32 against the fp64 oracle within the bf16 tolerances of SURVEY Q14 (2e-2 forward / 5e-2 gradients)."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    M, N, K = 4352, 300, 600
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1)
+    ref = x.double() @ w.double().t()
+    out32, out16 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ops.gemm_nt(Win.plain(x.to(dev)), w.to(dev), None, out32)
+    assert ops.get_math_mode() == "f32"
+    try:
+        ops.set_math_mode("bf16")
+        assert ops.get_math_mode() == "bf16"
+        ops.gemm_nt(Win.plain(x.to(dev)), w.to(dev), None, out16)
+        from tests.harness import run_train_parity
+        # B = 32: the stacked forward (3 x 32 x 34 rows) and the backward (32 x 34 rows) are big enough for the bf16 path (M >= 1024)
+        worst = run_train_parity(pkg, dev, batch=32, epochs=(11,), seed=77, check_step=False)
+    finally:
+        ops.set_math_mode("f32")
+    e32, e16 = rel(out32, ref), rel(out16, ref)
+    assert e32 < 1e-5 and 1e-4 < e16 < 2e-2, (e32, e16)
+    assert worst < 5e-2, worst
+    with pytest.raises(Exception):
+        ops.set_math_mode(2)

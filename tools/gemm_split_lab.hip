@@ -31,13 +31,15 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
     unsigned t[4], u[4], s[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned x = __builtin_bit_cast(unsigned, v[i]);
+        // NOTE: __builtin_bit_cast(unsigned, v[i]) on an ext_vector ELEMENT is miscompiled by hipcc 7.2 (every i reads element 0):
+        // copy the element to a scalar first
+        const float xf = v[i];
+        const unsigned x = __float_as_uint(xf);
         t[i] = x & 0xffff0000u;                                   // hi (truncated): exact prefix of the significand
         if (SPLITS > 1) {
-            const float r = v[i] - __builtin_bit_cast(float, t[i]);   // exact
-            const unsigned rb = __builtin_bit_cast(unsigned, r);
-            u[i] = rb & 0xffff0000u;
-            if (SPLITS > 2) s[i] = __builtin_bit_cast(unsigned, r - __builtin_bit_cast(float, u[i]));   // <= 8 bits left: exact in bf16
+            const float r = xf - __uint_as_float(t[i]);           // exact
+            u[i] = __float_as_uint(r) & 0xffff0000u;
+            if (SPLITS > 2) s[i] = __float_as_uint(r - __uint_as_float(u[i]));   // <= 8 bits left: exact in bf16
         }
     }
     out[0] = u32x2{pack_hi16(t[0], t[1]), pack_hi16(t[2], t[3])};
