@@ -26,6 +26,8 @@ SIGNATURES = {
     "tg_colsum": [P, I64, I32, I32, P, I32, P],
     "tg_gru_forward": [P, I64, P, P, P, P, P, P, I64, I32, I32, I32, P],
     "tg_gru_backward": [P, P, P, I64, P, P, P, P, I64, P, I32, I32, I32, P],
+    "tg_gru_h64_forward": [P, I64, P, P, P, P, P, P, I64, P, P, I32, I32, P],
+    "tg_gru_h64_backward": [P, P, P, P, I64, P, P, P, P, I64, I32, I32, P],
     "tg_gru_forward_cluster": [P, I64, P, P, P, P, P, P, I64, P, I64, I32, I32, I32, P],
     "tg_gru_backward_cluster": [P, P, P, I64, P, P, P, P, I64, P, I64, I32, I32, I32, P],
     "tg_bn_train_stats": [P, I32, I32, I32, P, P, P, P, P, P, F32, F32, I32, P],

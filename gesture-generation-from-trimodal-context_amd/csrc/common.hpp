@@ -84,6 +84,18 @@ __device__ __forceinline__ float gate_tanh(float x) {
     return copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), x);
 }
 
+// ---- exact three-way bf16 split of an fp32 value (the "bf16 x 3" matrix-core feed, see gemm_split.hip) -----------------------
+// x = hi + mid + lo exactly: hi = the top 8 significand bits of x (truncation), mid = the top 8 bits of x - hi, lo = the rest.
+// Each term is returned as an fp32 bit pattern whose low 16 bits are zero (its upper half IS the bf16 value).
+__device__ __forceinline__ void split3_bits(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(hi);
+    mid = __float_as_uint(r) & 0xffff0000u;
+    lo = __float_as_uint(r - __uint_as_float(mid));
+}
+// upper halves of two fp32 words -> one dword holding two bf16 (first element in the low half)
+__device__ __forceinline__ unsigned pack_hi16(unsigned first, unsigned second) { return __builtin_amdgcn_perm(second, first, 0x07060302u); }
+
 // ---- Philox4x32-10 ------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;

@@ -26,9 +26,6 @@ namespace tg {
 
 constexpr int SP_LD = 40;     // bf16 elements per LDS row (32 + 8 pad)
 
-// upper halves of two fp32 words -> one dword holding two bf16 (first element in the low half)
-__device__ __forceinline__ unsigned pack_hi16(unsigned first, unsigned second) { return __builtin_amdgcn_perm(second, first, 0x07060302u); }
-
 template <int SPLITS>
 __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
     if constexpr (SPLITS == 1) {          // plain bf16 tier: round to nearest even (v_cvt_pk_bf16_f32)
@@ -44,10 +41,7 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
             // (__builtin_bit_cast(unsigned, v[i]) on an ext_vector ELEMENT is miscompiled by hipcc 7.2 -- every i reads element 0:
             // copy the element to a scalar first)
             const float xf = v[i];
-            t[i] = __float_as_uint(xf) & 0xffff0000u;                 // hi: exact prefix of the significand
-            const float r = xf - __uint_as_float(t[i]);               // exact
-            u[i] = __float_as_uint(r) & 0xffff0000u;                  // mid
-            s[i] = __float_as_uint(r - __uint_as_float(u[i]));        // lo: <= 8 significant bits left, exact in bf16
+            split3_bits(xf, t[i], u[i], s[i]);
         }
         out[0] = u32x2{pack_hi16(t[0], t[1]), pack_hi16(t[2], t[3])};
         out[1] = u32x2{pack_hi16(u[0], u[1]), pack_hi16(u[2], u[3])};

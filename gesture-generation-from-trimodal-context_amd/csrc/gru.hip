@@ -11,9 +11,7 @@
 //    and all eight waves share the fused gate epilogue (sigmoid/tanh, h' = (1-z) n + z h), writing h_t straight into the
 //    layer output y, which doubles as the state store.
 //
-//  * H = 64 (discriminator): W_hh (48 KB per direction) lives in REGISTERS as MFMA B-fragments for the whole sequence;
-//    a workgroup owns 16 batch rows of one direction and walks all T steps in one launch, exchanging h_t between its
-//    four waves through 4 KB of LDS.  T x 4 layers x 6 passes of ~6 us launches become 24 launches of ~20 us.
+//  * H = 64 (discriminator): persistent kernels with W_hh in registers, see gru_h64.hip.
 #include "common.hpp"
 
 namespace tg {
@@ -215,184 +213,11 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_step_kernel(
     dh_w[(long)erow * H + ej] = dh;
 }
 
-// ---------------------------------------------------------------------------------------------- H = 64, persistent
-// One workgroup = 16 batch rows of one direction, 4 waves; wave w owns hidden units [16w, 16w+16) of all three gates
-// and keeps its 48 rows of W_hh as 12 float4 MFMA B-fragments in registers for the whole sequence.
-constexpr int HS = 64;
-constexpr int HS_LD = HS + 4;     // LDS row stride (floats): keeps float4 alignment, spreads banks
-
-__global__ __launch_bounds__(256) void gru_seq_fwd_h64_kernel(
-    const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
-    const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save,
-    long save_ds, int B, int T) {
-    __shared__ __attribute__((aligned(16))) float hs[16][HS_LD];
-    const int dir = blockIdx.y;
-    const float* whh = dir ? whh1 : whh0;
-    const float* bhh = dir ? bhh1 : bhh0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int j = wave * 16 + r16;                 // hidden unit of this lane's accumulator column
-    const int b0 = blockIdx.x * 16;
-
-    f32x4 wf[3][4];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wf[g][u] = *reinterpret_cast<const f32x4*>(whh + (long)(g * HS + j) * HS + 16 * u + 4 * kq);
-    const float bh_r = bhh[j], bh_z = bhh[HS + j], bh_n = bhh[2 * HS + j];
-    float hp[4] = {0.f, 0.f, 0.f, 0.f};
-    bool row_ok[4];
-    long row_base[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = b0 + kq * 4 + i;
-        row_ok[i] = row < B;
-        row_base[i] = (long)(row_ok[i] ? row : 0) * T;
-    }
-    for (int e = threadIdx.x; e < 16 * HS_LD; e += 256) (&hs[0][0])[e] = 0.f;
-    __syncthreads();
-
-    // input-side gate pre-activations are independent of the recurrence: software-pipelined one step ahead, so their
-    // (HBM/L2) latency hides behind a whole step instead of behind 48 MFMAs
-    float nx_r[4], nx_z[4], nx_n[4];
-    auto load_gi = [&](int tau_l) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float* gip = gi + dir * gi_ds + (row_base[i] + tau_l) * (3 * HS);
-            nx_r[i] = row_ok[i] ? gip[j] : 0.f;
-            nx_z[i] = row_ok[i] ? gip[HS + j] : 0.f;
-            nx_n[i] = row_ok[i] ? gip[2 * HS + j] : 0.f;
-        }
-    };
-    load_gi(dir ? T - 1 : 0);
-    for (int step = 0; step < T; ++step) {
-        const int tau = dir ? T - 1 - step : step;
-        float g_r[4], g_z[4], g_n[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { g_r[i] = nx_r[i]; g_z[i] = nx_z[i]; g_n[i] = nx_n[i]; }
-        if (step + 1 < T) load_gi(dir ? tau - 1 : tau + 1);
-        f32x4 acc[3];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (step > 0) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&hs[r16][16 * u + 4 * kq]);
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v], wf[g][u][v], acc[g], 0, 0, 0);
-            }
-        }
-        __syncthreads();                            // every wave has read h_{t-1}
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float hn = acc[2][i] + bh_n;
-            const float r = gate_sigmoid(g_r[i] + acc[0][i] + bh_r);
-            const float z = gate_sigmoid(g_z[i] + acc[1][i] + bh_z);
-            const float n = gate_tanh(g_n[i] + r * hn);
-            const float h = (1.f - z) * n + z * hp[i];
-            hp[i] = h;
-            hs[kq * 4 + i][j] = h;
-            if (row_ok[i]) {
-                Y[(row_base[i] + tau) * (2 * HS) + dir * HS + j] = h;
-                if (save) {
-                    float* sp = save + dir * save_ds + (row_base[i] + tau) * (4 * HS);
-                    sp[j] = r; sp[HS + j] = z; sp[2 * HS + j] = n; sp[3 * HS + j] = hn;
-                }
-            }
-        }
-        __syncthreads();                            // h_t complete in LDS
-    }
-}
-
-// Backward through time, same ownership; W_hh^T rows [16w, 16w+16) x 192 live in registers as 12 float4 fragments;
-// the gate gradients of the step just processed sit in LDS (16 x 192) as the next step's MFMA A operand.
-constexpr int DG_LD = 3 * HS + 4;
-
-__global__ __launch_bounds__(256) void gru_seq_bwd_h64_kernel(
-    const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ save, long save_ds,
-    const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh, long dg_ds,
-    int B, int T) {
-    __shared__ __attribute__((aligned(16))) float dgs[16][DG_LD];
-    const int dir = blockIdx.y;
-    const float* wt = dir ? wt1 : wt0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int j = wave * 16 + r16;
-    const int b0 = blockIdx.x * 16;
-
-    f32x4 wf[12];
-#pragma unroll
-    for (int u = 0; u < 12; ++u) wf[u] = *reinterpret_cast<const f32x4*>(wt + (long)j * (3 * HS) + 16 * u + 4 * kq);
-    bool row_ok[4];
-    long row_base[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = b0 + kq * 4 + i;
-        row_ok[i] = row < B;
-        row_base[i] = (long)(row_ok[i] ? row : 0) * T;
-    }
-    float dh_c[4] = {0.f, 0.f, 0.f, 0.f}, z_c[4] = {0.f, 0.f, 0.f, 0.f};   // dh and z of the step processed before
-    for (int e = threadIdx.x; e < 16 * DG_LD; e += 256) (&dgs[0][0])[e] = 0.f;
-    __syncthreads();
-
-    // the per-step operands (dy, saved gates, h_prev) do not depend on the recurrence: loaded one step ahead
-    float n_dy[4], n_r[4], n_z[4], n_n[4], n_hn[4], n_hp[4];
-    auto load_step = [&](int tau_l) {
-        const int tp = dir ? tau_l + 1 : tau_l - 1;
-        const bool hasp = dir ? (tau_l < T - 1) : (tau_l > 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = row_ok[i];
-            const float* sp = save + dir * save_ds + (row_base[i] + tau_l) * (4 * HS);
-            n_dy[i] = ok ? dY[(row_base[i] + tau_l) * (2 * HS) + dir * HS + j] : 0.f;
-            n_r[i] = ok ? sp[j] : 0.f; n_z[i] = ok ? sp[HS + j] : 0.f; n_n[i] = ok ? sp[2 * HS + j] : 0.f; n_hn[i] = ok ? sp[3 * HS + j] : 0.f;
-            n_hp[i] = (ok && hasp) ? Y[(row_base[i] + tp) * (2 * HS) + dir * HS + j] : 0.f;
-        }
-    };
-    load_step(dir ? 0 : T - 1);
-    for (int step = 0; step < T; ++step) {
-        const int tau = dir ? step : T - 1 - step;
-        float dy[4], r[4], z[4], n[4], hn[4], hp[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { dy[i] = n_dy[i]; r[i] = n_r[i]; z[i] = n_z[i]; n[i] = n_n[i]; hn[i] = n_hn[i]; hp[i] = n_hp[i]; }
-        if (step + 1 < T) load_step(dir ? tau + 1 : tau - 1);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if (step > 0) {
-#pragma unroll
-            for (int u = 0; u < 12; ++u) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&dgs[r16][16 * u + 4 * kq]);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], wf[u][0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], wf[u][1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], wf[u][2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], wf[u][3], acc1, 0, 0, 0);
-            }
-        }
-        __syncthreads();                            // every wave has read the previous step's gate gradients
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float dh = dy[i] + (step > 0 ? acc0[i] + acc1[i] + dh_c[i] * z_c[i] : 0.f);
-            const float dn = dh * (1.f - z[i]) * (1.f - n[i] * n[i]);
-            const float dz = dh * (hp[i] - n[i]) * z[i] * (1.f - z[i]);
-            const float dr = dn * hn[i] * r[i] * (1.f - r[i]);
-            dh_c[i] = dh; z_c[i] = z[i];
-            float* row = dgs[kq * 4 + i];
-            row[j] = dr; row[HS + j] = dz; row[2 * HS + j] = dn * r[i];
-            if (row_ok[i]) {
-                float* gi_o = dgi + dir * dg_ds + (row_base[i] + tau) * (3 * HS);
-                float* gh_o = dgh + dir * dg_ds + (row_base[i] + tau) * (3 * HS);
-                gi_o[j] = dr; gi_o[HS + j] = dz; gi_o[2 * HS + j] = dn;
-                gh_o[j] = dr; gh_o[HS + j] = dz; gh_o[2 * HS + j] = dn * r[i];
-            }
-        }
-        __syncthreads();
-    }
-}
-
 }  // namespace tg
 
 using namespace tg;
+
+constexpr int HS = 64;      // H = 64 runs in the persistent kernels of gru_h64.hip
 
 extern "C" int tg_gru_forward(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
                               const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
@@ -401,11 +226,9 @@ extern "C" int tg_gru_forward(const float* gi, int64_t gi_dir_stride, const floa
     TG_REQUIRE(B > 0 && T > 0 && H > 0 && H % 4 == 0, "tg_gru_forward: need H %% 4 == 0 (H=%d)", H);
     TG_REQUIRE(aligned16(w_hh_fwd) && aligned16(w_hh_rev) && aligned16(y), "tg_gru_forward: w_hh / y must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    if (H == HS) {
-        hipLaunchKernelGGL(gru_seq_fwd_h64_kernel, dim3(cdiv(B, 16), 2), dim3(256), 0, s, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev,
-                           b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, B, T);
-        return check_launch("tg_gru_forward(h64)");
-    }
+    if (H == HS)
+        return tg_gru_h64_forward(gi, gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, save_dir_stride, nullptr, nullptr, B, T,
+                                  stream);
     const int n_jt = cdiv(H, 16), n_bt = cdiv(B, GRU_MT * 16);
     dim3 grid(n_jt * n_bt * 2);
     for (int step = 0; step < T; ++step)
@@ -422,11 +245,8 @@ extern "C" int tg_gru_backward(const float* dy, const float* y, const float* sav
     TG_REQUIRE(aligned16(w_hh_t_fwd) && aligned16(w_hh_t_rev) && aligned16(dgh) && (dg_dir_stride % 4 == 0),
                "tg_gru_backward: w_hh_t / dgh must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    if (H == HS) {
-        hipLaunchKernelGGL(gru_seq_bwd_h64_kernel, dim3(cdiv(B, 16), 2), dim3(256), 0, s, dy, y, save, (long)save_dir_stride, w_hh_t_fwd,
-                           w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T);
-        return check_launch("tg_gru_backward(h64)");
-    }
+    if (H == HS)
+        return tg_gru_h64_backward(dy, nullptr, y, save, save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, dg_dir_stride, B, T, stream);
     const int n_jt = cdiv(H, 16), n_bt = cdiv(B, GRU_MT * 16);
     dim3 grid(n_jt * n_bt * 2);
     for (int step = 0; step < T; ++step)

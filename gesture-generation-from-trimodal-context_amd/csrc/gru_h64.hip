@@ -1,0 +1,271 @@
+// Persistent GRU recurrence for H = 64 (the discriminator's 4-layer bi-GRU, T = 28): one workgroup owns 16 batch rows of one
+// direction and walks the whole sequence; the dependent chain of T steps is what this kernel is about.
+//
+// Per step the recurrent product  gh^T[3 x 64 gate units][16 rows] = W_hh[192][64] . h_{t-1}^T  runs on the bf16 matrix cores
+// at fp32 accuracy (exact three-way split of both operands, six partial products, common.hpp / gemm_split.hip): wave w owns
+// hidden units [16w, 16w + 16) of the three gates, its 48 rows of W_hh live in registers as pre-split bf16 A-fragments for the
+// whole sequence (72 VGPRs), h_{t-1} comes from LDS as three bf16 planes.  36 MFMAs of 16 cycles per wave and step instead of the
+// 48 f32 MFMAs of 32 cycles of the first version.  The product is taken TRANSPOSED (weights as the A operand, h as B): a lane's
+// four accumulator values are then four CONSECUTIVE hidden units of ONE batch row, so every global access of the gate epilogue
+// (gi, y, saved gates, dropout mask) is a 16-byte vector and h_t goes back to LDS as one 8-byte store per plane.
+// h is double-buffered in LDS: ONE barrier per step, and it waits for LDS only (s_waitcnt lgkmcnt(0) + s_barrier) -- the
+// step's global stores and the next step's operand prefetch stay in flight across it.
+//
+// Optional fused inter-layer dropout (nn.GRU dropout=0.3 between layers): with drop_mask != NULL the forward also writes
+// y_drop = y * mask (the next layer's input) and the backward multiplies the incoming gradient by the mask while loading it --
+// the separate dropout / mask-multiply passes and their launches disappear.  The mask is drawn beforehand for all layers of a
+// pass by ONE tg_dropout_mask launch (or injected by the parity tests).
+#include "common.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace tg {
+
+constexpr int HS = 64;
+constexpr int HX_LD = HS + 8;          // bf16 per LDS row of the h planes (144 B: 16-byte aligned, rows spread over the banks)
+constexpr int DG_LD = 3 * HS + 8;      // bf16 per LDS row of the gate-gradient planes (400 B)
+
+// eight consecutive fp32 -> three bf16x8 fragments (hi / mid / lo planes)
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8 (&out)[3]) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xa = a[i], xb = b[i];
+        split3_bits(xa, h[i], m[i], l[i]);
+        split3_bits(xb, h[4 + i], m[4 + i], l[4 + i]);
+    }
+    out[0] = __builtin_bit_cast(bf16x8, u32x4{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])});
+    out[1] = __builtin_bit_cast(bf16x8, u32x4{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])});
+    out[2] = __builtin_bit_cast(bf16x8, u32x4{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])});
+}
+
+// four consecutive fp32 -> three 8-byte LDS words (4 bf16 each)
+__device__ __forceinline__ void split4_store(const f32x4 v, __bf16* p0, __bf16* p1, __bf16* p2) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = v[i];
+        split3_bits(x, h[i], m[i], l[i]);
+    }
+    *reinterpret_cast<u32x2*>(p0) = u32x2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])};
+    *reinterpret_cast<u32x2*>(p1) = u32x2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])};
+    *reinterpret_cast<u32x2*>(p2) = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
+}
+
+// acc += W (A operand, split planes wa[0..2]) x h (B operand, split planes fb[0..2]); the six significant partial products,
+// smallest first
+__device__ __forceinline__ f32x4 mma_x3(const bf16x8 (&wa)[3], const bf16x8 (&fb)[3], f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2], fb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], fb[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], fb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[1], acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[0], acc, 0, 0, 0);
+}
+
+// LDS-only workgroup barrier: the step's global stores / prefetched loads are NOT drained
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
+    const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
+    const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
+    const float* __restrict__ drop_mask, float* __restrict__ y_drop, int B, int T) {
+    __shared__ __attribute__((aligned(16))) __bf16 hs[2][3][16][HX_LD];
+    const int dir = blockIdx.y;
+    const float* whh = dir ? whh1 : whh0;
+    const float* bhh = dir ? bhh1 : bhh0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    // W_hh rows (gate g, unit 16 wave + r16), k = 32 ks + 8 kq .. +7 -> pre-split A fragments, resident for the whole sequence
+    bf16x8 wa[3][2][3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* p = whh + (long)(g * HS + 16 * wave + r16) * HS + 32 * ks + 8 * kq;
+            split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[g][ks]);
+        }
+    // gate-epilogue role: batch row b0 + r16, hidden units u0 .. u0 + 3
+    const int u0 = 16 * wave + 4 * kq;
+    const int row = blockIdx.x * 16 + r16;
+    const bool row_ok = row < B;
+    const long rbase = (long)(row_ok ? row : 0) * T;
+    f32x4 bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bh[g] = *reinterpret_cast<const f32x4*>(bhh + g * HS + u0);
+    f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    // operands that do not depend on the recurrence are loaded one step ahead
+    f32x4 nx[3], nxm = {1.f, 1.f, 1.f, 1.f};
+    auto prefetch = [&](int tau_l) {
+        const float* gp = gi + dir * gi_ds + (rbase + tau_l) * (3 * HS) + u0;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) nx[g] = row_ok ? *reinterpret_cast<const f32x4*>(gp + g * HS) : zero;
+        if (drop_mask) nxm = row_ok ? *reinterpret_cast<const f32x4*>(drop_mask + (rbase + tau_l) * (2 * HS) + dir * HS + u0) : zero;
+    };
+    prefetch(dir ? T - 1 : 0);
+    for (int step = 0; step < T; ++step) {
+        const int tau = dir ? T - 1 - step : step;
+        f32x4 gv[3], mk = nxm;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gv[g] = nx[g];
+        if (step + 1 < T) prefetch(dir ? tau - 1 : tau + 1);
+        f32x4 acc[3] = {zero, zero, zero};
+        if (step > 0) {
+            const int rb = (step - 1) & 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fb[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&hs[rb][s][r16][32 * ks + 8 * kq]);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = mma_x3(wa[g][ks], fb, acc[g]);
+            }
+        }
+        f32x4 h, r4, z4, n4, hn4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float hn = acc[2][q] + bh[2][q];
+            const float r = gate_sigmoid(gv[0][q] + acc[0][q] + bh[0][q]);
+            const float z = gate_sigmoid(gv[1][q] + acc[1][q] + bh[1][q]);
+            const float n = gate_tanh(gv[2][q] + r * hn);
+            h[q] = (1.f - z) * n + z * hp[q];
+            r4[q] = r; z4[q] = z; n4[q] = n; hn4[q] = hn;
+        }
+        hp = h;
+        const int wb = step & 1;
+        split4_store(h, &hs[wb][0][r16][u0], &hs[wb][1][r16][u0], &hs[wb][2][r16][u0]);
+        if (row_ok) {
+            const long o = (rbase + tau) * (2 * HS) + dir * HS + u0;
+            *reinterpret_cast<f32x4*>(Y + o) = h;
+            if (y_drop) *reinterpret_cast<f32x4*>(y_drop + o) = h * mk;
+            if (save) {
+                float* sp = save + dir * save_ds + (rbase + tau) * (4 * HS) + u0;
+                *reinterpret_cast<f32x4*>(sp) = r4;
+                *reinterpret_cast<f32x4*>(sp + HS) = z4;
+                *reinterpret_cast<f32x4*>(sp + 2 * HS) = n4;
+                *reinterpret_cast<f32x4*>(sp + 3 * HS) = hn4;
+            }
+        }
+        lds_barrier();                       // h_t complete in LDS (and everybody is done with the buffer written next step)
+    }
+}
+
+// Backward through time, same ownership.  dh_{t} needs dgh_{t+1} @ W_hh (contraction over the 192 gate rows): taken transposed like
+// the forward, A = W_hh^T rows [16 wave, 16 wave + 16) (pre-split, 6 k-steps x 3 planes in registers), B = the previous step's
+// gate-gradient tile from LDS (three bf16 planes, double-buffered).
+__global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
+    const float* __restrict__ dY, const float* __restrict__ dy_mask, const float* __restrict__ Y, const float* __restrict__ save,
+    long save_ds, const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh,
+    long dg_ds, int B, int T) {
+    __shared__ __attribute__((aligned(16))) __bf16 dgs[2][3][16][DG_LD];
+    const int dir = blockIdx.y;
+    const float* wt = dir ? wt1 : wt0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    bf16x8 wa[6][3];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const float* p = wt + (long)(16 * wave + r16) * (3 * HS) + 32 * ks + 8 * kq;
+        split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[ks]);
+    }
+    const int u0 = 16 * wave + 4 * kq;
+    const int row = blockIdx.x * 16 + r16;
+    const bool row_ok = row < B;
+    const long rbase = (long)(row_ok ? row : 0) * T;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dh_c = zero, z_c = zero;              // dh and z of the step processed before
+
+    f32x4 n_dy, n_r, n_z, n_n, n_hn, n_hp;
+    auto prefetch = [&](int tau_l) {
+        const int tp = dir ? tau_l + 1 : tau_l - 1;
+        const bool hasp = dir ? (tau_l < T - 1) : (tau_l > 0);
+        const long o = (rbase + tau_l) * (2 * HS) + dir * HS + u0;
+        const float* sp = save + dir * save_ds + (rbase + tau_l) * (4 * HS) + u0;
+        n_dy = row_ok ? *reinterpret_cast<const f32x4*>(dY + o) : zero;
+        if (dy_mask) n_dy = n_dy * (row_ok ? *reinterpret_cast<const f32x4*>(dy_mask + o) : zero);
+        n_r = row_ok ? *reinterpret_cast<const f32x4*>(sp) : zero;
+        n_z = row_ok ? *reinterpret_cast<const f32x4*>(sp + HS) : zero;
+        n_n = row_ok ? *reinterpret_cast<const f32x4*>(sp + 2 * HS) : zero;
+        n_hn = row_ok ? *reinterpret_cast<const f32x4*>(sp + 3 * HS) : zero;
+        n_hp = (row_ok && hasp) ? *reinterpret_cast<const f32x4*>(Y + (rbase + tp) * (2 * HS) + dir * HS + u0) : zero;
+    };
+    prefetch(dir ? 0 : T - 1);
+    for (int step = 0; step < T; ++step) {
+        const int tau = dir ? step : T - 1 - step;
+        const f32x4 dy = n_dy, r = n_r, z = n_z, n = n_n, hn = n_hn, hp = n_hp;
+        if (step + 1 < T) prefetch(dir ? tau + 1 : tau - 1);
+        f32x4 acc = zero;
+        if (step > 0) {
+            const int rb = (step - 1) & 1;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                bf16x8 fb[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&dgs[rb][s][r16][32 * ks + 8 * kq]);
+                acc = mma_x3(wa[ks], fb, acc);
+            }
+        }
+        f32x4 g_r, g_z, g_n, g_nr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dh = dy[q] + (step > 0 ? acc[q] + dh_c[q] * z_c[q] : 0.f);
+            const float dn = dh * (1.f - z[q]) * (1.f - n[q] * n[q]);
+            const float dz = dh * (hp[q] - n[q]) * z[q] * (1.f - z[q]);
+            const float dr = dn * hn[q] * r[q] * (1.f - r[q]);
+            dh_c[q] = dh; z_c[q] = z[q];
+            g_r[q] = dr; g_z[q] = dz; g_n[q] = dn; g_nr[q] = dn * r[q];
+        }
+        const int wb = step & 1;
+        split4_store(g_r, &dgs[wb][0][r16][u0], &dgs[wb][1][r16][u0], &dgs[wb][2][r16][u0]);
+        split4_store(g_z, &dgs[wb][0][r16][HS + u0], &dgs[wb][1][r16][HS + u0], &dgs[wb][2][r16][HS + u0]);
+        split4_store(g_nr, &dgs[wb][0][r16][2 * HS + u0], &dgs[wb][1][r16][2 * HS + u0], &dgs[wb][2][r16][2 * HS + u0]);
+        if (row_ok) {
+            float* gi_o = dgi + dir * dg_ds + (rbase + tau) * (3 * HS) + u0;
+            float* gh_o = dgh + dir * dg_ds + (rbase + tau) * (3 * HS) + u0;
+            *reinterpret_cast<f32x4*>(gi_o) = g_r; *reinterpret_cast<f32x4*>(gi_o + HS) = g_z; *reinterpret_cast<f32x4*>(gi_o + 2 * HS) = g_n;
+            *reinterpret_cast<f32x4*>(gh_o) = g_r; *reinterpret_cast<f32x4*>(gh_o + HS) = g_z; *reinterpret_cast<f32x4*>(gh_o + 2 * HS) = g_nr;
+        }
+        lds_barrier();
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
+                                  const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
+                                  const float* drop_mask, float* y_drop, int32_t B, int32_t T, void* stream) {
+    TG_REQUIRE(gi && w_hh_fwd && w_hh_rev && b_hh_fwd && b_hh_rev && y, "tg_gru_h64_forward: null pointer");
+    TG_REQUIRE(B > 0 && T > 0, "tg_gru_h64_forward: bad sizes B=%d T=%d", B, T);
+    TG_REQUIRE((drop_mask == nullptr) == (y_drop == nullptr), "tg_gru_h64_forward: drop_mask and y_drop go together");
+    TG_REQUIRE(aligned16(gi) && aligned16(w_hh_fwd) && aligned16(w_hh_rev) && aligned16(b_hh_fwd) && aligned16(b_hh_rev) && aligned16(y) &&
+               (save == nullptr || aligned16(save)) && (drop_mask == nullptr || (aligned16(drop_mask) && aligned16(y_drop))) &&
+               gi_dir_stride % 4 == 0 && save_dir_stride % 4 == 0, "tg_gru_h64_forward: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(gru_h64_fwd_kernel, dim3(cdiv(B, 16), 2), dim3(256), 0, (hipStream_t)stream, gi, (long)gi_dir_stride, w_hh_fwd,
+                       w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask, y_drop, B, T);
+    return check_launch("tg_gru_h64_forward");
+}
+
+extern "C" int tg_gru_h64_backward(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
+                                   const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
+                                   int32_t B, int32_t T, void* stream) {
+    TG_REQUIRE(dy && y && save && w_hh_t_fwd && w_hh_t_rev && dgi && dgh, "tg_gru_h64_backward: null pointer");
+    TG_REQUIRE(B > 0 && T > 0, "tg_gru_h64_backward: bad sizes B=%d T=%d", B, T);
+    TG_REQUIRE(aligned16(dy) && aligned16(y) && aligned16(save) && aligned16(w_hh_t_fwd) && aligned16(w_hh_t_rev) && aligned16(dgi) &&
+               aligned16(dgh) && (dy_mask == nullptr || aligned16(dy_mask)) && save_dir_stride % 4 == 0 && dg_dir_stride % 4 == 0,
+               "tg_gru_h64_backward: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(gru_h64_bwd_kernel, dim3(cdiv(B, 16), 2), dim3(256), 0, (hipStream_t)stream, dy, dy_mask, y, save,
+                       (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T);
+    return check_launch("tg_gru_h64_backward");
+}

@@ -274,6 +274,12 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     tape.x, tape.y, tape.save, tape.masks = [], [], [], []
     tape.B, tape.T, tape.H = B, T, H
     cur = x
+    # H = 64 (discriminator): the inter-layer dropout is fused into the recurrence kernels (csrc/gru_h64.hip); the masks of all
+    # layers of the pass come from ONE draw launch (or from the parity tests)
+    fused_drop = H == 64 and training and n_layers > 1 and (p_drop > 0 or inject is not None)
+    drawn = None
+    if fused_drop and p_drop > 0 and not (inject is not None and all(f"{tag}.gru.drop{l}" in inject for l in range(n_layers - 1))):
+        drawn = ops.dropout_mask(empty(n_layers - 1, B, T, 2 * H, like=x), p_drop, rng.state, rng.site(f"{tag}.gru.drop"))
     for l in range(n_layers):
         Kin = cur.shape[2]
         gi = empty(2, B, T, 3 * H, like=x)
@@ -282,12 +288,21 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
                         gi[d].view(B * T, 3 * H))
         y = empty(B, T, 2 * H, like=x)
         sv = empty(2, B, T, 4 * H, like=x) if save else None
-        ops.gru_forward(gi, (P[f"{prefix}.weight_hh_l{l}"], P[f"{prefix}.weight_hh_l{l}_reverse"]),
-                        (P[f"{prefix}.bias_hh_l{l}"], P[f"{prefix}.bias_hh_l{l}_reverse"]), y, sv)
-        tape.x.append(cur); tape.y.append(y); tape.save.append(sv)
+        whh = (P[f"{prefix}.weight_hh_l{l}"], P[f"{prefix}.weight_hh_l{l}_reverse"])
+        bhh = (P[f"{prefix}.bias_hh_l{l}"], P[f"{prefix}.bias_hh_l{l}_reverse"])
         mask = None
-        if training and l < n_layers - 1:
-            name = f"{tag}.gru.drop{l}"
+        name = f"{tag}.gru.drop{l}"
+        if fused_drop and l < n_layers - 1:
+            mask = inject[name].contiguous() if (inject is not None and name in inject) else (drawn[l] if drawn is not None else None)
+        if mask is not None:
+            nxt = torch.empty_like(y)
+            ops.gru_forward(gi, whh, bhh, y, sv, drop_mask=mask, y_drop=nxt)
+            tape.x.append(cur); tape.y.append(y); tape.save.append(sv); tape.masks.append(mask)
+            cur = nxt
+            continue
+        ops.gru_forward(gi, whh, bhh, y, sv)
+        tape.x.append(cur); tape.y.append(y); tape.save.append(sv)
+        if training and l < n_layers - 1 and not fused_drop:
             if inject is not None and name in inject:
                 mask = inject[name]
                 cur = ops.mul(y, mask, torch.empty_like(y))
@@ -359,11 +374,15 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
     dh = empty(4 * nb * H, like=dy)
     fk = fork if fork is not None else Fork(dy.device, enabled=False)
     for l in range(n_layers - 1, -1, -1):
+        dy_mask = None
         if tape.masks[l] is not None:
-            dy = ops.mul(dy, tape.masks[l][rows].contiguous(), torch.empty_like(dy))
+            if H == 64:
+                dy_mask = tape.masks[l][rows].contiguous()         # multiplied in while the recurrence kernel loads dy
+            else:
+                dy = ops.mul(dy, tape.masks[l][rows].contiguous(), torch.empty_like(dy))
         wt = tuple(transpose2d(P[f"{prefix}.weight_hh_l{l}{s}"]) for s in ("", "_reverse"))
         dgi, dgh = empty(2, nb, T, 3 * H, like=dy), empty(2, nb, T, 3 * H, like=dy)
-        ops.gru_backward(dy, tape.y[l], tape.save[l], wt, dgi, dgh, dh, b0=b0, nb=nb)
+        ops.gru_backward(dy.contiguous(), tape.y[l], tape.save[l], wt, dgi, dgh, dh, b0=b0, nb=nb, dy_mask=dy_mask)
         x_l = tape.x[l][rows]
         Kin = x_l.shape[2]
         y_l = tape.y[l][rows]

@@ -194,8 +194,9 @@ def check_async_errors():
                                f"workgroup {info[2]}, flag words seen {info[4:14]}; results are invalid")
 
 
-def gru_forward(gi, w_hh, b_hh, y, save):
-    """gi: [2, B, T, 3H] contiguous; w_hh/b_hh: (fwd, rev) pairs; y: [B, T, 2H]; save: [2, B, T, 4H] or None."""
+def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None):
+    """gi: [2, B, T, 3H] contiguous; w_hh/b_hh: (fwd, rev) pairs; y: [B, T, 2H]; save: [2, B, T, 4H] or None.
+    drop_mask / y_drop ([B, T, 2H], H = 64 only): fused inter-layer dropout, y_drop = y * drop_mask."""
     _flat(gi, "gi"); _flat(y, "y")
     _, B, T, H3 = gi.shape
     H = H3 // 3
@@ -204,6 +205,14 @@ def gru_forward(gi, w_hh, b_hh, y, save):
         _flat(w, "w_hh"); _flat(b, "b_hh"); assert tuple(w.shape) == (3 * H, H) and b.numel() == 3 * H
     if save is not None:
         _flat(save, "save"); assert tuple(save.shape) == (2, B, T, 4 * H)
+    if H == 64:
+        if drop_mask is not None:
+            _flat(drop_mask, "drop_mask"); _flat(y_drop, "y_drop")
+            assert tuple(drop_mask.shape) == tuple(y.shape) == tuple(y_drop.shape)
+        call("tg_gru_h64_forward", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
+             B * T * 4 * H, _p(drop_mask), _p(y_drop), B, T, _stream())
+        return y
+    assert drop_mask is None and y_drop is None, "fused dropout exists for H = 64 only"
     if GRU_CLUSTER and H > 64 and _lib.load().tg_gru_cluster_supported(B, H):
         ws = _gru_cluster_ws(gi.device, B, H)
         call("tg_gru_forward_cluster", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
@@ -214,9 +223,10 @@ def gru_forward(gi, w_hh, b_hh, y, save):
     return y
 
 
-def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None):
+def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None, dy_mask=None):
     """Backward through time for batch rows [b0, b0+nb) of a (possibly larger) stacked forward.
-    dy: [nb, T, 2H]; y: [B, T, 2H]; save: [2, B, T, 4H]; w_hh_t: (fwd, rev) each [H, 3H]; dgi/dgh: [2, nb, T, 3H]."""
+    dy: [nb, T, 2H]; y: [B, T, 2H]; save: [2, B, T, 4H]; w_hh_t: (fwd, rev) each [H, 3H]; dgi/dgh: [2, nb, T, 3H].
+    dy_mask ([nb, T, 2H], H = 64 only): multiplied into dy while it is loaded (fused dropout backward)."""
     _flat(dy, "dy"); _flat(y, "y"); _flat(save, "save"); _flat(dgi, "dgi"); _flat(dgh, "dgh"); _flat(dh_scratch, "dh")
     B, T, H2 = y.shape
     H = H2 // 2
@@ -227,6 +237,13 @@ def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None):
     for w in w_hh_t:
         _flat(w, "w_hh_t"); assert tuple(w.shape) == (H, 3 * H)
     ys, ss = y[b0:b0 + nb], save[:, b0:b0 + nb]
+    if H == 64:
+        if dy_mask is not None:
+            _flat(dy_mask, "dy_mask"); assert tuple(dy_mask.shape) == tuple(dy.shape)
+        call("tg_gru_h64_backward", _p(dy), _p(dy_mask), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
+             _p(dgi), _p(dgh), nb * T * 3 * H, nb, T, _stream())
+        return
+    assert dy_mask is None, "fused dropout backward exists for H = 64 only"
     if GRU_CLUSTER and H > 64 and _lib.load().tg_gru_cluster_bwd_supported(nb, H):
         ws = _gru_cluster_ws(dy.device, nb, H, bwd=True)
         call("tg_gru_backward_cluster", _p(dy), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),

@@ -97,7 +97,7 @@ int tg_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, int
  * save : [2][B][T][4H] r, z, n, (W_hn h + b_hn) per step for the backward pass, or NULL (inference / no-grad)
  * Gate order and maths are PyTorch's: r,z = sigmoid, n = tanh(gi_n + r*(W_hn h + b_hn)), h' = (1-z) n + z h.
  * H != 64: one launch per time step (both directions, all batch rows); the launch boundary is the grid-wide dependency.
- * H == 64: one persistent launch for the whole sequence (W_hh held in registers as MFMA fragments). */
+ * H == 64: one persistent launch for the whole sequence (tg_gru_h64_forward without the fused dropout). */
 int tg_gru_forward(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
                    const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
                    int32_t B, int32_t T, int32_t H, void* stream);
@@ -108,6 +108,20 @@ int tg_gru_forward(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd
 int tg_gru_backward(const float* dy, const float* y, const float* save, int64_t save_dir_stride,
                     const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
                     float* dh_scratch, int32_t B, int32_t T, int32_t H, void* stream);
+
+/* H = 64 recurrence (the discriminator's GRU): one persistent launch per layer, recurrent product on the bf16 matrix cores at
+ * fp32 accuracy (csrc/gru_h64.hip).  Same tensors as tg_gru_forward / tg_gru_backward plus the fused inter-layer dropout of
+ * nn.GRU(dropout=p):
+ *   forward : drop_mask [B][T][128] (inverted-dropout scale mask, 0 or 1/(1-p)) and y_drop [B][T][128] -- both or neither;
+ *             y_drop = y * drop_mask is the next layer's input (y itself stays the recurrent state / backward operand).
+ *   backward: dy_mask [B][T][128] or NULL: the incoming gradient is multiplied by it while it is loaded (the gradient w.r.t.
+ *             y_drop becomes the gradient w.r.t. y).  No dh_scratch: the carried dh stays in registers. */
+int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
+                       const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
+                       const float* drop_mask, float* y_drop, int32_t B, int32_t T, void* stream);
+int tg_gru_h64_backward(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
+                        const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
+                        int32_t B, int32_t T, void* stream);
 
 /* Persistent, cluster-synchronised variant of tg_gru_forward for H <= 320 (the generator): ONE launch walks all T
  * steps of both directions; the workgroups that share a batch tile exchange h_t through `ws` with write-through stores and

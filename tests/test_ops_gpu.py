@@ -419,3 +419,48 @@ def test_bf16_math_mode_tier(pkg, dev):
     assert worst < 5e-2, worst
     with pytest.raises(Exception):
         ops.set_math_mode(2)
+
+
+@pytest.mark.parametrize("B", [5, 70, 256])
+def test_gru_h64_stack_with_fused_dropout(pkg, dev, B):
+    """The discriminator's GRU stack (4 layers, H = 64, T = 28) with injected inter-layer dropout masks against a layer-by-layer
+    nn.GRU fp64 reference that multiplies the same masks in between: forward output, input gradient, every weight gradient.  The
+    masks ride inside the recurrence kernels (y_drop = y * mask in the forward, dy * mask in the backward load)."""
+    Lm = pkg.layers
+    T, H, L = 28, 64, 4
+    layers = [torch.nn.GRU(8 if l == 0 else 2 * H, H, num_layers=1, batch_first=True, bidirectional=True).double() for l in range(L)]
+    g = torch.Generator().manual_seed(B)
+    masks = [(torch.rand(B, T, 2 * H, generator=g) >= 0.3).double() / 0.7 for _ in range(L - 1)]
+    x = rnd(B, T, 8, seed=31).double().requires_grad_(True)
+    cur = x
+    for l in range(L):
+        cur, _ = layers[l](cur)
+        if l < L - 1:
+            cur = cur * masks[l]
+    dy = rnd(B, T, 2 * H, seed=32).double()
+    cur.backward(dy)
+    P = {}
+    for l in range(L):
+        for k, v in layers[l].named_parameters():
+            P["gru." + k.replace("_l0", f"_l{l}")] = v.detach().float().to(dev).contiguous()
+    G = {k: torch.zeros_like(v) for k, v in P.items()}
+    inject = {f"d.gru.drop{l}": masks[l].float().to(dev) for l in range(L - 1)}
+    yg, tape = Lm.gru_stack_fwd(x.detach().float().to(dev), P, "gru", L, H, p_drop=0.3, training=True, save=True, inject=inject, tag="d")
+    assert rel(yg, cur) < 1e-5
+    dx = Lm.gru_stack_bwd(dy.float().to(dev), tape, P, G, "gru", L)
+    assert rel(dx, x.grad) < 1e-4
+    for l in range(L):
+        for k, v in layers[l].named_parameters():
+            assert rel(G["gru." + k.replace("_l0", f"_l{l}")], v.grad) < 1e-4, (l, k)
+    # drawn masks (no injection): keep-rate and scale, and y_drop == y * mask
+    class R:
+        def __init__(self): self.state = pkg.ops.new_rng_state(11, dev); self.n = {}
+        def site(self, name): return self.n.setdefault(name, len(self.n) + 1)
+    y2, tape2 = Lm.gru_stack_fwd(x.detach().float().to(dev), P, "gru", L, H, p_drop=0.3, training=True, save=True, rng=R(), tag="d")
+    for l in range(L - 1):
+        m = tape2.masks[l]
+        vals = torch.unique(m)
+        assert vals.numel() == 2 and float(vals[0]) == 0 and abs(float(vals[1]) - 1 / 0.7) < 1e-6
+        if B >= 70:
+            assert abs(float((m > 0).float().mean()) - 0.7) < 0.02
+        assert torch.equal(tape2.x[l + 1], tape2.y[l] * m)
