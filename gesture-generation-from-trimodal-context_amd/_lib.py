@@ -19,9 +19,27 @@ class Window(C.Structure):
 P, I32, I64, F32, U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
 WP = C.POINTER(Window)
 
+
+class NtProblem(C.Structure):
+    """struct tg_gemm_nt_problem"""
+    _fields_ = [("A", Window), ("Bw", P), ("ldb", I64), ("b_seg_k", I32), ("reserved", I32), ("b_seg_stride", I64), ("bias", P), ("C", P),
+                ("c_batch_stride", I64), ("c_row_stride", I64), ("c_rows_out", I32), ("M", I32), ("N", I32), ("act_slope", F32),
+                ("accumulate", I32)]
+
+
+class TnProblem(C.Structure):
+    """struct tg_gemm_tn_problem"""
+    _fields_ = [("dY", P), ("ldy", I64), ("A", Window), ("dW", P), ("ldw", I64), ("M", I32), ("N", I32), ("out_kw", I32), ("reserved", I32),
+                ("dbias", P), ("ws", P), ("ws_floats", I64)]
+
+
+MAX_GROUP = 8
+
 # name -> argtypes (all return int); mirrors include/trimodal_hip.h one to one
 SIGNATURES = {
     "tg_gemm_nt": [WP, P, I64, P, P, I64, I64, I32, I32, I32, F32, I32, P],
+    "tg_gemm_nt_group": [C.POINTER(NtProblem), I32, P],
+    "tg_gemm_tn_group": [C.POINTER(TnProblem), I32, P],
     "tg_gemm_tn": [P, I64, WP, P, I64, I32, I32, I32, P, P, I64, P],
     "tg_colsum": [P, I64, I32, I32, P, I32, P],
     "tg_gru_forward": [P, I64, P, P, P, P, P, P, I64, I32, I32, I32, P],
@@ -90,6 +108,8 @@ def load():
     lib.tg_last_error.restype = C.c_char_p
     lib.tg_gemm_tn_ws_floats.restype = C.c_int64
     lib.tg_gemm_tn_ws_floats.argtypes = [I32, I32, I32]
+    lib.tg_gemm_nt_family.restype = C.c_int32
+    lib.tg_gemm_nt_family.argtypes = [C.POINTER(NtProblem)]
     lib.tg_set_math_mode.restype = C.c_int
     lib.tg_set_math_mode.argtypes = [I32]
     lib.tg_get_math_mode.restype = C.c_int

@@ -62,6 +62,60 @@ inline Win to_win(const tg_window* w) {
     return d;
 }
 
+// ---- grouped launches ---------------------------------------------------------------------------------------------------------
+// Several independent products of one layer (both GRU directions' input projections, the four weight gradients of a GRU layer, the
+// stride phases of a conv input-gradient ...) run as ONE launch: the problem table travels BY VALUE in the kernel arguments (safe
+// under hipGraph capture), workgroup ranges [wg_begin[i], wg_begin[i+1]) belong to problem i.
+constexpr int TG_MAX_GROUP = 8;
+
+struct NtProb {
+    Win A;
+    const float* Bw;
+    long ldb;
+    long b_seg_stride;       // K-concatenated weights: k in [s * b_seg_k, (s+1) * b_seg_k) reads Bw + s * b_seg_stride + n * ldb + (k - s * b_seg_k)
+    int b_seg_k;             // (== K: one weight matrix)
+    const float* bias;
+    float* C;
+    long cbs, crs;
+    int cR, M, N;
+    float slope;
+    int accumulate;
+    int n_nt;
+};
+
+struct NtGroup {
+    int n;
+    int wg_begin[TG_MAX_GROUP + 1];
+    NtProb p[TG_MAX_GROUP];
+};
+
+struct TnProb {
+    const float* dY;
+    long ldy;
+    Win A;
+    float* dW;
+    long ldw;
+    int M, N, rows_per_split, out_kw;
+    float* partial;
+    float* dbias;
+    int vec_y, vec_a, n_nt, n_kt;
+};
+
+struct TnGroup {
+    int n;
+    int wg_begin[TG_MAX_GROUP + 1];
+    TnProb p[TG_MAX_GROUP];
+};
+
+// index of the problem that owns workgroup `bid` (wave-uniform)
+template <typename G>
+__device__ __forceinline__ int group_find(const G& g, int bid) {
+    int i = 0;
+#pragma unroll
+    for (int q = 1; q < TG_MAX_GROUP; ++q) i += (q < g.n && bid >= g.wg_begin[q]) ? 1 : 0;
+    return i;
+}
+
 // XCD-aware workgroup order.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with a private
 // 4 MB L2), so neighbours in id space -- which here share a weight slice or an activation panel -- land on eight
 // different L2s and every one of them re-fetches the shared operand from Infinity Cache / HBM.  This bijection hands each

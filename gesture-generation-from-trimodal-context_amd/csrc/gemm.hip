@@ -56,15 +56,24 @@ __device__ __forceinline__ void load_nt_frags(const Win& A, const long (&a_off)[
 
 // Workgroup = 4 waves arranged WM x WN, each wave a 32x32 output tile (2x2 MFMA tiles of 16x16).
 template <bool VEC, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(Win A, const float* __restrict__ Bw, long ldb,
-                                                      const float* __restrict__ bias, float* __restrict__ C, long cbs,
-                                                      long crs, int cR, int M, int N, float slope, int accumulate, int n_nt) {
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
+    const int pi = group_find(g, blockIdx.x);
+    const NtProb& pr = g.p[pi];
+    const Win A = pr.A;
+    const float* __restrict__ Bw = pr.Bw;
+    const long ldb = pr.ldb;
+    const float* __restrict__ bias = pr.bias;
+    float* __restrict__ C = pr.C;
+    const long cbs = pr.cbs, crs = pr.crs;
+    const int cR = pr.cR, M = pr.M, N = pr.N, accumulate = pr.accumulate, n_nt = pr.n_nt;
+    const float slope = pr.slope;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, kq = lane >> 4;
     // logical order: output-column tile fastest -> the workgroups that re-read one A row panel sit on ONE XCD's L2
-    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    // (every problem's workgroup range starts at a multiple of 8, so bid & 7 still names the XCD)
+    const int lid = xcd_chunked_id(blockIdx.x - g.wg_begin[pi], g.wg_begin[pi + 1] - g.wg_begin[pi]);
     const int m_base = (lid / n_nt) * (WM * 32) + wm * 32;
     const int n_base = (lid % n_nt) * (WN * 32) + wn * 32;
     if (m_base >= M || n_base >= N) return;   // no LDS, no barriers: a whole wave may leave
@@ -165,9 +174,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Win A, const float* __rest
 // The tile is chosen per shape by nt_pick_tile(): the f32 pipe sustains ~100 TFLOP/s on real data whatever the tile
 // (tools/gemm_lab.hip), so what matters is tile quantisation and filling 256 CUs x 3 workgroups.
 template <int TM, int TN, int BK = 16>
-__global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __restrict__ Bw, long ldb,
-                                                          const float* __restrict__ bias, float* __restrict__ C, long cbs,
-                                                          long crs, int cR, int M, int N, float slope, int accumulate, int n_nt) {
+__global__ __launch_bounds__(256) void gemm_nt_big_kernel(const NtGroup g) {
+    const int pi = group_find(g, blockIdx.x);
+    const NtProb& pr = g.p[pi];
+    const Win A = pr.A;
+    const float* __restrict__ Bw = pr.Bw;
+    const long ldb = pr.ldb, b_seg_stride = pr.b_seg_stride;
+    const int b_seg_k = pr.b_seg_k;
+    const float* __restrict__ bias = pr.bias;
+    float* __restrict__ C = pr.C;
+    const long cbs = pr.cbs, crs = pr.crs;
+    const int cR = pr.cR, M = pr.M, N = pr.N, accumulate = pr.accumulate, n_nt = pr.n_nt;
+    const float slope = pr.slope;
     constexpr int BM = 32 * TM, BN = 32 * TN;         // workgroup tile
     constexpr int PPR = BK / 4;                       // 16-byte pieces per slab row
     constexpr int RPP = 256 / PPR;                    // slab rows staged per pass of the 256 threads
@@ -180,8 +198,9 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int lid = xcd_chunked_id(blockIdx.x - g.wg_begin[pi], g.wg_begin[pi + 1] - g.wg_begin[pi]);
     const int m0 = (lid / n_nt) * BM, n0 = (lid % n_nt) * BN;
+    if (m0 >= M) return;                               // padding workgroup of a grouped launch (uniform: before any barrier)
     const int K = A.K;
 
     // staging role: row (t / PPR) [+RPP per extra piece], 16-byte piece (t % PPR) of the BK-deep slab
@@ -208,6 +227,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
         b_ptr[i] = Bw + (long)(b_ok[i] ? n : 0) * ldb;
     }
     int kk = sk / A.cw, c = sk - (sk / A.cw) * A.cw;   // tap / channel of this thread's piece, advanced by BK per slab
+    int bsg = sk / b_seg_k, bc = sk - (sk / b_seg_k) * b_seg_k;   // weight segment / column inside it, likewise
 
     f32x4 ga[NPA], gb[NPB];
     auto fetch = [&](int k0) {
@@ -223,10 +243,12 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(Win A, const float* __
 #pragma unroll
         for (int i = 0; i < NPB; ++i) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            gb[i] = (b_ok[i] && inb) ? *reinterpret_cast<const f32x4*>(b_ptr[i] + k) : z;
+            gb[i] = (b_ok[i] && inb) ? *reinterpret_cast<const f32x4*>(b_ptr[i] + bsg * b_seg_stride + bc) : z;
         }
         c += BK;
         while (c >= A.cw) { c -= A.cw; ++kk; }
+        bc += BK;
+        while (bc >= b_seg_k) { bc -= b_seg_k; ++bsg; }
     };
 
     f32x4 acc[TM][TN];
@@ -309,10 +331,17 @@ static NtTile nt_pick_tile(int M, int N) {
 // flight while the current slab's MR/4 * WTN * WTK MFMAs per wave run: one barrier per slab.  <2, 2, 16> (64 x 64 tile) is the
 // configuration in use; larger ones (<4, 2, 32>: 128 x 64, 64 MFMAs per wave per barrier) compile but measured slower here.
 template <int WTN, int WTK, int MR>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, long ldy, Win A, float* __restrict__ dW,
-                                                      long ldw, int M, int N, int rows_per_split, int out_kw,
-                                                      float* __restrict__ partial, float* __restrict__ dbias, int vec_y, int vec_a,
-                                                      int n_nt, int n_kt) {
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnGroup g) {
+    const int pi = group_find(g, blockIdx.x);
+    const TnProb& pr = g.p[pi];
+    const float* __restrict__ dY = pr.dY;
+    const long ldy = pr.ldy, ldw = pr.ldw;
+    const Win A = pr.A;
+    float* __restrict__ dW = pr.dW;
+    const int M = pr.M, N = pr.N, rows_per_split = pr.rows_per_split, out_kw = pr.out_kw;
+    float* __restrict__ partial = pr.partial;
+    float* __restrict__ dbias = pr.dbias;
+    const int vec_y = pr.vec_y, vec_a = pr.vec_a, n_nt = pr.n_nt, n_kt = pr.n_kt;
     constexpr int BN = 32 * WTN, BC = 32 * WTK;            // tile of dW: BN rows (n) x BC columns (k)
     constexpr int LDY = BN + 4, LDX = BC + 4;
     constexpr int PY = BN / 4, PX = BC / 4;                // 16-byte pieces per slab row
@@ -325,11 +354,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     const int r16 = lane & 15, mq = lane >> 4;
     const int wn = wave >> 1, wk = wave & 1;
     // logical order: (n tile, k tile) fastest, split slowest -> the tiles that re-read one chunk of rows share an XCD
-    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int lid = xcd_chunked_id(blockIdx.x - g.wg_begin[pi], g.wg_begin[pi + 1] - g.wg_begin[pi]);
     const int tn_n = lid % n_nt, tn_k = (lid / n_nt) % n_kt, tn_s = lid / (n_nt * n_kt);
     const int n0 = tn_n * BN, k0 = tn_k * BC;
     const int K = A.K;
     const int m_begin = tn_s * rows_per_split;
+    if (m_begin >= M) return;                              // padding workgroup of a grouped launch (uniform: before any barrier)
     const int m_end = min(M, m_begin + rows_per_split);
 
     // staging roles: dY piece i = row (t / PY) + i * (256 / PY), columns 4 * (t % PY) .. +3; A piece likewise with PX
@@ -464,20 +494,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 }
 
 // Deterministic combine of the split-M partial tiles: fp64 sum over the splits in a fixed order, one rounding, += into dW.
-// One (n, k) entry per 16 threads: the split axis is strided over them, then summed in lane order.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int splits, int N, int K, int cw, int out_kw,
-                                                        float* __restrict__ dW, long ldw) {
+// One (n, k) entry per SUB consecutive threads (SUB = 16 or 256: the ~2000 splits of the audio conv1 gradient, whose output has only
+// 240 entries, need a whole workgroup per entry -- 16 threads per entry took 65 us there): the split axis is strided over them, the
+// partial sums are then added in lane order.
+template <int SUB>
+__global__ __launch_bounds__(256) void tn_reduce_kernel_t(const float* __restrict__ partial, int splits, int N, int K, int cw, int out_kw,
+                                                          float* __restrict__ dW, long ldw) {
     __shared__ double sh[256];
+    constexpr int EPW = 256 / SUB;                  // entries per workgroup and iteration
     const long total = (long)N * K;
-    const int sub = threadIdx.x & 15;
-    const long n_iter = (total + 15) / 16;          // every thread of a workgroup runs the same number of iterations
+    const int sub = threadIdx.x % SUB;
+    const long n_iter = (total + EPW - 1) / EPW;    // every thread of a workgroup runs the same number of iterations
     for (long it = blockIdx.x; it < n_iter; it += gridDim.x) {
-        const long i = it * 16 + (threadIdx.x >> 4);
+        const long i = it * EPW + threadIdx.x / SUB;
         double s = 0.0;
         if (i < total)
-            for (int q = sub; q < splits; q += 16) s += (double)partial[(long)q * total + i];
+            for (int q = sub; q < splits; q += SUB) s += (double)partial[(long)q * total + i];
         sh[threadIdx.x] = s;
         __syncthreads();
+#pragma unroll
+        for (int w = SUB / 2; w >= 16; w >>= 1) {   // tree down to 16 partials per entry (fixed order)
+            if (sub < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+            __syncthreads();
+        }
         if (sub == 0 && i < total) {
             double tot = 0.0;
 #pragma unroll
@@ -512,8 +551,7 @@ using namespace tg;
 // bf16 matrix-core path of the big products (gemm_split.hip): three-way operand split at fp32 accuracy (math mode 0, default) or
 // plain bf16 operands (math mode 1).  TG_GEMM_X3=0 in the environment keeps math mode 0 on the f32-MFMA kernels below.
 extern "C" int tg_get_math_mode(void);
-int tg_gemm_nt_split_launch(const Win& w, const float* Bw, long ldb, const float* bias, float* C, long cbs, long crs, int cR, int M,
-                            int N, float slope, int accumulate, hipStream_t s);
+int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s);
 static bool use_split_path() {
     static int x3 = -1;
     if (x3 < 0) {
@@ -530,43 +568,103 @@ static int check_window(const tg_window* w, const char* who) {
     return 0;
 }
 
-extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bias, float* C,
-                          int64_t c_batch_stride, int64_t c_row_stride, int32_t c_rows_out, int32_t M, int32_t N,
-                          float act_slope, int32_t accumulate, void* stream) {
-    if (int e = check_window(A, "tg_gemm_nt")) return e;
-    TG_REQUIRE(Bw && C, "tg_gemm_nt: null pointer");
-    TG_REQUIRE(M > 0 && N > 0 && c_rows_out > 0 && ldb >= A->K, "tg_gemm_nt: bad sizes M=%d N=%d ldb=%ld K=%d", M, N, (long)ldb, A->K);
-    Win w = to_win(A);
-    const bool vec = (w.cw % 4 == 0) && (w.K % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr) &&
-                     (ldb % 4 == 0) && aligned16(Bw);
-    hipStream_t s = (hipStream_t)stream;
-    if (vec && N >= 48 && M >= 1024 && w.K >= 64 && use_split_path())
-        return tg_gemm_nt_split_launch(w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope,
-                                       accumulate, s);
-    if (vec && N >= 48 && M >= 1024 && w.K >= 64) {
-        const NtTile tl = nt_pick_tile(M, N);
-        const int n_nt = cdiv(N, 32 * tl.tn);
-        const dim3 grid(cdiv(M, 32 * tl.tm) * n_nt);
-#define TG_NT_BIG(TM_, TN_) hipLaunchKernelGGL((gemm_nt_big_kernel<TM_, TN_>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, \
-                                               (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt)
+// kernel family of one product: 0 = big (LDS-staged: split-bf16 or f32 tiles), 1 = narrow (N <= 32), 2 = small 64 x 64
+static bool nt_vec(const NtProb& p) {
+    const Win& w = p.A;
+    return (w.cw % 4 == 0) && (w.K % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr) && (p.ldb % 4 == 0) && aligned16(p.Bw) &&
+           (p.b_seg_k % 4 == 0) && (p.b_seg_stride % 4 == 0);
+}
+static int nt_family(const NtProb& p) {
+    if (nt_vec(p) && p.N >= 48 && p.M >= 1024 && p.A.K >= 64) return 0;
+    return p.N <= 32 ? 1 : 2;
+}
+
+// Lay the problems of a group out over one grid: every problem's workgroup range starts at a multiple of 8 (the XCD round-robin
+// then still maps bid & 7 to the XCD inside each problem); the padding workgroups find m0 >= M and leave.
+static int nt_layout(NtGroup& g, int bm, int bn) {
+    int wg = 0;
+    for (int i = 0; i < g.n; ++i) {
+        g.p[i].n_nt = cdiv(g.p[i].N, bn);
+        g.wg_begin[i] = wg;
+        wg += (cdiv(g.p[i].M, bm) * g.p[i].n_nt + 7) / 8 * 8;
+    }
+    for (int i = g.n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
+    return wg;
+}
+
+static int nt_launch(NtGroup& g, hipStream_t s) {
+    const int fam = nt_family(g.p[0]);
+    bool vec = true;
+    for (int i = 0; i < g.n; ++i) {
+        TG_REQUIRE(nt_family(g.p[i]) == fam, "tg_gemm_nt_group: problem %d does not fit the kernel family of problem 0 (M=%d N=%d K=%d)", i,
+                   g.p[i].M, g.p[i].N, g.p[i].A.K);
+        vec = vec && nt_vec(g.p[i]);
+        TG_REQUIRE(fam == 0 || g.p[i].b_seg_k == g.p[i].A.K, "tg_gemm_nt: K-concatenated weights need the big-product path (problem %d)", i);
+    }
+    if (fam == 0 && use_split_path()) return tg_gemm_nt_split_launch(g, s);
+    if (fam == 0) {
+        int Mx = 0, Nx = 0;
+        for (int i = 0; i < g.n; ++i) { Mx = Mx > g.p[i].M ? Mx : g.p[i].M; Nx = Nx > g.p[i].N ? Nx : g.p[i].N; }
+        const NtTile tl = nt_pick_tile(Mx * g.n, Nx);
+        const dim3 grid(nt_layout(g, 32 * tl.tm, 32 * tl.tn));
+#define TG_NT_BIG(TM_, TN_) hipLaunchKernelGGL((gemm_nt_big_kernel<TM_, TN_>), grid, dim3(256), 0, s, g)
         if (tl.tm == 4 && tl.tn == 4) TG_NT_BIG(4, 4);
         else if (tl.tm == 4 && tl.tn == 3) TG_NT_BIG(4, 3);
         else if (tl.tm == 4 && tl.tn == 2) TG_NT_BIG(4, 2);
         else if (tl.tm == 2 && tl.tn == 2) TG_NT_BIG(2, 2);
         else TG_NT_BIG(2, 1);
 #undef TG_NT_BIG
-    } else if (N <= 32) {
-        const int n_nt = cdiv(N, 32);
-        dim3 grid(cdiv(M, 128) * n_nt);
-        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
-        else     hipLaunchKernelGGL((gemm_nt_kernel<false, 4, 1>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
+    } else if (fam == 1) {
+        const dim3 grid(nt_layout(g, 128, 32));
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1>), grid, dim3(256), 0, s, g);
+        else     hipLaunchKernelGGL((gemm_nt_kernel<false, 4, 1>), grid, dim3(256), 0, s, g);
     } else {
-        const int n_nt = cdiv(N, 64);
-        dim3 grid(cdiv(M, 64) * n_nt);
-        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 2, 2>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
-        else     hipLaunchKernelGGL((gemm_nt_kernel<false, 2, 2>), grid, dim3(256), 0, s, w, Bw, (long)ldb, bias, C, (long)c_batch_stride, (long)c_row_stride, c_rows_out, M, N, act_slope, accumulate, n_nt);
+        const dim3 grid(nt_layout(g, 64, 64));
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 2, 2>), grid, dim3(256), 0, s, g);
+        else     hipLaunchKernelGGL((gemm_nt_kernel<false, 2, 2>), grid, dim3(256), 0, s, g);
     }
     return check_launch("tg_gemm_nt");
+}
+
+static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
+    if (int e = check_window(&q.A, "tg_gemm_nt")) return e;
+    TG_REQUIRE(q.Bw && q.C, "tg_gemm_nt: null pointer (problem %d)", idx);
+    TG_REQUIRE(q.M > 0 && q.N > 0 && q.c_rows_out > 0, "tg_gemm_nt: bad sizes M=%d N=%d (problem %d)", q.M, q.N, idx);
+    const int seg = q.b_seg_k > 0 ? q.b_seg_k : q.A.K;
+    TG_REQUIRE(q.A.K % seg == 0 && q.ldb >= seg, "tg_gemm_nt: weight segments of %d do not tile K=%d / ldb=%ld (problem %d)", seg, q.A.K,
+               (long)q.ldb, idx);
+    p.A = to_win(&q.A);
+    p.Bw = q.Bw; p.ldb = (long)q.ldb; p.b_seg_k = seg; p.b_seg_stride = q.b_seg_k > 0 ? (long)q.b_seg_stride : 0;
+    p.bias = q.bias; p.C = q.C; p.cbs = (long)q.c_batch_stride; p.crs = (long)q.c_row_stride; p.cR = q.c_rows_out;
+    p.M = q.M; p.N = q.N; p.slope = q.act_slope; p.accumulate = q.accumulate; p.n_nt = 0;
+    return 0;
+}
+
+extern "C" int32_t tg_gemm_nt_family(const tg_gemm_nt_problem* problem) {
+    NtProb p;
+    if (!problem || nt_fill(p, *problem, 0)) return -1;
+    return nt_family(p);
+}
+
+extern "C" int tg_gemm_nt_group(const tg_gemm_nt_problem* problems, int32_t n, void* stream) {
+    TG_REQUIRE(problems && n >= 1 && n <= TG_MAX_GROUP, "tg_gemm_nt_group: 1..%d problems", TG_MAX_GROUP);
+    NtGroup g;
+    g.n = n;
+    for (int i = 0; i < n; ++i)
+        if (int e = nt_fill(g.p[i], problems[i], i)) return e;
+    for (int i = n; i < TG_MAX_GROUP; ++i) g.p[i] = g.p[0];
+    return nt_launch(g, (hipStream_t)stream);
+}
+
+extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bias, float* C,
+                          int64_t c_batch_stride, int64_t c_row_stride, int32_t c_rows_out, int32_t M, int32_t N,
+                          float act_slope, int32_t accumulate, void* stream) {
+    TG_REQUIRE(A, "tg_gemm_nt: null window");
+    tg_gemm_nt_problem q;
+    q.A = *A; q.Bw = Bw; q.ldb = ldb; q.b_seg_k = 0; q.b_seg_stride = 0; q.bias = bias; q.C = C; q.c_batch_stride = c_batch_stride;
+    q.c_row_stride = c_row_stride; q.c_rows_out = c_rows_out; q.M = M; q.N = N; q.act_slope = act_slope; q.accumulate = accumulate;
+    TG_REQUIRE(ldb >= A->K, "tg_gemm_nt: ldb=%ld < K=%d", (long)ldb, A->K);
+    return tg_gemm_nt_group(&q, 1, stream);
 }
 
 // Split plan of a weight gradient: 64 x 64 tiles of dW (the 128 x 64 / 32-row-slab configuration <4, 2, 32> of the kernel measured
@@ -591,34 +689,70 @@ static void tn_plan(int M, int N, int K, bool two_pass, int* splits_out, int* ro
     *splits_out = cdiv(M, rows);
 }
 
+static void launch_tn_reduce(const float* partial, int splits, int N, int K, int cw, int out_kw, float* dW, long ldw, hipStream_t s) {
+    const long total = (long)N * K;
+    if (splits >= 512) {
+        const long blocks = total > 4096 ? 4096 : total;
+        hipLaunchKernelGGL(tn_reduce_kernel_t<256>, dim3((int)blocks), dim3(256), 0, s, partial, splits, N, K, cw, out_kw, dW, ldw);
+    } else {
+        long blocks = (total + 15) / 16;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(tn_reduce_kernel_t<16>, dim3((int)blocks), dim3(256), 0, s, partial, splits, N, K, cw, out_kw, dW, ldw);
+    }
+}
+
 extern "C" int64_t tg_gemm_tn_ws_floats(int32_t M, int32_t N, int32_t K) {
     int splits, rows;
     tn_plan(M, N, K, true, &splits, &rows);
     return (int64_t)splits * N * K;
 }
 
+static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int* splits_out) {
+    if (int e = check_window(&q.A, "tg_gemm_tn")) return e;
+    TG_REQUIRE(q.dY && q.dW && q.M > 0 && q.N > 0 && q.ldy >= q.N && q.ldw >= q.A.K, "tg_gemm_tn: bad arguments (problem %d)", idx);
+    TG_REQUIRE(q.out_kw == 0 || q.out_kw * q.A.cw == q.A.K, "tg_gemm_tn: out_kw=%d must be 0 or K/cw (problem %d)", q.out_kw, idx);
+    p.A = to_win(&q.A);
+    int splits, rows_per_split;
+    tn_plan(q.M, q.N, p.A.K, q.ws != nullptr, &splits, &rows_per_split);
+    TG_REQUIRE(q.ws == nullptr || q.ws_floats >= (int64_t)splits * q.N * p.A.K, "tg_gemm_tn: workspace too small (%ld < %ld floats, problem %d)",
+               (long)q.ws_floats, (long)splits * q.N * p.A.K, idx);
+    p.dY = q.dY; p.ldy = (long)q.ldy; p.dW = q.dW; p.ldw = (long)q.ldw; p.M = q.M; p.N = q.N; p.rows_per_split = rows_per_split;
+    p.out_kw = q.out_kw; p.partial = q.ws; p.dbias = q.dbias;
+    p.vec_y = (q.ldy % 4 == 0) && aligned16(q.dY);
+    p.vec_a = (p.A.cw % 4 == 0) && (p.A.bs % 4 == 0) && (p.A.rs % 4 == 0) && aligned16(p.A.ptr);
+    p.n_nt = cdiv(q.N, 64); p.n_kt = cdiv(p.A.K, 64);
+    *splits_out = splits;
+    return 0;
+}
+
+extern "C" int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, void* stream) {
+    TG_REQUIRE(problems && n >= 1 && n <= TG_MAX_GROUP, "tg_gemm_tn_group: 1..%d problems", TG_MAX_GROUP);
+    TnGroup g;
+    g.n = n;
+    int splits[TG_MAX_GROUP], wg = 0;
+    for (int i = 0; i < n; ++i) {
+        if (int e = tn_fill(g.p[i], problems[i], i, &splits[i])) return e;
+        g.wg_begin[i] = wg;
+        wg += (g.p[i].n_nt * g.p[i].n_kt * splits[i] + 7) / 8 * 8;
+    }
+    for (int i = n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
+    for (int i = n; i < TG_MAX_GROUP; ++i) g.p[i] = g.p[0];
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 16>), dim3(wg), dim3(256), 0, s, g);
+    for (int i = 0; i < n; ++i)
+        if (g.p[i].partial) {       // deterministic fp64 combine of this problem's split partials
+            const TnProb& p = g.p[i];
+            launch_tn_reduce(p.partial, splits[i], p.N, p.A.K, p.A.cw, p.out_kw, p.dW, p.ldw, s);
+        }
+    return check_launch("tg_gemm_tn");
+}
+
 extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,
                           int32_t out_kw, float* dbias, float* ws, int64_t ws_floats, void* stream) {
-    if (int e = check_window(A, "tg_gemm_tn")) return e;
-    TG_REQUIRE(dY && dW && M > 0 && N > 0 && ldy >= N && ldw >= A->K, "tg_gemm_tn: bad arguments");
-    TG_REQUIRE(out_kw == 0 || out_kw * A->cw == A->K, "tg_gemm_tn: out_kw=%d must be 0 or K/cw", out_kw);
-    Win w = to_win(A);
-    int splits, rows_per_split;
-    tn_plan(M, N, w.K, ws != nullptr, &splits, &rows_per_split);
-    TG_REQUIRE(ws == nullptr || ws_floats >= (int64_t)splits * N * w.K, "tg_gemm_tn: workspace too small (%ld < %ld floats)",
-               (long)ws_floats, (long)splits * N * w.K);
-    const int vec_y = (ldy % 4 == 0) && aligned16(dY);
-    const int vec_a = (w.cw % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr);
-    const int n_nt = cdiv(N, 64), n_kt = cdiv(w.K, 64);
-    dim3 grid(n_nt * n_kt * splits);
-    hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 16>), grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, w, dW, (long)ldw, M, N,
-                       rows_per_split, out_kw, ws, dbias, vec_y, vec_a, n_nt, n_kt);
-    if (ws) {
-        int blocks = cdiv((long)N * w.K, 16);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, splits, N, w.K, w.cw, out_kw, dW, (long)ldw);
-    }
-    return check_launch("tg_gemm_tn");
+    TG_REQUIRE(A, "tg_gemm_tn: null window");
+    tg_gemm_tn_problem q;
+    q.dY = dY; q.ldy = ldy; q.A = *A; q.dW = dW; q.ldw = ldw; q.M = M; q.N = N; q.out_kw = out_kw; q.dbias = dbias; q.ws = ws; q.ws_floats = ws_floats;
+    return tg_gemm_tn_group(&q, 1, stream);
 }
 
 extern "C" int tg_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream) {

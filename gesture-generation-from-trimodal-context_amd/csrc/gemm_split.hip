@@ -52,9 +52,18 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
 // C(m, n) = act(sum_k A(m,k) * Bw[n][k] + bias[n]) (+ C).  A: fp32 row window (vectorisable layout: checked by the caller),
 // Bw: fp32 [N][ldb].  Same contract as gemm_nt_big_kernel (gemm.hip).
 template <int TM, int TN, int SPLITS, int DB>
-__global__ __launch_bounds__(256) void gemm_nt_split_kernel(Win A, const float* __restrict__ Bw, long ldb,
-                                                            const float* __restrict__ bias, float* __restrict__ C, long cbs,
-                                                            long crs, int cR, int M, int N, float slope, int accumulate, int n_nt) {
+__global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
+    const int pi = group_find(g, blockIdx.x);
+    const NtProb& pr = g.p[pi];
+    const Win A = pr.A;
+    const float* __restrict__ Bw = pr.Bw;
+    const long ldb = pr.ldb, b_seg_stride = pr.b_seg_stride;
+    const int b_seg_k = pr.b_seg_k;
+    const float* __restrict__ bias = pr.bias;
+    float* __restrict__ C = pr.C;
+    const long cbs = pr.cbs, crs = pr.crs;
+    const int cR = pr.cR, M = pr.M, N = pr.N, accumulate = pr.accumulate, n_nt = pr.n_nt;
+    const float slope = pr.slope;
     constexpr int BM = 32 * TM, BN = 32 * TN;
     constexpr int NPA = BM / 32, NPB = BN / 32;               // f32x4 pieces per thread per slab (8 pieces per 32-deep row)
     constexpr int NS = SPLITS;
@@ -63,8 +72,9 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(Win A, const float* 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int lid = xcd_chunked_id(blockIdx.x - g.wg_begin[pi], g.wg_begin[pi + 1] - g.wg_begin[pi]);
     const int m0 = (lid / n_nt) * BM, n0 = (lid % n_nt) * BN;
+    if (m0 >= M) return;                                       // padding workgroup of a grouped launch (uniform: before any barrier)
     const int K = A.K;
 
     // staging map: 8 consecutive lanes cover one 128-byte row piece of the slab (32 fp32): whole cache lines per load instruction;
@@ -91,6 +101,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(Win A, const float* 
         b_ptr[q] = Bw + (long)(b_ok[q] ? n : 0) * ldb;
     }
     int kk = sp / A.cw, c = sp - (sp / A.cw) * A.cw;          // tap / channel of this thread's piece, advanced by 32 per slab
+    int bsg = sp / b_seg_k, bc = sp - (sp / b_seg_k) * b_seg_k;   // weight segment / column inside it, likewise
 
     f32x4 ga[NPA], gb[NPB];
     auto fetch = [&](int k0) {
@@ -110,11 +121,13 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(Win A, const float* 
 #pragma unroll
         for (int q = 0; q < NPB; ++q) {
             const bool ok = b_ok[q] && inb;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? b_ptr[q] + k : Bw);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? b_ptr[q] + bsg * b_seg_stride + bc : Bw);
             gb[q] = ok ? v : z;
         }
         c += 32;
         while (c >= A.cw) { c -= A.cw; ++kk; }
+        bc += 32;
+        while (bc >= b_seg_k) { bc -= b_seg_k; ++bsg; }
     };
 
     f32x4 acc[TM][TN];
@@ -218,13 +231,20 @@ static SplitTile split_pick_tile(int M, int N) {
     return {2, 2, 1};
 }
 
-int tg_gemm_nt_split_launch(const Win& w, const float* Bw, long ldb, const float* bias, float* C, long cbs, long crs, int cR, int M,
-                            int N, float slope, int accumulate, hipStream_t s) {
-    const SplitTile tl = split_pick_tile(M, N);
-    const int n_nt = cdiv(N, 32 * tl.tn);
-    const dim3 grid(cdiv(M, 32 * tl.tm) * n_nt);
-#define TG_SPLIT(TM_, TN_, SP_, DB_) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_>), grid, dim3(256), 0, s, w, Bw, ldb, bias, C, \
-                                                        cbs, crs, cR, M, N, slope, accumulate, n_nt)
+int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
+    int Mx = 0, Nx = 0;
+    for (int i = 0; i < g.n; ++i) { Mx = Mx > g.p[i].M ? Mx : g.p[i].M; Nx = Nx > g.p[i].N ? Nx : g.p[i].N; }
+    const SplitTile tl = split_pick_tile(Mx * g.n, Nx);
+    const int bm = 32 * tl.tm, bn = 32 * tl.tn;
+    int wg = 0;
+    for (int i = 0; i < g.n; ++i) {             // every problem's range starts at a multiple of 8 (XCD mapping, see gemm.hip nt_layout)
+        g.p[i].n_nt = cdiv(g.p[i].N, bn);
+        g.wg_begin[i] = wg;
+        wg += (cdiv(g.p[i].M, bm) * g.p[i].n_nt + 7) / 8 * 8;
+    }
+    for (int i = g.n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
+    const dim3 grid(wg);
+#define TG_SPLIT(TM_, TN_, SP_, DB_) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_>), grid, dim3(256), 0, s, g)
 #define TG_SPLIT_MENU(SP_)                                              \
     do {                                                                \
         if (tl.tm == 4 && tl.tn == 3 && !tl.db) TG_SPLIT(4, 3, SP_, 0); \

@@ -180,12 +180,14 @@ def conv_dgrad(dy, w, L_in, *, stride=1):
     packed = empty(stride, Ci, J * Co, like=w)
     ops.conv_dgrad_pack(w, packed, stride)
     dx = empty(B, L_in, Ci, like=w)
+    probs = []
     for r in range(stride):
         nq = (L_in - r + stride - 1) // stride
         if nq <= 0:
             continue
-        A = Win.taps(dy, J, shift=0, dil=-1, rows_out=nq)
-        ops.gemm_nt(A, packed[r], None, dx[:, r:, :], c_batch_stride=dx.stride(0), c_row_stride=stride * Ci, c_rows_out=nq)
+        probs.append(dict(A=Win.taps(dy, J, shift=0, dil=-1, rows_out=nq), W=packed[r], bias=None, out=dx[:, r:, :],
+                          c_batch_stride=dx.stride(0), c_row_stride=stride * Ci, c_rows_out=nq))
+    ops.gemm_nt_group(probs)                     # the stride phases write disjoint rows of dx: one launch
     return dx
 
 
@@ -283,9 +285,9 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     for l in range(n_layers):
         Kin = cur.shape[2]
         gi = empty(2, B, T, 3 * H, like=x)
-        for d, sfx in enumerate(("", "_reverse")):
-            ops.gemm_nt(Win.plain(cur.view(B * T, Kin)), P[f"{prefix}.weight_ih_l{l}{sfx}"], P[f"{prefix}.bias_ih_l{l}{sfx}"],
-                        gi[d].view(B * T, 3 * H))
+        a_win = Win.plain(cur.view(B * T, Kin))
+        ops.gemm_nt_group([dict(A=a_win, W=P[f"{prefix}.weight_ih_l{l}{sfx}"], bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
+                                out=gi[d].view(B * T, 3 * H)) for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
         y = empty(B, T, 2 * H, like=x)
         sv = empty(2, B, T, 4 * H, like=x) if save else None
         whh = (P[f"{prefix}.weight_hh_l{l}"], P[f"{prefix}.weight_hh_l{l}_reverse"])
@@ -389,19 +391,29 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
         if param_grads:
             fk.keep(dgi, dgh, x_l, y_l)
             with fk:
+                probs = []
+                x_win = Win.plain(x_l.reshape(nb * T, Kin))
                 for d, sfx in enumerate(("", "_reverse")):
                     gi2, gh2 = dgi[d].view(nb * T, 3 * H), dgh[d].view(nb * T, 3 * H)
-                    ops.gemm_tn(gi2, Win.plain(x_l.reshape(nb * T, Kin)), G[f"{prefix}.weight_ih_l{l}{sfx}"],
-                                dbias=G[f"{prefix}.bias_ih_l{l}{sfx}"])
+                    probs.append(dict(dY=gi2, A=x_win, dW=G[f"{prefix}.weight_ih_l{l}{sfx}"], dbias=G[f"{prefix}.bias_ih_l{l}{sfx}"]))
                     # h_{t-1} of direction d is the layer output one step back (forward) / ahead (reverse), zero at the ends
                     hwin = Win.taps(y_l[:, :, d * H:(d + 1) * H], 1, shift=(1 if d else -1), dil=1, rows_out=T)
-                    ops.gemm_tn(gh2, hwin, G[f"{prefix}.weight_hh_l{l}{sfx}"], dbias=G[f"{prefix}.bias_hh_l{l}{sfx}"])
+                    probs.append(dict(dY=gh2, A=hwin, dW=G[f"{prefix}.weight_hh_l{l}{sfx}"], dbias=G[f"{prefix}.bias_hh_l{l}{sfx}"]))
+                ops.gemm_tn_group(probs)                 # the layer's four weight gradients (+ four bias gradients), one launch
         dx = None
         if need_dx or l > 0:
             dx = empty(nb * T, Kin, like=dy)
-            for d, sfx in enumerate(("", "_reverse")):
-                ops.gemm_nt(Win.plain(dgi[d].view(nb * T, 3 * H)), transpose2d(P[f"{prefix}.weight_ih_l{l}{sfx}"]), None, dx,
-                            accumulate=(d == 1))
+            wt_ih = [transpose2d(P[f"{prefix}.weight_ih_l{l}{sfx}"]) for sfx in ("", "_reverse")]          # [Kin][3H] each
+            seg = (wt_ih[1].data_ptr() - wt_ih[0].data_ptr()) // 4
+            if nb * T >= 1024 and Kin >= 48 and (wt_ih[1].data_ptr() - wt_ih[0].data_ptr()) % 16 == 0:
+                # dx = [dgi_fwd | dgi_rev] @ [W_ih_fwd ; W_ih_rev]: ONE product over the concatenated K = 6H -- the two directions are
+                # two "taps" of the A window (dgi is [2][nb*T][3H]) and two segments of the weight operand
+                a_cat = Win(dgi, batches=1, batch_stride=0, row_stride=3 * H, rows_in=2 * nb * T, rows_out=nb * T, cw=3 * H, K=6 * H,
+                            dil=nb * T)
+                ops.gemm_nt(a_cat, wt_ih[0], None, dx, b_seg=(3 * H, seg))
+            else:
+                for d in range(2):
+                    ops.gemm_nt(Win.plain(dgi[d].view(nb * T, 3 * H)), wt_ih[d], None, dx, accumulate=(d == 1))
         dy = dx.view(nb, T, Kin) if dx is not None else None
     if fork is None:
         fk.join()

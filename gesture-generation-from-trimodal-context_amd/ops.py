@@ -79,12 +79,13 @@ class Win:
                    cw=Cc, K=n_taps * Cc, row_step=1, shift=shift, dil=dil)
 
 
-def gemm_nt(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None,
-            c_rows_out=None, M=None):
-    """out(m, :) = act(A(m, :) @ W^T + bias) [+ out].  W: [N, K] (row stride may exceed K).
-    out: 2-D view [M, N] (unit inner stride) unless explicit C addressing is given."""
+def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, M=None,
+                b_seg=None):
+    """Checked tg_gemm_nt_problem.  b_seg = (seg_k, seg_stride_floats): K-concatenated weights, W is the first [N, seg_k] segment and
+    segment s starts seg_stride_floats * s floats after it (the caller keeps every segment alive)."""
     _f32(W, "W"); _f32(out, "out")
-    assert W.dim() == 2 and W.stride(1) == 1 and W.shape[1] == A.K, (W.shape, A.K)
+    seg_k = A.K if b_seg is None else int(b_seg[0])
+    assert W.dim() == 2 and W.stride(1) == 1 and W.shape[1] == seg_k and A.K % seg_k == 0, (W.shape, A.K, seg_k)
     N = W.shape[0]
     M = A.M if M is None else M
     if bias is not None:
@@ -96,11 +97,40 @@ def gemm_nt(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_st
     max_off = (nb - 1) * c_batch_stride + (c_rows_out - 1) * c_row_stride + N - 1
     if max_off >= _room(out):
         raise ValueError(f"gemm_nt: output exceeds its tensor ({max_off} >= {_room(out)})")
-    if (W.shape[0] - 1) * W.stride(0) + A.K - 1 >= _room(W):
+    if (W.shape[0] - 1) * W.stride(0) + seg_k - 1 >= _room(W):
         raise ValueError("gemm_nt: W exceeds its tensor")
-    call("tg_gemm_nt", C.byref(A.s), _p(W), W.stride(0), _p(bias), _p(out), c_batch_stride, c_row_stride, c_rows_out,
-         M, N, float(act_slope), int(bool(accumulate)), _stream())
+    q = _lib.NtProblem()
+    q.A = A.s
+    q.Bw, q.ldb = W.data_ptr(), W.stride(0)
+    q.b_seg_k, q.b_seg_stride = (0, 0) if b_seg is None else (seg_k, int(b_seg[1]))
+    q.bias = bias.data_ptr() if bias is not None else None
+    q.C, q.c_batch_stride, q.c_row_stride, q.c_rows_out = out.data_ptr(), c_batch_stride, c_row_stride, c_rows_out
+    q.M, q.N, q.act_slope, q.accumulate = M, N, float(act_slope), int(bool(accumulate))
+    return q
+
+
+def gemm_nt(A: Win, W, bias, out, **kw):
+    """out(m, :) = act(A(m, :) @ W^T + bias) [+ out].  W: [N, K] (row stride may exceed K).
+    out: 2-D view [M, N] (unit inner stride) unless explicit C addressing is given."""
+    q = _nt_problem(A, W, bias, out, **kw)
+    call("tg_gemm_nt_group", C.byref(q), 1, _stream())
     return out
+
+
+def gemm_nt_group(problems):
+    """Several independent products in ONE launch.  problems: list of dicts with the arguments of gemm_nt (A, W, bias, out, ...).
+    They must fall into one kernel family (all 'big', i.e. M >= 1024, N >= 48, K >= 64 -- or all narrow / all small); outputs must
+    not overlap."""
+    qs = [_nt_problem(**p) for p in problems]
+    fam = [_lib.load().tg_gemm_nt_family(C.byref(q)) for q in qs]
+    i = 0
+    while i < len(qs):                      # runs of equal kernel family, at most MAX_GROUP each, in the caller's order
+        j = i
+        while j < len(qs) and fam[j] == fam[i] and j - i < _lib.MAX_GROUP:
+            j += 1
+        arr = (_lib.NtProblem * (j - i))(*qs[i:j])
+        call("tg_gemm_nt_group", arr, j - i, _stream())
+        i = j
 
 
 def zero_(t):
@@ -134,9 +164,7 @@ def get_math_mode():
 TN_TWO_PASS_ROWS = 32768     # reductions at least this long combine their partials in fp64 (deterministic) instead of atomics
 
 
-def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
-    """dW[n, perm(k)] += sum_m dY[m, n] * A(m, k); dbias[n] += sum_m dY[m, n] when given.
-    dY: 2-D view [M, N]; dW: contiguous, N rows of K floats."""
+def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None):
     _f32(dY, "dY"); _f32(dW, "dW")
     assert dY.dim() == 2 and dY.stride(1) == 1 and dY.shape[0] == A.M, (dY.shape, A.M)
     M, N = dY.shape
@@ -152,8 +180,30 @@ def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
         # conv3 weight gradient), the combine kernel writes that layout from contiguous partials instead
         nws = _lib.load().tg_gemm_tn_ws_floats(M, N, A.K)
         ws = torch.empty(nws, device=dW.device, dtype=torch.float32)
-    call("tg_gemm_tn", _p(dY), dY.stride(0), C.byref(A.s), _p(dW), A.K, M, N, int(out_kw), _p(dbias), _p(ws), nws, _stream())
+        if keep is not None:
+            keep.append(ws)
+    q = _lib.TnProblem()
+    q.dY, q.ldy, q.A, q.dW, q.ldw = dY.data_ptr(), dY.stride(0), A.s, dW.data_ptr(), A.K
+    q.M, q.N, q.out_kw = M, N, int(out_kw)
+    q.dbias = dbias.data_ptr() if dbias is not None else None
+    q.ws, q.ws_floats = (ws.data_ptr() if ws is not None else None), nws
+    return q, ws
+
+
+def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
+    """dW[n, perm(k)] += sum_m dY[m, n] * A(m, k); dbias[n] += sum_m dY[m, n] when given.
+    dY: 2-D view [M, N]; dW: contiguous, N rows of K floats."""
+    q, ws = _tn_problem(dY, A, dW, out_kw=out_kw, dbias=dbias)
+    call("tg_gemm_tn_group", C.byref(q), 1, _stream())
     return dW
+
+
+def gemm_tn_group(problems):
+    """Several independent weight gradients in ONE launch.  problems: list of dicts with the arguments of gemm_tn."""
+    assert 1 <= len(problems) <= _lib.MAX_GROUP
+    keep = []
+    arr = (_lib.TnProblem * len(problems))(*[_tn_problem(keep=keep, **p)[0] for p in problems])
+    call("tg_gemm_tn_group", arr, len(problems), _stream())
 
 
 def colsum(X, out, *, accumulate=True):

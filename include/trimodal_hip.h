@@ -72,6 +72,26 @@ typedef struct tg_window {
  *   Replaces nn.Linear / nn.Conv1d / nn.ConvTranspose1d forward and their input-gradients:
  *   model/multimodal_context_net.py:13-22,51,89-93,100-104,214-220,225-226; model/tcn.py:19,25;
  *   the x @ W_ih^T half of nn.GRU (:98,223); model/embedding_net.py:24,48-62,187-206. */
+typedef struct tg_gemm_nt_problem {
+    tg_window A;
+    const float* Bw;
+    int64_t ldb;
+    int32_t b_seg_k;           /* 0: one weight matrix.  > 0 (a divisor of K): K-concatenated weights, k in [s*b_seg_k, (s+1)*b_seg_k) */
+    int32_t reserved;          /*    reads Bw + s*b_seg_stride + n*ldb + (k - s*b_seg_k) -- e.g. both GRU directions' W_ih^T side by side */
+    int64_t b_seg_stride;
+    const float* bias;
+    float* C;
+    int64_t c_batch_stride, c_row_stride;
+    int32_t c_rows_out, M, N;
+    float act_slope;
+    int32_t accumulate;
+} tg_gemm_nt_problem;
+/* tg_gemm_nt_group: up to 8 independent tg_gemm_nt products in ONE launch (both GRU directions' input projections, the stride
+ * phases of a conv input-gradient ...).  All problems must fall into the same kernel family as problem 0 (big / narrow / small);
+ * outputs must not overlap.  The table is copied into the kernel arguments: nothing has to outlive the call. */
+int tg_gemm_nt_group(const tg_gemm_nt_problem* problems, int32_t n, void* stream);
+/* kernel family a problem would run in (0 big, 1 narrow N <= 32, 2 small; -1 invalid): problems of one group must agree */
+int32_t tg_gemm_nt_family(const tg_gemm_nt_problem* problem);
 int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bias, float* C,
                int64_t c_batch_stride, int64_t c_row_stride, int32_t c_rows_out, int32_t M, int32_t N,
                float act_slope, int32_t accumulate, void* stream);
@@ -85,6 +105,19 @@ int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bi
  *   Replaces the weight-gradient half of aten::convolution_backward / addmm backward for the same call sites. */
 int64_t tg_gemm_tn_ws_floats(int32_t M, int32_t N, int32_t K);
 /*   dbias != NULL: also dbias[n] += sum_m dY[m*ldy + n] (the bias gradient rides along; no separate pass over dY). */
+typedef struct tg_gemm_tn_problem {
+    const float* dY;
+    int64_t ldy;
+    tg_window A;
+    float* dW;
+    int64_t ldw;
+    int32_t M, N, out_kw, reserved;
+    float* dbias;
+    float* ws;
+    int64_t ws_floats;
+} tg_gemm_tn_problem;
+/* tg_gemm_tn_group: up to 8 independent weight gradients in ONE launch (the four of a GRU layer: W_ih / W_hh of both directions). */
+int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, void* stream);
 int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,
                int32_t out_kw, float* dbias, float* ws, int64_t ws_floats, void* stream);
 

@@ -464,3 +464,37 @@ def test_gru_h64_stack_with_fused_dropout(pkg, dev, B):
         if B >= 70:
             assert abs(float((m > 0).float().mean()) - 0.7) < 0.02
         assert torch.equal(tape2.x[l + 1], tape2.y[l] * m)
+
+
+def test_grouped_gemm_launches_and_concatenated_k(pkg, dev):
+    """tg_gemm_nt_group / tg_gemm_tn_group: several products in one launch == the same products one by one == fp64; problems of
+    different kernel families in one call are partitioned by the wrapper; K-concatenated weights (b_seg) with a two-tap A window
+    reproduce dx = dgi_fwd @ W_fwd + dgi_rev @ W_rev of the GRU backward."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    M, K = 2100, 108
+    x = rnd(M, K, seed=1).to(dev)
+    ws = [rnd(n, K, seed=10 + i, scale=0.1).to(dev) for i, n in enumerate((900, 900, 20, 70))]      # big, big, narrow, big
+    bs = [rnd(w.shape[0], seed=20 + i).to(dev) for i, w in enumerate(ws)]
+    outs = [torch.full((M, w.shape[0]), float("nan"), device=dev) for w in ws]
+    ops.gemm_nt_group([dict(A=Win.plain(x), W=w, bias=b, out=o, act_slope=0.3) for w, b, o in zip(ws, bs, outs)])
+    for w, b, o in zip(ws, bs, outs):
+        ref = F.leaky_relu(x.double().cpu() @ w.double().cpu().t() + b.double().cpu(), 0.3)
+        assert rel(o, ref) < 1e-5
+    # K-concatenation: A = [2][M][Kh] seen as two taps, weights = two [N][Kh] segments somewhere in memory
+    Mh, Kh, N = 1500, 192, 128
+    dgi = rnd(2, Mh, Kh, seed=30).to(dev)
+    wbuf = rnd(3, N, Kh, seed=31, scale=0.1).to(dev)                      # segment 0 = wbuf[0], segment 1 = wbuf[2] (stride 2*N*Kh floats)
+    a_cat = Win(dgi, batches=1, batch_stride=0, row_stride=Kh, rows_in=2 * Mh, rows_out=Mh, cw=Kh, K=2 * Kh, dil=Mh)
+    out = torch.full((Mh, N), float("nan"), device=dev)
+    ops.gemm_nt(a_cat, wbuf[0], None, out, b_seg=(Kh, 2 * N * Kh))
+    ref = dgi[0].double().cpu() @ wbuf[0].double().cpu().t() + dgi[1].double().cpu() @ wbuf[2].double().cpu().t()
+    assert rel(out, ref) < 1e-5
+    # four weight gradients of different shapes in one launch, with bias gradients
+    Mt = 1088
+    dys = [rnd(Mt, n, seed=40 + i).to(dev) for i, n in enumerate((192, 192, 96, 33))]
+    xs = [rnd(Mt, k, seed=50 + i).to(dev) for i, k in enumerate((128, 64, 200, 7))]
+    dws = [torch.zeros(dy.shape[1], xx.shape[1], device=dev) for dy, xx in zip(dys, xs)]
+    dbs = [torch.zeros(dy.shape[1], device=dev) for dy in dys]
+    ops.gemm_tn_group([dict(dY=dy, A=Win.plain(xx), dW=dw, dbias=db) for dy, xx, dw, db in zip(dys, xs, dws, dbs)])
+    for dy, xx, dw, db in zip(dys, xs, dws, dbs):
+        assert rel(dw, dy.double().cpu().t() @ xx.double().cpu()) < 1e-5 and rel(db, dy.double().cpu().sum(0)) < 1e-5

@@ -148,6 +148,103 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const float* __restrict
         }
 }
 
+// PF2: as gemm_split_kernel<.., DB = 1> but with TWO register sets: the global loads of slab s+2 are issued while slab s is
+// multiplied, so a slab's load latency is covered by two iterations (matters when only one workgroup fits a CU / small grids).
+template <int TM, int TN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gemm_split_pf2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                                    int M, int N, int K, int n_nt) {
+    constexpr int BM = 32 * TM, BN = 32 * TN, NT = 64 * WAVES;
+    constexpr int NPA = (BM * 8 + NT - 1) / NT, NPB = (BN * 8 + NT - 1) / NT;
+    constexpr int WMW = WAVES / 2;                               // waves along M (2 along N)
+    constexpr int WTM = 2 * TM / WMW;                            // 16-row MFMA tiles per wave along M
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2][3][BM + BN][LDH];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int lid = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int m0 = (lid / n_nt) * BM, n0 = (lid % n_nt) * BN;
+    const int sp = 4 * (t & 7), sr0 = t >> 3;
+    constexpr int RS = NT / 8;                                   // rows staged per pass
+    const float* ap[NPA]; const float* bp[NPB]; bool aok[NPA], bok[NPB];
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) { const int m = m0 + sr0 + RS * q; aok[q] = m < M && sr0 + RS * q < BM; ap[q] = A + (long)(aok[q] ? m : 0) * K + sp; }
+#pragma unroll
+    for (int q = 0; q < NPB; ++q) { const int n = n0 + sr0 + RS * q; bok[q] = n < N && sr0 + RS * q < BN; bp[q] = B + (long)(bok[q] ? n : 0) * K + sp; }
+    f32x4 ga[2][NPA], gb[2][NPB];
+    auto fetch = [&](int k0, f32x4 (&ra)[NPA], f32x4 (&rb)[NPB]) {
+        const bool inb = k0 + sp < K;
+        const int kc = inb ? k0 : 0;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) { const f32x4 v = *reinterpret_cast<const f32x4*>(ap[q] + kc); ra[q] = (aok[q] && inb) ? v : z; }
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) { const f32x4 v = *reinterpret_cast<const f32x4*>(bp[q] + kc); rb[q] = (bok[q] && inb) ? v : z; }
+    };
+    f32x4 acc[WTM][TN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto stage_mul = [&](int buf, int k_next, f32x4 (&ra)[NPA], f32x4 (&rb)[NPB]) {
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) {
+            u32x2 o[3];
+            split4<3>(ra[q], o);
+            if (sr0 + RS * q < BM)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][sr0 + RS * q][sp]) = o[s];
+        }
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) {
+            u32x2 o[3];
+            split4<3>(rb[q], o);
+            if (sr0 + RS * q < BN)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][BM + sr0 + RS * q][sp]) = o[s];
+        }
+        __syncthreads();
+        fetch(k_next, ra, rb);
+        bf16x8 fa[3][WTM], fb[3][TN];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(&lds[buf][s][wm * (16 * WTM) + i * 16 + r16][8 * kq]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(&lds[buf][s][BM + wn * (16 * TN) + j * 16 + r16][8 * kq]);
+        }
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);
+            }
+    };
+    fetch(0, ga[0], gb[0]);
+    fetch(32, ga[1], gb[1]);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        stage_mul(0, k0 + 64, ga[0], gb[0]);
+        if (k0 + 32 < K) stage_mul(1, k0 + 96, ga[1], gb[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = m0 + wm * (16 * WTM) + i * 16 + kq * 4 + q;
+            if (row >= M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (16 * TN) + j * 16 + r16;
+                if (col < N) C[(long)row * N + col] = acc[i][j][q];
+            }
+        }
+}
+
 // the f32-MFMA reference kernel of the library (gemm_nt_big_kernel<4, 3>: 128 x 96 tile, 16-deep slabs), plain matrices
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
@@ -260,6 +357,17 @@ static void run_split(const float* A, const float* B, float* C, int M, int N, in
     check(tag, C, M, N, K, hA, hB, us);
 }
 
+template <int TM, int TN, int WAVES>
+static void run_pf2(const float* A, const float* B, float* C, int M, int N, int K, const std::vector<float>& hA, const std::vector<float>& hB) {
+    const int n_nt = (N + 32 * TN - 1) / (32 * TN);
+    dim3 grid(((M + 32 * TM - 1) / (32 * TM)) * n_nt);
+    hipMemset(C, 0, (size_t)M * N * 4);
+    const float us = time_us([&]() { hipLaunchKernelGGL((gemm_split_pf2_kernel<TM, TN, WAVES>), grid, dim3(64 * WAVES), 0, 0, A, B, C, M, N, K, n_nt); });
+    char tag[96];
+    snprintf(tag, sizeof tag, "bf16 x3  tile %dx%d pf2 %dw wgs %d", 32 * TM, 32 * TN, WAVES, grid.x);
+    check(tag, C, M, N, K, hA, hB, us);
+}
+
 template <int TM, int TN>
 static void run_f32(const float* A, const float* B, float* C, int M, int N, int K, const std::vector<float>& hA, const std::vector<float>& hB) {
     const int n_nt = (N + 32 * TN - 1) / (32 * TN);
@@ -272,7 +380,7 @@ static void run_f32(const float* A, const float* B, float* C, int M, int N, int 
 }
 
 int main() {
-    const int shapes[][3] = {{13056, 900, 600}, {13056, 1800, 600}, {13056, 300, 600}, {4352, 600, 900}, {4352, 300, 600}, {13056, 900, 108}};
+    const int shapes[][3] = {{13056, 900, 600}, {13056, 300, 600}, {4352, 600, 900}, {4352, 600, 1800}, {4352, 300, 600}, {13056, 900, 108}, {7168, 192, 128}};
     for (auto& sh : shapes) {
         const int M = sh[0], N = sh[1], K = sh[2];
         printf("M=%d N=%d K=%d  (%.2f GFLOP)\n", M, N, K, 2.0 * M * N * K / 1e9);
@@ -287,15 +395,19 @@ int main() {
         hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
         run_f32<4, 3>(A, B, C, M, N, K, hA, hB);
         run_f32<4, 4>(A, B, C, M, N, K, hA, hB);
-        run_split<4, 4, 3, 0>(A, B, C, M, N, K, hA, hB);
-        run_split<4, 4, 3, 1>(A, B, C, M, N, K, hA, hB);
         run_split<4, 3, 3, 0>(A, B, C, M, N, K, hA, hB);
         run_split<4, 3, 3, 1>(A, B, C, M, N, K, hA, hB);
         run_split<4, 2, 3, 0>(A, B, C, M, N, K, hA, hB);
         run_split<4, 2, 3, 1>(A, B, C, M, N, K, hA, hB);
         run_split<2, 2, 3, 1>(A, B, C, M, N, K, hA, hB);
-        run_split<4, 4, 2, 1>(A, B, C, M, N, K, hA, hB);
-        run_split<4, 4, 1, 1>(A, B, C, M, N, K, hA, hB);
+        run_split<2, 3, 3, 0>(A, B, C, M, N, K, hA, hB);
+        run_split<2, 3, 3, 1>(A, B, C, M, N, K, hA, hB);
+        run_pf2<4, 3, 4>(A, B, C, M, N, K, hA, hB);
+        run_pf2<4, 3, 8>(A, B, C, M, N, K, hA, hB);
+        run_pf2<4, 2, 4>(A, B, C, M, N, K, hA, hB);
+        run_pf2<4, 2, 8>(A, B, C, M, N, K, hA, hB);
+        run_pf2<2, 3, 4>(A, B, C, M, N, K, hA, hB);
+        run_pf2<2, 2, 4>(A, B, C, M, N, K, hA, hB);
         hipFree(A); hipFree(B); hipFree(C);
     }
     return 0;
