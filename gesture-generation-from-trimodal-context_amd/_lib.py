@@ -24,7 +24,7 @@ class NtProblem(C.Structure):
     """struct tg_gemm_nt_problem"""
     _fields_ = [("A", Window), ("Bw", P), ("ldb", I64), ("b_seg_k", I32), ("reserved", I32), ("b_seg_stride", I64), ("bias", P), ("C", P),
                 ("c_batch_stride", I64), ("c_row_stride", I64), ("c_rows_out", I32), ("M", I32), ("N", I32), ("act_slope", F32),
-                ("accumulate", I32)]
+                ("accumulate", I32), ("out_scale", P)]
 
 
 class TnProblem(C.Structure):
@@ -50,6 +50,7 @@ SIGNATURES = {
     "tg_gru_backward_cluster": [P, P, P, I64, P, P, P, P, I64, P, I64, I32, I32, I32, P],
     "tg_bn_train_stats": [P, I32, I32, I32, P, P, P, P, P, P, F32, F32, I32, P],
     "tg_bn_eval_stats": [P, P, I32, F32, P, P, P],
+    "tg_bn_train_fused": [P, P, I32, I32, I32, P, P, P, P, P, P, P, F32, F32, F32, I32, P],
     "tg_bn_apply": [P, P, I32, I32, I32, P, P, P, P, F32, P],
     "tg_bn_backward": [P, P, P, I32, I32, P, P, P, P, F32, P, P, P, P],
     "tg_zero": [P, I64, P],
@@ -69,6 +70,7 @@ SIGNATURES = {
     "tg_permute3": [P, P, I32, I32, I32, I32, I32, I32, P],
     "tg_conv_dgrad_pack": [P, P, I32, I32, I32, I32, P],
     "tg_weight_norm_fwd": [P, P, P, I32, I32, I32, P],
+    "tg_weight_norm_fwd_batch": [I32, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), I32, I32, I32, P],
     "tg_weight_norm_bwd": [P, P, P, P, P, I32, I32, I32, P],
     "tg_rng_advance": [P, P],
     "tg_dropout_mask": [P, I64, F32, P, U32, P],

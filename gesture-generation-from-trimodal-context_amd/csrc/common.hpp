@@ -75,6 +75,7 @@ struct NtProb {
     long b_seg_stride;       // K-concatenated weights: k in [s * b_seg_k, (s+1) * b_seg_k) reads Bw + s * b_seg_stride + n * ldb + (k - s * b_seg_k)
     int b_seg_k;             // (== K: one weight matrix)
     const float* bias;
+    const float* mul;        // optional element-wise multiplier applied after the activation (a dropout scale mask), addressed like C
     float* C;
     long cbs, crs;
     int cR, M, N;

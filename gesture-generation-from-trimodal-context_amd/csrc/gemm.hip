@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
     const float* __restrict__ Bw = pr.Bw;
     const long ldb = pr.ldb;
     const float* __restrict__ bias = pr.bias;
+    const float* __restrict__ mul = pr.mul;
     float* __restrict__ C = pr.C;
     const long cbs = pr.cbs, crs = pr.crs;
     const int cR = pr.cR, M = pr.M, N = pr.N, accumulate = pr.accumulate, n_nt = pr.n_nt;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
             const int cb = row / cR;
             const int cr = row - cb * cR;
             float* crow = C + (long)cb * cbs + (long)cr * crs;
+            const float* mrow = mul ? mul + (long)cb * cbs + (long)cr * crs : nullptr;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int col = n_base + nt * 16 + r16;
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
                 float v = acc[mt][nt][i];
                 if (bias) v += bias[col];
                 v = act_fn(v, slope);
+                if (mrow) v *= mrow[col];
                 if (accumulate) v += crow[col];
                 crow[col] = v;
             }
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(const NtGroup g) {
     const long ldb = pr.ldb, b_seg_stride = pr.b_seg_stride;
     const int b_seg_k = pr.b_seg_k;
     const float* __restrict__ bias = pr.bias;
+    const float* __restrict__ mul = pr.mul;
     float* __restrict__ C = pr.C;
     const long cbs = pr.cbs, crs = pr.crs;
     const int cR = pr.cR, M = pr.M, N = pr.N, accumulate = pr.accumulate, n_nt = pr.n_nt;
@@ -295,6 +299,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(const NtGroup g) {
             const int cb = row / cR;
             const int cr = row - cb * cR;
             float* crow = C + (long)cb * cbs + (long)cr * crs;
+            const float* mrow = mul ? mul + (long)cb * cbs + (long)cr * crs : nullptr;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn * (16 * TN) + j * 16 + r16;
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(const NtGroup g) {
                 float v = acc[i][j][q];
                 if (bias) v += bias[col];
                 v = act_fn(v, slope);
+                if (mrow) v *= mrow[col];
                 if (accumulate) v += crow[col];
                 crow[col] = v;
             }
@@ -635,7 +641,7 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
                (long)q.ldb, idx);
     p.A = to_win(&q.A);
     p.Bw = q.Bw; p.ldb = (long)q.ldb; p.b_seg_k = seg; p.b_seg_stride = q.b_seg_k > 0 ? (long)q.b_seg_stride : 0;
-    p.bias = q.bias; p.C = q.C; p.cbs = (long)q.c_batch_stride; p.crs = (long)q.c_row_stride; p.cR = q.c_rows_out;
+    p.bias = q.bias; p.mul = q.out_scale; p.C = q.C; p.cbs = (long)q.c_batch_stride; p.crs = (long)q.c_row_stride; p.cR = q.c_rows_out;
     p.M = q.M; p.N = q.N; p.slope = q.act_slope; p.accumulate = q.accumulate; p.n_nt = 0;
     return 0;
 }
@@ -663,6 +669,7 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
     tg_gemm_nt_problem q;
     q.A = *A; q.Bw = Bw; q.ldb = ldb; q.b_seg_k = 0; q.b_seg_stride = 0; q.bias = bias; q.C = C; q.c_batch_stride = c_batch_stride;
     q.c_row_stride = c_row_stride; q.c_rows_out = c_rows_out; q.M = M; q.N = N; q.act_slope = act_slope; q.accumulate = accumulate;
+    q.out_scale = nullptr; q.reserved = 0;
     TG_REQUIRE(ldb >= A->K, "tg_gemm_nt: ldb=%ld < K=%d", (long)ldb, A->K);
     return tg_gemm_nt_group(&q, 1, stream);
 }

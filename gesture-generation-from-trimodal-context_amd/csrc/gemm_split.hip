@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
     const long ldb = pr.ldb, b_seg_stride = pr.b_seg_stride;
     const int b_seg_k = pr.b_seg_k;
     const float* __restrict__ bias = pr.bias;
+    const float* __restrict__ mul = pr.mul;
     float* __restrict__ C = pr.C;
     const long cbs = pr.cbs, crs = pr.crs;
     const int cR = pr.cR, M = pr.M, N = pr.N, accumulate = pr.accumulate, n_nt = pr.n_nt;
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
             const int cb = row / cR;
             const int cr = row - cb * cR;
             float* crow = C + (long)cb * cbs + (long)cr * crs;
+            const float* mrow = mul ? mul + (long)cb * cbs + (long)cr * crs : nullptr;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn * (16 * TN) + j * 16 + r16;
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
                 float v = acc[i][j][q];
                 if (bias) v += bias[col];
                 v = act_fn(v, slope);
+                if (mrow) v *= mrow[col];
                 if (accumulate) v += crow[col];
                 crow[col] = v;
             }

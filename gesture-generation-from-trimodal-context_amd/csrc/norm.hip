@@ -149,9 +149,129 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// ---- small tensors (the discriminator's and the autoencoder's BatchNorms: a few thousand rows): ONE workgroup does statistics,
+// running-stat update and normalisation in one launch -- the multi-kernel path costs four launches of ~5 us for microseconds of work.
+constexpr int BN_SMALL_THREADS = 1024;
+constexpr long BN_SMALL_MAX = 1L << 19;          // elements (2 MB): stays in L2 between the two passes
+
+__device__ __forceinline__ void block_sum2(double& a, double& b, double (*sh)[BN_SMALL_THREADS], int C, int rpi) {
+    // a, b: per-thread partials of channel (threadIdx.x % C); on return threads < C hold the channel totals
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        double x = 0.0, y = 0.0;
+        for (int q = 0; q < rpi; ++q) { x += sh[0][q * C + threadIdx.x]; y += sh[1][q * C + threadIdx.x]; }
+        a = x; b = y;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_train_kernel(
+    const float* __restrict__ x, float* __restrict__ y, int rows_per_group, int C, int groups, float* __restrict__ mean, float* __restrict__ rstd,
+    float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float slope, float eps, float momentum, int repeats) {
+    __shared__ double sh[2][BN_SMALL_THREADS];
+    __shared__ float s_mean[256], s_rstd[256];
+    const int rpi = BN_SMALL_THREADS / C;
+    const int c = threadIdx.x % C, rsub = threadIdx.x / C;
+    float rm = 0.f, rv = 0.f;
+    if ((int)threadIdx.x < C) { rm = rmean ? rmean[c] : 0.f; rv = rvar ? rvar[c] : 0.f; }
+    for (int g = 0; g < groups; ++g) {
+        const float* xg = x + (long)g * rows_per_group * C;
+        double s = 0.0, ss = 0.0;
+        if (rsub < rpi)
+            for (int r = rsub; r < rows_per_group; r += rpi) {
+                const float v = xg[(long)r * C + c];
+                s += v;
+                ss += (double)v * v;
+            }
+        block_sum2(s, ss, sh, C, rpi);
+        if ((int)threadIdx.x < C) {
+            const double n = (double)rows_per_group;
+            const double m = s / n;
+            double var = ss / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+            mean[g * C + c] = mf; rstd[g * C + c] = rs;
+            s_mean[c] = mf; s_rstd[c] = rs;
+            const double unbiased = rows_per_group > 1 ? var * n / (n - 1.0) : var;
+            for (int q = 0; q < repeats; ++q) {
+                rm = (1.f - momentum) * rm + momentum * mf;
+                rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+            }
+        }
+        __syncthreads();
+        if (y) {
+            float* yg = y + (long)g * rows_per_group * C;
+            const long total = (long)rows_per_group * C;
+            for (long e = threadIdx.x; e < total; e += BN_SMALL_THREADS) {
+                const int cc = (int)(e % C);
+                yg[e] = act_fn((xg[e] - s_mean[cc]) * s_rstd[cc] * gamma[cc] + beta[cc], slope);
+            }
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < C) {
+        if (rmean) rmean[c] = rm;
+        if (rvar) rvar[c] = rv;
+    }
+    if (threadIdx.x == 0 && nbt) *nbt += (int64_t)groups * repeats;
+}
+
+__global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int rows, int C, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double sh[2][BN_SMALL_THREADS];
+    __shared__ double s_m1[256], s_m2[256];
+    const int rpi = BN_SMALL_THREADS / C;
+    const int c = threadIdx.x % C, rsub = threadIdx.x / C;
+    double s = 0.0, sx = 0.0;
+    if (rsub < rpi) {
+        const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+        for (int r = rsub; r < rows; r += rpi) {
+            const float xh = (x[(long)r * C + c] - mu) * rs;
+            const float z = xh * ga + be;
+            const float dz = dy[(long)r * C + c] * (z >= 0.f ? 1.f : slope);
+            s += dz;
+            sx += (double)dz * xh;
+        }
+    }
+    block_sum2(s, sx, sh, C, rpi);
+    if ((int)threadIdx.x < C) {
+        if (dbeta) dbeta[c] += (float)s;
+        if (dgamma) dgamma[c] += (float)sx;
+        s_m1[c] = s / (double)rows;
+        s_m2[c] = sx / (double)rows;
+    }
+    __syncthreads();
+    const long total = (long)rows * C;
+    for (long e = threadIdx.x; e < total; e += BN_SMALL_THREADS) {
+        const int cc = (int)(e % C);
+        const float rs = rstd[cc], ga = gamma[cc];
+        const float xh = (x[e] - mean[cc]) * rs;
+        const float z = xh * ga + beta[cc];
+        const float dz = dy[e] * (z >= 0.f ? 1.f : slope);
+        dx[e] = (float)((double)(ga * rs) * ((double)dz - s_m1[cc] - (double)xh * s_m2[cc]));
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
+
+// statistics + running-stat update + normalisation of a small tensor in ONE launch (y may be NULL: statistics only)
+extern "C" int tg_bn_train_fused(const float* x, float* y, int32_t rows, int32_t C, int32_t groups, float* mean, float* rstd,
+                                 float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                                 const float* beta, float act_slope, float eps, float momentum, int32_t repeats, void* stream) {
+    TG_REQUIRE(x && mean && rstd && repeats >= 1 && (y == nullptr || (gamma && beta)), "tg_bn_train_fused: null pointer / repeats < 1");
+    TG_REQUIRE(C > 0 && C <= 256 && groups > 0 && rows > 0 && rows % groups == 0 && (long)rows * C <= BN_SMALL_MAX,
+               "tg_bn_train_fused: C=%d (<=256), rows=%d, groups=%d, at most %ld elements", C, rows, groups, BN_SMALL_MAX);
+    hipLaunchKernelGGL(bn_small_train_kernel, dim3(1), dim3(BN_SMALL_THREADS), 0, (hipStream_t)stream, x, y, rows / groups, C, groups, mean, rstd,
+                       running_mean, running_var, num_batches_tracked, gamma, beta, act_slope, eps, momentum, repeats);
+    return check_launch("tg_bn_train_fused");
+}
 
 extern "C" int tg_bn_train_stats(const float* x, int32_t rows, int32_t C, int32_t groups, double* ws, float* mean, float* rstd,
                                  float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
@@ -195,6 +315,11 @@ extern "C" int tg_bn_backward(const float* dy, const float* x, float* dx, int32_
     TG_REQUIRE(dy && x && dx && mean && rstd && gamma && beta && ws, "tg_bn_backward: null pointer");
     TG_REQUIRE(rows > 0 && C > 0 && C <= 256, "tg_bn_backward: C=%d must be <= 256", C);
     hipStream_t s = (hipStream_t)stream;
+    if ((long)rows * C <= BN_SMALL_MAX) {          // one workgroup: reduce, then apply (3 launches -> 1)
+        hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(1), dim3(BN_SMALL_THREADS), 0, s, dy, x, dx, rows, C, mean, rstd, gamma, beta, act_slope,
+                           dgamma, dbeta);
+        return check_launch("tg_bn_backward(small)");
+    }
     if (zero_async(ws, sizeof(double) * 2 * (size_t)C, s)) return 1;
     const int rpi = 256 / C;
     int blocks = cdiv(rows, rpi * 16);

@@ -200,18 +200,33 @@ class GeneratorEngine(_Engine):
         E = P[f"{te}.embedding.weight"].shape[1]
         emb = ops.embed_gather(P[f"{te}.embedding.weight"], in_text.contiguous().view(-1), L.empty(Bs, T, E, like=in_data))
         cur, emb_mask = self._drop(f"{tag}.emb_drop", emb, 0.1, inject) if training else (emb, None)
+        # every weight-normed conv of the TCN in one launch: w = g v / ||v|| as the forward GEMM operand [Co][2 Ci] and, transposed,
+        # as the input-gradient operand [Ci][2 Co] (model/tcn.py:19,25)
+        names = [f"{te}.tcn.network.{i}.{c}" for i in range(self.n_layers) for c in ("conv1", "conv2")]
+        wps, wts = ops.weight_norm_fwd_batch([P[n + ".weight_v"] for n in names], [P[n + ".weight_g"] for n in names], want_t=training)
+        # the eight dropout masks of the block convs: injected (tests) or ONE draw launch; each rides in its conv's GEMM epilogue
+        sites = [f"{tag}.tcn{i}.drop{ci + 1}" for i in range(self.n_layers) for ci in range(2)]
+        masks = [None] * len(sites)
+        if training:
+            if inject is not None and all(sn in inject for sn in sites):
+                masks = [inject[sn].contiguous() for sn in sites]
+            elif self.p_drop > 0.0:
+                drawn = ops.dropout_mask(L.empty(len(sites), Bs, T, wps.shape[1], like=in_data), self.p_drop, self.rng.state,
+                                         self.rng.site(f"{tag}.tcn.drop"))
+                masks = [inject[sn].contiguous() if (inject is not None and sn in inject) else drawn[j] for j, sn in enumerate(sites)]
         tcn = []
         for i in range(self.n_layers):
             d = 2 ** i
             blk = {"x": cur, "d": d}
             h = cur
-            for ci, name in enumerate(("conv1", "conv2")):
-                pre = f"{te}.tcn.network.{i}.{name}"
-                v = P[pre + ".weight_v"]
-                wp = ops.weight_norm_fwd(v, P[pre + ".weight_g"], L.empty(v.shape[0], 2 * v.shape[1], like=v))
-                c = L.conv_fwd(h, wp, P[pre + ".bias"], 2, pad=d, dil=d, rows_out=T, act_slope=0.0)   # causal: chomp
-                o, m = self._drop(f"{tag}.tcn{i}.drop{ci + 1}", c, self.p_drop, inject) if training else (c, None)
-                blk[f"in{ci}"], blk[f"wp{ci}"], blk[f"o{ci}"], blk[f"m{ci}"] = h, wp, o, m
+            for ci in range(2):
+                j = 2 * i + ci
+                m = masks[j]
+                if m is not None:
+                    assert m.shape == (Bs, T, wps.shape[1]), (sites[j], m.shape)
+                # causal conv (chomp) + ReLU + dropout scale in one GEMM
+                o = L.conv_fwd(h, wps[j], P[names[j] + ".bias"], 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=m)
+                blk[f"in{ci}"], blk[f"wt{ci}"], blk[f"o{ci}"], blk[f"m{ci}"] = h, (wts[j] if wts is not None else None), o, m
                 h = o
             y = ops.add_relu(h, cur, torch.empty_like(cur))
             blk["y"] = y
@@ -266,6 +281,8 @@ class GeneratorEngine(_Engine):
             d_text = d_in2[:, self.c_text:self.c_text + 32]
             dcur = L.linear_bwd(d_text, tp["text_x"][rows].reshape(M, -1), P[f"{te}.decoder.weight"], G[f"{te}.decoder.weight"],
                                 G[f"{te}.decoder.bias"])
+            Co_t = P[f"{te}.tcn.network.0.conv1.weight_v"].shape[0]
+            dwp_all = ops.zeros(2 * self.n_layers, Co_t, 2 * Co_t, device=dcur.device)       # packed weight gradients of the 8 convs: one fill
             for i in range(self.n_layers - 1, -1, -1):
                 blk = tp["tcn"][i]
                 d = blk["d"]
@@ -280,12 +297,11 @@ class GeneratorEngine(_Engine):
                     dc3 = dc.view(nb, T, -1)
                     xin = blk[f"in{ci}"][rows]
                     v = P[pre + ".weight_v"]
-                    dwp = ops.zeros(v.shape[0], 2 * v.shape[1], device=v.device, dtype=v.dtype)
+                    dwp = dwp_all[2 * i + ci]
                     ops.gemm_tn(dc, Win.conv(xin, 2, pad=d, dil=d, rows_out=T), dwp, dbias=G[pre + ".bias"])
                     ops.weight_norm_bwd(dwp, v, P[pre + ".weight_g"], G[pre + ".weight_g"], G[pre + ".weight_v"])
-                    # dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0]  -> taps (t + d, t) with B = wp^T per tap
-                    wT = L.empty(xin.shape[2], 2 * v.shape[0], like=v)
-                    ops.permute3(blk[f"wp{ci}"].view(v.shape[0], 2, xin.shape[2]), wT, (2, 1, 0))
+                    # dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0]  -> taps (t + d, t) with B = w^T per tap (from the forward's batch)
+                    wT = blk[f"wt{ci}"]
                     if ci == 1:
                         dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, L.empty(M, xin.shape[2], like=dc))
                     else:   # first conv of the block: add into the residual branch gradient

@@ -146,7 +146,7 @@ def conv_out_len(L, kw, stride=1, pad=0, dil=1):
     return (L + 2 * pad - dil * (kw - 1) - 1) // stride + 1
 
 
-def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=1.0, rows_out=None):
+def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=1.0, rows_out=None, out_scale=None):
     """x: (B, L, Ci) view; w_packed: [Co, kw*Ci]; out: (B, Lout, Co) view (may be a channel slice of a wider buffer)."""
     B, L, _ = x.shape
     Lo = conv_out_len(L, kw, stride, pad, dil) if rows_out is None else rows_out
@@ -156,7 +156,7 @@ def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=
     assert tuple(out.shape) == (B, Lo, Co) and out.stride(2) == 1
     A = Win.conv(x, kw, stride=stride, pad=pad, dil=dil, rows_out=Lo)
     ops.gemm_nt(A, w_packed, b, out, act_slope=act_slope, c_batch_stride=out.stride(0), c_row_stride=out.stride(1),
-                c_rows_out=Lo)
+                c_rows_out=Lo, out_scale=out_scale)
     return out
 
 
@@ -235,6 +235,10 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, *, training, groups=1
     g = groups if training else 1
     st.mean, st.rstd = empty(g, Cc, like=x), empty(g, Cc, like=x)
     st.groups, st.x, st.slope = g, x, act_slope
+    if training and x2.numel() <= ops.BN_SMALL_MAX:
+        y = torch.empty_like(x) if out is None else out
+        ops.bn_train_fused(x2, y.view(-1, Cc), g, st.mean, st.rstd, running_mean, running_var, nbt, gamma, beta, act_slope, repeats=repeats)
+        return y, st
     if training:
         ws = torch.empty(2 * g * Cc, device=x.device, dtype=torch.float64)
         ops.bn_train_stats(x2, g, ws, st.mean, st.rstd, running_mean, running_var, nbt, repeats=repeats)

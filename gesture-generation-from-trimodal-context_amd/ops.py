@@ -80,7 +80,7 @@ class Win:
 
 
 def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, M=None,
-                b_seg=None):
+                b_seg=None, out_scale=None):
     """Checked tg_gemm_nt_problem.  b_seg = (seg_k, seg_stride_floats): K-concatenated weights, W is the first [N, seg_k] segment and
     segment s starts seg_stride_floats * s floats after it (the caller keeps every segment alive)."""
     _f32(W, "W"); _f32(out, "out")
@@ -106,6 +106,10 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
     q.bias = bias.data_ptr() if bias is not None else None
     q.C, q.c_batch_stride, q.c_row_stride, q.c_rows_out = out.data_ptr(), c_batch_stride, c_row_stride, c_rows_out
     q.M, q.N, q.act_slope, q.accumulate = M, N, float(act_slope), int(bool(accumulate))
+    if out_scale is not None:                  # element-wise multiplier applied after the activation, addressed exactly like `out`
+        _f32(out_scale, "out_scale")
+        assert out_scale.shape == out.shape and out_scale.stride() == out.stride(), (out_scale.shape, out.shape)
+        q.out_scale = out_scale.data_ptr()
     return q
 
 
@@ -313,6 +317,20 @@ def bn_train_stats(x2d, groups, ws, mean, rstd, running_mean, running_var, nbt, 
          _p(running_mean), _p(running_var), _p(nbt), float(eps), float(momentum), int(repeats), _stream())
 
 
+BN_SMALL_MAX = 1 << 19        # elements a single-workgroup fused BatchNorm launch handles (csrc/norm.hip)
+
+
+def bn_train_fused(x2d, y2d, groups, mean, rstd, running_mean, running_var, nbt, gamma, beta, act_slope, eps=1e-5, momentum=0.1, repeats=1):
+    """Small tensors: batch statistics, running-stat update and y = act(gamma * xhat + beta) in one launch."""
+    _flat(x2d, "x"); _flat(y2d, "y"); rows, Cc = x2d.shape
+    assert y2d.shape == x2d.shape and rows * Cc <= BN_SMALL_MAX and mean.numel() == groups * Cc == rstd.numel()
+    assert gamma.numel() == Cc == beta.numel() and (nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda))
+    call("tg_bn_train_fused", _p(x2d), _p(y2d), rows, Cc, groups, _p(_flat(mean, "mean")), _p(_flat(rstd, "rstd")), _p(running_mean),
+         _p(running_var), _p(nbt), _p(_flat(gamma, "gamma")), _p(_flat(beta, "beta")), float(act_slope), float(eps), float(momentum),
+         int(repeats), _stream())
+    return y2d
+
+
 def bn_eval_stats(running_mean, running_var, mean, rstd, eps=1e-5):
     Cc = running_mean.numel()
     call("tg_bn_eval_stats", _p(_flat(running_mean, "rm")), _p(_flat(running_var, "rv")), Cc, float(eps),
@@ -447,6 +465,21 @@ def weight_norm_fwd(v, g, w_packed):
     _flat(v, "v"); _flat(g, "g"); _flat(w_packed, "w"); Co, Ci, kw = v.shape
     assert g.numel() == Co and w_packed.numel() == v.numel()
     call("tg_weight_norm_fwd", _p(v), _p(g), _p(w_packed), Co, Ci, kw, _stream()); return w_packed
+
+
+def weight_norm_fwd_batch(vs, gs, want_t=True):
+    """Every weight-normed conv of a network in one launch.  vs / gs: lists of (Co, Ci, kw) / (Co, 1, 1) parameters of equal shape.
+    Returns (w_packed [n, Co, kw*Ci], w_t [n, Ci, kw*Co] or None)."""
+    n = len(vs)
+    Co, Ci, kw = vs[0].shape
+    for v, g in zip(vs, gs):
+        _flat(v, "v"); _flat(g, "g"); assert tuple(v.shape) == (Co, Ci, kw) and g.numel() == Co
+    wp = torch.empty(n, Co, kw * Ci, device=vs[0].device)
+    wt = torch.empty(n, Ci, kw * Co, device=vs[0].device) if want_t else None
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    call("tg_weight_norm_fwd_batch", n, arr(vs), arr(gs), arr([wp[i] for i in range(n)]),
+         arr([wt[i] for i in range(n)]) if want_t else None, Co, Ci, kw, _stream())
+    return wp, wt
 
 
 def weight_norm_bwd(dw_packed, v, g, dg, dv):

@@ -85,6 +85,8 @@ typedef struct tg_gemm_nt_problem {
     int32_t c_rows_out, M, N;
     float act_slope;
     int32_t accumulate;
+    const float* out_scale;    /* NULL, or an element-wise multiplier applied after the activation, addressed like C: the inverted-dropout
+                                  scale mask of F.dropout(relu(conv(x))) (model/tcn.py:22-29) rides in the epilogue */
 } tg_gemm_nt_problem;
 /* tg_gemm_nt_group: up to 8 independent tg_gemm_nt products in ONE launch (both GRU directions' input projections, the stride
  * phases of a conv input-gradient ...).  All problems must fall into the same kernel family as problem 0 (big / narrow / small);
@@ -190,6 +192,11 @@ int tg_bn_train_stats(const float* x, int32_t rows, int32_t C, int32_t groups, d
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                       float momentum, int32_t repeats, void* stream);
 /* eval mode: mean/rstd from running stats. */
+/* Small tensors (rows * C <= 2^19, the discriminator's and the autoencoder's BatchNorms): statistics, running-stat update AND
+ * y = act(gamma * xhat + beta) in ONE single-workgroup launch; y == NULL computes the statistics only. */
+int tg_bn_train_fused(const float* x, float* y, int32_t rows, int32_t C, int32_t groups, float* mean, float* rstd,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                      const float* beta, float act_slope, float eps, float momentum, int32_t repeats, void* stream);
 int tg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
                      float* rstd, void* stream);
 /* y = act((x - mean[g]) * rstd[g] * gamma + beta). */
@@ -253,6 +260,10 @@ int tg_conv_dgrad_pack(const float* w, float* out, int32_t Co, int32_t Ci, int32
 int tg_weight_norm_fwd(const float* v, const float* g, float* w_packed, int32_t Co, int32_t Ci, int32_t kw,
                        void* stream);
 /* dw_packed: [Co][kw][Ci] -> dg[Co], dv[Co][Ci][kw] (both accumulate). */
+/* All weight-normed convs of a network in ONE launch (same Co, Ci, kw): w_packed[i] as tg_weight_norm_fwd, and -- when w_t != NULL --
+ * w_t[i] = the same weight as [Ci][kw*Co] (w_t[ci][tap*Co + co]), the B operand of the conv's input gradient. */
+int tg_weight_norm_fwd_batch(int32_t n, const float* const* v, const float* const* g, float* const* w_packed, float* const* w_t,
+                             int32_t Co, int32_t Ci, int32_t kw, void* stream);
 int tg_weight_norm_bwd(const float* dw_packed, const float* v, const float* g, float* dg, float* dv, int32_t Co,
                        int32_t Ci, int32_t kw, void* stream);
 
