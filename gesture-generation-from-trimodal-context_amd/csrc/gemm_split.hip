@@ -16,7 +16,7 @@
 // (64 B) padded to 80 B so a lane's fragment -- A[row l&15][k = 8*(l>>4) .. +7] -- is one conflict-light 16-byte ds_read.  The
 // next slab's global loads are in flight (registers) while the current slab is split, stored and multiplied.  DB = 0 keeps ONE
 // LDS buffer (two barriers per slab, <= 54 KB: two workgroups per CU, the better choice when the grid has >= 2 workgroups per
-// CU); DB = 1 double-buffers (one barrier per slab, one workgroup per CU: better for the small grids of the backward shapes).
+// CU); DB = 1 double-buffers (one barrier per slab): used with the 64-row tiles of the small grids of the backward shapes.
 #include "common.hpp"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -221,16 +221,17 @@ extern "C" int tg_set_math_mode(int32_t mode) {
 
 extern "C" int tg_get_math_mode(void) { return g_math_mode; }
 
-// Tile menu (tools/gemm_split_lab.hip on the shapes of the training step).  Single-buffered tiles run two workgroups per CU and win
-// when the grid has at least ~2 workgroups per CU; the double-buffered ones win on the small grids of the backward shapes.
+// Tile menu (tools/gemm_split_lab.hip on the shapes of the training step).  Single-buffered 128-row tiles run two workgroups per CU
+// and win when the grid has at least ~2 workgroups per CU (the stacked forward, M = 13056); the backward shapes (M = 4352) have too
+// few 128-row tiles for that and run 64-row double-buffered tiles instead (476 x [64 x 96] for N = 600: 50 us against 59 for 238 x
+// [128 x 96] and 68 for the f32-MFMA kernel).
 struct SplitTile { int tm, tn, db; };
 static SplitTile split_pick_tile(int M, int N) {
     auto wgs = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(N, bn); };
     auto waste = [&](int bn) { return cdiv(N, bn) * bn - N; };
     if (wgs(128, 96) >= 512 && waste(96) <= waste(64) + 32) return {4, 3, 0};
     if (wgs(128, 64) >= 384) return {4, 2, 0};
-    if (wgs(128, 96) >= 160 && waste(96) <= waste(64) + 32) return {4, 3, 1};
-    if (wgs(128, 64) >= 160) return {4, 2, 1};
+    if (wgs(64, 96) >= 256 && waste(96) <= waste(64) + 32) return {2, 3, 1};
     return {2, 2, 1};
 }
 
@@ -250,10 +251,9 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
 #define TG_SPLIT(TM_, TN_, SP_, DB_) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_>), grid, dim3(256), 0, s, g)
 #define TG_SPLIT_MENU(SP_)                                              \
     do {                                                                \
-        if (tl.tm == 4 && tl.tn == 3 && !tl.db) TG_SPLIT(4, 3, SP_, 0); \
-        else if (tl.tm == 4 && tl.tn == 3) TG_SPLIT(4, 3, SP_, 1);      \
-        else if (tl.tm == 4 && tl.tn == 2 && !tl.db) TG_SPLIT(4, 2, SP_, 0); \
-        else if (tl.tm == 4 && tl.tn == 2) TG_SPLIT(4, 2, SP_, 1);      \
+        if (tl.tm == 4 && tl.tn == 3) TG_SPLIT(4, 3, SP_, 0);           \
+        else if (tl.tm == 4 && tl.tn == 2) TG_SPLIT(4, 2, SP_, 0);      \
+        else if (tl.tm == 2 && tl.tn == 3) TG_SPLIT(2, 3, SP_, 1);      \
         else TG_SPLIT(2, 2, SP_, 1);                                    \
     } while (0)
     if (g_math_mode == 1) TG_SPLIT_MENU(1);
