@@ -17,6 +17,8 @@
 // Residency: 512-thread workgroups with > 128 VGPRs -> one per CU; the host launches at most 256 of them (all co-resident on
 // an otherwise in-order stream).  Every spin is bounded: on a timeout the workgroup sets the timeout word, stops waiting for
 // the rest of the sequence and runs to completion (results are then garbage and the host raises on the timeout word).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace tg {
@@ -372,6 +374,24 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_kernel(
 
 using namespace tg;
 
+// bf16 x 3 versions of the two kernels (gru_cluster_x3.hip): default; TG_GRU_X3=0 in the environment keeps the f32-MFMA kernels above
+int64_t tg_gru_x3_fwd_exchange_bytes(int b_pad, int cw);
+int64_t tg_gru_x3_bwd_exchange_bytes(int b_pad, int cw);
+int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
+                         float* save, long save_ds, void* hx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
+                         hipStream_t s);
+int tg_gru_x3_bwd_launch(const float* dy, const float* y, const float* save, long save_ds, const float* wt0, const float* wt1, float* dgi,
+                         float* dgh, long dg_ds, void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
+                         hipStream_t s);
+static bool use_gru_x3() {
+    static int x3 = -1;
+    if (x3 < 0) {
+        const char* e = getenv("TG_GRU_X3");
+        x3 = (e && e[0] == '0') ? 0 : 1;
+    }
+    return x3 == 1;
+}
+
 // Workgroups that can be co-resident at one per CU: the device's CU count (256 on a whole MI355X; fewer under CPX/DPX partitioning
 // or CU masking, where the cluster kernels must not be used: a member that can never become resident stalls its cluster until
 // the spin bound).  0 when no device is usable (the caller then falls back to the per-step launches).
@@ -407,7 +427,8 @@ extern "C" int64_t tg_gru_cluster_ws_bytes(int32_t B, int32_t H) {
     cluster_plan(B, H, &mt, &n_bt, &cw);
     const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
     const int64_t b_pad = (int64_t)n_bt * 16 * mt;
-    return flag_words * 4 + 4 * b_pad * GC_HX * 4;
+    const int64_t f32_bytes = 4 * b_pad * GC_HX * 4, x3_bytes = tg_gru_x3_fwd_exchange_bytes((int)b_pad, cw);
+    return flag_words * 4 + (f32_bytes > x3_bytes ? f32_bytes : x3_bytes);
 }
 
 extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
@@ -431,6 +452,9 @@ extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, co
     if (zero_async(flags, (size_t)(flag_words - GC_FLAG_STRIDE) * 4, s)) return 1;
     float* hx = (float*)(tmo + flag_words);
     const int b_pad = n_bt * 16 * mt;
+    if (use_gru_x3())
+        return tg_gru_x3_fwd_launch(mt, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, hx, flags,
+                                    tmo, B, T, H, n_bt, cw, b_pad, s);
     dim3 grid(2 * n_bt * cw);
     if (mt == 1)
         hipLaunchKernelGGL(gru_seq_fwd_cluster_kernel<1>, grid, dim3(512), 0, s, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd,
@@ -459,7 +483,8 @@ extern "C" int64_t tg_gru_cluster_bwd_ws_bytes(int32_t B, int32_t H) {
     int n_bt, cw;
     cluster_plan_bwd(B, H, &n_bt, &cw);
     const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
-    return flag_words * 4 + 4 * (int64_t)n_bt * 16 * 3 * GC_HX * 4;
+    const int64_t f32_bytes = 4 * (int64_t)n_bt * 16 * 3 * GC_HX * 4, x3_bytes = tg_gru_x3_bwd_exchange_bytes(n_bt * 16, cw);
+    return flag_words * 4 + (f32_bytes > x3_bytes ? f32_bytes : x3_bytes);
 }
 
 extern "C" int tg_gru_backward_cluster(const float* dy, const float* y, const float* save, int64_t save_dir_stride,
@@ -479,6 +504,9 @@ extern "C" int tg_gru_backward_cluster(const float* dy, const float* y, const fl
     unsigned* flags = tmo + GC_FLAG_STRIDE;
     if (zero_async(flags, (size_t)(flag_words - GC_FLAG_STRIDE) * 4, s)) return 1;
     float* gx = (float*)(tmo + flag_words);
+    if (use_gru_x3())
+        return tg_gru_x3_bwd_launch(dy, y, save, (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, gx, flags, tmo, B, T,
+                                    H, n_bt, cw, n_bt * 16, s);
     hipLaunchKernelGGL(gru_seq_bwd_cluster_kernel<1>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, y, save, (long)save_dir_stride, w_hh_t_fwd,
                        w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, gx, flags, tmo, B, T, H, n_bt, cw, n_bt * 16);
     return check_launch("tg_gru_backward_cluster");

@@ -1,0 +1,440 @@
+// Persistent, cluster-synchronised GRU recurrence for the generator (H <= 320), recurrent product on the bf16 matrix cores at fp32
+// accuracy.  Same cluster structure and hand-off protocol as gru_cluster.hip (the f32-MFMA version, kept as the reference and the
+// TG_GRU_X3=0 fallback): the CW = ceil(H / 32) workgroups that share a batch tile exchange h_t through write-through (sc1) stores
+// + a drained flag word per member, one polling wave, sc1 loads straight into MFMA fragments; every spin is bounded.
+//
+// What changes is the arithmetic of the dependent chain.  v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 matrix rate, and the 120
+// f32 MFMAs per wave and step (3.2 us at two waves per SIMD) were half of the ~7 us step.  Here every fp32 operand is split EXACTLY
+// into three bf16 terms (common.hpp split3_bits) and the six significant partial products run on v_mfma_f32_16x16x32_bf16:
+//   * W_hh: member m's 96 rows are split ONCE, when the kernel starts, and stay in registers as bf16 A-fragments (<= 108 VGPRs);
+//   * h_t : split by its PRODUCER in the gate epilogue and published as three bf16 planes (6 bytes per element instead of 4), so
+//           the consumers' critical path holds no conversion at all -- their 16-byte sc1 loads are the MFMA B-fragments.
+// The product is taken transposed (C^T = W . h^T), so a lane's four accumulator values are four consecutive hidden units of one
+// batch row.  K steps of 32 coincide with the members' 32-unit slices: k-step j of the product reads exactly the block member j
+// published, [member][plane][row][32 units], 64 bytes per row and plane -- a wave's epilogue stores cover whole 128-byte lines.
+// Per wave and step: <= 108 bf16 MFMAs of 16 cycles instead of 120 f32 MFMAs of 32.
+#include "common.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace tg {
+
+typedef __attribute__((address_space(1))) unsigned gu32x;
+
+constexpr int XC_UNITS = 32;          // hidden units per workgroup = one 32-deep k-step of the product
+constexpr int XC_FLAG_STRIDE = 16;    // flag words per cluster (one 64-byte line)
+constexpr int XC_KS = 4;              // K slices (waves along K)
+constexpr int XC_SPS = 3;             // k-steps per slice, forward: ceil(10 / 4)
+constexpr unsigned XC_SPIN_LIMIT = 1u << 26;
+constexpr unsigned XC_RSRC3 = 0x00020000u;
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// eight consecutive fp32 (two float4) -> three bf16x8 fragments (hi / mid / lo planes)
+__device__ __forceinline__ void xc_split8(const f32x4 a, const f32x4 b, bf16x8 (&out)[3]) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xa = a[i], xb = b[i];
+        split3_bits(xa, h[i], m[i], l[i]);
+        split3_bits(xb, h[4 + i], m[4 + i], l[4 + i]);
+    }
+    out[0] = as_bf16x8(u32x4{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])});
+    out[1] = as_bf16x8(u32x4{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])});
+    out[2] = as_bf16x8(u32x4{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])});
+}
+
+// four consecutive fp32 -> three 8-byte words (4 bf16 each)
+__device__ __forceinline__ void xc_split4(const f32x4 v, u32x2 (&out)[3]) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = v[i];
+        split3_bits(x, h[i], m[i], l[i]);
+    }
+    out[0] = u32x2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])};
+    out[1] = u32x2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])};
+    out[2] = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
+}
+
+// wa: hi and mid planes of the weight fragment (registers); w_lo: its lo plane (read back from LDS: it feeds one MFMA in six)
+__device__ __forceinline__ f32x4 xc_mma(const bf16x8 (&wa)[2], const bf16x8 w_lo, const bf16x8 (&fb)[3], f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo, fb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], fb[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], fb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[1], acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[0], acc, 0, 0, 0);
+}
+
+// bounded poll of the cluster's flag words by ONE wave (relaxed sc1 loads + s_sleep); returns false after a timeout (diagnostics
+// written to the sticky timeout block)
+__device__ __forceinline__ bool xc_wait(gu32x* cl_flags, int CW, int lane, unsigned want, unsigned* tmo, int step) {
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned v = lane < CW ? __hip_atomic_load(cl_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        if (__all(v >= want)) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > XC_SPIN_LIMIT) {                    // wave-uniform
+            if (lane == 0) {
+                __hip_atomic_store((gu32x*)tmo + 1, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store((gu32x*)tmo + 2, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane < CW) __hip_atomic_store((gu32x*)tmo + 4 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store((gu32x*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+
+// exchange buffer (bytes): [slot 2][dir 2][block][plane 3][b_pad rows][32 units] bf16; block = member (forward) or gate * CW + member
+// (backward); plane_bytes = b_pad * 64
+template <int MT>
+__global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
+    const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
+    const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
+    void* hx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int CW, int b_pad) {
+    __shared__ __attribute__((aligned(16))) f32x4 red[XC_KS][2][MT][3][64];
+    __shared__ __attribute__((aligned(16))) bf16x8 wlo[8][3 * XC_SPS][64];       // lo plane of every wave's weight fragments (lane-private slots)
+    const int n_cl = 2 * n_bt;
+    int cl, m;
+    if (n_cl % 8 == 0) {        // members of one cluster on block ids of one residue mod 8: same XCD as observed (speed only)
+        cl = (blockIdx.x % 8) + 8 * ((blockIdx.x / 8) / CW);
+        m = (blockIdx.x / 8) % CW;
+    } else {
+        cl = blockIdx.x / CW;
+        m = blockIdx.x % CW;
+    }
+    const int dir = cl / n_bt, bt = cl % n_bt;
+    const float* whh = dir ? whh1 : whh0;
+    const float* bhh = dir ? bhh1 : bhh0;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: K-slice bounds and exchange offsets stay in SGPRs
+    const int ut = wave & 1, ks = wave >> 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int b0 = bt * (16 * MT);
+
+    // k-steps (= member blocks) of this wave's K slice: CW steps dealt as evenly as possible over the 4 slices
+    const int s_base = CW / XC_KS, s_rem = CW % XC_KS;
+    const int s_cnt = s_base + (ks < s_rem ? 1 : 0);
+    const int s_beg = ks * s_base + (ks < s_rem ? ks : s_rem);
+
+    // W_hh rows (gate g, unit 32 m + 16 ut + r16), k = 32 (s_beg + p) + 8 kq .. +7: pre-split A fragments, resident
+    bf16x8 wa[3][XC_SPS][2];
+    {
+        const int j = m * XC_UNITS + ut * 16 + r16;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int p = 0; p < XC_SPS; ++p) {
+                const int k = 32 * (s_beg + p) + 8 * kq;
+                const float* src = whh + (long)(g * H + j) * H + k;
+                const bool ok = p < s_cnt && j < H;
+                const f32x4 a = (ok && k < H) ? *reinterpret_cast<const f32x4*>(src) : z;          // H % 4 == 0
+                const f32x4 b = (ok && k + 4 < H) ? *reinterpret_cast<const f32x4*>(src + 4) : z;
+                bf16x8 pl[3];
+                xc_split8(a, b, pl);
+                wa[g][p][0] = pl[0]; wa[g][p][1] = pl[1];
+                wlo[wave][g * XC_SPS + p][lane] = pl[2];
+            }
+    }
+    // ---- epilogue role: thread e < 128 * MT finalises batch row (e / 8) of the tile, hidden units 4 * (e % 8) .. +3 of the slice
+    const int e = threadIdx.x;
+    const bool epi = e < 128 * MT;
+    const int row_l = e >> 3, ug = e & 7;
+    const int e_mt = (row_l >> 4) % MT, e_lane = (row_l & 15) + 16 * (ug & 3), e_ut = ug >> 2;
+    const int row = b0 + row_l;
+    const int unit0 = m * XC_UNITS + 4 * ug;
+    const bool e_ok = epi && row < B && unit0 < H;           // H % 4 == 0: the four units are valid together
+    const f32x4 bhn = (epi && unit0 < H) ? *reinterpret_cast<const f32x4*>(bhh + 2 * H + unit0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                                   // wlo visible (read back by the same lane: ordering only)
+
+    const int plane_bytes = b_pad * 64;
+    const int slot_bytes = CW * 3 * plane_bytes;                       // one (slot, dir)
+    __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx, 0, 4 * slot_bytes, XC_RSRC3);
+    gu32x* my_flag = (gu32x*)(flags + cl * XC_FLAG_STRIDE + m);
+    gu32x* cl_flags = (gu32x*)(flags + cl * XC_FLAG_STRIDE);
+    bool aborted = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int tau = dir ? T - 1 - step : step;
+        // input-side pre-activations do not depend on the recurrence: issue their loads before the wait
+        f32x4 gv[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            gv[g] = e_ok ? *reinterpret_cast<const f32x4*>(gi + dir * gi_ds + ((long)row * T + tau) * (3 * H) + g * H + unit0) : z;
+            // b_hr, b_hz enter the r / z pre-activations additively: folded in here (re-read every step, an L2 hit issued with the gi
+            // loads -- cheaper than eight resident VGPRs in a kernel at the register cap)
+            if (g < 2 && e_ok) gv[g] += *reinterpret_cast<const f32x4*>(bhh + g * H + unit0);
+        }
+        f32x4 acc[MT][3];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (step > 0) {
+            if (wave == 0 && !aborted) aborted = !xc_wait(cl_flags, CW, lane, (unsigned)step, tmo, step);
+            __syncthreads();                        // the other waves load only behind the polling wave's barrier
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // compiler ordering only; every load below is sc1
+            const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes;
+            bf16x8 fb[XC_SPS][MT][3];
+#pragma unroll
+            for (int p = 0; p < XC_SPS; ++p)
+                if (p < s_cnt) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) {
+                            // lane part in the VGPR offset (one register for all 18 loads), wave-uniform part in the scalar offset
+                            const int soff = off0 + ((s_beg + p) * 3 + s) * plane_bytes + (b0 + i * 16) * 64;
+                            fb[p][i][s] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, r16 * 64 + kq * 16, soff, 16));   // aux 16 = sc1
+                        }
+                }
+#pragma unroll
+            for (int p = 0; p < XC_SPS; ++p)
+                if (p < s_cnt) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) acc[i][g] = xc_mma(wa[g][p], wlo[wave][g * XC_SPS + p][lane], fb[p][i], acc[i][g]);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) red[ks][ut][i][g][lane] = acc[i][g];
+        __syncthreads();
+
+        f32x4 h = {0.f, 0.f, 0.f, 0.f}, r4, z4, n4, hn4;
+        if (epi) {
+            f32x4 gh[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                f32x4 s = red[0][e_ut][e_mt][g][e_lane];
+#pragma unroll
+                for (int q = 1; q < XC_KS; ++q) s += red[q][e_ut][e_mt][g][e_lane];
+                gh[g] = s;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float hn = gh[2][q] + bhn[q];
+                const float r = gate_sigmoid(gv[0][q] + gh[0][q]);
+                const float z = gate_sigmoid(gv[1][q] + gh[1][q]);
+                const float n = gate_tanh(gv[2][q] + r * hn);
+                h[q] = (1.f - z) * n + z * hp[q];
+                r4[q] = r; z4[q] = z; n4[q] = n; hn4[q] = hn;
+            }
+            hp = h;
+            // publish h_t as three bf16 planes: 8-byte write-through stores; the 8 threads of a row cover its 64 bytes, a wave's 8 rows
+            // four whole 128-byte lines per plane
+            u32x2 pl[3];
+            xc_split4(h, pl);
+            const int woff = (dir * 2 + (step & 1)) * slot_bytes + m * 3 * plane_bytes + row * 64 + ug * 8;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], hx_rsrc, woff + s * plane_bytes, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY wave drains its stores before the flag
+        __syncthreads();                                       // (also: `red` is free again)
+        if (threadIdx.x == 0) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e_ok) {                                            // outputs for later kernels: plain stores, off the critical path
+            *reinterpret_cast<f32x4*>(Y + ((long)row * T + tau) * (2 * H) + dir * H + unit0) = h;
+            if (save) {
+                float* sp = save + dir * save_ds + ((long)row * T + tau) * (4 * H) + unit0;
+                *reinterpret_cast<f32x4*>(sp) = r4;
+                *reinterpret_cast<f32x4*>(sp + H) = z4;
+                *reinterpret_cast<f32x4*>(sp + 2 * H) = n4;
+                *reinterpret_cast<f32x4*>(sp + 3 * H) = hn4;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------ backward
+// dh_tau = dy_tau + dh_next * z_next + dgh_next @ W_hh (contraction over the 3H gate rows).  A = W_hh^T rows [32 m, 32 m + 32)
+// (pre-split, resident), B = the cluster's dgh tile of the previous step: block (gate g, member j) of the exchange buffer is k-step
+// g * CW + j of the product.  One 16-row batch tile per workgroup; the 3 CW k-steps are dealt over EIGHT K slices (one per wave,
+// each wave both unit tiles): 4 k-steps per wave keep the fragment registers at 64 (weights hi / mid) + 48 (dgh planes).
+constexpr int XC_KSB = 8;             // K slices, backward
+constexpr int XC_SPB8 = 4;            // k-steps per slice, backward: ceil(30 / 8)
+
+__global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
+    const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ save, long save_ds,
+    const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh, long dg_ds,
+    void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int CW, int b_pad) {
+    __shared__ __attribute__((aligned(16))) f32x4 red[XC_KSB][2][64];
+    __shared__ __attribute__((aligned(16))) bf16x8 wlo[8][2 * XC_SPB8][64];
+    const int n_cl = 2 * n_bt;
+    int cl, m;
+    if (n_cl % 8 == 0) {
+        cl = (blockIdx.x % 8) + 8 * ((blockIdx.x / 8) / CW);
+        m = (blockIdx.x / 8) % CW;
+    } else {
+        cl = blockIdx.x / CW;
+        m = blockIdx.x % CW;
+    }
+    const int dir = cl / n_bt, bt = cl % n_bt;
+    const float* wt = dir ? wt1 : wt0;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: K-slice bounds and exchange offsets stay in SGPRs
+    const int ks = wave;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int b0 = bt * 16;
+    const int H3 = 3 * H;
+
+    const int n_steps = 3 * CW;                      // k-steps of 32 gate rows: (gate, member) blocks
+    const int s_base = n_steps / XC_KSB, s_rem = n_steps % XC_KSB;
+    const int s_cnt = s_base + (ks < s_rem ? 1 : 0);
+    const int s_beg = ks * s_base + (ks < s_rem ? ks : s_rem);
+
+    // W_hh^T rows (unit 32 m + 16 u + r16), u = 0, 1: k-step q = (gate g, member j) covers gate rows g * H + 32 j + 8 kq .. +7
+    bf16x8 wa[2][XC_SPB8][2];
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int p = 0; p < XC_SPB8; ++p) {
+                const int j = m * XC_UNITS + u * 16 + r16;
+                const int q = s_beg + p;
+                const int g = q / CW, jm = q - g * CW;
+                const int ku = 32 * jm + 8 * kq;                   // unit index inside the gate
+                const bool ok = p < s_cnt && j < H;
+                const float* src = wt + (long)(ok ? j : 0) * H3 + (ok ? g * H + ku : 0);
+                const f32x4 a = (ok && ku < H) ? *reinterpret_cast<const f32x4*>(src) : z;
+                const f32x4 b = (ok && ku + 4 < H) ? *reinterpret_cast<const f32x4*>(src + 4) : z;
+                bf16x8 pl[3];
+                xc_split8(a, b, pl);
+                wa[u][p][0] = pl[0]; wa[u][p][1] = pl[1];
+                wlo[wave][u * XC_SPB8 + p][lane] = pl[2];
+            }
+    }
+    __syncthreads();
+    const int e = threadIdx.x;
+    const bool epi = e < 128;
+    const int row_l = e >> 3, ug = e & 7;
+    const int e_lane = (row_l & 15) + 16 * (ug & 3), e_ut = ug >> 2;
+    const int row = b0 + row_l;
+    const int unit0 = m * XC_UNITS + 4 * ug;
+    const bool e_ok = epi && row < B && unit0 < H;
+    f32x4 dh_c = {0.f, 0.f, 0.f, 0.f}, z_c = {0.f, 0.f, 0.f, 0.f};
+
+    const int plane_bytes = b_pad * 64;
+    const int slot_bytes = 3 * CW * 3 * plane_bytes;
+    __amdgpu_buffer_rsrc_t gx_rsrc = __builtin_amdgcn_make_buffer_rsrc(gx, 0, 4 * slot_bytes, XC_RSRC3);
+    gu32x* my_flag = (gu32x*)(flags + cl * XC_FLAG_STRIDE + m);
+    gu32x* cl_flags = (gu32x*)(flags + cl * XC_FLAG_STRIDE);
+    bool aborted = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int tau = dir ? step : T - 1 - step;
+        const int tau_prev = dir ? tau + 1 : tau - 1;           // producer of h_prev for this cell
+        const bool has_prev = dir ? (tau < T - 1) : (tau > 0);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 dy = zero, r = zero, z = zero, n = zero, hn = zero, hp = zero;
+        if (e_ok) {
+            dy = *reinterpret_cast<const f32x4*>(dY + ((long)row * T + tau) * (2 * H) + dir * H + unit0);
+            const float* sp = save + dir * save_ds + ((long)row * T + tau) * (4 * H) + unit0;
+            r = *reinterpret_cast<const f32x4*>(sp);
+            z = *reinterpret_cast<const f32x4*>(sp + H);
+            n = *reinterpret_cast<const f32x4*>(sp + 2 * H);
+            hn = *reinterpret_cast<const f32x4*>(sp + 3 * H);
+            if (has_prev) hp = *reinterpret_cast<const f32x4*>(Y + ((long)row * T + tau_prev) * (2 * H) + dir * H + unit0);
+        }
+        f32x4 acc[2] = {zero, zero};
+        if (step > 0) {
+            if (wave == 0 && !aborted) aborted = !xc_wait(cl_flags, CW, lane, (unsigned)step, tmo, step);
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes + b0 * 64;
+            bf16x8 fb[XC_SPB8][3];
+#pragma unroll
+            for (int p = 0; p < XC_SPB8; ++p)
+                if (p < s_cnt) {
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        fb[p][s] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(gx_rsrc, r16 * 64 + kq * 16, off0 + ((s_beg + p) * 3 + s) * plane_bytes, 16));
+                }
+#pragma unroll
+            for (int p = 0; p < XC_SPB8; ++p)
+                if (p < s_cnt) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[u] = xc_mma(wa[u][p], wlo[wave][u * XC_SPB8 + p][lane], fb[p], acc[u]);
+                }
+        }
+        red[ks][0][lane] = acc[0];
+        red[ks][1][lane] = acc[1];
+        __syncthreads();
+
+        f32x4 g_r = zero, g_z = zero, g_n = zero, g_nr = zero;
+        if (epi) {
+            f32x4 s = red[0][e_ut][e_lane];
+#pragma unroll
+            for (int q = 1; q < XC_KSB; ++q) s += red[q][e_ut][e_lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dh = dy[q] + (step > 0 ? s[q] + dh_c[q] * z_c[q] : 0.f);
+                const float dn = dh * (1.f - z[q]) * (1.f - n[q] * n[q]);
+                const float dz = dh * (hp[q] - n[q]) * z[q] * (1.f - z[q]);
+                const float dr = dn * hn[q] * r[q] * (1.f - r[q]);
+                dh_c[q] = dh; z_c[q] = z[q];
+                g_r[q] = dr; g_z[q] = dz; g_n[q] = dn; g_nr[q] = dn * r[q];
+            }
+            // publish this step's dgh tile: blocks (gate 0..2, member m), three bf16 planes each
+            const int woff = (dir * 2 + (step & 1)) * slot_bytes + row * 64 + ug * 8;
+            u32x2 pl[3];
+            xc_split4(g_r, pl);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((0 * CW + m) * 3 + s) * plane_bytes, 0, 16);
+            xc_split4(g_z, pl);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((1 * CW + m) * 3 + s) * plane_bytes, 0, 16);
+            xc_split4(g_nr, pl);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((2 * CW + m) * 3 + s) * plane_bytes, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e_ok) {
+            float* gi_o = dgi + dir * dg_ds + ((long)row * T + tau) * H3 + unit0;
+            float* gh_o = dgh + dir * dg_ds + ((long)row * T + tau) * H3 + unit0;
+            *reinterpret_cast<f32x4*>(gi_o) = g_r; *reinterpret_cast<f32x4*>(gi_o + H) = g_z; *reinterpret_cast<f32x4*>(gi_o + 2 * H) = g_n;
+            *reinterpret_cast<f32x4*>(gh_o) = g_r; *reinterpret_cast<f32x4*>(gh_o + H) = g_z; *reinterpret_cast<f32x4*>(gh_o + 2 * H) = g_nr;
+        }
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+// exchange-buffer bytes of the two kernels (the flag block in front of it is laid out by gru_cluster.hip)
+int64_t tg_gru_x3_fwd_exchange_bytes(int b_pad, int cw) { return 4LL * cw * 3 * b_pad * 64; }
+int64_t tg_gru_x3_bwd_exchange_bytes(int b_pad, int cw) { return 4LL * 3 * cw * 3 * b_pad * 64; }
+
+int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
+                         float* save, long save_ds, void* hx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
+                         hipStream_t s) {
+    dim3 grid(2 * n_bt * cw);
+    if (mt == 1)
+        hipLaunchKernelGGL(gru_seq_fwd_cluster_x3_kernel<1>, grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, hx, flags, tmo, B,
+                           T, H, n_bt, cw, b_pad);
+    else
+        hipLaunchKernelGGL(gru_seq_fwd_cluster_x3_kernel<2>, grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, hx, flags, tmo, B,
+                           T, H, n_bt, cw, b_pad);
+    return check_launch("tg_gru_forward_cluster(x3)");
+}
+
+int tg_gru_x3_bwd_launch(const float* dy, const float* y, const float* save, long save_ds, const float* wt0, const float* wt1, float* dgi,
+                         float* dgh, long dg_ds, void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
+                       flags, tmo, B, T, H, n_bt, cw, b_pad);
+    return check_launch("tg_gru_backward_cluster(x3)");
+}
