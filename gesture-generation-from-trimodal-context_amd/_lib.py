@@ -112,6 +112,8 @@ def load():
     lib.tg_gemm_tn_ws_floats.argtypes = [I32, I32, I32]
     lib.tg_gemm_nt_family.restype = C.c_int32
     lib.tg_gemm_nt_family.argtypes = [C.POINTER(NtProblem)]
+    lib.tg_bn_fused_supported.restype = C.c_int32
+    lib.tg_bn_fused_supported.argtypes = [I32, I32, I32]
     lib.tg_set_math_mode.restype = C.c_int
     lib.tg_set_math_mode.argtypes = [I32]
     lib.tg_get_math_mode.restype = C.c_int

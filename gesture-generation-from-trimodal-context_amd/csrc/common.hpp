@@ -82,6 +82,7 @@ struct NtProb {
     float slope;
     int accumulate;
     int n_nt;
+    int vec_c;               // C / mul rows can be accessed as 16-byte pieces (N % 4 == 0, strides % 4 == 0, aligned pointers)
 };
 
 struct NtGroup {

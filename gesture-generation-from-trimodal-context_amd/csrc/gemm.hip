@@ -643,6 +643,8 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
     p.Bw = q.Bw; p.ldb = (long)q.ldb; p.b_seg_k = seg; p.b_seg_stride = q.b_seg_k > 0 ? (long)q.b_seg_stride : 0;
     p.bias = q.bias; p.mul = q.out_scale; p.C = q.C; p.cbs = (long)q.c_batch_stride; p.crs = (long)q.c_row_stride; p.cR = q.c_rows_out;
     p.M = q.M; p.N = q.N; p.slope = q.act_slope; p.accumulate = q.accumulate; p.n_nt = 0;
+    p.vec_c = (q.N % 4 == 0) && (q.c_batch_stride % 4 == 0) && (q.c_row_stride % 4 == 0) && aligned16(q.C) &&
+              (q.bias == nullptr || aligned16(q.bias)) && (q.out_scale == nullptr || aligned16(q.out_scale));
     return 0;
 }
 

@@ -69,7 +69,12 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
     constexpr int NPA = BM / 32, NPB = BN / 32;               // f32x4 pieces per thread per slab (8 pieces per 32-deep row)
     constexpr int NS = SPLITS;
     constexpr int NB = DB ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NB][NS][BM + BN][SP_LD];      // ONE array (A rows first, then B rows)
+    constexpr int CLD = BN + 4;                                // row stride (floats) of the epilogue's accumulator tile
+    constexpr int OPER_BYTES = NB * NS * (BM + BN) * SP_LD * 2, CT_BYTES = BM * CLD * 4;
+    // ONE array: operand slabs [NB][NS][BM + BN][SP_LD] bf16 (A rows first, then B rows); reused by the epilogue as [BM][CLD] fp32
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OPER_BYTES > CT_BYTES ? OPER_BYTES : CT_BYTES];
+    typedef __bf16 (*lds_t)[NS][BM + BN][SP_LD];
+    const lds_t lds = reinterpret_cast<lds_t>(smem);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -182,6 +187,39 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
         if (DB) buf ^= 1;
     }
 
+    const int vec_c = pr.vec_c;
+    if (vec_c) {
+        // ---- epilogue through LDS: the accumulator tile goes row-major into the (now idle) slab memory, then every thread handles
+        // 16-byte row pieces -- C, the bias, the dropout mask and the accumulate operand are read / written as coalesced float4
+        // instead of one scalar per (lane, tile) with 64-byte segments
+        float* ct = reinterpret_cast<float*>(smem);
+        __syncthreads();                                        // every wave is done with the last operand slab
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    ct[(wm * (16 * TM) + i * 16 + kq * 4 + q) * CLD + wn * (16 * TN) + j * 16 + r16] = acc[i][j][q];
+        __syncthreads();
+        constexpr int C4 = BN / 4;
+        for (int idx = t; idx < BM * C4; idx += 256) {
+            const int rl = idx / C4, c4 = idx - rl * C4;
+            const int row = m0 + rl, col = n0 + 4 * c4;
+            if (row >= M || col >= N) continue;                 // N % 4 == 0: a piece is inside or outside as a whole
+            f32x4 v = *reinterpret_cast<const f32x4*>(&ct[rl * CLD + 4 * c4]);
+            const int cb = row / cR;
+            const int cr = row - cb * cR;
+            const long o = (long)cb * cbs + (long)cr * crs + col;
+            if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q], slope);
+            if (mul) v *= *reinterpret_cast<const f32x4*>(mul + o);
+            if (accumulate) v += *reinterpret_cast<const f32x4*>(C + o);
+            *reinterpret_cast<f32x4*>(C + o) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll

@@ -151,18 +151,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // ---- small tensors (the discriminator's and the autoencoder's BatchNorms: a few thousand rows): ONE workgroup does statistics,
 // running-stat update and normalisation in one launch -- the multi-kernel path costs four launches of ~5 us for microseconds of work.
+// 16-byte accesses throughout: with C a multiple of 4 that divides 4096, thread t always sees the same four channels (its element
+// index advances by 4096 per iteration), so the per-thread partial sums are eight fp64 registers and the loads of successive
+// iterations are independent requests in flight together.
 constexpr int BN_SMALL_THREADS = 1024;
 constexpr long BN_SMALL_MAX = 1L << 19;          // elements (2 MB): stays in L2 between the two passes
 
-__device__ __forceinline__ void block_sum2(double& a, double& b, double (*sh)[BN_SMALL_THREADS], int C, int rpi) {
-    // a, b: per-thread partials of channel (threadIdx.x % C); on return threads < C hold the channel totals
-    sh[0][threadIdx.x] = a;
-    sh[1][threadIdx.x] = b;
-    __syncthreads();
-    if ((int)threadIdx.x < C) {
-        double x = 0.0, y = 0.0;
-        for (int q = 0; q < rpi; ++q) { x += sh[0][q * C + threadIdx.x]; y += sh[1][q * C + threadIdx.x]; }
-        a = x; b = y;
+// per-channel totals of the four per-thread partial pairs: threads with equal (t * 4) % C hold the same channels
+__device__ __forceinline__ void bn_small_reduce(const double (&a)[4], const double (&b)[4], double* sh_a, double* sh_b, int C) {
+    // sh_a / sh_b: [C] accumulators in LDS, zeroed by the caller
+    const int c0 = (threadIdx.x * 4) % C;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        atomicAdd(&sh_a[c0 + q], a[q]);          // LDS fp64 atomics: 1024 / (C / 4) adders per channel, once per pass
+        atomicAdd(&sh_b[c0 + q], b[q]);
     }
     __syncthreads();
 }
@@ -171,26 +173,29 @@ __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_train_kernel(
     const float* __restrict__ x, float* __restrict__ y, int rows_per_group, int C, int groups, float* __restrict__ mean, float* __restrict__ rstd,
     float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt, const float* __restrict__ gamma,
     const float* __restrict__ beta, float slope, float eps, float momentum, int repeats) {
-    __shared__ double sh[2][BN_SMALL_THREADS];
+    __shared__ double sh_a[256], sh_b[256];
     __shared__ float s_mean[256], s_rstd[256];
-    const int rpi = BN_SMALL_THREADS / C;
-    const int c = threadIdx.x % C, rsub = threadIdx.x / C;
+    const int c0 = (threadIdx.x * 4) % C;
     float rm = 0.f, rv = 0.f;
-    if ((int)threadIdx.x < C) { rm = rmean ? rmean[c] : 0.f; rv = rvar ? rvar[c] : 0.f; }
+    if ((int)threadIdx.x < C) { rm = rmean ? rmean[threadIdx.x] : 0.f; rv = rvar ? rvar[threadIdx.x] : 0.f; }
+    const long total4 = (long)rows_per_group * C / 4;
     for (int g = 0; g < groups; ++g) {
-        const float* xg = x + (long)g * rows_per_group * C;
-        double s = 0.0, ss = 0.0;
-        if (rsub < rpi)
-            for (int r = rsub; r < rows_per_group; r += rpi) {
-                const float v = xg[(long)r * C + c];
-                s += v;
-                ss += (double)v * v;
-            }
-        block_sum2(s, ss, sh, C, rpi);
+        const f32x4* xg = reinterpret_cast<const f32x4*>(x + (long)g * rows_per_group * C);
+        if ((int)threadIdx.x < C) { sh_a[threadIdx.x] = 0.0; sh_b[threadIdx.x] = 0.0; }
+        __syncthreads();
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (long i = threadIdx.x; i < total4; i += BN_SMALL_THREADS) {
+            const f32x4 v = xg[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s[q] += v[q]; ss[q] += (double)v[q] * v[q]; }
+        }
+        bn_small_reduce(s, ss, sh_a, sh_b, C);
         if ((int)threadIdx.x < C) {
+            const int c = threadIdx.x;
             const double n = (double)rows_per_group;
-            const double m = s / n;
-            double var = ss / n - m * m;
+            const double m = sh_a[c] / n;
+            double var = sh_b[c] / n - m * m;
             if (var < 0.0) var = 0.0;
             const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
             mean[g * C + c] = mf; rstd[g * C + c] = rs;
@@ -203,18 +208,24 @@ __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_train_kernel(
         }
         __syncthreads();
         if (y) {
-            float* yg = y + (long)g * rows_per_group * C;
-            const long total = (long)rows_per_group * C;
-            for (long e = threadIdx.x; e < total; e += BN_SMALL_THREADS) {
-                const int cc = (int)(e % C);
-                yg[e] = act_fn((xg[e] - s_mean[cc]) * s_rstd[cc] * gamma[cc] + beta[cc], slope);
+            f32x4* yg = reinterpret_cast<f32x4*>(y + (long)g * rows_per_group * C);
+            float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mu[q] = s_mean[c0 + q]; rs[q] = s_rstd[c0 + q]; ga[q] = gamma[c0 + q]; be[q] = beta[c0 + q]; }
+#pragma unroll 4
+            for (long i = threadIdx.x; i < total4; i += BN_SMALL_THREADS) {
+                const f32x4 v = xg[i];
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = act_fn((v[q] - mu[q]) * rs[q] * ga[q] + be[q], slope);   // association of bn_apply_kernel
+                yg[i] = o;
             }
         }
         __syncthreads();
     }
     if ((int)threadIdx.x < C) {
-        if (rmean) rmean[c] = rm;
-        if (rvar) rvar[c] = rv;
+        if (rmean) rmean[threadIdx.x] = rm;
+        if (rvar) rvar[threadIdx.x] = rv;
     }
     if (threadIdx.x == 0 && nbt) *nbt += (int64_t)groups * repeats;
 }
@@ -223,37 +234,50 @@ __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int rows, int C, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double sh[2][BN_SMALL_THREADS];
-    __shared__ double s_m1[256], s_m2[256];
-    const int rpi = BN_SMALL_THREADS / C;
-    const int c = threadIdx.x % C, rsub = threadIdx.x / C;
-    double s = 0.0, sx = 0.0;
-    if (rsub < rpi) {
-        const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
-        for (int r = rsub; r < rows; r += rpi) {
-            const float xh = (x[(long)r * C + c] - mu) * rs;
-            const float z = xh * ga + be;
-            const float dz = dy[(long)r * C + c] * (z >= 0.f ? 1.f : slope);
-            s += dz;
-            sx += (double)dz * xh;
+    __shared__ double sh_a[256], sh_b[256];
+    const int c0 = (threadIdx.x * 4) % C;
+    if ((int)threadIdx.x < C) { sh_a[threadIdx.x] = 0.0; sh_b[threadIdx.x] = 0.0; }
+    __syncthreads();
+    float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mu[q] = mean[c0 + q]; rs[q] = rstd[c0 + q]; ga[q] = gamma[c0 + q]; be[q] = beta[c0 + q]; }
+    const long total4 = (long)rows * C / 4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, sx[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (long i = threadIdx.x; i < total4; i += BN_SMALL_THREADS) {
+        const f32x4 xv = x4[i], dv = dy4[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xh = (xv[q] - mu[q]) * rs[q];
+            const float z = xh * ga[q] + be[q];
+            const float dz = dv[q] * (z >= 0.f ? 1.f : slope);
+            s[q] += dz;
+            sx[q] += (double)dz * xh;
         }
     }
-    block_sum2(s, sx, sh, C, rpi);
+    bn_small_reduce(s, sx, sh_a, sh_b, C);
     if ((int)threadIdx.x < C) {
-        if (dbeta) dbeta[c] += (float)s;
-        if (dgamma) dgamma[c] += (float)sx;
-        s_m1[c] = s / (double)rows;
-        s_m2[c] = sx / (double)rows;
+        if (dbeta) dbeta[threadIdx.x] += (float)sh_a[threadIdx.x];
+        if (dgamma) dgamma[threadIdx.x] += (float)sh_b[threadIdx.x];
     }
-    __syncthreads();
-    const long total = (long)rows * C;
-    for (long e = threadIdx.x; e < total; e += BN_SMALL_THREADS) {
-        const int cc = (int)(e % C);
-        const float rs = rstd[cc], ga = gamma[cc];
-        const float xh = (x[e] - mean[cc]) * rs;
-        const float z = xh * ga + beta[cc];
-        const float dz = dy[e] * (z >= 0.f ? 1.f : slope);
-        dx[e] = (float)((double)(ga * rs) * ((double)dz - s_m1[cc] - (double)xh * s_m2[cc]));
+    double m1[4], m2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { m1[q] = sh_a[c0 + q] / (double)rows; m2[q] = sh_b[c0 + q] / (double)rows; }
+    f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+#pragma unroll 4
+    for (long i = threadIdx.x; i < total4; i += BN_SMALL_THREADS) {
+        const f32x4 xv = x4[i], dv = dy4[i];
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xh = (xv[q] - mu[q]) * rs[q];
+            const float z = xh * ga[q] + be[q];
+            const float dz = dv[q] * (z >= 0.f ? 1.f : slope);
+            o[q] = (float)((double)(ga[q] * rs[q]) * ((double)dz - m1[q] - (double)xh * m2[q]));
+        }
+        dx4[i] = o;
     }
 }
 
@@ -261,13 +285,18 @@ __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_bwd_kernel(
 
 using namespace tg;
 
+extern "C" int32_t tg_bn_fused_supported(int32_t rows, int32_t C, int32_t groups) {
+    return C >= 4 && C <= 256 && C % 4 == 0 && 4096 % C == 0 && groups > 0 && rows > 0 && rows % groups == 0 && (long)rows * C <= BN_SMALL_MAX &&
+           ((long)(rows / groups) * C) % 4 == 0;
+}
+
 // statistics + running-stat update + normalisation of a small tensor in ONE launch (y may be NULL: statistics only)
 extern "C" int tg_bn_train_fused(const float* x, float* y, int32_t rows, int32_t C, int32_t groups, float* mean, float* rstd,
                                  float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
                                  const float* beta, float act_slope, float eps, float momentum, int32_t repeats, void* stream) {
     TG_REQUIRE(x && mean && rstd && repeats >= 1 && (y == nullptr || (gamma && beta)), "tg_bn_train_fused: null pointer / repeats < 1");
-    TG_REQUIRE(C > 0 && C <= 256 && groups > 0 && rows > 0 && rows % groups == 0 && (long)rows * C <= BN_SMALL_MAX,
-               "tg_bn_train_fused: C=%d (<=256), rows=%d, groups=%d, at most %ld elements", C, rows, groups, BN_SMALL_MAX);
+    TG_REQUIRE(tg_bn_fused_supported(rows, C, groups) && aligned16(x) && (y == nullptr || aligned16(y)),
+               "tg_bn_train_fused: unsupported shape C=%d rows=%d groups=%d (see tg_bn_fused_supported) or unaligned pointers", C, rows, groups);
     hipLaunchKernelGGL(bn_small_train_kernel, dim3(1), dim3(BN_SMALL_THREADS), 0, (hipStream_t)stream, x, y, rows / groups, C, groups, mean, rstd,
                        running_mean, running_var, num_batches_tracked, gamma, beta, act_slope, eps, momentum, repeats);
     return check_launch("tg_bn_train_fused");
@@ -315,7 +344,7 @@ extern "C" int tg_bn_backward(const float* dy, const float* x, float* dx, int32_
     TG_REQUIRE(dy && x && dx && mean && rstd && gamma && beta && ws, "tg_bn_backward: null pointer");
     TG_REQUIRE(rows > 0 && C > 0 && C <= 256, "tg_bn_backward: C=%d must be <= 256", C);
     hipStream_t s = (hipStream_t)stream;
-    if ((long)rows * C <= BN_SMALL_MAX) {          // one workgroup: reduce, then apply (3 launches -> 1)
+    if (tg_bn_fused_supported(rows, C, 1) && aligned16(dy) && aligned16(x) && aligned16(dx)) {   // one workgroup: reduce, then apply (3 launches -> 1)
         hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(1), dim3(BN_SMALL_THREADS), 0, s, dy, x, dx, rows, C, mean, rstd, gamma, beta, act_slope,
                            dgamma, dbeta);
         return check_launch("tg_bn_backward(small)");

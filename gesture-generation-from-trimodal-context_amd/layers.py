@@ -235,7 +235,7 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, *, training, groups=1
     g = groups if training else 1
     st.mean, st.rstd = empty(g, Cc, like=x), empty(g, Cc, like=x)
     st.groups, st.x, st.slope = g, x, act_slope
-    if training and x2.numel() <= ops.BN_SMALL_MAX:
+    if training and ops.bn_fused_supported(x2.shape[0], Cc, g):
         y = torch.empty_like(x) if out is None else out
         ops.bn_train_fused(x2, y.view(-1, Cc), g, st.mean, st.rstd, running_mean, running_var, nbt, gamma, beta, act_slope, repeats=repeats)
         return y, st

@@ -317,13 +317,15 @@ def bn_train_stats(x2d, groups, ws, mean, rstd, running_mean, running_var, nbt, 
          _p(running_mean), _p(running_var), _p(nbt), float(eps), float(momentum), int(repeats), _stream())
 
 
-BN_SMALL_MAX = 1 << 19        # elements a single-workgroup fused BatchNorm launch handles (csrc/norm.hip)
+def bn_fused_supported(rows, C, groups=1):
+    """True when the single-workgroup fused BatchNorm launch handles this shape (csrc/norm.hip)."""
+    return bool(_lib.load().tg_bn_fused_supported(int(rows), int(C), int(groups)))
 
 
 def bn_train_fused(x2d, y2d, groups, mean, rstd, running_mean, running_var, nbt, gamma, beta, act_slope, eps=1e-5, momentum=0.1, repeats=1):
     """Small tensors: batch statistics, running-stat update and y = act(gamma * xhat + beta) in one launch."""
     _flat(x2d, "x"); _flat(y2d, "y"); rows, Cc = x2d.shape
-    assert y2d.shape == x2d.shape and rows * Cc <= BN_SMALL_MAX and mean.numel() == groups * Cc == rstd.numel()
+    assert y2d.shape == x2d.shape and bn_fused_supported(rows, Cc, groups) and mean.numel() == groups * Cc == rstd.numel()
     assert gamma.numel() == Cc == beta.numel() and (nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda))
     call("tg_bn_train_fused", _p(x2d), _p(y2d), rows, Cc, groups, _p(_flat(mean, "mean")), _p(_flat(rstd, "rstd")), _p(running_mean),
          _p(running_var), _p(nbt), _p(_flat(gamma, "gamma")), _p(_flat(beta, "beta")), float(act_slope), float(eps), float(momentum),

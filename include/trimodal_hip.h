@@ -192,8 +192,10 @@ int tg_bn_train_stats(const float* x, int32_t rows, int32_t C, int32_t groups, d
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                       float momentum, int32_t repeats, void* stream);
 /* eval mode: mean/rstd from running stats. */
-/* Small tensors (rows * C <= 2^19, the discriminator's and the autoencoder's BatchNorms): statistics, running-stat update AND
- * y = act(gamma * xhat + beta) in ONE single-workgroup launch; y == NULL computes the statistics only. */
+/* Small tensors (the discriminator's and the autoencoder's BatchNorms): statistics, running-stat update AND y = act(gamma * xhat +
+ * beta) in ONE single-workgroup launch; y == NULL computes the statistics only.  tg_bn_fused_supported: rows * C <= 2^19, C a
+ * multiple of 4 that divides 4096 (16-byte accesses with fixed channels per thread); x / y 16-byte aligned. */
+int32_t tg_bn_fused_supported(int32_t rows, int32_t C, int32_t groups);
 int tg_bn_train_fused(const float* x, float* y, int32_t rows, int32_t C, int32_t groups, float* mean, float* rstd,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
                       const float* beta, float act_slope, float eps, float momentum, int32_t repeats, void* stream);
