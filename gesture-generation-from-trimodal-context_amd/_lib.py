@@ -46,8 +46,8 @@ SIGNATURES = {
     "tg_gru_backward": [P, P, P, I64, P, P, P, P, I64, P, I32, I32, I32, P],
     "tg_gru_h64_forward": [P, I64, P, P, P, P, P, P, I64, P, P, I32, I32, P],
     "tg_gru_h64_backward": [P, P, P, P, I64, P, P, P, P, I64, I32, I32, P],
-    "tg_gru_forward_cluster": [P, I64, P, P, P, P, P, P, I64, P, I64, I32, I32, I32, P],
-    "tg_gru_backward_cluster": [P, P, P, I64, P, P, P, P, I64, P, I64, I32, I32, I32, P],
+    "tg_gru_forward_cluster": [P, I64, P, P, P, P, P, P, I64, P, P, P, I64, I32, I32, I32, P],
+    "tg_gru_backward_cluster": [P, P, P, P, I64, P, P, P, P, I64, P, I64, I32, I32, I32, P],
     "tg_bn_train_stats": [P, I32, I32, I32, P, P, P, P, P, P, F32, F32, I32, P],
     "tg_bn_eval_stats": [P, P, I32, F32, P, P, P],
     "tg_bn_train_fused": [P, P, I32, I32, I32, P, P, P, P, P, P, P, F32, F32, F32, I32, P],
@@ -117,6 +117,7 @@ def load():
     lib.tg_set_math_mode.restype = C.c_int
     lib.tg_set_math_mode.argtypes = [I32]
     lib.tg_get_math_mode.restype = C.c_int
+    lib.tg_gru_cluster_fused_dropout.restype = C.c_int32
     lib.tg_gru_cluster_supported.restype = C.c_int32
     lib.tg_gru_cluster_supported.argtypes = [I32, I32]
     lib.tg_gru_cluster_ws_bytes.restype = C.c_int64

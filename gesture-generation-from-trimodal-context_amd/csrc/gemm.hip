@@ -558,6 +558,7 @@ using namespace tg;
 // plain bf16 operands (math mode 1).  TG_GEMM_X3=0 in the environment keeps math mode 0 on the f32-MFMA kernels below.
 extern "C" int tg_get_math_mode(void);
 int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s);
+int tg_gemm_tn_split_launch(const TnGroup& g, int total_wgs, hipStream_t s);
 static bool use_split_path() {
     static int x3 = -1;
     if (x3 < 0) {
@@ -747,7 +748,15 @@ extern "C" int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, v
     for (int i = n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
     for (int i = n; i < TG_MAX_GROUP; ++i) g.p[i] = g.p[0];
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 16>), dim3(wg), dim3(256), 0, s, g);
+    // bf16 x 3 kernel (gemm_split.hip) when every problem is on the vectorisable layout and long enough to amortise its 32-row slabs
+    bool x3 = use_split_path() && tg_get_math_mode() == 0;
+    for (int i = 0; i < n; ++i)
+        x3 = x3 && g.p[i].vec_y && g.p[i].vec_a && g.p[i].N % 4 == 0 && g.p[i].A.K % 4 == 0 && g.p[i].M >= 1024 && g.p[i].N >= 48 && g.p[i].A.K >= 48;
+    if (x3) {
+        if (int e = tg_gemm_tn_split_launch(g, wg, s)) return e;
+    } else {
+        hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 16>), dim3(wg), dim3(256), 0, s, g);
+    }
     for (int i = 0; i < n; ++i)
         if (g.p[i].partial) {       // deterministic fp64 combine of this problem's split partials
             const TnProb& p = g.p[i];

@@ -245,6 +245,162 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradients on the same bf16 x 3 scheme:  dW[n][k] += sum_m dY[m][n] * A(m, k)  (+ dbias[n] += sum_m dY[m][n]).
+// The reduction runs over ROWS, so both MFMA operands are column-strided in memory.  32-row slabs of dY and of the A window are
+// staged row-major into LDS exactly as they are loaded (coalesced 16-byte pieces, split into three bf16 planes, 8-byte stores);
+// the fragments -- eight consecutive rows m of one column per lane -- come out of LDS through gfx950's transposing read,
+// ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block and every lane receives one COLUMN of it, so two reads give
+// a lane its 8 x bf16 fragment with no shuffle and no transposed staging (which would need 2-byte scattered stores).  Plain row-major
+// rows make these reads 2-way bank-conflicted (rows 8 apart share banks whatever the padding: cdna_hip_programming.md T10); at 24
+// reads against 24 MFMAs of 16 cycles per wave and slab that is hidden.
+// Workgroup = 64 x 64 tile of dW, 4 waves as 2 (n) x 2 (k), each 32 x 32 = 2 x 2 MFMA tiles; the m range is split over workgroups
+// exactly as in gemm_tn_kernel (gemm.hip: same split plan, same epilogue: float atomics or per-split partial tiles).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+constexpr int TX_LD = 72;      // bf16 per LDS row: 64 + 8 pad (144 B: every lane address stays 8-byte aligned)
+
+// fragment of lane (r16, kq) for the 16-column tile starting at `col0` of a [32][TX_LD] bf16 image: rows 8 kq .. 8 kq + 7, column r16
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* img, int col0, int r16, int kq) {
+    const __bf16* p0 = img + (8 * kq + (r16 >> 2)) * TX_LD + col0 + 4 * (r16 & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * TX_LD));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_split_kernel(const TnGroup g) {
+    const int pi = group_find(g, blockIdx.x);
+    const TnProb& pr = g.p[pi];
+    const float* __restrict__ dY = pr.dY;
+    const long ldy = pr.ldy, ldw = pr.ldw;
+    const Win A = pr.A;
+    float* __restrict__ dW = pr.dW;
+    const int M = pr.M, N = pr.N, rows_per_split = pr.rows_per_split, out_kw = pr.out_kw;
+    float* __restrict__ partial = pr.partial;
+    float* __restrict__ dbias = pr.dbias;
+    const int n_nt = pr.n_nt, n_kt = pr.n_kt;
+    constexpr int MR = 32;                                   // slab depth = the MFMA's K
+    __shared__ __attribute__((aligned(16))) __bf16 ys[2][3][MR][TX_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 xs[2][3][MR][TX_LD];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int lid = xcd_chunked_id(blockIdx.x - g.wg_begin[pi], g.wg_begin[pi + 1] - g.wg_begin[pi]);
+    const int tn_n = lid % n_nt, tn_k = (lid / n_nt) % n_kt, tn_s = lid / (n_nt * n_kt);
+    const int n0 = tn_n * 64, k0 = tn_k * 64;
+    const int K = A.K;
+    const int m_begin = tn_s * rows_per_split;
+    if (m_begin >= M) return;                              // padding workgroup of a grouped launch (uniform: before any barrier)
+    const int m_end = min(M, m_begin + rows_per_split);
+
+    // staging: 16 pieces (of 4 columns) per 64-column slab row, 2 pieces of dY and 2 of A per thread and slab (rows srow, srow + 16)
+    const int srow = t >> 4, scol = 4 * (t & 15);
+    const int yn = n0 + scol, ak = k0 + scol;
+    const bool y_ok = yn < N, a_ok = ak < K;               // N % 4 == 0 and K % 4 == 0 on this path: a piece is in or out as a whole
+    const int kc = a_ok ? ak : 0;
+    const int a_tap = kc / A.cw, a_ch = kc - a_tap * A.cw;
+    int mb[2], mr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m_begin + srow + 16 * i;
+        mb[i] = m / A.rows_out;
+        mr[i] = m - mb[i] * A.rows_out;
+    }
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bias = dbias != nullptr && tn_k == 0;
+
+    f32x4 yv[2], xv[2];
+    auto fetch = [&](int m0) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + srow + 16 * i;
+            const bool in = m < m_end;
+            yv[i] = (in && y_ok) ? *reinterpret_cast<const f32x4*>(dY + (long)m * ldy + yn) : z;
+            const int sr = mr[i] * A.step + A.shift + a_tap * A.dil;
+            xv[i] = (in && a_ok && sr >= 0 && sr < A.rows_in) ? *reinterpret_cast<const f32x4*>(A.ptr + (long)mb[i] * A.bs + (long)sr * A.rs + a_ch) : z;
+            mr[i] += MR;
+            while (mr[i] >= A.rows_out) { mr[i] -= A.rows_out; ++mb[i]; }
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(m_begin);
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += MR) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x2 o[3];
+            split4<3>(yv[i], o);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x2*>(&ys[buf][s][srow + 16 * i][scol]) = o[s];
+            if (want_bias) bsum += yv[i];
+            split4<3>(xv[i], o);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x2*>(&xs[buf][s][srow + 16 * i][scol]) = o[s];
+        }
+        __syncthreads();                                   // slab `buf` complete; the other buffer is free again
+        if (m0 + MR < m_end) fetch(m0 + MR);               // next slab's loads fly during the MFMAs
+        bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                fa[s][q] = tr_frag(&ys[buf][s][0][0], wn * 32 + q * 16, r16, kq);
+                fb[s][q] = tr_frag(&xs[buf][s][0][0], wk * 32 + q * 16, r16, kq);
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x4 cc = acc[nt][kt];
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][nt], fb[0][kt], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][nt], fb[2][kt], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][nt], fb[1][kt], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][nt], fb[0][kt], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][nt], fb[1][kt], cc, 0, 0, 0);
+                acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][nt], fb[0][kt], cc, 0, 0, 0);
+            }
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + wn * 32 + nt * 16 + kq * 4 + i;
+                const int kcol = k0 + wk * 32 + kt * 16 + r16;
+                if (n < N && kcol < K && partial) {
+                    partial[((long)tn_s * N + n) * K + kcol] = acc[nt][kt][i];     // combined in fp64 by the reduce kernel
+                } else if (n < N && kcol < K) {
+                    const long off = out_kw > 0 ? (long)(kcol % A.cw) * out_kw + kcol / A.cw : (long)kcol;
+                    atomicAdd(&dW[(long)n * ldw + off], acc[nt][kt][i]);
+                }
+            }
+    if (want_bias) {       // column sums of dY over this split: 16 staging rows -> one value per column
+        __shared__ __attribute__((aligned(16))) float bs[16][68];
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&bs[srow][scol]) = bsum;
+        __syncthreads();
+        if (t < 64 && n0 + t < N) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += bs[r][t];
+            atomicAdd(&dbias[n0 + t], sacc);
+        }
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -299,4 +455,10 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
 #undef TG_SPLIT_MENU
 #undef TG_SPLIT
     return check_launch("tg_gemm_nt(split)");
+}
+
+// every problem of the group must be on the vectorisable layout (checked by the caller: TnProb.vec_y && vec_a, N % 4 == 0, K % 4 == 0)
+int tg_gemm_tn_split_launch(const TnGroup& g, int total_wgs, hipStream_t s) {
+    hipLaunchKernelGGL(gemm_tn_split_kernel, dim3(total_wgs), dim3(256), 0, s, g);
+    return check_launch("tg_gemm_tn(split)");
 }

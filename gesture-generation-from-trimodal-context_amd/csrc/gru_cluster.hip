@@ -378,9 +378,9 @@ using namespace tg;
 int64_t tg_gru_x3_fwd_exchange_bytes(int b_pad, int cw);
 int64_t tg_gru_x3_bwd_exchange_bytes(int b_pad, int cw);
 int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
-                         float* save, long save_ds, void* hx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
-                         hipStream_t s);
-int tg_gru_x3_bwd_launch(const float* dy, const float* y, const float* save, long save_ds, const float* wt0, const float* wt1, float* dgi,
+                         float* save, long save_ds, const float* drop_mask, float* y_drop, void* hx, unsigned* flags, unsigned* tmo, int B, int T,
+                         int H, int n_bt, int cw, int b_pad, hipStream_t s);
+int tg_gru_x3_bwd_launch(const float* dy, const float* dy_mask, const float* y, const float* save, long save_ds, const float* wt0, const float* wt1, float* dgi,
                          float* dgh, long dg_ds, void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
                          hipStream_t s);
 static bool use_gru_x3() {
@@ -431,10 +431,15 @@ extern "C" int64_t tg_gru_cluster_ws_bytes(int32_t B, int32_t H) {
     return flag_words * 4 + (f32_bytes > x3_bytes ? f32_bytes : x3_bytes);
 }
 
+extern "C" int32_t tg_gru_cluster_fused_dropout(void) { return use_gru_x3() ? 1 : 0; }
+
 extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
                                       const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
-                                      void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream) {
+                                      const float* drop_mask, float* y_drop, void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H,
+                                      void* stream) {
     TG_REQUIRE(gi && w_hh_fwd && w_hh_rev && b_hh_fwd && b_hh_rev && y && ws, "tg_gru_forward_cluster: null pointer");
+    TG_REQUIRE((drop_mask == nullptr) == (y_drop == nullptr) && (drop_mask == nullptr || (use_gru_x3() && aligned16(drop_mask) && aligned16(y_drop))),
+               "tg_gru_forward_cluster: drop_mask / y_drop go together, 16-byte aligned, and need tg_gru_cluster_fused_dropout() != 0");
     TG_REQUIRE(T > 0 && tg_gru_cluster_supported(B, H), "tg_gru_forward_cluster: unsupported shape B=%d H=%d", B, H);
     TG_REQUIRE(ws_bytes >= tg_gru_cluster_ws_bytes(B, H), "tg_gru_forward_cluster: workspace too small");
     TG_REQUIRE(aligned16(gi) && aligned16(w_hh_fwd) && aligned16(w_hh_rev) && aligned16(b_hh_fwd) && aligned16(b_hh_rev) && aligned16(y) &&
@@ -453,8 +458,8 @@ extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, co
     float* hx = (float*)(tmo + flag_words);
     const int b_pad = n_bt * 16 * mt;
     if (use_gru_x3())
-        return tg_gru_x3_fwd_launch(mt, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, hx, flags,
-                                    tmo, B, T, H, n_bt, cw, b_pad, s);
+        return tg_gru_x3_fwd_launch(mt, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask,
+                                    y_drop, hx, flags, tmo, B, T, H, n_bt, cw, b_pad, s);
     dim3 grid(2 * n_bt * cw);
     if (mt == 1)
         hipLaunchKernelGGL(gru_seq_fwd_cluster_kernel<1>, grid, dim3(512), 0, s, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd,
@@ -487,10 +492,11 @@ extern "C" int64_t tg_gru_cluster_bwd_ws_bytes(int32_t B, int32_t H) {
     return flag_words * 4 + (f32_bytes > x3_bytes ? f32_bytes : x3_bytes);
 }
 
-extern "C" int tg_gru_backward_cluster(const float* dy, const float* y, const float* save, int64_t save_dir_stride,
+extern "C" int tg_gru_backward_cluster(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
                                        const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
                                        void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream) {
     TG_REQUIRE(dy && y && save && w_hh_t_fwd && w_hh_t_rev && dgi && dgh && ws, "tg_gru_backward_cluster: null pointer");
+    TG_REQUIRE(dy_mask == nullptr || (use_gru_x3() && aligned16(dy_mask)), "tg_gru_backward_cluster: dy_mask needs tg_gru_cluster_fused_dropout() != 0");
     TG_REQUIRE(T > 0 && tg_gru_cluster_bwd_supported(B, H), "tg_gru_backward_cluster: unsupported shape B=%d H=%d", B, H);
     TG_REQUIRE(ws_bytes >= tg_gru_cluster_bwd_ws_bytes(B, H), "tg_gru_backward_cluster: workspace too small");
     TG_REQUIRE(aligned16(dy) && aligned16(y) && aligned16(save) && aligned16(w_hh_t_fwd) && aligned16(w_hh_t_rev) && aligned16(dgi) &&
@@ -505,7 +511,7 @@ extern "C" int tg_gru_backward_cluster(const float* dy, const float* y, const fl
     if (zero_async(flags, (size_t)(flag_words - GC_FLAG_STRIDE) * 4, s)) return 1;
     float* gx = (float*)(tmo + flag_words);
     if (use_gru_x3())
-        return tg_gru_x3_bwd_launch(dy, y, save, (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, gx, flags, tmo, B, T,
+        return tg_gru_x3_bwd_launch(dy, dy_mask, y, save, (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, gx, flags, tmo, B, T,
                                     H, n_bt, cw, n_bt * 16, s);
     hipLaunchKernelGGL(gru_seq_bwd_cluster_kernel<1>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, y, save, (long)save_dir_stride, w_hh_t_fwd,
                        w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, gx, flags, tmo, B, T, H, n_bt, cw, n_bt * 16);

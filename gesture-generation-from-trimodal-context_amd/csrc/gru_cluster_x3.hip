@@ -95,7 +95,8 @@ template <int MT>
 __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
     const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
-    void* hx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int CW, int b_pad) {
+    const float* __restrict__ drop_mask, float* __restrict__ y_drop, void* hx, unsigned* flags, unsigned* tmo, int B, int T, int H,
+    int n_bt, int CW, int b_pad) {
     __shared__ __attribute__((aligned(16))) f32x4 red[XC_KS][2][MT][3][64];
     __shared__ __attribute__((aligned(16))) bf16x8 wlo[8][3 * XC_SPS][64];       // lo plane of every wave's weight fragments (lane-private slots)
     const int n_cl = 2 * n_bt;
@@ -243,7 +244,9 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
         __syncthreads();                                       // (also: `red` is free again)
         if (threadIdx.x == 0) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (e_ok) {                                            // outputs for later kernels: plain stores, off the critical path
-            *reinterpret_cast<f32x4*>(Y + ((long)row * T + tau) * (2 * H) + dir * H + unit0) = h;
+            const long yo = ((long)row * T + tau) * (2 * H) + dir * H + unit0;
+            *reinterpret_cast<f32x4*>(Y + yo) = h;
+            if (y_drop) *reinterpret_cast<f32x4*>(y_drop + yo) = h * *reinterpret_cast<const f32x4*>(drop_mask + yo);   // fused inter-layer dropout
             if (save) {
                 float* sp = save + dir * save_ds + ((long)row * T + tau) * (4 * H) + unit0;
                 *reinterpret_cast<f32x4*>(sp) = r4;
@@ -264,7 +267,7 @@ constexpr int XC_KSB = 8;             // K slices, backward
 constexpr int XC_SPB8 = 4;            // k-steps per slice, backward: ceil(30 / 8)
 
 __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
-    const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ save, long save_ds,
+    const float* __restrict__ dY, const float* __restrict__ dy_mask, const float* __restrict__ Y, const float* __restrict__ save, long save_ds,
     const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh, long dg_ds,
     void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int CW, int b_pad) {
     __shared__ __attribute__((aligned(16))) f32x4 red[XC_KSB][2][64];
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
         f32x4 dy = zero, r = zero, z = zero, n = zero, hn = zero, hp = zero;
         if (e_ok) {
             dy = *reinterpret_cast<const f32x4*>(dY + ((long)row * T + tau) * (2 * H) + dir * H + unit0);
+            if (dy_mask) dy = dy * *reinterpret_cast<const f32x4*>(dy_mask + ((long)row * T + tau) * (2 * H) + dir * H + unit0);
             const float* sp = save + dir * save_ds + ((long)row * T + tau) * (4 * H) + unit0;
             r = *reinterpret_cast<const f32x4*>(sp);
             z = *reinterpret_cast<const f32x4*>(sp + H);
@@ -419,22 +423,22 @@ int64_t tg_gru_x3_fwd_exchange_bytes(int b_pad, int cw) { return 4LL * cw * 3 * 
 int64_t tg_gru_x3_bwd_exchange_bytes(int b_pad, int cw) { return 4LL * 3 * cw * 3 * b_pad * 64; }
 
 int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
-                         float* save, long save_ds, void* hx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
-                         hipStream_t s) {
+                         float* save, long save_ds, const float* drop_mask, float* y_drop, void* hx, unsigned* flags, unsigned* tmo, int B, int T,
+                         int H, int n_bt, int cw, int b_pad, hipStream_t s) {
     dim3 grid(2 * n_bt * cw);
     if (mt == 1)
-        hipLaunchKernelGGL(gru_seq_fwd_cluster_x3_kernel<1>, grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, hx, flags, tmo, B,
-                           T, H, n_bt, cw, b_pad);
+        hipLaunchKernelGGL(gru_seq_fwd_cluster_x3_kernel<1>, grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, drop_mask, y_drop,
+                           hx, flags, tmo, B, T, H, n_bt, cw, b_pad);
     else
-        hipLaunchKernelGGL(gru_seq_fwd_cluster_x3_kernel<2>, grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, hx, flags, tmo, B,
-                           T, H, n_bt, cw, b_pad);
+        hipLaunchKernelGGL(gru_seq_fwd_cluster_x3_kernel<2>, grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, drop_mask, y_drop,
+                           hx, flags, tmo, B, T, H, n_bt, cw, b_pad);
     return check_launch("tg_gru_forward_cluster(x3)");
 }
 
-int tg_gru_x3_bwd_launch(const float* dy, const float* y, const float* save, long save_ds, const float* wt0, const float* wt1, float* dgi,
+int tg_gru_x3_bwd_launch(const float* dy, const float* dy_mask, const float* y, const float* save, long save_ds, const float* wt0, const float* wt1, float* dgi,
                          float* dgh, long dg_ds, void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
                          hipStream_t s) {
-    hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
+    hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, dy_mask, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
                        flags, tmo, B, T, H, n_bt, cw, b_pad);
     return check_launch("tg_gru_backward_cluster(x3)");
 }

@@ -280,9 +280,9 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     tape.x, tape.y, tape.save, tape.masks = [], [], [], []
     tape.B, tape.T, tape.H = B, T, H
     cur = x
-    # H = 64 (discriminator): the inter-layer dropout is fused into the recurrence kernels (csrc/gru_h64.hip); the masks of all
-    # layers of the pass come from ONE draw launch (or from the parity tests)
-    fused_drop = H == 64 and training and n_layers > 1 and (p_drop > 0 or inject is not None)
+    # the inter-layer dropout rides in the recurrence kernels (csrc/gru_h64.hip, csrc/gru_cluster_x3.hip): the masks of all layers of
+    # the pass come from ONE draw launch (or from the parity tests)
+    fused_drop = ops.gru_fused_dropout(B, H) and training and n_layers > 1 and (p_drop > 0 or inject is not None)
     drawn = None
     if fused_drop and p_drop > 0 and not (inject is not None and all(f"{tag}.gru.drop{l}" in inject for l in range(n_layers - 1))):
         drawn = ops.dropout_mask(empty(n_layers - 1, B, T, 2 * H, like=x), p_drop, rng.state, rng.site(f"{tag}.gru.drop"))
@@ -382,7 +382,7 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
     for l in range(n_layers - 1, -1, -1):
         dy_mask = None
         if tape.masks[l] is not None:
-            if H == 64:
+            if ops.gru_fused_dropout(nb, H, bwd=True):
                 dy_mask = tape.masks[l][rows].contiguous()         # multiplied in while the recurrence kernel loads dy
             else:
                 dy = ops.mul(dy, tape.masks[l][rows].contiguous(), torch.empty_like(dy))

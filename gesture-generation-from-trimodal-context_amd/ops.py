@@ -248,9 +248,18 @@ def check_async_errors():
                                f"workgroup {info[2]}, flag words seen {info[4:14]}; results are invalid")
 
 
+def gru_fused_dropout(B, H, bwd=False):
+    """True when the recurrence kernel that will run for (B, H) applies the inter-layer dropout itself (drop_mask / dy_mask)."""
+    if H == 64:
+        return True
+    lib = _lib.load()
+    fits = lib.tg_gru_cluster_bwd_supported(B, H) if bwd else lib.tg_gru_cluster_supported(B, H)
+    return bool(GRU_CLUSTER and H > 64 and fits and lib.tg_gru_cluster_fused_dropout())
+
+
 def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None):
     """gi: [2, B, T, 3H] contiguous; w_hh/b_hh: (fwd, rev) pairs; y: [B, T, 2H]; save: [2, B, T, 4H] or None.
-    drop_mask / y_drop ([B, T, 2H], H = 64 only): fused inter-layer dropout, y_drop = y * drop_mask."""
+    drop_mask / y_drop ([B, T, 2H], where gru_fused_dropout(B, H)): fused inter-layer dropout, y_drop = y * drop_mask."""
     _flat(gi, "gi"); _flat(y, "y")
     _, B, T, H3 = gi.shape
     H = H3 // 3
@@ -266,12 +275,15 @@ def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None):
         call("tg_gru_h64_forward", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
              B * T * 4 * H, _p(drop_mask), _p(y_drop), B, T, _stream())
         return y
-    assert drop_mask is None and y_drop is None, "fused dropout exists for H = 64 only"
     if GRU_CLUSTER and H > 64 and _lib.load().tg_gru_cluster_supported(B, H):
+        if drop_mask is not None:
+            _flat(drop_mask, "drop_mask"); _flat(y_drop, "y_drop")
+            assert tuple(drop_mask.shape) == tuple(y.shape) == tuple(y_drop.shape) and gru_fused_dropout(B, H)
         ws = _gru_cluster_ws(gi.device, B, H)
         call("tg_gru_forward_cluster", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
-             B * T * 4 * H, C.c_void_p(ws.data_ptr()), ws.numel() * 4, B, T, H, _stream())
+             B * T * 4 * H, _p(drop_mask), _p(y_drop), C.c_void_p(ws.data_ptr()), ws.numel() * 4, B, T, H, _stream())
         return y
+    assert drop_mask is None and y_drop is None, "fused dropout: H = 64 or the bf16x3 cluster kernels only (ops.gru_fused_dropout)"
     call("tg_gru_forward", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
          B * T * 4 * H, B, T, H, _stream())
     return y
@@ -297,12 +309,14 @@ def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None, dy
         call("tg_gru_h64_backward", _p(dy), _p(dy_mask), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
              _p(dgi), _p(dgh), nb * T * 3 * H, nb, T, _stream())
         return
-    assert dy_mask is None, "fused dropout backward exists for H = 64 only"
     if GRU_CLUSTER and H > 64 and _lib.load().tg_gru_cluster_bwd_supported(nb, H):
+        if dy_mask is not None:
+            _flat(dy_mask, "dy_mask"); assert tuple(dy_mask.shape) == tuple(dy.shape) and gru_fused_dropout(nb, H, bwd=True)
         ws = _gru_cluster_ws(dy.device, nb, H, bwd=True)
-        call("tg_gru_backward_cluster", _p(dy), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
+        call("tg_gru_backward_cluster", _p(dy), _p(dy_mask), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
              _p(dgi), _p(dgh), nb * T * 3 * H, C.c_void_p(ws.data_ptr()), ws.numel() * 4, nb, T, H, _stream())
         return
+    assert dy_mask is None, "fused dropout backward: H = 64 or the bf16x3 cluster kernels only (ops.gru_fused_dropout)"
     call("tg_gru_backward", _p(dy), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
          _p(dgi), _p(dgh), nb * T * 3 * H, _p(dh_scratch), nb, T, H, _stream())
 

@@ -169,15 +169,19 @@ int tg_gru_h64_backward(const float* dy, const float* dy_mask, const float* y, c
  * count is queried: B <= 384 at H = 300 on the 256 CUs of an unpartitioned MI355X; 0 under CPX/DPX partitions that are too small). */
 int32_t tg_gru_cluster_supported(int32_t B, int32_t H);
 int64_t tg_gru_cluster_ws_bytes(int32_t B, int32_t H);
+/* drop_mask / y_drop ([B][T][2H], both or neither; need tg_gru_cluster_fused_dropout() != 0): the inter-layer dropout of
+ * nn.GRU(dropout=p) rides in the kernel's output stage, y_drop = y * drop_mask is the next layer's input. */
+int32_t tg_gru_cluster_fused_dropout(void);
 int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
                            const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
-                           void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream);
+                           const float* drop_mask, float* y_drop, void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream);
 
 /* Persistent cluster-synchronised variant of tg_gru_backward (B <= 192 at H = 300; no dh_scratch: the carried dh stays in
  * registers).  Same workspace / timeout-word convention as tg_gru_forward_cluster. */
 int32_t tg_gru_cluster_bwd_supported(int32_t B, int32_t H);
 int64_t tg_gru_cluster_bwd_ws_bytes(int32_t B, int32_t H);
-int tg_gru_backward_cluster(const float* dy, const float* y, const float* save, int64_t save_dir_stride,
+/* dy_mask ([B][T][2H] or NULL): multiplied into dy while it is loaded (the backward of the fused dropout). */
+int tg_gru_backward_cluster(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
                             const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
                             void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream);
 

@@ -498,3 +498,47 @@ def test_grouped_gemm_launches_and_concatenated_k(pkg, dev):
     ops.gemm_tn_group([dict(dY=dy, A=Win.plain(xx), dW=dw, dbias=db) for dy, xx, dw, db in zip(dys, xs, dws, dbs)])
     for dy, xx, dw, db in zip(dys, xs, dws, dbs):
         assert rel(dw, dy.double().cpu().t() @ xx.double().cpu()) < 1e-5 and rel(db, dy.double().cpu().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(4352, 900, 600), (1088, 52, 76), (2176, 300, 108), (1500, 64, 48)])
+def test_gemm_tn_split_bf16x3_path_is_fp32_accurate(pkg, dev, M, N, K):
+    """Weight gradients on the bf16 matrix cores (three-way split operands, hardware-transposed LDS reads, csrc/gemm_split.hip) against
+    fp64 at the fp32 tolerance: ragged N / K (multiples of 4, not of the 64-wide tile), rows spanning 8 decades, bias gradient, and a
+    second call accumulating on top of the first."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g) * torch.pow(10.0, torch.randint(-4, 3, (1, N), generator=g).float())
+    x = torch.randn(M, K, generator=g)
+    dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    ops.gemm_tn(dy.to(dev), Win.plain(x.to(dev)), dw, dbias=db)
+    ref = dy.double().t() @ x.double()
+    scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)              # per output row: the dY columns span 7 decades
+    assert float(((dw.double().cpu() - ref).abs() / scale).max()) < 1e-5
+    assert rel(db, dy.double().sum(0)) < 1e-5
+    ops.gemm_tn(dy.to(dev), Win.plain(x.to(dev)), dw, dbias=db)
+    assert float(((dw.double().cpu() - 2 * ref).abs() / scale).max()) < 1e-5
+
+
+def test_gemm_tn_split_with_conv_window(pkg, dev):
+    """The same kernel behind a dilated causal conv window (the TCN weight gradient, M = B*T = 1360 rows) and the shifted h_{t-1} view of
+    the GRU's W_hh gradient."""
+    Lm, ops, Win = pkg.layers, pkg.ops, pkg.ops.Win
+    B, T, Cc, d = 40, 34, 300, 4
+    x = rnd(B, Cc, T, seed=80).double().requires_grad_(True)
+    w = rnd(Cc, Cc, 2, seed=81, scale=0.05).double().requires_grad_(True)
+    y = F.conv1d(x, w, None, padding=d, dilation=d)[:, :, :T]
+    dyt = rnd(B, Cc, T, seed=82).double()
+    y.backward(dyt)
+    dwp = torch.zeros(Cc, 2 * Cc, device=dev)
+    dc = cl(dyt.float()).to(dev).reshape(B * T, Cc)
+    ops.gemm_tn(dc, Win.conv(cl(x.detach().float()).to(dev), 2, pad=d, dil=d, rows_out=T), dwp)
+    want = w.grad.permute(0, 2, 1).reshape(Cc, 2 * Cc)                       # packed [Co][tap * Ci + ci]
+    assert rel(dwp, want) < 1e-5
+    H = 300
+    yl = rnd(B, T, 2 * H, seed=83).to(dev)
+    gh = rnd(B * T, 3 * H, seed=84).to(dev)
+    dwh = torch.zeros(3 * H, H, device=dev)
+    hwin = Win.taps(yl[:, :, :H], 1, shift=-1, dil=1, rows_out=T)
+    ops.gemm_tn(gh, hwin, dwh)
+    hprev = torch.cat([torch.zeros(B, 1, H, device=dev), yl[:, :-1, :H]], dim=1).reshape(B * T, H)
+    assert rel(dwh, gh.double().cpu().t() @ hprev.double().cpu()) < 1e-5
