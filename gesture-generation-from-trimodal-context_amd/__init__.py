@@ -9,6 +9,7 @@ from .modules import ConvDiscriminator, EmbeddingNet, PoseGenerator  # noqa: F40
 from .optim import FusedAdam  # noqa: F401
 from .train_gan import GanTrainer, GraphedGanStep, StepLosses  # noqa: F401
 from .vocab import Vocab  # noqa: F401
+from . import checkpoint, config, data, ddp, eval_metrics, fgd, layers, ops, synthesize  # noqa: F401,E402  (hip.fgd, hip.config, ... as INTEGRATION.md uses them)
 
 __all__ = ["PoseGenerator", "ConvDiscriminator", "EmbeddingNet", "FusedAdam", "GanTrainer", "GraphedGanStep", "StepLosses",
            "Vocab"]

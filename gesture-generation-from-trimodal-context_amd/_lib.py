@@ -82,6 +82,8 @@ SIGNATURES = {
     "tg_reparam_bwd": [P, P, P, P, P, I64, P],
     "tg_gan_d_loss": [P, P, I32, P, P, P, P],
     "tg_gan_g_loss": [P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32, F32, I32, P, P, P, P, P, P, P],
+    "tg_d_head_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, P],
+    "tg_d_head_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
     "tg_l1_mean": [P, P, I64, P, P],
     "tg_sigmoid": [P, P, I64, P],
     "tg_sigmoid_bwd": [P, P, P, I64, P],

@@ -418,7 +418,7 @@ int tg_act_mask_bwd(const float* dy, const float* y, const float* mask, float sl
     return check_launch("tg_act_mask_bwd");
 }
 int tg_zero(void* p, int64_t bytes, void* stream) {
-    TG_REQUIRE(bytes >= 0, "tg_zero: bad size");
+    TG_REQUIRE(p != nullptr && bytes >= 0 && bytes % 4 == 0, "tg_zero: null pointer or size %ld not a non-negative multiple of 4", (long)bytes);
     return zero_async(p, (size_t)bytes, (hipStream_t)stream);
 }
 int tg_mul(const float* x, const float* mask, float* y, int64_t n, void* stream) {

@@ -208,6 +208,74 @@ __global__ __launch_bounds__(256) void pose_metrics_kernel(const float* __restri
     }
 }
 
+// ---- discriminator head (multimodal_context_net.py:243-252): sum of the GRU directions -> Linear(H -> 1) per frame -> view(B, T) ->
+// Linear(T -> 1) -> sigmoid, as ONE launch (four before: add_halves, two 1-column GEMMs, sigmoid); one wave per clip.
+__global__ __launch_bounds__(256) void d_head_fwd_kernel(const float* __restrict__ y, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ l1,
+                                                         float* __restrict__ logit, float* __restrict__ prob, int B, int T, int H) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float* yr = y + ((long)b * T + t) * (2 * H);
+        float v = 0.f;
+        for (int j = lane; j < H; j += 64) v += (yr[j] + yr[H + j]) * w1[j];
+        v = wave_sum(v);                                     // valid in lane 0
+        if (lane == 0) {
+            const float l = v + b1[0];
+            l1[(long)b * T + t] = l;
+            acc += l * w2[t];
+        }
+    }
+    if (lane == 0) {
+        const float lg = acc + b2[0];
+        logit[b] = lg;
+        prob[b] = sigmoidf_(lg);
+    }
+}
+
+// backward of the head for d_logit (gradient w.r.t. the pre-sigmoid output): dy [B][T][2H] (both halves equal), and -- when
+// param_grads -- dW1 / db1 / dW2 / db2 accumulated with one atomic per workgroup and entry.
+__global__ __launch_bounds__(256) void d_head_bwd_kernel(const float* __restrict__ d_logit, const float* __restrict__ y,
+                                                         const float* __restrict__ l1, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, float* __restrict__ dy, float* __restrict__ dw1,
+                                                         float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2, int B,
+                                                         int T, int H) {
+    __shared__ float s_w1[4][64], s_w2[4][64], s_b[4][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.x * 4 + wv;
+    float a_w1 = 0.f, a_w2 = 0.f, a_b1 = 0.f, a_b2 = 0.f;      // H <= 64 on this path: lane j owns dW1[j]; lane t < T owns dW2[t]
+    if (b < B) {
+        const float dl = d_logit[b];
+        a_b2 = dl;
+        if (lane < T) a_w2 = dl * l1[(long)b * T + lane];
+        for (int t = 0; t < T; ++t) {
+            const float dl1 = dl * w2[t];
+            a_b1 += dl1;
+            if (lane < H) {
+                const long o = ((long)b * T + t) * (2 * H) + lane;
+                const float dv = dl1 * w1[lane];
+                if (dw1) a_w1 += dl1 * (y[o] + y[o + H]);
+                dy[o] = dv;
+                dy[o + H] = dv;
+            }
+        }
+    }
+    if (!dw1) return;                                          // (uniform) input gradient only
+    s_w1[wv][lane] = a_w1; s_w2[wv][lane] = a_w2;
+    if (lane == 0) { s_b[wv][0] = a_b1; s_b[wv][1] = a_b2; }
+    __syncthreads();
+    if (wv == 0) {
+        const float t1 = s_w1[0][lane] + s_w1[1][lane] + s_w1[2][lane] + s_w1[3][lane];
+        const float t2 = s_w2[0][lane] + s_w2[1][lane] + s_w2[2][lane] + s_w2[3][lane];
+        if (lane < H) atomicAdd(&dw1[lane], t1);
+        if (lane < T) atomicAdd(&dw2[lane], t2);
+        if (lane == 0) {
+            atomicAdd(db1, s_b[0][0] + s_b[1][0] + s_b[2][0] + s_b[3][0]);
+            atomicAdd(db2, s_b[0][1] + s_b[1][1] + s_b[2][1] + s_b[3][1]);
+        }
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -236,6 +304,21 @@ int tg_gan_g_loss(const float* out_pose, const float* target, const float* out_r
     return check_launch("tg_gan_g_loss");
 }
 
+int tg_d_head_fwd(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, float* l1, float* logit, float* prob,
+                  int32_t B, int32_t T, int32_t H, void* stream) {
+    TG_REQUIRE(y && w1 && b1 && w2 && b2 && l1 && logit && prob && B > 0 && T > 0 && H > 0, "tg_d_head_fwd: bad arguments");
+    hipLaunchKernelGGL(d_head_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, y, w1, b1, w2, b2, l1, logit, prob, B, T, H);
+    return check_launch("tg_d_head_fwd");
+}
+int tg_d_head_bwd(const float* d_logit, const float* y, const float* l1, const float* w1, const float* w2, float* dy, float* dw1, float* db1,
+                  float* dw2, float* db2, int32_t B, int32_t T, int32_t H, void* stream) {
+    TG_REQUIRE(d_logit && y && l1 && w1 && w2 && dy && B > 0 && T > 0 && T <= 64 && H > 0 && H <= 64, "tg_d_head_bwd: bad arguments (T, H <= 64)");
+    TG_REQUIRE((dw1 != nullptr) == (db1 != nullptr) && (dw1 != nullptr) == (dw2 != nullptr) && (dw1 != nullptr) == (db2 != nullptr),
+               "tg_d_head_bwd: parameter gradients are all given or all NULL");
+    hipLaunchKernelGGL(d_head_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, d_logit, y, l1, w1, w2, dy, dw1, db1, dw2, db2, B,
+                       T, H);
+    return check_launch("tg_d_head_bwd");
+}
 int tg_l1_mean(const float* a, const float* b, int64_t n, float* out, void* stream) {
     TG_REQUIRE(a && b && out && n > 0, "tg_l1_mean: bad arguments");
     if (zero_async(out, sizeof(float), ST)) return 1;

@@ -367,11 +367,9 @@ class DiscriminatorEngine(_Engine):
         T = x.shape[1]
         y, gtape = L.gru_stack_fwd(x, P, "gru", 4, self.H, p_drop=0.3, training=training, rng=self.rng, save=save,
                                    inject=inject, tag=tag)
-        o = ops.add_halves(y, L.empty(Bs * T, self.H, like=y))
-        l1 = L.linear_fwd(o, P["out.weight"], P["out.bias"])                 # (Bs*T, 1)
-        logit = L.linear_fwd(l1.view(Bs, T), P["out2.weight"], P["out2.bias"])   # (Bs, 1)
-        prob = ops.sigmoid(logit, torch.empty_like(logit))
-        tp.update(convs=convs, gru=gtape, o=o, l1=l1, T=T)
+        # head: direction sum -> Linear(64 -> 1) per frame -> Linear(28 -> 1) -> sigmoid (:243-252), one launch
+        l1, logit, prob = ops.d_head_fwd(y, P["out.weight"], P["out.bias"], P["out2.weight"], P["out2.bias"])
+        tp.update(convs=convs, gru=gtape, y=y, l1=l1, T=T)
         return {"logit": logit, "prob": prob, "tape": tp if save else None}
 
     def backward(self, tp, d_logit, *, b0=0, nb=None, param_grads=True, need_dposes=False):
@@ -385,11 +383,9 @@ class DiscriminatorEngine(_Engine):
         grp, ng = b0 // per, nb // per
         M = nb * T
         pg = param_grads
-        dl1 = L.linear_bwd(d_logit.contiguous().view(nb, 1), tp["l1"].view(Bs, T)[rows], P["out2.weight"],
-                           G["out2.weight"] if pg else None, G["out2.bias"] if pg else None)            # (nb, T)
-        do = L.linear_bwd(dl1.view(M, 1), tp["o"][b0 * T:b0 * T + M], P["out.weight"], G["out.weight"] if pg else None,
-                          G["out.bias"] if pg else None)
-        dy = ops.dup_halves(do, L.empty(nb, T, 2 * H, like=do))
+        dy = ops.d_head_bwd(d_logit.contiguous().view(nb), tp["y"][rows], tp["l1"][rows], P["out.weight"], P["out2.weight"],
+                            L.empty(nb, T, 2 * H, like=d_logit),
+                            (G["out.weight"], G["out.bias"], G["out2.weight"], G["out2.bias"]) if pg else None)
         dx = L.gru_stack_bwd(dy, tp["gru"], P, G, "gru", 4, b0=b0, nb=nb, param_grads=pg)              # (nb, 28, 8)
         for li in (2, 1, 0):
             idx, Co, Ci = self.CONVS[li]

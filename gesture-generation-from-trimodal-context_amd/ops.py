@@ -564,6 +564,26 @@ def gan_g_loss(out_pose, target, out_rand, z, z_rand, mu, logvar, logit_out, wei
          _p(d_out), _p(d_mu), _p(d_logvar), _p(d_logit), _stream())
 
 
+def d_head_fwd(y, w1, b1, w2, b2):
+    """ConvDiscriminator head: y [B, T, 2H] -> (l1 [B, T], logit [B, 1], prob [B, 1]) in one launch."""
+    _flat(y, "y"); B, T, H2 = y.shape; H = H2 // 2
+    assert w1.numel() == H and b1.numel() == 1 and w2.numel() == T and b2.numel() == 1
+    l1, logit, prob = (torch.empty(B, T, device=y.device), torch.empty(B, 1, device=y.device), torch.empty(B, 1, device=y.device))
+    call("tg_d_head_fwd", _p(y), _p(_flat(w1, "w1")), _p(b1), _p(_flat(w2, "w2")), _p(b2), _p(l1), _p(logit), _p(prob), B, T, H, _stream())
+    return l1, logit, prob
+
+
+def d_head_bwd(d_logit, y, l1, w1, w2, dy, grads=None):
+    """Backward of the head: d_logit [nb] -> dy [nb, T, 2H]; grads = (dw1, db1, dw2, db2) accumulate, or None."""
+    _flat(d_logit, "d_logit"); _flat(y, "y"); _flat(l1, "l1"); _flat(dy, "dy")
+    nb, T, H2 = y.shape; H = H2 // 2
+    assert d_logit.numel() == nb and tuple(l1.shape) == (nb, T) and tuple(dy.shape) == tuple(y.shape) and H <= 64 and T <= 64
+    g = (None,) * 4 if grads is None else tuple(_flat(t, "grad") for t in grads)
+    call("tg_d_head_bwd", _p(d_logit), _p(y), _p(l1), _p(_flat(w1, "w1")), _p(_flat(w2, "w2")), _p(dy), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]),
+         nb, T, H, _stream())
+    return dy
+
+
 def l1_mean(a, b, out):
     call("tg_l1_mean", _p(a), _p(b), _same(a, b), _p(_flat(out, "out")), _stream()); return out
 

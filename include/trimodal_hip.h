@@ -307,6 +307,14 @@ int tg_gan_g_loss(const float* out_pose, const float* target, const float* out_r
                   int32_t TD, int32_t Z, float w_huber, float w_kld, float w_div, float w_gan, int32_t use_gan,
                   float* ws, float* scalars, float* d_out, float* d_mu, float* d_logvar, float* d_logit_out,
                   void* stream);
+/* ConvDiscriminator head (multimodal_context_net.py:243-252) in one launch each way.  y: [B][T][2H] last GRU layer output;
+ * w1/b1: out (Linear H -> 1), w2/b2: out2 (Linear T -> 1).  forward: l1 [B][T] per-frame logits (kept for the backward), logit [B]
+ * (pre-sigmoid), prob [B].  backward: d_logit [B] -> dy [B][T][2H]; dw1/db1/dw2/db2 accumulate (all NULL: input gradient only). */
+int tg_d_head_fwd(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, float* l1, float* logit, float* prob,
+                  int32_t B, int32_t T, int32_t H, void* stream);
+int tg_d_head_bwd(const float* d_logit, const float* y, const float* l1, const float* w1, const float* w2, float* dy, float* dw1, float* db1,
+                  float* dw2, float* db2, int32_t B, int32_t T, int32_t H, void* stream);
+
 /* out[0] = mean |a - b| over n elements (F.l1_loss, train.py:282). */
 int tg_l1_mean(const float* a, const float* b, int64_t n, float* out, void* stream);
 /* y = 1 / (1 + exp(-x)) */

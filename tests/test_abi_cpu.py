@@ -3,6 +3,9 @@ mirror has the reference's state_dict key set, and the product package never tou
 import ctypes
 import os
 import re
+import sys
+
+import pytest
 
 import torch
 
@@ -84,3 +87,26 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("load() must raise when the HIP library is missing")
+
+
+def test_every_entry_point_validates_its_arguments(pkg):
+    """tests/abi_fuzz.py: every C-ABI function called with nulls / zero sizes / negative sizes / zeroed tables comes back with a status
+    and never crashes -- no GPU needed, validation precedes any launch."""
+    from tests.abi_fuzz import fuzz
+    assert fuzz() >= 4 * len(pkg._lib.SIGNATURES)
+
+
+def test_entry_points_under_host_address_sanitizer():
+    """The same fuzz against the host-ASan build of the library (make -C csrc asan) in a subprocess with the ASan runtime preloaded:
+    an out-of-bounds read of a launcher (problem tables, pointer arrays, split plans) would abort the subprocess with a report."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "gesture-generation-from-trimodal-context_amd", "csrc")
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not rt or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no ROCm toolchain / ASan runtime on this machine")
+    subprocess.run(["make", "-C", csrc, "-j4", "asan"], check=True, capture_output=True)
+    lib = os.path.join(ROOT, "gesture-generation-from-trimodal-context_amd", "libtrimodal_hip_asan.so")
+    env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=66")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_fuzz.py"), lib], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "abi fuzz ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
