@@ -75,14 +75,23 @@ class GanTrainer:
         self._cut = None                    # set by GraphedGanStep while capturing: cuts the graph at sync points
 
     def _sync(self, *action):
-        """A gradient-exchange point.  Eager: run the collective now.  Capturing: end the current graph segment here and
-        let the replay loop issue the collective between segments (collectives stay outside hipGraphs)."""
+        """A gradient-exchange point.  Eager, or capturing with collectives inside the graph (GraphedGanStep, default): run the
+        collective here -- RCCL's kernels become nodes of the same hipGraph, on RCCL's stream, joined back by the 'wait' action.
+        Capturing in segment mode: end the current graph segment here and let the replay loop issue the collective between segments."""
         if self.grad_sync is None:
             return
         if self._cut is not None:
             self._cut(action)
         else:
             self.grad_sync.run(action)
+
+    def _assert_no_pending_exchange(self):
+        """The persistent cluster GRU kernels need all their workgroups co-resident (csrc/gru_cluster_x3.hip): no gradient bucket may
+        still be in flight on RCCL's stream when one of them starts.  The schedule guarantees it (buckets are launched after the last
+        recurrence of the backward, 'wait' precedes the optimiser step); this makes a future reordering fail loudly instead of
+        stalling a cluster until its spin bound."""
+        if self.grad_sync is not None and self.grad_sync.pending:
+            raise RuntimeError("a gradient bucket is still in flight at a point where cluster-synchronised kernels are about to run")
 
     # -------------------------------------------------------------------------------------------------------
     def train_iter(self, epoch, in_text, in_audio, target, vid, inject=None):
@@ -109,6 +118,10 @@ class GanTrainer:
         G, D = self.G, self.D
         B = target.shape[0]
         dev = target.device
+        self._assert_no_pending_exchange()
+        if G.use_side_stream and ops.GRU_CLUSTER:
+            raise RuntimeError("TG_SIDE_STREAM=1 cannot be combined with the cluster-synchronised GRU kernels (set TG_GRU_CLUSTER=0): "
+                               "side-stream kernels beside them break the co-residency their hand-off relies on")
         G.rng.advance(); D.rng.advance()
         target = target.contiguous().float()
         pre = ops.make_pre_seq(target, torch.empty(B, target.shape[1], target.shape[2] + 1, device=dev), self.hp["n_pre_poses"])
@@ -178,6 +191,7 @@ class GanTrainer:
         if post:
             d_poses = D.backward(dres["tape"], d_logit.view(B, 1), param_grads=False, need_dposes=True)
             ops.axpy(d_poses, d_out, 1.0, accumulate=True)
+        self._assert_no_pending_exchange()                    # the generator's backward recurrences come next
         on_ready = (lambda prefixes: self._sync("bucket", G.slab, prefixes)) if self.grad_sync is not None else None
         G.backward(st["res"]["tape"], d_out, d_mu, d_lv, b0=st["i2"] * B, nb=B, on_ready=on_ready)
 
@@ -196,7 +210,14 @@ class GraphedGanStep:
     gradient-exchange points: the replay loop launches each segment and issues the RCCL all-reduce of the bucket that just
     became final, asynchronously, so it overlaps the next segment (the rest of the backward)."""
 
-    def __init__(self, trainer: GanTrainer, epoch, in_text, in_audio, target, vid, warmup_iters=2):
+    def __init__(self, trainer: GanTrainer, epoch, in_text, in_audio, target, vid, warmup_iters=2, capture_collectives=None):
+        """capture_collectives (data parallel only): True = the RCCL all-reduces are captured INTO the graph (one graph per iteration,
+        no host work between segments); False = graph segments cut at the exchange points, collectives issued eagerly between them.
+        Default: environment TG_DDP_CAPTURE (1 unless set to 0)."""
+        import os
+        if capture_collectives is None:
+            capture_collectives = os.environ.get("TG_DDP_CAPTURE", "1") != "0"
+        self.capture_collectives = bool(capture_collectives) and trainer.grad_sync is not None
         self.trainer, self.epoch = trainer, epoch
         self.static = [t.clone() for t in (in_text, in_audio, target, vid)]
         side = torch.cuda.Stream()
@@ -222,7 +243,7 @@ class GraphedGanStep:
                 self.segments.append((state["g"], action))
                 state["g"] = torch.cuda.CUDAGraph()
                 state["g"].capture_begin(pool=pool, capture_error_mode=mode)
-            trainer._cut = cut
+            trainer._cut = None if self.capture_collectives else cut
             try:
                 self.losses = trainer.train_iter(epoch, *self.static)
             finally:

@@ -490,7 +490,7 @@ def test_data_parallel_graph_segments_single_rank(pkg, dev, tmp_path):
     dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=dev)
     try:
         out = []
-        for use_ddp in (False, True):
+        for use_ddp, capture in ((False, None), (True, False), (True, True)):
             gst, dst = O.make_generator_state(5, V, S), O.make_discriminator_state(6)
             args, G, Dn = build_models(pkg, dev, gst, dst, V, S)
             G.train(); Dn.train()
@@ -498,13 +498,16 @@ def test_data_parallel_graph_segments_single_rank(pkg, dev, tmp_path):
             tr = pkg.GanTrainer(G, Dn, args, grad_sync=sync)
             if use_ddp:
                 ddp.broadcast_parameters([tr.G.slab.ensure(), tr.D.slab.ensure()])
-            step = pkg.GraphedGanStep(tr, 11, text, audio, poses, vid, warmup_iters=1)
-            assert (len(step.segments) > 1) == use_ddp
+            # capture=False: graph segments cut at the all-reduce points, collectives issued between them; capture=True: the RCCL
+            # all-reduces are nodes of ONE hipGraph
+            step = pkg.GraphedGanStep(tr, 11, text, audio, poses, vid, warmup_iters=1, capture_collectives=capture)
+            assert (len(step.segments) > 1) == (use_ddp and not capture)
             losses = [step().to_dict() for _ in range(3)]
             out.append(losses)
-        for a, b in zip(*out):
-            for k in a:
-                assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
+        for other in out[1:]:
+            for a, b in zip(out[0], other):
+                for k in a:
+                    assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
     finally:
         dist.destroy_process_group()
 
