@@ -86,14 +86,18 @@ def time_kernel(fn, iters=50, warm=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+PEAK_HBM = 8.0e12                  # /opt/skills/guides/MI355X_MICROARCH.md, "HBM3E peak BW" (spec; 6.29 TB/s measured for a float4 copy)
+
+
 def dominant_kernel_roofline(pkg, device, batch):
-    """The single kernel with the largest share of the iteration (profiles/r1_g_by_shape.txt): the persistent cluster-synchronised
-    GRU recurrence of the generator's stacked forward, gru_seq_fwd_cluster_kernel<2> at B = 3*batch, H = 300, T = 34 -- one launch
-    per layer walks all 34 steps of both directions (csrc/gru_cluster.hip).
+    """The single kernel with the largest share of the iteration (profiles/r2_*_by_shape.txt): the persistent cluster-synchronised GRU
+    recurrence of the generator's stacked forward, gru_seq_fwd_cluster_x3_kernel<2> at B = 3*batch, H = 300, T = 34 -- one launch per
+    layer walks all 34 steps of both directions (csrc/gru_cluster_x3.hip).
     Algorithmic FLOPs per launch: (T-1) steps x 2 directions x B x 3H x H x 2 (the h_{t-1} @ W_hh^T products; gate maths excluded).
-    The kernel is bound by the per-step inter-workgroup hand-off latency, not by MFMA issue or HBM: the fraction says how far.
-    The timed call is tg_gru_forward_cluster = the 1.6 KB flag-zeroing kernel + the persistent kernel: HIP events see both
-    (~249 us), rocprofv3's per-kernel average is the persistent kernel alone (~239 us, profiles/r1_g_kernel_stats.csv)."""
+    Peak = the fp32 matrix peak: the kernel computes an fp32-accurate product (each one issued as six bf16 MFMAs on exactly split
+    operands, i.e. 6 x the algorithmic FLOPs on the bf16 pipe).  It is bound by the per-step inter-workgroup hand-off latency, not
+    by MFMA issue or HBM: the fraction says how far.  The timed call is tg_gru_forward_cluster = the flag-zeroing kernel + the
+    persistent kernel on the launch stream (HIP events); rocprofv3's per-kernel average is the persistent kernel alone."""
     ops = pkg.ops
     Bs, H = 3 * batch, 300
     gi = torch.randn(2, Bs, T, 3 * H, device=device) * 0.1
@@ -104,12 +108,30 @@ def dominant_kernel_roofline(pkg, device, batch):
     dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, sv), iters=20)
     ops.check_async_errors()
     flops = (T - 1) * 2 * Bs * H * 3 * H * 2
-    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape (profiles/r1_g_pmc_gru_fwd_cluster.txt):
-    # FETCH_SIZE 70635.7 KB x 2 (gfx950 wide-read correction) + WRITE_SIZE 186401.1 KB.  Only valid for batch 128 (B_s = 384).
-    traffic = (2 * 70635.7 + 186401.1) * 1024 if batch == 128 else None
-    return {"kernel": "gru_seq_fwd_cluster_kernel<2>", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape (profiles/r2_pmc_gru_fwd_cluster_x3.txt):
+    # 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE.  Only valid for batch 128 (B_s = 384).
+    traffic = PMC_TRAFFIC_GRU_FWD if batch == 128 else None
+    return {"kernel": "gru_seq_fwd_cluster_x3_kernel<2>", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": traffic, "launch_us": dt * 1e6,
-            "flop_per_launch": flops, "us_per_step": dt * 1e6 / T}
+            "flop_per_launch": flops, "us_per_step": dt * 1e6 / T,
+            "note": "fp32-accurate product issued as 6 bf16 MFMAs per MAC on split operands; peak = fp32 matrix peak"}
+
+
+PMC_TRAFFIC_GRU_FWD = None         # bytes per launch, filled in from profiles/r2_pmc_gru_fwd_cluster_x3.txt
+
+
+def hbm_kernel_roofline(pkg, device):
+    """The HBM-shaped kernel with the largest traffic of the iteration: the fused Adam step over the generator's flat parameter slab
+    (13.2 M parameters at V = 20 000): reads p, g, m, v and writes p, m, v = 28 bytes per parameter, one launch."""
+    ops = pkg.ops
+    n = 13_204_940
+    p, g, m, v = (torch.randn(n, device=device) * 0.01 for _ in range(4))
+    v.abs_()
+    step = torch.ones((), device=device, dtype=torch.int32)
+    dt = time_kernel(lambda: ops.adam_step(p, g, m, v, 5e-4, 0.5, 0.999, 1e-8, step), iters=20)
+    nbytes = 28 * n
+    return {"kernel": "adam_kernel", "bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+            "frac": nbytes / dt / PEAK_HBM, "traffic": None, "launch_us": dt * 1e6, "bytes_per_launch": nbytes}
 
 
 def cpu_baseline(batch, budget_s=20.0, max_steps=3):
@@ -349,6 +371,7 @@ def main():
             "losses": loss_dict,
         }
         out["roofline"] = dominant_kernel_roofline(pkg, device, a.batch)
+        out["roofline_hbm"] = hbm_kernel_roofline(pkg, device)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.batch)
         line = json.dumps(out)

@@ -717,13 +717,28 @@ extern "C" int64_t tg_gemm_tn_ws_floats(int32_t M, int32_t N, int32_t K) {
     return (int64_t)splits * N * K;
 }
 
-static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int* splits_out) {
+static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int group_tiles, int* splits_out) {
     if (int e = check_window(&q.A, "tg_gemm_tn")) return e;
     TG_REQUIRE(q.dY && q.dW && q.M > 0 && q.N > 0 && q.ldy >= q.N && q.ldw >= q.A.K, "tg_gemm_tn: bad arguments (problem %d)", idx);
     TG_REQUIRE(q.out_kw == 0 || q.out_kw * q.A.cw == q.A.K, "tg_gemm_tn: out_kw=%d must be 0 or K/cw (problem %d)", q.out_kw, idx);
     p.A = to_win(&q.A);
     int splits, rows_per_split;
     tn_plan(q.M, q.N, p.A.K, q.ws != nullptr, &splits, &rows_per_split);
+    if (q.ws == nullptr && group_tiles > cdiv(q.N, 64) * cdiv(p.A.K, 64)) {
+        // grouped launch, atomic combine: the group as a whole fills the chip, so each problem needs fewer row splits -- and every split
+        // costs one float atomic per output element (memory-side, ~1.3 TB/s chip-wide: 14 splits of the four GRU weight gradients
+        // were 91 MB of atomics, a third of the launch).  Aim at ~1536 workgroups for the group, at least 256 rows per split.
+        int s2 = cdiv(1536, group_tiles);
+        const int cap = cdiv(q.M, 256);
+        if (s2 > cap) s2 = cap;
+        if (s2 < 1) s2 = 1;
+        if (s2 < splits) {
+            int rows = cdiv(q.M, s2);
+            rows = ((rows + 31) / 32) * 32;
+            rows_per_split = rows;
+            splits = cdiv(q.M, rows);
+        }
+    }
     TG_REQUIRE(q.ws == nullptr || q.ws_floats >= (int64_t)splits * q.N * p.A.K, "tg_gemm_tn: workspace too small (%ld < %ld floats, problem %d)",
                (long)q.ws_floats, (long)splits * q.N * p.A.K, idx);
     p.dY = q.dY; p.ldy = (long)q.ldy; p.dW = q.dW; p.ldw = (long)q.ldw; p.M = q.M; p.N = q.N; p.rows_per_split = rows_per_split;
@@ -739,9 +754,11 @@ extern "C" int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, v
     TG_REQUIRE(problems && n >= 1 && n <= TG_MAX_GROUP, "tg_gemm_tn_group: 1..%d problems", TG_MAX_GROUP);
     TnGroup g;
     g.n = n;
-    int splits[TG_MAX_GROUP], wg = 0;
+    int splits[TG_MAX_GROUP], wg = 0, group_tiles = 0;
+    for (int i = 0; i < n; ++i)
+        if (problems[i].N > 0 && problems[i].A.K > 0) group_tiles += cdiv(problems[i].N, 64) * cdiv(problems[i].A.K, 64);
     for (int i = 0; i < n; ++i) {
-        if (int e = tn_fill(g.p[i], problems[i], i, &splits[i])) return e;
+        if (int e = tn_fill(g.p[i], problems[i], i, group_tiles, &splits[i])) return e;
         g.wg_begin[i] = wg;
         wg += (g.p[i].n_nt * g.p[i].n_kt * splits[i] + 7) / 8 * 8;
     }

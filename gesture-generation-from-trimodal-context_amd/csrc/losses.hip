@@ -213,24 +213,32 @@ __global__ __launch_bounds__(256) void pose_metrics_kernel(const float* __restri
 __global__ __launch_bounds__(256) void d_head_fwd_kernel(const float* __restrict__ y, const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ l1,
                                                          float* __restrict__ logit, float* __restrict__ prob, int B, int T, int H) {
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    float acc = 0.f;
-    for (int t = 0; t < T; ++t) {
+    // one workgroup per clip: thread (t = tid / 8, jj = tid % 8) sums every 8th hidden unit of frame t (independent loads in flight
+    // together), 8-lane shuffle reduce -> l1[b][t]; the T per-frame logits then meet in LDS for the second Linear.  T <= 32.
+    __shared__ float s_l[32];
+    const int b = blockIdx.x, t = threadIdx.x >> 3, jj = threadIdx.x & 7;
+    float v = 0.f;
+    if (t < T) {
         const float* yr = y + ((long)b * T + t) * (2 * H);
-        float v = 0.f;
-        for (int j = lane; j < H; j += 64) v += (yr[j] + yr[H + j]) * w1[j];
-        v = wave_sum(v);                                     // valid in lane 0
-        if (lane == 0) {
-            const float l = v + b1[0];
-            l1[(long)b * T + t] = l;
-            acc += l * w2[t];
-        }
+        for (int j = jj; j < H; j += 8) v += (yr[j] + yr[H + j]) * w1[j];
     }
-    if (lane == 0) {
-        const float lg = acc + b2[0];
-        logit[b] = lg;
-        prob[b] = sigmoidf_(lg);
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    if (jj == 0 && t < 32) {
+        const float l = t < T ? v + b1[0] : 0.f;
+        if (t < T) l1[(long)b * T + t] = l;
+        s_l[t] = t < T ? l * w2[t] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float a = threadIdx.x < 32 ? s_l[threadIdx.x] : 0.f;
+        a = wave_sum(a);
+        if (threadIdx.x == 0) {
+            const float lg = a + b2[0];
+            logit[b] = lg;
+            prob[b] = sigmoidf_(lg);
+        }
     }
 }
 
@@ -306,8 +314,8 @@ int tg_gan_g_loss(const float* out_pose, const float* target, const float* out_r
 
 int tg_d_head_fwd(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, float* l1, float* logit, float* prob,
                   int32_t B, int32_t T, int32_t H, void* stream) {
-    TG_REQUIRE(y && w1 && b1 && w2 && b2 && l1 && logit && prob && B > 0 && T > 0 && H > 0, "tg_d_head_fwd: bad arguments");
-    hipLaunchKernelGGL(d_head_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, y, w1, b1, w2, b2, l1, logit, prob, B, T, H);
+    TG_REQUIRE(y && w1 && b1 && w2 && b2 && l1 && logit && prob && B > 0 && T > 0 && T <= 32 && H > 0, "tg_d_head_fwd: bad arguments (T <= 32)");
+    hipLaunchKernelGGL(d_head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y, w1, b1, w2, b2, l1, logit, prob, B, T, H);
     return check_launch("tg_d_head_fwd");
 }
 int tg_d_head_bwd(const float* d_logit, const float* y, const float* l1, const float* w1, const float* w2, float* dy, float* dw1, float* db1,

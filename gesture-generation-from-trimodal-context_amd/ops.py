@@ -252,6 +252,11 @@ def gru_fused_dropout(B, H, bwd=False):
     """True when the recurrence kernel that will run for (B, H) applies the inter-layer dropout itself (drop_mask / dy_mask)."""
     if H == 64:
         return True
+    # the cluster kernels can do it too (drop_mask / y_drop, dy_mask), but measured on the generator (B = 384, H = 300) the mask read +
+    # y_drop write inside the latency-critical persistent kernel cost as much as the separate fused draw-and-apply pass saved
+    # (211 -> 233 us per launch against 33 us): opt-in with TG_GRU_FUSED_DROPOUT=1
+    if os.environ.get("TG_GRU_FUSED_DROPOUT", "0") == "0":
+        return False
     lib = _lib.load()
     fits = lib.tg_gru_cluster_bwd_supported(B, H) if bwd else lib.tg_gru_cluster_supported(B, H)
     return bool(GRU_CLUSTER and H > 64 and fits and lib.tg_gru_cluster_fused_dropout())
