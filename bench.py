@@ -117,7 +117,7 @@ def dominant_kernel_roofline(pkg, device, batch):
             "note": "fp32-accurate product issued as 6 bf16 MFMAs per MAC on split operands; peak = fp32 matrix peak"}
 
 
-PMC_TRAFFIC_GRU_FWD = None         # bytes per launch, filled in from profiles/r2_pmc_gru_fwd_cluster_x3.txt
+PMC_TRAFFIC_GRU_FWD = 371.6e6      # bytes per launch: (2 x FETCH_SIZE 80 097 KB + WRITE_SIZE 202 737 KB) x 1024, profiles/r2_pmc_gru_fwd_cluster_x3.txt
 
 
 def hbm_kernel_roofline(pkg, device):

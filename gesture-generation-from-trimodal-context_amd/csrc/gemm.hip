@@ -558,7 +558,7 @@ using namespace tg;
 // plain bf16 operands (math mode 1).  TG_GEMM_X3=0 in the environment keeps math mode 0 on the f32-MFMA kernels below.
 extern "C" int tg_get_math_mode(void);
 int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s);
-int tg_gemm_tn_split_launch(const TnGroup& g, int total_wgs, hipStream_t s);
+int tg_gemm_tn_split_launch(const TnGroup& g, int total_wgs, int tnw, int tkw, hipStream_t s);
 static bool use_split_path() {
     static int x3 = -1;
     if (x3 < 0) {
@@ -681,8 +681,7 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
 // slower on every shape of the training step, tools/tn_probe.py), the m range cut into ~320-row pieces (20 slabs: enough to
 // amortise the prologue and the atomic epilogue) but at least ~640 workgroups; measured optimum on the M = 4352 weight
 // gradients: 10-16 splits whatever the tile count.
-static void tn_plan(int M, int N, int K, bool two_pass, int* splits_out, int* rows_out) {
-    const int tiles = cdiv(N, 64) * cdiv(K, 64);
+static void tn_plan(int M, int tiles, bool two_pass, int* splits_out, int* rows_out) {
     int splits = cdiv(M, 320);
     if (splits < cdiv(640, tiles)) splits = cdiv(640, tiles);
     if (two_pass) {                       // short fp32 chains per split: at most 512 rows, fp64 across splits
@@ -713,22 +712,24 @@ static void launch_tn_reduce(const float* partial, int splits, int N, int K, int
 
 extern "C" int64_t tg_gemm_tn_ws_floats(int32_t M, int32_t N, int32_t K) {
     int splits, rows;
-    tn_plan(M, N, K, true, &splits, &rows);
+    tn_plan(M, cdiv(N, 64) * cdiv(K, 64), true, &splits, &rows);       // 64 x 64 tiles: the upper bound over the tile menu
     return (int64_t)splits * N * K;
 }
 
-static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int group_tiles, int* splits_out) {
+static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int group_tiles, int bn, int bk, int* splits_out) {
     if (int e = check_window(&q.A, "tg_gemm_tn")) return e;
     TG_REQUIRE(q.dY && q.dW && q.M > 0 && q.N > 0 && q.ldy >= q.N && q.ldw >= q.A.K, "tg_gemm_tn: bad arguments (problem %d)", idx);
     TG_REQUIRE(q.out_kw == 0 || q.out_kw * q.A.cw == q.A.K, "tg_gemm_tn: out_kw=%d must be 0 or K/cw (problem %d)", q.out_kw, idx);
     p.A = to_win(&q.A);
     int splits, rows_per_split;
-    tn_plan(q.M, q.N, p.A.K, q.ws != nullptr, &splits, &rows_per_split);
-    if (q.ws == nullptr && group_tiles > cdiv(q.N, 64) * cdiv(p.A.K, 64)) {
+    tn_plan(q.M, cdiv(q.N, bn) * cdiv(p.A.K, bk), q.ws != nullptr, &splits, &rows_per_split);
+    if (q.ws == nullptr && group_tiles > cdiv(q.N, bn) * cdiv(p.A.K, bk)) {
         // grouped launch, atomic combine: the group as a whole fills the chip, so each problem needs fewer row splits -- and every split
         // costs one float atomic per output element (memory-side, ~1.3 TB/s chip-wide: 14 splits of the four GRU weight gradients
         // were 91 MB of atomics, a third of the launch).  Aim at ~1536 workgroups for the group, at least 256 rows per split.
-        int s2 = cdiv(1536, group_tiles);
+        static int target_wgs = -1;          // lab switch TG_TN_WGS: workgroups aimed at per grouped launch
+        if (target_wgs < 0) { const char* e = getenv("TG_TN_WGS"); target_wgs = e ? atoi(e) : 1536; }
+        int s2 = cdiv(target_wgs, group_tiles);
         const int cap = cdiv(q.M, 256);
         if (s2 > cap) s2 = cap;
         if (s2 < 1) s2 = 1;
@@ -745,7 +746,7 @@ static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int group_ti
     p.out_kw = q.out_kw; p.partial = q.ws; p.dbias = q.dbias;
     p.vec_y = (q.ldy % 4 == 0) && aligned16(q.dY);
     p.vec_a = (p.A.cw % 4 == 0) && (p.A.bs % 4 == 0) && (p.A.rs % 4 == 0) && aligned16(p.A.ptr);
-    p.n_nt = cdiv(q.N, 64); p.n_kt = cdiv(p.A.K, 64);
+    p.n_nt = cdiv(q.N, bn); p.n_kt = cdiv(p.A.K, bk);
     *splits_out = splits;
     return 0;
 }
@@ -754,23 +755,41 @@ extern "C" int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, v
     TG_REQUIRE(problems && n >= 1 && n <= TG_MAX_GROUP, "tg_gemm_tn_group: 1..%d problems", TG_MAX_GROUP);
     TnGroup g;
     g.n = n;
+    // bf16 x 3 kernel (gemm_split.hip) when every problem is on the vectorisable layout and long enough to amortise its 32-row slabs
+    bool x3 = use_split_path() && tg_get_math_mode() == 0;
+    bool two_pass = false;            // workspaces are sized for the 64 x 64 tile's split plan (tg_gemm_tn_ws_floats)
+    for (int i = 0; i < n; ++i) {
+        const tg_gemm_tn_problem& q = problems[i];
+        TG_REQUIRE(q.A.ptr && q.A.cw > 0 && q.A.K > 0 && q.N > 0, "tg_gemm_tn: bad arguments (problem %d)", i);
+        const bool vec = (q.ldy % 4 == 0) && aligned16(q.dY) && (q.A.cw % 4 == 0) && (q.A.batch_stride % 4 == 0) && (q.A.row_stride % 4 == 0) && aligned16(q.A.ptr);
+        x3 = x3 && vec && q.N % 4 == 0 && q.A.K % 4 == 0 && q.M >= 1024 && q.N >= 48 && q.A.K >= 48;
+        two_pass = two_pass || q.ws != nullptr;
+    }
+    // tile (tools/tn_tile_lab.py, profiles/r2_tn_tile_lab.txt): 64 x 64, or 128 x 64 when every problem has >= 512 output rows; 128 x 128
+    // and wider run at one workgroup per CU and lose 15-30 % on every shape of the step
+    int tnw = 2, tkw = 2;
+    if (x3 && !two_pass) {
+        static int forced = -1;
+        if (forced < 0) { const char* e = getenv("TG_TN_TILE"); forced = e ? atoi(e) : 0; }
+        int min_n = 1 << 30;
+        for (int i = 0; i < n; ++i) min_n = problems[i].N < min_n ? problems[i].N : min_n;
+        if (forced >= 22) { tnw = forced / 10; tkw = forced % 10; }       // lab switch
+        else if (min_n >= 512) { tnw = 4; tkw = 2; }                      // 128 x 64: the GRU weight gradients (N = 900) 208 -> 185 us per group
+    }
+    const int bn = 32 * tnw, bk = 32 * tkw;
     int splits[TG_MAX_GROUP], wg = 0, group_tiles = 0;
     for (int i = 0; i < n; ++i)
-        if (problems[i].N > 0 && problems[i].A.K > 0) group_tiles += cdiv(problems[i].N, 64) * cdiv(problems[i].A.K, 64);
+        if (problems[i].N > 0 && problems[i].A.K > 0) group_tiles += cdiv(problems[i].N, bn) * cdiv(problems[i].A.K, bk);
     for (int i = 0; i < n; ++i) {
-        if (int e = tn_fill(g.p[i], problems[i], i, group_tiles, &splits[i])) return e;
+        if (int e = tn_fill(g.p[i], problems[i], i, group_tiles, bn, bk, &splits[i])) return e;
         g.wg_begin[i] = wg;
         wg += (g.p[i].n_nt * g.p[i].n_kt * splits[i] + 7) / 8 * 8;
     }
     for (int i = n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
     for (int i = n; i < TG_MAX_GROUP; ++i) g.p[i] = g.p[0];
     hipStream_t s = (hipStream_t)stream;
-    // bf16 x 3 kernel (gemm_split.hip) when every problem is on the vectorisable layout and long enough to amortise its 32-row slabs
-    bool x3 = use_split_path() && tg_get_math_mode() == 0;
-    for (int i = 0; i < n; ++i)
-        x3 = x3 && g.p[i].vec_y && g.p[i].vec_a && g.p[i].N % 4 == 0 && g.p[i].A.K % 4 == 0 && g.p[i].M >= 1024 && g.p[i].N >= 48 && g.p[i].A.K >= 48;
     if (x3) {
-        if (int e = tg_gemm_tn_split_launch(g, wg, s)) return e;
+        if (int e = tg_gemm_tn_split_launch(g, wg, tnw, tkw, s)) return e;
     } else {
         hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 16>), dim3(wg), dim3(256), 0, s, g);
     }

@@ -441,6 +441,7 @@ extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, co
     TG_REQUIRE((drop_mask == nullptr) == (y_drop == nullptr) && (drop_mask == nullptr || (use_gru_x3() && aligned16(drop_mask) && aligned16(y_drop))),
                "tg_gru_forward_cluster: drop_mask / y_drop go together, 16-byte aligned, and need tg_gru_cluster_fused_dropout() != 0");
     TG_REQUIRE(T > 0 && tg_gru_cluster_supported(B, H), "tg_gru_forward_cluster: unsupported shape B=%d H=%d", B, H);
+    TG_REQUIRE((int64_t)B * T * 4 * H * 4 < (1LL << 31), "tg_gru_forward_cluster: B * T * 4H floats must stay below 2 GB (32-bit buffer offsets), T=%d", T);
     TG_REQUIRE(ws_bytes >= tg_gru_cluster_ws_bytes(B, H), "tg_gru_forward_cluster: workspace too small");
     TG_REQUIRE(aligned16(gi) && aligned16(w_hh_fwd) && aligned16(w_hh_rev) && aligned16(b_hh_fwd) && aligned16(b_hh_rev) && aligned16(y) &&
                aligned16(ws) && (save == nullptr || aligned16(save)) && gi_dir_stride % 4 == 0 && save_dir_stride % 4 == 0,
@@ -498,6 +499,7 @@ extern "C" int tg_gru_backward_cluster(const float* dy, const float* dy_mask, co
     TG_REQUIRE(dy && y && save && w_hh_t_fwd && w_hh_t_rev && dgi && dgh && ws, "tg_gru_backward_cluster: null pointer");
     TG_REQUIRE(dy_mask == nullptr || (use_gru_x3() && aligned16(dy_mask)), "tg_gru_backward_cluster: dy_mask needs tg_gru_cluster_fused_dropout() != 0");
     TG_REQUIRE(T > 0 && tg_gru_cluster_bwd_supported(B, H), "tg_gru_backward_cluster: unsupported shape B=%d H=%d", B, H);
+    TG_REQUIRE((int64_t)B * T * 4 * H * 4 < (1LL << 31), "tg_gru_backward_cluster: B * T * 4H floats must stay below 2 GB (32-bit buffer offsets), T=%d", T);
     TG_REQUIRE(ws_bytes >= tg_gru_cluster_bwd_ws_bytes(B, H), "tg_gru_backward_cluster: workspace too small");
     TG_REQUIRE(aligned16(dy) && aligned16(y) && aligned16(save) && aligned16(w_hh_t_fwd) && aligned16(w_hh_t_rev) && aligned16(dgi) &&
                aligned16(dgh) && aligned16(ws) && save_dir_stride % 4 == 0 && dg_dir_stride % 4 == 0,

@@ -28,9 +28,12 @@ constexpr int XC_FLAG_STRIDE = 16;    // flag words per cluster (one 64-byte lin
 constexpr int XC_KS = 4;              // K slices (waves along K)
 constexpr int XC_SPS = 3;             // k-steps per slice, forward: ceil(10 / 4)
 constexpr unsigned XC_SPIN_LIMIT = 1u << 26;
+constexpr int XC_POLL_WAVE = 7;       // of 8; epilogue threads live in waves 0 .. 3 (forward) / 0 .. 1 (backward)
 constexpr unsigned XC_RSRC3 = 0x00020000u;
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f32x4 as_f32x4(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+__device__ __forceinline__ u32x4 as_u32x4(f32x4 v) { return __builtin_bit_cast(u32x4, v); }
 
 // eight consecutive fp32 (two float4) -> three bf16x8 fragments (hi / mid / lo planes)
 __device__ __forceinline__ void xc_split8(const f32x4 a, const f32x4 b, bf16x8 (&out)[3]) {
@@ -150,7 +153,10 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
     const int row = b0 + row_l;
     const int unit0 = m * XC_UNITS + 4 * ug;
     const bool e_ok = epi && row < B && unit0 < H;           // H % 4 == 0: the four units are valid together
-    const f32x4 bhn = (epi && unit0 < H) ? *reinterpret_cast<const f32x4*>(bhh + 2 * H + unit0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bh[3];                                             // b_hr, b_hz, b_hn of this thread's four units
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bh[g] = (epi && unit0 < H) ? *reinterpret_cast<const f32x4*>(bhh + g * H + unit0) : zero4;
     f32x4 hp = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                                   // wlo visible (read back by the same lane: ordering only)
 
@@ -161,18 +167,35 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
     gu32x* cl_flags = (gu32x*)(flags + cl * XC_FLAG_STRIDE);
     bool aborted = false;
 
+    // The per-step streams (gi in; y, saved gates, dropped y out) go through BUFFER instructions: a lane without a valid (row, unit)
+    // carries an offset past num_records -- its loads return 0 and its stores are dropped by the bounds check -- so every one of them is
+    // issued unconditionally.  A lane-predicated load or store (s_cbranch_execz around it) makes the count of outstanding operations
+    // dynamic, and hipcc then drains everything (s_waitcnt vmcnt(0)) at the next dependent use: the first version of this loop waited
+    // at the top of every step for the previous step's output stores, then for the gi loads, then for the bias loads -- three exposed
+    // round trips per step.  Now gi for step s + 1 is requested right after step s has published its flag and is in flight during the
+    // next hand-off; nothing but the exchange itself is waited for.  (All byte sizes < 2^31: checked by the host.)
+    constexpr unsigned OOB = 0x80000000u;
+    const int epi_wave = wave < 2 * MT;                                // scalar: waves that own epilogue threads
+    __amdgpu_buffer_rsrc_t gi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gi + dir * gi_ds), 0, B * T * 3 * H * 4, XC_RSRC3);
+    __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(Y, 0, B * T * 2 * H * 4, XC_RSRC3);
+    __amdgpu_buffer_rsrc_t yd_rsrc = __builtin_amdgcn_make_buffer_rsrc(y_drop ? y_drop : Y, 0, B * T * 2 * H * 4, XC_RSRC3);
+    __amdgpu_buffer_rsrc_t dm_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(drop_mask ? drop_mask : Y), 0, B * T * 2 * H * 4, XC_RSRC3);
+    __amdgpu_buffer_rsrc_t sv_rsrc = __builtin_amdgcn_make_buffer_rsrc(save ? save + dir * save_ds : Y, 0, save ? B * T * 4 * H * 4 : 0, XC_RSRC3);
+    const unsigned gi_v = e_ok ? (unsigned)((row * T * 3 * H + unit0) * 4) : OOB;          // + (tau * 3H + g * H) * 4 (scalar)
+    const unsigned y_v = e_ok ? (unsigned)((row * T * 2 * H + dir * H + unit0) * 4) : OOB;  // + tau * 2H * 4
+    const unsigned sv_v = e_ok ? (unsigned)((row * T * 4 * H + unit0) * 4) : OOB;           // + (tau * 4H + j * H) * 4
+    f32x4 gn[3] = {zero4, zero4, zero4}, mkn = zero4;                  // gi (and the dropout mask) of the NEXT step
+    auto prefetch = [&](int st) {
+        const int sl = st < T ? st : T - 1;                            // past the end: a valid address again, never used
+        const int tl = dir ? T - 1 - sl : sl;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gn[g] = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(gi_rsrc, gi_v, (tl * 3 * H + g * H) * 4, 0));
+        if (drop_mask) mkn = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(dm_rsrc, y_v, tl * 2 * H * 4, 0));
+    };
+    if (epi_wave) prefetch(0);
+
     for (int step = 0; step < T; ++step) {
         const int tau = dir ? T - 1 - step : step;
-        // input-side pre-activations do not depend on the recurrence: issue their loads before the wait
-        f32x4 gv[3];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            gv[g] = e_ok ? *reinterpret_cast<const f32x4*>(gi + dir * gi_ds + ((long)row * T + tau) * (3 * H) + g * H + unit0) : z;
-            // b_hr, b_hz enter the r / z pre-activations additively: folded in here (re-read every step, an L2 hit issued with the gi
-            // loads -- cheaper than eight resident VGPRs in a kernel at the register cap)
-            if (g < 2 && e_ok) gv[g] += *reinterpret_cast<const f32x4*>(bhh + g * H + unit0);
-        }
         f32x4 acc[MT][3];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -180,7 +203,10 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
             for (int g = 0; g < 3; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         if (step > 0) {
-            if (wave == 0 && !aborted) aborted = !xc_wait(cl_flags, CW, lane, (unsigned)step, tmo, step);
+            // the polling wave is one WITHOUT epilogue threads: its memory queue holds no output stores / prefetch loads of the previous
+            // step, so the first poll returns after one L2 round trip (vmcnt counts in order: wave 0 would see its flag loads return
+            // only behind its own stores)
+            if (wave == XC_POLL_WAVE && !aborted) aborted = !xc_wait(cl_flags, CW, lane, (unsigned)step, tmo, step);
             __syncthreads();                        // the other waves load only behind the polling wave's barrier
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // compiler ordering only; every load below is sc1
             const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes;
@@ -212,8 +238,8 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
             for (int g = 0; g < 3; ++g) red[ks][ut][i][g][lane] = acc[i][g];
         __syncthreads();
 
-        f32x4 h = {0.f, 0.f, 0.f, 0.f}, r4, z4, n4, hn4;
-        if (epi) {
+        f32x4 h = {0.f, 0.f, 0.f, 0.f}, r4 = zero4, z4 = zero4, n4 = zero4, hn4 = zero4, mk = zero4;
+        if (epi_wave) {
             f32x4 gh[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
@@ -222,12 +248,13 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
                 for (int q = 1; q < XC_KS; ++q) s += red[q][e_ut][e_mt][g][e_lane];
                 gh[g] = s;
             }
+            mk = mkn;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float hn = gh[2][q] + bhn[q];
-                const float r = gate_sigmoid(gv[0][q] + gh[0][q]);
-                const float z = gate_sigmoid(gv[1][q] + gh[1][q]);
-                const float n = gate_tanh(gv[2][q] + r * hn);
+                const float hn = gh[2][q] + bh[2][q];
+                const float r = gate_sigmoid(gn[0][q] + bh[0][q] + gh[0][q]);
+                const float z = gate_sigmoid(gn[1][q] + bh[1][q] + gh[1][q]);
+                const float n = gate_tanh(gn[2][q] + r * hn);
                 h[q] = (1.f - z) * n + z * hp[q];
                 r4[q] = r; z4[q] = z; n4[q] = n; hn4[q] = hn;
             }
@@ -243,17 +270,17 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY wave drains its stores before the flag
         __syncthreads();                                       // (also: `red` is free again)
         if (threadIdx.x == 0) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e_ok) {                                            // outputs for later kernels: plain stores, off the critical path
-            const long yo = ((long)row * T + tau) * (2 * H) + dir * H + unit0;
-            *reinterpret_cast<f32x4*>(Y + yo) = h;
-            if (y_drop) *reinterpret_cast<f32x4*>(y_drop + yo) = h * *reinterpret_cast<const f32x4*>(drop_mask + yo);   // fused inter-layer dropout
+        if (epi_wave) {                                        // outputs for later kernels and the next step's inputs: off the critical path
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(h), y_rsrc, y_v, tau * 2 * H * 4, 0);
+            if (y_drop) __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(h * mk), yd_rsrc, y_v, tau * 2 * H * 4, 0);   // fused inter-layer dropout
             if (save) {
-                float* sp = save + dir * save_ds + ((long)row * T + tau) * (4 * H) + unit0;
-                *reinterpret_cast<f32x4*>(sp) = r4;
-                *reinterpret_cast<f32x4*>(sp + H) = z4;
-                *reinterpret_cast<f32x4*>(sp + 2 * H) = n4;
-                *reinterpret_cast<f32x4*>(sp + 3 * H) = hn4;
+                const int so = tau * 4 * H * 4;
+                __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(r4), sv_rsrc, sv_v, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(z4), sv_rsrc, sv_v, so + H * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(n4), sv_rsrc, sv_v, so + 2 * H * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(hn4), sv_rsrc, sv_v, so + 3 * H * 4, 0);
             }
+            prefetch(step + 1);
         }
     }
 }
@@ -325,7 +352,8 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     const int row = b0 + row_l;
     const int unit0 = m * XC_UNITS + 4 * ug;
     const bool e_ok = epi && row < B && unit0 < H;
-    f32x4 dh_c = {0.f, 0.f, 0.f, 0.f}, z_c = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dhz = zero;                                  // dh * z of the step processed before
 
     const int plane_bytes = b_pad * 64;
     const int slot_bytes = 3 * CW * 3 * plane_bytes;
@@ -334,25 +362,40 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     gu32x* cl_flags = (gu32x*)(flags + cl * XC_FLAG_STRIDE);
     bool aborted = false;
 
+    // per-step streams through bounds-checked buffer instructions, requested one step ahead (see the forward kernel)
+    constexpr unsigned OOB = 0x80000000u;
+    const int epi_wave = wave < 2;
+    __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY), 0, B * T * 2 * H * 4, XC_RSRC3);
+    __amdgpu_buffer_rsrc_t dm_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy_mask ? dy_mask : dY), 0, B * T * 2 * H * 4, XC_RSRC3);
+    __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Y), 0, B * T * 2 * H * 4, XC_RSRC3);
+    __amdgpu_buffer_rsrc_t sv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(save + dir * save_ds), 0, B * T * 4 * H * 4, XC_RSRC3);
+    __amdgpu_buffer_rsrc_t gi_rsrc = __builtin_amdgcn_make_buffer_rsrc(dgi + dir * dg_ds, 0, B * T * H3 * 4, XC_RSRC3);
+    __amdgpu_buffer_rsrc_t gh_rsrc = __builtin_amdgcn_make_buffer_rsrc(dgh + dir * dg_ds, 0, B * T * H3 * 4, XC_RSRC3);
+    const unsigned y_v = e_ok ? (unsigned)((row * T * 2 * H + dir * H + unit0) * 4) : OOB;  // + tau * 2H * 4
+    const unsigned sv_v = e_ok ? (unsigned)((row * T * 4 * H + unit0) * 4) : OOB;           // + (tau * 4H + j * H) * 4
+    const unsigned dg_v = e_ok ? (unsigned)((row * T * H3 + unit0) * 4) : OOB;              // + (tau * 3H + g * H) * 4
+    f32x4 dy = zero, dm = zero, r = zero, z = zero, n = zero, hn = zero, hp = zero;         // operands of the NEXT step's cell
+    auto prefetch = [&](int st) {
+        const int sl = st < T ? st : T - 1;
+        const int tl = dir ? sl : T - 1 - sl;
+        const int tp = dir ? tl + 1 : tl - 1;                       // producer of h_prev for this cell
+        const bool has_prev = tp >= 0 && tp < T;
+        dy = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(dy_rsrc, y_v, tl * 2 * H * 4, 0));
+        if (dy_mask) dm = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(dm_rsrc, y_v, tl * 2 * H * 4, 0));
+        const int so = tl * 4 * H * 4;
+        r = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(sv_rsrc, sv_v, so, 0));
+        z = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(sv_rsrc, sv_v, so + H * 4, 0));
+        n = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(sv_rsrc, sv_v, so + 2 * H * 4, 0));
+        hn = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(sv_rsrc, sv_v, so + 3 * H * 4, 0));
+        hp = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(y_rsrc, has_prev ? y_v : OOB, (has_prev ? tp : 0) * 2 * H * 4, 0));   // h_prev = 0 at the sequence end
+    };
+    if (epi_wave) prefetch(0);
+
     for (int step = 0; step < T; ++step) {
         const int tau = dir ? step : T - 1 - step;
-        const int tau_prev = dir ? tau + 1 : tau - 1;           // producer of h_prev for this cell
-        const bool has_prev = dir ? (tau < T - 1) : (tau > 0);
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        f32x4 dy = zero, r = zero, z = zero, n = zero, hn = zero, hp = zero;
-        if (e_ok) {
-            dy = *reinterpret_cast<const f32x4*>(dY + ((long)row * T + tau) * (2 * H) + dir * H + unit0);
-            if (dy_mask) dy = dy * *reinterpret_cast<const f32x4*>(dy_mask + ((long)row * T + tau) * (2 * H) + dir * H + unit0);
-            const float* sp = save + dir * save_ds + ((long)row * T + tau) * (4 * H) + unit0;
-            r = *reinterpret_cast<const f32x4*>(sp);
-            z = *reinterpret_cast<const f32x4*>(sp + H);
-            n = *reinterpret_cast<const f32x4*>(sp + 2 * H);
-            hn = *reinterpret_cast<const f32x4*>(sp + 3 * H);
-            if (has_prev) hp = *reinterpret_cast<const f32x4*>(Y + ((long)row * T + tau_prev) * (2 * H) + dir * H + unit0);
-        }
         f32x4 acc[2] = {zero, zero};
         if (step > 0) {
-            if (wave == 0 && !aborted) aborted = !xc_wait(cl_flags, CW, lane, (unsigned)step, tmo, step);
+            if (wave == XC_POLL_WAVE && !aborted) aborted = !xc_wait(cl_flags, CW, lane, (unsigned)step, tmo, step);
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes + b0 * 64;
@@ -376,17 +419,18 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
         __syncthreads();
 
         f32x4 g_r = zero, g_z = zero, g_n = zero, g_nr = zero;
-        if (epi) {
+        if (epi_wave) {
             f32x4 s = red[0][e_ut][e_lane];
 #pragma unroll
             for (int q = 1; q < XC_KSB; ++q) s += red[q][e_ut][e_lane];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float dh = dy[q] + (step > 0 ? s[q] + dh_c[q] * z_c[q] : 0.f);
+                const float dyq = dy_mask ? dy[q] * dm[q] : dy[q];
+                const float dh = dyq + s[q] + dhz[q];              // step 0: s = 0 (no product), dhz = 0
                 const float dn = dh * (1.f - z[q]) * (1.f - n[q] * n[q]);
                 const float dz = dh * (hp[q] - n[q]) * z[q] * (1.f - z[q]);
                 const float dr = dn * hn[q] * r[q] * (1.f - r[q]);
-                dh_c[q] = dh; z_c[q] = z[q];
+                dhz[q] = dh * z[q];
                 g_r[q] = dr; g_z[q] = dz; g_n[q] = dn; g_nr[q] = dn * r[q];
             }
             // publish this step's dgh tile: blocks (gate 0..2, member m), three bf16 planes each
@@ -405,11 +449,15 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e_ok) {
-            float* gi_o = dgi + dir * dg_ds + ((long)row * T + tau) * H3 + unit0;
-            float* gh_o = dgh + dir * dg_ds + ((long)row * T + tau) * H3 + unit0;
-            *reinterpret_cast<f32x4*>(gi_o) = g_r; *reinterpret_cast<f32x4*>(gi_o + H) = g_z; *reinterpret_cast<f32x4*>(gi_o + 2 * H) = g_n;
-            *reinterpret_cast<f32x4*>(gh_o) = g_r; *reinterpret_cast<f32x4*>(gh_o + H) = g_z; *reinterpret_cast<f32x4*>(gh_o + 2 * H) = g_nr;
+        if (epi_wave) {
+            const int go = tau * H3 * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_r), gi_rsrc, dg_v, go, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_z), gi_rsrc, dg_v, go + H * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_n), gi_rsrc, dg_v, go + 2 * H * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_r), gh_rsrc, dg_v, go, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_z), gh_rsrc, dg_v, go + H * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_nr), gh_rsrc, dg_v, go + 2 * H * 4, 0);
+            prefetch(step + 1);
         }
     }
 }

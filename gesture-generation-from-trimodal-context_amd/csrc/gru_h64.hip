@@ -16,12 +16,20 @@
 // the separate dropout / mask-multiply passes and their launches disappear.  The mask is drawn beforehand for all layers of a
 // pass by ONE tg_dropout_mask launch (or injected by the parity tests).
 #include "common.hpp"
+#include <type_traits>
+#include <utility>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace tg {
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), unrolled
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int HS = 64;
 constexpr int HX_LD = HS + 8;          // bf16 per LDS row of the h planes (144 B: 16-byte aligned, rows spread over the banks)
@@ -72,6 +80,13 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// No lane-dependent control flow inside the step loop: hipcc counts outstanding vector-memory operations statically, and a predicated
+// load or store makes the count dynamic -- it then drains EVERYTHING (s_waitcnt vmcnt(0)) before the next use of a prefetched value,
+// which put one full store round trip (~1.2 us) on every step of the first version (1.6 us per step, of which 0.25 us MFMA).  So:
+// rows past the batch are CLAMPED to the last row (those lanes recompute row B - 1 bit for bit and store the same values to the same
+// addresses), the optional outputs are template parameters, the prefetch of the step after the last re-reads a valid address, and
+// step 0 multiplies a zeroed LDS tile instead of branching around the product.
+template <bool SAVE, bool DROP, int D>
 __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
     const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
@@ -92,76 +107,80 @@ __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
             const float* p = whh + (long)(g * HS + 16 * wave + r16) * HS + 32 * ks + 8 * kq;
             split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[g][ks]);
         }
-    // gate-epilogue role: batch row b0 + r16, hidden units u0 .. u0 + 3
+    // gate-epilogue role: batch row b0 + r16 (clamped), hidden units u0 .. u0 + 3
     const int u0 = 16 * wave + 4 * kq;
-    const int row = blockIdx.x * 16 + r16;
-    const bool row_ok = row < B;
-    const long rbase = (long)(row_ok ? row : 0) * T;
+    const int row = min((int)blockIdx.x * 16 + r16, B - 1);
+    const long rbase = (long)row * T;
     f32x4 bh[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) bh[g] = *reinterpret_cast<const f32x4*>(bhh + g * HS + u0);
     f32x4 hp = {0.f, 0.f, 0.f, 0.f};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // h_{-1} = 0: the tile step 0 reads
+    for (int i = threadIdx.x; i < 3 * 16 * HX_LD / 2; i += 256) reinterpret_cast<unsigned*>(&hs[1][0][0][0])[i] = 0u;
 
-    // operands that do not depend on the recurrence are loaded one step ahead
-    f32x4 nx[3], nxm = {1.f, 1.f, 1.f, 1.f};
-    auto prefetch = [&](int tau_l) {
+    // operands that do not depend on the recurrence: ring of D register sets, set j holds step s with s % D == j
+    f32x4 nx[D][3], nxm[D];
+    auto prefetch = [&](auto set_c, int step_l) {
+        constexpr int j = decltype(set_c)::value;
+        const int sl = step_l < T ? step_l : T - 1;          // past the end: re-read a valid address, never used
+        const int tau_l = dir ? T - 1 - sl : sl;
         const float* gp = gi + dir * gi_ds + (rbase + tau_l) * (3 * HS) + u0;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) nx[g] = row_ok ? *reinterpret_cast<const f32x4*>(gp + g * HS) : zero;
-        if (drop_mask) nxm = row_ok ? *reinterpret_cast<const f32x4*>(drop_mask + (rbase + tau_l) * (2 * HS) + dir * HS + u0) : zero;
+        for (int g = 0; g < 3; ++g) nx[j][g] = *reinterpret_cast<const f32x4*>(gp + g * HS);
+        if constexpr (DROP) nxm[j] = *reinterpret_cast<const f32x4*>(drop_mask + (rbase + tau_l) * (2 * HS) + dir * HS + u0);
     };
-    prefetch(dir ? T - 1 : 0);
-    for (int step = 0; step < T; ++step) {
+    auto do_step = [&](auto set_c, int step) {
+        constexpr int j = decltype(set_c)::value;
         const int tau = dir ? T - 1 - step : step;
-        f32x4 gv[3], mk = nxm;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) gv[g] = nx[g];
-        if (step + 1 < T) prefetch(dir ? tau - 1 : tau + 1);
         f32x4 acc[3] = {zero, zero, zero};
-        if (step > 0) {
-            const int rb = (step - 1) & 1;
+        const int rb = (step + 1) & 1;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fb[3];
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fb[3];
 #pragma unroll
-                for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&hs[rb][s][r16][32 * ks + 8 * kq]);
+            for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&hs[rb][s][r16][32 * ks + 8 * kq]);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) acc[g] = mma_x3(wa[g][ks], fb, acc[g]);
-            }
+            for (int g = 0; g < 3; ++g) acc[g] = mma_x3(wa[g][ks], fb, acc[g]);
         }
         f32x4 h, r4, z4, n4, hn4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float hn = acc[2][q] + bh[2][q];
-            const float r = gate_sigmoid(gv[0][q] + acc[0][q] + bh[0][q]);
-            const float z = gate_sigmoid(gv[1][q] + acc[1][q] + bh[1][q]);
-            const float n = gate_tanh(gv[2][q] + r * hn);
+            const float r = gate_sigmoid(nx[j][0][q] + acc[0][q] + bh[0][q]);
+            const float z = gate_sigmoid(nx[j][1][q] + acc[1][q] + bh[1][q]);
+            const float n = gate_tanh(nx[j][2][q] + r * hn);
             h[q] = (1.f - z) * n + z * hp[q];
             r4[q] = r; z4[q] = z; n4[q] = n; hn4[q] = hn;
         }
         hp = h;
         const int wb = step & 1;
         split4_store(h, &hs[wb][0][r16][u0], &hs[wb][1][r16][u0], &hs[wb][2][r16][u0]);
-        if (row_ok) {
-            const long o = (rbase + tau) * (2 * HS) + dir * HS + u0;
-            *reinterpret_cast<f32x4*>(Y + o) = h;
-            if (y_drop) *reinterpret_cast<f32x4*>(y_drop + o) = h * mk;
-            if (save) {
-                float* sp = save + dir * save_ds + (rbase + tau) * (4 * HS) + u0;
-                *reinterpret_cast<f32x4*>(sp) = r4;
-                *reinterpret_cast<f32x4*>(sp + HS) = z4;
-                *reinterpret_cast<f32x4*>(sp + 2 * HS) = n4;
-                *reinterpret_cast<f32x4*>(sp + 3 * HS) = hn4;
-            }
+        const long o = (rbase + tau) * (2 * HS) + dir * HS + u0;
+        *reinterpret_cast<f32x4*>(Y + o) = h;
+        if constexpr (DROP) *reinterpret_cast<f32x4*>(y_drop + o) = h * nxm[j];
+        if constexpr (SAVE) {
+            float* sp = save + dir * save_ds + (rbase + tau) * (4 * HS) + u0;
+            *reinterpret_cast<f32x4*>(sp) = r4;
+            *reinterpret_cast<f32x4*>(sp + HS) = z4;
+            *reinterpret_cast<f32x4*>(sp + 2 * HS) = n4;
+            *reinterpret_cast<f32x4*>(sp + 3 * HS) = hn4;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch(set_c, step + D);           // refill the set just consumed: D steps of compute hide the load latency
+        __builtin_amdgcn_sched_barrier(0);
         lds_barrier();                       // h_t complete in LDS (and everybody is done with the buffer written next step)
-    }
+    };
+    static_for<D>([&](auto j) { prefetch(j, decltype(j)::value); });
+    lds_barrier();
+    for (int step0 = 0; step0 < T; step0 += D)               // T % D == 0 (host)
+        static_for<D>([&](auto j) { do_step(j, step0 + decltype(j)::value); });
 }
 
 // Backward through time, same ownership.  dh_{t} needs dgh_{t+1} @ W_hh (contraction over the 192 gate rows): taken transposed like
 // the forward, A = W_hh^T rows [16 wave, 16 wave + 16) (pre-split, 6 k-steps x 3 planes in registers), B = the previous step's
-// gate-gradient tile from LDS (three bf16 planes, double-buffered).
+// gate-gradient tile from LDS (three bf16 planes, double-buffered; zero for the first step).
+template <bool MASK, int D>
 __global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
     const float* __restrict__ dY, const float* __restrict__ dy_mask, const float* __restrict__ Y, const float* __restrict__ save,
     long save_ds, const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh,
@@ -179,69 +198,87 @@ __global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
         split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[ks]);
     }
     const int u0 = 16 * wave + 4 * kq;
-    const int row = blockIdx.x * 16 + r16;
-    const bool row_ok = row < B;
-    const long rbase = (long)(row_ok ? row : 0) * T;
+    const int row = min((int)blockIdx.x * 16 + r16, B - 1);        // clamped: see the forward kernel
+    const long rbase = (long)row * T;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 dh_c = zero, z_c = zero;              // dh and z of the step processed before
+    f32x4 dhz = zero;                           // dh * z of the step processed before (a carried copy of the LOADED z would keep the set's
+                                                // registers alive across its refill and cost a copy + wait at the end of every block)
+    for (int i = threadIdx.x; i < 3 * 16 * DG_LD / 2; i += 256) reinterpret_cast<unsigned*>(&dgs[1][0][0][0])[i] = 0u;
 
-    f32x4 n_dy, n_r, n_z, n_n, n_hn, n_hp;
-    auto prefetch = [&](int tau_l) {
+    // ring of D register sets (see the forward kernel): dy (x mask), r, z, n, W_hn h + b_hn, h_prev of the set's step
+    f32x4 n_dy[D], n_mk[D], n_r[D], n_z[D], n_n[D], n_hn[D], n_hp[D];
+    float n_keep[D];
+    auto prefetch = [&](auto set_c, int step_l) {
+        constexpr int j = decltype(set_c)::value;
+        const int sl = step_l < T ? step_l : T - 1;
+        const int tau_l = dir ? sl : T - 1 - sl;
         const int tp = dir ? tau_l + 1 : tau_l - 1;
-        const bool hasp = dir ? (tau_l < T - 1) : (tau_l > 0);
+        const bool hasp = tp >= 0 && tp < T;
         const long o = (rbase + tau_l) * (2 * HS) + dir * HS + u0;
         const float* sp = save + dir * save_ds + (rbase + tau_l) * (4 * HS) + u0;
-        n_dy = row_ok ? *reinterpret_cast<const f32x4*>(dY + o) : zero;
-        if (dy_mask) n_dy = n_dy * (row_ok ? *reinterpret_cast<const f32x4*>(dy_mask + o) : zero);
-        n_r = row_ok ? *reinterpret_cast<const f32x4*>(sp) : zero;
-        n_z = row_ok ? *reinterpret_cast<const f32x4*>(sp + HS) : zero;
-        n_n = row_ok ? *reinterpret_cast<const f32x4*>(sp + 2 * HS) : zero;
-        n_hn = row_ok ? *reinterpret_cast<const f32x4*>(sp + 3 * HS) : zero;
-        n_hp = (row_ok && hasp) ? *reinterpret_cast<const f32x4*>(Y + (rbase + tp) * (2 * HS) + dir * HS + u0) : zero;
+        n_dy[j] = *reinterpret_cast<const f32x4*>(dY + o);
+        if constexpr (MASK) n_mk[j] = *reinterpret_cast<const f32x4*>(dy_mask + o);
+        n_r[j] = *reinterpret_cast<const f32x4*>(sp);
+        n_z[j] = *reinterpret_cast<const f32x4*>(sp + HS);
+        n_n[j] = *reinterpret_cast<const f32x4*>(sp + 2 * HS);
+        n_hn[j] = *reinterpret_cast<const f32x4*>(sp + 3 * HS);
+        n_hp[j] = *reinterpret_cast<const f32x4*>(Y + (rbase + (hasp ? tp : tau_l)) * (2 * HS) + dir * HS + u0);   // always a valid address
+        n_keep[j] = hasp ? 1.f : 0.f;
     };
-    prefetch(dir ? 0 : T - 1);
-    for (int step = 0; step < T; ++step) {
+    auto do_step = [&](auto set_c, int step) {
+        constexpr int j = decltype(set_c)::value;
         const int tau = dir ? step : T - 1 - step;
-        const f32x4 dy = n_dy, r = n_r, z = n_z, n = n_n, hn = n_hn, hp = n_hp;
-        if (step + 1 < T) prefetch(dir ? tau + 1 : tau - 1);
         f32x4 acc = zero;
-        if (step > 0) {
-            const int rb = (step - 1) & 1;
+        const int rb = (step + 1) & 1;
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                bf16x8 fb[3];
+        for (int ks = 0; ks < 6; ++ks) {
+            bf16x8 fb[3];
 #pragma unroll
-                for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&dgs[rb][s][r16][32 * ks + 8 * kq]);
-                acc = mma_x3(wa[ks], fb, acc);
-            }
+            for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&dgs[rb][s][r16][32 * ks + 8 * kq]);
+            acc = mma_x3(wa[ks], fb, acc);
         }
         f32x4 g_r, g_z, g_n, g_nr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float dh = dy[q] + (step > 0 ? acc[q] + dh_c[q] * z_c[q] : 0.f);
-            const float dn = dh * (1.f - z[q]) * (1.f - n[q] * n[q]);
-            const float dz = dh * (hp[q] - n[q]) * z[q] * (1.f - z[q]);
-            const float dr = dn * hn[q] * r[q] * (1.f - r[q]);
-            dh_c[q] = dh; z_c[q] = z[q];
-            g_r[q] = dr; g_z[q] = dz; g_n[q] = dn; g_nr[q] = dn * r[q];
+            float dyq = n_dy[j][q];
+            if constexpr (MASK) dyq *= n_mk[j][q];
+            const float r = n_r[j][q], z = n_z[j][q], n = n_n[j][q], hn = n_hn[j][q], hp = n_hp[j][q] * n_keep[j];
+            const float dh = dyq + acc[q] + dhz[q];                   // step 0: zero tile, dhz = 0
+            const float dn = dh * (1.f - z) * (1.f - n * n);
+            const float dz = dh * (hp - n) * z * (1.f - z);
+            const float dr = dn * hn * r * (1.f - r);
+            dhz[q] = dh * z;
+            g_r[q] = dr; g_z[q] = dz; g_n[q] = dn; g_nr[q] = dn * r;
         }
         const int wb = step & 1;
         split4_store(g_r, &dgs[wb][0][r16][u0], &dgs[wb][1][r16][u0], &dgs[wb][2][r16][u0]);
         split4_store(g_z, &dgs[wb][0][r16][HS + u0], &dgs[wb][1][r16][HS + u0], &dgs[wb][2][r16][HS + u0]);
         split4_store(g_nr, &dgs[wb][0][r16][2 * HS + u0], &dgs[wb][1][r16][2 * HS + u0], &dgs[wb][2][r16][2 * HS + u0]);
-        if (row_ok) {
-            float* gi_o = dgi + dir * dg_ds + (rbase + tau) * (3 * HS) + u0;
-            float* gh_o = dgh + dir * dg_ds + (rbase + tau) * (3 * HS) + u0;
-            *reinterpret_cast<f32x4*>(gi_o) = g_r; *reinterpret_cast<f32x4*>(gi_o + HS) = g_z; *reinterpret_cast<f32x4*>(gi_o + 2 * HS) = g_n;
-            *reinterpret_cast<f32x4*>(gh_o) = g_r; *reinterpret_cast<f32x4*>(gh_o + HS) = g_z; *reinterpret_cast<f32x4*>(gh_o + 2 * HS) = g_nr;
-        }
+        float* gi_o = dgi + dir * dg_ds + (rbase + tau) * (3 * HS) + u0;
+        float* gh_o = dgh + dir * dg_ds + (rbase + tau) * (3 * HS) + u0;
+        *reinterpret_cast<f32x4*>(gi_o) = g_r; *reinterpret_cast<f32x4*>(gi_o + HS) = g_z; *reinterpret_cast<f32x4*>(gi_o + 2 * HS) = g_n;
+        *reinterpret_cast<f32x4*>(gh_o) = g_r; *reinterpret_cast<f32x4*>(gh_o + HS) = g_z; *reinterpret_cast<f32x4*>(gh_o + 2 * HS) = g_nr;
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch(set_c, step + D);
+        __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
-    }
+    };
+    static_for<D>([&](auto j) { prefetch(j, decltype(j)::value); });
+    lds_barrier();
+    for (int step0 = 0; step0 < T; step0 += D)               // T % D == 0 (host)
+        static_for<D>([&](auto j) { do_step(j, step0 + decltype(j)::value); });
 }
 
 }  // namespace tg
 
 using namespace tg;
+
+// lab switch TG_H64_RING = 1 | 2 | 4: depth of the operand prefetch ring (default 4)
+static int h64_ring() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TG_H64_RING"); v = e ? atoi(e) : 4; }
+    return v;
+}
 
 extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
                                   const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
@@ -252,8 +289,23 @@ extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const 
     TG_REQUIRE(aligned16(gi) && aligned16(w_hh_fwd) && aligned16(w_hh_rev) && aligned16(b_hh_fwd) && aligned16(b_hh_rev) && aligned16(y) &&
                (save == nullptr || aligned16(save)) && (drop_mask == nullptr || (aligned16(drop_mask) && aligned16(y_drop))) &&
                gi_dir_stride % 4 == 0 && save_dir_stride % 4 == 0, "tg_gru_h64_forward: operands must be 16-byte aligned");
-    hipLaunchKernelGGL(gru_h64_fwd_kernel, dim3(cdiv(B, 16), 2), dim3(256), 0, (hipStream_t)stream, gi, (long)gi_dir_stride, w_hh_fwd,
-                       w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask, y_drop, B, T);
+// prefetch ring depth: the deepest of 4 / 2 / 1 that divides T
+#define TG_H64_FWD(SAVE_, DROP_, D_)                                                                                                        \
+    hipLaunchKernelGGL((gru_h64_fwd_kernel<SAVE_, DROP_, D_>), dim3(cdiv(B, 16), 2), dim3(256), 0, (hipStream_t)stream, gi, (long)gi_dir_stride, \
+                       w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask, y_drop, B, T)
+#define TG_H64_FWD_D(D_)                                  \
+    do {                                                  \
+        if (save && drop_mask) TG_H64_FWD(true, true, D_);    \
+        else if (save) TG_H64_FWD(true, false, D_);           \
+        else if (drop_mask) TG_H64_FWD(false, true, D_);      \
+        else TG_H64_FWD(false, false, D_);                    \
+    } while (0)
+    const int ring = h64_ring();
+    if (T % 4 == 0 && ring >= 4) TG_H64_FWD_D(4);
+    else if (T % 2 == 0 && ring >= 2) TG_H64_FWD_D(2);
+    else TG_H64_FWD_D(1);
+#undef TG_H64_FWD_D
+#undef TG_H64_FWD
     return check_launch("tg_gru_h64_forward");
 }
 
@@ -265,7 +317,19 @@ extern "C" int tg_gru_h64_backward(const float* dy, const float* dy_mask, const 
     TG_REQUIRE(aligned16(dy) && aligned16(y) && aligned16(save) && aligned16(w_hh_t_fwd) && aligned16(w_hh_t_rev) && aligned16(dgi) &&
                aligned16(dgh) && (dy_mask == nullptr || aligned16(dy_mask)) && save_dir_stride % 4 == 0 && dg_dir_stride % 4 == 0,
                "tg_gru_h64_backward: operands must be 16-byte aligned");
-    hipLaunchKernelGGL(gru_h64_bwd_kernel, dim3(cdiv(B, 16), 2), dim3(256), 0, (hipStream_t)stream, dy, dy_mask, y, save,
-                       (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T);
+#define TG_H64_BWD(MASK_, D_)                                                                                                          \
+    hipLaunchKernelGGL((gru_h64_bwd_kernel<MASK_, D_>), dim3(cdiv(B, 16), 2), dim3(256), 0, (hipStream_t)stream, dy, dy_mask, y, save, \
+                       (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T)
+#define TG_H64_BWD_D(D_)                       \
+    do {                                       \
+        if (dy_mask) TG_H64_BWD(true, D_);     \
+        else TG_H64_BWD(false, D_);            \
+    } while (0)
+    const int ring = h64_ring();
+    if (T % 4 == 0 && ring >= 4) TG_H64_BWD_D(4);
+    else if (T % 2 == 0 && ring >= 2) TG_H64_BWD_D(2);
+    else TG_H64_BWD_D(1);
+#undef TG_H64_BWD_D
+#undef TG_H64_BWD
     return check_launch("tg_gru_h64_backward");
 }

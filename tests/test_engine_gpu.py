@@ -650,3 +650,36 @@ def test_persistent_kernel_timeout_word_is_sticky(pkg, dev):
     with pytest.raises(RuntimeError, match="timed out"):
         losses.to_dict()
     tr.train_iter(11, text, audio, poses, vid).to_dict()           # cleared by the host read: the next iteration is clean
+
+
+def test_atomic_weight_gradient_combine_run_to_run_spread(pkg, dev):
+    """Weight gradients of short products combine their row splits with float atomics (order not fixed; products with >= 32 768 rows and
+    conv-layout outputs use the deterministic two-pass combine).  Five runs of one B = 16 iteration from identical state and identical
+    draws: forward values and losses are bit-identical, every gradient tensor's spread stays below 2e-6 of its largest element --
+    an order of magnitude inside the 1e-4 parity tolerance, the size of one fp32 rounding of the sum."""
+    V, S, B = 64, 9, 16
+    gst, dst = O.make_generator_state(7, V, S), O.make_discriminator_state(8)
+    text, audio, vid, poses = (t.to(dev) for t in O.make_batch(11, B, V, S))
+    runs = []
+    for _ in range(5):
+        args, G, D = build_models(pkg, dev, gst, dst, V, S)
+        tr = pkg.GanTrainer(G, D, args)
+        tr.G.rng.state[0] = 5; tr.D.rng.state[0] = 6
+        losses = tr.train_iter(11, text, audio, poses, vid).to_dict()
+        runs.append((losses, {k: v.detach().clone() for k, v in tr.G.views()[1].items()},
+                     {k: v.detach().clone() for k, v in tr.D.views()[1].items()}))
+    worst = 0.0
+    for losses, gg, dg in runs[1:]:
+        for k, v in losses.items():
+            assert v == runs[0][0][k] or abs(v - runs[0][0][k]) <= 1e-6 * max(1.0, abs(v)), (k, v, runs[0][0][k])
+        for mine, ref in ((gg, runs[0][1]), (dg, runs[0][2])):
+            for k, v in mine.items():
+                scale = float(ref[k].abs().max())
+                if scale == 0:
+                    assert float(v.abs().max()) == 0, k
+                    continue
+                spread = float((v - ref[k]).abs().max()) / scale
+                worst = max(worst, spread)
+                if k not in ZERO_GRAD_KEYS:
+                    assert spread <= 2e-6, (k, spread)
+    print("atomic combine: worst run-to-run gradient spread %.2e" % worst)

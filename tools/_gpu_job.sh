@@ -1,10 +1,5 @@
-python -m pytest tests -m gpu -q -x 2>&1 | tail -12 > gpurun_out/r2_t8.log
-bash tools/r2_profile.sh r2_f > gpurun_out/r2_f_profile.log 2>&1
-for m in plain cap seg; do
-  case $m in plain) fl="";; cap) fl="--force-ddp"; export TG_DDP_CAPTURE=1;; seg) fl="--force-ddp"; export TG_DDP_CAPTURE=0;; esac
-  python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline $fl 2> gpurun_out/r2_f_ddp_$m.err | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$m', d['ms_per_step'], d['value'])" >> gpurun_out/r2_f_ddp.txt
-done
-unset TG_DDP_CAPTURE
-bash tools/r2_pmc.sh > gpurun_out/r2_pmc.log 2>&1
-python3 bench.py > gpurun_out/r2_f_bench_full.json 2> gpurun_out/r2_f_bench_full.err
-cat gpurun_out/r2_t8.log gpurun_out/r2_f_ddp.txt; tail -c 1200 gpurun_out/r2_f_bench_full.json
+python -m pytest tests/test_ops_gpu.py -m gpu -q -x 2>&1 | tail -4 > gpurun_out/r2_t11.log
+for tile in 22 42 44; do for wgs in 1536 3072 6144; do echo "### tile $tile wgs $wgs"; TG_TN_TILE=$tile TG_TN_WGS=$wgs python3 tools/tn_tile_lab.py 2>&1 | grep -v amdgpu.ids | head -4; done; done > gpurun_out/r2_i_tn_lab.txt 2>&1
+python3 tools/gru_cluster_probe.py > gpurun_out/r2_i_gru_probe.txt 2>&1
+bash tools/r2_profile.sh r2_i > gpurun_out/r2_i_profile.log 2>&1
+cat gpurun_out/r2_t11.log gpurun_out/r2_i_tn_lab.txt gpurun_out/r2_i_gru_probe.txt; tail -c 300 gpurun_out/r2_i_bench.json; head -16 gpurun_out/r2_i_by_shape.txt
