@@ -72,6 +72,7 @@ SIGNATURES = {
     "tg_weight_norm_fwd": [P, P, P, I32, I32, I32, P],
     "tg_weight_norm_fwd_batch": [I32, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), I32, I32, I32, P],
     "tg_weight_norm_bwd": [P, P, P, P, P, I32, I32, I32, P],
+    "tg_weight_norm_bwd_batch": [I32, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), I32, I32, I32, P],
     "tg_rng_advance": [P, P],
     "tg_dropout_mask": [P, I64, F32, P, U32, P],
     "tg_dropout_apply": [P, P, P, I64, F32, P, U32, P],

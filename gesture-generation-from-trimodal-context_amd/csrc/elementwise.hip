@@ -264,6 +264,31 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
     }
 }
 
+// every weight-normed conv of a network in one launch (blockIdx.y = conv): dw[j] = packed weight gradient of conv j
+struct WnBwdBatch { const float* dw[8]; const float* v[8]; const float* g[8]; float* dg[8]; float* dv[8]; };
+__global__ __launch_bounds__(256) void weight_norm_bwd_batch_kernel(const WnBwdBatch b, int Ci, int kw) {
+    __shared__ float sh[4];
+    const int co = blockIdx.x, j = blockIdx.y, n = Ci * kw;
+    const float* vr = b.v[j] + (long)co * n;
+    const float* dw = b.dw[j] + (long)co * n;
+    float s = 0.f, d = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int ci = i / kw, kk = i - ci * kw;
+        s += vr[i] * vr[i];
+        d += dw[(long)kk * Ci + ci] * vr[i];
+    }
+    const float n2 = block_sum(s, sh);
+    const float dot = block_sum(d, sh);
+    const float nrm = sqrtf(n2);
+    if (threadIdx.x == 0) b.dg[j][co] += dot / nrm;
+    const float a = b.g[j][co] / nrm, bcoef = dot / n2;
+    float* dv = b.dv[j] + (long)co * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int ci = i / kw, kk = i - ci * kw;
+        dv[i] += a * (dw[(long)kk * Ci + ci] - bcoef * vr[i]);
+    }
+}
+
 // ---- RNG -----------------------------------------------------------------------------------------------------------
 __global__ void rng_advance_kernel(uint64_t* st) { st[1] += 1; }
 __global__ void dropout_mask_kernel(float* __restrict__ mask, long n, float p, const uint64_t* __restrict__ st, uint32_t site) {
@@ -509,6 +534,18 @@ int tg_weight_norm_bwd(const float* dw_packed, const float* v, const float* g, f
     TG_REQUIRE(dw_packed && v && g && dg && dv && Co > 0 && Ci > 0 && kw > 0, "tg_weight_norm_bwd: bad arguments");
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(Co), dim3(256), 0, ST, dw_packed, v, g, dg, dv, Ci, kw);
     return check_launch("tg_weight_norm_bwd");
+}
+int tg_weight_norm_bwd_batch(int32_t n, const float* const* dw_packed, const float* const* v, const float* const* g, float* const* dg,
+                             float* const* dv, int32_t Co, int32_t Ci, int32_t kw, void* stream) {
+    TG_REQUIRE(n >= 1 && n <= 8 && dw_packed && v && g && dg && dv && Co > 0 && Ci > 0 && kw > 0, "tg_weight_norm_bwd_batch: 1..8 convs, non-null tables");
+    WnBwdBatch b;
+    for (int i = 0; i < 8; ++i) {
+        const int j = i < n ? i : 0;
+        TG_REQUIRE(dw_packed[j] && v[j] && g[j] && dg[j] && dv[j], "tg_weight_norm_bwd_batch: null entry %d", j);
+        b.dw[i] = dw_packed[j]; b.v[i] = v[j]; b.g[i] = g[j]; b.dg[i] = dg[j]; b.dv[i] = dv[j];
+    }
+    hipLaunchKernelGGL(weight_norm_bwd_batch_kernel, dim3(Co, n), dim3(256), 0, ST, b, Ci, kw);
+    return check_launch("tg_weight_norm_bwd_batch");
 }
 int tg_rng_advance(uint64_t* rng_state, void* stream) {
     TG_REQUIRE(rng_state, "tg_rng_advance: null");

@@ -273,10 +273,12 @@ __global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
 
 using namespace tg;
 
-// lab switch TG_H64_RING = 1 | 2 | 4: depth of the operand prefetch ring (default 4)
+// TG_H64_RING = 1 | 2 | 4: depth of the operand prefetch ring.  Default 1: measured at B = 128 / 256, T = 28 (tools/h64_probe.py,
+// profiles/r2_j_h64_probe.txt) one step of look-ahead is enough once the loop has no lane predicates (fwd 32 us), deeper rings cost
+// registers and code size for nothing (36 us at depth 2 and 4)
 static int h64_ring() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TG_H64_RING"); v = e ? atoi(e) : 4; }
+    if (v < 0) { const char* e = getenv("TG_H64_RING"); v = e ? atoi(e) : 1; }
     return v;
 }
 

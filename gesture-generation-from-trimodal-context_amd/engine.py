@@ -283,6 +283,7 @@ class GeneratorEngine(_Engine):
                                 G[f"{te}.decoder.bias"])
             Co_t = P[f"{te}.tcn.network.0.conv1.weight_v"].shape[0]
             dwp_all = ops.zeros(2 * self.n_layers, Co_t, 2 * Co_t, device=dcur.device)       # packed weight gradients of the 8 convs: one fill
+            wn_pre = []                                                                       # weight-norm backward of all convs: one launch after the loop
             for i in range(self.n_layers - 1, -1, -1):
                 blk = tp["tcn"][i]
                 d = blk["d"]
@@ -299,7 +300,7 @@ class GeneratorEngine(_Engine):
                     v = P[pre + ".weight_v"]
                     dwp = dwp_all[2 * i + ci]
                     ops.gemm_tn(dc, Win.conv(xin, 2, pad=d, dil=d, rows_out=T), dwp, dbias=G[pre + ".bias"])
-                    ops.weight_norm_bwd(dwp, v, P[pre + ".weight_g"], G[pre + ".weight_g"], G[pre + ".weight_v"])
+                    wn_pre.append((dwp, pre))
                     # dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0]  -> taps (t + d, t) with B = w^T per tap (from the forward's batch)
                     wT = blk[f"wt{ci}"]
                     if ci == 1:
@@ -307,6 +308,11 @@ class GeneratorEngine(_Engine):
                     else:   # first conv of the block: add into the residual branch gradient
                         dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, dsum, accumulate=True)
                 dcur = dh
+            for j0 in range(0, len(wn_pre), 8):
+                chunk = wn_pre[j0:j0 + 8]
+                ops.weight_norm_bwd_batch([dw for dw, _ in chunk], [P[pre + ".weight_v"] for _, pre in chunk],
+                                          [P[pre + ".weight_g"] for _, pre in chunk], [G[pre + ".weight_g"] for _, pre in chunk],
+                                          [G[pre + ".weight_v"] for _, pre in chunk])
             em = tp["emb_mask"]
             demb = ops.mul(dcur, em[rows].reshape(M, -1), torch.empty_like(dcur)) if em is not None else dcur
             if f"{te}.embedding.weight" not in self.slab.frozen:           # freeze_wordembed (:40-41): no gradient, never stepped

@@ -509,6 +509,17 @@ def weight_norm_bwd(dw_packed, v, g, dg, dv):
     call("tg_weight_norm_bwd", _p(dw_packed), _p(v), _p(g), _p(_flat(dg, "dg")), _p(dv), Co, Ci, kw, _stream())
 
 
+def weight_norm_bwd_batch(dws, vs, gs, dgs, dvs):
+    """weight_norm_bwd for up to 8 convs of equal shape in one launch (lists of tensors, one entry per conv)."""
+    n = len(vs)
+    Co, Ci, kw = vs[0].shape
+    for dw, v, g, dg, dv in zip(dws, vs, gs, dgs, dvs):
+        assert tuple(v.shape) == (Co, Ci, kw) and _same(dw, v, dv) and dg.numel() == Co == g.numel()
+        _flat(dg, "dg"); _flat(g, "g")
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    call("tg_weight_norm_bwd_batch", n, arr(dws), arr(vs), arr(gs), arr(dgs), arr(dvs), Co, Ci, kw, _stream())
+
+
 # ------------------------------------------------------------------------------------------------- RNG
 def new_rng_state(seed, device):
     return torch.tensor([int(seed) & (2 ** 63 - 1), 0], dtype=torch.int64, device=device)

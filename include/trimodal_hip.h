@@ -265,13 +265,16 @@ int tg_conv_dgrad_pack(const float* w, float* out, int32_t Co, int32_t Ci, int32
  * v: [Co][Ci][kw], g: [Co].  w_packed: [Co][kw][Ci] = g * v / ||v||  (tap-major, the layout tg_gemm_nt wants). */
 int tg_weight_norm_fwd(const float* v, const float* g, float* w_packed, int32_t Co, int32_t Ci, int32_t kw,
                        void* stream);
-/* dw_packed: [Co][kw][Ci] -> dg[Co], dv[Co][Ci][kw] (both accumulate). */
 /* All weight-normed convs of a network in ONE launch (same Co, Ci, kw): w_packed[i] as tg_weight_norm_fwd, and -- when w_t != NULL --
  * w_t[i] = the same weight as [Ci][kw*Co] (w_t[ci][tap*Co + co]), the B operand of the conv's input gradient. */
 int tg_weight_norm_fwd_batch(int32_t n, const float* const* v, const float* const* g, float* const* w_packed, float* const* w_t,
                              int32_t Co, int32_t Ci, int32_t kw, void* stream);
+/* dw_packed: [Co][kw][Ci] -> dg[Co], dv[Co][Ci][kw] (both accumulate). */
 int tg_weight_norm_bwd(const float* dw_packed, const float* v, const float* g, float* dg, float* dv, int32_t Co,
                        int32_t Ci, int32_t kw, void* stream);
+/* The same for n <= 8 convs of equal shape in one launch (tables of n pointers). */
+int tg_weight_norm_bwd_batch(int32_t n, const float* const* dw_packed, const float* const* v, const float* const* g, float* const* dg,
+                             float* const* dv, int32_t Co, int32_t Ci, int32_t kw, void* stream);
 
 /* ---- randomness: Philox4x32-10 counter RNG, graph-replay safe -----------------------------------------
  * rng_state: device uint64[2] = {seed, step}.  tg_rng_advance bumps step by one (launch once per iteration).

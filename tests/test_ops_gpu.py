@@ -261,6 +261,17 @@ def test_weight_norm_and_dgrad_pack(pkg, dev):
     dg, dv = torch.zeros(Co, device=dev), torch.zeros_like(vg)
     ops.weight_norm_bwd(dw.permute(0, 2, 1).contiguous().float().to(dev).view(Co, kw * Ci), vg, gg, dg, dv)
     assert rel(dg, g.grad.view(-1)) < 1e-5 and rel(dv, v.grad) < 1e-5
+    # the batched launch == the single one, per conv (three convs with different data, accumulating into non-zero gradients)
+    dwp = dw.permute(0, 2, 1).contiguous().float().to(dev).view(Co, kw * Ci)
+    vs = [vg * (1 + 0.1 * i) for i in range(3)]
+    gs = [gg + 0.01 * i for i in range(3)]
+    dws = [dwp * (1 - 0.2 * i) for i in range(3)]
+    dgs_b, dvs_b = [torch.full((Co,), 0.5, device=dev) for _ in range(3)], [torch.full_like(vg, 0.25) for _ in range(3)]
+    ops.weight_norm_bwd_batch(dws, vs, gs, dgs_b, dvs_b)
+    for i in range(3):
+        dg1, dv1 = torch.full((Co,), 0.5, device=dev), torch.full_like(vg, 0.25)
+        ops.weight_norm_bwd(dws[i], vs[i], gs[i], dg1, dv1)
+        assert torch.equal(dg1, dgs_b[i]) and torch.equal(dv1, dvs_b[i])
     w2 = rnd(8, 5, 15, seed=38).to(dev)
     packed = ops.conv_dgrad_pack(w2, torch.empty(6, 5, 3 * 8, device=dev), 6).cpu().view(6, 5, 3, 8)
     for r in range(6):
