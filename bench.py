@@ -26,6 +26,7 @@ V, S, T, D, A = 20000, 1371, 34, 27, 36267
 # algorithmic work per clip of one post-warm-up iteration: 5 G-forward-equivalents + 9 D-forward-equivalents
 FLOP_PER_CLIP = 2.735e9
 PEAK_F32_MFMA = 157.3e12          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA = 2.5e15           # same table, dense bf16 matrix peak (no sparsity)
 
 
 def make_args():
@@ -114,7 +115,9 @@ def dominant_kernel_roofline(pkg, device, batch):
     return {"kernel": "gru_seq_fwd_cluster_x3_kernel<2>", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": traffic, "launch_us": dt * 1e6,
             "flop_per_launch": flops, "us_per_step": dt * 1e6 / T,
-            "note": "fp32-accurate product issued as 6 bf16 MFMAs per MAC on split operands; peak = fp32 matrix peak"}
+            "peak_bf16x3": PEAK_BF16_MFMA / 6 / 1e12, "frac_bf16x3": flops / dt / (PEAK_BF16_MFMA / 6),
+            "note": "fp32-accurate product issued as 6 bf16 MFMAs per MAC on split operands; peak = fp32 matrix peak "
+                    "(peak_bf16x3 = dense bf16 MFMA peak / 6, the ceiling of this arithmetic)"}
 
 
 PMC_TRAFFIC_GRU_FWD = 371.6e6      # bytes per launch: (2 x FETCH_SIZE 80 097 KB + WRITE_SIZE 202 737 KB) x 1024, profiles/r2_pmc_gru_fwd_cluster_x3.txt

@@ -37,7 +37,7 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // Zero `bytes` (a multiple of 4) at p with a kernel of this library.  Used instead of hipMemsetAsync everywhere: a memset
 // captured into a hipGraph replays as a runtime fill kernel that reads its pattern from a staging area of the runtime, and on
 // ROCm 7.2 that area is reused by eager blit copies issued between replays -- the "zero" fill then wrote copy arguments
-// (source / destination pointers) over the flag words of the persistent GRU kernels (tools/feeder_probe2.py).
+// (source / destination pointers) over the flag words of the persistent GRU kernels (tools/graph_memset_hazard_probe.py).
 int zero_async(void* p, size_t bytes, hipStream_t s);
 
 // grid for a grid-stride element-wise kernel: enough blocks to fill 256 CUs, capped (guide: Guideline 11)

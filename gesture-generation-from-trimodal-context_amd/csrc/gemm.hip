@@ -12,6 +12,9 @@
 // are staged through LDS with coalesced 16-byte loads, double-buffered, one barrier per tile.
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.hpp"
 
 namespace tg {
@@ -54,8 +57,13 @@ __device__ __forceinline__ void load_nt_frags(const Win& A, const long (&a_off)[
     }
 }
 
+template <int N, typename F, int... I>
+__device__ __forceinline__ void nt_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void nt_static_for(F&& f) { nt_static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
 // Workgroup = 4 waves arranged WM x WN, each wave a 32x32 output tile (2x2 MFMA tiles of 16x16).
-template <bool VEC, int WM, int WN>
+template <bool VEC, int WM, int WN, int NT_RING>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
     const int pi = group_find(g, blockIdx.x);
     const NtProb& pr = g.p[pi];
@@ -108,62 +116,126 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // tap / channel of this lane's first k, advanced incrementally (VEC path: cw % 4 == 0, no division in the loop)
-    int k = 4 * kq;
-    int kk = 0, c = k;
-    if (VEC) {
-        kk = k / A.cw;
-        c = k - kk * A.cw;
-    }
-    f32x4 fa[2], fb[2], na[2], nb[2];
-    load_nt_frags<VEC>(A, a_off, a_r, a_ok, b_ptr, b_ok, k, kk, c, fa, fb);
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const bool more = k0 + 16 < K;
-        if (more) {
-            k += 16;
-            if (VEC) {
-                c += 16;
-                while (c >= A.cw) { c -= A.cw; ++kk; }
+    if constexpr (VEC) {
+        // Ring of NT_RING k-steps of operands in flight (16 VGPRs each; 4 for small grids with a long K, where nothing else hides the
+        // latency, 1 for chip-filling grids, where occupancy does and the registers cost more than they give: conv1-sized launches
+        // went 95 -> 128 us with a ring of 4).  The loads are issued UNCONDITIONALLY from an always-valid address and zeroed
+        // when the set is used (mask bits): a predicated load makes the count of outstanding loads dynamic and hipcc then drains
+        // everything (vmcnt(0)) at the next use -- with the one-deep prefetch of the first version every 16-deep k-step of a small grid
+        // cost a full memory latency (audio conv4, 40 workgroups: 56 us for 0.27 GFLOP).
+        constexpr int R = NT_RING;
+        int k = 4 * kq;
+        int kk = k / A.cw, c = k - (k / A.cw) * A.cw;      // tap / channel of this lane's next k, advanced by 16 per load (cw % 4 == 0)
+        f32x4 ra[R][2], rb[R][2];
+        unsigned rm[R];
+        auto load = [&](auto set_c) {
+            constexpr int j = decltype(set_c)::value;
+            const bool inb = k < K;
+            unsigned m = 0u;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int sr = a_r[mt] + kk * A.dil;
+                const bool ok = a_ok[mt] && inb && sr >= 0 && sr < A.rows_in;
+                ra[j][mt] = *reinterpret_cast<const f32x4*>(ok ? A.ptr + a_off[mt] + (long)sr * A.rs + c : A.ptr);
+                m |= ok ? (1u << mt) : 0u;
             }
-            load_nt_frags<VEC>(A, a_off, a_r, a_ok, b_ptr, b_ok, k, kk, c, na, nb);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const bool ok = b_ok[nt] && inb;
+                rb[j][nt] = *reinterpret_cast<const f32x4*>(ok ? b_ptr[nt] + k : Bw);
+                m |= ok ? (4u << nt) : 0u;
+            }
+            rm[j] = m;
+            k += 16;
+            c += 16;
+            while (c >= A.cw) { c -= A.cw; ++kk; }
+        };
+        nt_static_for<R>([&](auto j) { load(j); });
+        for (int k0 = 0; k0 < K; k0 += 16 * R) {
+            nt_static_for<R>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                {                                           // (k-steps past K multiply masked zeros: no branch, so the counts stay static)
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 fa[2], fb[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        fa[i] = (rm[j] >> i) & 1u ? ra[j][i] : z;
+                        fb[i] = (rm[j] >> (2 + i)) & 1u ? rb[j][i] : z;
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][v], fb[nt][v], acc[mt][nt], 0, 0, 0);
+                    load(jc);                               // the k-step R ahead (past K: a valid address, masked)
+                }
+            });
         }
+    } else {
+        int k = 4 * kq;
+        f32x4 fa[2], fb[2], na[2], nb[2];
+        load_nt_frags<VEC>(A, a_off, a_r, a_ok, b_ptr, b_ok, k, 0, k, fa, fb);
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            const bool more = k0 + 16 < K;
+            if (more) {
+                k += 16;
+                load_nt_frags<VEC>(A, a_off, a_r, a_ok, b_ptr, b_ok, k, 0, k, na, nb);
+            }
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+            for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][v], fb[nt][v], acc[mt][nt], 0, 0, 0);
-        if (more) {
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][v], fb[nt][v], acc[mt][nt], 0, 0, 0);
+            if (more) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
+                for (int i = 0; i < 2; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
+            }
         }
     }
 
-    // C/D layout of the 16x16 tile: row = (lane>>4)*4 + i, col = lane&15
+    // C/D layout of the 16x16 tile: row = (lane>>4)*4 + i, col = lane&15.  Every global read of the epilogue (bias, dropout mask,
+    // accumulate operand: up to 34 per lane) is issued before the first use, from always-valid addresses; element by element they
+    // each waited out an L2 round trip in turn.
+    long off[2][4][2];
+    bool okc[2][4][2];
+    float bv[2] = {0.f, 0.f}, mv[2][4][2], cv[2][4][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = n_base + nt * 16 + r16;
+        if (bias) bv[nt] = bias[col < N ? col : 0];
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = m_base + mt * 16 + kq * 4 + i;
-            if (row >= M) continue;
-            const int cb = row / cR;
-            const int cr = row - cb * cR;
-            float* crow = C + (long)cb * cbs + (long)cr * crs;
-            const float* mrow = mul ? mul + (long)cb * cbs + (long)cr * crs : nullptr;
+            const int rr = row < M ? row : 0;
+            const int cb = rr / cR;
+            const int cr = rr - cb * cR;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int col = n_base + nt * 16 + r16;
-                if (col >= N) continue;
-                float v = acc[mt][nt][i];
-                if (bias) v += bias[col];
-                v = act_fn(v, slope);
-                if (mrow) v *= mrow[col];
-                if (accumulate) v += crow[col];
-                crow[col] = v;
+                okc[mt][i][nt] = row < M && col < N;
+                off[mt][i][nt] = okc[mt][i][nt] ? (long)cb * cbs + (long)cr * crs + col : 0;
+                if (mul) mv[mt][i][nt] = mul[off[mt][i][nt]];
+                if (accumulate) cv[mt][i][nt] = C[off[mt][i][nt]];
             }
         }
-    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float v = act_fn(acc[mt][nt][i] + bv[nt], slope);
+                if (mul) v *= mv[mt][i][nt];
+                if (accumulate) v += cv[mt][i][nt];
+                if (okc[mt][i][nt]) C[off[mt][i][nt]] = v;
+            }
 }
 
 // LDS-staged path of tg_gemm_nt for the big products of the step (GRU input projections, TCN convs, their input
@@ -621,14 +693,21 @@ static int nt_launch(NtGroup& g, hipStream_t s) {
         else if (tl.tm == 2 && tl.tn == 2) TG_NT_BIG(2, 2);
         else TG_NT_BIG(2, 1);
 #undef TG_NT_BIG
-    } else if (fam == 1) {
-        const dim3 grid(nt_layout(g, 128, 32));
-        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1>), grid, dim3(256), 0, s, g);
-        else     hipLaunchKernelGGL((gemm_nt_kernel<false, 4, 1>), grid, dim3(256), 0, s, g);
     } else {
-        const dim3 grid(nt_layout(g, 64, 64));
-        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<true, 2, 2>), grid, dim3(256), 0, s, g);
-        else     hipLaunchKernelGGL((gemm_nt_kernel<false, 2, 2>), grid, dim3(256), 0, s, g);
+        int Kx = 0;
+        for (int i = 0; i < g.n; ++i) Kx = Kx > g.p[i].A.K ? Kx : g.p[i].A.K;
+        const int wgs = fam == 1 ? nt_layout(g, 128, 32) : nt_layout(g, 64, 64);
+        const dim3 grid(wgs);
+        const bool deep = wgs < 1024 && Kx >= 256;        // operand ring of 4 k-steps: small grid, long reduction (see the kernel)
+        if (fam == 1) {
+            if (vec && deep) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 4>), grid, dim3(256), 0, s, g);
+            else if (vec)    hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 1>), grid, dim3(256), 0, s, g);
+            else             hipLaunchKernelGGL((gemm_nt_kernel<false, 4, 1, 1>), grid, dim3(256), 0, s, g);
+        } else {
+            if (vec && deep) hipLaunchKernelGGL((gemm_nt_kernel<true, 2, 2, 4>), grid, dim3(256), 0, s, g);
+            else if (vec)    hipLaunchKernelGGL((gemm_nt_kernel<true, 2, 2, 1>), grid, dim3(256), 0, s, g);
+            else             hipLaunchKernelGGL((gemm_nt_kernel<false, 2, 2, 1>), grid, dim3(256), 0, s, g);
+        }
     }
     return check_launch("tg_gemm_nt");
 }

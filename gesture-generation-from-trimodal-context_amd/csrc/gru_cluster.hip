@@ -455,7 +455,8 @@ extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, co
     // (ops.check_async_errors), so a timeout in any launch that shares this workspace survives the launches after it.
     unsigned* tmo = (unsigned*)ws;
     unsigned* flags = tmo + GC_FLAG_STRIDE;
-    if (zero_async(flags, (size_t)(flag_words - GC_FLAG_STRIDE) * 4, s)) return 1;
+    // (the bf16 x 3 kernels number their flags by generation and need no zeroing: gru_cluster_x3.hip)
+    if (!use_gru_x3() && zero_async(flags, (size_t)(flag_words - GC_FLAG_STRIDE) * 4, s)) return 1;
     float* hx = (float*)(tmo + flag_words);
     const int b_pad = n_bt * 16 * mt;
     if (use_gru_x3())
@@ -510,7 +511,7 @@ extern "C" int tg_gru_backward_cluster(const float* dy, const float* dy_mask, co
     hipStream_t s = (hipStream_t)stream;
     unsigned* tmo = (unsigned*)ws;              // sticky timeout block: cleared by the host only (see the forward entry point)
     unsigned* flags = tmo + GC_FLAG_STRIDE;
-    if (zero_async(flags, (size_t)(flag_words - GC_FLAG_STRIDE) * 4, s)) return 1;
+    if (!use_gru_x3() && zero_async(flags, (size_t)(flag_words - GC_FLAG_STRIDE) * 4, s)) return 1;
     float* gx = (float*)(tmo + flag_words);
     if (use_gru_x3())
         return tg_gru_x3_bwd_launch(dy, dy_mask, y, save, (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, gx, flags, tmo, B, T,

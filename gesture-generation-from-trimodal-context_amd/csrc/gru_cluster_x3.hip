@@ -28,6 +28,7 @@ constexpr int XC_FLAG_STRIDE = 16;    // flag words per cluster (one 64-byte lin
 constexpr int XC_KS = 4;              // K slices (waves along K)
 constexpr int XC_SPS = 3;             // k-steps per slice, forward: ceil(10 / 4)
 constexpr unsigned XC_SPIN_LIMIT = 1u << 26;
+constexpr int XC_GEN_WORD = 15;       // generation word of a cluster's 16-word flag line (members use words 0 .. CW - 1 <= 9)
 constexpr int XC_POLL_WAVE = 7;       // of 8; epilogue threads live in waves 0 .. 3 (forward) / 0 .. 1 (backward)
 constexpr unsigned XC_RSRC3 = 0x00020000u;
 
@@ -77,8 +78,8 @@ __device__ __forceinline__ f32x4 xc_mma(const bf16x8 (&wa)[2], const bf16x8 w_lo
 __device__ __forceinline__ bool xc_wait(gu32x* cl_flags, int CW, int lane, unsigned want, unsigned* tmo, int step) {
     unsigned spins = 0;
     for (;;) {
-        const unsigned v = lane < CW ? __hip_atomic_load(cl_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-        if (__all(v >= want)) return true;
+        const unsigned v = lane < CW ? __hip_atomic_load(cl_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+        if (__all((int)(v - want) >= 0)) return true;        // generations wrap: compare the difference
         __builtin_amdgcn_s_sleep(1);
         if (++spins > XC_SPIN_LIMIT) {                    // wave-uniform
             if (lane == 0) {
@@ -166,6 +167,12 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
     gu32x* my_flag = (gu32x*)(flags + cl * XC_FLAG_STRIDE + m);
     gu32x* cl_flags = (gu32x*)(flags + cl * XC_FLAG_STRIDE);
     bool aborted = false;
+    // Flag words are never zeroed between launches: member m publishes gen + step + 1, where gen is the cluster's GENERATION word
+    // (word 15 of its flag line), read here by every member and advanced by T + 1 by member 0 when it leaves.  Member 0 can only
+    // finish step T - 1 after every member has published step T - 2, i.e. after every member has read gen (T >= 2; with T == 1
+    // nothing is published or advanced -- there is no consumer).  Every value a launch leaves behind is <= gen + T < the next gen,
+    // so stale words never satisfy a wait; the workspace only has to be zero ONCE, before its first use.
+    const unsigned gen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cl_flags + XC_GEN_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 
     // The per-step streams (gi in; y, saved gates, dropped y out) go through BUFFER instructions: a lane without a valid (row, unit)
     // carries an offset past num_records -- its loads return 0 and its stores are dropped by the bounds check -- so every one of them is
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
             // the polling wave is one WITHOUT epilogue threads: its memory queue holds no output stores / prefetch loads of the previous
             // step, so the first poll returns after one L2 round trip (vmcnt counts in order: wave 0 would see its flag loads return
             // only behind its own stores)
-            if (wave == XC_POLL_WAVE && !aborted) aborted = !xc_wait(cl_flags, CW, lane, (unsigned)step, tmo, step);
+            if (wave == XC_POLL_WAVE && !aborted) aborted = !xc_wait(cl_flags, CW, lane, gen + (unsigned)step, tmo, step);
             __syncthreads();                        // the other waves load only behind the polling wave's barrier
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // compiler ordering only; every load below is sc1
             const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes;
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY wave drains its stores before the flag
         __syncthreads();                                       // (also: `red` is free again)
-        if (threadIdx.x == 0) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0 && T >= 2) __hip_atomic_store(my_flag, gen + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (epi_wave) {                                        // outputs for later kernels and the next step's inputs: off the critical path
             __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(h), y_rsrc, y_v, tau * 2 * H * 4, 0);
             if (y_drop) __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(h * mk), yd_rsrc, y_v, tau * 2 * H * 4, 0);   // fused inter-layer dropout
@@ -283,6 +290,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
             prefetch(step + 1);
         }
     }
+    if (m == 0 && threadIdx.x == 0 && T >= 2) __hip_atomic_store(cl_flags + XC_GEN_WORD, gen + (unsigned)(T + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------------ backward
@@ -361,6 +369,12 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     gu32x* my_flag = (gu32x*)(flags + cl * XC_FLAG_STRIDE + m);
     gu32x* cl_flags = (gu32x*)(flags + cl * XC_FLAG_STRIDE);
     bool aborted = false;
+    // Flag words are never zeroed between launches: member m publishes gen + step + 1, where gen is the cluster's GENERATION word
+    // (word 15 of its flag line), read here by every member and advanced by T + 1 by member 0 when it leaves.  Member 0 can only
+    // finish step T - 1 after every member has published step T - 2, i.e. after every member has read gen (T >= 2; with T == 1
+    // nothing is published or advanced -- there is no consumer).  Every value a launch leaves behind is <= gen + T < the next gen,
+    // so stale words never satisfy a wait; the workspace only has to be zero ONCE, before its first use.
+    const unsigned gen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cl_flags + XC_GEN_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 
     // per-step streams through bounds-checked buffer instructions, requested one step ahead (see the forward kernel)
     constexpr unsigned OOB = 0x80000000u;
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
         const int tau = dir ? step : T - 1 - step;
         f32x4 acc[2] = {zero, zero};
         if (step > 0) {
-            if (wave == XC_POLL_WAVE && !aborted) aborted = !xc_wait(cl_flags, CW, lane, (unsigned)step, tmo, step);
+            if (wave == XC_POLL_WAVE && !aborted) aborted = !xc_wait(cl_flags, CW, lane, gen + (unsigned)step, tmo, step);
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes + b0 * 64;
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0 && T >= 2) __hip_atomic_store(my_flag, gen + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (epi_wave) {
             const int go = tau * H3 * 4;
             __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_r), gi_rsrc, dg_v, go, 0);
@@ -460,6 +474,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
             prefetch(step + 1);
         }
     }
+    if (m == 0 && threadIdx.x == 0 && T >= 2) __hip_atomic_store(cl_flags + XC_GEN_WORD, gen + (unsigned)(T + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace tg

@@ -161,7 +161,9 @@ int tg_gru_h64_backward(const float* dy, const float* dy_mask, const float* y, c
 /* Persistent, cluster-synchronised variant of tg_gru_forward for H <= 320 (the generator): ONE launch walks all T
  * steps of both directions; the workgroups that share a batch tile exchange h_t through `ws` with write-through stores and
  * per-workgroup flag words, no grid-wide barrier (csrc/gru_cluster.hip).  Same arguments and results as tg_gru_forward.
- * ws: tg_gru_cluster_ws_bytes(B, H) bytes of device memory, 16-byte aligned, ZERO-FILLED ONCE by the caller when allocated.  Its
+ * ws: tg_gru_cluster_ws_bytes(B, H) bytes of device memory, 16-byte aligned, ZERO-FILLED ONCE by the caller when allocated and
+ * then left to the library: the flag words behind the timeout block are numbered by a per-cluster generation that persists from
+ * launch to launch (no fill kernel per launch; re-zeroing the WHOLE workspace between launches is allowed, part of it is not).  Its
  * first 16 words are a sticky TIMEOUT block: word 0 is set by the kernel if a bounded spin expires (results are then invalid),
  * words 1.. hold diagnostics.  No launch ever clears them -- a timeout in any launch sharing the workspace stays visible until
  * the caller reads word 0 back (after synchronising) and clears it itself.

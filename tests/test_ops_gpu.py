@@ -167,6 +167,46 @@ def test_gru_cluster_kernels_match_step_launches(pkg, dev, B):
         ops.GRU_CLUSTER = prev
 
 
+def test_gru_cluster_flag_generations_across_sequence_lengths(pkg, dev):
+    """The cluster kernels never zero their flag words: each launch numbers them from the cluster's generation word and advances it by
+    T + 1 (csrc/gru_cluster_x3.hip).  Launches of DIFFERENT lengths -- including T = 1 (nothing published) and T = 2 (the shortest with a
+    hand-off) -- on the SAME workspace, back to back without a host sync in between, must each match the per-step launches: a stale flag
+    accepted as current would hand a consumer the previous launch's h tile."""
+    ops = pkg.ops
+    H, B = 300, 40
+    g = torch.Generator().manual_seed(5)
+    w = [(torch.randn(3 * H, H, generator=g) * 0.08).to(dev) for _ in range(2)]
+    b = [(torch.randn(3 * H, generator=g) * 0.05).to(dev) for _ in range(2)]
+    wt = [x.t().contiguous() for x in w]
+    prev = ops.GRU_CLUSTER
+    try:
+        jobs = []
+        for T in (34, 2, 1, 7, 1, 34, 3, 2):
+            gi = (torch.randn(2, B, T, 3 * H, generator=g) * 0.5).to(dev)
+            dy = torch.randn(B, T, 2 * H, generator=g).to(dev)
+            jobs.append((T, gi, dy))
+        res = {}
+        for cluster in (True, False):
+            ops.GRU_CLUSTER = cluster
+            outs = []
+            for T, gi, dy in jobs:                                  # enqueued back to back
+                y = torch.full((B, T, 2 * H), float("nan"), device=dev)
+                sv = torch.full((2, B, T, 4 * H), float("nan"), device=dev)
+                dgi = torch.full((2, B, T, 3 * H), float("nan"), device=dev)
+                dgh = torch.full((2, B, T, 3 * H), float("nan"), device=dev)
+                ops.gru_forward(gi, w, b, y, sv)
+                ops.gru_backward(dy, y, sv, wt, dgi, dgh, torch.zeros(4 * B * H, device=dev))
+                outs.append((y, sv, dgi, dgh))
+            res[cluster] = outs
+        ops.check_async_errors()
+        for (T, _, _), oc, os_ in zip(jobs, res[True], res[False]):
+            for a, c in zip(os_, oc):
+                assert bool(torch.isfinite(c).all()), T
+                assert float((a - c).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), T
+    finally:
+        ops.GRU_CLUSTER = prev
+
+
 # ------------------------------------------------------------------------------------------------ BatchNorm
 @pytest.mark.parametrize("rows,C,groups,slope", [(3 * 500, 16, 3, 0.3), (64, 256, 1, 1.0), (2 * 96, 8, 2, 1.0)])
 def test_batchnorm_train_eval_backward(pkg, dev, rows, C, groups, slope):
@@ -227,6 +267,19 @@ def test_elementwise_family(pkg, dev):
     for perm in ((0, 2, 1), (2, 1, 0), (1, 2, 0)):
         assert torch.equal(ops.permute3(t, torch.empty(t.numel(), device=dev), perm).view([t.shape[p] for p in perm]).cpu(),
                            t.cpu().permute(*perm).contiguous())
+    # batched jobs (layers.WeightPrep's table): inner-dimension swaps take the LDS-tiled path, anything else the element-wise one; ragged
+    # sizes, one workgroup range per job
+    srcs = [rnd(1, 900, 300, seed=33).to(dev), rnd(4, 37, 70, seed=34).to(dev), rnd(16, 15, 2, seed=35).to(dev), rnd(3, 5, 7, seed=36).to(dev)]
+    perms = [(0, 2, 1), (0, 2, 1), (0, 2, 1), (2, 0, 1)]
+    dsts = [torch.full((x.numel(),), float("nan"), device=dev) for x in srcs]
+    rows, wg0 = [], 0
+    for x, d_, pm in zip(srcs, dsts, perms):
+        nwg = max(1, min(64, (x.numel() + 2047) // 2048))
+        rows.append([x.data_ptr(), d_.data_ptr(), *x.shape, *pm, wg0, nwg])
+        wg0 += nwg
+    ops.permute3_batch(torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), wg0)
+    for x, d_, pm in zip(srcs, dsts, perms):
+        assert torch.equal(d_.view([x.shape[p] for p in pm]).cpu(), x.cpu().permute(*pm).contiguous()), (tuple(x.shape), pm)
     tg = rnd(6, 34, 27, seed=32).to(dev)
     pre = ops.make_pre_seq(tg, torch.empty(6, 34, 28, device=dev), 4).cpu()
     assert torch.equal(pre[:, :4, :27], tg.cpu()[:, :4]) and float(pre[:, 4:].abs().max()) == 0 and torch.all(pre[:, :4, 27] == 1)
