@@ -53,6 +53,10 @@ SIGNATURES = {
     "tg_bn_train_fused": [P, P, I32, I32, I32, P, P, P, P, P, P, P, F32, F32, F32, I32, P],
     "tg_bn_apply": [P, P, I32, I32, I32, P, P, P, P, F32, P],
     "tg_bn_backward": [P, P, P, I32, I32, P, P, P, P, F32, P, P, P, P],
+    "tg_wav_front_stats": [P, I64, I32, I32, P, P, I32, I32, I32, P, I64, P, P, P, P, P, P, F32, F32, I32, P],
+    "tg_wav_front_apply": [P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, P, P],
+    "tg_wav_front_backward": [P, P, P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, I64, P, P, P, P, P],
+    "tg_wav_front_backward_fused": [P, I32, P, P, P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, I64, P, P, P, P, P],
     "tg_zero": [P, I64, P],
     "tg_permute3_batch": [P, I32, I32, P],
     "tg_add_relu": [P, P, P, I64, P],
@@ -129,6 +133,9 @@ def load():
     lib.tg_gru_cluster_bwd_supported.argtypes = [I32, I32]
     lib.tg_gru_cluster_bwd_ws_bytes.restype = C.c_int64
     lib.tg_gru_cluster_bwd_ws_bytes.argtypes = [I32, I32]
+    for q, at in (("tg_wav_front_ws_doubles", []), ("tg_wav_front_fstat_doubles", []), ("tg_wav_front_gate_words", [I32, I32])):
+        getattr(lib, q).restype = C.c_int64
+        getattr(lib, q).argtypes = at
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: intended
         fn.argtypes = argtypes

@@ -125,22 +125,30 @@ __global__ void embed_gather_kernel(const float* __restrict__ table, const int64
 // Dense embedding gradient.  The padded text input is mostly index 0: consecutive look-ups with the same
 // index are summed in registers and flushed with ONE atomic per run, so the hot PAD row sees n_idx/CHUNK atomics per
 // column instead of thousands.
-constexpr int SCATTER_CHUNK = 64;
+// The chunk's indices and gradient rows are loaded up front (16 + 16 independent requests per thread), the run combine then works on
+// registers: the former 64-long loop issued one index load and one row load per iteration, each waiting for the last (49 us for the 4352
+// word rows on 68 workgroups, 34 us for 128 speaker rows on 2).
+constexpr int SCATTER_CHUNK = 16;
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ dout, const int64_t* __restrict__ idx,
                                                             float* __restrict__ dtable, int n_idx, int D, int n_rows) {
     const int i0 = blockIdx.x * SCATTER_CHUNK;
-    const int i1 = min(n_idx, i0 + SCATTER_CHUNK);
+    int64_t ids[SCATTER_CHUNK];
+#pragma unroll
+    for (int q = 0; q < SCATTER_CHUNK; ++q) ids[q] = i0 + q < n_idx ? idx[i0 + q] : -1;      // -1: never flushed, never equal to a valid id
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
-        int64_t cur = idx[i0];
+        float v[SCATTER_CHUNK];
+#pragma unroll
+        for (int q = 0; q < SCATTER_CHUNK; ++q) v[q] = dout[(long)min(i0 + q, n_idx - 1) * D + c];
+        int64_t cur = ids[0];
         float acc = 0.f;
-        for (int i = i0; i < i1; ++i) {
-            const int64_t id = idx[i];
-            if (id != cur) {
+#pragma unroll
+        for (int q = 0; q < SCATTER_CHUNK; ++q) {
+            if (ids[q] != cur) {
                 if (cur >= 0 && cur < n_rows) atomicAdd(&dtable[cur * D + c], acc);
                 acc = 0.f;
-                cur = id;
+                cur = ids[q];
             }
-            acc += dout[(long)i * D + c];
+            acc += v[q];
         }
         if (cur >= 0 && cur < n_rows) atomicAdd(&dtable[cur * D + c], acc);
     }
@@ -321,6 +329,9 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_batch_kernel(const WnBwdB
 
 // ---- RNG -----------------------------------------------------------------------------------------------------------
 __global__ void rng_advance_kernel(uint64_t* st) { st[1] += 1; }
+// VEC: n % 4 == 0 and 16-byte aligned pointers (checked by the launcher): one 16-byte access per array and Philox draw instead of four
+// scalar ones (the GRU inter-layer dropout moved 93 MB at 2.7 TB/s through the scalar form)
+template <bool VEC>
 __global__ void dropout_mask_kernel(float* __restrict__ mask, long n, float p, const uint64_t* __restrict__ st, uint32_t site) {
     const uint64_t seed = st[0];
     const uint32_t step = (uint32_t)st[1];
@@ -329,14 +340,22 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, long n, float p, c
     GRID_STRIDE(i, n4) {
         uint32_t r[4];
         philox4x32(seed, (uint64_t)i, site, step, r);
+        if (VEC) {
+            f32x4 m;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long e = i * 4 + q;
-            if (e < n) mask[e] = u01(r[q]) >= p ? keep : 0.f;
+            for (int q = 0; q < 4; ++q) m[q] = u01(r[q]) >= p ? keep : 0.f;
+            reinterpret_cast<f32x4*>(mask)[i] = m;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long e = i * 4 + q;
+                if (e < n) mask[e] = u01(r[q]) >= p ? keep : 0.f;
+            }
         }
     }
 }
 // draw the mask and apply it in one pass: y = x * mask (same draws as dropout_mask_kernel for the same state / site)
+template <bool VEC>
 __global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, long n, float p,
                                      const uint64_t* __restrict__ st, uint32_t site) {
     const uint64_t seed = st[0];
@@ -345,14 +364,24 @@ __global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restr
     const long n4 = (n + 3) / 4;
     GRID_STRIDE(i, n4) {
         uint32_t r[4];
-        philox4x32(seed, (uint64_t)i, site, step, r);
+        if (VEC) {
+            const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];       // in flight while the ten Philox rounds run
+            philox4x32(seed, (uint64_t)i, site, step, r);
+            f32x4 m;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long e = i * 4 + q;
-            if (e < n) {
-                const float m = u01(r[q]) >= p ? keep : 0.f;
-                mask[e] = m;
-                y[e] = x[e] * m;
+            for (int q = 0; q < 4; ++q) m[q] = u01(r[q]) >= p ? keep : 0.f;
+            reinterpret_cast<f32x4*>(mask)[i] = m;
+            reinterpret_cast<f32x4*>(y)[i] = xv * m;
+        } else {
+            philox4x32(seed, (uint64_t)i, site, step, r);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long e = i * 4 + q;
+                if (e < n) {
+                    const float m = u01(r[q]) >= p ? keep : 0.f;
+                    mask[e] = m;
+                    y[e] = x[e] * m;
+                }
             }
         }
     }
@@ -584,12 +613,14 @@ int tg_rng_advance(uint64_t* rng_state, void* stream) {
 }
 int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream) {
     TG_REQUIRE(mask && rng_state && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout_mask: bad arguments");
-    EW(dropout_mask_kernel, (n + 3) / 4, mask, (long)n, p, rng_state, site);
+    if (n % 4 == 0 && aligned16(mask)) EW(dropout_mask_kernel<true>, n / 4, mask, (long)n, p, rng_state, site);
+    else EW(dropout_mask_kernel<false>, (n + 3) / 4, mask, (long)n, p, rng_state, site);
     return check_launch("tg_dropout_mask");
 }
 int tg_dropout_apply(const float* x, float* y, float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream) {
     TG_REQUIRE(x && y && mask && rng_state && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout_apply: bad arguments");
-    EW(dropout_apply_kernel, (n + 3) / 4, x, y, mask, (long)n, p, rng_state, site);
+    if (n % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(mask)) EW(dropout_apply_kernel<true>, n / 4, x, y, mask, (long)n, p, rng_state, site);
+    else EW(dropout_apply_kernel<false>, (n + 3) / 4, x, y, mask, (long)n, p, rng_state, site);
     return check_launch("tg_dropout_apply");
 }
 int tg_normal(float* out, int64_t n, const uint64_t* rng_state, uint32_t site, void* stream) {

@@ -173,6 +173,15 @@ class GeneratorEngine(_Engine):
         fork.keep(x, in_data)
         fork.__enter__()                 # audio encoder on the side stream, text encoder + speaker path on the main one
         for idx, Co, Ci, stride, pad in WAV_CONVS:
+            if idx == 0 and L.wav_front_supported(P[f"{fe}.0.weight"]):
+                # conv1 + BatchNorm + LeakyReLU straight from the raw audio: the 16-channel pre-BatchNorm tensor (65 MB at B = 128) never exists
+                y, st = L.wav_front_fwd(x.view(Ba, -1), P[f"{fe}.0.weight"], P[f"{fe}.0.bias"], P[f"{fe}.1.weight"], P[f"{fe}.1.bias"],
+                                        Bf[f"{fe}.1.running_mean"], Bf[f"{fe}.1.running_var"], Bf[f"{fe}.1.num_batches_tracked"],
+                                        stride=stride, pad=pad, training=training, groups=1 if shared else groups, act_slope=0.3,
+                                        repeats=groups if shared else 1)
+                wav.append((x, st, y.shape[1]))
+                x = y
+                continue
             wp = L.pack_conv_weight(P[f"{fe}.{idx}.weight"])
             last = idx == 9
             out = in_data[:, :, ca:ca + 32] if (last and not shared) else None
@@ -337,9 +346,19 @@ class GeneratorEngine(_Engine):
             L.conv_wgrad(dyw, x_rows, G[f"{fe}.{idx}.weight"], G[f"{fe}.{idx}.bias"], WAV_KW, stride=stride, pad=pad)
             if li == 0:
                 break
-            dxa = L.conv_dgrad(dyw, P[f"{fe}.{idx}.weight"], x_rows.shape[1], stride=stride)   # grad w.r.t. act(BN(c_prev))
             pidx = WAV_CONVS[li - 1][0] + 1
-            _, st_prev, _ = tp["wav"][li - 1]
+            x_prev, st_prev, _ = tp["wav"][li - 1]
+            if isinstance(st_prev, L.WavFrontState) and L.wav_front_bwd_fused_supported(P[f"{fe}.{idx}.weight"], stride):
+                # conv2's input gradient, BatchNorm1's backward and conv1's weight gradient in ONE reduction over d c2
+                L.wav_front_bwd_fused(dyw, P[f"{fe}.{idx}.weight"], st_prev, x_prev.view(x_prev.shape[0], -1), P[f"{fe}.0.weight"],
+                                      P[f"{fe}.0.bias"], P[f"{fe}.1.weight"], G[f"{fe}.0.weight"], G[f"{fe}.0.bias"], G[f"{fe}.1.weight"],
+                                      G[f"{fe}.1.bias"], g0=wgrp, row0=wrow0)
+                break
+            dxa = L.conv_dgrad(dyw, P[f"{fe}.{idx}.weight"], x_rows.shape[1], stride=stride)   # grad w.r.t. act(BN(c_prev))
+            if isinstance(st_prev, L.WavFrontState):        # fused front end: BatchNorm backward and conv1's weight gradient in one reduction
+                L.wav_front_bwd(dxa, st_prev, x_prev.view(x_prev.shape[0], -1), P[f"{fe}.0.weight"], P[f"{fe}.0.bias"], P[f"{fe}.1.weight"],
+                                G[f"{fe}.0.weight"], G[f"{fe}.0.bias"], G[f"{fe}.1.weight"], G[f"{fe}.1.bias"], g0=wgrp, row0=wrow0)
+                break
             dyw = L.bn_bwd(dxa, st_prev, P[f"{fe}.{pidx}.weight"], P[f"{fe}.{pidx}.bias"], G[f"{fe}.{pidx}.weight"],
                            G[f"{fe}.{pidx}.bias"], g0=wgrp, ng=1, row0=wrow0)
         ready(("audio_encoder",))

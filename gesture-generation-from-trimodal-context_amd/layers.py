@@ -59,7 +59,7 @@ class WeightPrep:
         self.by_key[key] = dst
         rows, wg0 = [], 0
         for s3, d, pm in g["jobs"]:
-            nwg = max(1, min(64, (s3.numel() + 2047) // 2048))
+            nwg = max(1, min(512, (s3.numel() + 2047) // 2048))      # ~2 LDS tiles (32 x 32) per workgroup: the 64-workgroup cap serialised 8+ tiles each
             rows.append([s3.data_ptr(), d.data_ptr(), *s3.shape, *pm, wg0, nwg])
             wg0 += nwg
         if g["desc"] is not None:
@@ -265,6 +265,66 @@ def bn_bwd(dy, st, gamma, beta, dgamma, dbeta, *, g0=0, ng=1, row0=0):
         ops.bn_backward(dy[sl].reshape(-1, Cc), x.reshape(-1, Cc), dx[sl].view(-1, Cc), st.mean[g0 + g], st.rstd[g0 + g],
                         gamma, beta, st.slope, ws, dgamma, dbeta)
     return dx
+
+
+# ----------------------------------------------------------------------------------------------- WavEncoder front end
+class WavFrontState:
+    """What the fused Conv1d(1,16,15) -> BatchNorm1d -> LeakyReLU block keeps for its backward pass: per-group statistics, the forward's
+    sums (fstat) and one gate bit per output element -- not the pre-BatchNorm tensor."""
+    __slots__ = ("mean", "rstd", "fstat", "gate", "groups", "slope", "stride", "pad", "T1", "words_per_clip")
+
+
+def wav_front_supported(w):
+    return ops.WAV_FUSED and tuple(w.shape) == (16, 1, 15)
+
+
+def wav_front_fwd(audio, w, b, gamma, beta, running_mean, running_var, nbt, *, stride, pad, training, groups=1, act_slope=0.3, repeats=1):
+    """audio: (B, L) view.  Returns (y (B, T1, 16), WavFrontState).  Train mode: batch statistics per group of B / groups clips."""
+    B, L = audio.shape
+    T1 = conv_out_len(L, 15, stride, pad)
+    g = groups if training else 1
+    assert B % g == 0
+    per = B // g
+    st = WavFrontState()
+    st.mean, st.rstd = empty(g, 16, like=audio), empty(g, 16, like=audio)
+    st.groups, st.slope, st.stride, st.pad, st.T1 = g, act_slope, stride, pad, T1
+    st.words_per_clip = 4 * ((T1 + 15) // 16)
+    st.fstat = st.gate = None
+    y = empty(B, T1, 16, like=audio)
+    if training:
+        st.fstat = torch.empty(g, 272, device=audio.device, dtype=torch.float64)
+        st.gate = torch.empty(B * st.words_per_clip, device=audio.device, dtype=torch.int64)
+        for q in range(g):
+            ops.wav_front_stats(audio[q * per:(q + 1) * per], w, b, stride, pad, st.mean[q], st.rstd[q], running_mean, running_var, nbt,
+                                st.fstat[q], repeats=repeats)
+    else:
+        ops.bn_eval_stats(running_mean, running_var, st.mean, st.rstd)
+    for q in range(g):
+        sl = slice(q * per, (q + 1) * per)
+        ops.wav_front_apply(audio[sl], w, b, stride, pad, st.mean[q], st.rstd[q], gamma, beta, act_slope, y[sl],
+                            st.gate[q * per * st.words_per_clip:(q + 1) * per * st.words_per_clip] if training else None)
+    return y, st
+
+
+def wav_front_bwd(dact, st, audio, w, b, gamma, dW, db, dgamma, dbeta, *, g0=0, row0=0):
+    """dact: (nb, T1, 16) gradient w.r.t. the block's output for ONE statistics group g0 whose clips start at batch index row0."""
+    nb = dact.shape[0]
+    wpc = st.words_per_clip
+    ops.wav_front_backward(dact.contiguous(), st.gate[row0 * wpc:(row0 + nb) * wpc], audio[row0:row0 + nb], w, b, st.stride, st.pad,
+                           st.mean[g0], st.rstd[g0], gamma, st.fstat[g0], st.slope, dW.view(-1) if dW is not None else None, db, dgamma, dbeta)
+
+
+def wav_front_bwd_fused_supported(w2, stride2):
+    return ops.WAV_FUSED_DGRAD and tuple(w2.shape) == (32, 16, 15) and stride2 == 6
+
+
+def wav_front_bwd_fused(dc2, w2, st, audio, w, b, gamma, dW, db, dgamma, dbeta, *, g0=0, row0=0):
+    """wav_front_bwd fed with the gradient w.r.t. the NEXT conv's output (dc2: (nb, T2, 32), w2: (32, 16, 15), stride 6): that conv's input
+    gradient is formed tile by tile inside the reduction."""
+    nb = dc2.shape[0]
+    wpc = st.words_per_clip
+    ops.wav_front_backward_fused(dc2.contiguous(), w2, st.gate[row0 * wpc:(row0 + nb) * wpc], audio[row0:row0 + nb], w, b, st.stride, st.pad,
+                                 st.mean[g0], st.rstd[g0], gamma, st.fstat[g0], st.slope, dW.view(-1) if dW is not None else None, db, dgamma, dbeta)
 
 
 # ----------------------------------------------------------------------------------------------- GRU stack

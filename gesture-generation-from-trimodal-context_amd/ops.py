@@ -374,6 +374,84 @@ def bn_backward(dy2d, x2d, dx2d, mean, rstd, gamma, beta, act_slope, ws, dgamma,
     return dx2d
 
 
+# ------------------------------------------------------------------------------------------------- WavEncoder front end
+# Conv1d(1, 16, 15) -> BatchNorm1d(16) -> LeakyReLU on raw audio without the pre-BatchNorm tensor (csrc/audio.hip); TG_WAV_FUSED=0 keeps
+# the generic window-GEMM + BatchNorm launches
+WAV_FUSED = os.environ.get("TG_WAV_FUSED", "1") != "0"
+WAV_FUSED_DGRAD = os.environ.get("TG_WAV_FUSED_DGRAD", "1") != "0"      # backward also forms conv2's input gradient inside the reduction
+_wav_ws = {}
+
+
+def _wav_scratch(dev):
+    """Per-device scratch of the front-end reductions (partials of one launch, consumed by the finalize launch right behind it)."""
+    ws = _wav_ws.get(dev)
+    if ws is None:
+        ws = torch.empty(_lib.load().tg_wav_front_ws_doubles(), dtype=torch.float64, device=dev)
+        _wav_ws[dev] = ws
+    return ws
+
+
+def _wav_geom(audio, w, bias, stride, pad):
+    _f32(audio, "audio"); _flat(w, "w"); _flat(bias, "bias")
+    assert audio.dim() == 2 and audio.stride(1) == 1, (audio.shape, audio.stride())
+    B, L = audio.shape
+    assert tuple(w.shape) == (16, 1, 15) and bias.numel() == 16, w.shape
+    if (B - 1) * audio.stride(0) + L - 1 >= _room(audio):
+        raise ValueError("wav_front: audio exceeds its tensor")
+    T1 = (L + 2 * pad - 15) // stride + 1
+    return B, L, T1
+
+
+def wav_front_stats(audio, w, bias, stride, pad, mean, rstd, running_mean, running_var, nbt, fstat, eps=1e-5, momentum=0.1, repeats=1):
+    B, L, T1 = _wav_geom(audio, w, bias, stride, pad)
+    ws = _wav_scratch(audio.device)
+    assert mean.numel() == 16 == rstd.numel() and fstat.dtype == torch.float64 and fstat.numel() >= _lib.load().tg_wav_front_fstat_doubles()
+    assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda)
+    call("tg_wav_front_stats", _p(audio), audio.stride(0), B, L, _p(w), _p(bias), int(stride), int(pad), T1, _p(ws), ws.numel(),
+         _p(_flat(mean, "mean")), _p(_flat(rstd, "rstd")), _p(running_mean), _p(running_var), _p(nbt), _p(fstat), float(eps), float(momentum),
+         int(repeats), _stream())
+
+
+def wav_front_apply(audio, w, bias, stride, pad, mean, rstd, gamma, beta, act_slope, y, gate=None):
+    B, L, T1 = _wav_geom(audio, w, bias, stride, pad)
+    _flat(y, "y"); assert tuple(y.shape) == (B, T1, 16), (y.shape, B, T1)
+    assert mean.numel() == 16 == rstd.numel() == gamma.numel() == beta.numel()
+    if gate is not None:
+        assert gate.dtype == torch.int64 and gate.is_cuda and gate.is_contiguous() and gate.numel() >= _lib.load().tg_wav_front_gate_words(B, T1)
+    call("tg_wav_front_apply", _p(audio), audio.stride(0), B, L, _p(w), _p(bias), int(stride), int(pad), T1, _p(_flat(mean, "mean")),
+         _p(_flat(rstd, "rstd")), _p(_flat(gamma, "gamma")), _p(_flat(beta, "beta")), float(act_slope), _p(y), _p(gate), _stream())
+    return y
+
+
+def wav_front_backward(dact, gate, audio, w, bias, stride, pad, mean, rstd, gamma, fstat, act_slope, dW, dbias, dgamma, dbeta):
+    B, L, T1 = _wav_geom(audio, w, bias, stride, pad)
+    _flat(dact, "dact"); assert tuple(dact.shape) == (B, T1, 16), (dact.shape, B, T1)
+    assert gate.dtype == torch.int64 and gate.is_cuda and gate.is_contiguous() and gate.numel() >= _lib.load().tg_wav_front_gate_words(B, T1)
+    assert fstat.dtype == torch.float64 and fstat.is_cuda and fstat.numel() >= _lib.load().tg_wav_front_fstat_doubles()
+    for t, n in ((dW, 240), (dbias, 16), (dgamma, 16), (dbeta, 16)):
+        assert t is None or (_flat(t, "grad").numel() == n)
+    ws = _wav_scratch(audio.device)
+    call("tg_wav_front_backward", _p(dact), _p(gate), _p(audio), audio.stride(0), B, L, _p(w), _p(bias), int(stride), int(pad), T1,
+         _p(_flat(mean, "mean")), _p(_flat(rstd, "rstd")), _p(_flat(gamma, "gamma")), _p(fstat), float(act_slope), _p(ws), ws.numel(),
+         _p(dW), _p(dbias), _p(dgamma), _p(dbeta), _stream())
+
+
+def wav_front_backward_fused(dc2, w2, gate, audio, w, bias, stride, pad, mean, rstd, gamma, fstat, act_slope, dW, dbias, dgamma, dbeta):
+    """wav_front_backward with d act = conv_dgrad(dc2, w2) (Conv1d(16, 32, 15, stride 6)) formed inside the kernel."""
+    B, L, T1 = _wav_geom(audio, w, bias, stride, pad)
+    _flat(dc2, "dc2"); _flat(w2, "w2")
+    T2 = (T1 - 15) // 6 + 1
+    assert tuple(dc2.shape) == (B, T2, 32) and tuple(w2.shape) == (32, 16, 15), (dc2.shape, w2.shape, B, T2)
+    assert gate.dtype == torch.int64 and gate.is_cuda and gate.is_contiguous() and gate.numel() >= _lib.load().tg_wav_front_gate_words(B, T1)
+    assert fstat.dtype == torch.float64 and fstat.is_cuda and fstat.numel() >= _lib.load().tg_wav_front_fstat_doubles()
+    for t, n in ((dW, 240), (dbias, 16), (dgamma, 16), (dbeta, 16)):
+        assert t is None or (_flat(t, "grad").numel() == n)
+    ws = _wav_scratch(audio.device)
+    call("tg_wav_front_backward_fused", _p(dc2), T2, _p(w2), _p(gate), _p(audio), audio.stride(0), B, L, _p(w), _p(bias), int(stride), int(pad), T1,
+         _p(_flat(mean, "mean")), _p(_flat(rstd, "rstd")), _p(_flat(gamma, "gamma")), _p(fstat), float(act_slope), _p(ws), ws.numel(),
+         _p(dW), _p(dbias), _p(dgamma), _p(dbeta), _stream())
+
+
 # ------------------------------------------------------------------------------------------------- element-wise
 def _same(*ts):
     n = ts[0].numel()

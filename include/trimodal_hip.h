@@ -216,6 +216,40 @@ int tg_bn_backward(const float* dy, const float* x, float* dx, int32_t rows, int
                    const float* rstd, const float* gamma, const float* beta, float act_slope, double* ws,
                    float* dgamma, float* dbeta, void* stream);
 
+/* ---- WavEncoder front end: Conv1d(1, 16, 15, stride, padding) -> BatchNorm1d(16) -> LeakyReLU, fused ------------------------
+ * Replaces feat_extractor[0..2] of model/multimodal_context_net.py:13-15 (and their autograd backward) without materialising the
+ * pre-BatchNorm tensor: the convolution is recomputed from the raw audio wherever it is needed (csrc/audio.hip).
+ * audio: B clips of L samples, `audio_stride` floats apart; w [16][15], bias [16]; T1 = (L + 2 pad - 15) / stride + 1 output frames.
+ * ws: scratch of tg_wav_front_ws_doubles() doubles (no initialisation needed); fstat: tg_wav_front_fstat_doubles() doubles written by
+ * _stats and read by _backward (sums of the forward pass); gate: tg_wav_front_gate_words(B, T1) 64-bit words written by _apply
+ * (one bit per output element: pre-activation >= 0) and read by _backward. */
+int64_t tg_wav_front_ws_doubles(void);
+int64_t tg_wav_front_fstat_doubles(void);
+int64_t tg_wav_front_gate_words(int32_t B, int32_t T1);
+/* train-mode batch statistics of the conv output over all B * T1 frames: mean / rstd [16], running statistics updated `repeats` times
+ * (momentum form of nn.BatchNorm1d), num_batches_tracked += repeats.  running_* / num_batches_tracked / fstat may be NULL. */
+int tg_wav_front_stats(const float* audio, int64_t audio_stride, int32_t B, int32_t L, const float* w, const float* bias, int32_t stride,
+                       int32_t pad, int32_t T1, double* ws, int64_t ws_doubles, float* mean, float* rstd, float* running_mean,
+                       float* running_var, int64_t* num_batches_tracked, double* fstat, float eps, float momentum, int32_t repeats,
+                       void* stream);
+/* y [B][T1][16] = act((conv - mean) * rstd * gamma + beta) (mean / rstd from _stats, or tg_bn_eval_stats in eval mode); gate may be NULL. */
+int tg_wav_front_apply(const float* audio, int64_t audio_stride, int32_t B, int32_t L, const float* w, const float* bias, int32_t stride,
+                       int32_t pad, int32_t T1, const float* mean, const float* rstd, const float* gamma, const float* beta, float act_slope,
+                       float* y, uint64_t* gate, void* stream);
+/* backward of the block for d y = dact [B][T1][16]: dW [16][15], dbias, dgamma, dbeta accumulate (each may be NULL); the input is raw
+ * audio, so no input gradient. */
+int tg_wav_front_backward(const float* dact, const uint64_t* gate, const float* audio, int64_t audio_stride, int32_t B, int32_t L, const float* w,
+                          const float* bias, int32_t stride, int32_t pad, int32_t T1, const float* mean, const float* rstd, const float* gamma,
+                          const double* fstat, float act_slope, double* ws, int64_t ws_doubles, float* dW, float* dbias, float* dgamma,
+                          float* dbeta, void* stream);
+
+/* The same backward with the input gradient of the NEXT layer, Conv1d(16, 32, 15, stride 6) (feat_extractor[3], weight w2 [32][16][15]),
+ * computed on the fly from dc2 [B][T2][32] = the gradient w.r.t. that conv's output: d act is never materialised. */
+int tg_wav_front_backward_fused(const float* dc2, int32_t T2, const float* w2, const uint64_t* gate, const float* audio, int64_t audio_stride,
+                                int32_t B, int32_t L, const float* w, const float* bias, int32_t stride, int32_t pad, int32_t T1,
+                                const float* mean, const float* rstd, const float* gamma, const double* fstat, float act_slope, double* ws,
+                                int64_t ws_doubles, float* dW, float* dbias, float* dgamma, float* dbeta, void* stream);
+
 /* ---- element-wise / data movement ------------------------------------------------------------------- */
 /* y = max(a + b, 0)  (model/tcn.py:46);  dx = dy * (y > 0). */
 int tg_add_relu(const float* a, const float* b, float* y, int64_t n, void* stream);

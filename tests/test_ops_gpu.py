@@ -208,7 +208,9 @@ def test_gru_cluster_flag_generations_across_sequence_lengths(pkg, dev):
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm
-@pytest.mark.parametrize("rows,C,groups,slope", [(3 * 500, 16, 3, 0.3), (64, 256, 1, 1.0), (2 * 96, 8, 2, 1.0)])
+@pytest.mark.parametrize("rows,C,groups,slope", [(3 * 500, 16, 3, 0.3), (64, 256, 1, 1.0), (2 * 96, 8, 2, 1.0),
+                                                  (2 * 20001, 32, 2, 0.3),       # streaming kernels, 16-byte path
+                                                  (50001, 12, 1, 0.3)])          # streaming kernels, scalar path (12 does not divide 1024)
 def test_batchnorm_train_eval_backward(pkg, dev, rows, C, groups, slope):
     Lm = pkg.layers
     x = (rnd(rows, C, seed=19) * 2 + 0.5)
@@ -606,3 +608,65 @@ def test_gemm_tn_split_with_conv_window(pkg, dev):
     ops.gemm_tn(gh, hwin, dwh)
     hprev = torch.cat([torch.zeros(B, 1, H, device=dev), yl[:, :-1, :H]], dim=1).reshape(B * T, H)
     assert rel(dwh, gh.double().cpu().t() @ hprev.double().cpu()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ WavEncoder front end
+@pytest.mark.parametrize("B,L,stride,pad,groups", [(3, 333, 5, 40, 1), (4, 1207, 5, 160, 2), (2, 36267, 5, 1600, 1)])
+def test_wav_front_conv_bn_lrelu_fused(pkg, dev, B, L, stride, pad, groups):
+    """Conv1d(1,16,15,stride,pad) -> BatchNorm1d(16) -> LeakyReLU(0.3) (multimodal_context_net.py:13-15) recomputed from the raw audio
+    (csrc/audio.hip) against torch fp64 autograd: output, running statistics, and every gradient of the block; frame counts that are
+    not a multiple of the 16-frame tile, statistics groups, eval mode."""
+    Lm = pkg.layers
+    audio = rnd(B, L, seed=31)
+    audio[:, : L // 7] *= 0.05                     # a quiet stretch: uneven statistics along time
+    w, b = rnd(16, 1, 15, seed=32, scale=0.3), rnd(16, seed=33, scale=0.2)
+    ga, be = 1.0 + rnd(16, seed=34, scale=0.2), rnd(16, seed=35, scale=0.3)
+    rm0, rv0 = rnd(16, seed=36, scale=0.1), 1.0 + rnd(16, seed=37, scale=0.1).abs()
+    per = B // groups
+    # reference, one statistics group after the other (stacked forward calls of the same module)
+    P = [t.double().requires_grad_(True) for t in (w, b, ga, be)]
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    ys = []
+    for g in range(groups):
+        c = F.conv1d(audio[g * per:(g + 1) * per].double().unsqueeze(1), P[0], P[1], stride=stride, padding=pad)
+        ys.append(F.leaky_relu(F.batch_norm(c, rm, rv, P[2], P[3], training=True, momentum=0.1, eps=1e-5), 0.3))
+    y_ref = torch.cat(ys, 0)                                            # (B, 16, T1)
+    T1 = y_ref.shape[2]
+    dy = rnd(B, 16, T1, seed=38)
+    d = lambda t: t.to(dev).contiguous()
+    rm_d, rv_d, nbt = d(rm0), d(rv0), torch.zeros((), dtype=torch.int64, device=dev)
+    wd, bd, gad, bed = d(w), d(b), d(ga), d(be)
+    y, st = Lm.wav_front_fwd(d(audio), wd, bd, gad, bed, rm_d, rv_d, nbt, stride=stride, pad=pad, training=True, groups=groups)
+    assert tuple(y.shape) == (B, T1, 16) and int(nbt) == groups
+    assert rel(y, cl(y_ref)) < 1e-5
+    assert rel(rm_d, rm) < 1e-5 and rel(rv_d, rv) < 1e-5
+    # backward, group by group (the engine differentiates one group of a stacked forward)
+    for g in range(groups):
+        grads = torch.autograd.grad(ys[g], P, dy[g * per:(g + 1) * per].double(), retain_graph=True)
+        dW, db, dga, dbe = (torch.zeros(16, 1, 15, device=dev), torch.zeros(16, device=dev), torch.zeros(16, device=dev), torch.zeros(16, device=dev))
+        Lm.wav_front_bwd(d(cl(dy[g * per:(g + 1) * per])), st, d(audio), wd, bd, gad, dW, db, dga, dbe, g0=g, row0=g * per)
+        assert rel(dW, grads[0]) < 1e-4 and rel(dga, grads[2]) < 1e-4 and rel(dbe, grads[3]) < 1e-4, (rel(dW, grads[0]), rel(dga, grads[2]), rel(dbe, grads[3]))
+        assert float(db.abs().max()) < 1e-4 * float(grads[0].abs().max())          # zero by construction (bias in front of a train-mode BatchNorm)
+        Lm.wav_front_bwd(d(cl(dy[g * per:(g + 1) * per])), st, d(audio), wd, bd, gad, dW, None, None, dbe, g0=g, row0=g * per)   # accumulates; NULL outputs
+        assert rel(dW, 2 * grads[0]) < 1e-4 and rel(dbe, 2 * grads[3]) < 1e-4
+    # second form: conv2's input gradient formed inside the reduction (feat_extractor[3] = Conv1d(16, 32, 15, stride 6))
+    if T1 >= 15:
+        w2 = rnd(32, 16, 15, seed=39, scale=0.1)
+        for g in range(groups):
+            c2 = F.conv1d(ys[g], w2.double(), None, stride=6)
+            dc2 = rnd(per, 32, c2.shape[2], seed=40 + g)
+            grads = torch.autograd.grad(c2, P, dc2.double(), retain_graph=True)
+            dW, db, dga, dbe = (torch.zeros(16, 1, 15, device=dev), torch.zeros(16, device=dev), torch.zeros(16, device=dev), torch.zeros(16, device=dev))
+            Lm.wav_front_bwd_fused(d(cl(dc2)), d(w2), st, d(audio), wd, bd, gad, dW, db, dga, dbe, g0=g, row0=g * per)
+            errs = (rel(dW, grads[0]), rel(dga, grads[2]), rel(dbe, grads[3]))
+            assert max(errs) < 1e-4, errs
+            assert float(db.abs().max()) < 1e-4 * float(grads[0].abs().max())
+    # the generic launches (window GEMM + BatchNorm kernels) agree with the fused block to rounding
+    c2 = Lm.conv_fwd(d(audio)[:per].unsqueeze(2), wd.view(16, 15), bd, 15, stride=stride, pad=pad)
+    y2, _ = Lm.bn_fwd(c2, gad, bed, d(rm0), d(rv0), torch.zeros((), dtype=torch.int64, device=dev), training=True, act_slope=0.3)
+    assert rel(y2, y[:per]) < 1e-5
+    # eval mode: running statistics, no tape
+    ye, ste = Lm.wav_front_fwd(d(audio), wd, bd, gad, bed, rm_d, rv_d, nbt, stride=stride, pad=pad, training=False, groups=groups)
+    ce = F.conv1d(audio.double().unsqueeze(1), P[0], P[1], stride=stride, padding=pad)
+    ye_ref = F.leaky_relu(F.batch_norm(ce, rm_d.double().cpu(), rv_d.double().cpu(), P[2], P[3], training=False, eps=1e-5), 0.3)
+    assert rel(ye, cl(ye_ref)) < 1e-5 and ste.gate is None and int(nbt) == groups
