@@ -21,6 +21,7 @@
 namespace tg {
 
 constexpr int WV_CO = 16, WV_KW = 15;
+constexpr unsigned WV_RSRC3 = 0x00020000u;      // buffer descriptor word 3: raw buffer, 32-bit data format, bounds check on the byte offset
 constexpr int WV_XA = 256;                 // fstat layout: [X^T A | sum X] 16 x 16, then sum A [16]
 constexpr int WV_FSTAT = WV_XA + 16;
 constexpr int WV_PART = WV_FSTAT + 32;     // per-workgroup partial of the statistics pass: fstat + sum x [16] + sum x^2 [16]
@@ -51,33 +52,57 @@ __device__ __forceinline__ void wav_weight_frag(const float* __restrict__ w, con
     }
 }
 
-// conv output of tile (clip b, frames 16 tt ...): register i = frame 16 tt + 4 i + (lane >> 4), channel lane & 15
-__device__ __forceinline__ f32x4 wav_conv_tile(const WavGeom& g, const float* clip, int tt, const float (&wf)[4]) {
+// A tile is INTERIOR when its 16 frames exist and every sample of their windows lies inside the clip (no padding): true for ~92 % of the
+// tiles (padding 1600 of 36267 samples per side).  Interior tiles take the FAST loaders: one lane-constant offset plus immediates instead of
+// ~15 VALU instructions of clamping and predicates per load -- the kernels were bound by exactly that address arithmetic (wav_stats: 39 us,
+// of which 7 us matrix work).  `interior` is wave-uniform.
+__device__ __forceinline__ bool wav_interior(const WavGeom& g, int t_first, int t_last) {
+    return t_last < g.T1 && g.stride * t_first - g.pad >= 0 && g.stride * t_last - g.pad + WV_KW - 1 < g.L;
+}
+
+// window operand of the forward product for tile (clip, frames 16 tt ...): lane (m, k) holds taps 4 j + k of frame 4 (m & 3) + (m >> 2)
+template <bool FAST>
+__device__ __forceinline__ void wav_conv_load(const WavGeom& g, const float* clip, int tt, float (&a)[4]) {
     const int l = threadIdx.x & 63;
     const int m = l & 15, k = l >> 4;
     const int t = 16 * tt + 4 * (m & 3) + (m >> 2);
     const int base = g.stride * t - g.pad + k;
-    float a[4];
+    if constexpr (FAST) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int tap = 4 * j + k;
-        a[j] = wav_sample(clip, base + 4 * j, g.L, tap < WV_KW);
-        if (tap == WV_KW) a[j] = 1.f;
+        for (int j = 0; j < 4; ++j) a[j] = clip[base + 4 * j];        // tap 15 of the last frame may read one sample past the window: still inside the clip or its successor
+        a[3] = k == 3 ? 1.f : a[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tap = 4 * j + k;
+            a[j] = wav_sample(clip, base + 4 * j, g.L, tap < WV_KW);
+            if (tap == WV_KW) a[j] = 1.f;
+        }
     }
+}
+// conv output of the tile: register i = frame 16 tt + 4 i + (lane >> 4), channel lane & 15
+__device__ __forceinline__ f32x4 wav_conv_mma(const float (&a)[4], const float (&wf)[4]) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], wf[j], acc, 0, 0, 0);
     return acc;
 }
 
-// window operand of the reductions over frames (X^T A, G^T A): lane (n = tap, k) holds sample tap n of frame 16 tt + 4 i + k; tap 15 is 1
+// window operand of the reductions over frames (X^T A, G^T A): lane (n = tap, k) holds sample tap n of frame t = t0 + k; tap 15 is 1
+template <bool FAST>
+__device__ __forceinline__ float wav_window_at(const WavGeom& g, const float* clip, int t) {
+    const int n = threadIdx.x & 15;
+    if constexpr (FAST) {
+        const float v = clip[g.stride * t - g.pad + n];
+        return n == WV_KW ? 1.f : v;
+    } else {
+        const bool row_ok = t < g.T1;
+        const float v = wav_sample(clip, g.stride * t - g.pad + n, g.L, row_ok && n < WV_KW);
+        return (n == WV_KW && row_ok) ? 1.f : v;
+    }
+}
 __device__ __forceinline__ float wav_window_frag(const WavGeom& g, const float* clip, int tt, int i) {
-    const int l = threadIdx.x & 63;
-    const int n = l & 15, k = l >> 4;
-    const int t = 16 * tt + 4 * i + k;
-    const bool row_ok = t < g.T1;
-    const float v = wav_sample(clip, g.stride * t - g.pad + n, g.L, row_ok && n < WV_KW);
-    return (n == WV_KW && row_ok) ? 1.f : v;
+    return wav_window_at<false>(g, clip, 16 * tt + 4 * i + (int)((threadIdx.x & 63) >> 4));
 }
 
 // ---- forward pass 1: statistics ----------------------------------------------------------------------------------------------
@@ -93,21 +118,47 @@ __global__ __launch_bounds__(WV_STATS_THREADS) void wav_stats_kernel(WavGeom g, 
     f32x4 xa = {0.f, 0.f, 0.f, 0.f};
     double sx = 0.0, sxx = 0.0, sa = 0.0;
     const int tiles = g.B * g.TT;
-    for (int tile = blockIdx.x * nwaves + wave; tile < tiles; tile += gridDim.x * nwaves) {
-        const int b = tile / g.TT, tt = tile - b * g.TT;
+    const int tstep = gridDim.x * nwaves;
+    // software pipeline: the next tile's eight sample requests are in flight while this tile's eight MFMAs run (a wave walks ~15 tiles; without
+    // it every tile cost a full memory round trip: 42 us for 3 us of matrix work)
+    float a_cur[4], af_cur[4], a_nxt[4], af_nxt[4];
+    int tile = blockIdx.x * nwaves + wave;
+    auto load_tile = [&](int tl, float (&a)[4], float (&af)[4]) {
+        const int tc = tl < tiles ? tl : tiles - 1;
+        const int b = tc / g.TT, tt = tc - b * g.TT;
         const float* clip = g.audio + (long)b * g.a_stride;
-        const f32x4 x = wav_conv_tile(g, clip, tt, wf);
+        if (wav_interior(g, 16 * tt, 16 * tt + 15) && (b + 1 < g.B || g.stride * (16 * tt + 15) - g.pad + WV_KW < g.L)) {
+            wav_conv_load<true>(g, clip, tt, a);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = wav_window_at<true>(g, clip, 16 * tt + 4 * i + (l >> 4));
+        } else {
+            wav_conv_load<false>(g, clip, tt, a);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = wav_window_at<false>(g, clip, 16 * tt + 4 * i + (l >> 4));
+        }
+    };
+    load_tile(tile, a_cur, af_cur);
+    for (; tile < tiles; tile += tstep) {
+        load_tile(tile + tstep, a_nxt, af_nxt);
+        const int b = tile / g.TT, tt = tile - b * g.TT;
+        const f32x4 x = wav_conv_mma(a_cur, wf);
+        // per-tile partial sums of four values in fp32, accumulated over the wave's tiles in fp64 (three fp64 operations per tile instead of twelve)
+        float s4 = 0.f, q4 = 0.f, a4 = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = 16 * tt + 4 * i + (l >> 4) < g.T1;
             float xv = x[i];
             xv = ok ? xv : 0.f;
-            sx += xv;
-            sxx += (double)xv * xv;
-            const float af = wav_window_frag(g, clip, tt, i);
-            sa += af;
-            xa = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, af, xa, 0, 0, 0);
+            s4 += xv;
+            q4 = __builtin_fmaf(xv, xv, q4);
+            a4 += ok ? af_cur[i] : 0.f;
+            xa = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, af_cur[i], xa, 0, 0, 0);
         }
+        sx += (double)s4;
+        sxx += (double)q4;
+        sa += (double)a4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a_cur[i] = a_nxt[i]; af_cur[i] = af_nxt[i]; }
     }
     // lanes l, l ^ 16, l ^ 32 hold the same channel (sx, sxx) / the same tap (sa): fixed-order butterfly
     sx += __shfl_xor(sx, 16); sx += __shfl_xor(sx, 32);
@@ -185,21 +236,41 @@ __global__ __launch_bounds__(256) void wav_apply_kernel(WavGeom g, const float* 
     wav_weight_frag(w, bias, wf);
     const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
     const int tiles = g.B * g.TT;
-    for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
-        const int b = tile / g.TT, tt = tile - b * g.TT;
+    const int tstep = gridDim.x * 4;
+    __amdgpu_buffer_rsrc_t gate_rsrc = __builtin_amdgcn_make_buffer_rsrc(gate ? (void*)gate : (void*)y, 0, gate ? tiles * 32 : 0, WV_RSRC3);
+    float a_cur[4], a_nxt[4];
+    int tile = blockIdx.x * 4 + wave;
+    auto load_tile = [&](int tl, float (&a)[4]) {
+        const int tc = tl < tiles ? tl : tiles - 1;
+        const int b = tc / g.TT, tt = tc - b * g.TT;
         const float* clip = g.audio + (long)b * g.a_stride;
-        const f32x4 x = wav_conv_tile(g, clip, tt, wf);
-        float* yt = y + ((long)b * g.T1 + 16 * tt) * WV_CO;
+        if (wav_interior(g, 16 * tt, 16 * tt + 15) && (b + 1 < g.B || g.stride * (16 * tt + 15) - g.pad + WV_KW < g.L)) wav_conv_load<true>(g, clip, tt, a);
+        else wav_conv_load<false>(g, clip, tt, a);
+    };
+    load_tile(tile, a_cur);
+    for (; tile < tiles; tile += tstep) {
+        load_tile(tile + tstep, a_nxt);                        // next tile's samples in flight behind this tile's stores
+        const int b = tile / g.TT, tt = tile - b * g.TT;
+        const f32x4 x = wav_conv_mma(a_cur, wf);
+        // stores through buffer descriptors whose range ends with the clip (frames past T1 of the last tile) / is empty (no gate wanted):
+        // the hardware drops out-of-range lanes, so no lane-predicated store makes the vector-memory count dynamic (the compiler would then
+        // drain everything before the prefetched samples are used)
+        __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(y + (long)b * g.T1 * WV_CO, 0, g.T1 * WV_CO * 4, WV_RSRC3);
+        unsigned long long mine = 0ull;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = 16 * tt + 4 * i + (l >> 4) < g.T1;
             const float xh = (x[i] - mu) * rs;                 // association of bn_apply_kernel
             const float z = xh * ga + be;
             const bool pos = z >= 0.f;
-            if (ok) yt[64 * i + l] = pos ? z : z * slope;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pos ? z : z * slope), y_rsrc, (unsigned)((16 * tt * WV_CO + 64 * i + l) * 4), 0, 0);
             const unsigned long long word = __ballot(ok && pos);
-            if (gate && l == 0) gate[(long)tile * 4 + i] = word;
+            mine = l == i ? word : mine;
         }
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{(unsigned)mine, (unsigned)(mine >> 32)}, gate_rsrc, l < 4 ? (unsigned)(l * 8) : 0x80000000u, tile * 32, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
     }
 }
 
@@ -270,39 +341,90 @@ __device__ __forceinline__ void wav_bwd_fused_phase(const WavGeom& g, const floa
     const int tiles = g.B * QB;
     const int wpc = 4 * g.TT;
     const int fr_a = 4 * (n & 3) + (n >> 2);             // frame of MFMA row n (= l & 15) in the first product
-    for (int tile = wave_in_phase; tile < tiles; tile += waves_in_phase) {
-        const int b = tile / QB, qb = tile - b * QB;
+    // software pipeline over the wave's ~15 tiles: the next tile's 14 requests (6 x 16-byte operand rows, 4 gate words, 4 samples) are in
+    // flight while this tile's 28 MFMAs run
+    struct Tile {
+        f32x4 a[NJ][2];
+        unsigned long long word[4];
+        float af[4];
+        bool fast;          // wave-uniform: interior tile
+    };
+    auto load_tile = [&](int tl, Tile& T_) {
+        const int tc = tl < tiles ? tl : tiles - 1;
+        const int b = tc / QB, qb = tc - b * QB;
         const float* clip = g.audio + (long)b * g.a_stride;
         const float* dcb = dc2 + (long)b * T2 * WV_C2 + 4 * kq;
-        f32x4 a[NJ][2];
+        const unsigned long long* gb = gate + (long)b * wpc;
+        const int t_first = WV_S2 * 16 * qb + p, t_last = t_first + WV_S2 * 15;
+        if (16 * qb - (NJ - 1) >= 0 && 16 * qb + 15 < T2 && wav_interior(g, t_first, t_last) &&
+            (b + 1 < g.B || g.stride * t_last - g.pad + WV_KW < g.L)) {      // interior tile (wave-uniform): no clamps, no predicates (lane n = 15 reads one sample past the window)
+            const float* d0 = dcb + (16 * qb + fr_a) * WV_C2;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) T_.a[j][u] = *reinterpret_cast<const f32x4*>(d0 - j * WV_C2 + 16 * u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = WV_S2 * (16 * qb + 4 * i + kq) + p;
+                T_.word[i] = gb[t >> 2];
+                const float sv = clip[g.stride * t - g.pad + n];
+                T_.af[i] = n == WV_KW ? 1.f : sv;
+            }
+            T_.fast = true;
+            return;
+        }
+        T_.fast = false;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int row = 16 * qb + fr_a - j;
             const int rc = row < 0 ? 0 : (row >= T2 ? T2 - 1 : row);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) a[j][u] = *reinterpret_cast<const f32x4*>(dcb + (long)rc * WV_C2 + 16 * u);
+            for (int u = 0; u < 2; ++u) T_.a[j][u] = *reinterpret_cast<const f32x4*>(dcb + (long)rc * WV_C2 + 16 * u);
         }
-        // gate words and window samples of the tile's frames (register i: frame 16 qb + 4 i + kq of phase p)
-        unsigned long long word[4];
-        float af[4];
-        bool ok[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {                  // register i: frame 16 qb + 4 i + kq of phase p
             const int t = WV_S2 * (16 * qb + 4 * i + kq) + p;
-            ok[i] = t < g.T1;
-            const int tc = ok[i] ? t : g.T1 - 1;
-            word[i] = gate[(long)b * wpc + (tc >> 2)] >> (16 * (tc & 3) + n);
-            const float sv = wav_sample(clip, g.stride * tc - g.pad + n, g.L, ok[i] && n < WV_KW);
-            af[i] = (n == WV_KW && ok[i]) ? 1.f : sv;
+            const bool ok = t < g.T1;
+            const int tc1 = ok ? t : g.T1 - 1;
+            T_.word[i] = gb[tc1 >> 2];
+            const float sv = wav_sample(clip, g.stride * tc1 - g.pad + n, g.L, ok && n < WV_KW);
+            T_.af[i] = (n == WV_KW && ok) ? 1.f : sv;
         }
+    };
+    Tile cur, nxt;
+    int tile = wave_in_phase;
+    load_tile(tile, cur);
+    for (; tile < tiles; tile += waves_in_phase) {
+        load_tile(tile + waves_in_phase, nxt);
+        const int b = tile / QB, qb = tile - b * QB;
         f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        if (cur.fast) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 av = cur.a[j][u];
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], wf[j][u][0], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], wf[j][u][1], d1, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], wf[j][u][2], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], wf[j][u][3], d1, 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sh = 16 * ((WV_S2 * (4 * i + kq) + p + WV_S2 * 16 * qb) & 3) + n;
+                const bool pos = (cur.word[i] >> sh) & 1ull;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32((d0[i] + d1[i]) * (pos ? 1.f : slope), cur.af[i], acc, 0, 0, 0);
+            }
+            cur = nxt;
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int row = 16 * qb + fr_a - j;
             const bool rok = row >= 0 && row < T2;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                f32x4 av = a[j][u];
+                f32x4 av = cur.a[j][u];
                 av = rok ? av : f32x4{0.f, 0.f, 0.f, 0.f};
                 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], wf[j][u][0], d0, 0, 0, 0);      // two accumulators: the dependent-accumulator
                 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], wf[j][u][1], d1, 0, 0, 0);      // latency exceeds the issue interval
@@ -312,10 +434,15 @@ __device__ __forceinline__ void wav_bwd_fused_phase(const WavGeom& g, const floa
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float v = (d0[i] + d1[i]) * ((word[i] & 1ull) ? 1.f : slope);
-            v = ok[i] ? v : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, af[i], acc, 0, 0, 0);
+            const int t = WV_S2 * (16 * qb + 4 * i + kq) + p;
+            const bool ok = t < g.T1;
+            const int tc1 = ok ? t : g.T1 - 1;
+            const bool pos = (cur.word[i] >> (16 * (tc1 & 3) + n)) & 1ull;
+            float v = (d0[i] + d1[i]) * (pos ? 1.f : slope);
+            v = ok ? v : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, cur.af[i], acc, 0, 0, 0);
         }
+        cur = nxt;
     }
 }
 
@@ -394,7 +521,7 @@ static int wav_geom(WavGeom& g, const char* who, const float* audio, int64_t aud
     TG_REQUIRE(audio && B > 0 && L > 0 && stride > 0 && pad >= 0 && T1 > 0 && audio_stride >= L, "%s: bad audio geometry (B=%d L=%d stride=%d pad=%d T1=%d)", who, B, L,
                stride, pad, T1);
     TG_REQUIRE((long)T1 == ((long)L + 2L * pad - WV_KW) / stride + 1 && (long)L + 2L * pad >= WV_KW, "%s: T1=%d is not the conv length of L=%d", who, T1, L);
-    TG_REQUIRE((long)B * ((T1 + 15) / 16) < (1L << 30) && (long)stride * T1 + WV_KW < (1L << 30), "%s: problem too large for 32-bit tile indices", who);
+    TG_REQUIRE((long)B * ((T1 + 15) / 16) < (1L << 25) && (long)stride * T1 + WV_KW < (1L << 24), "%s: problem too large for 32-bit tile / byte offsets", who);
     g.audio = audio; g.a_stride = audio_stride; g.B = B; g.L = L; g.T1 = T1; g.TT = (T1 + 15) / 16; g.stride = stride; g.pad = pad;
     return 0;
 }

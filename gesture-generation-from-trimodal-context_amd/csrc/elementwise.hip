@@ -173,9 +173,16 @@ __global__ void permute3_kernel(const float* __restrict__ in, float* __restrict_
 // workgroup count; a workgroup finds its job by scanning the (short) table, then grid-strides inside the job.
 __global__ __launch_bounds__(256) void permute3_batch_kernel(const long* __restrict__ desc, int n_jobs) {
     __shared__ float tile[32][33];
-    int job = 0;
-    for (int j = 1; j < n_jobs; ++j)
-        if ((long)blockIdx.x >= desc[10 * j + 8]) job = j;
+    // job = the last table entry whose first workgroup is <= blockIdx.x.  Every wave counts them with one ballot per 64 entries (lane j
+    // loads entry j's first workgroup: independent loads) -- the serial scan this replaces walked the table one dependent global load at a
+    // time, ~0.5 us per entry: 20-28 us for the 30-40 jobs of a network, more than the transposes themselves.
+    int job = -1;
+    for (int j0 = 0; j0 < n_jobs; j0 += 64) {
+        const int j = j0 + (int)(threadIdx.x & 63);
+        const bool mine = j < n_jobs && (long)blockIdx.x >= desc[10 * (j < n_jobs ? j : 0) + 8];
+        job += __popcll(__ballot(mine));
+    }
+    if (job < 0) job = 0;
     const long* e = desc + 10 * job;
     const float* in = reinterpret_cast<const float*>(e[0]);
     float* out = reinterpret_cast<float*>(e[1]);
@@ -208,6 +215,21 @@ __global__ __launch_bounds__(256) void permute3_batch_kernel(const long* __restr
                 if (i1 < d[1] && i2 < d[2]) dst[(long)i2 * d[1] + i1] = tile[tx][ty + 8 * q];
             }
             __syncthreads();
+        }
+        return;
+    }
+    if (p0 == 9) {
+        // conv input-gradient pack (conv_dgrad_pack_kernel): src (Co, Ci, kw) -> [stride][Ci][J * Co], stride = p1, zero taps past kw
+        const int Co = d[0], Ci = d[1], kw = d[2], st = p1, J = (kw + st - 1) / st;
+        const int n = st * Ci * J * Co;
+        for (int i = (int)((long)blockIdx.x - wg0) * 256 + threadIdx.x; i < n; i += (int)nwg * 256) {
+            const int co = i % Co;
+            int t = i / Co;
+            const int j = t % J; t /= J;
+            const int ci = t % Ci;
+            const int r = t / Ci;
+            const int k = r + st * j;
+            out[i] = k < kw ? in[(co * Ci + ci) * kw + k] : 0.f;
         }
         return;
     }

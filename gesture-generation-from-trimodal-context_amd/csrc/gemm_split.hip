@@ -18,6 +18,7 @@
 // LDS buffer (two barriers per slab, <= 54 KB: two workgroups per CU, the better choice when the grid has >= 2 workgroups per
 // CU); DB = 1 double-buffers (one barrier per slab): used with the 64-row tiles of the small grids of the backward shapes.
 #include "common.hpp"
+#include <stdlib.h>
 #include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -58,7 +59,9 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
 
 // C(m, n) = act(sum_k A(m,k) * Bw[n][k] + bias[n]) (+ C).  A: fp32 row window (vectorisable layout: checked by the caller),
 // Bw: fp32 [N][ldb].  Same contract as gemm_nt_big_kernel (gemm.hip).
-template <int TM, int TN, int SPLITS, int DB>
+// RING = register sets of global loads in flight (slabs fetched ahead): 1 = the next slab only, 2 = two slabs ahead (+ 4 (TM + TN)
+// VGPRs; the loads of a slab then have two MFMA sections to land instead of one)
+template <int TM, int TN, int SPLITS, int DB, int RING = 1>
 __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
     const int pi = group_find(g, blockIdx.x);
     const NtProb& pr = g.p[pi];
@@ -117,9 +120,10 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
     int kk = sp / A.cw, c = sp - (sp / A.cw) * A.cw;          // tap / channel of this thread's piece, advanced by 32 per slab
     int bsg = sp / b_seg_k, bc = sp - (sp / b_seg_k) * b_seg_k;   // weight segment / column inside it, likewise
 
-    f32x4 ga[NPA], gb[NPB];
-    unsigned ga_ok = 0u, gb_ok = 0u;
-    auto fetch = [&](int k0) {
+    f32x4 ga[RING][NPA], gb[RING][NPB];
+    unsigned ga_ok[RING], gb_ok[RING];
+    auto fetch = [&](auto set_c, int k0) {
+        constexpr int set = decltype(set_c)::value;
         // loads are issued UNCONDITIONALLY from an always-valid address: a predicated load makes the number of outstanding loads
         // dynamic and hipcc then drains everything (vmcnt(0)) at the next use.  Out-of-range pieces are zeroed when the slab is STAGED
         // (masks ga_ok / gb_ok), not here: a select placed next to its load is scheduled right behind it and waits for the loads
@@ -131,16 +135,16 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
         for (int q = 0; q < NPA; ++q) {
             const int sr = a_r[q] + kk * A.dil;
             const bool ok = a_ok[q] && inb && sr >= 0 && sr < A.rows_in;
-            ga[q] = *reinterpret_cast<const f32x4*>(ok ? A.ptr + a_off[q] + (long)sr * A.rs + c : A.ptr);
+            ga[set][q] = *reinterpret_cast<const f32x4*>(ok ? A.ptr + a_off[q] + (long)sr * A.rs + c : A.ptr);
             ma |= ok ? (1u << q) : 0u;
         }
 #pragma unroll
         for (int q = 0; q < NPB; ++q) {
             const bool ok = b_ok[q] && inb;
-            gb[q] = *reinterpret_cast<const f32x4*>(ok ? b_ptr[q] + bsg * b_seg_stride + bc : Bw);
+            gb[set][q] = *reinterpret_cast<const f32x4*>(ok ? b_ptr[q] + bsg * b_seg_stride + bc : Bw);
             mb |= ok ? (1u << q) : 0u;
         }
-        ga_ok = ma; gb_ok = mb;
+        ga_ok[set] = ma; gb_ok[set] = mb;
         c += 32;
         while (c >= A.cw) { c -= A.cw; ++kk; }
         bc += 32;
@@ -153,26 +157,29 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, RING - 1>;
     int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    // one slab: stage register set `set` into LDS, refill the set with the slab RING ahead, multiply
+    auto slab = [&](auto set_c, int k0) {
+        constexpr int set = decltype(set_c)::value;
         if (!DB && k0 > 0) __syncthreads();                     // single buffer: everybody has read the previous slab
 #pragma unroll
         for (int q = 0; q < NPA; ++q) {
             u32x2 o[NS];
-            split4<SPLITS>((ga_ok >> q) & 1u ? ga[q] : f32x4{0.f, 0.f, 0.f, 0.f}, o);
+            split4<SPLITS>((ga_ok[set] >> q) & 1u ? ga[set][q] : f32x4{0.f, 0.f, 0.f, 0.f}, o);
 #pragma unroll
             for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][sr0 + 32 * q][sp_w]) = o[s];
         }
 #pragma unroll
         for (int q = 0; q < NPB; ++q) {
             u32x2 o[NS];
-            split4<SPLITS>((gb_ok >> q) & 1u ? gb[q] : f32x4{0.f, 0.f, 0.f, 0.f}, o);
+            split4<SPLITS>((gb_ok[set] >> q) & 1u ? gb[set][q] : f32x4{0.f, 0.f, 0.f, 0.f}, o);
 #pragma unroll
             for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][BM + sr0 + 32 * q][sp_w]) = o[s];
         }
         __syncthreads();
-        if (k0 + 32 < K) fetch(k0 + 32);
+        if (k0 + 32 * RING < K) fetch(set_c, k0 + 32 * RING);
         bf16x8 fa[NS][TM], fb[NS][TN];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -196,6 +203,16 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], cc, 0, 0, 0);
             }
         if (DB) buf ^= 1;
+    };
+    fetch(set0{}, 0);
+    if constexpr (RING == 2) {
+        if (32 < K) fetch(set1{}, 32);
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            slab(set0{}, k0);
+            if (k0 + 32 < K) slab(set1{}, k0 + 32);
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 32) slab(set0{}, k0);
     }
 
     const int vec_c = pr.vec_c;
@@ -548,7 +565,12 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
     }
     for (int i = g.n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
     const dim3 grid(wg);
-#define TG_SPLIT(TM_, TN_, SP_, DB_) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_>), grid, dim3(256), 0, s, g)
+    static const int ring = [] { const char* e = getenv("TG_NT_RING"); return e ? atoi(e) : 1; }();      // slabs of loads in flight (1 or 2)
+#define TG_SPLIT(TM_, TN_, SP_, DB_)                                                                                   \
+    do {                                                                                                               \
+        if (ring == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_, 2>), grid, dim3(256), 0, s, g);    \
+        else hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_, 1>), grid, dim3(256), 0, s, g);              \
+    } while (0)
 #define TG_SPLIT_MENU(SP_)                                              \
     do {                                                                \
         if (tl.tm == 4 && tl.tn == 3) TG_SPLIT(4, 3, SP_, 0);           \

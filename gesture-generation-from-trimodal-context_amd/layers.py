@@ -44,7 +44,8 @@ class WeightPrep:
         return None
 
     def get(self, src3, perm, out_shape):
-        """The permuted copy of src3 (3-D view of a slab parameter) or None when the caller has to permute inline."""
+        """The permuted copy of src3 (3-D view of a slab parameter) or None when the caller has to permute inline.
+        perm = (9, stride, 0) is the conv input-gradient pack (ops.conv_dgrad_pack) of a (Co, Ci, kw) weight."""
         key = (src3.data_ptr(), tuple(src3.shape), perm)
         hit = self.by_key.get(key)
         if hit is not None:
@@ -53,13 +54,19 @@ class WeightPrep:
         if gid is None or torch.cuda.is_current_stream_capturing():
             return None
         dst = empty(*out_shape, like=src3)
-        ops.permute3(src3, dst.view(-1), perm)                    # fresh now; later refreshes keep it so
+        if perm[0] == 9:
+            ops.conv_dgrad_pack(src3, dst, perm[1])
+        else:
+            ops.permute3(src3, dst.view(-1), perm)                # fresh now; later refreshes keep it so
         g = self.groups[gid]
         g["jobs"].append((src3, dst, perm))
         self.by_key[key] = dst
         rows, wg0 = [], 0
         for s3, d, pm in g["jobs"]:
-            nwg = max(1, min(512, (s3.numel() + 2047) // 2048))      # ~2 LDS tiles (32 x 32) per workgroup: the 64-workgroup cap serialised 8+ tiles each
+            # ~2 LDS tiles (32 x 32 per batch index) per workgroup.  Counted in TILES, not elements: a conv pack (Co, Ci, kw) is Co small
+            # tiles -- sized by elements it got one workgroup that walked 16-64 tiles one after the other (16-27 us per launch)
+            tiles = s3.shape[0] * ((s3.shape[1] + 31) // 32) * ((s3.shape[2] + 31) // 32) if tuple(pm) == (0, 2, 1) else (d.numel() + 1023) // 1024
+            nwg = max(1, min(512, (tiles + 1) // 2))
             rows.append([s3.data_ptr(), d.data_ptr(), *s3.shape, *pm, wg0, nwg])
             wg0 += nwg
         if g["desc"] is not None:
@@ -121,6 +128,20 @@ def pack_conv_weight(w):
     return out
 
 
+def dgrad_pack(w, stride):
+    """Conv1d weight (Co, Ci, kw) -> [stride][Ci][J * Co], J = ceil(kw / stride): the B operands of the input-gradient phases (conv_dgrad).
+    Cached per optimiser step by an active WeightPrep, packed inline otherwise."""
+    Co, Ci, kw = w.shape
+    J = (kw + stride - 1) // stride
+    if _PREP is not None and w.is_contiguous():
+        hit = _PREP.get(w, (9, stride, 0), (stride, Ci, J * Co))
+        if hit is not None:
+            return hit
+    packed = empty(stride, Ci, J * Co, like=w)
+    ops.conv_dgrad_pack(w, packed, stride)
+    return packed
+
+
 # ----------------------------------------------------------------------------------------------- linear
 def linear_fwd(x2d, W, b, out=None, act_slope=1.0):
     if out is None:
@@ -177,8 +198,7 @@ def conv_dgrad(dy, w, L_in, *, stride=1):
     B, Lo, Co = dy.shape
     _, Ci, kw = w.shape
     J = (kw + stride - 1) // stride
-    packed = empty(stride, Ci, J * Co, like=w)
-    ops.conv_dgrad_pack(w, packed, stride)
+    packed = dgrad_pack(w, stride)
     dx = empty(B, L_in, Ci, like=w)
     probs = []
     for r in range(stride):
@@ -196,8 +216,7 @@ def conv_transpose_fwd(x, w, b, *, out=None):
     Same arithmetic as conv_dgrad with the roles of the channel axes swapped."""
     B, L, Ci = x.shape
     _, Co, kw = w.shape
-    packed = empty(1, Co, kw * Ci, like=w)
-    ops.conv_dgrad_pack(w, packed, 1)            # (Ci, Co, kw) seen as a conv weight (Co'=Ci, Ci'=Co)
+    packed = dgrad_pack(w, 1)                    # (Ci, Co, kw) seen as a conv weight (Co'=Ci, Ci'=Co)
     Lo = L + kw - 1
     if out is None:
         out = empty(B, Lo, Co, like=x)
