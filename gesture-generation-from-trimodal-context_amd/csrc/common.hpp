@@ -155,6 +155,29 @@ __device__ __forceinline__ void split3_bits(float x, unsigned& hi, unsigned& mid
 // upper halves of two fp32 words -> one dword holding two bf16 (first element in the low half)
 __device__ __forceinline__ unsigned pack_hi16(unsigned first, unsigned second) { return __builtin_amdgcn_perm(second, first, 0x07060302u); }
 
+// one 8-column piece of a plane buffer ([3][rows + 1][cwp] bf16, see gemm_planes.hip): columns c .. c + 7 of row r of an fp32 matrix
+// [rows][cw] (row stride ldx), zero past cw and in the extra row `rows`
+typedef unsigned tg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3_write_piece(const float* __restrict__ x, long ldx, int rows, int cw, int cwp, __bf16* __restrict__ planes,
+                                                   long plane_stride, long r, int c, bool vec) {
+    float v[8];
+    if (r < rows && vec && c + 8 <= cw) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * ldx + c), b = *reinterpret_cast<const f32x4*>(x + r * ldx + c + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = a[q]; v[4 + q] = b[q]; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (r < rows && c + q < cw) ? x[r * ldx + c + q] : 0.f;
+    }
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) split3_bits(v[q], h[q], m[q], l[q]);
+    const long o = r * cwp + c;
+    *reinterpret_cast<tg_u32x4*>(planes + o) = tg_u32x4{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])};
+    *reinterpret_cast<tg_u32x4*>(planes + plane_stride + o) = tg_u32x4{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])};
+    *reinterpret_cast<tg_u32x4*>(planes + 2 * plane_stride + o) = tg_u32x4{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])};
+}
+
 // ---- Philox4x32-10 ------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;

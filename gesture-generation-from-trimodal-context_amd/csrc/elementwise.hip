@@ -218,6 +218,17 @@ __global__ __launch_bounds__(256) void permute3_batch_kernel(const long* __restr
         }
         return;
     }
+    if (p0 == 8) {
+        // bf16 x 3 planes of a weight matrix (gemm_planes.hip): src [d0 rows][d1 = cw] fp32 contiguous -> [3][d0 + 1][d2 = cwp] bf16
+        const int rows = d[0], cw = d[1], cwp = d[2], c8 = cwp / 8;
+        const long total = (long)(rows + 1) * c8, plane = (long)(rows + 1) * cwp;
+        const bool vec = (cw % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
+        for (long i = ((long)blockIdx.x - wg0) * 256 + threadIdx.x; i < total; i += nwg * 256) {
+            const long r = i / c8;
+            split3_write_piece(in, (long)cw, rows, cw, cwp, reinterpret_cast<__bf16*>(out), plane, r, (int)(i - r * c8) * 8, vec);
+        }
+        return;
+    }
     if (p0 == 9) {
         // conv input-gradient pack (conv_dgrad_pack_kernel): src (Co, Ci, kw) -> [stride][Ci][J * Co], stride = p1, zero taps past kw
         const int Co = d[0], Ci = d[1], kw = d[2], st = p1, J = (kw + st - 1) / st;

@@ -61,8 +61,9 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
 // Bw: fp32 [N][ldb].  Same contract as gemm_nt_big_kernel (gemm.hip).
 // RING = register sets of global loads in flight (slabs fetched ahead): 1 = the next slab only, 2 = two slabs ahead (+ 4 (TM + TN)
 // VGPRs; the loads of a slab then have two MFMA sections to land instead of one)
-template <int TM, int TN, int SPLITS, int DB, int RING = 1>
-__global__ __launch_bounds__(256) void gemm_nt_split_kernel(const NtGroup g) {
+// OCC = waves per SIMD the register allocation is held to (HIP's second launch-bounds argument; 1 = unconstrained)
+template <int TM, int TN, int SPLITS, int DB, int RING = 1, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g) {
     const int pi = group_find(g, blockIdx.x);
     const NtProb& pr = g.p[pi];
     const Win A = pr.A;
@@ -566,9 +567,13 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
     for (int i = g.n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
     const dim3 grid(wg);
     static const int ring = [] { const char* e = getenv("TG_NT_RING"); return e ? atoi(e) : 1; }();      // slabs of loads in flight (1 or 2)
+    // the 128-row tiles held to 3 (128 x 96: 180 -> 162 VGPRs) / 4 (128 x 64) waves per SIMD: three workgroups per CU instead of two, 119.7 ->
+    // 116.5 us on [13056 x 900 x 600], 6.29 -> 6.24 ms per iteration (TG_NT_OCC=0 keeps the unconstrained allocation)
+    static const int occ = [] { const char* e = getenv("TG_NT_OCC"); return e ? atoi(e) : 1; }();
 #define TG_SPLIT(TM_, TN_, SP_, DB_)                                                                                   \
     do {                                                                                                               \
         if (ring == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_, 2>), grid, dim3(256), 0, s, g);    \
+        else if (occ && TM_ == 4 && SP_ == 3) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_, 1, (TM_ == 4 && SP_ == 3) ? (TN_ == 3 ? 3 : 4) : 1>), grid, dim3(256), 0, s, g); \
         else hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_, 1>), grid, dim3(256), 0, s, g);              \
     } while (0)
 #define TG_SPLIT_MENU(SP_)                                              \

@@ -53,16 +53,24 @@ class WeightPrep:
         gid = self._group_of(src3.data_ptr())
         if gid is None or torch.cuda.is_current_stream_capturing():
             return None
-        dst = empty(*out_shape, like=src3)
-        if perm[0] == 9:
+        if perm[0] == 8:                                          # bf16 x 3 planes of a weight [rows][cw] (src3 = (1, rows, cw)): [3][rows + 1][cwp] bf16
+            dst = ops.split3_planes(src3[0]).t
+        elif perm[0] == 9:
+            dst = empty(*out_shape, like=src3)
             ops.conv_dgrad_pack(src3, dst, perm[1])
         else:
+            dst = empty(*out_shape, like=src3)
             ops.permute3(src3, dst.view(-1), perm)                # fresh now; later refreshes keep it so
         g = self.groups[gid]
         g["jobs"].append((src3, dst, perm))
         self.by_key[key] = dst
         rows, wg0 = [], 0
         for s3, d, pm in g["jobs"]:
+            if pm[0] == 8:                                        # table entry: d0 = rows, d1 = cw, d2 = cwp
+                nwg = max(1, min(512, (d.numel() // 3 + 16383) // 16384))
+                rows.append([s3.data_ptr(), d.data_ptr(), s3.shape[1], s3.shape[2], d.shape[2], 8, 0, 0, wg0, nwg])
+                wg0 += nwg
+                continue
             # ~2 LDS tiles (32 x 32 per batch index) per workgroup.  Counted in TILES, not elements: a conv pack (Co, Ci, kw) is Co small
             # tiles -- sized by elements it got one workgroup that walked 16-64 tiles one after the other (16-27 us per launch)
             tiles = s3.shape[0] * ((s3.shape[1] + 31) // 32) * ((s3.shape[2] + 31) // 32) if tuple(pm) == (0, 2, 1) else (d.numel() + 1023) // 1024
@@ -126,6 +134,16 @@ def pack_conv_weight(w):
     out = empty(Co, kw * Ci, like=w)
     ops.permute3(w, out, (0, 2, 1))
     return out
+
+
+def weight_planes(w2d):
+    """bf16 x 3 planes (ops.Planes) of a weight matrix [N][K]: refreshed once per optimiser step by an active WeightPrep, split inline otherwise."""
+    N, K = w2d.shape
+    if _PREP is not None and w2d.is_contiguous():
+        hit = _PREP.get(w2d.view(1, N, K), (8, 0, 0), None)
+        if hit is not None:
+            return ops.Planes(hit, N, K, hit.shape[2])
+    return ops.split3_planes(w2d)
 
 
 def dgrad_pack(w, stride):
@@ -368,9 +386,16 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     for l in range(n_layers):
         Kin = cur.shape[2]
         gi = empty(2, B, T, 3 * H, like=x)
-        a_win = Win.plain(cur.view(B * T, Kin))
-        ops.gemm_nt_group([dict(A=a_win, W=P[f"{prefix}.weight_ih_l{l}{sfx}"], bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
-                                out=gi[d].view(B * T, 3 * H)) for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
+        if ops.GEMM_PLANES and B * T >= 1024 and H > 64:
+            # pre-split operands: the layer input is split into bf16 x 3 planes once (not by each of the 19 column tiles that stage it), the
+            # weights once per optimiser step (WeightPrep)
+            a_pl = ops.split3_planes(cur.view(B * T, Kin))
+            ops.gemm_nt_planes_group([dict(A=a_pl, Bp=weight_planes(P[f"{prefix}.weight_ih_l{l}{sfx}"]), bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
+                                           out=gi[d].view(B * T, 3 * H)) for d, sfx in enumerate(("", "_reverse"))])
+        else:
+            a_win = Win.plain(cur.view(B * T, Kin))
+            ops.gemm_nt_group([dict(A=a_win, W=P[f"{prefix}.weight_ih_l{l}{sfx}"], bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
+                                    out=gi[d].view(B * T, 3 * H)) for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
         y = empty(B, T, 2 * H, like=x)
         sv = empty(2, B, T, 4 * H, like=x) if save else None
         whh = (P[f"{prefix}.weight_hh_l{l}"], P[f"{prefix}.weight_hh_l{l}_reverse"])

@@ -137,6 +137,83 @@ def gemm_nt_group(problems):
         i = j
 
 
+# ------------------------------------------------------------------------------------------------- pre-split (bf16 x 3 planes) operands
+# csrc/gemm_planes.hip: the fp32-accurate bf16 x 3 product with both operands split ONCE into hi / mid / lo planes instead of by every tile
+# that stages them.  Opt-in (TG_GEMM_PLANES=1): measured on the GRU input projection (2 x [13056 x 900 x 600]) it removes the split
+# arithmetic (4.8 -> 1.9 vector instructions per MFMA) but moves 6 instead of 4 bytes per operand element from L2 to the CUs (25.4 M
+# against 14.7 M 64-byte requests per launch, profiles/r2_r_pmc_planes.txt) and ends up level with the split-while-staging kernel
+# (175 + 13 us for the split pass against 168 us inside the captured iteration).
+GEMM_PLANES = os.environ.get("TG_GEMM_PLANES", "0") != "0"
+
+
+class Planes:
+    """bf16 x 3 planes of an fp32 matrix [rows][cw]: tensor [3][rows + 1][cwp] bf16 (cwp = cw rounded up to 32; row `rows` is zero)."""
+    __slots__ = ("t", "rows", "cw", "cwp")
+
+    def __init__(self, t, rows, cw, cwp):
+        self.t, self.rows, self.cw, self.cwp = t, rows, cw, cwp
+
+    @property
+    def plane_stride(self):
+        return (self.rows + 1) * self.cwp
+
+
+def planes_cwp(cw):
+    return (cw + 31) // 32 * 32
+
+
+def split3_planes(x2d, out=None):
+    """fp32 [rows][cw] view (unit inner stride) -> Planes."""
+    _f32(x2d, "x"); assert x2d.dim() == 2 and x2d.stride(1) == 1
+    rows, cw = x2d.shape
+    if (rows - 1) * x2d.stride(0) + cw - 1 >= _room(x2d):
+        raise ValueError("split3_planes: x exceeds its tensor")
+    cwp = planes_cwp(cw)
+    t = torch.empty(3, rows + 1, cwp, device=x2d.device, dtype=torch.bfloat16) if out is None else out
+    assert tuple(t.shape) == (3, rows + 1, cwp) and t.is_contiguous() and t.dtype == torch.bfloat16
+    call("tg_split3_planes", _p(x2d), x2d.stride(0), rows, cw, C.c_void_p(t.data_ptr()), cwp, (rows + 1) * cwp, _stream())
+    return Planes(t, rows, cw, cwp)
+
+
+def _np_problem(A: Planes, Bp: Planes, bias, out, *, taps=1, batches=1, batch_rows=0, rows_in=None, rows_out=None, row_step=1, shift=0, dil=1,
+                act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, out_scale=None):
+    """Checked tg_gemm_nt_planes_problem.  A: activation planes (window over its rows), Bp: weight planes of [N * taps rows][cw]."""
+    _f32(out, "out")
+    assert A.cwp == Bp.cwp and A.cw == Bp.cw and Bp.rows % taps == 0, (A.cw, Bp.cw, Bp.rows, taps)
+    N = Bp.rows // taps
+    rows_in = A.rows if rows_in is None else rows_in
+    rows_out = rows_in if rows_out is None else rows_out
+    M = batches * rows_out
+    assert (batches - 1) * batch_rows + rows_in <= A.rows
+    if bias is not None:
+        _f32(bias, "bias"); assert bias.numel() == N and bias.is_contiguous()
+    if c_row_stride is None:
+        assert out.dim() == 2 and out.stride(1) == 1 and tuple(out.shape) == (M, N), (out.shape, M, N)
+        c_batch_stride, c_row_stride, c_rows_out = 0, out.stride(0), M
+    nb = (M + c_rows_out - 1) // c_rows_out
+    if (nb - 1) * c_batch_stride + (c_rows_out - 1) * c_row_stride + N - 1 >= _room(out):
+        raise ValueError("gemm_nt_planes: output exceeds its tensor")
+    q = _lib.NtPlanesProblem()
+    q.A, q.a_plane_stride, q.a_rows, q.cwp = A.t.data_ptr(), A.plane_stride, A.rows, A.cwp
+    q.a_batch_rows, q.rows_in, q.rows_out, q.row_step, q.shift, q.dil, q.taps = batch_rows, rows_in, rows_out, row_step, shift, dil, taps
+    q.B, q.b_plane_stride = Bp.t.data_ptr(), Bp.plane_stride
+    q.bias = bias.data_ptr() if bias is not None else None
+    q.C, q.c_batch_stride, q.c_row_stride, q.c_rows_out = out.data_ptr(), c_batch_stride, c_row_stride, c_rows_out
+    q.M, q.N, q.act_slope, q.accumulate = M, N, float(act_slope), int(bool(accumulate))
+    if out_scale is not None:
+        _f32(out_scale, "out_scale")
+        assert out_scale.shape == out.shape and out_scale.stride() == out.stride()
+        q.out_scale = out_scale.data_ptr()
+    return q
+
+
+def gemm_nt_planes_group(problems):
+    """Independent products on pre-split operands in ONE launch.  problems: dicts with the arguments of _np_problem (A, Bp, bias, out, ...)."""
+    assert 1 <= len(problems) <= _lib.MAX_GROUP
+    arr = (_lib.NtPlanesProblem * len(problems))(*[_np_problem(**p) for p in problems])
+    call("tg_gemm_nt_planes_group", arr, len(problems), _stream())
+
+
 def zero_(t):
     """In-place zero fill by a kernel of the library (never a memset: see csrc/common.hpp zero_async)."""
     if not t.is_contiguous() or (t.numel() * t.element_size()) % 4:

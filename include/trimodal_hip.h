@@ -98,6 +98,30 @@ int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bi
                int64_t c_batch_stride, int64_t c_row_stride, int32_t c_rows_out, int32_t M, int32_t N,
                float act_slope, int32_t accumulate, void* stream);
 
+/* ---- tg_gemm_nt on pre-split operands (csrc/gemm_planes.hip): same products and epilogue as tg_gemm_nt, fp32-accurate on the bf16
+ * matrix cores, but both operands arrive as three bf16 planes (x = hi + mid + lo exactly) so the main loop does no split arithmetic.
+ * Plane buffer of an fp32 matrix [rows][cw]: [3][rows + 1][cwp] bf16 (cwp = cw rounded up to a multiple of 32, zero columns; row `rows`
+ * all zero), planes `plane_stride` ELEMENTS apart.  tg_split3_planes writes one from fp32. */
+int tg_split3_planes(const float* x, int64_t ldx, int32_t rows, int32_t cw, void* planes, int32_t cwp, int64_t plane_stride, void* stream);
+typedef struct tg_gemm_nt_planes_problem {
+    const void* A;             /* planes of the activation buffer, a_rows (+ the zero row) rows of cwp channels */
+    int64_t a_plane_stride;
+    int32_t a_rows, cwp;
+    int64_t a_batch_rows;      /* row window as in tg_window, in ROWS of the buffer: output row m = (batch b, r) reads source rows */
+    int32_t rows_in, rows_out; /*   b * a_batch_rows + r * row_step + shift + tap * dil, tap = 0 .. taps - 1 (zero outside [0, rows_in)) */
+    int32_t row_step, shift, dil, taps;
+    const void* B;             /* planes of the weights [3][N][taps][cwp] (tg_split3_planes over the N * taps rows of cw of a packed weight) */
+    int64_t b_plane_stride;
+    const float* bias;
+    float* C;
+    int64_t c_batch_stride, c_row_stride;
+    int32_t c_rows_out, M, N;
+    float act_slope;
+    int32_t accumulate;
+    const float* out_scale;
+} tg_gemm_nt_planes_problem;
+int tg_gemm_nt_planes_group(const tg_gemm_nt_planes_problem* problems, int32_t n, void* stream);
+
 /* tg_gemm_tn (weight gradient, accumulates): dW[n*ldw + perm(k)] += sum_m dY[m*ldy + n] * A(m, k).
  *   out_kw == 0: perm(k) = k.  out_kw == K/cw: perm(k) = (k % cw) * out_kw + k / cw, i.e. the gradient lands in
  *   the (Cout, Cin, kw) layout of nn.Conv1d weights.

@@ -670,3 +670,55 @@ def test_wav_front_conv_bn_lrelu_fused(pkg, dev, B, L, stride, pad, groups):
     ce = F.conv1d(audio.double().unsqueeze(1), P[0], P[1], stride=stride, padding=pad)
     ye_ref = F.leaky_relu(F.batch_norm(ce, rm_d.double().cpu(), rv_d.double().cpu(), P[2], P[3], training=False, eps=1e-5), 0.3)
     assert rel(ye, cl(ye_ref)) < 1e-5 and ste.gate is None and int(nbt) == groups
+
+
+# ------------------------------------------------------------------------------------------------ pre-split (bf16 x 3 planes) GEMM
+def test_split3_planes_are_exact(pkg, dev):
+    """hi + mid + lo == x bit for bit, every term a bf16; padding columns and the extra row are zero."""
+    ops = pkg.ops
+    x = (rnd(37, 108, seed=51) * torch.logspace(-6, 6, 108)).to(dev)
+    pl = ops.split3_planes(x)
+    assert pl.cwp == 128 and tuple(pl.t.shape) == (3, 38, 128)
+    s = pl.t[0].double() + pl.t[1].double() + pl.t[2].double()
+    assert torch.equal(s[:37, :108].float(), x) and float(s[:37, 108:].abs().max()) == 0 and float(s[37].abs().max()) == 0
+    xs = torch.zeros(50, 200, device=dev); xs[:, 3:111] = rnd(50, 108, seed=52).to(dev)
+    pv = ops.split3_planes(xs[:, 3:111])                                   # unaligned strided view: scalar path
+    assert torch.equal((pv.t[0].double() + pv.t[1].double() + pv.t[2].double())[:50, :108].float(), xs[:, 3:111])
+
+
+@pytest.mark.parametrize("M,N,K", [(13056, 900, 600), (4352, 300, 108), (1030, 52, 70), (2048, 96, 32)])
+def test_gemm_nt_planes_is_fp32_accurate(pkg, dev, M, N, K):
+    """tg_gemm_nt_planes_group vs fp64 on operands spanning eight decades: the fp32 gate (1e-5), tile edges in M and N, K padding, grouped
+    launch, bias / activation / accumulate / out_scale epilogue."""
+    ops = pkg.ops
+    x = (rnd(M, K, seed=53) * torch.logspace(-4, 4, K)).to(dev)
+    w = [(rnd(N, K, seed=54 + i, scale=0.1) * torch.logspace(2, -2, K)).to(dev) for i in range(2)]
+    b = [rnd(N, seed=56 + i).to(dev) for i in range(2)]
+    ref = [F.leaky_relu(x.double().cpu() @ w[i].double().cpu().t() + b[i].double().cpu(), 0.3) for i in range(2)]
+    a_pl = ops.split3_planes(x)
+    out = torch.full((2, M, N), float("nan"), device=dev)
+    ops.gemm_nt_planes_group([dict(A=a_pl, Bp=ops.split3_planes(w[i]), bias=b[i], out=out[i], act_slope=0.3) for i in range(2)])
+    assert rel(out[0], ref[0]) < 1e-5 and rel(out[1], ref[1]) < 1e-5, (rel(out[0], ref[0]), rel(out[1], ref[1]))
+    mask = (torch.rand(M, N, generator=torch.Generator().manual_seed(5)) > 0.3).float().to(dev) * 1.25
+    base = out[0].clone()
+    ops.gemm_nt_planes_group([dict(A=a_pl, Bp=ops.split3_planes(w[1]), bias=None, out=out[0], accumulate=True, out_scale=mask)])
+    ref2 = base.double().cpu() + (x.double().cpu() @ w[1].double().cpu().t()) * mask.double().cpu()
+    assert rel(out[0], ref2) < 1e-5
+
+
+def test_gemm_nt_planes_conv_window(pkg, dev):
+    """Dilated causal conv (model/tcn.py) as a two-tap row window over the plane buffer: rows before the sequence start read the zero row."""
+    ops = pkg.ops
+    B, T, Ci, Co, d = 40, 34, 300, 300, 4
+    x = rnd(B, Ci, T, seed=58)
+    w = rnd(Co, Ci, 2, seed=59, scale=0.05)
+    bias = rnd(Co, seed=60)
+    ref = F.conv1d(x.double(), w.double(), bias.double(), padding=d, dilation=d)[:, :, :T]          # Chomp1d
+    xcl = cl(x).to(dev)                                                                              # (B, T, Ci)
+    a_pl = ops.split3_planes(xcl.view(B * T, Ci))
+    wp = w.permute(0, 2, 1).contiguous().to(dev)                                                     # [Co][tap][Ci]: tap-major packed weight
+    b_pl = ops.split3_planes(wp.view(Co * 2, Ci))
+    out = torch.empty(B * T, Co, device=dev)
+    ops.gemm_nt_planes_group([dict(A=a_pl, Bp=b_pl, bias=bias.to(dev), out=out, taps=2, batches=B, batch_rows=T, rows_in=T, rows_out=T,
+                                   shift=-d, dil=d)])
+    assert rel(out.view(B, T, Co), cl(ref)) < 1e-5
