@@ -62,6 +62,8 @@ SIGNATURES = {
     "tg_bn_eval_stats": [P, P, I32, F32, P, P, P],
     "tg_bn_train_fused": [P, P, I32, I32, I32, P, P, P, P, P, P, P, F32, F32, F32, I32, P],
     "tg_bn_apply": [P, P, I32, I32, I32, P, P, P, P, F32, P],
+    "tg_bn2_train": [P, P, I32, I32, I32, P, I64, P, P, P, P, P, P, P, F32, F32, F32, I32, P],
+    "tg_bn2_backward": [P, P, P, I32, I32, I32, P, P, P, P, F32, P, I64, P, P, P],
     "tg_bn_backward": [P, P, P, I32, I32, P, P, P, P, F32, P, P, P, P],
     "tg_wav_front_stats": [P, I64, I32, I32, P, P, I32, I32, I32, P, I64, P, P, P, P, P, P, F32, F32, I32, P],
     "tg_wav_front_apply": [P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, P, P],
@@ -143,6 +145,10 @@ def load():
     lib.tg_gru_cluster_bwd_supported.argtypes = [I32, I32]
     lib.tg_gru_cluster_bwd_ws_bytes.restype = C.c_int64
     lib.tg_gru_cluster_bwd_ws_bytes.argtypes = [I32, I32]
+    lib.tg_bn2_supported.restype = C.c_int32
+    lib.tg_bn2_supported.argtypes = [I32, I32]
+    lib.tg_bn2_ws_doubles.restype = C.c_int64
+    lib.tg_bn2_ws_doubles.argtypes = [I32, I32, I32]
     for q, at in (("tg_wav_front_ws_doubles", []), ("tg_wav_front_fstat_doubles", []), ("tg_wav_front_gate_words", [I32, I32])):
         getattr(lib, q).restype = C.c_int64
         getattr(lib, q).argtypes = at

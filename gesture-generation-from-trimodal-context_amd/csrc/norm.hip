@@ -387,6 +387,210 @@ __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_bwd_kernel(
     }
 }
 
+// ---- two-launch BatchNorm (train forward: partial sums | finalize + apply; backward: partial sums | finalize + apply) --------------------
+// For everything between the single-workgroup kernels above (<= 32 K elements) and -- replacing them -- the zero / stats / finalize / apply
+// chain: no zero fill, no atomics (per-workgroup partials combined in fixed order by every workgroup of the second launch), all statistics
+// groups of a stacked forward in ONE launch (grid.y), and the backward of several groups likewise (the discriminator step ran one
+// single-workgroup launch of 13-16 us per group and layer).
+// part layout: [groups][P][2][C] doubles.
+__global__ __launch_bounds__(256) void bn2_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, long rows_per_group, int C,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                          double* __restrict__ part) {
+    // dy == nullptr: (sum x, sum x^2); else (sum dz, sum dz xhat) with dz = dy act'(z), statistics of group blockIdx.y at mean/rstd + g C
+    __shared__ double sh[2][256];
+    const int g = blockIdx.y, P = gridDim.x;
+    const long total4 = rows_per_group * C / 4;
+    const long base4 = (long)g * total4;
+    const long i0 = (long)blockIdx.x * 256 + threadIdx.x, step = (long)P * 256;
+    const int c0 = (int)((i0 * 4) % C);
+    if ((int)threadIdx.x < C) { sh[0][threadIdx.x] = 0.0; sh[1][threadIdx.x] = 0.0; }
+    __syncthreads();
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + base4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    if (dy == nullptr) {
+#pragma unroll 4
+        for (long i = i0; i < total4; i += step) {
+            const f32x4 v = x4[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s[q] += v[q]; ss[q] += (double)v[q] * v[q]; }
+        }
+    } else {
+        const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy) + base4;
+        float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { mu[q] = mean[g * C + c0 + q]; rs[q] = rstd[g * C + c0 + q]; ga[q] = gamma[c0 + q]; be[q] = beta[c0 + q]; }
+#pragma unroll 4
+        for (long i = i0; i < total4; i += step) {
+            const f32x4 xv = x4[i], dv = dy4[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float xh = (xv[q] - mu[q]) * rs[q];
+                const float z = xh * ga[q] + be[q];
+                const float dz = dv[q] * (z >= 0.f ? 1.f : slope);
+                s[q] += dz;
+                ss[q] += (double)dz * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { atomicAdd(&sh[0][c0 + q], s[q]); atomicAdd(&sh[1][c0 + q], ss[q]); }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        double* o = part + (((long)g * P + blockIdx.x) * 2) * C;
+        o[threadIdx.x] = sh[0][threadIdx.x];
+        o[C + threadIdx.x] = sh[1][threadIdx.x];
+    }
+}
+
+// totals of group g's P partials into tot[2][C] (LDS), fixed order: thread (c, slice) sums every (256 / C)-th partial, then the slices
+__device__ __forceinline__ void bn2_totals(const double* __restrict__ part, int g, int P, int C, double (*tot)[256], double (*sl)[256]) {
+    const int S = 256 / C;                       // slices
+    const int c = threadIdx.x % C, sidx = threadIdx.x / C;
+    double a = 0.0, b = 0.0;
+    if (sidx < S) {
+#pragma unroll 8
+        for (int p = sidx; p < P; p += S) {          // independent loads, eight in flight
+            const double* o = part + (((long)g * P + p) * 2) * C;
+            a += o[c];
+            b += o[C + c];
+        }
+    }
+    sl[0][threadIdx.x] = a;
+    sl[1][threadIdx.x] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        double ta = 0.0, tb = 0.0;
+        for (int q = 0; q < S; ++q) { ta += sl[0][q * C + c]; tb += sl[1][q * C + c]; }
+        tot[0][c] = ta;
+        tot[1][c] = tb;
+    }
+    __syncthreads();
+}
+
+// many partials (large tensors): combined once per group by this launch instead of by every workgroup of the apply launch
+__global__ __launch_bounds__(256) void bn2_reduce_kernel(const double* __restrict__ part, int P, int C, double* __restrict__ out) {
+    __shared__ double tot[2][256], sl[2][256];
+    bn2_totals(part, blockIdx.x, P, C, tot, sl);
+    if ((int)threadIdx.x < C) {
+        out[((long)blockIdx.x * 2) * C + threadIdx.x] = tot[0][threadIdx.x];
+        out[((long)blockIdx.x * 2 + 1) * C + threadIdx.x] = tot[1][threadIdx.x];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn2_fwd_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long rows_per_group, int C, int groups,
+                                                            const double* __restrict__ part, int P, float* __restrict__ mean, float* __restrict__ rstd,
+                                                            float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float slope, float eps,
+                                                            float momentum, int repeats) {
+    __shared__ double tot[2][256], sl[2][256];
+    __shared__ float s_mean[256], s_rstd[256];
+    const int g = blockIdx.y;
+    const double n = (double)rows_per_group;
+    if (blockIdx.x == 0 && g == 0) {
+        // running statistics: the groups are successive forward calls of the same module -- updated in call order by one workgroup
+        float rm = 0.f, rv = 0.f;
+        if ((int)threadIdx.x < C) { rm = rmean ? rmean[threadIdx.x] : 0.f; rv = rvar ? rvar[threadIdx.x] : 0.f; }
+        for (int gg = 0; gg < groups; ++gg) {
+            bn2_totals(part, gg, P, C, tot, sl);
+            if ((int)threadIdx.x < C) {
+                const int c = threadIdx.x;
+                const double m = tot[0][c] / n;
+                double var = tot[1][c] / n - m * m;
+                if (var < 0.0) var = 0.0;
+                const double unbiased = rows_per_group > 1 ? var * n / (n - 1.0) : var;
+                for (int q = 0; q < repeats; ++q) {
+                    rm = (1.f - momentum) * rm + momentum * (float)m;
+                    rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+                }
+            }
+            __syncthreads();
+        }
+        if ((int)threadIdx.x < C) {
+            if (rmean) rmean[threadIdx.x] = rm;
+            if (rvar) rvar[threadIdx.x] = rv;
+        }
+        if (threadIdx.x == 0 && nbt) *nbt += (int64_t)groups * repeats;
+    }
+    bn2_totals(part, g, P, C, tot, sl);
+    if ((int)threadIdx.x < C) {
+        const int c = threadIdx.x;
+        const double m = tot[0][c] / n;
+        double var = tot[1][c] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+        s_mean[c] = mf; s_rstd[c] = rs;
+        if (blockIdx.x == 0) { mean[g * C + c] = mf; rstd[g * C + c] = rs; }
+    }
+    __syncthreads();
+    if (y == nullptr) return;
+    const long total4 = rows_per_group * C / 4;
+    const long i0 = (long)blockIdx.x * 256 + threadIdx.x, step = (long)gridDim.x * 256;
+    const int c0 = (int)((i0 * 4) % C);
+    float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mu[q] = s_mean[c0 + q]; rs[q] = s_rstd[c0 + q]; ga[q] = gamma[c0 + q]; be[q] = beta[c0 + q]; }
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + (long)g * total4;
+    f32x4* y4 = reinterpret_cast<f32x4*>(y) + (long)g * total4;
+#pragma unroll 4
+    for (long i = i0; i < total4; i += step) {
+        const f32x4 v = x4[i];
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = act_fn((v[q] - mu[q]) * rs[q] * ga[q] + be[q], slope);          // association of bn_apply_kernel
+        y4[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                                            long rows_per_group, int C, int groups, const double* __restrict__ part, int P,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double tot[2][256], sl[2][256];
+    const int g = blockIdx.y;
+    if (blockIdx.x == 0 && g == 0 && (dgamma || dbeta)) {
+        double a = 0.0, b = 0.0;                 // parameter gradients: the groups' sums in group order, one workgroup
+        for (int gg = 0; gg < groups; ++gg) {
+            bn2_totals(part, gg, P, C, tot, sl);
+            if ((int)threadIdx.x < C) { a += tot[0][threadIdx.x]; b += tot[1][threadIdx.x]; }
+            __syncthreads();
+        }
+        if ((int)threadIdx.x < C) {
+            if (dbeta) dbeta[threadIdx.x] += (float)a;
+            if (dgamma) dgamma[threadIdx.x] += (float)b;
+        }
+    }
+    bn2_totals(part, g, P, C, tot, sl);
+    const long total4 = rows_per_group * C / 4;
+    const long i0 = (long)blockIdx.x * 256 + threadIdx.x, step = (long)gridDim.x * 256;
+    const int c0 = (int)((i0 * 4) % C);
+    const double inv_n = 1.0 / (double)rows_per_group;
+    float mu[4], rs[4], ga[4], be[4];
+    double m1[4], m2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        mu[q] = mean[g * C + c0 + q]; rs[q] = rstd[g * C + c0 + q]; ga[q] = gamma[c0 + q]; be[q] = beta[c0 + q];
+        m1[q] = tot[0][c0 + q] * inv_n; m2[q] = tot[1][c0 + q] * inv_n;
+    }
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + (long)g * total4;
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy) + (long)g * total4;
+    f32x4* dx4 = reinterpret_cast<f32x4*>(dx) + (long)g * total4;
+#pragma unroll 2
+    for (long i = i0; i < total4; i += step) {
+        const f32x4 xv = x4[i], dv = dy4[i];
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xh = (xv[q] - mu[q]) * rs[q];
+            const float z = xh * ga[q] + be[q];
+            const float dz = dv[q] * (z >= 0.f ? 1.f : slope);
+            o[q] = (float)((double)(ga[q] * rs[q]) * ((double)dz - m1[q] - (double)xh * m2[q]));     // fp64 means: see bn_bwd_apply_kernel
+        }
+        dx4[i] = o;
+    }
+}
+
 // 16-byte kernels: a thread keeps the same four channels across its grid-stride loop
 inline bool bn_vec_ok(int C, long elems) { return C >= 4 && C <= 256 && C % 4 == 0 && 1024 % C == 0 && elems % 4 == 0; }
 
@@ -484,4 +688,58 @@ extern "C" int tg_bn_backward(const float* dy, const float* x, float* dx, int32_
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)rows * C, 256, 4)), dim3(256), 0, s, dy, x, dx, (long)rows, C, mean, rstd,
                        gamma, beta, act_slope, ws, dgamma, dbeta);
     return check_launch("tg_bn_backward");
+}
+
+// ---- two-launch forms (csrc/norm.hip bn2_*): all `groups` statistics groups of x [groups * rows_per_group][C] in one pair of launches.
+extern "C" int32_t tg_bn2_supported(int32_t rows_per_group, int32_t C) {
+    return rows_per_group > 0 && bn_vec_ok(C, (long)rows_per_group * C) && 256 % C == 0;
+}
+static int bn2_parts(long rows_per_group, int C) {
+    long p = (rows_per_group * C / 4 + 2047) / 2048;
+    return (int)(p < 1 ? 1 : (p > 256 ? 256 : p));
+}
+constexpr int BN2_INLINE_PARTS = 32;          // up to this many partials every apply workgroup combines them itself; beyond, one reduce launch
+extern "C" int64_t tg_bn2_ws_doubles(int32_t rows_per_group, int32_t C, int32_t groups) {
+    return tg_bn2_supported(rows_per_group, C) && groups > 0 ? (int64_t)groups * (bn2_parts(rows_per_group, C) + 1) * 2 * C : 0;
+}
+// partial sums of all groups -> (pointer, count) the apply launch reads
+static const double* bn2_combine(double* ws, int P, int C, int groups, int* p_out, hipStream_t s) {
+    if (P <= BN2_INLINE_PARTS) { *p_out = P; return ws; }
+    double* tot = ws + (long)groups * P * 2 * C;
+    hipLaunchKernelGGL(bn2_reduce_kernel, dim3(groups), dim3(256), 0, s, ws, P, C, tot);
+    *p_out = 1;
+    return tot;
+}
+
+extern "C" int tg_bn2_train(const float* x, float* y, int32_t rows_per_group, int32_t C, int32_t groups, double* ws, int64_t ws_doubles, float* mean,
+                            float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                            const float* beta, float act_slope, float eps, float momentum, int32_t repeats, void* stream) {
+    TG_REQUIRE(x && ws && mean && rstd && groups > 0 && repeats >= 1 && (y == nullptr || (gamma && beta)), "tg_bn2_train: null pointer / bad counts");
+    TG_REQUIRE(tg_bn2_supported(rows_per_group, C) && aligned16(x) && (y == nullptr || aligned16(y)), "tg_bn2_train: unsupported shape C=%d rows=%d (tg_bn2_supported) or unaligned pointers", C, rows_per_group);
+    TG_REQUIRE(ws_doubles >= tg_bn2_ws_doubles(rows_per_group, C, groups), "tg_bn2_train: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int P = bn2_parts(rows_per_group, C);
+    hipLaunchKernelGGL(bn2_partial_kernel, dim3(P, groups), dim3(256), 0, s, x, (const float*)nullptr, (long)rows_per_group, C, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1.f, ws);
+    int Pa;
+    const double* tot = bn2_combine(ws, P, C, groups, &Pa, s);
+    hipLaunchKernelGGL(bn2_fwd_apply_kernel, dim3(P, groups), dim3(256), 0, s, x, y, (long)rows_per_group, C, groups, tot, Pa, mean, rstd, running_mean,
+                       running_var, num_batches_tracked, gamma, beta, act_slope, eps, momentum, repeats);
+    return check_launch("tg_bn2_train");
+}
+
+extern "C" int tg_bn2_backward(const float* dy, const float* x, float* dx, int32_t rows_per_group, int32_t C, int32_t groups, const float* mean,
+                               const float* rstd, const float* gamma, const float* beta, float act_slope, double* ws, int64_t ws_doubles,
+                               float* dgamma, float* dbeta, void* stream) {
+    TG_REQUIRE(dy && x && dx && mean && rstd && gamma && beta && ws && groups > 0, "tg_bn2_backward: null pointer / bad counts");
+    TG_REQUIRE(tg_bn2_supported(rows_per_group, C) && aligned16(dy) && aligned16(x) && aligned16(dx), "tg_bn2_backward: unsupported shape C=%d rows=%d or unaligned pointers", C, rows_per_group);
+    TG_REQUIRE(ws_doubles >= tg_bn2_ws_doubles(rows_per_group, C, groups), "tg_bn2_backward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int P = bn2_parts(rows_per_group, C);
+    hipLaunchKernelGGL(bn2_partial_kernel, dim3(P, groups), dim3(256), 0, s, x, dy, (long)rows_per_group, C, mean, rstd, gamma, beta, act_slope, ws);
+    int Pa;
+    const double* tot = bn2_combine(ws, P, C, groups, &Pa, s);
+    hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3(P, groups), dim3(256), 0, s, dy, x, dx, (long)rows_per_group, C, groups, tot, Pa, mean, rstd, gamma, beta,
+                       act_slope, dgamma, dbeta);
+    return check_launch("tg_bn2_backward");
 }

@@ -272,6 +272,10 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, *, training, groups=1
     g = groups if training else 1
     st.mean, st.rstd = empty(g, Cc, like=x), empty(g, Cc, like=x)
     st.groups, st.x, st.slope = g, x, act_slope
+    if training and x2.shape[0] % g == 0 and ops.bn2_supported(x2.shape[0] // g, Cc, g) and x2.is_contiguous():
+        y = torch.empty_like(x) if out is None else out
+        ops.bn2_train(x2, y.view(-1, Cc), g, st.mean, st.rstd, running_mean, running_var, nbt, gamma, beta, act_slope, repeats=repeats)
+        return y, st
     if training and ops.bn_fused_supported(x2.shape[0], Cc, g):
         y = torch.empty_like(x) if out is None else out
         ops.bn_train_fused(x2, y.view(-1, Cc), g, st.mean, st.rstd, running_mean, running_var, nbt, gamma, beta, act_slope, repeats=repeats)
@@ -295,6 +299,13 @@ def bn_bwd(dy, st, gamma, beta, dgamma, dbeta, *, g0=0, ng=1, row0=0):
     per = nb // ng
     dy = dy.contiguous()
     dx = torch.empty_like(dy)
+    rpg = dy[0].numel() // Cc * per
+    x_all = st.x[row0:row0 + nb]
+    if ops.bn2_supported(rpg, Cc, ng) and x_all.is_contiguous():
+        # every group of the call in one pair of launches
+        ops.bn2_backward(dy.view(-1, Cc), x_all.reshape(-1, Cc), dx.view(-1, Cc), ng, st.mean[g0:g0 + ng], st.rstd[g0:g0 + ng], gamma, beta, st.slope,
+                         dgamma, dbeta)
+        return dx
     ws = torch.empty(2 * Cc, device=dy.device, dtype=torch.float64)
     for g in range(ng):
         sl = slice(g * per, (g + 1) * per)

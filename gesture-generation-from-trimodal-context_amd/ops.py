@@ -429,6 +429,37 @@ def bn_train_fused(x2d, y2d, groups, mean, rstd, running_mean, running_var, nbt,
     return y2d
 
 
+BN2_MIN_ELEMS = 16384        # below: the single-workgroup fused kernels (one launch) win
+
+
+def bn2_supported(rows_per_group, C, groups=1):
+    """True when the two-launch BatchNorm kernels (csrc/norm.hip bn2_*) take this shape."""
+    return rows_per_group * C * groups >= BN2_MIN_ELEMS and bool(_lib.load().tg_bn2_supported(int(rows_per_group), int(C)))
+
+
+def bn2_train(x2d, y2d, groups, mean, rstd, running_mean, running_var, nbt, gamma, beta, act_slope, eps=1e-5, momentum=0.1, repeats=1):
+    _flat(x2d, "x"); rows, Cc = x2d.shape
+    assert rows % groups == 0 and (y2d is None or (_flat(y2d, "y").shape == x2d.shape)) and mean.numel() == groups * Cc == rstd.numel()
+    assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda)
+    rpg = rows // groups
+    ws = torch.empty(_lib.load().tg_bn2_ws_doubles(rpg, Cc, groups), device=x2d.device, dtype=torch.float64)
+    call("tg_bn2_train", _p(x2d), _p(y2d), rpg, Cc, groups, _p(ws), ws.numel(), _p(_flat(mean, "mean")), _p(_flat(rstd, "rstd")), _p(running_mean),
+         _p(running_var), _p(nbt), _p(gamma), _p(beta), float(act_slope), float(eps), float(momentum), int(repeats), _stream())
+    return y2d
+
+
+def bn2_backward(dy2d, x2d, dx2d, groups, mean, rstd, gamma, beta, act_slope, dgamma, dbeta):
+    """mean / rstd: [groups, C] statistics of exactly the groups held by dy / x (contiguous rows, group after group)."""
+    _flat(dy2d, "dy"); _flat(x2d, "x"); _flat(dx2d, "dx"); rows, Cc = x2d.shape
+    assert dy2d.shape == x2d.shape == dx2d.shape and rows % groups == 0 and mean.numel() == groups * Cc == rstd.numel()
+    assert mean.is_contiguous() and rstd.is_contiguous()
+    rpg = rows // groups
+    ws = torch.empty(_lib.load().tg_bn2_ws_doubles(rpg, Cc, groups), device=x2d.device, dtype=torch.float64)
+    call("tg_bn2_backward", _p(dy2d), _p(x2d), _p(dx2d), rpg, Cc, groups, _p(mean), _p(rstd), _p(_flat(gamma, "gamma")), _p(_flat(beta, "beta")),
+         float(act_slope), _p(ws), ws.numel(), _p(dgamma), _p(dbeta), _stream())
+    return dx2d
+
+
 def bn_eval_stats(running_mean, running_var, mean, rstd, eps=1e-5):
     Cc = running_mean.numel()
     call("tg_bn_eval_stats", _p(_flat(running_mean, "rm")), _p(_flat(running_var, "rv")), Cc, float(eps),

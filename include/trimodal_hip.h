@@ -240,6 +240,20 @@ int tg_bn_backward(const float* dy, const float* x, float* dx, int32_t rows, int
                    const float* rstd, const float* gamma, const float* beta, float act_slope, double* ws,
                    float* dgamma, float* dbeta, void* stream);
 
+/* Two-launch forms for tensors past the single-workgroup size: x [groups * rows_per_group][C] holds `groups` stacked forward calls, each
+ * normalised with its own batch statistics (mean / rstd [groups][C]); no zero fill, no atomics, deterministic.  ws: tg_bn2_ws_doubles
+ * doubles of scratch.  tg_bn2_train: statistics, running-stat updates in call order (each `repeats` times) and y = act(BN(x)) (y may be
+ * NULL: statistics only); tg_bn2_backward: dx for all groups and dgamma / dbeta += the groups' sums (either may be NULL).
+ * Supported: C a multiple of 4 that divides 256, rows_per_group * C a multiple of 4, 16-byte aligned pointers. */
+int32_t tg_bn2_supported(int32_t rows_per_group, int32_t C);
+int64_t tg_bn2_ws_doubles(int32_t rows_per_group, int32_t C, int32_t groups);
+int tg_bn2_train(const float* x, float* y, int32_t rows_per_group, int32_t C, int32_t groups, double* ws, int64_t ws_doubles, float* mean,
+                 float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                 const float* beta, float act_slope, float eps, float momentum, int32_t repeats, void* stream);
+int tg_bn2_backward(const float* dy, const float* x, float* dx, int32_t rows_per_group, int32_t C, int32_t groups, const float* mean,
+                    const float* rstd, const float* gamma, const float* beta, float act_slope, double* ws, int64_t ws_doubles,
+                    float* dgamma, float* dbeta, void* stream);
+
 /* ---- WavEncoder front end: Conv1d(1, 16, 15, stride, padding) -> BatchNorm1d(16) -> LeakyReLU, fused ------------------------
  * Replaces feat_extractor[0..2] of model/multimodal_context_net.py:13-15 (and their autograd backward) without materialising the
  * pre-BatchNorm tensor: the convolution is recomputed from the raw audio wherever it is needed (csrc/audio.hip).

@@ -209,7 +209,8 @@ def test_gru_cluster_flag_generations_across_sequence_lengths(pkg, dev):
 
 # ------------------------------------------------------------------------------------------------ BatchNorm
 @pytest.mark.parametrize("rows,C,groups,slope", [(3 * 500, 16, 3, 0.3), (64, 256, 1, 1.0), (2 * 96, 8, 2, 1.0),
-                                                  (2 * 20001, 32, 2, 0.3),       # streaming kernels, 16-byte path
+                                                  (3 * 2048, 8, 3, 1.0), (2 * 600, 64, 2, 0.2),     # two-launch kernels (bn2_*), several groups
+                                                  (2 * 20001, 32, 2, 0.3),       # two-launch kernels, many partial workgroups
                                                   (50001, 12, 1, 0.3)])          # streaming kernels, scalar path (12 does not divide 1024)
 def test_batchnorm_train_eval_backward(pkg, dev, rows, C, groups, slope):
     Lm = pkg.layers
@@ -233,6 +234,15 @@ def test_batchnorm_train_eval_backward(pkg, dev, rows, C, groups, slope):
     dx = Lm.bn_bwd(dy[g_sel * per:(g_sel + 1) * per].float().to(dev), st, gamma.to(dev), beta.to(dev), dg, db, g0=g_sel, ng=1,
                    row0=g_sel * per)
     assert rel(dx, xs.grad[g_sel * per:(g_sel + 1) * per]) < 1e-4 and rel(dg, bn.weight.grad) < 1e-4 and rel(db, bn.bias.grad) < 1e-4
+    if groups > 1:                                   # all groups of the stacked call at once (the discriminator step's real + fake halves)
+        xs2 = x.double().requires_grad_(True)
+        bn2m = torch.nn.BatchNorm1d(C).double()
+        bn2m.weight.data, bn2m.bias.data = gamma.double().clone(), beta.double().clone()
+        ys2 = torch.cat([F.leaky_relu(bn2m(xs2[g * per:(g + 1) * per]), slope) for g in range(groups)])
+        ys2.backward(dy)
+        dg2, db2 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dx2 = Lm.bn_bwd(dy.float().to(dev), st, gamma.to(dev), beta.to(dev), dg2, db2, g0=0, ng=groups, row0=0)
+        assert rel(dx2, xs2.grad) < 1e-4 and rel(dg2, bn2m.weight.grad) < 1e-4 and rel(db2, bn2m.bias.grad) < 1e-4
     bn.eval()
     ye, _ = Lm.bn_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rmg, rvg, nbt, training=False, act_slope=slope)
     assert rel(ye, F.leaky_relu(bn(x.double()), slope)) < 1e-5
