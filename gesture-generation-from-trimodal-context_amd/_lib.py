@@ -69,6 +69,8 @@ SIGNATURES = {
     "tg_wav_front_apply": [P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, P, P],
     "tg_wav_front_backward": [P, P, P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, I64, P, P, P, P, P],
     "tg_wav_front_backward_fused": [P, I32, P, P, P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, I64, P, P, P, P, P],
+    "tg_speaker_fwd": [P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, I64, I32, P],
+    "tg_speaker_bwd": [P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, I32, P],
     "tg_zero": [P, I64, P],
     "tg_permute3_batch": [P, I32, I32, P],
     "tg_add_relu": [P, P, P, I64, P],
@@ -145,6 +147,7 @@ def load():
     lib.tg_gru_cluster_bwd_supported.argtypes = [I32, I32]
     lib.tg_gru_cluster_bwd_ws_bytes.restype = C.c_int64
     lib.tg_gru_cluster_bwd_ws_bytes.argtypes = [I32, I32]
+    lib.tg_speaker_bwd_max_rows.restype = C.c_int32
     lib.tg_bn2_supported.restype = C.c_int32
     lib.tg_bn2_supported.argtypes = [I32, I32]
     lib.tg_bn2_ws_doubles.restype = C.c_int64

@@ -122,18 +122,27 @@ class GeneratorEngine(_Engine):
         if self.use_text:
             self._text_fwd(P, in_text, in_data, tp, training, inject, tag)
         mu = logvar = z = None
+        z_in_place = False
         if self.z_mode == "speaker":
             # ---- speaker embedding -> mu/logvar -> reparameterised z (:125-131; embedding_net.py:10-13)
             assert vid is not None
-            se = ops.embed_gather(P["speaker_embedding.0.weight"], vid.contiguous(), L.empty(Bs, 16, like=pre_seq))
-            zc = L.linear_fwd(se, P["speaker_embedding.1.weight"], P["speaker_embedding.1.bias"])
-            mu = L.linear_fwd(zc, P["speaker_mu.weight"], P["speaker_mu.bias"])
-            logvar = L.linear_fwd(zc, P["speaker_logvar.weight"], P["speaker_logvar.bias"])
             if inject is not None and f"{tag}.eps" in inject:
                 eps = inject[f"{tag}.eps"].contiguous()
             else:
-                eps = ops.normal(torch.empty_like(mu), self.rng.state, self.rng.site(f"{tag}.eps"))
-            z = ops.reparam_fwd(mu, logvar, eps, torch.empty_like(mu))
+                eps = ops.normal(L.empty(Bs, 16, like=pre_seq), self.rng.state, self.rng.site(f"{tag}.eps"))
+            if ops.SPEAKER_FUSED:
+                # gather, three 16 x 16 linears, reparameterisation and the per-frame copy into the GRU input: one launch
+                se, zc, mu, logvar, z = ops.speaker_fwd(P["speaker_embedding.0.weight"], vid.contiguous(), P["speaker_embedding.1.weight"],
+                                                        P["speaker_embedding.1.bias"], P["speaker_mu.weight"], P["speaker_mu.bias"],
+                                                        P["speaker_logvar.weight"], P["speaker_logvar.bias"], eps,
+                                                        rep=in_data.view(Bs * T, in_size)[:, self.c_z:], T=T)
+                z_in_place = True
+            else:
+                se = ops.embed_gather(P["speaker_embedding.0.weight"], vid.contiguous(), L.empty(Bs, 16, like=pre_seq))
+                zc = L.linear_fwd(se, P["speaker_embedding.1.weight"], P["speaker_embedding.1.bias"])
+                mu = L.linear_fwd(zc, P["speaker_mu.weight"], P["speaker_mu.bias"])
+                logvar = L.linear_fwd(zc, P["speaker_logvar.weight"], P["speaker_logvar.bias"])
+                z = ops.reparam_fwd(mu, logvar, eps, torch.empty_like(mu))
             tp.update(se=se, zc=zc, mu=mu, logvar=logvar, eps=eps, vid=vid)
         elif self.z_mode == "random":
             # ---- plain noise vector (:132-134)
@@ -146,7 +155,7 @@ class GeneratorEngine(_Engine):
         fork.join()
         flat_in = in_data.view(Bs * T, in_size)
         ops.copy2d(pre_seq.contiguous().view(Bs * T, D + 1), flat_in[:, :D + 1])
-        if z is not None:
+        if z is not None and not z_in_place:
             ops.repeat_rows(z, flat_in[:, self.c_z:], Bs, T)
 
         # ---- 4-layer bidirectional GRU, sum of directions, output MLP (:155-158)
@@ -273,6 +282,15 @@ class GeneratorEngine(_Engine):
         if self.z_mode == "speaker":
             # speaker path
             dz = ops.sum_rows(d_in2[:, self.c_z:], L.empty(nb, 16, like=d_in), nb, T)
+            if ops.speaker_bwd_supported(nb):
+                # reparameterisation, the three linears' weight / bias / input gradients and the embedding scatter: one launch
+                ops.speaker_bwd(dz, d_mu.contiguous() if d_mu is not None else None, d_logvar.contiguous() if d_logvar is not None else None,
+                                tp["logvar"][rows], tp["eps"][rows], tp["zc"][rows], tp["se"][rows], tp["vid"][rows].contiguous(),
+                                P["speaker_embedding.1.weight"], P["speaker_mu.weight"], P["speaker_logvar.weight"],
+                                G["speaker_embedding.1.weight"], G["speaker_embedding.1.bias"], G["speaker_mu.weight"], G["speaker_mu.bias"],
+                                G["speaker_logvar.weight"], G["speaker_logvar.bias"], G["speaker_embedding.0.weight"])
+                dz = None
+        if self.z_mode == "speaker" and dz is not None:
             dmu = d_mu.clone() if d_mu is not None else ops.zeros_like(dz)
             dlv = d_logvar.clone() if d_logvar is not None else ops.zeros_like(dz)
             ops.reparam_bwd(dz, tp["logvar"][rows], tp["eps"][rows], dmu, dlv)

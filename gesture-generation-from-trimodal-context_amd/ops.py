@@ -750,6 +750,47 @@ def reparam_bwd(dz, logvar, eps, dmu, dlogvar):
     call("tg_reparam_bwd", _p(dz), _p(logvar), _p(eps), _p(dmu), _p(dlogvar), _same(dz, logvar, eps, dmu, dlogvar), _stream())
 
 
+SPEAKER_FUSED = os.environ.get("TG_SPEAKER_FUSED", "1") != "0"
+
+
+def speaker_fwd(table, vid, w1, b1, wmu, bmu, wlv, blv, eps, rep=None, T=0):
+    """Fused speaker path forward -> (se, zc, mu, logvar, z), each [B, 16]; rep: 2-D view [B * T, 16] (row stride free) that receives z per frame."""
+    _flat(table, "table"); _i64(vid, "vid"); _flat(eps, "eps")
+    B = vid.numel()
+    assert table.shape[1] == 16 and tuple(eps.shape) == (B, 16)
+    for w in (w1, wmu, wlv):
+        _flat(w, "w"); assert tuple(w.shape) == (16, 16)
+    for b in (b1, bmu, blv):
+        _flat(b, "b"); assert b.numel() == 16
+    outs = [torch.empty(B, 16, device=table.device) for _ in range(5)]
+    rep_ld = 0
+    if rep is not None:
+        _chk2d(rep, B * T, 16, "rep"); rep_ld = rep.stride(0)
+    call("tg_speaker_fwd", _p(table), _p(vid), table.shape[0], _p(w1), _p(b1), _p(wmu), _p(bmu), _p(wlv), _p(blv), _p(eps), *[_p(o) for o in outs], B,
+         _p(rep), rep_ld, int(T), _stream())
+    return outs
+
+
+def speaker_bwd_supported(nb):
+    return SPEAKER_FUSED and nb <= _lib.load().tg_speaker_bwd_max_rows()
+
+
+def speaker_bwd(dz, d_mu, d_logvar, logvar, eps, zc, se, vid, w1, wmu, wlv, dw1, db1, dwmu, dbmu, dwlv, dblv, dtable):
+    nb = dz.shape[0]
+    for t in (dz, logvar, eps, zc, se):
+        _flat(t, "operand"); assert tuple(t.shape) == (nb, 16), t.shape
+    for t in (d_mu, d_logvar):
+        assert t is None or (_flat(t, "direct gradient").shape == dz.shape)
+    _i64(vid, "vid"); assert vid.numel() == nb
+    for t in (w1, wmu, wlv, dw1, dwmu, dwlv):
+        _flat(t, "w"); assert t.numel() == 256
+    for t in (db1, dbmu, dblv):
+        _flat(t, "b"); assert t.numel() == 16
+    _flat(dtable, "dtable"); assert dtable.shape[1] == 16
+    call("tg_speaker_bwd", _p(dz), _p(d_mu), _p(d_logvar), _p(logvar), _p(eps), _p(zc), _p(se), _p(vid), dtable.shape[0], _p(w1), _p(wmu), _p(wlv),
+         _p(dw1), _p(db1), _p(dwmu), _p(dbmu), _p(dwlv), _p(dblv), _p(dtable), nb, _stream())
+
+
 def gan_d_loss(logit_real, logit_fake, out, d_real, d_fake):
     B = _same(logit_real, logit_fake, d_real, d_fake); _flat(out, "out")
     call("tg_gan_d_loss", _p(logit_real), _p(logit_fake), B, _p(out), _p(d_real), _p(d_fake), _stream())

@@ -254,6 +254,19 @@ int tg_bn2_backward(const float* dy, const float* x, float* dx, int32_t rows_per
                     const float* rstd, const float* gamma, const float* beta, float act_slope, double* ws, int64_t ws_doubles,
                     float* dgamma, float* dbeta, void* stream);
 
+/* ---- speaker / style path (model/multimodal_context_net.py:83-95,125-137; embedding_net.py:10-13), fused ------------------------------
+ * forward: se = table[vid], zc = W1 se + b1, mu = Wmu zc + bmu, logvar = Wlv zc + blv, z = mu + eps * exp(0.5 logvar) (all [B][16]); with
+ * rep != NULL also rep[(b * T + t) * rep_ld + j] = z[b][j] (the style columns of the GRU input).
+ * backward (nb <= tg_speaker_bwd_max_rows()): dz [nb][16] = gradient w.r.t. z; d_mu_in / d_logvar_in: direct gradients or NULL; every
+ * parameter gradient accumulates; dtable rows meet in float atomics. */
+int tg_speaker_fwd(const float* table, const int64_t* vid, int32_t n_rows, const float* w1, const float* b1, const float* wmu, const float* bmu,
+                   const float* wlv, const float* blv, const float* eps, float* se, float* zc, float* mu, float* logvar, float* z,
+                   int32_t B, float* rep, int64_t rep_ld, int32_t T, void* stream);
+int32_t tg_speaker_bwd_max_rows(void);
+int tg_speaker_bwd(const float* dz, const float* d_mu_in, const float* d_logvar_in, const float* logvar, const float* eps, const float* zc,
+                   const float* se, const int64_t* vid, int32_t n_rows, const float* w1, const float* wmu, const float* wlv, float* dw1,
+                   float* db1, float* dwmu, float* dbmu, float* dwlv, float* dblv, float* dtable, int32_t nb, void* stream);
+
 /* ---- WavEncoder front end: Conv1d(1, 16, 15, stride, padding) -> BatchNorm1d(16) -> LeakyReLU, fused ------------------------
  * Replaces feat_extractor[0..2] of model/multimodal_context_net.py:13-15 (and their autograd backward) without materialising the
  * pre-BatchNorm tensor: the convolution is recomputed from the raw audio wherever it is needed (csrc/audio.hip).
