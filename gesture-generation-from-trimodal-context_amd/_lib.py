@@ -71,6 +71,7 @@ SIGNATURES = {
     "tg_wav_front_backward_fused": [P, I32, P, P, P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, I64, P, P, P, P, P],
     "tg_speaker_fwd": [P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, I64, I32, P],
     "tg_speaker_bwd": [P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, I32, P],
+    "tg_wav_conv2_wgrad": [P, P, I32, I32, I32, P, I64, P, P, P],
     "tg_zero": [P, I64, P],
     "tg_permute3_batch": [P, I32, I32, P],
     "tg_add_relu": [P, P, P, I64, P],
@@ -152,7 +153,7 @@ def load():
     lib.tg_bn2_supported.argtypes = [I32, I32]
     lib.tg_bn2_ws_doubles.restype = C.c_int64
     lib.tg_bn2_ws_doubles.argtypes = [I32, I32, I32]
-    for q, at in (("tg_wav_front_ws_doubles", []), ("tg_wav_front_fstat_doubles", []), ("tg_wav_front_gate_words", [I32, I32])):
+    for q, at in (("tg_wav_conv2_wgrad_ws_floats", []), ("tg_wav_front_ws_doubles", []), ("tg_wav_front_fstat_doubles", []), ("tg_wav_front_gate_words", [I32, I32])):
         getattr(lib, q).restype = C.c_int64
         getattr(lib, q).argtypes = at
     for name, argtypes in SIGNATURES.items():

@@ -517,6 +517,94 @@ __global__ __launch_bounds__(1024) void wav_bwd_finalize_kernel(const double* __
     }
 }
 
+// ---- weight gradient of the second conv, Conv1d(16, 32, 15, stride 6) -------------------------------------------------------------------
+//   dW2[co][ci][k] = sum_{b, q} dc2[b, q, co] act[b, 6 q + k, ci]        db2[co] = sum dc2[b, q, co]
+// a [32 x 240] result reduced over B * T2 = 168 k rows.  The generic weight-gradient GEMM tiles the OUTPUT (64 x 64, N = 32 fills half a
+// tile) and re-reads the 65 MB activation through its tap windows per tile column: 75 us + 24 us of partial combine.  Here a wave keeps the WHOLE
+// result -- 2 (co tiles) x 16 (taps; tap 15 is a ones column that yields db2) accumulators of v_mfma_f32_16x16x4_f32 = 128 registers -- and
+// walks its share of the rows four at a time: 2 loads of dc2 and 15 of the activation rows feed 32 MFMAs; each activation row is read once
+// from HBM (re-used by the 2-3 taps that touch it out of L1).  Per-wave results meet in LDS, per-workgroup partials in a fixed-order fp64
+// combine (wav_conv2_wgrad_reduce_kernel).
+constexpr int WV_W2_WGS = 256, WV_W2_THREADS = 768;        // 12 waves = 3 per SIMD (151 registers): what hides the groups' load latency
+constexpr int WV_W2_OUT = WV_C2 * 16 * WV_CO;          // 32 co x 16 taps (15 + ones) x 16 ci = 8192 partial sums
+
+__global__ __launch_bounds__(WV_W2_THREADS) void wav_conv2_wgrad_kernel(const float* __restrict__ dc2, const float* __restrict__ act, int B, int T1, int T2,
+                                                                        float* __restrict__ partial) {
+    __shared__ float red[WV_W2_OUT];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    const int r16 = l & 15, kq = l >> 4;
+    constexpr int nwaves = WV_W2_THREADS / 64;
+    for (int i = threadIdx.x; i < WV_W2_OUT; i += WV_W2_THREADS) red[i] = 0.f;
+    __syncthreads();
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { acc[k][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int GQ = (T2 + 3) / 4;                          // groups of four output frames per clip
+    const int groups = B * GQ;
+    const int gstep = gridDim.x * nwaves;
+    struct Grp { float a[2]; float x[15]; };
+    auto load_group = [&](int gi, Grp& G_) {
+        const int gc = gi < groups ? gi : groups - 1;
+        const int b = gc / GQ, q0 = (gc - b * GQ) * 4;
+        const int q = q0 + kq;
+        const bool ok = gi < groups && q < T2;
+        const int qc = q < T2 ? q : T2 - 1;
+        const float* dp = dc2 + ((long)b * T2 + qc) * WV_C2 + r16;
+        const float a0 = dp[0], a1 = dp[16];
+        G_.a[0] = ok ? a0 : 0.f;                          // rows past the clip (or past the wave's range) contribute nothing
+        G_.a[1] = ok ? a1 : 0.f;
+        const float* xp = act + ((long)b * T1 + WV_S2 * qc) * WV_CO + r16;      // 6 qc + 14 <= T1 - 1 by the conv geometry
+#pragma unroll
+        for (int k = 0; k < WV_KW2; ++k) G_.x[k] = xp[k * WV_CO];
+    };
+    Grp cur, nxt;
+    const float one = r16 == 0 ? 1.f : 0.f;               // tap 15: column 0 of a ones matrix -> sum of dc2 (the bias gradient)
+    int gi = blockIdx.x * nwaves + wave;
+    load_group(gi, cur);
+    for (; gi < groups; gi += gstep) {
+        load_group(gi + gstep, nxt);                      // next group's 17 requests in flight behind this group's 32 MFMAs
+#pragma unroll
+        for (int k = 0; k < WV_KW2; ++k) {
+            acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[0], cur.x[k], acc[k][0], 0, 0, 0);
+            acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[1], cur.x[k], acc[k][1], 0, 0, 0);
+        }
+        acc[15][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[0], one, acc[15][0], 0, 0, 0);
+        acc[15][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[1], one, acc[15][1], 0, 0, 0);
+        cur = nxt;
+    }
+    // (a ring of three register sets -- two groups of requests in flight -- measured SLOWER: 87 us against 51)
+    // accumulator (tap k, co tile ct): lane holds rows co = 16 ct + 4 kq + i, column ci = r16 -> red[co][k][ci]
+    for (int w = 0; w < nwaves; ++w) {                    // the waves add their results one after the other: fixed order, no atomics
+        if (wave == w) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) red[((16 * ct + 4 * kq + i) * 16 + k) * WV_CO + r16] += acc[k][ct][i];
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < WV_W2_OUT; i += WV_W2_THREADS) partial[(long)blockIdx.x * WV_W2_OUT + i] = red[i];
+}
+
+// fixed-order fp64 combine of the workgroup partials: four threads per entry (each a quarter of the partial list, loads in flight together)
+__global__ __launch_bounds__(256) void wav_conv2_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ dW2,
+                                                                     float* __restrict__ db2) {
+    const int e = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    double s = 0.0;
+#pragma unroll 8
+    for (int q = sub; q < nparts; q += 4) s += (double)partial[(long)q * WV_W2_OUT + e];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (sub == 0) {
+        const int co = e / 256, k = (e >> 4) & 15, ci = e & 15;
+        if (k < WV_KW2) { if (dW2) dW2[(co * WV_CO + ci) * WV_KW2 + k] += (float)s; }
+        else if (ci == 0 && db2) db2[co] += (float)s;
+    }
+}
+
 static int wav_geom(WavGeom& g, const char* who, const float* audio, int64_t audio_stride, int32_t B, int32_t L, int32_t stride, int32_t pad, int32_t T1) {
     TG_REQUIRE(audio && B > 0 && L > 0 && stride > 0 && pad >= 0 && T1 > 0 && audio_stride >= L, "%s: bad audio geometry (B=%d L=%d stride=%d pad=%d T1=%d)", who, B, L,
                stride, pad, T1);
@@ -596,4 +684,18 @@ extern "C" int tg_wav_front_backward_fused(const float* dc2, int32_t T2, const f
     hipLaunchKernelGGL(wav_bwd_fused_kernel, dim3(wgs), dim3(WV_BWD_THREADS), 0, s, g, dc2, T2, w2, reinterpret_cast<const unsigned long long*>(gate), act_slope, ws);
     hipLaunchKernelGGL(wav_bwd_finalize_kernel, dim3(WV_CO), dim3(1024), 0, s, ws, wgs, (long)B * T1, fstat, w, bias, mean, rstd, gamma, dW, dbias, dgamma, dbeta);
     return check_launch("tg_wav_front_backward_fused");
+}
+
+extern "C" int64_t tg_wav_conv2_wgrad_ws_floats(void) { return (int64_t)WV_W2_WGS * WV_W2_OUT; }
+
+extern "C" int tg_wav_conv2_wgrad(const float* dc2, const float* act, int32_t B, int32_t T1, int32_t T2, float* ws, int64_t ws_floats, float* dW2,
+                                  float* db2, void* stream) {
+    TG_REQUIRE(dc2 && act && ws && B > 0 && T1 >= WV_KW2 && T2 == (T1 - WV_KW2) / WV_S2 + 1, "tg_wav_conv2_wgrad: bad arguments (T2=%d is not the conv length of T1=%d)", T2, T1);
+    TG_REQUIRE((long)B * T1 * WV_CO < (1L << 31) && ws_floats >= tg_wav_conv2_wgrad_ws_floats(), "tg_wav_conv2_wgrad: problem too large / workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const long groups = (long)B * ((T2 + 3) / 4);
+    const int wgs = groups < (long)WV_W2_WGS * (WV_W2_THREADS / 64) ? cdiv(groups, WV_W2_THREADS / 64) : WV_W2_WGS;
+    hipLaunchKernelGGL(wav_conv2_wgrad_kernel, dim3(wgs), dim3(WV_W2_THREADS), 0, s, dc2, act, B, T1, T2, ws);
+    hipLaunchKernelGGL(wav_conv2_wgrad_reduce_kernel, dim3(WV_W2_OUT / 64), dim3(256), 0, s, ws, wgs, dW2, db2);
+    return check_launch("tg_wav_conv2_wgrad");
 }

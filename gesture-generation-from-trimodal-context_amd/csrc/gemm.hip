@@ -699,8 +699,11 @@ static int nt_launch(NtGroup& g, hipStream_t s) {
         const int wgs = fam == 1 ? nt_layout(g, 128, 32) : nt_layout(g, 64, 64);
         const dim3 grid(wgs);
         const bool deep = wgs < 1024 && Kx >= 256;        // operand ring of 4 k-steps: small grid, long reduction (see the kernel)
+        static const int mid_ring = [] { const char* e = getenv("TG_NT_NARROW_RING"); return e ? atoi(e) : 1; }();      // lab switch: ring depth of the chip-filling narrow grids with K >= 64
         if (fam == 1) {
             if (vec && deep) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 4>), grid, dim3(256), 0, s, g);
+            else if (vec && mid_ring == 2 && Kx >= 64) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 2>), grid, dim3(256), 0, s, g);
+            else if (vec && mid_ring == 4 && Kx >= 64) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 4>), grid, dim3(256), 0, s, g);
             else if (vec)    hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 1>), grid, dim3(256), 0, s, g);
             else             hipLaunchKernelGGL((gemm_nt_kernel<false, 4, 1, 1>), grid, dim3(256), 0, s, g);
         } else {

@@ -361,7 +361,10 @@ class GeneratorEngine(_Engine):
             idx, Co, Ci, stride, pad = WAV_CONVS[li]
             x_in, st, _ = tp["wav"][li]                     # input of conv li (post BN+act of the previous block)
             x_rows = x_in[wrows]
-            L.conv_wgrad(dyw, x_rows, G[f"{fe}.{idx}.weight"], G[f"{fe}.{idx}.bias"], WAV_KW, stride=stride, pad=pad)
+            if li == 1 and ops.WAV_FUSED and (Co, Ci, stride, pad) == (32, 16, 6, 0) and x_rows.is_contiguous():
+                ops.wav_conv2_wgrad(dyw.contiguous(), x_rows, G[f"{fe}.{idx}.weight"], G[f"{fe}.{idx}.bias"])     # whole result per wave: one pass over the 65 MB activation
+            else:
+                L.conv_wgrad(dyw, x_rows, G[f"{fe}.{idx}.weight"], G[f"{fe}.{idx}.bias"], WAV_KW, stride=stride, pad=pad)
             if li == 0:
                 break
             pidx = WAV_CONVS[li - 1][0] + 1

@@ -560,6 +560,23 @@ def wav_front_backward_fused(dc2, w2, gate, audio, w, bias, stride, pad, mean, r
          _p(dW), _p(dbias), _p(dgamma), _p(dbeta), _stream())
 
 
+_w2_ws = {}
+
+
+def wav_conv2_wgrad(dc2, act, dW2, db2):
+    """dW2 (32, 16, 15) / db2 (32) += the gradients of Conv1d(16, 32, 15, stride 6) for dc2 (B, T2, 32) over act (B, T1, 16): one pass, deterministic."""
+    _flat(dc2, "dc2"); _flat(act, "act")
+    B, T1, _ = act.shape
+    T2 = (T1 - 15) // 6 + 1
+    assert act.shape[2] == 16 and tuple(dc2.shape) == (B, T2, 32), (act.shape, dc2.shape)
+    assert dW2 is None or (_flat(dW2, "dW2").numel() == 32 * 16 * 15)
+    assert db2 is None or (_flat(db2, "db2").numel() == 32)
+    ws = _w2_ws.get(act.device)
+    if ws is None:
+        ws = _w2_ws[act.device] = torch.empty(_lib.load().tg_wav_conv2_wgrad_ws_floats(), device=act.device)
+    call("tg_wav_conv2_wgrad", _p(dc2), _p(act), B, T1, T2, _p(ws), ws.numel(), _p(dW2), _p(db2), _stream())
+
+
 # ------------------------------------------------------------------------------------------------- element-wise
 def _same(*ts):
     n = ts[0].numel()

@@ -301,6 +301,13 @@ int tg_wav_front_backward_fused(const float* dc2, int32_t T2, const float* w2, c
                                 const float* mean, const float* rstd, const float* gamma, const double* fstat, float act_slope, double* ws,
                                 int64_t ws_doubles, float* dW, float* dbias, float* dgamma, float* dbeta, void* stream);
 
+/* Weight and bias gradient of feat_extractor[3] = Conv1d(16, 32, 15, stride 6): dW2 [32][16][15] += sum dc2[b, q, co] act[b, 6 q + k, ci],
+ * db2 [32] += sum dc2 (either may be NULL); act [B][T1][16], dc2 [B][T2][32], T2 = (T1 - 15) / 6 + 1.  ws: tg_wav_conv2_wgrad_ws_floats()
+ * floats of scratch.  One pass over the activation, deterministic. */
+int64_t tg_wav_conv2_wgrad_ws_floats(void);
+int tg_wav_conv2_wgrad(const float* dc2, const float* act, int32_t B, int32_t T1, int32_t T2, float* ws, int64_t ws_floats, float* dW2,
+                       float* db2, void* stream);
+
 /* ---- element-wise / data movement ------------------------------------------------------------------- */
 /* y = max(a + b, 0)  (model/tcn.py:46);  dx = dy * (y > 0). */
 int tg_add_relu(const float* a, const float* b, float* y, int64_t n, void* stream);

@@ -732,3 +732,21 @@ def test_gemm_nt_planes_conv_window(pkg, dev):
     ops.gemm_nt_planes_group([dict(A=a_pl, Bp=b_pl, bias=bias.to(dev), out=out, taps=2, batches=B, batch_rows=T, rows_in=T, rows_out=T,
                                    shift=-d, dil=d)])
     assert rel(out.view(B, T, Co), cl(ref)) < 1e-5
+
+
+@pytest.mark.parametrize("B,T1", [(3, 217), (5, 1313), (2, 7891)])
+def test_wav_conv2_weight_gradient(pkg, dev, B, T1):
+    """Specialised weight / bias gradient of Conv1d(16, 32, 15, stride 6) (csrc/audio.hip) vs torch fp64 autograd; accumulates; frame counts
+    that leave a partial group of four output frames."""
+    ops = pkg.ops
+    x = rnd(B, 16, T1, seed=71)
+    w = rnd(32, 16, 15, seed=72, scale=0.1).double().requires_grad_(True)
+    b = rnd(32, seed=73).double().requires_grad_(True)
+    y = F.conv1d(x.double(), w, b, stride=6)
+    dy = rnd(B, 32, y.shape[2], seed=74)
+    gw, gb = torch.autograd.grad(y, (w, b), dy.double())
+    dW, db = torch.zeros(32, 16, 15, device=dev), torch.zeros(32, device=dev)
+    ops.wav_conv2_wgrad(cl(dy).to(dev), cl(x).to(dev), dW, db)
+    assert rel(dW, gw) < 1e-4 and rel(db, gb) < 1e-4, (rel(dW, gw), rel(db, gb))
+    ops.wav_conv2_wgrad(cl(dy).to(dev), cl(x).to(dev), dW, None)
+    assert rel(dW, 2 * gw) < 1e-4 and rel(db, gb) < 1e-4
