@@ -76,6 +76,7 @@ SIGNATURES = {
     "tg_permute3_batch": [P, I32, I32, P],
     "tg_add_relu": [P, P, P, I64, P],
     "tg_act_mask_bwd": [P, P, P, F32, P, I64, P],
+    "tg_act_mask_bwd2": [P, P, P, P, F32, P, P, I64, P],
     "tg_mul": [P, P, P, I64, P],
     "tg_axpy": [P, P, F32, I32, I64, P],
     "tg_copy2d": [P, I64, P, I64, I32, I32, I32, P],

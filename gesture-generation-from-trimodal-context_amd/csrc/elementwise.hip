@@ -27,18 +27,57 @@ int zero_async(void* p, size_t bytes, hipStream_t s) {
     return check_launch("zero_async");
 }
 
-__global__ void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
-    GRID_STRIDE(i, n) { const float v = a[i] + b[i]; y[i] = v > 0.f ? v : 0.f; }
-}
-__global__ void act_mask_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ mask, float slope,
-                                    float* __restrict__ dx, long n) {
+// 16-byte forms (n % 4 == 0, aligned pointers: checked by the launchers) of the residual-block glue; V = f32x4 or float
+template <typename V>
+__global__ void add_relu_vkernel(const V* __restrict__ a, const V* __restrict__ b, V* __restrict__ y, long n) {
+    constexpr int W = sizeof(V) / 4;
     GRID_STRIDE(i, n) {
-        float g = dy[i] * (y[i] > 0.f ? 1.f : slope);
-        if (mask) g *= mask[i];
-        dx[i] = g;
+        const V av = a[i], bv = b[i];
+        V o;
+        for (int q = 0; q < W; ++q) { const float v = ((const float*)&av)[q] + ((const float*)&bv)[q]; ((float*)&o)[q] = v > 0.f ? v : 0.f; }
+        y[i] = o;
     }
 }
-__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ y, long n) {
+template <typename V>
+__global__ void act_mask_bwd_kernel(const V* __restrict__ dy, const V* __restrict__ y, const V* __restrict__ mask, float slope, V* __restrict__ dx, long n) {
+    constexpr int W = sizeof(V) / 4;
+    GRID_STRIDE(i, n) {
+        const V dv = dy[i], yv = y[i];
+        V mv = dv;
+        if (mask) mv = mask[i];
+        V o;
+        for (int q = 0; q < W; ++q) {
+            float g = ((const float*)&dv)[q] * (((const float*)&yv)[q] > 0.f ? 1.f : slope);
+            if (mask) g *= ((const float*)&mv)[q];
+            ((float*)&o)[q] = g;
+        }
+        dx[i] = o;
+    }
+}
+// two gates of a residual block in one pass (model/tcn.py:46 backward): dsum = dy * (y > 0) -- the gradient at relu(out + x), kept for the
+// residual branch -- and dc = dsum * (o > 0 ? 1 : slope) * mask, the gradient at the block's second conv
+template <typename V>
+__global__ void act_mask_bwd2_kernel(const V* __restrict__ dy, const V* __restrict__ y, const V* __restrict__ o, const V* __restrict__ mask, float slope,
+                                     V* __restrict__ dsum, V* __restrict__ dc, long n) {
+    constexpr int W = sizeof(V) / 4;
+    GRID_STRIDE(i, n) {
+        const V dv = dy[i], yv = y[i], ov = o[i];
+        V mv = dv;
+        if (mask) mv = mask[i];
+        V s_, c_;
+        for (int q = 0; q < W; ++q) {
+            const float g = ((const float*)&dv)[q] * (((const float*)&yv)[q] > 0.f ? 1.f : 0.f);
+            float h = g * (((const float*)&ov)[q] > 0.f ? 1.f : slope);
+            if (mask) h *= ((const float*)&mv)[q];
+            ((float*)&s_)[q] = g;
+            ((float*)&c_)[q] = h;
+        }
+        dsum[i] = s_;
+        dc[i] = c_;
+    }
+}
+template <typename V>
+__global__ void mul_kernel(const V* __restrict__ x, const V* __restrict__ m, V* __restrict__ y, long n) {
     GRID_STRIDE(i, n) y[i] = x[i] * m[i];
 }
 __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, float alpha, int acc, long n) {
@@ -526,13 +565,23 @@ extern "C" {
 
 int tg_add_relu(const float* a, const float* b, float* y, int64_t n, void* stream) {
     TG_REQUIRE(a && b && y && n >= 0, "tg_add_relu: bad arguments");
-    EW(add_relu_kernel, n, a, b, y, (long)n);
+    if (n % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(y)) EW(add_relu_vkernel<f32x4>, n / 4, (const f32x4*)a, (const f32x4*)b, (f32x4*)y, (long)n / 4);
+    else EW(add_relu_vkernel<float>, n, a, b, y, (long)n);
     return check_launch("tg_add_relu");
 }
 int tg_act_mask_bwd(const float* dy, const float* y, const float* mask, float slope, float* dx, int64_t n, void* stream) {
     TG_REQUIRE(dy && y && dx && n >= 0, "tg_act_mask_bwd: bad arguments");
-    EW(act_mask_bwd_kernel, n, dy, y, mask, slope, dx, (long)n);
+    if (n % 4 == 0 && aligned16(dy) && aligned16(y) && aligned16(dx) && (!mask || aligned16(mask)))
+        EW(act_mask_bwd_kernel<f32x4>, n / 4, (const f32x4*)dy, (const f32x4*)y, (const f32x4*)mask, slope, (f32x4*)dx, (long)n / 4);
+    else EW(act_mask_bwd_kernel<float>, n, dy, y, mask, slope, dx, (long)n);
     return check_launch("tg_act_mask_bwd");
+}
+int tg_act_mask_bwd2(const float* dy, const float* y, const float* o, const float* mask, float slope, float* dsum, float* dc, int64_t n, void* stream) {
+    TG_REQUIRE(dy && y && o && dsum && dc && n >= 0, "tg_act_mask_bwd2: bad arguments");
+    if (n % 4 == 0 && aligned16(dy) && aligned16(y) && aligned16(o) && aligned16(dsum) && aligned16(dc) && (!mask || aligned16(mask)))
+        EW(act_mask_bwd2_kernel<f32x4>, n / 4, (const f32x4*)dy, (const f32x4*)y, (const f32x4*)o, (const f32x4*)mask, slope, (f32x4*)dsum, (f32x4*)dc, (long)n / 4);
+    else EW(act_mask_bwd2_kernel<float>, n, dy, y, o, mask, slope, dsum, dc, (long)n);
+    return check_launch("tg_act_mask_bwd2");
 }
 int tg_zero(void* p, int64_t bytes, void* stream) {
     TG_REQUIRE(p != nullptr && bytes >= 0 && bytes % 4 == 0, "tg_zero: null pointer or size %ld not a non-negative multiple of 4", (long)bytes);
@@ -540,7 +589,8 @@ int tg_zero(void* p, int64_t bytes, void* stream) {
 }
 int tg_mul(const float* x, const float* mask, float* y, int64_t n, void* stream) {
     TG_REQUIRE(x && mask && y && n >= 0, "tg_mul: bad arguments");
-    EW(mul_kernel, n, x, mask, y, (long)n);
+    if (n % 4 == 0 && aligned16(x) && aligned16(mask) && aligned16(y)) EW(mul_kernel<f32x4>, n / 4, (const f32x4*)x, (const f32x4*)mask, (f32x4*)y, (long)n / 4);
+    else EW(mul_kernel<float>, n, x, mask, y, (long)n);
     return check_launch("tg_mul");
 }
 int tg_axpy(const float* x, float* y, float alpha, int32_t accumulate, int64_t n, void* stream) {

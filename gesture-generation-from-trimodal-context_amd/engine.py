@@ -315,13 +315,16 @@ class GeneratorEngine(_Engine):
                 blk = tp["tcn"][i]
                 d = blk["d"]
                 Cc = dcur.shape[1]
-                dsum = ops.act_mask_bwd(dcur, blk["y"][rows].reshape(M, Cc), None, 0.0, torch.empty_like(dcur))   # relu(out + x)
+                # relu(out + x) and the second conv's relu + dropout gate in one pass
+                o1, m1 = blk["o1"][rows].reshape(M, -1), blk["m1"]
+                dsum, dc_top = ops.act_mask_bwd2(dcur, blk["y"][rows].reshape(M, Cc), o1, None if m1 is None else m1[rows].reshape(M, -1), 0.0,
+                                                 torch.empty_like(dcur), torch.empty_like(o1))
                 dh = dsum
                 for ci, name in ((1, "conv2"), (0, "conv1")):
                     pre = f"{te}.tcn.network.{i}.{name}"
                     o = blk[f"o{ci}"][rows].reshape(M, -1)
                     m = blk[f"m{ci}"]
-                    dc = ops.act_mask_bwd(dh, o, None if m is None else m[rows].reshape(M, -1), 0.0, torch.empty_like(o))
+                    dc = dc_top if ci == 1 else ops.act_mask_bwd(dh, o, None if m is None else m[rows].reshape(M, -1), 0.0, torch.empty_like(o))
                     dc3 = dc.view(nb, T, -1)
                     xin = blk[f"in{ci}"][rows]
                     v = P[pre + ".weight_v"]

@@ -594,6 +594,12 @@ def act_mask_bwd(dy, y, mask, slope, dx):
     call("tg_act_mask_bwd", _p(dy), _p(y), _p(mask), float(slope), _p(dx), n, _stream()); return dx
 
 
+def act_mask_bwd2(dy, y, o, mask, slope, dsum, dc):
+    """(dsum, dc): dsum = dy * (y > 0), dc = dsum * (o > 0 ? 1 : slope) * mask -- both gates of a residual block's backward in one pass."""
+    n = _same(dy, y, o, dsum, dc) if mask is None else _same(dy, y, o, mask, dsum, dc)
+    call("tg_act_mask_bwd2", _p(dy), _p(y), _p(o), _p(mask), float(slope), _p(dsum), _p(dc), n, _stream()); return dsum, dc
+
+
 def mul(x, mask, y):
     call("tg_mul", _p(x), _p(mask), _p(y), _same(x, mask, y), _stream()); return y
 

@@ -311,6 +311,8 @@ int tg_wav_conv2_wgrad(const float* dc2, const float* act, int32_t B, int32_t T1
 /* ---- element-wise / data movement ------------------------------------------------------------------- */
 /* y = max(a + b, 0)  (model/tcn.py:46);  dx = dy * (y > 0). */
 int tg_add_relu(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* both gates of a residual block's backward in one pass: dsum = dy * (y > 0); dc = dsum * (o > 0 ? 1 : slope) * mask (mask may be NULL) */
+int tg_act_mask_bwd2(const float* dy, const float* y, const float* o, const float* mask, float slope, float* dsum, float* dc, int64_t n, void* stream);
 /* dx = dy * mask * (y > 0 ? 1 : slope); mask may be NULL (=1).  Backward of act() followed by dropout. */
 int tg_act_mask_bwd(const float* dy, const float* y, const float* mask, float slope, float* dx, int64_t n,
                     void* stream);

@@ -299,6 +299,21 @@ def test_elementwise_family(pkg, dev):
     assert rel(ops.sigmoid_bwd(b, sg, torch.empty_like(a)), b.cpu().double() * sg.cpu().double() * (1 - sg.cpu().double())) < 1e-6
 
 
+def test_residual_block_gates_one_pass(pkg, dev):
+    ops = pkg.ops
+    for n in (4096, 1003):                                       # 16-byte and scalar paths
+        dy, y, o = rnd(n, seed=81).to(dev), rnd(n, seed=82).to(dev), rnd(n, seed=83).to(dev)
+        m = ((torch.rand(n, generator=torch.Generator().manual_seed(9)) > 0.3).float() / 0.7).to(dev)
+        dsum, dc = ops.act_mask_bwd2(dy, y, o, m, 0.0, torch.empty_like(dy), torch.empty_like(dy))
+        ref_s = dy * (y > 0).float()
+        assert torch.equal(dsum, ref_s) and torch.equal(dc, ref_s * (o > 0).float() * m)
+        dsum2, dc2 = ops.act_mask_bwd2(dy, y, o, None, 0.2, torch.empty_like(dy), torch.empty_like(dy))
+        assert torch.equal(dc2, ref_s * torch.where(o > 0, torch.ones_like(o), torch.full_like(o, 0.2)))
+        assert torch.equal(ops.act_mask_bwd(dy, y, m, 0.0, torch.empty_like(dy)), ref_s * m)
+        assert torch.equal(ops.mul(dy, m, torch.empty_like(dy)), dy * m)
+        assert torch.equal(ops.add_relu(dy, y, torch.empty_like(dy)), torch.relu(dy + y))
+
+
 def test_embedding_gather_scatter(pkg, dev):
     ops = pkg.ops
     V, D, n = 50, 300, 4 * 34
