@@ -494,13 +494,15 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
     rows = slice(b0, b0 + nb)
     dh = empty(4 * nb * H, like=dy)
     fk = fork if fork is not None else Fork(dy.device, enabled=False)
+    scaled = False               # dy already carries the dropout scale of the layer below (applied in the input-gradient GEMM's epilogue)
     for l in range(n_layers - 1, -1, -1):
         dy_mask = None
-        if tape.masks[l] is not None:
+        if tape.masks[l] is not None and not scaled:
             if ops.gru_fused_dropout(nb, H, bwd=True):
                 dy_mask = tape.masks[l][rows].contiguous()         # multiplied in while the recurrence kernel loads dy
             else:
                 dy = ops.mul(dy, tape.masks[l][rows].contiguous(), torch.empty_like(dy))
+        scaled = False
         wt = tuple(transpose2d(P[f"{prefix}.weight_hh_l{l}{s}"]) for s in ("", "_reverse"))
         dgi, dgh = empty(2, nb, T, 3 * H, like=dy), empty(2, nb, T, 3 * H, like=dy)
         ops.gru_backward(dy.contiguous(), tape.y[l], tape.save[l], wt, dgi, dgh, dh, b0=b0, nb=nb, dy_mask=dy_mask)
@@ -526,10 +528,16 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
             seg = (wt_ih[1].data_ptr() - wt_ih[0].data_ptr()) // 4
             if nb * T >= 1024 and Kin >= 48 and (wt_ih[1].data_ptr() - wt_ih[0].data_ptr()) % 16 == 0:
                 # dx = [dgi_fwd | dgi_rev] @ [W_ih_fwd ; W_ih_rev]: ONE product over the concatenated K = 6H -- the two directions are
-                # two "taps" of the A window (dgi is [2][nb*T][3H]) and two segments of the weight operand
+                # two "taps" of the A window (dgi is [2][nb*T][3H]) and two segments of the weight operand.  The inter-layer dropout's
+                # backward (the layer below's mask) rides in the epilogue instead of a separate multiply pass.
                 a_cat = Win(dgi, batches=1, batch_stride=0, row_stride=3 * H, rows_in=2 * nb * T, rows_out=nb * T, cw=3 * H, K=6 * H,
                             dil=nb * T)
-                ops.gemm_nt(a_cat, wt_ih[0], None, dx, b_seg=(3 * H, seg))
+                below = tape.masks[l - 1] if l > 0 else None
+                if below is not None and not ops.gru_fused_dropout(nb, H, bwd=True):
+                    ops.gemm_nt(a_cat, wt_ih[0], None, dx, b_seg=(3 * H, seg), out_scale=below[rows].reshape(nb * T, Kin))
+                    scaled = True
+                else:
+                    ops.gemm_nt(a_cat, wt_ih[0], None, dx, b_seg=(3 * H, seg))
             else:
                 for d in range(2):
                     ops.gemm_nt(Win.plain(dgi[d].view(nb * T, 3 * H)), wt_ih[d], None, dx, accumulate=(d == 1))

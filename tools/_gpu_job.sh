@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "residual or elementwise" > gpurun_out/s15_ops.log 2>&1; tail -3 gpurun_out/s15_ops.log
-python -m pytest tests/test_engine_gpu.py -m gpu -q -x -k "golden or graph" > gpurun_out/s15_engine.log 2>&1; tail -3 gpurun_out/s15_engine.log
-bash tools/r2_profile.sh r2_v > gpurun_out/r2_v_profile.log 2>&1; grep -o "\"ms_per_step\": [0-9.]*" gpurun_out/r2_v_bench.json
-grep "act_mask\|add_relu\|mul_k" gpurun_out/r2_v_timeline.txt | tail -4
+python -m pytest tests -m gpu -q -x > gpurun_out/s16_tests.log 2>&1; echo "rc=$?" >> gpurun_out/s16_tests.log; tail -4 gpurun_out/s16_tests.log
+python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/s16_bench.json 2> gpurun_out/s16_bench.err; grep -o "\"ms_per_step\": [0-9.]*" gpurun_out/s16_bench.json
+python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --force-ddp > gpurun_out/s16_bench_ddp.json 2> gpurun_out/s16_bench_ddp.err; grep -o "\"ms_per_step\": [0-9.]*" gpurun_out/s16_bench_ddp.json
+TG_DDP_CAPTURE=0 python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --force-ddp > gpurun_out/s16_bench_ddp_seg.json 2> gpurun_out/s16_bench_ddp.err; grep -o "\"ms_per_step\": [0-9.]*" gpurun_out/s16_bench_ddp_seg.json
