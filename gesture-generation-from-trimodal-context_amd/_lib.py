@@ -57,6 +57,7 @@ SIGNATURES = {
     "tg_gru_h64_forward": [P, I64, P, P, P, P, P, P, I64, P, P, I32, I32, P],
     "tg_gru_h64_backward": [P, P, P, P, I64, P, P, P, P, I64, I32, I32, P],
     "tg_gru_forward_cluster": [P, I64, P, P, P, P, P, P, I64, P, P, P, I64, I32, I32, I32, P],
+    "tg_gru_forward_cluster_rows": [P, I64, P, P, P, P, P, P, I64, P, P, P, I64, I32, I32, I32, I32, I32, P],
     "tg_gru_backward_cluster": [P, P, P, P, I64, P, P, P, P, I64, P, I64, I32, I32, I32, P],
     "tg_bn_train_stats": [P, I32, I32, I32, P, P, P, P, P, P, F32, F32, I32, P],
     "tg_bn_eval_stats": [P, P, I32, F32, P, P, P],
@@ -94,6 +95,7 @@ SIGNATURES = {
     "tg_weight_norm_bwd": [P, P, P, P, P, I32, I32, I32, P],
     "tg_weight_norm_bwd_batch": [I32, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), I32, I32, I32, P],
     "tg_rng_advance": [P, P],
+    "tg_iter_begin": [P, P, P, P, P],
     "tg_dropout_mask": [P, I64, F32, P, U32, P],
     "tg_dropout_apply": [P, P, P, I64, F32, P, U32, P],
     "tg_normal": [P, I64, P, U32, P],

@@ -401,6 +401,14 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_batch_kernel(const WnBwdB
 
 // ---- RNG -----------------------------------------------------------------------------------------------------------
 __global__ void rng_advance_kernel(uint64_t* st) { st[1] += 1; }
+// start of a training iteration: both networks' RNG step counters and the Adam step counters of the optimisers that will step in it, in ONE
+// launch (they were four single-thread launches of 4.7 us each inside the captured iteration)
+__global__ void iter_begin_kernel(uint64_t* rng_a, uint64_t* rng_b, int32_t* cnt_a, int32_t* cnt_b) {
+    if (rng_a) rng_a[1] += 1;
+    if (rng_b) rng_b[1] += 1;
+    if (cnt_a) *cnt_a += 1;
+    if (cnt_b) *cnt_b += 1;
+}
 // VEC: n % 4 == 0 and 16-byte aligned pointers (checked by the launcher): one 16-byte access per array and Philox draw instead of four
 // scalar ones (the GRU inter-layer dropout moved 93 MB at 2.7 TB/s through the scalar form)
 template <bool VEC>
@@ -688,6 +696,11 @@ int tg_weight_norm_bwd_batch(int32_t n, const float* const* dw_packed, const flo
     }
     hipLaunchKernelGGL(weight_norm_bwd_batch_kernel, dim3(Co, n), dim3(256), 0, ST, b, Ci, kw);
     return check_launch("tg_weight_norm_bwd_batch");
+}
+int tg_iter_begin(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, void* stream) {
+    TG_REQUIRE(rng_a || rng_b || adam_step_a || adam_step_b, "tg_iter_begin: nothing to advance");
+    hipLaunchKernelGGL(iter_begin_kernel, dim3(1), dim3(1), 0, ST, rng_a, rng_b, adam_step_a, adam_step_b);
+    return check_launch("tg_iter_begin");
 }
 int tg_rng_advance(uint64_t* rng_state, void* stream) {
     TG_REQUIRE(rng_state, "tg_rng_advance: null");

@@ -379,7 +379,7 @@ int64_t tg_gru_x3_fwd_exchange_bytes(int b_pad, int cw);
 int64_t tg_gru_x3_bwd_exchange_bytes(int b_pad, int cw);
 int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
                          float* save, long save_ds, const float* drop_mask, float* y_drop, void* hx, unsigned* flags, unsigned* tmo, int B, int T,
-                         int H, int n_bt, int cw, int b_pad, hipStream_t s);
+                         int H, int n_bt, int cw, int b_pad, int save_row0, int save_rows, hipStream_t s);
 int tg_gru_x3_bwd_launch(const float* dy, const float* dy_mask, const float* y, const float* save, long save_ds, const float* wt0, const float* wt1, float* dgi,
                          float* dgh, long dg_ds, void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
                          hipStream_t s);
@@ -437,7 +437,16 @@ extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, co
                                       const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
                                       const float* drop_mask, float* y_drop, void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H,
                                       void* stream) {
+    return tg_gru_forward_cluster_rows(gi, gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, save_dir_stride, drop_mask, y_drop, ws, ws_bytes,
+                                       B, T, H, 0, B, stream);
+}
+
+extern "C" int tg_gru_forward_cluster_rows(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
+                                           const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
+                                           const float* drop_mask, float* y_drop, void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H,
+                                           int32_t save_row0, int32_t save_rows, void* stream) {
     TG_REQUIRE(gi && w_hh_fwd && w_hh_rev && b_hh_fwd && b_hh_rev && y && ws, "tg_gru_forward_cluster: null pointer");
+    TG_REQUIRE(save_row0 >= 0 && save_rows >= 0 && (int64_t)save_row0 + save_rows <= B, "tg_gru_forward_cluster_rows: saved rows [%d, %d) outside the batch", save_row0, save_row0 + save_rows);
     TG_REQUIRE((drop_mask == nullptr) == (y_drop == nullptr) && (drop_mask == nullptr || (use_gru_x3() && aligned16(drop_mask) && aligned16(y_drop))),
                "tg_gru_forward_cluster: drop_mask / y_drop go together, 16-byte aligned, and need tg_gru_cluster_fused_dropout() != 0");
     TG_REQUIRE(T > 0 && tg_gru_cluster_supported(B, H), "tg_gru_forward_cluster: unsupported shape B=%d H=%d", B, H);
@@ -461,7 +470,7 @@ extern "C" int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, co
     const int b_pad = n_bt * 16 * mt;
     if (use_gru_x3())
         return tg_gru_x3_fwd_launch(mt, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask,
-                                    y_drop, hx, flags, tmo, B, T, H, n_bt, cw, b_pad, s);
+                                    y_drop, hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows, s);     // (the f32-MFMA fallback below saves every row)
     dim3 grid(2 * n_bt * cw);
     if (mt == 1)
         hipLaunchKernelGGL(gru_seq_fwd_cluster_kernel<1>, grid, dim3(512), 0, s, gi, (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd,

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
     const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
     const float* __restrict__ drop_mask, float* __restrict__ y_drop, void* hx, unsigned* flags, unsigned* tmo, int B, int T, int H,
-    int n_bt, int CW, int b_pad) {
+    int n_bt, int CW, int b_pad, int save_row0, int save_rows) {
     __shared__ __attribute__((aligned(16))) f32x4 red[XC_KS][2][MT][3][64];
     __shared__ __attribute__((aligned(16))) bf16x8 wlo[8][3 * XC_SPS][64];       // lo plane of every wave's weight fragments (lane-private slots)
     const int n_cl = 2 * n_bt;
@@ -190,7 +190,9 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
     __amdgpu_buffer_rsrc_t sv_rsrc = __builtin_amdgcn_make_buffer_rsrc(save ? save + dir * save_ds : Y, 0, save ? B * T * 4 * H * 4 : 0, XC_RSRC3);
     const unsigned gi_v = e_ok ? (unsigned)((row * T * 3 * H + unit0) * 4) : OOB;          // + (tau * 3H + g * H) * 4 (scalar)
     const unsigned y_v = e_ok ? (unsigned)((row * T * 2 * H + dir * H + unit0) * 4) : OOB;  // + tau * 2H * 4
-    const unsigned sv_v = e_ok ? (unsigned)((row * T * 4 * H + unit0) * 4) : OOB;           // + (tau * 4H + j * H) * 4
+    // gates are saved only for the batch rows that will be differentiated (of the three stacked generator calls of a GAN iteration one is:
+    // two thirds of the 125 MB per layer were written for nobody); the other lanes' stores fall outside the descriptor and are dropped
+    const unsigned sv_v = (e_ok && row >= save_row0 && row < save_row0 + save_rows) ? (unsigned)((row * T * 4 * H + unit0) * 4) : OOB;   // + (tau * 4H + j * H) * 4
     f32x4 gn[3] = {zero4, zero4, zero4}, mkn = zero4;                  // gi (and the dropout mask) of the NEXT step
     auto prefetch = [&](int st) {
         const int sl = st < T ? st : T - 1;                            // past the end: a valid address again, never used
@@ -487,14 +489,14 @@ int64_t tg_gru_x3_bwd_exchange_bytes(int b_pad, int cw) { return 4LL * 3 * cw * 
 
 int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
                          float* save, long save_ds, const float* drop_mask, float* y_drop, void* hx, unsigned* flags, unsigned* tmo, int B, int T,
-                         int H, int n_bt, int cw, int b_pad, hipStream_t s) {
+                         int H, int n_bt, int cw, int b_pad, int save_row0, int save_rows, hipStream_t s) {
     dim3 grid(2 * n_bt * cw);
     if (mt == 1)
         hipLaunchKernelGGL(gru_seq_fwd_cluster_x3_kernel<1>, grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, drop_mask, y_drop,
-                           hx, flags, tmo, B, T, H, n_bt, cw, b_pad);
+                           hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows);
     else
         hipLaunchKernelGGL(gru_seq_fwd_cluster_x3_kernel<2>, grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, drop_mask, y_drop,
-                           hx, flags, tmo, B, T, H, n_bt, cw, b_pad);
+                           hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows);
     return check_launch("tg_gru_forward_cluster(x3)");
 }
 

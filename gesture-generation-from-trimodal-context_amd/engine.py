@@ -101,7 +101,7 @@ class GeneratorEngine(_Engine):
         self.in_size = self.c_z + (16 if self.z_mode else 0)
 
     # ---------------------------------------------------------------------------------------------- forward
-    def forward(self, pre_seq, in_text, in_audio, vid, *, training, groups=1, save=False, inject=None, tag="g"):
+    def forward(self, pre_seq, in_text, in_audio, vid, *, training, groups=1, save=False, inject=None, tag="g", save_rows=None):
         """Stacked forward: the batch may hold `groups` reference forward calls back to back (BatchNorm statistics are
         per group).  Returns a dict with out/z/mu/logvar (+ the tape when save=True)."""
         P, G, Bf = self.views()
@@ -160,7 +160,7 @@ class GeneratorEngine(_Engine):
 
         # ---- 4-layer bidirectional GRU, sum of directions, output MLP (:155-158)
         y, gtape = L.gru_stack_fwd(in_data, P, "gru", self.n_layers, H, p_drop=self.p_drop, training=training, rng=self.rng,
-                                   save=save, inject=inject, tag=tag)
+                                   save=save, inject=inject, tag=tag, save_rows=save_rows)      # save_rows: the batch rows backward() will be asked for
         o = ops.add_halves(y, L.empty(Bs * T, H, like=y))
         h1 = L.linear_fwd(o, P["out.0.weight"], P["out.0.bias"])            # LeakyReLU(True) == identity (README.md:122)
         out = L.linear_fwd(h1, P["out.2.weight"], P["out.2.bias"]).view(Bs, T, D)

@@ -380,7 +380,7 @@ class GRUTape:
     __slots__ = ("x", "y", "save", "masks", "B", "T", "H")
 
 
-def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save=False, inject=None, tag="g"):
+def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save=False, inject=None, tag="g", save_rows=None):
     """Multi-layer bidirectional GRU.  x: (B, T, Kin) contiguous.  P: name -> parameter tensor.
     Returns (y_last (B,T,2H), tape)."""
     B, T, _ = x.shape
@@ -417,11 +417,11 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
             mask = inject[name].contiguous() if (inject is not None and name in inject) else (drawn[l] if drawn is not None else None)
         if mask is not None:
             nxt = torch.empty_like(y)
-            ops.gru_forward(gi, whh, bhh, y, sv, drop_mask=mask, y_drop=nxt)
+            ops.gru_forward(gi, whh, bhh, y, sv, drop_mask=mask, y_drop=nxt, save_rows=save_rows)
             tape.x.append(cur); tape.y.append(y); tape.save.append(sv); tape.masks.append(mask)
             cur = nxt
             continue
-        ops.gru_forward(gi, whh, bhh, y, sv)
+        ops.gru_forward(gi, whh, bhh, y, sv, save_rows=save_rows)
         tape.x.append(cur); tape.y.append(y); tape.save.append(sv)
         if training and l < n_layers - 1 and not fused_drop:
             if inject is not None and name in inject:

@@ -339,9 +339,10 @@ def gru_fused_dropout(B, H, bwd=False):
     return bool(GRU_CLUSTER and H > 64 and fits and lib.tg_gru_cluster_fused_dropout())
 
 
-def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None):
+def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None, save_rows=None):
     """gi: [2, B, T, 3H] contiguous; w_hh/b_hh: (fwd, rev) pairs; y: [B, T, 2H]; save: [2, B, T, 4H] or None.
-    drop_mask / y_drop ([B, T, 2H], where gru_fused_dropout(B, H)): fused inter-layer dropout, y_drop = y * drop_mask."""
+    drop_mask / y_drop ([B, T, 2H], where gru_fused_dropout(B, H)): fused inter-layer dropout, y_drop = y * drop_mask.
+    save_rows = (row0, n): only these batch rows of `save` are needed (the cluster kernels then skip the rest; other kernels save all)."""
     _flat(gi, "gi"); _flat(y, "y")
     _, B, T, H3 = gi.shape
     H = H3 // 3
@@ -362,8 +363,10 @@ def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None):
             _flat(drop_mask, "drop_mask"); _flat(y_drop, "y_drop")
             assert tuple(drop_mask.shape) == tuple(y.shape) == tuple(y_drop.shape) and gru_fused_dropout(B, H)
         ws = _gru_cluster_ws(gi.device, B, H)
-        call("tg_gru_forward_cluster", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
-             B * T * 4 * H, _p(drop_mask), _p(y_drop), C.c_void_p(ws.data_ptr()), ws.numel() * 4, B, T, H, _stream())
+        r0, rn = (0, B) if save_rows is None else (int(save_rows[0]), int(save_rows[1]))
+        assert 0 <= r0 and rn >= 0 and r0 + rn <= B
+        call("tg_gru_forward_cluster_rows", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
+             B * T * 4 * H, _p(drop_mask), _p(y_drop), C.c_void_p(ws.data_ptr()), ws.numel() * 4, B, T, H, r0, rn, _stream())
         return y
     assert drop_mask is None and y_drop is None, "fused dropout: H = 64 or the bf16x3 cluster kernels only (ops.gru_fused_dropout)"
     call("tg_gru_forward", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
@@ -736,6 +739,15 @@ def new_rng_state(seed, device):
 
 def rng_advance(state):
     call("tg_rng_advance", _p(_i64(state, "rng_state")), _stream())
+
+
+def iter_begin(rng_a, rng_b, step_a, step_b):
+    """Advance up to two RNG states and up to two Adam step counters in one launch (None = skip)."""
+    for r in (rng_a, rng_b):
+        assert r is None or _i64(r, "rng_state") is r
+    for c in (step_a, step_b):
+        assert c is None or (c.is_cuda and c.dtype == torch.int32)
+    call("tg_iter_begin", _p(rng_a), _p(rng_b), _p(step_a), _p(step_b), _stream())
 
 
 def dropout_mask(mask, p, state, site):

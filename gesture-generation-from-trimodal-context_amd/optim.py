@@ -20,10 +20,12 @@ class FusedAdam:
     def zero_grad(self, set_to_none=False):
         self.slab.zero_grad()
 
-    def step(self):
+    def step(self, counter_advanced=False):
+        """counter_advanced: the device-side step counter was already incremented for this step (ops.iter_begin at the iteration's start)."""
         s = self.slab
         n = s.n_train                                  # frozen parameters sit behind the trainable prefix and are never stepped
-        ops.counter_inc(s.step)
+        if not counter_advanced:
+            ops.counter_inc(s.step)
         ops.adam_step(s.flat[:n], s.grad[:n], s.m[:n], s.v[:n], self.lr, self.betas[0], self.betas[1], self.eps, s.step)
 
     def state_dict(self):

@@ -122,7 +122,8 @@ class GanTrainer:
         if G.use_side_stream and ops.GRU_CLUSTER:
             raise RuntimeError("TG_SIDE_STREAM=1 cannot be combined with the cluster-synchronised GRU kernels (set TG_GRU_CLUSTER=0): "
                                "side-stream kernels beside them break the co-residency their hand-off relies on")
-        G.rng.advance(); D.rng.advance()
+        # both RNG step counters and the Adam step counters of the optimisers that step in this iteration: one launch
+        ops.iter_begin(G.rng.state, D.rng.state, self.g_opt.slab.step, self.d_opt.slab.step if post else None)
         target = target.contiguous().float()
         pre = ops.make_pre_seq(target, torch.empty(B, target.shape[1], target.shape[2] + 1, device=dev), self.hp["n_pre_poses"])
         speaker = self.G.z_mode == "speaker"
@@ -142,7 +143,7 @@ class GanTrainer:
         pre_s = pre.repeat(ng, 1, 1) if ng > 1 else pre                # data movement only
         text_s = in_text.contiguous().repeat(ng, 1) if ng > 1 else in_text.contiguous()
         res = G.forward(pre_s, text_s, in_audio.float(), vid_s, training=True, groups=ng, save=True,
-                        inject=_stack_inject(inject, tags, "g"), tag="g")
+                        inject=_stack_inject(inject, tags, "g"), tag="g", save_rows=(i2 * B, B))     # only call g2 is differentiated (:50-88)
         sl = lambda t, i: None if t is None else t[i * B:(i + 1) * B]
         st = dict(B=B, target=target, res=res, i2=i2, ng=ng, out2=sl(res["out"], i2), out3=sl(res["out"], ng - 1),
                   z2=sl(res["z"], i2), z3=sl(res["z"], ng - 1), mu2=sl(res["mu"], i2), lv2=sl(res["logvar"], i2))
@@ -162,7 +163,7 @@ class GanTrainer:
         ops.gan_d_loss(logit[:B], logit[B:], st["d_scalar"], d_logit[:B], d_logit[B:])
         D.backward(dres["tape"], d_logit.view(-1, 1), b0=0, nb=2 * B, param_grads=True)
         self._sync("all", D.slab)
-        self.d_opt.step()
+        self.d_opt.step(counter_advanced=True)
 
     # ---- phase 3: generator losses and backward (train_gan.py:47-91)
     def phase_g_backward(self, st, post, inject):
@@ -198,7 +199,7 @@ class GanTrainer:
     # ---- phase 4: generator update (train_gan.py:92)
     def phase_g_update(self):
         self._sync("wait")
-        self.g_opt.step()
+        self.g_opt.step(counter_advanced=True)
 
 
 class GraphedGanStep:

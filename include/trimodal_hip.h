@@ -201,6 +201,12 @@ int32_t tg_gru_cluster_fused_dropout(void);
 int tg_gru_forward_cluster(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
                            const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
                            const float* drop_mask, float* y_drop, void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream);
+/* The same, saving the gates only for batch rows [save_row0, save_row0 + save_rows): of the stacked generator calls of a GAN iteration
+ * (train_gan.py:30,50,67) only one is differentiated; the other rows of `save` are left untouched. */
+int tg_gru_forward_cluster_rows(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
+                                const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
+                                const float* drop_mask, float* y_drop, void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H,
+                                int32_t save_row0, int32_t save_rows, void* stream);
 
 /* Persistent cluster-synchronised variant of tg_gru_backward (B <= 192 at H = 300; no dh_scratch: the carried dh stays in
  * registers).  Same workspace / timeout-word convention as tg_gru_forward_cluster. */
@@ -376,6 +382,9 @@ int tg_weight_norm_bwd_batch(int32_t n, const float* const* dw_packed, const flo
  * rng_state: device uint64[2] = {seed, step}.  tg_rng_advance bumps step by one (launch once per iteration).
  * Every draw site passes its own `site` id so streams never collide. */
 int tg_rng_advance(uint64_t* rng_state, void* stream);
+/* start of a training iteration in one launch: rng_state[1] += 1 for up to two RNG states and += 1 for up to two Adam step counters
+ * (tg_adam_step then runs with the counter already advanced); any pointer may be NULL, not all. */
+int tg_iter_begin(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, void* stream);
 int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream);
 /* Draw the same mask and apply it in one pass: mask as tg_dropout_mask, y[i] = x[i] * mask[i] (F.dropout, train mode). */
 int tg_dropout_apply(const float* x, float* y, float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site,
