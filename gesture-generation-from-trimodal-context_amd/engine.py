@@ -193,14 +193,24 @@ class GeneratorEngine(_Engine):
                 continue
             wp = L.pack_conv_weight(P[f"{fe}.{idx}.weight"])
             last = idx == 9
-            out = in_data[:, :, ca:ca + 32] if (last and not shared) else None
+            if last and shared:
+                # the encoder ran once for all stacked calls: its last conv writes every group's slice of the GRU input itself -- one grouped
+                # launch of `groups` identical (tiny, latency-bound) products instead of one product + a copy launch per group
+                Lo = L.conv_out_len(x.shape[1], WAV_KW, stride, pad)
+                assert Lo == T, f"audio length gives {Lo} frames, expected {T}"
+                a_win = Win.conv(x, WAV_KW, stride=stride, pad=pad, rows_out=Lo)
+                probs = []
+                for g in range(groups):
+                    o = in_data[g * Ba:(g + 1) * Ba, :, ca:ca + 32]
+                    probs.append(dict(A=a_win, W=wp, bias=P[f"{fe}.{idx}.bias"], out=o, c_batch_stride=o.stride(0), c_row_stride=o.stride(1), c_rows_out=Lo))
+                ops.gemm_nt_group(probs)
+                wav.append((x, None, None))
+                break
+            out = in_data[:, :, ca:ca + 32] if last else None
             c = L.conv_fwd(x, wp, P[f"{fe}.{idx}.bias"], WAV_KW, stride=stride, pad=pad, out=out)
             if last:
                 assert c.shape[1] == T, f"audio length gives {c.shape[1]} frames, expected {T}"
                 wav.append((x, None, None))
-                if shared:
-                    for g in range(groups):
-                        ops.copy2d(c.view(Ba * T, 32), in_data[g * Ba:(g + 1) * Ba].view(Ba * T, in_size)[:, ca:ca + 32])
                 break
             y, st = L.bn_fwd(c, P[f"{fe}.{idx + 1}.weight"], P[f"{fe}.{idx + 1}.bias"], Bf[f"{fe}.{idx + 1}.running_mean"],
                              Bf[f"{fe}.{idx + 1}.running_var"], Bf[f"{fe}.{idx + 1}.num_batches_tracked"],
