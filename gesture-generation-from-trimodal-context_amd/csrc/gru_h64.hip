@@ -62,6 +62,18 @@ __device__ __forceinline__ void split4_store(const f32x4 v, __bf16* p0, __bf16* 
     *reinterpret_cast<u32x2*>(p2) = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
 }
 
+// Make a fragment opaque to the optimiser.  Without this hipcc REMATERIALISES the pre-split weight fragments inside the step loop -- it keeps
+// only the loaded fp32 weights live and redoes the whole three-way split (and / sub / and / sub / perm per element: ~290 of the 570
+// instructions of a forward step, ~330 of a backward step) on every one of the T steps, to save 24 of 512 registers.  ISA check:
+// the step loop must hold ~8 v_and_b32 (the split of h_t), not ~104.  (Measured: the step takes the same 1.2 / 1.7 us with 304 as with
+// 568 instructions -- the redone split filled issue slots beside the step's dependent chain LDS -> 36 MFMAs -> 24 quarter-rate
+// transcendentals -> split -> LDS -> barrier, which is what bounds it; the pin saves the energy, not the time.)
+__device__ __forceinline__ void pin_fragment(bf16x8& v) {
+    u32x4 t = __builtin_bit_cast(u32x4, v);
+    asm volatile("" : "+v"(t));
+    v = __builtin_bit_cast(bf16x8, t);
+}
+
 // acc += W (A operand, split planes wa[0..2]) x h (B operand, split planes fb[0..2]); the six significant partial products,
 // smallest first
 __device__ __forceinline__ f32x4 mma_x3(const bf16x8 (&wa)[3], const bf16x8 (&fb)[3], f32x4 acc) {
@@ -106,6 +118,8 @@ __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
         for (int ks = 0; ks < 2; ++ks) {
             const float* p = whh + (long)(g * HS + 16 * wave + r16) * HS + 32 * ks + 8 * kq;
             split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[g][ks]);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) pin_fragment(wa[g][ks][s]);
         }
     // gate-epilogue role: batch row b0 + r16 (clamped), hidden units u0 .. u0 + 3
     const int u0 = 16 * wave + 4 * kq;
@@ -196,6 +210,8 @@ __global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
     for (int ks = 0; ks < 6; ++ks) {
         const float* p = wt + (long)(16 * wave + r16) * (3 * HS) + 32 * ks + 8 * kq;
         split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[ks]);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) pin_fragment(wa[ks][s]);
     }
     const int u0 = 16 * wave + 4 * kq;
     const int row = min((int)blockIdx.x * 16 + r16, B - 1);        // clamped: see the forward kernel
