@@ -106,10 +106,10 @@ def dominant_kernel_roofline(pkg, device, batch):
     b = [torch.randn(3 * H, device=device) * 0.05 for _ in range(2)]
     y = torch.empty(Bs, T, 2 * H, device=device)
     sv = torch.empty(2, Bs, T, 4 * H, device=device)
-    dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, sv), iters=20)
+    dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, sv, save_rows=(batch, batch)), iters=20)      # as the trainer calls it (gates saved for call g2 only)
     ops.check_async_errors()
     flops = (T - 1) * 2 * Bs * H * 3 * H * 2
-    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape (profiles/r2_pmc_gru_fwd_cluster_x3.txt):
+    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape and call (profiles/r2_z_pmc_gru_fwd_cluster_x3.txt):
     # 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE.  Only valid for batch 128 (B_s = 384).
     traffic = PMC_TRAFFIC_GRU_FWD if batch == 128 else None
     return {"kernel": "gru_seq_fwd_cluster_x3_kernel<2>", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
@@ -120,7 +120,7 @@ def dominant_kernel_roofline(pkg, device, batch):
                     "(peak_bf16x3 = dense bf16 MFMA peak / 6, the ceiling of this arithmetic)"}
 
 
-PMC_TRAFFIC_GRU_FWD = 371.6e6      # bytes per launch: (2 x FETCH_SIZE 80 097 KB + WRITE_SIZE 202 737 KB) x 1024, profiles/r2_pmc_gru_fwd_cluster_x3.txt
+PMC_TRAFFIC_GRU_FWD = 287.5e6      # bytes per launch: (2 x FETCH_SIZE 79 853 KB + WRITE_SIZE 121 031 KB) x 1024, profiles/r2_z_pmc_gru_fwd_cluster_x3.txt (gates saved for call g2 only)
 
 
 def hbm_kernel_roofline(pkg, device):

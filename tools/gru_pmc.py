@@ -9,5 +9,5 @@ gi = torch.randn(2, B, T, 3 * H, device=dev) * 0.1
 w = [torch.randn(3 * H, H, device=dev) * 0.05 for _ in range(2)]
 b = [torch.randn(3 * H, device=dev) * 0.05 for _ in range(2)]
 y = torch.empty(B, T, 2 * H, device=dev); sv = torch.empty(2, B, T, 4 * H, device=dev)
-for _ in range(5): ops.gru_forward(gi, w, b, y, sv)
+for _ in range(5): ops.gru_forward(gi, w, b, y, sv, save_rows=(B // 3, B // 3))     # as the trainer calls it: gates saved for the differentiated call only
 torch.cuda.synchronize()
