@@ -231,7 +231,8 @@ def ae_bench(pkg, a, args, device, world, rank):
                 tr.train_iter(poses)
         torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread-local capture mode when a process group exists (N > 1 replicas): RCCL's helper threads must not invalidate the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"):
             loss = tr.train_iter(poses)
     step = graph.replay if graph is not None else (lambda: tr.train_iter(poses))
     for _ in range(max(a.warmup, 1)):

@@ -121,7 +121,8 @@ class WindowDecoder:
                     torch.cuda.synchronize()
                     self.graph = torch.cuda.CUDAGraph()
                     keep = [t.clone() for t in (self.pre_seq, self.tail, self.out)]
-                    with torch.cuda.graph(self.graph):
+                    pg_alive = torch.distributed.is_available() and torch.distributed.is_initialized()     # RCCL helper threads: see train_gan.GraphedGanStep
+                    with torch.cuda.graph(self.graph, capture_error_mode="thread_local" if pg_alive else "global"):
                         self._forward(False)
                     for t, k in zip((self.pre_seq, self.tail, self.out), keep):   # capture does not execute: restore state
                         t.copy_(k)

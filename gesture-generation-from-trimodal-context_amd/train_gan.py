@@ -236,7 +236,11 @@ class GraphedGanStep:
             state = {"g": torch.cuda.CUDAGraph()}
             # thread-local capture mode: other threads (the RCCL watchdog polls its events with hipEventQuery) must not invalidate
             # the capture; everything this thread issues between begin and end is still checked
-            mode = "thread_local" if trainer.grad_sync is not None else "global"
+            # (also when a process group merely EXISTS in this process: RCCL's helper threads -- communicator init, watchdog -- call the HIP
+            # runtime on their own schedule, and under the global mode such a call during our capture invalidates it or aborts the process:
+            # seen once as a SIGABRT while capturing a trainer without grad_sync after init_process_group("nccl"))
+            pg_alive = torch.distributed.is_available() and torch.distributed.is_initialized()
+            mode = "thread_local" if (trainer.grad_sync is not None or pg_alive) else "global"
             state["g"].capture_begin(pool=pool, capture_error_mode=mode)
 
             def cut(action):

@@ -487,10 +487,11 @@ def test_data_parallel_graph_segments_single_rank(pkg, dev, tmp_path):
     V, S, B = 64, 9, 8
     text, audio, vid, poses = O.make_batch(21, B, V, S)
     text, audio, vid, poses = text.to(dev), audio.to(dev), vid.to(dev), poses.to(dev)
-    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=dev)
+    out = []
     try:
-        out = []
         for use_ddp, capture in ((False, None), (True, False), (True, True)):
+            if use_ddp and not dist.is_initialized():     # the plain reference step is built before any RCCL thread exists in the process
+                dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=dev)
             gst, dst = O.make_generator_state(5, V, S), O.make_discriminator_state(6)
             args, G, Dn = build_models(pkg, dev, gst, dst, V, S)
             G.train(); Dn.train()
@@ -509,7 +510,9 @@ def test_data_parallel_graph_segments_single_rank(pkg, dev, tmp_path):
                 for k in a:
                     assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
     finally:
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
 
 
 def test_reference_checkpoint_runs_on_gpu(pkg, dev):
