@@ -11,6 +11,8 @@ Same order of operations and the same losses as the reference; what changes is t
     deferred read (StepLosses.to_dict()).
 With static shapes the whole iteration is captured into a hipGraph (GraphedGanStep).
 """
+import os
+
 import torch
 
 from . import layers as L
@@ -119,7 +121,7 @@ class GanTrainer:
         B = target.shape[0]
         dev = target.device
         self._assert_no_pending_exchange()
-        if G.use_side_stream and ops.GRU_CLUSTER:
+        if G.use_side_stream and ops.GRU_CLUSTER and os.environ.get("TG_SIDE_STREAM") != "2":      # "2": lab switch, measure anyway
             raise RuntimeError("TG_SIDE_STREAM=1 cannot be combined with the cluster-synchronised GRU kernels (set TG_GRU_CLUSTER=0): "
                                "side-stream kernels beside them break the co-residency their hand-off relies on")
         # both RNG step counters and the Adam step counters of the optimisers that step in this iteration: one launch

@@ -167,6 +167,28 @@ def test_gru_cluster_kernels_match_step_launches(pkg, dev, B):
         ops.GRU_CLUSTER = prev
 
 
+def test_gru_cluster_saves_gates_for_requested_rows_only(pkg, dev):
+    """tg_gru_forward_cluster_rows: of a stacked forward only one call is differentiated -- the gates are written for its batch rows, the
+    rest of `save` is left untouched, y is unchanged (B = 48 and 384: one and two 16-row tiles per cluster)."""
+    ops = pkg.ops
+    T, H = 6, 300
+    for B, r0, rn in ((48, 16, 16), (384, 128, 128), (40, 7, 13)):
+        if not pkg._lib.load().tg_gru_cluster_supported(B, H):
+            continue
+        g = torch.Generator().manual_seed(B)
+        w = [(torch.randn(3 * H, H, generator=g) * 0.08).to(dev) for _ in range(2)]
+        b = [(torch.randn(3 * H, generator=g) * 0.05).to(dev) for _ in range(2)]
+        gi = (torch.randn(2, B, T, 3 * H, generator=g) * 0.5).to(dev)
+        y0, sv0 = torch.empty(B, T, 2 * H, device=dev), torch.empty(2, B, T, 4 * H, device=dev)
+        ops.gru_forward(gi, w, b, y0, sv0)
+        y1 = torch.empty_like(y0)
+        sv1 = torch.full_like(sv0, float("nan"))
+        ops.gru_forward(gi, w, b, y1, sv1, save_rows=(r0, rn))
+        ops.check_async_errors()
+        assert torch.equal(y0, y1) and torch.equal(sv1[:, r0:r0 + rn], sv0[:, r0:r0 + rn])
+        assert bool(torch.isnan(sv1[:, :r0]).all()) and bool(torch.isnan(sv1[:, r0 + rn:]).all())
+
+
 def test_gru_cluster_flag_generations_across_sequence_lengths(pkg, dev):
     """The cluster kernels never zero their flag words: each launch numbers them from the cluster's generation word and advances it by
     T + 1 (csrc/gru_cluster_x3.hip).  Launches of DIFFERENT lengths -- including T = 1 (nothing published) and T = 2 (the shortest with a
