@@ -140,3 +140,81 @@ extern "C" int tg_speaker_bwd(const float* dz, const float* d_mu_in, const float
                        dw1, db1, dwmu, dbmu, dwlv, dblv, dtable, nb);
     return check_launch("tg_speaker_bwd");
 }
+
+// ---- output MLP of PoseGenerator: Linear(H, H/2) -> LeakyReLU(True) -> Linear(H/2, D)  (model/multimodal_context_net.py:100-104) ----------
+// nn.LeakyReLU(True) sets negative_slope = True == 1.0: the activation is the identity (reference README.md:122), so the two linears are ONE
+// linear map,  out = o (W2 W1)^T + (W2 b1 + b2).  The forward is then a single [M x H] x [H x D] product on the composed weight (instead of
+// M x H x H/2 + M x H/2 x D with a K = 150 middle dimension that is not a multiple of 4), and the backward needs the [M]-sized operands only in
+//   P = d_out^T o  [D x H],   s = colsum(d_out),   d o = d_out (W2 W1):
+//   dW2 = P W1^T + s b1^T,  db2 = s,  dW1 = W2^T P,  db1 = W2^T s      (out_mlp_param_grads_kernel: a few hundred thousand MACs).
+namespace tg {
+
+// (reduction loops unrolled by 10: ten independent loads in flight per thread -- rolled, every iteration waited out an L2 round trip: 67 us)
+// w21 [D][H] = W2 W1, w21t [H][D] (the operand of d o = d_out W21 as a row-major [N = H][K = D] matrix), b21 [D] = W2 b1 + b2
+__global__ __launch_bounds__(256) void out_mlp_compose_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                              const float* __restrict__ b2, int H, int Hm, int D, float* __restrict__ w21,
+                                                              float* __restrict__ w21t, float* __restrict__ b21) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D * H) {
+        const int d = i / H, h = i - d * H;
+        float a = 0.f;
+#pragma unroll 10
+        for (int m = 0; m < Hm; ++m) a = __builtin_fmaf(w2[d * Hm + m], w1[m * H + h], a);
+        w21[i] = a;
+        if (w21t) w21t[h * D + d] = a;
+    } else if (i < D * H + D) {
+        const int d = i - D * H;
+        float a = b2[d];
+#pragma unroll 10
+        for (int m = 0; m < Hm; ++m) a = __builtin_fmaf(w2[d * Hm + m], b1[m], a);
+        b21[d] = a;
+    }
+}
+
+// P [D][H], s [D] (accumulated by the caller's weight-gradient GEMM); all four gradients accumulate
+__global__ __launch_bounds__(256) void out_mlp_param_grads_kernel(const float* __restrict__ P, const float* __restrict__ s, const float* __restrict__ w1,
+                                                                  const float* __restrict__ b1, const float* __restrict__ w2, int H, int Hm, int D,
+                                                                  float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                                  float* __restrict__ db2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n1 = Hm * H, n2 = D * Hm;
+    if (i < n1) {                                        // dW1[m][h] += sum_d W2[d][m] P[d][h]
+        const int m = i / H, h = i - m * H;
+        float a = 0.f;
+#pragma unroll 10
+        for (int d = 0; d < D; ++d) a = __builtin_fmaf(w2[d * Hm + m], P[d * H + h], a);
+        dw1[i] += a;
+    } else if (i < n1 + n2) {                            // dW2[d][m] += sum_h P[d][h] W1[m][h] + s[d] b1[m]
+        const int j = i - n1, d = j / Hm, m = j - d * Hm;
+        float a = s[d] * b1[m];
+#pragma unroll 10
+        for (int h = 0; h < H; ++h) a = __builtin_fmaf(P[d * H + h], w1[m * H + h], a);
+        dw2[j] += a;
+    } else if (i < n1 + n2 + Hm) {                       // db1[m] += sum_d W2[d][m] s[d]
+        const int m = i - n1 - n2;
+        float a = 0.f;
+#pragma unroll 10
+        for (int d = 0; d < D; ++d) a = __builtin_fmaf(w2[d * Hm + m], s[d], a);
+        db1[m] += a;
+    } else if (i < n1 + n2 + Hm + D) {
+        const int d = i - n1 - n2 - Hm;
+        db2[d] += s[d];
+    }
+}
+
+}  // namespace tg
+
+extern "C" int tg_out_mlp_compose(const float* w1, const float* b1, const float* w2, const float* b2, int32_t H, int32_t Hm, int32_t D, float* w21,
+                                  float* w21t, float* b21, void* stream) {
+    TG_REQUIRE(w1 && b1 && w2 && b2 && w21 && b21 && H > 0 && Hm > 0 && D > 0, "tg_out_mlp_compose: bad arguments");
+    hipLaunchKernelGGL(out_mlp_compose_kernel, dim3(cdiv((long)D * H + D, 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, H, Hm, D, w21, w21t, b21);
+    return check_launch("tg_out_mlp_compose");
+}
+
+extern "C" int tg_out_mlp_param_grads(const float* P, const float* s, const float* w1, const float* b1, const float* w2, int32_t H, int32_t Hm, int32_t D,
+                                      float* dw1, float* db1, float* dw2, float* db2, void* stream) {
+    TG_REQUIRE(P && s && w1 && b1 && w2 && dw1 && db1 && dw2 && db2 && H > 0 && Hm > 0 && D > 0, "tg_out_mlp_param_grads: bad arguments");
+    const long n = (long)Hm * H + (long)D * Hm + Hm + D;
+    hipLaunchKernelGGL(out_mlp_param_grads_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, P, s, w1, b1, w2, H, Hm, D, dw1, db1, dw2, db2);
+    return check_launch("tg_out_mlp_param_grads");
+}
