@@ -63,8 +63,12 @@ template <int N, typename F>
 __device__ __forceinline__ void nt_static_for(F&& f) { nt_static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
 // Workgroup = 4 waves arranged WM x WN, each wave a 32x32 output tile (2x2 MFMA tiles of 16x16).
-template <bool VEC, int WM, int WN, int NT_RING>
+// KS = 4 (with WM = WN = 1, VEC): the four waves share ONE 32 x 32 tile and split its K range; the partial tiles meet in LDS and wave 0
+// runs the epilogue.  For narrow products with a long reduction and too few rows to fill the chip (audio conv4: M = 4352, N = 32,
+// K = 960 -> 34 workgroups of 128 rows, each wave walking 60 dependent k-steps): four times the workgroups, a quarter of the chain.
+template <bool VEC, int WM, int WN, int NT_RING, int KS = 1>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
+    static_assert(KS == 1 || (KS == 4 && WM == 1 && WN == 1 && VEC), "K split: one tile per workgroup, vectorised path");
     const int pi = group_find(g, blockIdx.x);
     const NtProb& pr = g.p[pi];
     const Win A = pr.A;
@@ -78,15 +82,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
     const float slope = pr.slope;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = KS > 1 ? 0 : wave / WN, wn = KS > 1 ? 0 : wave % WN;
     const int r16 = lane & 15, kq = lane >> 4;
     // logical order: output-column tile fastest -> the workgroups that re-read one A row panel sit on ONE XCD's L2
     // (every problem's workgroup range starts at a multiple of 8, so bid & 7 still names the XCD)
     const int lid = xcd_chunked_id(blockIdx.x - g.wg_begin[pi], g.wg_begin[pi + 1] - g.wg_begin[pi]);
     const int m_base = (lid / n_nt) * (WM * 32) + wm * 32;
     const int n_base = (lid % n_nt) * (WN * 32) + wn * 32;
-    if (m_base >= M || n_base >= N) return;   // no LDS, no barriers: a whole wave may leave
-    const int K = A.K;
+    if (m_base >= M || n_base >= N) return;   // no LDS, no barriers: a whole wave may leave (KS > 1: the whole workgroup does)
+    // this wave's K range: all of it, or its quarter rounded up to whole 16-deep k-steps
+    const int kslice = KS > 1 ? ((A.K + 16 * KS - 1) / (16 * KS)) * 16 : A.K;
+    const int K_beg = KS > 1 ? wave * kslice : 0;
+    const int K = KS > 1 ? (A.K < K_beg + kslice ? A.K : K_beg + kslice) : A.K;       // end of the range
 
     long a_off[2];
     int a_r[2];
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
         // everything (vmcnt(0)) at the next use -- with the one-deep prefetch of the first version every 16-deep k-step of a small grid
         // cost a full memory latency (audio conv4, 40 workgroups: 56 us for 0.27 GFLOP).
         constexpr int R = NT_RING;
-        int k = 4 * kq;
+        int k = K_beg + 4 * kq;
         int kk = k / A.cw, c = k - (k / A.cw) * A.cw;      // tap / channel of this lane's next k, advanced by 16 per load (cw % 4 == 0)
         f32x4 ra[R][2], rb[R][2];
         unsigned rm[R];
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
             while (c >= A.cw) { c -= A.cw; ++kk; }
         };
         nt_static_for<R>([&](auto j) { load(j); });
-        for (int k0 = 0; k0 < K; k0 += 16 * R) {
+        for (int k0 = K_beg; k0 < K; k0 += 16 * R) {
             nt_static_for<R>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 {                                           // (k-steps past K multiply masked zeros: no branch, so the counts stay static)
@@ -195,6 +202,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
                 for (int i = 0; i < 2; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
             }
         }
+    }
+
+    if constexpr (KS > 1) {
+        // partial tiles of waves 1 .. KS - 1 through LDS (lane-private slots), summed by wave 0 in wave order
+        __shared__ f32x4 red[KS - 1][4][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) red[wave - 1][mt * 2 + nt][lane] = acc[mt][nt];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] += red[q][mt * 2 + nt][lane];
     }
 
     // C/D layout of the 16x16 tile: row = (lane>>4)*4 + i, col = lane&15.  Every global read of the epilogue (bias, dropout mask,
@@ -700,6 +726,13 @@ static int nt_launch(NtGroup& g, hipStream_t s) {
         const dim3 grid(wgs);
         const bool deep = wgs < 1024 && Kx >= 256;        // operand ring of 4 k-steps: small grid, long reduction (see the kernel)
         static const int mid_ring = [] { const char* e = getenv("TG_NT_NARROW_RING"); return e ? atoi(e) : 1; }();      // lab switch: ring depth of the chip-filling narrow grids with K >= 64
+        static const int ksplit_on = [] { const char* e = getenv("TG_NT_KSPLIT"); return e ? atoi(e) : 1; }();
+        if (fam == 1 && vec && ksplit_on && wgs < 256 && Kx >= 256) {
+            // few rows, long reduction: one 32 x 32 tile per workgroup, its four waves split K (see the kernel)
+            const dim3 grid4(nt_layout(g, 32, 32));
+            hipLaunchKernelGGL((gemm_nt_kernel<true, 1, 1, 2, 4>), grid4, dim3(256), 0, s, g);
+            return check_launch("tg_gemm_nt");
+        }
         if (fam == 1) {
             if (vec && deep) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 4>), grid, dim3(256), 0, s, g);
             else if (vec && mid_ring == 2 && Kx >= 64) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 2>), grid, dim3(256), 0, s, g);

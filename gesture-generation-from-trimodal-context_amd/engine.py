@@ -111,7 +111,8 @@ class GeneratorEngine(_Engine):
         tp = {"Bs": Bs, "groups": groups, "training": training}
         in_size = self.in_size
         in_data = L.empty(Bs, T, in_size, like=pre_seq)
-        fork = L.Fork(pre_seq.device, enabled=self.use_side_stream and self.use_audio)
+        # TG_SIDE_STREAM_FWD=1: only the audio encoder beside the text encoder (no cluster kernel runs until the join)
+        fork = L.Fork(pre_seq.device, enabled=(self.use_side_stream or os.environ.get("TG_SIDE_STREAM_FWD", "0") != "0") and self.use_audio)
         # The reference evaluates BOTH encoders for 'audio' and 'text' (:117-123) and discards one.  The discarded text encoder
         # has no state, so it is skipped; the discarded audio encoder moves its BatchNorm running statistics in train mode, so
         # for 'text' it still runs (forward only, into a scratch buffer) to keep the state_dict identical after training.

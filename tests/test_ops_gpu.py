@@ -24,7 +24,8 @@ def cl(x):   # (B, C, L) -> channel-last (B, L, C)
 
 
 # ------------------------------------------------------------------------------------------------ GEMM family
-@pytest.mark.parametrize("M,N,K", [(200, 70, 108), (37, 27, 150), (4352, 900, 600), (5, 1, 28), (130, 33, 8)])
+@pytest.mark.parametrize("M,N,K", [(200, 70, 108), (37, 27, 150), (4352, 900, 600), (5, 1, 28), (130, 33, 8),
+                                   (4352, 32, 960), (130, 20, 300), (33, 7, 264)])        # last three: narrow + long K -> the K-split variant
 def test_gemm_nt_plain(pkg, dev, M, N, K):
     ops, Win = pkg.ops, pkg.ops.Win
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
