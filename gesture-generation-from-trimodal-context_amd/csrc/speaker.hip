@@ -154,51 +154,72 @@ namespace tg {
 __global__ __launch_bounds__(256) void out_mlp_compose_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                                               const float* __restrict__ b2, int H, int Hm, int D, float* __restrict__ w21,
                                                               float* __restrict__ w21t, float* __restrict__ b21) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // eight lanes per entry split the Hm-term sum (strided partials, shuffle tree: fixed order)
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(gid >> 3), sub = (int)(gid & 7);
+    float a = 0.f;
     if (i < D * H) {
         const int d = i / H, h = i - d * H;
-        float a = 0.f;
-#pragma unroll 10
-        for (int m = 0; m < Hm; ++m) a = __builtin_fmaf(w2[d * Hm + m], w1[m * H + h], a);
-        w21[i] = a;
-        if (w21t) w21t[h * D + d] = a;
+#pragma unroll 5
+        for (int m = sub; m < Hm; m += 8) a = __builtin_fmaf(w2[d * Hm + m], w1[m * H + h], a);
     } else if (i < D * H + D) {
         const int d = i - D * H;
-        float a = b2[d];
-#pragma unroll 10
-        for (int m = 0; m < Hm; ++m) a = __builtin_fmaf(w2[d * Hm + m], b1[m], a);
-        b21[d] = a;
+        if (sub == 0) a = b2[d];
+#pragma unroll 5
+        for (int m = sub; m < Hm; m += 8) a = __builtin_fmaf(w2[d * Hm + m], b1[m], a);
+    }
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    a += __shfl_xor(a, 4);
+    if (sub == 0) {
+        if (i < D * H) {
+            w21[i] = a;
+            if (w21t) w21t[(i % H) * D + i / H] = a;
+        } else if (i < D * H + D) {
+            b21[i - D * H] = a;
+        }
     }
 }
 
-// P [D][H], s [D] (accumulated by the caller's weight-gradient GEMM); all four gradients accumulate
+// P [D][H], s [D] (accumulated by the caller's weight-gradient GEMM); all four gradients accumulate.
+// Entries: [dW1: Hm * H, D-term sums] [dW2: D * Hm, H-term sums] [db1: Hm] [db2: D]; EIGHT lanes per entry split the sum (fixed order:
+// strided partials, then a shuffle tree), so the 300-term sums of dW2 are 38 loads per lane in flight instead of 300 in a row.
 __global__ __launch_bounds__(256) void out_mlp_param_grads_kernel(const float* __restrict__ P, const float* __restrict__ s, const float* __restrict__ w1,
                                                                   const float* __restrict__ b1, const float* __restrict__ w2, int H, int Hm, int D,
                                                                   float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
                                                                   float* __restrict__ db2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(gid >> 3), sub = (int)(gid & 7);
     const int n1 = Hm * H, n2 = D * Hm;
+    float a = 0.f;
+    int kind = -1, idx = 0;
     if (i < n1) {                                        // dW1[m][h] += sum_d W2[d][m] P[d][h]
+        kind = 0; idx = i;
         const int m = i / H, h = i - m * H;
-        float a = 0.f;
-#pragma unroll 10
-        for (int d = 0; d < D; ++d) a = __builtin_fmaf(w2[d * Hm + m], P[d * H + h], a);
-        dw1[i] += a;
+#pragma unroll 4
+        for (int d = sub; d < D; d += 8) a = __builtin_fmaf(w2[d * Hm + m], P[d * H + h], a);
     } else if (i < n1 + n2) {                            // dW2[d][m] += sum_h P[d][h] W1[m][h] + s[d] b1[m]
-        const int j = i - n1, d = j / Hm, m = j - d * Hm;
-        float a = s[d] * b1[m];
+        kind = 1; idx = i - n1;
+        const int d = idx / Hm, m = idx - d * Hm;
+        if (sub == 0) a = s[d] * b1[m];
 #pragma unroll 10
-        for (int h = 0; h < H; ++h) a = __builtin_fmaf(P[d * H + h], w1[m * H + h], a);
-        dw2[j] += a;
+        for (int h = sub; h < H; h += 8) a = __builtin_fmaf(P[d * H + h], w1[m * H + h], a);
     } else if (i < n1 + n2 + Hm) {                       // db1[m] += sum_d W2[d][m] s[d]
-        const int m = i - n1 - n2;
-        float a = 0.f;
-#pragma unroll 10
-        for (int d = 0; d < D; ++d) a = __builtin_fmaf(w2[d * Hm + m], s[d], a);
-        db1[m] += a;
+        kind = 2; idx = i - n1 - n2;
+#pragma unroll 4
+        for (int d = sub; d < D; d += 8) a = __builtin_fmaf(w2[d * Hm + idx], s[d], a);
     } else if (i < n1 + n2 + Hm + D) {
-        const int d = i - n1 - n2 - Hm;
-        db2[d] += s[d];
+        kind = 3; idx = i - n1 - n2 - Hm;
+        if (sub == 0) a = s[idx];
+    }
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    a += __shfl_xor(a, 4);
+    if (sub == 0) {
+        if (kind == 0) dw1[idx] += a;
+        else if (kind == 1) dw2[idx] += a;
+        else if (kind == 2) db1[idx] += a;
+        else if (kind == 3) db2[idx] += a;
     }
 }
 
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(256) void out_mlp_param_grads_kernel(const float* _
 extern "C" int tg_out_mlp_compose(const float* w1, const float* b1, const float* w2, const float* b2, int32_t H, int32_t Hm, int32_t D, float* w21,
                                   float* w21t, float* b21, void* stream) {
     TG_REQUIRE(w1 && b1 && w2 && b2 && w21 && b21 && H > 0 && Hm > 0 && D > 0, "tg_out_mlp_compose: bad arguments");
-    hipLaunchKernelGGL(out_mlp_compose_kernel, dim3(cdiv((long)D * H + D, 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, H, Hm, D, w21, w21t, b21);
+    hipLaunchKernelGGL(out_mlp_compose_kernel, dim3(cdiv(((long)D * H + D) * 8, 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, H, Hm, D, w21, w21t, b21);
     return check_launch("tg_out_mlp_compose");
 }
 
@@ -215,6 +236,6 @@ extern "C" int tg_out_mlp_param_grads(const float* P, const float* s, const floa
                                       float* dw1, float* db1, float* dw2, float* db2, void* stream) {
     TG_REQUIRE(P && s && w1 && b1 && w2 && dw1 && db1 && dw2 && db2 && H > 0 && Hm > 0 && D > 0, "tg_out_mlp_param_grads: bad arguments");
     const long n = (long)Hm * H + (long)D * Hm + Hm + D;
-    hipLaunchKernelGGL(out_mlp_param_grads_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, P, s, w1, b1, w2, H, Hm, D, dw1, db1, dw2, db2);
+    hipLaunchKernelGGL(out_mlp_param_grads_kernel, dim3(cdiv(n * 8, 256)), dim3(256), 0, (hipStream_t)stream, P, s, w1, b1, w2, H, Hm, D, dw1, db1, dw2, db2);
     return check_launch("tg_out_mlp_param_grads");
 }
