@@ -841,9 +841,9 @@ static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int group_ti
     if (q.ws == nullptr && group_tiles > cdiv(q.N, bn) * cdiv(p.A.K, bk)) {
         // grouped launch, atomic combine: the group as a whole fills the chip, so each problem needs fewer row splits -- and every split
         // costs one float atomic per output element (memory-side, ~1.3 TB/s chip-wide: 14 splits of the four GRU weight gradients
-        // were 91 MB of atomics, a third of the launch).  Aim at ~1536 workgroups for the group, at least 256 rows per split.
+        // were 91 MB of atomics, a third of the launch).  Aim at ~768 workgroups for the group, at least 256 rows per split.
         static int target_wgs = -1;          // lab switch TG_TN_WGS: workgroups aimed at per grouped launch
-        if (target_wgs < 0) { const char* e = getenv("TG_TN_WGS"); target_wgs = e ? atoi(e) : 1536; }
+        if (target_wgs < 0) { const char* e = getenv("TG_TN_WGS"); target_wgs = e ? atoi(e) : 768; }      // sweep of the final round-2 build: 768 beats 512 / 1024 / 1536 / 2048 by ~0.5 % of the iteration
         int s2 = cdiv(target_wgs, group_tiles);
         const int cap = cdiv(q.M, 256);
         if (s2 > cap) s2 = cap;
