@@ -788,3 +788,73 @@ def test_wav_conv2_weight_gradient(pkg, dev, B, T1):
     assert rel(dW, gw) < 1e-4 and rel(db, gb) < 1e-4, (rel(dW, gw), rel(db, gb))
     ops.wav_conv2_wgrad(cl(dy).to(dev), cl(x).to(dev), dW, None)
     assert rel(dW, 2 * gw) < 1e-4 and rel(db, gb) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ fused small sub-networks
+def test_speaker_path_fused_forward_backward(pkg, dev):
+    """tg_speaker_fwd / tg_speaker_bwd (model/multimodal_context_net.py:83-95,125-137; embedding_net.py:10-13) vs torch fp64 autograd:
+    embedding -> Linear(16,16) -> mu / logvar -> z = mu + eps exp(0.5 logvar) -> repeated over the frames; duplicate speaker ids; direct
+    gradients on mu / logvar (the KLD term)."""
+    ops = pkg.ops
+    S, B, T, W = 11, 21, 5, 24
+    table, w1, b1 = rnd(S, 16, seed=91), rnd(16, 16, seed=92, scale=0.3), rnd(16, seed=93, scale=0.1)
+    wmu, bmu, wlv, blv = rnd(16, 16, seed=94, scale=0.3), rnd(16, seed=95, scale=0.1), rnd(16, 16, seed=96, scale=0.3), rnd(16, seed=97, scale=0.1)
+    eps = rnd(B, 16, seed=98)
+    vid = torch.randint(0, S, (B,), generator=torch.Generator().manual_seed(99))
+    P = [t.double().requires_grad_(True) for t in (table, w1, b1, wmu, bmu, wlv, blv)]
+    se_r = P[0][vid]
+    zc_r = se_r @ P[1].t() + P[2]
+    mu_r, lv_r = zc_r @ P[3].t() + P[4], zc_r @ P[5].t() + P[6]
+    z_r = mu_r + eps.double() * torch.exp(0.5 * lv_r)
+    d = lambda t: t.to(dev).contiguous()
+    rep = torch.full((B * T, W), float("nan"), device=dev)
+    se, zc, mu, lv, z = ops.speaker_fwd(d(table), d(vid), d(w1), d(b1), d(wmu), d(bmu), d(wlv), d(blv), d(eps), rep=rep[:, 5:21], T=T)
+    for got, ref in ((se, se_r), (zc, zc_r), (mu, mu_r), (lv, lv_r), (z, z_r)):
+        assert rel(got, ref) < 1e-5
+    assert torch.equal(rep[:, 5:21].view(B, T, 16), z[:, None, :].expand(B, T, 16)) and bool(torch.isnan(rep[:, :5]).all()) and bool(torch.isnan(rep[:, 21:]).all())
+    dz, dmu_in, dlv_in = rnd(B, 16, seed=100), rnd(B, 16, seed=101, scale=0.1), rnd(B, 16, seed=102, scale=0.1)
+    loss = (z_r * dz.double()).sum() + (mu_r * dmu_in.double()).sum() + (lv_r * dlv_in.double()).sum()
+    grads = torch.autograd.grad(loss, P, retain_graph=True)
+    G = [torch.zeros_like(t, device=dev) for t in (table, w1, b1, wmu, bmu, wlv, blv)]
+    ops.speaker_bwd(d(dz), d(dmu_in), d(dlv_in), lv, d(eps), zc, se, d(vid), d(w1), d(wmu), d(wlv), G[1], G[2], G[3], G[4], G[5], G[6], G[0])
+    for got, ref in zip(G, grads):
+        assert rel(got, ref) < 1e-4, (got.shape, rel(got, ref))
+    ops.speaker_bwd(d(dz), None, None, lv, d(eps), zc, se, d(vid), d(w1), d(wmu), d(wlv), G[1], G[2], G[3], G[4], G[5], G[6], G[0])   # accumulates; no direct grads
+    g2 = torch.autograd.grad((z_r * dz.double()).sum(), P)
+    for got, r1, r2 in zip(G, grads, g2):
+        assert rel(got, r1 + r2) < 1e-4
+
+
+@pytest.mark.parametrize("H,Hm,D,M", [(300, 150, 27, 400), (8, 4, 27, 50)])
+def test_output_mlp_as_one_linear_map(pkg, dev, H, Hm, D, M):
+    """tg_out_mlp_compose / tg_out_mlp_param_grads: Linear(H, Hm) -> LeakyReLU(True) (identity) -> Linear(Hm, D) through the composed weight
+    (model/multimodal_context_net.py:100-104) vs torch fp64 autograd of the two-layer form."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    w1, b1, w2, b2 = rnd(Hm, H, seed=111, scale=0.1), rnd(Hm, seed=112, scale=0.1), rnd(D, Hm, seed=113, scale=0.1), rnd(D, seed=114, scale=0.1)
+    o, d_out = rnd(M, H, seed=115), rnd(M, D, seed=116)
+    P = [t.double().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    od = o.double().requires_grad_(True)
+    out_r = F.leaky_relu(od @ P[0].t() + P[1], 1.0) @ P[2].t() + P[3]
+    grads = torch.autograd.grad(out_r, P + [od], d_out.double())
+    d = lambda t: t.to(dev).contiguous()
+    w21, w21t, b21 = ops.out_mlp_compose(d(w1), d(b1), d(w2), d(b2))
+    assert torch.equal(w21.t().contiguous(), w21t)
+    out = ops.gemm_nt(Win.plain(d(o)), w21, b21, torch.empty(M, D, device=dev))
+    assert rel(out, out_r) < 1e-5
+    Pm, sv = torch.zeros(D, H, device=dev), torch.zeros(D, device=dev)
+    ops.gemm_tn(d(d_out), Win.plain(d(o)), Pm, dbias=sv)
+    G = [torch.zeros_like(t, device=dev) for t in (w1, b1, w2, b2)]
+    ops.out_mlp_param_grads(Pm, sv, d(w1), d(b1), d(w2), G[0], G[1], G[2], G[3])
+    for got, ref in zip(G, grads[:4]):
+        assert rel(got, ref) < 1e-4, (got.shape, rel(got, ref))
+    do = ops.gemm_nt(Win.plain(d(d_out)), w21t, None, torch.empty(M, H, device=dev))
+    assert rel(do, grads[4]) < 1e-4
+
+
+def test_iter_begin_advances_counters(pkg, dev):
+    ops = pkg.ops
+    ra, rb = ops.new_rng_state(5, dev), ops.new_rng_state(6, dev)
+    ca, cb = torch.full((), 3, dtype=torch.int32, device=dev), torch.full((), 9, dtype=torch.int32, device=dev)
+    ops.iter_begin(ra, rb, ca, None)
+    ops.iter_begin(ra, None, ca, cb)
+    assert ra.tolist() == [5, 2] and rb.tolist() == [6, 1] and int(ca) == 5 and int(cb) == 10
