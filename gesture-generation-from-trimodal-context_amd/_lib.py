@@ -73,8 +73,8 @@ SIGNATURES = {
     "tg_speaker_fwd": [P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, I64, I32, P],
     "tg_speaker_bwd": [P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, I32, P],
     "tg_wav_conv2_wgrad": [P, P, I32, I32, I32, P, I64, P, P, P],
-    "tg_out_mlp_compose": [P, P, P, P, I32, I32, I32, P, P, P, P],
-    "tg_out_mlp_param_grads": [P, P, P, P, P, I32, I32, I32, P, P, P, P, P],
+    "tg_out_mlp_compose": [P, P, P, P, I32, I32, I32, I32, P, P, P, P],
+    "tg_out_mlp_param_grads": [P, P, P, P, P, I32, I32, I32, I32, P, P, P, P, P],
     "tg_zero": [P, I64, P],
     "tg_permute3_batch": [P, I32, I32, P],
     "tg_add_relu": [P, P, P, I64, P],

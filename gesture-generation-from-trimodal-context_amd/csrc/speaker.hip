@@ -151,8 +151,10 @@ namespace tg {
 
 // (reduction loops unrolled by 10: ten independent loads in flight per thread -- rolled, every iteration waited out an L2 round trip: 67 us)
 // w21 [D][H] = W2 W1, w21t [H][D] (the operand of d o = d_out W21 as a row-major [N = H][K = D] matrix), b21 [D] = W2 b1 + b2
+// dup = 2: the composed weight is written twice side by side, w21 [D][2 H] = [W2 W1 | W2 W1] and w21t [2 H][D] -- the map then acts on the
+// GRU output [fwd | rev] directly (out = (y_fwd + y_rev) W21^T = y [W21 | W21]^T), and the direction sum is never materialised
 __global__ __launch_bounds__(256) void out_mlp_compose_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-                                                              const float* __restrict__ b2, int H, int Hm, int D, float* __restrict__ w21,
+                                                              const float* __restrict__ b2, int H, int Hm, int D, int dup, float* __restrict__ w21,
                                                               float* __restrict__ w21t, float* __restrict__ b21) {
     // eight lanes per entry split the Hm-term sum (strided partials, shuffle tree: fixed order)
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,8 +175,11 @@ __global__ __launch_bounds__(256) void out_mlp_compose_kernel(const float* __res
     a += __shfl_xor(a, 4);
     if (sub == 0) {
         if (i < D * H) {
-            w21[i] = a;
-            if (w21t) w21t[(i % H) * D + i / H] = a;
+            const int d = i / H, h = i - d * H;
+            for (int r = 0; r < dup; ++r) {
+                w21[d * (dup * H) + r * H + h] = a;
+                if (w21t) w21t[(r * H + h) * D + d] = a;
+            }
         } else if (i < D * H + D) {
             b21[i - D * H] = a;
         }
@@ -184,10 +189,13 @@ __global__ __launch_bounds__(256) void out_mlp_compose_kernel(const float* __res
 // P [D][H], s [D] (accumulated by the caller's weight-gradient GEMM); all four gradients accumulate.
 // Entries: [dW1: Hm * H, D-term sums] [dW2: D * Hm, H-term sums] [db1: Hm] [db2: D]; EIGHT lanes per entry split the sum (fixed order:
 // strided partials, then a shuffle tree), so the 300-term sums of dW2 are 38 loads per lane in flight instead of 300 in a row.
+// dup = 2: P arrives as [D][2 H] = d_out^T [y_fwd | y_rev]; its halves are added on the fly (P = d_out^T (y_fwd + y_rev))
 __global__ __launch_bounds__(256) void out_mlp_param_grads_kernel(const float* __restrict__ P, const float* __restrict__ s, const float* __restrict__ w1,
-                                                                  const float* __restrict__ b1, const float* __restrict__ w2, int H, int Hm, int D,
+                                                                  const float* __restrict__ b1, const float* __restrict__ w2, int H, int Hm, int D, int dup,
                                                                   float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
                                                                   float* __restrict__ db2) {
+    const int ldp = dup * H;
+    auto Pv = [&](int d, int h) { return dup == 2 ? P[d * ldp + h] + P[d * ldp + H + h] : P[d * ldp + h]; };
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = (int)(gid >> 3), sub = (int)(gid & 7);
     const int n1 = Hm * H, n2 = D * Hm;
@@ -197,13 +205,13 @@ __global__ __launch_bounds__(256) void out_mlp_param_grads_kernel(const float* _
         kind = 0; idx = i;
         const int m = i / H, h = i - m * H;
 #pragma unroll 4
-        for (int d = sub; d < D; d += 8) a = __builtin_fmaf(w2[d * Hm + m], P[d * H + h], a);
+        for (int d = sub; d < D; d += 8) a = __builtin_fmaf(w2[d * Hm + m], Pv(d, h), a);
     } else if (i < n1 + n2) {                            // dW2[d][m] += sum_h P[d][h] W1[m][h] + s[d] b1[m]
         kind = 1; idx = i - n1;
         const int d = idx / Hm, m = idx - d * Hm;
         if (sub == 0) a = s[d] * b1[m];
 #pragma unroll 10
-        for (int h = sub; h < H; h += 8) a = __builtin_fmaf(P[d * H + h], w1[m * H + h], a);
+        for (int h = sub; h < H; h += 8) a = __builtin_fmaf(Pv(d, h), w1[m * H + h], a);
     } else if (i < n1 + n2 + Hm) {                       // db1[m] += sum_d W2[d][m] s[d]
         kind = 2; idx = i - n1 - n2;
 #pragma unroll 4
@@ -225,17 +233,17 @@ __global__ __launch_bounds__(256) void out_mlp_param_grads_kernel(const float* _
 
 }  // namespace tg
 
-extern "C" int tg_out_mlp_compose(const float* w1, const float* b1, const float* w2, const float* b2, int32_t H, int32_t Hm, int32_t D, float* w21,
-                                  float* w21t, float* b21, void* stream) {
-    TG_REQUIRE(w1 && b1 && w2 && b2 && w21 && b21 && H > 0 && Hm > 0 && D > 0, "tg_out_mlp_compose: bad arguments");
-    hipLaunchKernelGGL(out_mlp_compose_kernel, dim3(cdiv(((long)D * H + D) * 8, 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, H, Hm, D, w21, w21t, b21);
+extern "C" int tg_out_mlp_compose(const float* w1, const float* b1, const float* w2, const float* b2, int32_t H, int32_t Hm, int32_t D, int32_t dup,
+                                  float* w21, float* w21t, float* b21, void* stream) {
+    TG_REQUIRE(w1 && b1 && w2 && b2 && w21 && b21 && H > 0 && Hm > 0 && D > 0 && (dup == 1 || dup == 2), "tg_out_mlp_compose: bad arguments");
+    hipLaunchKernelGGL(out_mlp_compose_kernel, dim3(cdiv(((long)D * H + D) * 8, 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, H, Hm, D, dup, w21, w21t, b21);
     return check_launch("tg_out_mlp_compose");
 }
 
 extern "C" int tg_out_mlp_param_grads(const float* P, const float* s, const float* w1, const float* b1, const float* w2, int32_t H, int32_t Hm, int32_t D,
-                                      float* dw1, float* db1, float* dw2, float* db2, void* stream) {
-    TG_REQUIRE(P && s && w1 && b1 && w2 && dw1 && db1 && dw2 && db2 && H > 0 && Hm > 0 && D > 0, "tg_out_mlp_param_grads: bad arguments");
+                                      int32_t dup, float* dw1, float* db1, float* dw2, float* db2, void* stream) {
+    TG_REQUIRE(P && s && w1 && b1 && w2 && dw1 && db1 && dw2 && db2 && H > 0 && Hm > 0 && D > 0 && (dup == 1 || dup == 2), "tg_out_mlp_param_grads: bad arguments");
     const long n = (long)Hm * H + (long)D * Hm + Hm + D;
-    hipLaunchKernelGGL(out_mlp_param_grads_kernel, dim3(cdiv(n * 8, 256)), dim3(256), 0, (hipStream_t)stream, P, s, w1, b1, w2, H, Hm, D, dw1, db1, dw2, db2);
+    hipLaunchKernelGGL(out_mlp_param_grads_kernel, dim3(cdiv(n * 8, 256)), dim3(256), 0, (hipStream_t)stream, P, s, w1, b1, w2, H, Hm, D, dup, dw1, db1, dw2, db2);
     return check_launch("tg_out_mlp_param_grads");
 }

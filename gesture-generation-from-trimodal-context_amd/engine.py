@@ -162,13 +162,14 @@ class GeneratorEngine(_Engine):
         # ---- 4-layer bidirectional GRU, sum of directions, output MLP (:155-158)
         y, gtape = L.gru_stack_fwd(in_data, P, "gru", self.n_layers, H, p_drop=self.p_drop, training=training, rng=self.rng,
                                    save=save, inject=inject, tag=tag, save_rows=save_rows)      # save_rows: the batch rows backward() will be asked for
-        o = ops.add_halves(y, L.empty(Bs * T, H, like=y))
         if ops.OUT_MLP_COMPOSED:
-            # LeakyReLU(True) == identity (README.md:122): Linear(300, 150) -> Linear(150, 27) is one linear map on the composed weight
-            w21, w21t, b21 = ops.out_mlp_compose(P["out.0.weight"], P["out.0.bias"], P["out.2.weight"], P["out.2.bias"])
-            out = L.linear_fwd(o, w21, b21).view(Bs, T, D)
-            tp.update(in_text=in_text, gru=gtape, o=o, h1=None, w21t=w21t, in_size=in_size)
+            # LeakyReLU(True) == identity (README.md:122): Linear(300, 150) -> Linear(150, 27) is one linear map on the composed weight; written
+            # twice side by side it acts on [fwd | rev] directly, so the direction sum (:155-156) is never formed
+            w21, w21t, b21 = ops.out_mlp_compose(P["out.0.weight"], P["out.0.bias"], P["out.2.weight"], P["out.2.bias"], dup=2)
+            out = L.linear_fwd(y.view(Bs * T, 2 * H), w21, b21).view(Bs, T, D)
+            tp.update(in_text=in_text, gru=gtape, o=None, y_last=y, h1=None, w21t=w21t, in_size=in_size)
         else:
+            o = ops.add_halves(y, L.empty(Bs * T, H, like=y))
             h1 = L.linear_fwd(o, P["out.0.weight"], P["out.0.bias"])
             out = L.linear_fwd(h1, P["out.2.weight"], P["out.2.bias"]).view(Bs, T, D)
             tp.update(in_text=in_text, gru=gtape, o=o, h1=h1, in_size=in_size)
@@ -291,17 +292,18 @@ class GeneratorEngine(_Engine):
         # out MLP
         if tp["h1"] is None:
             # composed output MLP: the batch-sized operands enter only P = d_out^T o (+ its column sums) and d o = d_out (W2 W1)
-            o_rows = tp["o"][b0 * T:b0 * T + M]
+            y_rows = tp["y_last"].view(-1, 2 * H)[b0 * T:b0 * T + M]
             buf = ops.zeros(D * H + D, device=d_out2.device)                    # one fill for both accumulators
             Pm, sv = buf[:D * H].view(D, H), buf[D * H:]
-            ops.gemm_tn(d_out2, Win.plain(o_rows), Pm, dbias=sv)
+            # P = d_out^T (y_fwd + y_rev): two products of one grouped launch accumulating into the same [D x H] block
+            ops.gemm_tn_group([dict(dY=d_out2, A=Win.plain(y_rows[:, :H]), dW=Pm, dbias=sv), dict(dY=d_out2, A=Win.plain(y_rows[:, H:]), dW=Pm)])
             ops.out_mlp_param_grads(Pm, sv, P["out.0.weight"], P["out.0.bias"], P["out.2.weight"], G["out.0.weight"], G["out.0.bias"],
                                     G["out.2.weight"], G["out.2.bias"])
-            do = ops.gemm_nt(Win.plain(d_out2), tp["w21t"], None, L.empty(M, H, like=d_out2))
+            dy = ops.gemm_nt(Win.plain(d_out2), tp["w21t"], None, L.empty(M, 2 * H, like=d_out2)).view(nb, T, 2 * H)   # both halves at once
         else:
             dh1 = L.linear_bwd(d_out2, tp["h1"][b0 * T:b0 * T + M], P["out.2.weight"], G["out.2.weight"], G["out.2.bias"])
             do = L.linear_bwd(dh1, tp["o"][b0 * T:b0 * T + M], P["out.0.weight"], G["out.0.weight"], G["out.0.bias"])
-        dy = ops.dup_halves(do, L.empty(nb, T, 2 * H, like=do))
+            dy = ops.dup_halves(do, L.empty(nb, T, 2 * H, like=do))
         fork = L.Fork(dy.device, enabled=self.use_side_stream)
         d_in = L.gru_stack_bwd(dy, tp["gru"], P, G, "gru", self.n_layers, b0=b0, nb=nb, fork=fork)      # (nb, T, in_size)
         d_in2 = d_in.view(M, in_size)

@@ -829,23 +829,24 @@ def speaker_bwd(dz, d_mu, d_logvar, logvar, eps, zc, se, vid, w1, wmu, wlv, dw1,
 OUT_MLP_COMPOSED = os.environ.get("TG_OUT_MLP_COMPOSED", "1") != "0"
 
 
-def out_mlp_compose(w1, b1, w2, b2):
-    """(w21 [D, H], w21t [H, D], b21 [D]) of Linear(H, Hm) -> identity -> Linear(Hm, D)."""
+def out_mlp_compose(w1, b1, w2, b2, dup=1):
+    """(w21 [D, dup H], w21t [dup H, D], b21 [D]) of Linear(H, Hm) -> identity -> Linear(Hm, D); dup = 2: the composed weight side by side
+    twice, acting on a bidirectional GRU output [fwd | rev] without the direction sum."""
     for t in (w1, b1, w2, b2):
         _flat(t, "parameter")
     Hm, H = w1.shape; D = w2.shape[0]
-    assert tuple(w2.shape) == (D, Hm) and b1.numel() == Hm and b2.numel() == D
-    w21, w21t, b21 = torch.empty(D, H, device=w1.device), torch.empty(H, D, device=w1.device), torch.empty(D, device=w1.device)
-    call("tg_out_mlp_compose", _p(w1), _p(b1), _p(w2), _p(b2), H, Hm, D, _p(w21), _p(w21t), _p(b21), _stream())
+    assert tuple(w2.shape) == (D, Hm) and b1.numel() == Hm and b2.numel() == D and dup in (1, 2)
+    w21, w21t, b21 = torch.empty(D, dup * H, device=w1.device), torch.empty(dup * H, D, device=w1.device), torch.empty(D, device=w1.device)
+    call("tg_out_mlp_compose", _p(w1), _p(b1), _p(w2), _p(b2), H, Hm, D, dup, _p(w21), _p(w21t), _p(b21), _stream())
     return w21, w21t, b21
 
 
-def out_mlp_param_grads(Pm, s, w1, b1, w2, dw1, db1, dw2, db2):
+def out_mlp_param_grads(Pm, s, w1, b1, w2, dw1, db1, dw2, db2, dup=1):
     Hm, H = w1.shape; D = w2.shape[0]
     for t in (Pm, s, w1, b1, w2, dw1, db1, dw2, db2):
         _flat(t, "operand")
-    assert tuple(Pm.shape) == (D, H) and s.numel() == D and dw1.numel() == Hm * H and dw2.numel() == D * Hm and db1.numel() == Hm and db2.numel() == D
-    call("tg_out_mlp_param_grads", _p(Pm), _p(s), _p(w1), _p(b1), _p(w2), H, Hm, D, _p(dw1), _p(db1), _p(dw2), _p(db2), _stream())
+    assert tuple(Pm.shape) == (D, dup * H) and s.numel() == D and dw1.numel() == Hm * H and dw2.numel() == D * Hm and db1.numel() == Hm and db2.numel() == D
+    call("tg_out_mlp_param_grads", _p(Pm), _p(s), _p(w1), _p(b1), _p(w2), H, Hm, D, dup, _p(dw1), _p(db1), _p(dw2), _p(db2), _stream())
 
 
 def gan_d_loss(logit_real, logit_fake, out, d_real, d_fake):

@@ -274,12 +274,14 @@ int tg_speaker_bwd(const float* dz, const float* d_mu_in, const float* d_logvar_
                    float* db1, float* dwmu, float* dbmu, float* dwlv, float* dblv, float* dtable, int32_t nb, void* stream);
 
 /* ---- output MLP Linear(H, Hm) -> LeakyReLU(True) (== identity, reference README.md:122) -> Linear(Hm, D), as ONE linear map -------------
- * (model/multimodal_context_net.py:100-104,157-158).  _compose: w21 [D][H] = W2 W1, w21t [H][D] its transpose (may be NULL), b21 = W2 b1 + b2.
- * _param_grads: from P [D][H] = d_out^T o and s [D] = colsum(d_out): dW1 += W2^T P, db1 += W2^T s, dW2 += P W1^T + s b1^T, db2 += s. */
-int tg_out_mlp_compose(const float* w1, const float* b1, const float* w2, const float* b2, int32_t H, int32_t Hm, int32_t D, float* w21,
-                       float* w21t, float* b21, void* stream);
+ * (model/multimodal_context_net.py:100-104,157-158).  _compose: w21 [D][dup H] = W2 W1 (written dup = 1 or 2 times side by side), w21t
+ * [dup H][D] its transpose (may be NULL), b21 = W2 b1 + b2.  dup = 2 lets the map act on the bidirectional GRU output [fwd | rev] without the
+ * direction sum (:155-156) being formed.  _param_grads: from P [D][dup H] = d_out^T o (dup = 2: its halves are added) and s [D] =
+ * colsum(d_out): dW1 += W2^T P, db1 += W2^T s, dW2 += P W1^T + s b1^T, db2 += s. */
+int tg_out_mlp_compose(const float* w1, const float* b1, const float* w2, const float* b2, int32_t H, int32_t Hm, int32_t D, int32_t dup,
+                       float* w21, float* w21t, float* b21, void* stream);
 int tg_out_mlp_param_grads(const float* P, const float* s, const float* w1, const float* b1, const float* w2, int32_t H, int32_t Hm, int32_t D,
-                           float* dw1, float* db1, float* dw2, float* db2, void* stream);
+                           int32_t dup, float* dw1, float* db1, float* dw2, float* db2, void* stream);
 
 /* ---- WavEncoder front end: Conv1d(1, 16, 15, stride, padding) -> BatchNorm1d(16) -> LeakyReLU, fused ------------------------
  * Replaces feat_extractor[0..2] of model/multimodal_context_net.py:13-15 (and their autograd backward) without materialising the

@@ -849,6 +849,19 @@ def test_output_mlp_as_one_linear_map(pkg, dev, H, Hm, D, M):
         assert rel(got, ref) < 1e-4, (got.shape, rel(got, ref))
     do = ops.gemm_nt(Win.plain(d(d_out)), w21t, None, torch.empty(M, H, device=dev))
     assert rel(do, grads[4]) < 1e-4
+    # dup = 2: the same map on a bidirectional input [fwd | rev] (o = fwd + rev is never formed)
+    yf, yr = rnd(M, H, seed=117), o - rnd(M, H, seed=117)
+    y2 = torch.cat([yf, yr], 1)
+    w21d, w21td, b21d = ops.out_mlp_compose(d(w1), d(b1), d(w2), d(b2), dup=2)
+    assert rel(ops.gemm_nt(Win.plain(d(y2)), w21d, b21d, torch.empty(M, D, device=dev)), out_r) < 1e-5
+    P2, s2 = torch.zeros(D, 2 * H, device=dev), torch.zeros(D, device=dev)
+    ops.gemm_tn(d(d_out), Win.plain(d(y2)), P2, dbias=s2)
+    G2 = [torch.zeros_like(t, device=dev) for t in (w1, b1, w2, b2)]
+    ops.out_mlp_param_grads(P2, s2, d(w1), d(b1), d(w2), G2[0], G2[1], G2[2], G2[3], dup=2)
+    for got, ref in zip(G2, grads[:4]):
+        assert rel(got, ref) < 1e-4
+    dy2 = ops.gemm_nt(Win.plain(d(d_out)), w21td, None, torch.empty(M, 2 * H, device=dev))
+    assert rel(dy2[:, :H], grads[4]) < 1e-4 and torch.equal(dy2[:, :H], dy2[:, H:])
 
 
 def test_iter_begin_advances_counters(pkg, dev):
