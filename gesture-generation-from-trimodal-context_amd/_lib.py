@@ -24,7 +24,7 @@ class NtProblem(C.Structure):
     """struct tg_gemm_nt_problem"""
     _fields_ = [("A", Window), ("Bw", P), ("ldb", I64), ("b_seg_k", I32), ("reserved", I32), ("b_seg_stride", I64), ("bias", P), ("C", P),
                 ("c_batch_stride", I64), ("c_row_stride", I64), ("c_rows_out", I32), ("M", I32), ("N", I32), ("act_slope", F32),
-                ("accumulate", I32), ("out_scale", P)]
+                ("accumulate", I32), ("out_scale", P), ("b_planes", P), ("b_plane_stride", I64), ("b_kp", I32), ("reserved2", I32)]
 
 
 class TnProblem(C.Structure):

@@ -83,6 +83,9 @@ struct NtProb {
     int accumulate;
     int n_nt;
     int vec_c;               // C / mul rows can be accessed as 16-byte pieces (N % 4 == 0, strides % 4 == 0, aligned pointers)
+    const __bf16* Bpl;       // optional pre-split weight operand: planes [3][>= N rows][Kp] bf16 (gemm_planes.hip), bpl_plane elements apart
+    long bpl_plane;
+    int Kp;
 };
 
 struct NtGroup {

@@ -405,8 +405,10 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
                                            out=gi[d].view(B * T, 3 * H)) for d, sfx in enumerate(("", "_reverse"))])
         else:
             a_win = Win.plain(cur.view(B * T, Kin))
+            wpl = (lambda w: weight_planes(w)) if (ops.NT_WEIGHT_PLANES and B * T >= 1024 and H > 64) else (lambda w: None)
             ops.gemm_nt_group([dict(A=a_win, W=P[f"{prefix}.weight_ih_l{l}{sfx}"], bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
-                                    out=gi[d].view(B * T, 3 * H)) for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
+                                    out=gi[d].view(B * T, 3 * H), w_planes=wpl(P[f"{prefix}.weight_ih_l{l}{sfx}"]))
+                               for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
         y = empty(B, T, 2 * H, like=x)
         sv = empty(2, B, T, 4 * H, like=x) if save else None
         whh = (P[f"{prefix}.weight_hh_l{l}"], P[f"{prefix}.weight_hh_l{l}_reverse"])

@@ -80,7 +80,7 @@ class Win:
 
 
 def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, M=None,
-                b_seg=None, out_scale=None):
+                b_seg=None, out_scale=None, w_planes=None):
     """Checked tg_gemm_nt_problem.  b_seg = (seg_k, seg_stride_floats): K-concatenated weights, W is the first [N, seg_k] segment and
     segment s starts seg_stride_floats * s floats after it (the caller keeps every segment alive)."""
     _f32(W, "W"); _f32(out, "out")
@@ -110,6 +110,9 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
         _f32(out_scale, "out_scale")
         assert out_scale.shape == out.shape and out_scale.stride() == out.stride(), (out_scale.shape, out.shape)
         q.out_scale = out_scale.data_ptr()
+    if w_planes is not None:                   # Planes of W (split3_planes / layers.weight_planes): the big-product kernels skip the weight split
+        assert b_seg is None and w_planes.rows == N and w_planes.cw == A.K and w_planes.t.is_cuda, (w_planes.rows, N, w_planes.cw, A.K)
+        q.b_planes, q.b_plane_stride, q.b_kp = w_planes.t.data_ptr(), w_planes.plane_stride, w_planes.cwp
     return q
 
 
@@ -144,6 +147,8 @@ def gemm_nt_group(problems):
 # against 14.7 M 64-byte requests per launch, profiles/r2_r_pmc_planes.txt) and ends up level with the split-while-staging kernel
 # (175 + 13 us for the split pass against 168 us inside the captured iteration).
 GEMM_PLANES = os.environ.get("TG_GEMM_PLANES", "0") != "0"
+# hybrid: only the WEIGHT operand pre-split (planes refreshed once per optimiser step), the activation still split while staged
+NT_WEIGHT_PLANES = os.environ.get("TG_NT_WEIGHT_PLANES", "0") != "0"
 
 
 class Planes:

@@ -87,6 +87,9 @@ typedef struct tg_gemm_nt_problem {
     int32_t accumulate;
     const float* out_scale;    /* NULL, or an element-wise multiplier applied after the activation, addressed like C: the inverted-dropout
                                   scale mask of F.dropout(relu(conv(x))) (model/tcn.py:22-29) rides in the epilogue */
+    const void* b_planes;      /* NULL, or the bf16 x 3 planes of Bw ([3][N + 1][b_kp] bf16 as written by tg_split3_planes, b_kp = K rounded up */
+    int64_t b_plane_stride;    /*   to 32, planes b_plane_stride elements apart): the big-product kernels then stage the weight operand */
+    int32_t b_kp, reserved2;   /*   without splitting it (one weight matrix only: b_seg_k == 0) */
 } tg_gemm_nt_problem;
 /* tg_gemm_nt_group: up to 8 independent tg_gemm_nt products in ONE launch (both GRU directions' input projections, the stride
  * phases of a conv input-gradient ...).  All problems must fall into the same kernel family as problem 0 (big / narrow / small);

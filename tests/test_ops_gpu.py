@@ -754,6 +754,20 @@ def test_gemm_nt_planes_is_fp32_accurate(pkg, dev, M, N, K):
     assert rel(out[0], ref2) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(13056, 900, 600), (13056, 900, 108), (13056, 300, 600), (2100, 130, 70)])
+def test_gemm_nt_split_with_presplit_weights_is_bit_identical(pkg, dev, M, N, K):
+    """Hybrid staging (weight operand from bf16 x 3 planes, activation split while staged): the planes hold exactly the terms the kernel would
+    have computed, so the result is bit for bit that of the plain call (128 x 96 and 128 x 64 tiles; other tiles ignore the planes)."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    x = (rnd(M, K, seed=61) * torch.logspace(-3, 3, K)).to(dev)
+    w, b = (rnd(N, K, seed=62, scale=0.1)).to(dev), rnd(N, seed=63).to(dev)
+    o0, o1 = torch.empty(M, N, device=dev), torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_nt(Win.plain(x), w, b, o0, act_slope=0.3)
+    ops.gemm_nt(Win.plain(x), w, b, o1, act_slope=0.3, w_planes=ops.split3_planes(w))
+    assert torch.equal(o0, o1)
+    assert rel(o0, F.leaky_relu(x.double().cpu() @ w.double().cpu().t() + b.double().cpu(), 0.3)) < 1e-5
+
+
 def test_gemm_nt_planes_conv_window(pkg, dev):
     """Dilated causal conv (model/tcn.py) as a two-tap row window over the plane buffer: rows before the sequence start read the zero row."""
     ops = pkg.ops
