@@ -42,13 +42,15 @@ __global__ __launch_bounds__(256) void speaker_fwd_kernel(const float* __restric
 }
 
 // dz [nb][16]: gradient w.r.t. z (already summed over the frames).  d_mu_in / d_lv_in: direct gradients (KLD term) or NULL.
-__global__ __launch_bounds__(256) void speaker_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ d_mu_in, const float* __restrict__ d_lv_in,
-                                                          const float* __restrict__ lv, const float* __restrict__ eps, const float* __restrict__ zc,
-                                                          const float* __restrict__ se, const int64_t* __restrict__ vid, int n_rows,
-                                                          const float* __restrict__ w1, const float* __restrict__ wmu, const float* __restrict__ wlv,
-                                                          float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dwmu,
-                                                          float* __restrict__ dbmu, float* __restrict__ dwlv, float* __restrict__ dblv,
-                                                          float* __restrict__ dtable, int nb) {
+// One workgroup of 1024 threads: every operand in LDS; the three 16 x 16 weight gradients are 768 entries, one thread each, summed over the
+// batch in order.
+__global__ __launch_bounds__(1024) void speaker_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ d_mu_in, const float* __restrict__ d_lv_in,
+                                                           const float* __restrict__ lv, const float* __restrict__ eps, const float* __restrict__ zc,
+                                                           const float* __restrict__ se, const int64_t* __restrict__ vid, int n_rows,
+                                                           const float* __restrict__ w1, const float* __restrict__ wmu, const float* __restrict__ wlv,
+                                                           float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dwmu,
+                                                           float* __restrict__ dbmu, float* __restrict__ dwlv, float* __restrict__ dblv,
+                                                           float* __restrict__ dtable, int nb) {
     extern __shared__ float sh[];                       // [5][nb][16]: dmu, dlv, zc, se, dzc
     float* s_dmu = sh;
     float* s_dlv = sh + (long)nb * SZ;
@@ -56,8 +58,9 @@ __global__ __launch_bounds__(256) void speaker_bwd_kernel(const float* __restric
     float* s_se = sh + 3L * nb * SZ;
     float* s_dzc = sh + 4L * nb * SZ;
     const int n = nb * SZ;
-#pragma unroll 8
-    for (int i = threadIdx.x; i < n; i += 256) {          // (unrolled: the seven loads of eight iterations in flight together)
+    const int nt = blockDim.x;
+#pragma unroll 2
+    for (int i = threadIdx.x; i < n; i += nt) {
         const float g = dz[i];
         s_dmu[i] = (d_mu_in ? d_mu_in[i] : 0.f) + g;                                         // reparam_bwd_kernel
         s_dlv[i] = (d_lv_in ? d_lv_in[i] : 0.f) + g * eps[i] * 0.5f * expf(0.5f * lv[i]);
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void speaker_bwd_kernel(const float* __restric
     }
     __syncthreads();
     // dzc = dmu . Wmu + dlv . Wlv   (input gradients of the two heads, summed)
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < n; i += nt) {
         const int b = i >> 4, k = i & 15;
         float a = 0.f;
 #pragma unroll
@@ -76,24 +79,25 @@ __global__ __launch_bounds__(256) void speaker_bwd_kernel(const float* __restric
         s_dzc[i] = a;
     }
     __syncthreads();
-    // weight gradients: thread (j, k) of the 16 x 16 matrix sums over the batch in order; bias gradients by the threads of row k == 0
-    {
-        const int j = threadIdx.x >> 4, k = threadIdx.x & 15;
-        float gm = 0.f, gl = 0.f, g1 = 0.f, bm = 0.f, bl = 0.f, bb1 = 0.f;
+    // weight gradients: thread (matrix, j, k) sums over the batch in order; bias gradients by the threads of column k == 0
+    if (threadIdx.x < 3 * SZ * SZ) {
+        const int mat = threadIdx.x >> 8, j = (threadIdx.x >> 4) & 15, k = threadIdx.x & 15;
+        const float* dsrc = mat == 0 ? s_dmu : (mat == 1 ? s_dlv : s_dzc);
+        const float* xsrc = mat == 2 ? s_se : s_zc;
+        float gsum = 0.f, bsum = 0.f;
+#pragma unroll 8
         for (int b = 0; b < nb; ++b) {
-            const float dm = s_dmu[b * SZ + j], dl = s_dlv[b * SZ + j], dc = s_dzc[b * SZ + j];
-            gm = __builtin_fmaf(dm, s_zc[b * SZ + k], gm);
-            gl = __builtin_fmaf(dl, s_zc[b * SZ + k], gl);
-            g1 = __builtin_fmaf(dc, s_se[b * SZ + k], g1);
-            bm += dm; bl += dl; bb1 += dc;
+            const float dv = dsrc[b * SZ + j];
+            gsum = __builtin_fmaf(dv, xsrc[b * SZ + k], gsum);
+            bsum += dv;
         }
-        dwmu[j * SZ + k] += gm;
-        dwlv[j * SZ + k] += gl;
-        dw1[j * SZ + k] += g1;
-        if (k == 0) { dbmu[j] += bm; dblv[j] += bl; db1[j] += bb1; }
+        float* dw = mat == 0 ? dwmu : (mat == 1 ? dwlv : dw1);
+        float* db = mat == 0 ? dbmu : (mat == 1 ? dblv : db1);
+        dw[j * SZ + k] += gsum;
+        if (k == 0) db[j] += bsum;
     }
     // dse = dzc . W1, scattered into the embedding gradient (duplicates of a speaker id meet in float atomics, like tg_embed_scatter_add)
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < n; i += nt) {
         const int b = i >> 4, k = i & 15;
         float a = 0.f;
 #pragma unroll
@@ -136,7 +140,7 @@ extern "C" int tg_speaker_bwd(const float* dz, const float* d_mu_in, const float
             raised = true;
         }
     }
-    hipLaunchKernelGGL(speaker_bwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, dz, d_mu_in, d_logvar_in, logvar, eps, zc, se, vid, n_rows, w1, wmu, wlv,
+    hipLaunchKernelGGL(speaker_bwd_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, dz, d_mu_in, d_logvar_in, logvar, eps, zc, se, vid, n_rows, w1, wmu, wlv,
                        dw1, db1, dwmu, dbmu, dwlv, dblv, dtable, nb);
     return check_launch("tg_speaker_bwd");
 }

@@ -260,8 +260,9 @@ def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None):
     if (M - 1) * dY.stride(0) + N - 1 >= _room(dY):
         raise ValueError("gemm_tn: dY exceeds its tensor")
     ws, nws = None, 0
-    if M >= TN_TWO_PASS_ROWS or (out_kw > 0 and M >= 1024):
-        # two-pass (partial tiles + fp64 combine): long reductions for accuracy, and every conv-layout output (out_kw > 0):
+    if M >= TN_TWO_PASS_ROWS or (out_kw > 0 and M >= 1024 and N * A.K >= 8192):
+        # two-pass (partial tiles + fp64 combine): long reductions for accuracy, and every conv-layout output (out_kw > 0) of >= 8 K entries
+        # (the discriminator's 16 x 81 ... 8 x 24 conv gradients are a few hundred atomics: the combine launch cost more than it saved):
         # the permuted (Co, Ci, kw) scatter makes the one-pass float atomics uncoalesced (measured 224 -> 39 us on the audio
         # conv3 weight gradient), the combine kernel writes that layout from contiguous partials instead
         nws = _lib.load().tg_gemm_tn_ws_floats(M, N, A.K)
