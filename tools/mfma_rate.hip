@@ -1,4 +1,4 @@
-// Back-to-back MFMA issue-rate probe: one wave per SIMD (256-thread blocks, 1 block per CU), independent accumulators.
+// Back-to-back MFMA issue-rate probe (MFMAs pinned with inline asm so the compiler cannot shuffle accumulators through AGPRs): one wave per SIMD (256-thread blocks, 1 block per CU), independent accumulators.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float 
         for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
         for (int it = 0; it < iters; ++it)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
         float s = 0; for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
         out[blockIdx.x * 256 + threadIdx.x] = s;
     } else if (MODE == 1) {   // f32 32x32x2, 4 accumulators
@@ -20,7 +20,17 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float 
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
         for (int it = 0; it < iters; ++it)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+        float s = 0; for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
+        out[blockIdx.x * 256 + threadIdx.x] = s;
+    } else if (MODE == 3) {   // bf16 32x32x16, 4 accumulators
+        bf16x8 fa, fb;
+        for (int j = 0; j < 8; ++j) { fa[j] = (__bf16)(a + j); fb[j] = (__bf16)(b - j); }
+        f32x16 acc[4];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa), "v"(fb));
         float s = 0; for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
         out[blockIdx.x * 256 + threadIdx.x] = s;
     } else {                  // bf16 16x16x32, 8 accumulators
@@ -30,7 +40,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float 
         for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
         for (int it = 0; it < iters; ++it)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa), "v"(fb));
         float s = 0; for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
         out[blockIdx.x * 256 + threadIdx.x] = s;
     }
@@ -51,10 +61,11 @@ template <int MODE> void run(const char* name, int per_iter, double flop_per_mfm
     hipFree(out);
 }
 int main() {
-    for (int blocks : {256, 512}) {
+    for (int blocks : {256, 512, 1024}) {
         run<0>("f32 16x16x4", 8, 2.0 * 16 * 16 * 4, blocks);
         run<1>("f32 32x32x2", 4, 2.0 * 32 * 32 * 2, blocks);
         run<2>("bf16 16x16x32", 8, 2.0 * 16 * 16 * 32, blocks);
+        run<3>("bf16 32x32x16", 4, 2.0 * 32 * 32 * 16, blocks);
     }
     return 0;
 }
