@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import layers as L
-from . import ops
+from . import ops, _lib
 from .ops import Win
 from .params import ParamSlab
 
@@ -340,6 +340,7 @@ class GeneratorEngine(_Engine):
             Co_t = P[f"{te}.tcn.network.0.conv1.weight_v"].shape[0]
             dwp_all = ops.zeros(2 * self.n_layers, Co_t, 2 * Co_t, device=dcur.device)       # packed weight gradients of the 8 convs: one fill
             wn_pre = []                                                                       # weight-norm backward of all convs: one launch after the loop
+            wg_probs = []
             for i in range(self.n_layers - 1, -1, -1):
                 blk = tp["tcn"][i]
                 d = blk["d"]
@@ -358,7 +359,9 @@ class GeneratorEngine(_Engine):
                     xin = blk[f"in{ci}"][rows]
                     v = P[pre + ".weight_v"]
                     dwp = dwp_all[2 * i + ci]
-                    ops.gemm_tn(dc, Win.conv(xin, 2, pad=d, dil=d, rows_out=T), dwp, dbias=G[pre + ".bias"])
+                    # the weight gradient is off the dependency chain: all convs' products go into ONE grouped launch after the loop
+                    # (eight launches of 33 us, each a tail-heavy 700-workgroup grid, against one that fills the chip)
+                    wg_probs.append(dict(dY=dc, A=Win.conv(xin, 2, pad=d, dil=d, rows_out=T), dW=dwp, dbias=G[pre + ".bias"]))
                     wn_pre.append((dwp, pre))
                     # dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0]  -> taps (t + d, t) with B = w^T per tap (from the forward's batch)
                     wT = blk[f"wt{ci}"]
@@ -367,6 +370,8 @@ class GeneratorEngine(_Engine):
                     else:   # first conv of the block: add into the residual branch gradient
                         dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, dsum, accumulate=True)
                 dcur = dh
+            for j0 in range(0, len(wg_probs), _lib.MAX_GROUP):
+                ops.gemm_tn_group(wg_probs[j0:j0 + _lib.MAX_GROUP])
             for j0 in range(0, len(wn_pre), 8):
                 chunk = wn_pre[j0:j0 + 8]
                 ops.weight_norm_bwd_batch([dw for dw, _ in chunk], [P[pre + ".weight_v"] for _, pre in chunk],
@@ -422,6 +427,8 @@ class GeneratorEngine(_Engine):
 class DiscriminatorEngine(_Engine):
     H = 64
     CONVS = ((0, 16, 27), (3, 8, 16), (6, 8, 8))
+    d_fork = os.environ.get("TG_D_FORK", "0") != "0"
+    d_defer_wgrad = os.environ.get("TG_D_DEFER_WGRAD", "1") != "0"
 
     def forward(self, poses, *, training, groups=1, save=False, inject=None, tag="d"):
         """poses: (Bs, 34, 27).  Returns {'logit': (Bs,1) pre-sigmoid, 'prob': sigmoid, 'tape'}."""
@@ -464,18 +471,33 @@ class DiscriminatorEngine(_Engine):
         dy = ops.d_head_bwd(d_logit.contiguous().view(nb), tp["y"][rows], tp["l1"][rows], P["out.weight"], P["out2.weight"],
                             L.empty(nb, T, 2 * H, like=d_logit),
                             (G["out.weight"], G["out.bias"], G["out2.weight"], G["out2.bias"]) if pg else None)
-        dx = L.gru_stack_bwd(dy, tp["gru"], P, G, "gru", 4, b0=b0, nb=nb, param_grads=pg)              # (nb, 28, 8)
+        # TG_D_FORK=1: the weight-gradient GEMMs (off the dependency chain) on a second stream beside the next layer's recurrence, which
+        # occupies 2 * nb / 16 workgroups; the H = 64 kernels have no cross-workgroup synchronisation, so sharing the device is safe
+        # (TG_D_FORK=1, lab: the weight-gradient GEMMs on a second stream beside the next layer's recurrence -- measured 0.19 ms SLOWER per
+        # iteration under graph replay: seven fork / join pairs cost more than the 140 us they hide)
+        fork = L.Fork(dy.device, enabled=pg and self.d_fork)
+        # default: every weight gradient of the backward pass is deferred and launched in three grouped launches at the end (they are off
+        # the dependency chain; one launch per layer was mostly launch latency and tail on the 32-workgroup-sized problems)
+        deferred = [] if (pg and not self.d_fork and self.d_defer_wgrad) else None
+        dx = L.gru_stack_bwd(dy, tp["gru"], P, G, "gru", 4, b0=b0, nb=nb, param_grads=pg, fork=fork, defer=deferred)    # (nb, 28, 8)
+        def finish(ret):
+            if deferred:
+                L.tn_group_deferred(deferred)
+            fork.join()
+            return ret
         for li in (2, 1, 0):
             idx, Co, Ci = self.CONVS[li]
             x_in, _ = tp["convs"][li]
             x_rows = x_in[rows]
             if pg:
-                L.conv_wgrad(dx, x_rows, G[f"pre_conv.{idx}.weight"], G[f"pre_conv.{idx}.bias"], 3)
+                fork.keep(dx, x_rows)
+                with fork:
+                    L.conv_wgrad(dx, x_rows, G[f"pre_conv.{idx}.weight"], G[f"pre_conv.{idx}.bias"], 3, defer=deferred)
             if li == 0 and not need_dposes:
-                return None
+                return finish(None)
             dxa = L.conv_dgrad(dx, P[f"pre_conv.{idx}.weight"], x_rows.shape[1])
             if li == 0:
-                return dxa
+                return finish(dxa)
             pidx = self.CONVS[li - 1][0] + 1
             _, st_prev = tp["convs"][li - 1]
             dx = L.bn_bwd(dxa, st_prev, P[f"pre_conv.{pidx}.weight"], P[f"pre_conv.{pidx}.bias"],

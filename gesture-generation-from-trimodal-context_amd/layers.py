@@ -6,7 +6,7 @@ gradients straight into the caller's gradient views (which live in one flat slab
 """
 import torch
 
-from . import ops
+from . import ops, _lib
 from .ops import Win
 
 
@@ -199,12 +199,27 @@ def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=
     return out
 
 
-def conv_wgrad(dy, x, dW, db, kw, *, stride=1, pad=0, dil=1):
+def tn_group_deferred(probs):
+    """Launch deferred weight-gradient problems in as few grouped launches as possible.  A group runs on the bf16 x 3 kernel only when
+    every member qualifies (tg_gemm_tn_group: vectorisable layout, M >= 1024, N and K >= 48 and multiples of 4), so the two kinds are
+    grouped separately."""
+    def x3(p):
+        dY, A = p["dY"], p["A"]
+        return dY.shape[0] >= 1024 and dY.shape[1] >= 48 and A.K >= 48 and dY.shape[1] % 4 == 0 and A.K % 4 == 0 and A.s.cw % 4 == 0
+    for kind in (True, False):
+        sel = [p for p in probs if x3(p) == kind]
+        for j0 in range(0, len(sel), _lib.MAX_GROUP):
+            ops.gemm_tn_group(sel[j0:j0 + _lib.MAX_GROUP])
+
+
+def conv_wgrad(dy, x, dW, db, kw, *, stride=1, pad=0, dil=1, defer=None):
     """dy: (B, Lout, Co) contiguous; x: (B, L, Ci) view; dW: (Co, Ci, kw) gradient view (accumulates)."""
     B, Lo, Co = dy.shape
     A = Win.conv(x, kw, stride=stride, pad=pad, dil=dil, rows_out=Lo)
     dy2 = dy.reshape(B * Lo, Co)
-    if dW is not None:
+    if dW is not None and defer is not None:
+        defer.append(dict(dY=dy2, A=A, dW=dW.view(Co, -1), out_kw=kw, dbias=db))
+    elif dW is not None:
         ops.gemm_tn(dy2, A, dW.view(Co, -1), out_kw=kw, dbias=db)
     elif db is not None:
         ops.colsum(dy2, db, accumulate=True)
@@ -487,10 +502,12 @@ class Fork:
         self._keep = []
 
 
-def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=True, param_grads=True, fork=None):
+def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=True, param_grads=True, fork=None, defer=None):
     """dy: (nb, T, 2H) gradient w.r.t. the last layer's output for rows [b0, b0+nb) of the taped forward.
     Accumulates into G[...] and returns dx (nb, T, Kin0).  With `fork`, each layer's weight-gradient GEMMs run on the side
-    stream while the main stream goes on with dx and the next layer's recurrence; the caller joins."""
+    stream while the main stream goes on with dx and the next layer's recurrence; the caller joins.  With `defer` (a list), the
+    weight-gradient problems are appended to it instead of launched: the caller groups them (tn_group_deferred) -- they are off the
+    dependency chain, and on the small H = 64 stack one launch per layer is mostly launch and tail."""
     B, T, H = tape.B, tape.T, tape.H
     nb = B - b0 if nb is None else nb
     rows = slice(b0, b0 + nb)
@@ -522,7 +539,10 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
                     # h_{t-1} of direction d is the layer output one step back (forward) / ahead (reverse), zero at the ends
                     hwin = Win.taps(y_l[:, :, d * H:(d + 1) * H], 1, shift=(1 if d else -1), dil=1, rows_out=T)
                     probs.append(dict(dY=gh2, A=hwin, dW=G[f"{prefix}.weight_hh_l{l}{sfx}"], dbias=G[f"{prefix}.bias_hh_l{l}{sfx}"]))
-                ops.gemm_tn_group(probs)                 # the layer's four weight gradients (+ four bias gradients), one launch
+                if defer is not None:
+                    defer.extend(probs)
+                else:
+                    ops.gemm_tn_group(probs)             # the layer's four weight gradients (+ four bias gradients), one launch
         dx = None
         if need_dx or l > 0:
             dx = empty(nb * T, Kin, like=dy)
