@@ -64,9 +64,18 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
 // OCC = waves per SIMD the register allocation is held to (HIP's second launch-bounds argument; 1 = unconstrained)
 // BPL: the weight operand arrives PRE-SPLIT (NtProb::Bpl, bf16 x 3 planes written once per optimiser step by layers.WeightPrep): its
 // staging is three 16-byte loads -> three 16-byte LDS stores per piece and no arithmetic -- the activation operand is still split while staged.
-template <int TM, int TN, int SPLITS, int DB, int RING = 1, int OCC = 1, bool BPL = false>
+// ABL (lab builds only, -DTG_LAB_ABLATE, tools/nt_ablate.py; results are WRONG by construction): bit 0 drops the MFMAs, bit 1 the split
+// arithmetic, bit 2 the LDS fragment reads, bit 3 the global operand loads -- what each phase costs in situ and how much of it overlaps
+// FAST: every problem of the group has a window WITHOUT padding (every (row, tap) inside the tensor: nt_fast_ok below), operands addressable
+// with 32-bit byte offsets, cw >= 32 and b_seg_k >= 32.  The slab loop then carries no row masks and no 64-bit address arithmetic: rows past
+// M / N are CLAMPED to the last one (their products are computed and dropped by the epilogue), a piece's address is one 32-bit add to an
+// SGPR base, the tap / segment walk is one compare-and-select per thread and slab, and only the K tail slab selects zeros.  The generic
+// loop spends ~110 of its 284 vector instructions per slab on exactly that (ISA count, 128 x 96 tile) and is vector-issue bound next to its
+// 72 MFMAs (tools/nt_ablate.py: every 160 vector instructions removed = 30 us of the 182 us launch).
+template <int TM, int TN, int SPLITS, int DB, int RING = 1, int OCC = 1, bool BPL = false, int ABL = 0, bool FAST = false>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g) {
     static_assert(!BPL || (SPLITS == 3 && RING == 1), "pre-split weights: the bf16 x 3 arithmetic, one slab of loads in flight");
+    static_assert(!FAST || !BPL, "fast addressing: fp32 operands");
     const int pi = group_find(g, blockIdx.x);
     const NtProb& pr = g.p[pi];
     const Win A = pr.A;
@@ -104,14 +113,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
     long a_off[NPA];
     int a_r[NPA];
     bool a_ok[NPA];
+    unsigned a_base[NPA], b_base[NPB];                        // FAST: byte offsets of (row, tap 0, column 0) from A.ptr / Bw
 #pragma unroll
     for (int q = 0; q < NPA; ++q) {
         const int m = m0 + sr0 + 32 * q;
         a_ok[q] = m < M;
-        const int mm = a_ok[q] ? m : 0;
+        const int mm = a_ok[q] ? m : (FAST ? M - 1 : 0);
         const int b = mm / A.rows_out;
         a_off[q] = (long)b * A.bs;
         a_r[q] = (mm - b * A.rows_out) * A.step + A.shift;
+        a_base[q] = (unsigned)((a_off[q] + (long)a_r[q] * A.rs) * 4);
     }
     const float* b_ptr[NPB];
     bool b_ok[NPB];
@@ -119,7 +130,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
     for (int q = 0; q < NPB; ++q) {
         const int n = n0 + sr0 + 32 * q;
         b_ok[q] = n < N;
-        b_ptr[q] = Bw + (long)(b_ok[q] ? n : 0) * ldb;
+        b_ptr[q] = Bw + (long)(b_ok[q] ? n : (FAST ? N - 1 : 0)) * ldb;
+        b_base[q] = (unsigned)((long)(b_ok[q] ? n : N - 1) * ldb * 4);
     }
     // pre-split weights: thread t owns 16-byte slot (t & 3) of weight rows (t >> 2) + 64 h of every plane (gemm_planes.hip staging map)
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -139,6 +151,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
     }
     int kk = sp / A.cw, c = sp - (sp / A.cw) * A.cw;          // tap / channel of this thread's piece, advanced by 32 per slab
     int bsg = sp / b_seg_k, bc = sp - (sp / b_seg_k) * b_seg_k;   // weight segment / column inside it, likewise
+    // FAST: byte offset of this thread's piece inside its row (tap walk folded in), and what a tap / segment wrap adds to it
+    unsigned ka = (unsigned)(((long)kk * A.dil * A.rs + c) * 4), kb = (unsigned)(((long)bsg * b_seg_stride + bc) * 4);
+    const unsigned ka_wrap = (unsigned)(((long)A.dil * A.rs - A.cw) * 4), kb_wrap = (unsigned)((b_seg_stride - b_seg_k) * 4);
+    const char* const a_bytes = reinterpret_cast<const char*>(A.ptr);
+    const char* const b_bytes = reinterpret_cast<const char*>(Bw);
 
     f32x4 ga[RING][NPA], gb[RING][NPB];
     unsigned ga_ok[RING], gb_ok[RING];
@@ -151,11 +168,26 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
         const int k = k0 + sp;
         const bool inb = k < K;
         unsigned ma = 0u, mb = 0u;
+        if constexpr (FAST) {
+            // pieces past K (tail slab only) re-read the row start; the staging of the tail slab selects zeros for them
+            const unsigned oa = inb ? ka : 0u, ob = inb ? kb : 0u;
+#pragma unroll
+            for (int q = 0; q < NPA; ++q) ga[set][q] = *reinterpret_cast<const f32x4*>(a_bytes + (a_base[q] + oa));
+#pragma unroll
+            for (int q = 0; q < NPB; ++q) gb[set][q] = *reinterpret_cast<const f32x4*>(b_bytes + (b_base[q] + ob));
+            ga_ok[set] = gb_ok[set] = inb ? ~0u : 0u;
+            c += 32; ka += 128u;
+            if (c >= A.cw) { c -= A.cw; ka += ka_wrap; }
+            bc += 32; kb += 128u;
+            if (bc >= b_seg_k) { bc -= b_seg_k; kb += kb_wrap; }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NPA; ++q) {
             const int sr = a_r[q] + kk * A.dil;
             const bool ok = a_ok[q] && inb && sr >= 0 && sr < A.rows_in;
-            ga[set][q] = *reinterpret_cast<const f32x4*>(ok ? A.ptr + a_off[q] + (long)sr * A.rs + c : A.ptr);
+            if constexpr (ABL & 8) ga[set][q] = f32x4{1.f + lane, 2.f, 3.f + k0, 4.f};
+            else ga[set][q] = *reinterpret_cast<const f32x4*>(ok ? A.ptr + a_off[q] + (long)sr * A.rs + c : A.ptr);
             ma |= ok ? (1u << q) : 0u;
         }
         if constexpr (BPL) {
@@ -167,7 +199,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
 #pragma unroll
             for (int q = 0; q < NPB; ++q) {
                 const bool ok = b_ok[q] && inb;
-                gb[set][q] = *reinterpret_cast<const f32x4*>(ok ? b_ptr[q] + bsg * b_seg_stride + bc : Bw);
+                if constexpr (ABL & 8) gb[set][q] = f32x4{.5f + lane, .25f, .125f + k0, 1.f};
+                else gb[set][q] = *reinterpret_cast<const f32x4*>(ok ? b_ptr[q] + bsg * b_seg_stride + bc : Bw);
                 mb |= ok ? (1u << q) : 0u;
             }
         }
@@ -188,12 +221,19 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
     using set1 = std::integral_constant<int, RING - 1>;
     int buf = 0;
     // one slab: stage register set `set` into LDS, refill the set with the slab RING ahead, multiply
-    auto slab = [&](auto set_c, int k0) {
+    // tail_c: this slab may hold pieces past K or past the operand's rows -> select zeros while staging (always, on the generic path)
+    auto slab = [&](auto set_c, int k0, auto tail_c) {
         constexpr int set = decltype(set_c)::value;
+        constexpr bool MASKED = !FAST || decltype(tail_c)::value;
         if (!DB && k0 > 0) __syncthreads();                     // single buffer: everybody has read the previous slab
 #pragma unroll
         for (int q = 0; q < NPA; ++q) {
             u32x2 o[NS];
+            if constexpr (ABL & 2) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) o[s] = u32x2{__float_as_uint(ga[set][q][0]), __float_as_uint(ga[set][q][2])};
+            } else if constexpr (!MASKED) split4<SPLITS>(ga[set][q], o);
+            else
             split4<SPLITS>((ga_ok[set] >> q) & 1u ? ga[set][q] : f32x4{0.f, 0.f, 0.f, 0.f}, o);
 #pragma unroll
             for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][sr0 + 32 * q][sp_w]) = o[s];
@@ -215,6 +255,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
 #pragma unroll
             for (int q = 0; q < NPB; ++q) {
                 u32x2 o[NS];
+                if constexpr (ABL & 2) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) o[s] = u32x2{__float_as_uint(gb[set][q][1]), __float_as_uint(gb[set][q][3])};
+                } else if constexpr (!MASKED) split4<SPLITS>(gb[set][q], o);
+                else
                 split4<SPLITS>((gb_ok[set] >> q) & 1u ? gb[set][q] : f32x4{0.f, 0.f, 0.f, 0.f}, o);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][BM + sr0 + 32 * q][sp_w]) = o[s];
@@ -226,15 +271,26 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(&lds[buf][s][wm * (16 * TM) + i * 16 + r16][fcol]);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (ABL & 4) { u32x2 c2 = {0x3f803f80u + lane + i, 0x3f003f00u + s}; fa[s][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(c2, c2, 0, 1, 0, 1)); }
+                else fa[s][i] = *reinterpret_cast<const bf16x8*>(&lds[buf][s][wm * (16 * TM) + i * 16 + r16][fcol]);
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(&lds[buf][s][BM + wn * (16 * TN) + j * 16 + r16][fcol]);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (ABL & 4) { u32x2 c2 = {0x3f803f80u + lane + j, 0x3e803e80u + s}; fb[s][j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(c2, c2, 0, 1, 0, 1)); }
+                else fb[s][j] = *reinterpret_cast<const bf16x8*>(&lds[buf][s][BM + wn * (16 * TN) + j * 16 + r16][fcol]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x4 cc = acc[i][j];
+                if constexpr (ABL & 1) {               // fragments stay live, no matrix instruction
+                    if (i == 0) { asm volatile("" :: "v"(fb[0][j]), "v"(fb[NS - 1][j]), "v"(fb[NS / 2][j])); }
+                    if (j == 0) { asm volatile("" :: "v"(fa[0][i]), "v"(fa[NS - 1][i]), "v"(fa[NS / 2][i])); }
+                    continue;
+                }
                 if constexpr (SPLITS == 3) {           // smallest terms first
                     cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][i], fb[0][j], cc, 0, 0, 0);
                     cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[2][j], cc, 0, 0, 0);
@@ -246,15 +302,35 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
             }
         if (DB) buf ^= 1;
     };
+    using tail_t = std::true_type;
+    using full_t = std::false_type;
     fetch(set0{}, 0);
     if constexpr (RING == 2) {
         if (32 < K) fetch(set1{}, 32);
-        for (int k0 = 0; k0 < K; k0 += 64) {
-            slab(set0{}, k0);
-            if (k0 + 32 < K) slab(set1{}, k0 + 32);
+        int k0 = 0;
+        if constexpr (FAST) {
+            for (; k0 + 64 <= K; k0 += 64) {
+                slab(set0{}, k0, full_t{});
+                slab(set1{}, k0 + 32, full_t{});
+            }
+            if (k0 + 32 <= K) {
+                slab(set0{}, k0, full_t{});
+                if (k0 + 32 < K) slab(set1{}, k0 + 32, tail_t{});
+            } else if (k0 < K) slab(set0{}, k0, tail_t{});
+        } else {
+            for (; k0 < K; k0 += 64) {
+                slab(set0{}, k0, tail_t{});
+                if (k0 + 32 < K) slab(set1{}, k0 + 32, tail_t{});
+            }
         }
     } else {
-        for (int k0 = 0; k0 < K; k0 += 32) slab(set0{}, k0);
+        int k0 = 0;
+        if constexpr (FAST) {
+            for (; k0 + 32 <= K; k0 += 32) slab(set0{}, k0, full_t{});
+            if (k0 < K) slab(set0{}, k0, tail_t{});
+        } else {
+            for (; k0 < K; k0 += 32) slab(set0{}, k0, tail_t{});
+        }
     }
 
     const int vec_c = pr.vec_c;
@@ -584,6 +660,24 @@ extern "C" int tg_get_math_mode(void) { return g_math_mode; }
 // and win when the grid has at least ~2 workgroups per CU (the stacked forward, M = 13056); the backward shapes (M = 4352) have too
 // few 128-row tiles for that and run 64-row double-buffered tiles instead (476 x [64 x 96] for N = 600: 50 us against 59 for 238 x
 // [128 x 96] and 68 for the f32-MFMA kernel).
+// FAST addressing precondition for one problem (host): no padding anywhere in the window, 32-bit byte offsets, taps / weight segments at
+// least one slab wide
+static bool nt_fast_ok(const NtProb& p) {
+    const Win& A = p.A;
+    if (A.cw < 32 || p.b_seg_k < 32 || A.K < 64 || A.cw % 4 != 0 || p.b_seg_k % 4 != 0 || A.K % A.cw != 0 || A.K % p.b_seg_k != 0) return false;
+    const int taps = A.K / A.cw, segs = A.K / p.b_seg_k;
+    if (A.rows_out <= 0 || p.M % A.rows_out != 0) return false;                 // whole batches
+    // source rows r * step + shift + kk * dil over r in [0, rows_out), kk in [0, taps): both extremes inside [0, rows_in)
+    const long r_lo = (A.step >= 0 ? 0 : (long)(A.rows_out - 1) * A.step) + A.shift + (A.dil >= 0 ? 0 : (long)(taps - 1) * A.dil);
+    const long r_hi = (A.step >= 0 ? (long)(A.rows_out - 1) * A.step : 0) + A.shift + (A.dil >= 0 ? (long)(taps - 1) * A.dil : 0);
+    if (r_lo < 0 || r_hi >= A.rows_in) return false;
+    if (A.bs < 0 || A.rs < 0 || p.ldb < 0 || p.b_seg_stride < 0) return false;
+    const long batches = p.M / A.rows_out;
+    const long a_max = (batches - 1) * A.bs + r_hi * A.rs + A.cw;                // elements
+    const long b_max = (long)(p.N - 1) * p.ldb + (long)(segs - 1) * p.b_seg_stride + p.b_seg_k;
+    return a_max < (1l << 29) && b_max < (1l << 29);
+}
+
 struct SplitTile { int tm, tn, db; };
 static SplitTile split_pick_tile(int M, int N) {
     auto wgs = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(N, bn); };
@@ -624,6 +718,33 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
         else if (tl.tm == 2 && tl.tn == 3) TG_SPLIT(2, 3, SP_, 1);      \
         else TG_SPLIT(2, 2, SP_, 1);                                    \
     } while (0)
+    // fast addressing (see the kernel's FAST note): decided for the group as a whole
+    static const int fast_on = [] { const char* e = getenv("TG_NT_FAST"); return e ? atoi(e) : 1; }();
+    bool fast = fast_on != 0 && g_math_mode == 0 && ring >= 1 && ring <= 2;
+    for (int i = 0; i < g.n && fast; ++i) fast = nt_fast_ok(g.p[i]);
+    if (fast) {
+        for (int i = 0; i < g.n; ++i) fast = fast && g.p[i].Bpl == nullptr;
+    }
+    if (fast) {
+#define TG_FAST(TM_, TN_, DB_, R_, O_) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, 3, DB_, R_, O_, false, 0, true>), grid, dim3(256), 0, s, g)
+        if (tl.tm == 4 && tl.tn == 3) { if (ring == 2) TG_FAST(4, 3, 0, 2, 3); else TG_FAST(4, 3, 0, 1, 3); }
+        else if (tl.tm == 4 && tl.tn == 2) { if (ring == 2) TG_FAST(4, 2, 0, 2, 4); else TG_FAST(4, 2, 0, 1, 4); }
+        else if (tl.tm == 2 && tl.tn == 3) { if (ring == 2) TG_FAST(2, 3, 1, 2, 1); else TG_FAST(2, 3, 1, 1, 1); }
+        else { if (ring == 2) TG_FAST(2, 2, 1, 2, 1); else TG_FAST(2, 2, 1, 1, 1); }
+#undef TG_FAST
+        return check_launch("tg_gemm_nt(split, fast addressing)");
+    }
+#ifdef TG_LAB_ABLATE
+    {
+        const char* e = getenv("TG_NT_ABL");
+        const int abl = e ? atoi(e) : 0;
+        if (abl && tl.tm == 4 && tl.tn == 3 && g_math_mode == 0) {
+#define TG_ABL(A_) case A_: hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 3, 0, 1, 3, false, A_>), grid, dim3(256), 0, s, g); return check_launch("tg_gemm_nt(split, ablated)")
+            switch (abl) { TG_ABL(1); TG_ABL(2); TG_ABL(3); TG_ABL(4); TG_ABL(5); TG_ABL(7); TG_ABL(8); TG_ABL(9); TG_ABL(11); TG_ABL(15); default: break; }
+#undef TG_ABL
+        }
+    }
+#endif
     bool planes = g_math_mode == 0 && ring != 2;
     for (int i = 0; i < g.n; ++i) planes = planes && g.p[i].Bpl != nullptr;
     if (planes && tl.tm == 4 && tl.tn == 3) { hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 3, 0, 1, 3, true>), grid, dim3(256), 0, s, g); return check_launch("tg_gemm_nt(split, weight planes)"); }

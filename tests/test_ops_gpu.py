@@ -508,6 +508,32 @@ def test_gemm_nt_split_bf16x3_path_is_fp32_accurate(pkg, dev, M, N, K):
     assert float(((out[:, 3:3 + N].double().cpu() - ref2).abs() / ref2.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)).max()) < 1e-5
 
 
+@pytest.mark.parametrize("B,L,C,taps,step,shift,dil,rows_out,N", [(37, 60, 36, 3, 2, 1, 2, 28, 100), (5, 400, 64, 2, 1, 0, 100, 300, 49),
+                                                                  (30, 40, 100, 1, 1, 3, 1, 35, 260), (1, 2200, 48, 4, 1, 0, 5, 2100, 96)])
+def test_gemm_nt_split_fast_addressing_tap_windows(pkg, dev, B, L, C, taps, step, shift, dil, rows_out, N):
+    """Windows WITHOUT padding take the split kernel's fast addressing (32-bit offsets, clamped rows, the tap walk as one compare-and-select per
+    slab): taps narrower than a slab's reach (cw not a multiple of 32: a slab straddles two taps), row steps and shifts, several batches,
+    ragged M / N / K tails, K-concatenated weight segments -- against an explicit gather in fp64."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    g = torch.Generator().manual_seed(B * L + C + taps)
+    x = torch.randn(B, L, C, generator=g)
+    K = taps * C
+    wbuf = torch.randn(taps, N + 3, C, generator=g) * 0.1                 # segment t = wbuf[t, :N]: seg_k = C, seg stride (N + 3) * C floats
+    bias = torch.randn(N, generator=g)
+    rows = torch.arange(rows_out) * step + shift
+    src = rows[:, None] + torch.arange(taps)[None, :] * dil                # (rows_out, taps), all inside [0, L) by construction
+    assert int(src.min()) >= 0 and int(src.max()) < L
+    A = x[:, src, :].reshape(B * rows_out, K).double()                     # (B, rows_out, taps, C) -> [M][K], tap-major like the window
+    Wcat = torch.cat([wbuf[t, :N] for t in range(taps)], dim=1).double()   # [N][K]
+    ref = F.leaky_relu(A @ Wcat.t() + bias.double(), 0.2)
+    xd, wd = x.to(dev), wbuf.to(dev)
+    win = Win(xd, batches=B, batch_stride=xd.stride(0), row_stride=xd.stride(1), rows_in=L, rows_out=rows_out, cw=C, K=K, row_step=step,
+              shift=shift, dil=dil)
+    out = torch.full((B * rows_out, N), float("nan"), device=dev)
+    ops.gemm_nt(win, wd[0, :N], bias.to(dev), out, act_slope=0.2, b_seg=(C, (N + 3) * C))
+    assert rel(out, ref) < 1e-5
+
+
 def test_bf16_math_mode_tier(pkg, dev):
     """tg_set_math_mode(1): the big forward / input-gradient products take bf16 operands (one MFMA per product, fp32 accumulate).
     Op-level error at the bf16 level (and clearly different from the fp32 result: the mode really switches), and one full GAN
