@@ -85,6 +85,26 @@ __device__ __forceinline__ f32x4 mma_x3(const bf16x8 (&wa)[3], const bf16x8 (&fb
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[0], acc, 0, 0, 0);
 }
 
+// Lab build only (-DTG_LAB_STAMP, make lab, tools/h64_stamps.py): s_memtime stamps of workgroup (0, 0), wave 0 at the phase boundaries of every
+// step, into a device array read back through tg_lab_h64_read_stamps.  The stamp's own s_waitcnt lgkmcnt(0) also drains LDS operations, so
+// a phase that ends in LDS stores includes their completion.  The product build contains none of this.
+#ifdef TG_LAB_STAMP
+__device__ unsigned long long tg_h64_stamps[64][8];
+__device__ int tg_h64_lab_mode;          // bit 0: skip the per-step output stores, bit 1: skip the operand prefetch (timing ablation, wrong results)
+#define TG_STAMP(step_, i_)                                                                   \
+    do {                                                                                      \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64 && (step_) < 64) {         \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                       \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
+            if (threadIdx.x == 0) tg_h64_stamps[step_][i_] = t_;                              \
+        }                                                                                     \
+    } while (0)
+#define TG_FORCE(v_) do { float f_; asm volatile("v_mov_b32 %0, %1" : "=v"(f_) : "v"(v_)); asm volatile("" :: "v"(f_)); } while (0)
+#else
+#define TG_STAMP(step_, i_) do { } while (0)
+#define TG_FORCE(v_) do { } while (0)
+#endif
+
 // LDS-only workgroup barrier: the step's global stores / prefetched loads are NOT drained
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -137,6 +157,9 @@ __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
     f32x4 nx[D][3], nxm[D];
     auto prefetch = [&](auto set_c, int step_l) {
         constexpr int j = decltype(set_c)::value;
+#ifdef TG_LAB_STAMP
+        if ((tg_h64_lab_mode & 2) && step_l >= D) return;
+#endif
         const int sl = step_l < T ? step_l : T - 1;          // past the end: re-read a valid address, never used
         const int tau_l = dir ? T - 1 - sl : sl;
         const float* gp = gi + dir * gi_ds + (rbase + tau_l) * (3 * HS) + u0;
@@ -144,11 +167,34 @@ __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
         for (int g = 0; g < 3; ++g) nx[j][g] = *reinterpret_cast<const f32x4*>(gp + g * HS);
         if constexpr (DROP) nxm[j] = *reinterpret_cast<const f32x4*>(drop_mask + (rbase + tau_l) * (2 * HS) + dir * HS + u0);
     };
+    // Outputs of a step are held in registers and stored in the NEXT step, right after that step's MFMAs are issued: a workgroup's 40
+    // 16-byte vector-memory instructions per step (6 stores + 4 prefetch loads per wave) take the CU's address unit several hundred cycles
+    // to accept (tools/h64_stamps.py: 530-1850 of a step's cycles were spent ISSUING them, between the gates and the barrier, i.e. on the
+    // recurrence's critical path); behind the MFMA issue they drain while the matrix pipe works.  The first flush (step 0) writes zeros to
+    // step 0's own addresses, overwritten in order by the real values one step later -- the number of outstanding operations stays static.
+    f32x4 d_h = zero, d_hm = zero, d_r = zero, d_z = zero, d_n = zero, d_hn = zero;
+    long d_o = (rbase + (dir ? T - 1 : 0)) * (2 * HS) + dir * HS + u0;
+    long d_s = (rbase + (dir ? T - 1 : 0)) * (4 * HS) + u0;
+    auto flush = [&]() {
+#ifdef TG_LAB_STAMP
+        if (tg_h64_lab_mode & 1) return;
+#endif
+        *reinterpret_cast<f32x4*>(Y + d_o) = d_h;
+        if constexpr (DROP) *reinterpret_cast<f32x4*>(y_drop + d_o) = d_hm;
+        if constexpr (SAVE) {
+            float* sp = save + dir * save_ds + d_s;
+            *reinterpret_cast<f32x4*>(sp) = d_r;
+            *reinterpret_cast<f32x4*>(sp + HS) = d_z;
+            *reinterpret_cast<f32x4*>(sp + 2 * HS) = d_n;
+            *reinterpret_cast<f32x4*>(sp + 3 * HS) = d_hn;
+        }
+    };
     auto do_step = [&](auto set_c, int step) {
         constexpr int j = decltype(set_c)::value;
         const int tau = dir ? T - 1 - step : step;
         f32x4 acc[3] = {zero, zero, zero};
         const int rb = (step + 1) & 1;
+        TG_STAMP(step, 0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fb[3];
@@ -157,6 +203,13 @@ __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc[g] = mma_x3(wa[g][ks], fb, acc[g]);
         }
+        TG_STAMP(step, 1);                               // fragments read, MFMAs issued
+        __builtin_amdgcn_sched_barrier(0);
+        flush();                                         // the previous step's outputs: issued in the shadow of the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        TG_STAMP(step, 2);                               // global stores issued
+        TG_FORCE(acc[0][3]); TG_FORCE(acc[1][3]); TG_FORCE(acc[2][3]);
+        TG_STAMP(step, 3);                               // MFMA results back
         f32x4 h, r4, z4, n4, hn4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -169,26 +222,194 @@ __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
         }
         hp = h;
         const int wb = step & 1;
+        TG_FORCE(h[0]); TG_FORCE(h[1]); TG_FORCE(h[2]); TG_FORCE(h[3]);
+        TG_STAMP(step, 4);                               // gates done
         split4_store(h, &hs[wb][0][r16][u0], &hs[wb][1][r16][u0], &hs[wb][2][r16][u0]);
-        const long o = (rbase + tau) * (2 * HS) + dir * HS + u0;
-        *reinterpret_cast<f32x4*>(Y + o) = h;
-        if constexpr (DROP) *reinterpret_cast<f32x4*>(y_drop + o) = h * nxm[j];
-        if constexpr (SAVE) {
-            float* sp = save + dir * save_ds + (rbase + tau) * (4 * HS) + u0;
-            *reinterpret_cast<f32x4*>(sp) = r4;
-            *reinterpret_cast<f32x4*>(sp + HS) = z4;
-            *reinterpret_cast<f32x4*>(sp + 2 * HS) = n4;
-            *reinterpret_cast<f32x4*>(sp + 3 * HS) = hn4;
-        }
+        TG_STAMP(step, 5);                               // h_t split and in LDS (stores complete)
+        d_h = h; d_r = r4; d_z = z4; d_n = n4; d_hn = hn4;
+        if constexpr (DROP) d_hm = h * nxm[j];
+        d_o = (rbase + tau) * (2 * HS) + dir * HS + u0;
+        d_s = (rbase + tau) * (4 * HS) + u0;
         __builtin_amdgcn_sched_barrier(0);
         prefetch(set_c, step + D);           // refill the set just consumed: D steps of compute hide the load latency
         __builtin_amdgcn_sched_barrier(0);
+        TG_STAMP(step, 6);
         lds_barrier();                       // h_t complete in LDS (and everybody is done with the buffer written next step)
+        TG_STAMP(step, 7);                   // past the barrier
     };
     static_for<D>([&](auto j) { prefetch(j, decltype(j)::value); });
     lds_barrier();
     for (int step0 = 0; step0 < T; step0 += D)               // T % D == 0 (host)
         static_for<D>([&](auto j) { do_step(j, step0 + decltype(j)::value); });
+    flush();                                                 // the last step's outputs
+}
+
+// ---- forward, second form: the recurrence waves touch no global memory ------------------------------------------------------------
+// tools/h64_ablate.py: the six 16-byte output stores per step cost the recurrence 0.4-0.6 us of a 1.25 us step -- not bandwidth (24 KB per
+// step) but ISSUE: each store instruction of a wave covers 16 rows x 64 bytes (half cache lines), the CU's one address unit takes ~60
+// cycles per such instruction, four waves issue them at the same moment, and a wave that is issuing cannot run its dependent chain.  Here
+// the workgroup has EIGHT waves: waves 0-3 are the recurrence exactly as above, except that a step's operands (gi, dropout mask) come out
+// of LDS and its outputs (h, h * mask, r, z, n, W_hn h + b) go into LDS; waves 4-7 move data: during step t they store the outputs of
+// step t - 1 from LDS to global memory -- each lane a 16-byte piece of a row's contiguous record, so a store instruction covers whole
+// lines -- and stage the operands of step t + 1 into LDS from registers loaded two steps earlier.  Both kinds of wave meet at the one
+// LDS-only barrier per step that the recurrence has anyway.  Every wave's vector-memory instruction count per step is static (clamped
+// rows and steps, no predicates); the movers' first flush writes the zero-initialised buffer to step 0's own addresses and is
+// overwritten in order one step later.
+constexpr int OB_LD = 6 * HS + 4;      // floats per LDS row of an output record [h | h*mask | r | z | n | hn] (+4: rows 16 bytes apart in the banks)
+constexpr int IB_LD = 4 * HS + 4;      // floats per LDS row of an operand record [gi_r | gi_z | gi_n | mask]
+template <bool SAVE, bool DROP>
+__global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
+    const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
+    const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
+    const float* __restrict__ drop_mask, float* __restrict__ y_drop, int B, int T) {
+    __shared__ __attribute__((aligned(16))) __bf16 hs[2][3][16][HX_LD];
+    __shared__ __attribute__((aligned(16))) float obuf[2][16][OB_LD];
+    __shared__ __attribute__((aligned(16))) float ibuf[2][16][IB_LD];
+    const int dir = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // h_{-1} = 0 (the tile step 0 reads) and a zero output record for the movers' first flush
+    for (int i = threadIdx.x; i < 3 * 16 * HX_LD / 2; i += 512) reinterpret_cast<unsigned*>(&hs[1][0][0][0])[i] = 0u;
+    for (int i = threadIdx.x; i < 16 * OB_LD; i += 512) (&obuf[1][0][0])[i] = 0.f;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------------------------ movers
+        const int ml = threadIdx.x - 256;                                    // 0 .. 255
+        constexpr int OPR = (1 + (DROP ? 1 : 0) + (SAVE ? 4 : 0)) * (HS / 4); // 16-byte pieces per output row in use
+        constexpr int NOUT = (16 * OPR + 255) / 256;                         // pieces per mover lane (whole: OPR is a multiple of 16)
+        constexpr int IPR = (3 + (DROP ? 1 : 0)) * (HS / 4);
+        constexpr int NIN = 16 * IPR / 256;
+        static_assert(16 * OPR % 256 == 0 && 16 * IPR % 256 == 0, "whole pieces per lane");
+        // output piece i of this lane: LDS offset (floats) and the global pointer for time index 0 (advanced by tau * stride per step)
+        int o_lds[NOUT];
+        float* o_ptr[NOUT];
+        long o_ts[NOUT];
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            const int pc = i * 256 + ml, r = pc / OPR, c = pc - r * OPR;     // row, piece inside the used part of the record
+            const int rowg = min((int)blockIdx.x * 16 + r, B - 1);
+            // used pieces in record order: h [0,16), then h*mask [16,32) if DROP, then the four saved gates
+            int arr = c / 16, u = 4 * (c - 16 * (c / 16));
+            int rec;                                                          // array index inside the LDS record
+            if (arr == 0) { rec = 0; o_ptr[i] = Y + (long)rowg * T * (2 * HS) + dir * HS + u; o_ts[i] = 2 * HS; }
+            else if (DROP && arr == 1) { rec = 1; o_ptr[i] = y_drop + (long)rowg * T * (2 * HS) + dir * HS + u; o_ts[i] = 2 * HS; }
+            else { const int g = arr - (DROP ? 2 : 1); rec = 2 + g; o_ptr[i] = save + dir * save_ds + (long)rowg * T * (4 * HS) + g * HS + u; o_ts[i] = 4 * HS; }
+            o_lds[i] = r * OB_LD + rec * HS + u;
+        }
+        int i_lds[NIN];
+        const float* i_ptr[NIN];
+        long i_ts[NIN];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int pc = i * 256 + ml, r = pc / IPR, c = pc - r * IPR;
+            const int rowg = min((int)blockIdx.x * 16 + r, B - 1);
+            const int arr = c / 16, u = 4 * (c - 16 * (c / 16));
+            if (arr < 3) { i_ptr[i] = gi + dir * gi_ds + (long)rowg * T * (3 * HS) + arr * HS + u; i_ts[i] = 3 * HS; }
+            else { i_ptr[i] = drop_mask + (long)rowg * T * (2 * HS) + dir * HS + u; i_ts[i] = 2 * HS; }
+            i_lds[i] = r * IB_LD + arr * HS + u;
+        }
+        f32x4 in_set[2][NIN];
+        auto load_step = [&](auto set_c, int step_l) {
+            constexpr int sc = decltype(set_c)::value;
+            const int sl = step_l < T ? step_l : T - 1;                      // past the end: a valid address, never consumed
+            const int tau_l = dir ? T - 1 - sl : sl;
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) in_set[sc][i] = *reinterpret_cast<const f32x4*>(i_ptr[i] + tau_l * i_ts[i]);
+        };
+        auto stage = [&](auto set_c, int buf) {
+            constexpr int sc = decltype(set_c)::value;
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) *reinterpret_cast<f32x4*>(&ibuf[buf][0][0] + i_lds[i]) = in_set[sc][i];
+        };
+        auto flush = [&](int buf, int step_o) {                              // outputs of step step_o, sitting in obuf[buf]
+            const int tau_o = dir ? T - 1 - step_o : step_o;
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i)
+                *reinterpret_cast<f32x4*>(o_ptr[i] + tau_o * o_ts[i]) = *reinterpret_cast<const f32x4*>(&obuf[buf][0][0] + o_lds[i]);
+        };
+        using s0 = std::integral_constant<int, 0>;
+        using s1 = std::integral_constant<int, 1>;
+        load_step(s0{}, 0);
+        stage(s0{}, 0);                                                      // operands of step 0
+        load_step(s1{}, 1);                                                  // set 1 <- step 1 (staged during step 0)
+        load_step(s0{}, 2);                                                  // set 0 <- step 2 (staged during step 1)
+        lds_barrier();
+        // during step t: stage the operands of step t + 1 (set (t + 1) & 1, loaded two steps ago), refill that set with step t + 3,
+        // store the outputs of step t - 1 (t = 0: the zero record to step 0's addresses)
+        auto mover_step = [&](auto set_c, int t) {
+            stage(set_c, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(set_c, t + 3);
+            flush((t + 1) & 1, t > 0 ? t - 1 : 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();
+        };
+        int t = 0;
+        for (; t + 1 < T; t += 2) { mover_step(s1{}, t); mover_step(s0{}, t + 1); }
+        if (t < T) mover_step(s1{}, t);
+        flush((T - 1) & 1, T - 1);                                           // the last step's outputs
+        return;
+    }
+
+    // -------------------------------------------------------------------------------------------------- recurrence waves
+    const float* whh = dir ? whh1 : whh0;
+    const float* bhh = dir ? bhh1 : bhh0;
+    const int r16 = lane & 15, kq = lane >> 4;
+    bf16x8 wa[3][2][3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* p = whh + (long)(g * HS + 16 * wave + r16) * HS + 32 * ks + 8 * kq;
+            split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[g][ks]);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) pin_fragment(wa[g][ks][s]);
+        }
+    const int u0 = 16 * wave + 4 * kq;
+    f32x4 bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bh[g] = *reinterpret_cast<const f32x4*>(bhh + g * HS + u0);
+    f32x4 hp = zero;
+    lds_barrier();
+    for (int step = 0; step < T; ++step) {
+        const int rb = (step + 1) & 1, wb = step & 1;
+        // this step's operands: requested first, consumed after the MFMAs
+        f32x4 gx[3], gm = zero;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gx[g] = *reinterpret_cast<const f32x4*>(&ibuf[wb][r16][g * HS + u0]);
+        if constexpr (DROP) gm = *reinterpret_cast<const f32x4*>(&ibuf[wb][r16][3 * HS + u0]);
+        f32x4 acc[3] = {zero, zero, zero};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fb[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&hs[rb][s][r16][32 * ks + 8 * kq]);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = mma_x3(wa[g][ks], fb, acc[g]);
+        }
+        f32x4 h, r4, z4, n4, hn4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float hn = acc[2][q] + bh[2][q];
+            const float r = gate_sigmoid(gx[0][q] + acc[0][q] + bh[0][q]);
+            const float z = gate_sigmoid(gx[1][q] + acc[1][q] + bh[1][q]);
+            const float n = gate_tanh(gx[2][q] + r * hn);
+            h[q] = (1.f - z) * n + z * hp[q];
+            r4[q] = r; z4[q] = z; n4[q] = n; hn4[q] = hn;
+        }
+        hp = h;
+        split4_store(h, &hs[wb][0][r16][u0], &hs[wb][1][r16][u0], &hs[wb][2][r16][u0]);
+        float* orow = &obuf[wb][r16][u0];
+        *reinterpret_cast<f32x4*>(orow) = h;
+        if constexpr (DROP) *reinterpret_cast<f32x4*>(orow + HS) = h * gm;
+        if constexpr (SAVE) {
+            *reinterpret_cast<f32x4*>(orow + 2 * HS) = r4;
+            *reinterpret_cast<f32x4*>(orow + 3 * HS) = z4;
+            *reinterpret_cast<f32x4*>(orow + 4 * HS) = n4;
+            *reinterpret_cast<f32x4*>(orow + 5 * HS) = hn4;
+        }
+        lds_barrier();                       // h_t and the step's record complete in LDS; the movers have staged step + 1
+    }
 }
 
 // Backward through time, same ownership.  dh_{t} needs dgh_{t+1} @ W_hh (contraction over the 192 gate rows): taken transposed like
@@ -285,6 +506,159 @@ __global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
         static_for<D>([&](auto j) { do_step(j, step0 + decltype(j)::value); });
 }
 
+// ---- backward, second form: recurrence waves + movers (see gru_h64_fwd2_kernel) ------------------------------------------------------
+// Per step the single-role kernel issues 7 loads and 6 stores of 16 bytes per lane; here waves 4-7 stage the step's operand record
+// [dy | mask | r | z | n | W_hn h + b | h_prev] into LDS two steps ahead and store the gate-gradient record [dr | dz | dn | dn r] of the
+// step before as the two contiguous 768-byte rows dgi = [dr, dz, dn], dgh = [dr, dz, dn r].
+constexpr int BO_LD = 4 * HS + 4;
+template <bool MASK>
+__global__ __launch_bounds__(512) void gru_h64_bwd2_kernel(
+    const float* __restrict__ dY, const float* __restrict__ dy_mask, const float* __restrict__ Y, const float* __restrict__ save,
+    long save_ds, const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh,
+    long dg_ds, int B, int T) {
+    constexpr int NARR = MASK ? 7 : 6;                       // operand arrays per row: dy, (mask), r, z, n, hn, h_prev
+    constexpr int BI_LD = NARR * HS + 4;
+    __shared__ __attribute__((aligned(16))) __bf16 dgs[2][3][16][DG_LD];
+    __shared__ __attribute__((aligned(16))) float obuf[2][16][BO_LD];
+    __shared__ __attribute__((aligned(16))) float ibuf[2][16][BI_LD];
+    const int dir = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < 3 * 16 * DG_LD / 2; i += 512) reinterpret_cast<unsigned*>(&dgs[1][0][0][0])[i] = 0u;
+    for (int i = threadIdx.x; i < 16 * BO_LD; i += 512) (&obuf[1][0][0])[i] = 0.f;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------------------------ movers
+        const int ml = threadIdx.x - 256;
+        constexpr int OPR = 6 * (HS / 4), NOUT = 16 * OPR / 256;             // 96 pieces per row, 6 per lane
+        constexpr int IPR = NARR * (HS / 4), NIN = 16 * IPR / 256;           // 112 (96) pieces per row, 7 (6) per lane
+        static_assert(16 * OPR % 256 == 0 && 16 * IPR % 256 == 0, "whole pieces per lane");
+        int o_lds[NOUT];
+        float* o_ptr[NOUT];
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            const int pc = i * 256 + ml, r = pc / OPR, c = pc - r * OPR;
+            const int rowg = min((int)blockIdx.x * 16 + r, B - 1);
+            const int half = c / 48, cc = c - 48 * half, arr = cc / 16, u = 4 * (cc - 16 * arr);
+            o_ptr[i] = (half ? dgh : dgi) + dir * dg_ds + (long)rowg * T * (3 * HS) + arr * HS + u;
+            o_lds[i] = r * BO_LD + ((half && arr == 2) ? 3 : arr) * HS + u;     // dgh's third gate is dn * r
+        }
+        int i_lds[NIN], i_kind[NIN];
+        const float* i_ptr[NIN];
+        long i_ts[NIN];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int pc = i * 256 + ml, r = pc / IPR, c = pc - r * IPR;
+            const int rowg = min((int)blockIdx.x * 16 + r, B - 1);
+            const int arr = c / 16, u = 4 * (c - 16 * arr);
+            const int a = MASK ? arr : (arr == 0 ? 0 : arr + 1);            // logical array: 0 dy, 1 mask, 2..5 r z n hn, 6 h_prev
+            const long yo = (long)rowg * T * (2 * HS) + dir * HS + u;
+            if (a == 0) { i_ptr[i] = dY + yo; i_ts[i] = 2 * HS; i_kind[i] = 0; }
+            else if (a == 1) { i_ptr[i] = dy_mask + yo; i_ts[i] = 2 * HS; i_kind[i] = 0; }
+            else if (a < 6) { i_ptr[i] = save + dir * save_ds + (long)rowg * T * (4 * HS) + (a - 2) * HS + u; i_ts[i] = 4 * HS; i_kind[i] = 0; }
+            else { i_ptr[i] = Y + yo; i_ts[i] = 2 * HS; i_kind[i] = 1; }    // h_prev: the neighbouring time index
+            i_lds[i] = r * BI_LD + arr * HS + u;
+        }
+        f32x4 in_set[2][NIN];
+        auto load_step = [&](auto set_c, int step_l) {
+            constexpr int sc = decltype(set_c)::value;
+            const int sl = step_l < T ? step_l : T - 1;
+            const int tau_l = dir ? sl : T - 1 - sl;
+            const int tp = dir ? tau_l + 1 : tau_l - 1;
+            const int tq = (tp >= 0 && tp < T) ? tp : tau_l;                 // no predecessor (last step): a valid address, multiplied by 0
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) in_set[sc][i] = *reinterpret_cast<const f32x4*>(i_ptr[i] + (i_kind[i] ? tq : tau_l) * i_ts[i]);
+        };
+        auto stage = [&](auto set_c, int buf) {
+            constexpr int sc = decltype(set_c)::value;
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) *reinterpret_cast<f32x4*>(&ibuf[buf][0][0] + i_lds[i]) = in_set[sc][i];
+        };
+        auto flush = [&](int buf, int step_o) {
+            const int tau_o = dir ? step_o : T - 1 - step_o;
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i)
+                *reinterpret_cast<f32x4*>(o_ptr[i] + (long)tau_o * (3 * HS)) = *reinterpret_cast<const f32x4*>(&obuf[buf][0][0] + o_lds[i]);
+        };
+        using s0 = std::integral_constant<int, 0>;
+        using s1 = std::integral_constant<int, 1>;
+        load_step(s0{}, 0);
+        stage(s0{}, 0);
+        load_step(s1{}, 1);
+        load_step(s0{}, 2);
+        lds_barrier();
+        auto mover_step = [&](auto set_c, int t) {
+            stage(set_c, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(set_c, t + 3);
+            flush((t + 1) & 1, t > 0 ? t - 1 : 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();
+        };
+        int t = 0;
+        for (; t + 1 < T; t += 2) { mover_step(s1{}, t); mover_step(s0{}, t + 1); }
+        if (t < T) mover_step(s1{}, t);
+        flush((T - 1) & 1, T - 1);
+        return;
+    }
+
+    // -------------------------------------------------------------------------------------------------- recurrence waves
+    const float* wt = dir ? wt1 : wt0;
+    const int r16 = lane & 15, kq = lane >> 4;
+    bf16x8 wa[6][3];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const float* p = wt + (long)(16 * wave + r16) * (3 * HS) + 32 * ks + 8 * kq;
+        split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[ks]);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) pin_fragment(wa[ks][s]);
+    }
+    const int u0 = 16 * wave + 4 * kq;
+    f32x4 dhz = zero;
+    lds_barrier();
+    for (int step = 0; step < T; ++step) {
+        const int rb = (step + 1) & 1, wb = step & 1;
+        const float* irow = &ibuf[wb][r16][u0];
+        f32x4 x_dy = *reinterpret_cast<const f32x4*>(irow), x_mk = zero;
+        if constexpr (MASK) x_mk = *reinterpret_cast<const f32x4*>(irow + HS);
+        constexpr int A0 = MASK ? 2 : 1;
+        const f32x4 x_r = *reinterpret_cast<const f32x4*>(irow + A0 * HS), x_z = *reinterpret_cast<const f32x4*>(irow + (A0 + 1) * HS);
+        const f32x4 x_n = *reinterpret_cast<const f32x4*>(irow + (A0 + 2) * HS), x_hn = *reinterpret_cast<const f32x4*>(irow + (A0 + 3) * HS);
+        const f32x4 x_hp = *reinterpret_cast<const f32x4*>(irow + (A0 + 4) * HS);
+        const float keep = step < T - 1 ? 1.f : 0.f;                 // the sequence's first time index has no predecessor
+        f32x4 acc = zero;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            bf16x8 fb[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&dgs[rb][s][r16][32 * ks + 8 * kq]);
+            acc = mma_x3(wa[ks], fb, acc);
+        }
+        f32x4 g_r, g_z, g_n, g_nr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dyq = x_dy[q];
+            if constexpr (MASK) dyq *= x_mk[q];
+            const float r = x_r[q], z = x_z[q], n = x_n[q], hn = x_hn[q], hp = x_hp[q] * keep;
+            const float dh = dyq + acc[q] + dhz[q];
+            const float dn = dh * (1.f - z) * (1.f - n * n);
+            const float dz = dh * (hp - n) * z * (1.f - z);
+            const float dr = dn * hn * r * (1.f - r);
+            dhz[q] = dh * z;
+            g_r[q] = dr; g_z[q] = dz; g_n[q] = dn; g_nr[q] = dn * r;
+        }
+        split4_store(g_r, &dgs[wb][0][r16][u0], &dgs[wb][1][r16][u0], &dgs[wb][2][r16][u0]);
+        split4_store(g_z, &dgs[wb][0][r16][HS + u0], &dgs[wb][1][r16][HS + u0], &dgs[wb][2][r16][HS + u0]);
+        split4_store(g_nr, &dgs[wb][0][r16][2 * HS + u0], &dgs[wb][1][r16][2 * HS + u0], &dgs[wb][2][r16][2 * HS + u0]);
+        float* orow = &obuf[wb][r16][u0];
+        *reinterpret_cast<f32x4*>(orow) = g_r;
+        *reinterpret_cast<f32x4*>(orow + HS) = g_z;
+        *reinterpret_cast<f32x4*>(orow + 2 * HS) = g_n;
+        *reinterpret_cast<f32x4*>(orow + 3 * HS) = g_nr;
+        lds_barrier();
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -318,6 +692,19 @@ extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const 
         else if (drop_mask) TG_H64_FWD(false, true, D_);      \
         else TG_H64_FWD(false, false, D_);                    \
     } while (0)
+    // second form (movers): default; TG_H64_MOVERS=0 keeps the single-role kernel
+    static const int movers = [] { const char* e = getenv("TG_H64_MOVERS"); return e ? atoi(e) : 1; }();
+    if (movers && T >= 3) {
+#define TG_H64_FWD2(SAVE_, DROP_)                                                                                                          \
+    hipLaunchKernelGGL((gru_h64_fwd2_kernel<SAVE_, DROP_>), dim3(cdiv(B, 16), 2), dim3(512), 0, (hipStream_t)stream, gi, (long)gi_dir_stride, \
+                       w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask, y_drop, B, T)
+        if (save && drop_mask) TG_H64_FWD2(true, true);
+        else if (save) TG_H64_FWD2(true, false);
+        else if (drop_mask) TG_H64_FWD2(false, true);
+        else TG_H64_FWD2(false, false);
+#undef TG_H64_FWD2
+        return check_launch("tg_gru_h64_forward");
+    }
     const int ring = h64_ring();
     if (T % 4 == 0 && ring >= 4) TG_H64_FWD_D(4);
     else if (T % 2 == 0 && ring >= 2) TG_H64_FWD_D(2);
@@ -326,6 +713,15 @@ extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const 
 #undef TG_H64_FWD
     return check_launch("tg_gru_h64_forward");
 }
+
+#ifdef TG_LAB_STAMP
+extern "C" int tg_lab_h64_set_mode(int mode) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(tg::tg_h64_lab_mode), &mode, sizeof(int)) == hipSuccess ? 0 : 1;
+}
+extern "C" int tg_lab_h64_read_stamps(unsigned long long* out) {      // out: [64][8]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tg::tg_h64_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int tg_gru_h64_backward(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
                                    const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
@@ -343,6 +739,14 @@ extern "C" int tg_gru_h64_backward(const float* dy, const float* dy_mask, const 
         if (dy_mask) TG_H64_BWD(true, D_);     \
         else TG_H64_BWD(false, D_);            \
     } while (0)
+    static const int movers = [] { const char* e = getenv("TG_H64_MOVERS"); return e ? atoi(e) : 1; }();
+    if (movers && T >= 3) {
+        if (dy_mask) hipLaunchKernelGGL((gru_h64_bwd2_kernel<true>), dim3(cdiv(B, 16), 2), dim3(512), 0, (hipStream_t)stream, dy, dy_mask, y, save,
+                                        (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T);
+        else hipLaunchKernelGGL((gru_h64_bwd2_kernel<false>), dim3(cdiv(B, 16), 2), dim3(512), 0, (hipStream_t)stream, dy, dy_mask, y, save,
+                                (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T);
+        return check_launch("tg_gru_h64_backward");
+    }
     const int ring = h64_ring();
     if (T % 4 == 0 && ring >= 4) TG_H64_BWD_D(4);
     else if (T % 2 == 0 && ring >= 2) TG_H64_BWD_D(2);
