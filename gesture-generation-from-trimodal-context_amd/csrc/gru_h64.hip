@@ -693,7 +693,8 @@ extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const 
         else TG_H64_FWD(false, false, D_);                    \
     } while (0)
     // second form (movers): default; TG_H64_MOVERS=0 keeps the single-role kernel
-    static const int movers = [] { const char* e = getenv("TG_H64_MOVERS"); return e ? atoi(e) : 1; }();
+    const char* const movers_env = getenv("TG_H64_MOVERS");          // read per call: the parity tests run both forms in one process
+    const int movers = movers_env ? atoi(movers_env) : 1;
     if (movers && T >= 3) {
 #define TG_H64_FWD2(SAVE_, DROP_)                                                                                                          \
     hipLaunchKernelGGL((gru_h64_fwd2_kernel<SAVE_, DROP_>), dim3(cdiv(B, 16), 2), dim3(512), 0, (hipStream_t)stream, gi, (long)gi_dir_stride, \
@@ -739,7 +740,8 @@ extern "C" int tg_gru_h64_backward(const float* dy, const float* dy_mask, const 
         if (dy_mask) TG_H64_BWD(true, D_);     \
         else TG_H64_BWD(false, D_);            \
     } while (0)
-    static const int movers = [] { const char* e = getenv("TG_H64_MOVERS"); return e ? atoi(e) : 1; }();
+    const char* const movers_env = getenv("TG_H64_MOVERS");          // read per call: the parity tests run both forms in one process
+    const int movers = movers_env ? atoi(movers_env) : 1;
     if (movers && T >= 3) {
         if (dy_mask) hipLaunchKernelGGL((gru_h64_bwd2_kernel<true>), dim3(cdiv(B, 16), 2), dim3(512), 0, (hipStream_t)stream, dy, dy_mask, y, save,
                                         (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T);

@@ -561,13 +561,16 @@ def test_bf16_math_mode_tier(pkg, dev):
         ops.set_math_mode(2)
 
 
-@pytest.mark.parametrize("B", [5, 70, 256])
-def test_gru_h64_stack_with_fused_dropout(pkg, dev, B):
-    """The discriminator's GRU stack (4 layers, H = 64, T = 28) with injected inter-layer dropout masks against a layer-by-layer
+@pytest.mark.parametrize("B,movers,T", [(5, 1, 28), (70, 1, 28), (256, 1, 28), (70, 0, 28), (256, 0, 28), (33, 1, 7), (33, 1, 3), (17, 1, 2)])
+def test_gru_h64_stack_with_fused_dropout(pkg, dev, B, movers, T, monkeypatch):
+    """The discriminator's GRU stack (4 layers, H = 64) with injected inter-layer dropout masks against a layer-by-layer
     nn.GRU fp64 reference that multiplies the same masks in between: forward output, input gradient, every weight gradient.  The
-    masks ride inside the recurrence kernels (y_drop = y * mask in the forward, dy * mask in the backward load)."""
+    masks ride inside the recurrence kernels (y_drop = y * mask in the forward, dy * mask in the backward load).  Both forms of the
+    kernels (mover waves -- the default -- and the single-role workgroup, TG_H64_MOVERS=0), odd and very short sequences, ragged batch
+    tiles."""
+    monkeypatch.setenv("TG_H64_MOVERS", str(movers))
     Lm = pkg.layers
-    T, H, L = 28, 64, 4
+    H, L = 64, 4
     layers = [torch.nn.GRU(8 if l == 0 else 2 * H, H, num_layers=1, batch_first=True, bidirectional=True).double() for l in range(L)]
     g = torch.Generator().manual_seed(B)
     masks = [(torch.rand(B, T, 2 * H, generator=g) >= 0.3).double() / 0.7 for _ in range(L - 1)]
