@@ -851,7 +851,9 @@ static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int group_ti
         // were 91 MB of atomics, a third of the launch).  Aim at ~768 workgroups for the group, at least 256 rows per split.
         static int target_wgs = -1;          // lab switch TG_TN_WGS: workgroups aimed at per grouped launch
         if (target_wgs < 0) { const char* e = getenv("TG_TN_WGS"); target_wgs = e ? atoi(e) : 768; }      // sweep of the final round-2 build: 768 beats 512 / 1024 / 1536 / 2048 by ~0.5 % of the iteration
-        int s2 = cdiv(target_wgs, group_tiles);
+        static int target_wgs22 = -1;        // the 64 x 64 tile's own target (two workgroups per CU by LDS: 512 slots)
+        if (target_wgs22 < 0) { const char* e = getenv("TG_TN_WGS22"); target_wgs22 = e ? atoi(e) : 2000; }      // same-box sweep of the final build: 768 / 1200 / 2000 / 3200 -> 5.467 / 5.444 / 5.434 / 5.453 ms per iteration
+        int s2 = cdiv(bn == 64 ? target_wgs22 : target_wgs, group_tiles);
         const int cap = cdiv(q.M, 256);
         if (s2 > cap) s2 = cap;
         if (s2 < 1) s2 = 1;

@@ -432,7 +432,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 // Other widths: plain rows padded by 8 bf16 (2-way conflicted transposed reads: rows 8 apart share banks whatever the padding).
 template <int W> struct TrImage {
     static constexpr bool SWZ = W == 128;
-    static constexpr int LD = SWZ ? W : W + 8;
+    static constexpr int LD = SWZ ? W : (W == 64 ? W + 4 : W + 8);      // 64-wide: 136-byte rows -> 52 KB per workgroup, three per CU
     static __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
     // element offset of column `col` (a multiple of 4) of row `row`
     static __device__ __forceinline__ int at(int row, int col) {

@@ -1,5 +1,6 @@
 set -o pipefail
 mkdir -p gpurun_out
-for cfg in "TG_TN_TILE=0" "TG_TN_TILE=42" "TG_TN_TILE=42 TG_TN_WGS=1536" "TG_TN_WGS=2304" "TG_TN_WGS=4096"; do
-  env $cfg timeout -k 10 200 python bench.py --steps 150 --warmup 30 --no-cpu-baseline > gpurun_out/s38_bench.json 2> gpurun_out/s38_bench.err && echo "$cfg $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/s38_bench.json)"
+timeout -k 10 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "tn or grouped or conv" > gpurun_out/s40_ops.log 2>&1; tail -3 gpurun_out/s40_ops.log
+for cfg in "TG_TN_WGS22=2000" "TG_TN_WGS22=2900" "TG_TN_WGS22=1500"; do
+  env $cfg timeout -k 10 200 python bench.py --steps 150 --warmup 30 --no-cpu-baseline > gpurun_out/s40_bench.json 2> gpurun_out/s40_bench.err && echo "$cfg $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/s40_bench.json)"
 done
