@@ -83,6 +83,10 @@ struct NtProb {
     int accumulate;
     int n_nt;
     int vec_c;               // C / mul rows can be accessed as 16-byte pieces (N % 4 == 0, strides % 4 == 0, aligned pointers)
+    const float* gate;       // optional epilogue extensions (gemm_split.hip only): keep the result where gate > 0 ...
+    const float* res;        // ... and / or a second output C2 = act2(C + res), slope res_slope; all addressed like C
+    float* C2;
+    float res_slope;
     const __bf16* Bpl;       // optional pre-split weight operand: planes [3][>= N rows][Kp] bf16 (gemm_planes.hip), bpl_plane elements apart
     long bpl_plane;
     int Kp;

@@ -679,6 +679,7 @@ static bool nt_vec(const NtProb& p) {
     return (w.cw % 4 == 0) && (w.K % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr) && (p.ldb % 4 == 0) && aligned16(p.Bw) &&
            (p.b_seg_k % 4 == 0) && (p.b_seg_stride % 4 == 0);
 }
+static bool nt_has_ext(const NtProb& p) { return p.gate != nullptr || p.res != nullptr; }
 static int nt_family(const NtProb& p) {
     if (nt_vec(p) && p.N >= 48 && p.M >= 1024 && p.A.K >= 64) return 0;
     return p.N <= 32 ? 1 : 2;
@@ -707,6 +708,8 @@ static int nt_launch(NtGroup& g, hipStream_t s) {
         TG_REQUIRE(fam == 0 || g.p[i].b_seg_k == g.p[i].A.K, "tg_gemm_nt: K-concatenated weights need the big-product path (problem %d)", i);
     }
     if (fam == 0 && use_split_path()) return tg_gemm_nt_split_launch(g, s);
+    for (int i = 0; i < g.n; ++i)
+        TG_REQUIRE(!nt_has_ext(g.p[i]), "tg_gemm_nt: gate / res / C2 need the big-product split path (tg_gemm_nt_ext_supported; problem %d)", i);
     if (fam == 0) {
         int Mx = 0, Nx = 0;
         for (int i = 0; i < g.n; ++i) { Mx = Mx > g.p[i].M ? Mx : g.p[i].M; Nx = Nx > g.p[i].N ? Nx : g.p[i].N; }
@@ -766,15 +769,25 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
                    "tg_gemm_nt: bad weight planes (problem %d): b_kp=%d must be a multiple of 32 >= K=%d, one weight matrix, aligned", idx, q.b_kp, q.A.K);
         p.Bpl = reinterpret_cast<const __bf16*>(q.b_planes); p.bpl_plane = (long)q.b_plane_stride; p.Kp = q.b_kp;
     }
+    TG_REQUIRE((q.res == nullptr) == (q.C2 == nullptr), "tg_gemm_nt: res and C2 go together (problem %d)", idx);
+    p.gate = q.gate; p.res = q.res; p.C2 = q.C2; p.res_slope = q.res_slope;
     p.vec_c = (q.N % 4 == 0) && (q.c_batch_stride % 4 == 0) && (q.c_row_stride % 4 == 0) && aligned16(q.C) &&
-              (q.bias == nullptr || aligned16(q.bias)) && (q.out_scale == nullptr || aligned16(q.out_scale));
+              (q.bias == nullptr || aligned16(q.bias)) && (q.out_scale == nullptr || aligned16(q.out_scale)) &&
+              (q.gate == nullptr || aligned16(q.gate)) && (q.res == nullptr || (aligned16(q.res) && aligned16(q.C2)));
     return 0;
 }
+
 
 extern "C" int32_t tg_gemm_nt_family(const tg_gemm_nt_problem* problem) {
     NtProb p;
     if (!problem || nt_fill(p, *problem, 0)) return -1;
     return nt_family(p);
+}
+
+extern "C" int32_t tg_gemm_nt_ext_supported(const tg_gemm_nt_problem* problem) {
+    NtProb p;
+    if (!problem || nt_fill(p, *problem, 0)) return 0;
+    return nt_family(p) == 0 && use_split_path() ? 1 : 0;
 }
 
 extern "C" int tg_gemm_nt_group(const tg_gemm_nt_problem* problems, int32_t n, void* stream) {
@@ -791,7 +804,7 @@ extern "C" int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, cons
                           int64_t c_batch_stride, int64_t c_row_stride, int32_t c_rows_out, int32_t M, int32_t N,
                           float act_slope, int32_t accumulate, void* stream) {
     TG_REQUIRE(A, "tg_gemm_nt: null window");
-    tg_gemm_nt_problem q;
+    tg_gemm_nt_problem q = {};
     q.A = *A; q.Bw = Bw; q.ldb = ldb; q.b_seg_k = 0; q.b_seg_stride = 0; q.bias = bias; q.C = C; q.c_batch_stride = c_batch_stride;
     q.c_row_stride = c_row_stride; q.c_rows_out = c_rows_out; q.M = M; q.N = N; q.act_slope = act_slope; q.accumulate = accumulate;
     q.out_scale = nullptr; q.reserved = 0;

@@ -84,6 +84,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
     const int b_seg_k = pr.b_seg_k;
     const float* __restrict__ bias = pr.bias;
     const float* __restrict__ mul = pr.mul;
+    const float* __restrict__ gate = pr.gate;
+    const float* __restrict__ res = pr.res;
+    float* __restrict__ C2 = pr.C2;
+    const float slope2 = pr.res_slope;
     float* __restrict__ C = pr.C;
     const long cbs = pr.cbs, crs = pr.crs;
     const int cR = pr.cR, M = pr.M, N = pr.N, accumulate = pr.accumulate, n_nt = pr.n_nt;
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p0 = 0; p0 < NP; p0 += CH) {
-            f32x4 bv[CH], mv[CH], cv[CH];
+            f32x4 bv[CH], mv[CH], cv[CH], gv[CH], rv[CH];
             long o[CH];
             bool ok[CH];
 #pragma unroll
@@ -371,6 +375,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
                 o[u] = ok[u] ? (long)cb * cbs + (long)cr * crs + col : 0;
                 bv[u] = bias ? *reinterpret_cast<const f32x4*>(bias + (ok[u] ? col : 0)) : z4;
                 if (mul) mv[u] = *reinterpret_cast<const f32x4*>(mul + o[u]);
+                if (gate) gv[u] = *reinterpret_cast<const f32x4*>(gate + o[u]);
+                if (res) rv[u] = *reinterpret_cast<const f32x4*>(res + o[u]);
                 if (accumulate) cv[u] = *reinterpret_cast<const f32x4*>(C + o[u]);
             }
 #pragma unroll
@@ -382,8 +388,18 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q], slope);
                 if (mul) v *= mv[u];
+                if (gate) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = gv[u][q] > 0.f ? v[q] : 0.f;
+                }
                 if (accumulate) v += cv[u];
                 if (ok[u]) *reinterpret_cast<f32x4*>(C + o[u]) = v;
+                if (res) {
+                    f32x4 w = v + rv[u];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] = act_fn(w[q], slope2);
+                    if (ok[u]) *reinterpret_cast<f32x4*>(C2 + o[u]) = w;
+                }
             }
         }
         return;
@@ -396,8 +412,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
             if (row >= M) continue;
             const int cb = row / cR;
             const int cr = row - cb * cR;
-            float* crow = C + (long)cb * cbs + (long)cr * crs;
-            const float* mrow = mul ? mul + (long)cb * cbs + (long)cr * crs : nullptr;
+            const long ro = (long)cb * cbs + (long)cr * crs;
+            float* crow = C + ro;
+            const float* mrow = mul ? mul + ro : nullptr;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn * (16 * TN) + j * 16 + r16;
@@ -406,8 +423,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
                 if (bias) v += bias[col];
                 v = act_fn(v, slope);
                 if (mrow) v *= mrow[col];
+                if (gate) v = gate[ro + col] > 0.f ? v : 0.f;
                 if (accumulate) v += crow[col];
                 crow[col] = v;
+                if (res) C2[ro + col] = act_fn(v + res[ro + col], slope2);
             }
         }
     }

@@ -251,20 +251,31 @@ class GeneratorEngine(_Engine):
                                          self.rng.site(f"{tag}.tcn.drop"))
                 masks = [inject[sn].contiguous() if (inject is not None and sn in inject) else drawn[j] for j, sn in enumerate(sites)]
         tcn = []
+        # the block's closing relu(out + x) as a second output of conv2's launch when that launch runs on a kernel with the epilogue
+        # extensions (ops.nt_ext_supported: the big-product path; small batches keep the separate add_relu pass)
+        fuse_res = wps.shape[1] == cur.shape[2] and cur.is_contiguous() and ops.nt_ext_supported(
+            Win.conv(cur, 2, pad=1, dil=1, rows_out=T), wps[0], cur, c_batch_stride=cur.stride(0), c_row_stride=cur.stride(1), c_rows_out=T)
         for i in range(self.n_layers):
             d = 2 ** i
             blk = {"x": cur, "d": d}
             h = cur
+            y = None
             for ci in range(2):
                 j = 2 * i + ci
                 m = masks[j]
                 if m is not None:
                     assert m.shape == (Bs, T, wps.shape[1]), (sites[j], m.shape)
                 # causal conv (chomp) + ReLU + dropout scale in one GEMM
-                o = L.conv_fwd(h, wps[j], P[names[j] + ".bias"], 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=m)
+                if ci == 1 and fuse_res:
+                    y = torch.empty_like(cur)
+                    o = L.conv_fwd(h, wps[j], P[names[j] + ".bias"], 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=m, res=cur, out2=y,
+                                   res_slope=0.0)
+                else:
+                    o = L.conv_fwd(h, wps[j], P[names[j] + ".bias"], 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=m)
                 blk[f"in{ci}"], blk[f"wt{ci}"], blk[f"o{ci}"], blk[f"m{ci}"] = h, (wts[j] if wts is not None else None), o, m
                 h = o
-            y = ops.add_relu(h, cur, torch.empty_like(cur))
+            if y is None:
+                y = ops.add_relu(h, cur, torch.empty_like(cur))
             blk["y"] = y
             tcn.append(blk)
             cur = y
@@ -350,11 +361,17 @@ class GeneratorEngine(_Engine):
                 dsum, dc_top = ops.act_mask_bwd2(dcur, blk["y"][rows].reshape(M, Cc), o1, None if m1 is None else m1[rows].reshape(M, -1), 0.0,
                                                  torch.empty_like(dcur), torch.empty_like(o1))
                 dh = dsum
+                dc_fused = None                  # conv1's output gradient when conv2's input-gradient launch gated it in its epilogue
                 for ci, name in ((1, "conv2"), (0, "conv1")):
                     pre = f"{te}.tcn.network.{i}.{name}"
                     o = blk[f"o{ci}"][rows].reshape(M, -1)
                     m = blk[f"m{ci}"]
-                    dc = dc_top if ci == 1 else ops.act_mask_bwd(dh, o, None if m is None else m[rows].reshape(M, -1), 0.0, torch.empty_like(o))
+                    if ci == 1:
+                        dc = dc_top
+                    elif dc_fused is not None:
+                        dc = dc_fused
+                    else:
+                        dc = ops.act_mask_bwd(dh, o, None if m is None else m[rows].reshape(M, -1), 0.0, torch.empty_like(o))
                     dc3 = dc.view(nb, T, -1)
                     xin = blk[f"in{ci}"][rows]
                     v = P[pre + ".weight_v"]
@@ -366,7 +383,16 @@ class GeneratorEngine(_Engine):
                     # dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0]  -> taps (t + d, t) with B = w^T per tap (from the forward's batch)
                     wT = blk[f"wt{ci}"]
                     if ci == 1:
-                        dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, L.empty(M, xin.shape[2], like=dc))
+                        a_win = Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T)
+                        dh = L.empty(M, xin.shape[2], like=dc)
+                        o0, m0 = blk["o0"][rows].reshape(M, -1), blk["m0"]
+                        if o0.shape == dh.shape and ops.nt_ext_supported(a_win, wT, dh):
+                            # relu + dropout backward of conv1's output (its saved post-dropout activation is the gate, the dropout scale
+                            # the multiplier) in this launch's epilogue: dh arrives as conv1's output gradient
+                            ops.gemm_nt(a_win, wT, None, dh, out_scale=None if m0 is None else m0[rows].reshape(M, -1), gate=o0)
+                            dc_fused = dh
+                        else:
+                            ops.gemm_nt(a_win, wT, None, dh)
                     else:   # first conv of the block: add into the residual branch gradient
                         dh = ops.gemm_nt(Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), wT, None, dsum, accumulate=True)
                 dcur = dh

@@ -185,8 +185,10 @@ def conv_out_len(L, kw, stride=1, pad=0, dil=1):
     return (L + 2 * pad - dil * (kw - 1) - 1) // stride + 1
 
 
-def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=1.0, rows_out=None, out_scale=None):
-    """x: (B, L, Ci) view; w_packed: [Co, kw*Ci]; out: (B, Lout, Co) view (may be a channel slice of a wider buffer)."""
+def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=1.0, rows_out=None, out_scale=None, res=None, out2=None,
+             res_slope=0.0):
+    """x: (B, L, Ci) view; w_packed: [Co, kw*Ci]; out: (B, Lout, Co) view (may be a channel slice of a wider buffer).
+    res / out2 (ops.nt_ext_supported only): out2 = leaky_relu(out + res, res_slope) written by the same launch."""
     B, L, _ = x.shape
     Lo = conv_out_len(L, kw, stride, pad, dil) if rows_out is None else rows_out
     Co = w_packed.shape[0]
@@ -195,7 +197,7 @@ def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=
     assert tuple(out.shape) == (B, Lo, Co) and out.stride(2) == 1
     A = Win.conv(x, kw, stride=stride, pad=pad, dil=dil, rows_out=Lo)
     ops.gemm_nt(A, w_packed, b, out, act_slope=act_slope, c_batch_stride=out.stride(0), c_row_stride=out.stride(1),
-                c_rows_out=Lo, out_scale=out_scale)
+                c_rows_out=Lo, out_scale=out_scale, res=res, out2=out2, res_slope=res_slope)
     return out
 
 

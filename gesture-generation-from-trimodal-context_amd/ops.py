@@ -80,9 +80,11 @@ class Win:
 
 
 def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, M=None,
-                b_seg=None, out_scale=None, w_planes=None):
+                b_seg=None, out_scale=None, w_planes=None, gate=None, res=None, out2=None, res_slope=0.0):
     """Checked tg_gemm_nt_problem.  b_seg = (seg_k, seg_stride_floats): K-concatenated weights, W is the first [N, seg_k] segment and
-    segment s starts seg_stride_floats * s floats after it (the caller keeps every segment alive)."""
+    segment s starts seg_stride_floats * s floats after it (the caller keeps every segment alive).
+    Epilogue extensions (big-product path only, nt_ext_supported): gate -- keep the result where gate > 0, zero elsewhere; res + out2 --
+    second output out2 = leaky_relu(out + res, res_slope).  All addressed exactly like `out`."""
     _f32(W, "W"); _f32(out, "out")
     seg_k = A.K if b_seg is None else int(b_seg[0])
     assert W.dim() == 2 and W.stride(1) == 1 and W.shape[1] == seg_k and A.K % seg_k == 0, (W.shape, A.K, seg_k)
@@ -110,10 +112,30 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
         _f32(out_scale, "out_scale")
         assert out_scale.shape == out.shape and out_scale.stride() == out.stride(), (out_scale.shape, out.shape)
         q.out_scale = out_scale.data_ptr()
+    for name, t in (("gate", gate), ("res", res), ("out2", out2)):
+        if t is not None:
+            _f32(t, name)
+            assert t.shape == out.shape and t.stride() == out.stride(), (name, t.shape, out.shape)
+    assert (res is None) == (out2 is None), "res and out2 go together"
+    if gate is not None:
+        q.gate = gate.data_ptr()
+    if res is not None:
+        q.res, q.C2, q.res_slope = res.data_ptr(), out2.data_ptr(), float(res_slope)
     if w_planes is not None:                   # Planes of W (split3_planes / layers.weight_planes): the big-product kernels skip the weight split
         assert b_seg is None and w_planes.rows == N and w_planes.cw == A.K and w_planes.t.is_cuda, (w_planes.rows, N, w_planes.cw, A.K)
         q.b_planes, q.b_plane_stride, q.b_kp = w_planes.t.data_ptr(), w_planes.plane_stride, w_planes.cwp
     return q
+
+
+NT_EPILOGUE_EXT = os.environ.get("TG_NT_EPILOGUE_EXT", "1") != "0"
+
+
+def nt_ext_supported(A: Win, W, out, **kw):
+    """True when gemm_nt(A, W, ..., out) would run on a kernel that implements the gate / res / out2 epilogue extensions."""
+    if not NT_EPILOGUE_EXT or not out.is_cuda:
+        return False
+    q = _nt_problem(A, W, None, out, **kw)
+    return bool(_lib.load().tg_gemm_nt_ext_supported(C.byref(q)))
 
 
 def gemm_nt(A: Win, W, bias, out, **kw):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 1
+#define TG_ABI_VERSION 2
 
 int tg_version(void);
 const char* tg_last_error(void);
@@ -90,6 +90,17 @@ typedef struct tg_gemm_nt_problem {
     const void* b_planes;      /* NULL, or the bf16 x 3 planes of Bw ([3][N + 1][b_kp] bf16 as written by tg_split3_planes, b_kp = K rounded up */
     int64_t b_plane_stride;    /*   to 32, planes b_plane_stride elements apart): the big-product kernels then stage the weight operand */
     int32_t b_kp, reserved2;   /*   without splitting it (one weight matrix only: b_seg_k == 0) */
+    /* Epilogue extensions (big-product path only, tg_gemm_nt_ext_supported): what the reference computes right after the product in
+     * model/tcn.py:27-45 without another pass over the tensor.  All three are addressed like C.
+     *   gate : the result (after act / out_scale) is kept where gate > 0 and zeroed elsewhere -- ReLU backward through the tensor the
+     *          product's consumer saw (the chain rule of relu + dropout of the PREVIOUS conv, applied to this input gradient);
+     *   res, C2 (together): second output C2 = act2(C_new + res), act2 = leaky-ReLU of slope res_slope (0: ReLU) -- the residual
+     *          block's relu(out + x) written next to out, which the backward still needs. */
+    const float* gate;
+    const float* res;
+    float* C2;
+    float res_slope;
+    int32_t reserved3;
 } tg_gemm_nt_problem;
 /* tg_gemm_nt_group: up to 8 independent tg_gemm_nt products in ONE launch (both GRU directions' input projections, the stride
  * phases of a conv input-gradient ...).  All problems must fall into the same kernel family as problem 0 (big / narrow / small);
@@ -97,6 +108,8 @@ typedef struct tg_gemm_nt_problem {
 int tg_gemm_nt_group(const tg_gemm_nt_problem* problems, int32_t n, void* stream);
 /* kernel family a problem would run in (0 big, 1 narrow N <= 32, 2 small; -1 invalid): problems of one group must agree */
 int32_t tg_gemm_nt_family(const tg_gemm_nt_problem* problem);
+/* 1 when this problem would run on a kernel that implements gate / res / C2 (family 0 on the bf16 x 3 or bf16 path), else 0 */
+int32_t tg_gemm_nt_ext_supported(const tg_gemm_nt_problem* problem);
 int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bias, float* C,
                int64_t c_batch_stride, int64_t c_row_stride, int32_t c_rows_out, int32_t M, int32_t N,
                float act_slope, int32_t accumulate, void* stream);

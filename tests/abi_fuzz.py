@@ -54,6 +54,7 @@ def fuzz(lib_path=None):
     for q in ("tg_gemm_tn_ws_floats", "tg_gru_cluster_ws_bytes", "tg_gru_cluster_bwd_ws_bytes"):
         getattr(lib, q)(*([1] * len(getattr(lib, q).argtypes)))
     assert lib.tg_gemm_nt_family(None) == -1
+    assert lib.tg_gemm_nt_ext_supported(None) == 0
     assert lib.tg_bn_fused_supported(0, 0, 0) == 0 and lib.tg_bn_fused_supported(4096, 16, 2) == 1
     return checked
 

@@ -534,6 +534,42 @@ def test_gemm_nt_split_fast_addressing_tap_windows(pkg, dev, B, L, C, taps, step
     assert rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(4352, 300, 600), (1100, 52, 72), (1030, 49, 68)])
+def test_gemm_nt_epilogue_gate_and_residual_output(pkg, dev, M, N, K):
+    """Epilogue extensions of the big-product path: `gate` (keep the result where gate > 0: relu + dropout backward of the producer's saved
+    activation) after act / out_scale, before accumulate; `res` + `out2` (out2 = relu(out + res): the TCN block's closing add + ReLU as a second
+    output).  Vectorised and scalar (N % 4 != 0) epilogues, ragged tiles; unsupported families refuse the operands loudly."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    g = torch.Generator().manual_seed(M + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    mask = (torch.rand(M, N, generator=g) > 0.3).float() / 0.7
+    gate = torch.relu(torch.randn(M, N, generator=g))                      # ~half zeros, like a saved post-ReLU activation
+    res = torch.randn(M, N, generator=g)
+    base = torch.randn(M, N, generator=g)
+    xd, wd = x.to(dev), w.to(dev)
+    assert ops.nt_ext_supported(Win.plain(xd), wd, torch.empty(M, N, device=dev))
+    # forward form: out = relu(x W^T + b) * mask, out2 = relu(out + res)
+    out, out2 = torch.full((M, N), float("nan"), device=dev), torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_nt(Win.plain(xd), wd, b.to(dev), out, act_slope=0.0, out_scale=mask.to(dev), res=res.to(dev), out2=out2)
+    ref = torch.relu(x.double() @ w.double().t() + b.double()) * mask.double()
+    assert rel(out, ref) < 1e-5
+    ref2 = torch.relu(out.double().cpu() + res.double())                    # from the kernel's own `out`: the add + ReLU must be exact
+    assert float((out2.double().cpu() - ref2).abs().max()) <= 1e-6 * float(ref2.abs().max())
+    # backward form: out = base + (x W^T * mask where gate > 0)
+    acc = base.to(dev).clone()
+    ops.gemm_nt(Win.plain(xd), wd, None, acc, out_scale=mask.to(dev), gate=gate.to(dev), accumulate=True)
+    refb = base.double() + (x.double() @ w.double().t()) * mask.double() * (gate > 0).double()
+    assert rel(acc, refb) < 1e-5
+    zeros = (gate == 0)
+    assert torch.equal(acc.cpu()[zeros], base[zeros])                        # gated-off entries contribute exactly nothing
+    # a product outside the big-product family must refuse the operands instead of ignoring them
+    xs, ws = torch.randn(64, 32, device=dev), torch.randn(20, 32, device=dev)
+    small = torch.empty(64, 20, device=dev)
+    assert not ops.nt_ext_supported(Win.plain(xs), ws, small)
+    with pytest.raises(Exception):
+        ops.gemm_nt(Win.plain(xs), ws, None, small, gate=torch.ones(64, 20, device=dev))
+
+
 def test_bf16_math_mode_tier(pkg, dev):
     """tg_set_math_mode(1): the big forward / input-gradient products take bf16 operands (one MFMA per product, fp32 accumulate).
     Op-level error at the bf16 level (and clearly different from the fp32 result: the mode really switches), and one full GAN
