@@ -1,6 +1,7 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "gemm_nt or grouped or conv" > gpurun_out/s41_ops.log 2>&1; tail -5 gpurun_out/s41_ops.log
-timeout -k 10 400 python -m pytest tests/test_engine_gpu.py -m gpu -q -x -k "golden or graph or variant" > gpurun_out/s41_engine.log 2>&1; tail -3 gpurun_out/s41_engine.log
-timeout -k 10 200 python bench.py --steps 200 --warmup 30 --no-cpu-baseline > gpurun_out/s41_bench.json 2> gpurun_out/s41_bench.err && grep -o '"ms_per_step": [0-9.]*' gpurun_out/s41_bench.json
-TG_NT_EPILOGUE_EXT=0 timeout -k 10 200 python bench.py --steps 200 --warmup 30 --no-cpu-baseline > gpurun_out/s41_bench_off.json 2> gpurun_out/s41_bench_off.err && grep -o '"ms_per_step": [0-9.]*' gpurun_out/s41_bench_off.json
+bash tools/r2_profile.sh r2_fin3 > gpurun_out/r2_fin3_profile.log 2>&1
+grep -o '"ms_per_step": [0-9.]*' gpurun_out/r2_fin3_bench.json
+timeout -k 10 300 python bench.py > gpurun_out/r2_fin3_bench_full.json 2> gpurun_out/r2_fin3_bench_full.err; head -c 300 gpurun_out/r2_fin3_bench_full.json; echo
+timeout -k 10 200 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --force-ddp > gpurun_out/r2_fin3_bench_ddp.json 2> gpurun_out/r2_fin3_bench_ddp.err; grep -o '"ms_per_step": [0-9.]*' gpurun_out/r2_fin3_bench_ddp.json
+timeout -k 10 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
