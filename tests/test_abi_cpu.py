@@ -111,3 +111,37 @@ def test_entry_points_under_host_address_sanitizer():
     env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=66")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_fuzz.py"), lib], env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "abi fuzz ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_deferred_weight_gradients_are_grouped_by_kernel_family(pkg, monkeypatch):
+    """layers.tn_group_deferred (host logic, no GPU): problems that qualify for the bf16 x 3 weight-gradient kernel and those that do not are
+    launched in separate groups of at most MAX_GROUP, every problem exactly once, order kept inside a kind."""
+    from types import SimpleNamespace as NS
+    L, ops = pkg.layers, pkg.ops
+    calls = []
+    monkeypatch.setattr(ops, "gemm_tn_group", lambda probs: calls.append(list(probs)))
+    def prob(M, N, K, tag):
+        return dict(dY=torch.zeros(M, N), A=NS(K=K, s=NS(cw=K)), dW=None, dbias=None, tag=tag)
+    big = [prob(7168, 192, 128, f"big{i}") for i in range(14)]           # the discriminator's GRU layers 1..3 (ih + hh) and layer 0 hh
+    small = [prob(7168, 192, 8, "ih0f"), prob(7168, 192, 8, "ih0r"), prob(7680, 8, 24, "conv2"), prob(8192, 8, 48, "conv1"), prob(512, 192, 128, "short")]
+    mixed = [big[0], small[0], *big[1:8], small[1], *big[8:], *small[2:]]
+    L.tn_group_deferred(mixed)
+    assert [len(c) for c in calls] == [8, 6, 5]
+    assert [p["tag"] for c in calls[:2] for p in c] == [f"big{i}" for i in range(14)]
+    assert [p["tag"] for p in calls[2]] == ["ih0f", "ih0r", "conv2", "conv1", "short"]
+
+
+def test_nt_epilogue_operands_are_checked_on_the_host(pkg, monkeypatch):
+    """ops._nt_problem: res and out2 go together and every epilogue operand must be laid out exactly like the output (the wrappers accept
+    CUDA tensors only; that check is lifted here to reach the layout checks without a GPU)."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    monkeypatch.setattr(ops, "_f32", lambda t, name="tensor": None)
+    x, w, out = torch.zeros(64, 32), torch.zeros(16, 32), torch.zeros(64, 16)
+    q = ops._nt_problem(Win.plain(x), w, None, out, gate=torch.zeros(64, 16), res=torch.zeros(64, 16), out2=torch.zeros(64, 16), res_slope=0.0)
+    assert q.gate and q.res and q.C2 and q.res_slope == 0.0
+    with pytest.raises(AssertionError):
+        ops._nt_problem(Win.plain(x), w, None, out, res=torch.zeros(64, 16))
+    with pytest.raises(AssertionError):
+        ops._nt_problem(Win.plain(x), w, None, out, gate=torch.zeros(64, 17))
+    with pytest.raises(AssertionError):
+        ops._nt_problem(Win.plain(x), w, None, out, gate=torch.zeros(16, 64).t())
