@@ -1,4 +1,4 @@
-"""Data-parallel gradient exchange on CPU: world_size 2, gloo backend.  Covers ddp.GradSync (bucket ranges in backward
+"""Data-parallel gradient exchange on CPU: world_size 2 and 4, gloo backend.  Covers ddp.GradSync (bucket ranges in backward
 order, asynchronous launch + wait, mean semantics), parameter broadcast and the trainer's sync-point routing, without
 any HIP call (ParamSlab and GradSync are device-agnostic)."""
 import importlib
@@ -39,8 +39,8 @@ def _worker(rank, world, port, out):
         G = _make_generator(pkg)
         slab = params.ParamSlab(G)
         # replicas start different, broadcast makes them rank 0's
-        if rank == 1:
-            slab.flat.add_(1.0)
+        if rank != 0:
+            slab.flat.add_(float(rank))
         ddp.broadcast_parameters([slab])
         ref = _make_generator(pkg)
         ok = all(torch.equal(p.detach(), q.detach()) for p, q in zip(G.parameters(), ref.parameters()))
@@ -60,8 +60,7 @@ def _worker(rank, world, port, out):
         # every parameter element is in exactly one bucket (only alignment padding is left out)
         for p, off in zip(slab.params, slab.offsets):
             assert covered[off:off + p.numel()].all()
-        other = torch.randn(slab.numel, generator=torch.Generator().manual_seed(100 + (1 - rank)))
-        expect = (mine + other) / 2
+        expect = sum(torch.randn(slab.numel, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
         err = float((slab.grad - expect)[covered].abs().max())
         # whole-slab form (discriminator step)
         slab.grad.copy_(mine)
@@ -75,20 +74,30 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_grad_sync_world2_gloo():
+def _run_world(world):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     res = [out.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
     for rank, ok, err, err2, view_ok in res:
         assert ok and view_ok, (rank, ok, view_ok)
         assert err < 1e-6 and err2 < 1e-6, (rank, err, err2)
+
+
+def test_grad_sync_world2_gloo():
+    _run_world(2)
+
+
+def test_grad_sync_world4_gloo():
+    """Rehearsal of a wider job on CPU ranks: bucketed mean over four replicas, broadcast from rank 0."""
+    _run_world(4)
 
 
 def test_trainer_routes_sync_points(pkg, monkeypatch):
