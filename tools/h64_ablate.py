@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("gesture-generation-from-trimodal-context_amd")
 lab = os.path.join(os.path.dirname(pkg._lib.LIB_PATH), "libtrimodal_hip_lab.so")
 pkg._lib.LIB_PATH = lab
+os.environ["TG_H64_MOVERS"] = "0"      # the stamps / ablation switches live in the single-role kernel (the form these tools studied)
 ops = pkg.ops
 dev = torch.device("cuda:0")
 T, H, B = 28, 64, 256
