@@ -2,7 +2,9 @@
 """Training-throughput benchmark of the trimodal gesture GAN hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1, either form: (a) plain `python bench.py --gpus N ...` -- this process then only LAUNCHES: it starts N fresh rank processes
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous) before touching any GPU itself, relays rank 0's JSON line and
+    returns non-zero if any rank failed; (b) python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]): config/multimodal_context.yml -- PoseGenerator + ConvDiscriminator, post-warm-up GAN
 iteration (3 G forwards, 1 G backward, 3 D forwards, D backward passes, both Adam steps), batch 128 clips of 34 frames x 27
@@ -13,6 +15,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +31,61 @@ V, S, T, D, A = 20000, 1371, 34, 27, 36267
 FLOP_PER_CLIP = 2.735e9
 PEAK_F32_MFMA = 157.3e12          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA = 2.5e15           # same table, dense bf16 matrix peak (no sparsity)
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv, worker=None, port=None, poll_s=0.2, env_extra=None):
+    """One process per GPU (the role of nn.DataParallel's replicas, scripts/train.py:93-96), started by THIS process as fresh children:
+    the launcher never initialises the GPU (no torch.cuda call happens before or after this function in the parent), so no process that
+    owns a HIP context is ever replaced or forked.  Child r gets RANK = LOCAL_RANK = r, WORLD_SIZE = LOCAL_WORLD_SIZE = n and a
+    127.0.0.1 rendezvous.  Rank 0's stdout is captured, every other stream passes through to stderr.  If a rank exits non-zero the
+    others are terminated (exact PIDs) so a failed rank cannot leave its peers waiting in a collective.
+    Returns (rc, last non-empty stdout line of rank 0 or None): rc is 0 only if every rank returned 0."""
+    worker = worker or os.path.abspath(__file__)
+    port = port or _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, worker] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=True))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    rc = 0
+    live = set(range(n))
+    kill_at = None
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench launcher: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in sorted(live):
+                    procs[o].terminate()
+                kill_at = time.time() + 10.0              # ranks that ignore SIGTERM inside a collective
+        if live:
+            if kill_at is not None and time.time() > kill_at:
+                for o in sorted(live):
+                    procs[o].kill()
+                kill_at = time.time() + 3600.0
+            time.sleep(poll_s)
+    reader.join(timeout=5.0)
+    text = [ln.rstrip("\n") for ln in lines if ln.strip()]
+    for ln in text[:-1]:
+        print(ln, file=sys.stderr, flush=True)            # anything rank 0 printed before its JSON line
+    return rc, (text[-1] if text else None)
 
 
 def make_args():
@@ -286,10 +345,18 @@ def main():
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path (graph segments + RCCL) even with one rank")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (no GPU call has been made in this process, none will be)
+        rc, line = launch_ranks(a.gpus, sys.argv[1:])
+        if line is not None:
+            print(line, flush=True)
+        sys.exit(rc if rc != 0 else (0 if line is not None else 1))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} in the environment (unset it to let bench.py start its own ranks, "
+                 f"or launch with torch.distributed.run --nproc-per-node {a.gpus})")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -317,8 +384,17 @@ def main():
         ddp.broadcast_parameters([trainer.G.slab.ensure(), trainer.D.slab.ensure()])
     text, audio, poses, vid = synthetic_batch(a.batch, 1234 + rank, device)
 
+    ddp_info = None
     if a.no_graph:
         step = lambda: trainer.train_iter(a.epoch, text, audio, poses, vid)
+        if grad_sync is not None:
+            ddp_info = {"ranks": grad_sync.world, "collectives": "eager", "rejected": []}
+    elif grad_sync is not None:
+        # captured collectives are tried first and must reproduce an eager iteration on every rank; otherwise all ranks fall back,
+        # in-process, to graph segments with eager collectives (train_gan.checked_ddp_step)
+        tg = importlib.import_module(PKG + ".train_gan")
+        step, ddp_info = tg.checked_ddp_step(trainer, a.epoch, text, audio, poses, vid, warmup_iters=2,
+                                             log=(lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else None)
     else:
         step = pkg.GraphedGanStep(trainer, a.epoch, text, audio, poses, vid, warmup_iters=2)
     feeder = None
@@ -374,6 +450,9 @@ def main():
                               "note": "whole iteration, algorithmic " + ("2.735" if a.epoch > 10 else "2.101") + " GFLOP/clip (SURVEY 8d), per GPU"},
             "losses": loss_dict,
         }
+        if ddp_info is not None:
+            out["ddp"] = {"ranks": ddp_info["ranks"], "collectives": ddp_info["collectives"],
+                          "rejected": [f"{m}: {w}" for m, w in ddp_info["rejected"]]}
         out["roofline"] = dominant_kernel_roofline(pkg, device, a.batch)
         out["roofline_hbm"] = hbm_kernel_roofline(pkg, device)
         if world == 1 and not a.no_cpu_baseline:

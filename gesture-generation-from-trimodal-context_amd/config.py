@@ -94,7 +94,17 @@ def parse_args(argv=None):
         raise SystemExit(f"{pre.config}: unknown option(s) {unknown}")
     import sys
     cli = list(sys.argv[1:] if argv is None else argv)
-    args = p.parse_args(_yaml_to_argv(cfg) + cli)             # later occurrences win for plain options: the command line overrides
+    # configargparse semantics: the command line overrides the file.  For plain options a later occurrence wins by itself; an
+    # action='append' option (train_data_path, mean_dir_vec ...) would instead be appended to the file's value, so a config key is
+    # dropped when the command line names the same option
+    on_cli = set()
+    for tok in cli:
+        if tok.startswith("-"):
+            act = p._option_string_actions.get(tok.split("=", 1)[0])
+            if act is not None:
+                on_cli.add(act.dest)
+    cfg = {k: v for k, v in cfg.items() if k not in on_cli}
+    args = p.parse_args(_yaml_to_argv(cfg) + cli)
     if args.model is None or args.model_save_path is None:
         raise SystemExit("--model and --model_save_path are required (config file or command line)")
     return args

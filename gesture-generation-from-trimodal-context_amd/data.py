@@ -113,8 +113,22 @@ class SpeechMotionDataset(torch.utils.data.Dataset):
         self.skeleton_resampling_fps, self.mean_dir_vec, self.remove_word_timing = pose_resampling_fps, mean_dir_vec, remove_word_timing
         self.expected_audio_length = int(round(n_poses / pose_resampling_fps * 16000))
         self.expected_spectrogram_length = calc_spectrogram_length_from_motion_length(n_poses, pose_resampling_fps)
-        self.lang_model, self.speaker_model = None, speaker_model
+        self.lang_model = None
         self.n_samples = len(samples)
+        # lmdb_data_loader.py:92-101: no speaker model given (None or 0) -> build one from the data; train.py then reads
+        # train_dataset.speaker_model to size the generator's speaker embedding and passes it on to the validation set
+        self.speaker_model = self._make_speaker_model(samples) if (speaker_model is None or speaker_model == 0) else speaker_model
+
+    @staticmethod
+    def _make_speaker_model(samples):
+        """_make_speaker_model (lmdb_data_loader.py:173-190): Vocab('vid') without default tokens (ids start at 1), one entry per video
+        id, in the order the ids are first met (the reference walks the raw videos of the LMDB; the clips here carry their video's id in
+        aux_info['vid'], so first-appearance order over the clips is the same walk)."""
+        from .vocab import Vocab
+        model = Vocab("vid", insert_default_tokens=False)
+        for smp in samples:
+            model.index_word(smp[5]["vid"])
+        return model
 
     def __len__(self):
         return self.n_samples

@@ -348,7 +348,11 @@ def check_async_errors():
     for key, ws in _gru_ws.items():
         if int(ws[0].item()) != 0:
             info = ws[:14].tolist()
-            ws[:16] = 0
+            # a timed-out launch leaves its cluster's generation word and the late members' flags out of step (the members that gave up
+            # advanced the generation, the ones that arrived late published against the new one): the next launch on this workspace
+            # would find its waits already satisfied by those stale flags.  Zero the WHOLE workspace -- timeout word, generations,
+            # flags -- so the next launch starts from the state of a fresh allocation.
+            ws.zero_()
             raise RuntimeError(f"persistent GRU kernel timed out waiting for a cluster member (device, B, H, bwd) = {key}: step {info[1]}, "
                                f"workgroup {info[2]}, flag words seen {info[4:14]}; results are invalid")
 
@@ -737,9 +741,11 @@ def weight_norm_fwd_batch(vs, gs, want_t=True):
         _flat(v, "v"); _flat(g, "g"); assert tuple(v.shape) == (Co, Ci, kw) and g.numel() == Co
     wp = torch.empty(n, Co, kw * Ci, device=vs[0].device)
     wt = torch.empty(n, Ci, kw * Co, device=vs[0].device) if want_t else None
-    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
-    call("tg_weight_norm_fwd_batch", n, arr(vs), arr(gs), arr([wp[i] for i in range(n)]),
-         arr([wt[i] for i in range(n)]) if want_t else None, Co, Ci, kw, _stream())
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    for j0 in range(0, n, 8):                       # the entry point takes 1..8 convs per launch; n_layers is a free hyper-parameter
+        j1 = min(n, j0 + 8)
+        call("tg_weight_norm_fwd_batch", j1 - j0, arr(vs[j0:j1]), arr(gs[j0:j1]), arr([wp[i] for i in range(j0, j1)]),
+             arr([wt[i] for i in range(j0, j1)]) if want_t else None, Co, Ci, kw, _stream())
     return wp, wt
 
 

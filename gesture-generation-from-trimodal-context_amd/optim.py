@@ -35,5 +35,11 @@ class FusedAdam:
 
     def load_state_dict(self, sd):
         s = self.slab
+        # the moments are flat images of the slab: they only mean something under the layout they were saved with (the order depends on
+        # which parameters were frozen, e.g. freeze_wordembed)
+        if "names" in sd and (list(sd["names"]) != list(s.names) or list(sd["offsets"]) != list(s.offsets)):
+            raise ValueError("optimizer state was saved under a different parameter layout (different frozen set or network): "
+                             f"{len(sd['names'])} tensors / {len(s.names)} here")
+        assert sd["exp_avg"].numel() == s.m.numel(), (sd["exp_avg"].numel(), s.m.numel())
         s.m.copy_(sd["exp_avg"]); s.v.copy_(sd["exp_avg_sq"])
         s.step.fill_(int(sd["step"]))

@@ -65,6 +65,9 @@ class ParamSlab:
     def ensure(self):
         """Module.to()/cuda() replaces .data and breaks the views: detect and rebuild."""
         p0 = self.params[0]
+        if {n for n, p in zip(self.names, self.params) if not p.requires_grad} != self.frozen:
+            raise RuntimeError("requires_grad of a parameter changed after the slab was laid out (the trainable prefix, Adam and the "
+                               "gradient exchange are sized at construction): build the module with its final freeze settings")
         if p0.data_ptr() != self._ptr or p0.device != self.flat.device or any(
                 p.requires_grad and (p.grad is None or p.grad.device != self.flat.device) for p in self.params[:2]):
             self.rebuild()

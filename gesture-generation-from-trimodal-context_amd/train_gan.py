@@ -95,6 +95,25 @@ class GanTrainer:
         if self.grad_sync is not None and self.grad_sync.pending:
             raise RuntimeError("a gradient bucket is still in flight at a point where cluster-synchronised kernels are about to run")
 
+    # ---- complete training state (weights, gradients, Adam moments and counters, RNG counters, BatchNorm buffers)
+    def _state_tensors(self):
+        out = []
+        for eng in (self.G, self.D):
+            s = eng.slab.ensure()
+            out += [s.flat, s.grad, s.m, s.v, s.step, eng.rng.state]
+            out += [b for _, b in eng.mod.named_buffers()]
+        return out
+
+    def snapshot(self):
+        """Copies of every tensor an iteration reads AND writes; restore(snapshot()) makes the next iteration repeat the last one bit
+        for bit up to the order of atomic float sums (used by the data-parallel self-check and the trajectory tests)."""
+        return [t.detach().clone() for t in self._state_tensors()]
+
+    def restore(self, snap):
+        with torch.no_grad():
+            for t, c in zip(self._state_tensors(), snap):
+                t.copy_(c)
+
     # -------------------------------------------------------------------------------------------------------
     def train_iter(self, epoch, in_text, in_audio, target, vid, inject=None):
         """in_text (B,34) int64, in_audio (B,A) f32, target (B,34,27) f32, vid (B,) int64, all on the GPU.
@@ -259,7 +278,7 @@ class GraphedGanStep:
             self.segments.append((state["g"], None))
         torch.cuda.current_stream().wait_stream(cap)
 
-    CHECK_EVERY = 64      # replays between two reads of the persistent kernels' sticky timeout word (one host sync each)
+    CHECK_EVERY = 16      # replays between two reads of the persistent kernels' sticky timeout word (one host sync each)
 
     def __call__(self, in_text=None, in_audio=None, target=None, vid=None):
         self._n_replays = getattr(self, "_n_replays", 0) + 1
@@ -273,3 +292,67 @@ class GraphedGanStep:
             if action is not None:
                 self.trainer.grad_sync.run(action)
         return self.losses
+
+
+def _all_ranks_agree(ok, device):
+    """Logical AND of `ok` over the process group (every rank must take the same path: a rank replaying captured collectives beside one
+    issuing them eagerly deadlocks)."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return bool(ok)
+    backend = torch.distributed.get_backend()
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
+def checked_ddp_step(trainer: GanTrainer, epoch, in_text, in_audio, target, vid, warmup_iters=2, tol=1e-3, modes=None, log=None):
+    """The data-parallel graphed step, self-checked before anybody times or trains with it (scripts/train.py:93-96 is the reference's
+    multi-GPU switch; its DataParallel has no such failure mode -- captured RCCL collectives do).
+
+    One EAGER iteration from the current state gives the reference losses; then, per candidate mode in order -- collectives captured
+    inside the hipGraph (default first), graph segments with eager collectives between them -- the graph is built, the state restored,
+    ONE replay run and its losses compared with the eager ones (relative `tol`).  A mode is accepted only if capture raised on NO rank
+    and the losses agree on EVERY rank (agreement is all-reduced, so all ranks switch together, in-process).  The state is restored
+    afterwards: the caller starts from exactly the state it passed in.  Returns (step, info) with info = {"ranks", "collectives",
+    "rejected": [(mode, reason)]}."""
+    import os
+    assert trainer.grad_sync is not None, "checked_ddp_step is the data-parallel constructor"
+    dev = target.device
+    say = log or (lambda *_: None)
+    if modes is None:
+        modes = ["captured", "segments"] if os.environ.get("TG_DDP_CAPTURE", "1") != "0" else ["segments"]
+    snap = trainer.snapshot()
+    ref = trainer.train_iter(epoch, in_text, in_audio, target, vid).to_dict()
+    trainer.restore(snap)
+    rejected = []
+    for mode in modes:
+        step, why = None, None
+        try:
+            step = GraphedGanStep(trainer, epoch, in_text, in_audio, target, vid, warmup_iters=warmup_iters,
+                                  capture_collectives=(mode == "captured"))
+        except Exception as e:                       # capture refused (RCCL / runtime): fall through to the next mode
+            why = f"capture raised {type(e).__name__}: {e}"
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+        if not _all_ranks_agree(step is not None, dev):
+            rejected.append((mode, why or "capture failed on another rank"))
+            say(f"ddp self-check: {mode} rejected ({rejected[-1][1]})")
+            trainer.grad_sync.pending = []
+            trainer.restore(snap)
+            continue
+        trainer.restore(snap)
+        got = step().to_dict()
+        bad = [k for k in ref if k not in got or not (abs(got[k] - ref[k]) <= tol * max(1.0, abs(ref[k])))]
+        if not _all_ranks_agree(not bad, dev):
+            why = "losses differ from the eager iteration: " + ", ".join(f"{k} {got.get(k)} vs {ref[k]}" for k in bad) if bad else \
+                  "losses differ on another rank"
+            rejected.append((mode, why))
+            say(f"ddp self-check: {mode} rejected ({why})")
+            trainer.restore(snap)
+            continue
+        trainer.restore(snap)
+        say(f"ddp self-check: {mode} accepted, losses equal the eager iteration within {tol:g}")
+        return step, {"ranks": trainer.grad_sync.world, "collectives": mode, "rejected": rejected}
+    raise RuntimeError("no data-parallel graph mode passed its self-check: " + "; ".join(f"{m}: {w}" for m, w in rejected))

@@ -107,6 +107,30 @@ def test_dataset_items_and_collate_match_reference_golden(pkg):
         assert np.array_equal(D.make_audio_fixed_length(a, n), g["fixlen/" + key])
 
 
+def test_dataset_builds_speaker_model_when_none_given(pkg):
+    """lmdb_data_loader.py:92-101,173-190: speaker_model None or 0 -> the dataset builds Vocab('vid') from the data (ids from 1, one per
+    video id); train.py reads train_dataset.speaker_model to build the generator.  Checked on the reference's own g10 samples: collate()
+    must then return a usable vid tensor (the z_type='speaker' engine asserts on it)."""
+    D = _mods(pkg)
+    g = load("g10_dataset.npz")
+    samples = dataset_samples(g)
+    vids = []
+    for smp in samples:
+        if smp[5]["vid"] not in vids:
+            vids.append(smp[5]["vid"])
+    for arg in (None, 0):
+        ds = D.SpeechMotionDataset(samples, 34, 10, 15, speaker_model=arg)
+        sm = ds.speaker_model
+        assert isinstance(sm, pkg.Vocab) and sm.name == "vid" and sm.n_words == len(vids) + 1          # row 0 unused (SURVEY Q7)
+        assert [sm.word2index[v] for v in vids] == list(range(1, len(vids) + 1))
+        assert sum(sm.word2count.values()) == len(samples)
+        ds.set_lang_model(fixture_lang(pkg.Vocab, int(g["vocab_size"])))
+        text, vec, audio, vid = D.collate([ds[i] for i in range(min(4, len(ds)))], ds.speaker_model)
+        assert vid is not None and vid.dtype == torch.int64 and int(vid.min()) >= 1 and int(vid.max()) < sm.n_words
+    given = pkg.Vocab.speakers(5)
+    assert D.SpeechMotionDataset(samples, 34, 10, 15, speaker_model=given).speaker_model is given
+
+
 def test_window_inputs_and_fade_out_match_reference_golden(pkg):
     """synthesize.window_inputs / num_windows / fade_out_to_mean == what scripts/synthesize.py:generate_gestures fed its model and
     did to its output (recorded window inputs; fade-out applied to the reference's own un-faded result)."""
