@@ -142,11 +142,15 @@ def load():
     lib.tg_gemm_nt_family.argtypes = [C.POINTER(NtProblem)]
     lib.tg_gemm_nt_ext_supported.restype = C.c_int32
     lib.tg_gemm_nt_ext_supported.argtypes = [C.POINTER(NtProblem)]
+    lib.tg_gemm_nt_kernel_plan.restype = C.c_int32
+    lib.tg_gemm_nt_kernel_plan.argtypes = [C.POINTER(NtProblem), I32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.tg_bn_fused_supported.restype = C.c_int32
     lib.tg_bn_fused_supported.argtypes = [I32, I32, I32]
     lib.tg_set_math_mode.restype = C.c_int
     lib.tg_set_math_mode.argtypes = [I32]
     lib.tg_get_math_mode.restype = C.c_int
+    lib.tg_set_nt_mover_waves.restype = C.c_int
+    lib.tg_set_nt_mover_waves.argtypes = [I32]
     lib.tg_gru_cluster_fused_dropout.restype = C.c_int32
     lib.tg_gru_cluster_supported.restype = C.c_int32
     lib.tg_gru_cluster_supported.argtypes = [I32, I32]

@@ -90,6 +90,7 @@ struct NtProb {
     const __bf16* Bpl;       // optional pre-split weight operand: planes [3][>= N rows][Kp] bf16 (gemm_planes.hip), bpl_plane elements apart
     long bpl_plane;
     int Kp;
+    unsigned a_bytes, b_bytes;   // byte extents of the A tensor / the weights from their base pointers (gemm_mw.hip buffer descriptors; filled by its launcher)
 };
 
 struct NtGroup {

@@ -762,7 +762,7 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
     p.Bw = q.Bw; p.ldb = (long)q.ldb; p.b_seg_k = seg; p.b_seg_stride = q.b_seg_k > 0 ? (long)q.b_seg_stride : 0;
     p.bias = q.bias; p.mul = q.out_scale; p.C = q.C; p.cbs = (long)q.c_batch_stride; p.crs = (long)q.c_row_stride; p.cR = q.c_rows_out;
     p.M = q.M; p.N = q.N; p.slope = q.act_slope; p.accumulate = q.accumulate; p.n_nt = 0;
-    p.Bpl = nullptr; p.bpl_plane = 0; p.Kp = 0;
+    p.Bpl = nullptr; p.bpl_plane = 0; p.Kp = 0; p.a_bytes = p.b_bytes = 0;
     if (q.b_planes) {
         TG_REQUIRE(q.b_seg_k == 0 && q.b_kp % 32 == 0 && q.b_kp >= q.A.K && q.b_plane_stride >= (int64_t)q.N * q.b_kp && q.b_plane_stride % 8 == 0 &&
                        aligned16(q.b_planes) && (int64_t)(q.N + 1) * q.b_kp < (1LL << 30),
@@ -788,6 +788,25 @@ extern "C" int32_t tg_gemm_nt_ext_supported(const tg_gemm_nt_problem* problem) {
     NtProb p;
     if (!problem || nt_fill(p, *problem, 0)) return 0;
     return nt_family(p) == 0 && use_split_path() ? 1 : 0;
+}
+
+bool tg_gemm_nt_mw_eligible(NtGroup& g, int* tm, int* tn);
+extern "C" int32_t tg_gemm_nt_kernel_plan(const tg_gemm_nt_problem* problems, int32_t n, int32_t* tile_m, int32_t* tile_n) {
+    if (!problems || n < 1 || n > TG_MAX_GROUP) return -1;
+    NtGroup g;
+    g.n = n;
+    for (int i = 0; i < n; ++i)
+        if (nt_fill(g.p[i], problems[i], i)) return -1;
+    for (int i = n; i < TG_MAX_GROUP; ++i) g.p[i] = g.p[0];
+    const int fam = nt_family(g.p[0]);
+    for (int i = 0; i < n; ++i)
+        if (nt_family(g.p[i]) != fam) return -1;
+    if (fam != 0 || !use_split_path()) return 0;
+    int tm = 0, tn = 0;
+    if (!tg_gemm_nt_mw_eligible(g, &tm, &tn)) return 1;
+    if (tile_m) *tile_m = 32 * tm;
+    if (tile_n) *tile_n = 32 * tn;
+    return 2;
 }
 
 extern "C" int tg_gemm_nt_group(const tg_gemm_nt_problem* problems, int32_t n, void* stream) {

@@ -707,7 +707,14 @@ static SplitTile split_pick_tile(int M, int N) {
     return {2, 2, 1};
 }
 
+bool tg_gemm_nt_mw_eligible(NtGroup& g, int* tm, int* tn);
+int tg_gemm_nt_mw_launch(NtGroup& g, int tm, int tn, int splits, hipStream_t s);
+
 int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
+    {   // many-row products whose big tiles fill the chip: mover-wave kernel (gemm_mw.hip)
+        int tm = 0, tn = 0;
+        if (tg_gemm_nt_mw_eligible(g, &tm, &tn)) return tg_gemm_nt_mw_launch(g, tm, tn, g_math_mode == 1 ? 1 : 3, s);
+    }
     int Mx = 0, Nx = 0;
     for (int i = 0; i < g.n; ++i) { Mx = Mx > g.p[i].M ? Mx : g.p[i].M; Nx = Nx > g.p[i].N ? Nx : g.p[i].N; }
     const SplitTile tl = split_pick_tile(Mx * g.n, Nx);

@@ -138,6 +138,21 @@ def nt_ext_supported(A: Win, W, out, **kw):
     return bool(_lib.load().tg_gemm_nt_ext_supported(C.byref(q)))
 
 
+def set_nt_mover_waves(on):
+    """True / False: force the mover-wave kernel on / off; None: back to the environment default (TG_NT_MW, on)."""
+    call("tg_set_nt_mover_waves", -1 if on is None else int(bool(on)))
+
+
+def nt_kernel_plan(problems):
+    """(plan, tile_m, tile_n) for a group given as gemm_nt_group's list of dicts: plan 0 = f32-MFMA / narrow / small kernels, 1 = bf16 x 3
+    staged slabs (gemm_split.hip), 2 = bf16 x 3 mover waves (gemm_mw.hip); tiles are 0 unless plan == 2."""
+    qs = [_nt_problem(**p) for p in problems]
+    arr = (_lib.NtProblem * len(qs))(*qs)
+    tm, tn = C.c_int32(0), C.c_int32(0)
+    plan = int(_lib.load().tg_gemm_nt_kernel_plan(arr, len(qs), C.byref(tm), C.byref(tn)))
+    return plan, tm.value, tn.value
+
+
 def gemm_nt(A: Win, W, bias, out, **kw):
     """out(m, :) = act(A(m, :) @ W^T + bias) [+ out].  W: [N, K] (row stride may exceed K).
     out: 2-D view [M, N] (unit inner stride) unless explicit C addressing is given."""

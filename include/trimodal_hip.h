@@ -110,6 +110,15 @@ int tg_gemm_nt_group(const tg_gemm_nt_problem* problems, int32_t n, void* stream
 int32_t tg_gemm_nt_family(const tg_gemm_nt_problem* problem);
 /* 1 when this problem would run on a kernel that implements gate / res / C2 (family 0 on the bf16 x 3 or bf16 path), else 0 */
 int32_t tg_gemm_nt_ext_supported(const tg_gemm_nt_problem* problem);
+/* Which kernel a group of n problems would run on, without launching: 0 = f32-MFMA / narrow / small kernels (gemm.hip),
+ * 1 = bf16 x 3 staged-slab kernel (gemm_split.hip), 2 = bf16 x 3 mover-wave kernel (gemm_mw.hip: 512-thread workgroups, big tiles,
+ * chosen when its tiles fill the chip); -1 invalid.  *tile_m / *tile_n (may be NULL) receive the workgroup tile for plan 2.
+ * Replaces nothing in the reference (torch picks its own GEMM there, multimodal_context_net.py:98-99, model/tcn.py:19-46): test
+ * and profiling aid, so that a parity test can assert WHICH kernel it covered. */
+int32_t tg_gemm_nt_kernel_plan(const tg_gemm_nt_problem* problems, int32_t n, int32_t* tile_m, int32_t* tile_n);
+/* Process-wide switch of the mover-wave kernel: 1 on, 0 off (every big product on gemm_split.hip), -1 back to the environment default
+ * (TG_NT_MW, on).  For same-process A/B timing (tools/nt_mw_probe.py) and tests; results are equal within the fp32 tolerance either way. */
+int tg_set_nt_mover_waves(int32_t on);
 int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bias, float* C,
                int64_t c_batch_stride, int64_t c_row_stride, int32_t c_rows_out, int32_t M, int32_t N,
                float act_slope, int32_t accumulate, void* stream);

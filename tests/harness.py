@@ -77,17 +77,18 @@ def grad_errors(mine, ref):
 
 
 def run_train_parity(pkg, dev, batch=4, epochs=(0, 11), n_words=512, n_speakers=17, seed=77, verbose=False, dropout=True,
-                     input_context="both", z_type="speaker", rand_seed=1017, check_step=True):
+                     input_context="both", z_type="speaker", rand_seed=1017, check_step=True, n_layers=4):
     """Oracle (fp64, CPU) and HIP path on identical weights, inputs and random draws, one iteration per epoch value,
     fresh models each.  Returns the worst normalised error over losses, gradients, BN buffers and updated parameters."""
     worst = 0.0
     z_mode = z_type if z_type in ("speaker", "random") else None
-    gst0 = O.make_generator_state(3, n_words, n_speakers, input_context=input_context, z_mode=z_mode)
+    gst0 = O.make_generator_state(3, n_words, n_speakers, input_context=input_context, z_mode=z_mode, layers=n_layers)
     dst0 = O.make_discriminator_state(4)
     text, audio, vid, poses = O.make_batch(seed, batch, n_words, n_speakers)
     for epoch in epochs:
         og, od = O.clone_state(gst0, torch.float64), O.clone_state(dst0, torch.float64)
         hp = dict(O.HP)
+        hp["n_layers"] = n_layers
         if not dropout:
             hp["dropout_prob"] = 0.0
         # seed note: the fp64 oracle and the fp32 path can disagree on the sign of a ReLU pre-activation that is ~0
@@ -96,7 +97,7 @@ def run_train_parity(pkg, dev, batch=4, epochs=(0, 11), n_words=512, n_speakers=
         rand = O.Rand(seed=rand_seed + epoch) if dropout else _NoDrop(seed=rand_seed + epoch)
         oret, extra = O.train_iter_gan(og, od, {}, {}, epoch, text, audio.double(), poses.double(), vid, rand, hp, want_grads=True,
                                        input_context=input_context, z_type=z_type)
-        args, G, D = build_models(pkg, dev, gst0, dst0, n_words, n_speakers, make_args(input_context=input_context, z_type=z_type))
+        args, G, D = build_models(pkg, dev, gst0, dst0, n_words, n_speakers, make_args(input_context=input_context, z_type=z_type, n_layers=n_layers))
         tr = pkg.GanTrainer(G, D, args)
         losses = tr.train_iter(epoch, text.to(dev), audio.to(dev), poses.to(dev), vid.to(dev), inject=to_device_inject(rand.rec, dev))
         ret = losses.to_dict()

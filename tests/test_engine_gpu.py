@@ -55,6 +55,13 @@ def test_generator_variants_match_fp64_oracle(pkg, dev, ctx, zt):
     assert worst < 1e-4, worst
 
 
+def test_five_layer_generator_matches_fp64_oracle(pkg, dev):
+    """n_layers is a plain hyper-parameter (config/parse_args.py): 5 TCN blocks = 10 weight-normed convs (more than one batched
+    weight-norm launch takes) and a 5-layer GRU, forward and backward."""
+    worst = run_train_parity(pkg, dev, batch=3, epochs=(11,), n_layers=5, verbose=True)
+    assert worst < 1e-4, worst
+
+
 def test_variant_module_api_shapes(pkg, dev):
     """forward() return arity follows the reference: z/mu/logvar are None where the reference returns None (:132-137)."""
     V, S, B = 64, 9, 3

@@ -570,6 +570,90 @@ def test_gemm_nt_epilogue_gate_and_residual_output(pkg, dev, M, N, K):
         ops.gemm_nt(Win.plain(xs), ws, None, small, gate=torch.ones(64, 20, device=dev))
 
 
+def _row_err(out, ref):
+    return float(((out.double().cpu() - ref).abs() / ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)).max())
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(13000, 900, 600, (128, 192)), (13056, 900, 108, (128, 192)), (13056, 300, 600, (128, 160)),
+                                        (9999, 596, 1000, (128, 160))])
+def test_gemm_nt_mover_wave_kernel_is_fp32_accurate(pkg, dev, M, N, K, tile):
+    """csrc/gemm_mw.hip (512-thread workgroups: four mover waves stage + split the operands, four matrix waves multiply; big tiles, one
+    workgroup per CU) on the shapes it is chosen for -- the stacked forward's GRU input projections (multimodal_context_net.py:98-99: N =
+    900, K = 600 / 108) and the TCN convs (model/tcn.py:19-46: N = 300) -- against fp64 at the fp32 tolerance: ragged tails in M, N and K,
+    operands spanning 8 decades (lost low-order terms would show), bias + activation, accumulate, strided output, a two-problem group."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * torch.pow(10.0, torch.randint(-4, 4, (M, 1), generator=g).float())
+    ws = [torch.randn(N, K, generator=g) * 0.1 for _ in range(2)]
+    bs = [torch.randn(N, generator=g) for _ in range(2)]
+    xd = x.to(dev)
+    outs = [torch.full((M, N + 8), float("nan"), device=dev) for _ in range(2)]
+    probs = [dict(A=Win.plain(xd), W=w.to(dev), bias=b.to(dev), out=o[:, 4:4 + N], act_slope=0.3) for w, b, o in zip(ws, bs, outs)]
+    plan = ops.nt_kernel_plan(probs)
+    assert plan == (2,) + tile, plan                          # this test is about the mover-wave kernel: fail if the dispatcher chose another
+    ops.gemm_nt_group(probs)
+    for w, b, o in zip(ws, bs, outs):
+        ref = F.leaky_relu(x.double() @ w.double().t() + b.double(), 0.3)
+        assert _row_err(o[:, 4:4 + N], ref) < 1e-5
+        assert bool(torch.isnan(o[:, :4]).all()) and bool(torch.isnan(o[:, 4 + N:]).all())
+    ops.gemm_nt(Win.plain(xd), ws[0].to(dev), None, outs[0][:, 4:4 + N], accumulate=True)
+    ref2 = F.leaky_relu(x.double() @ ws[0].double().t() + bs[0].double(), 0.3) + x.double() @ ws[0].double().t()
+    assert _row_err(outs[0][:, 4:4 + N], ref2) < 1e-5
+
+
+def test_gemm_nt_mover_wave_kernel_windows_and_epilogues(pkg, dev):
+    """The same kernel behind the windows and epilogues of the text encoder at the stacked forward's size (B_s = 384 clips x 34 frames):
+    the dilated causal conv with its zero padding (rows before the clip read as zero through the buffer descriptor's range check),
+    ReLU + dropout scale + the block's closing relu(out + x) as second output (forward form, model/tcn.py:27-46), the input-gradient
+    form with reversed taps (negative dilation), gate and accumulate, and K-concatenated weight segments over a two-tap window."""
+    ops, Win, Lm = pkg.ops, pkg.ops.Win, pkg.layers
+    B, T, Cc, d = 384, 34, 300, 4
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cc, T, generator=g).double()
+    w = (torch.randn(Cc, Cc, 2, generator=g) * 0.05).double()
+    b = torch.randn(Cc, generator=g).double()
+    mask = ((torch.rand(B, T, Cc, generator=g) > 0.3).float() / 0.7)
+    res = torch.randn(B, T, Cc, generator=g)
+    xd = cl(x.float()).to(dev)
+    wp = Lm.pack_conv_weight(w.float().to(dev))
+    a_win = Win.conv(xd, 2, pad=d, dil=d, rows_out=T)
+    out, out2 = torch.full((B, T, Cc), float("nan"), device=dev), torch.full((B, T, Cc), float("nan"), device=dev)
+    assert ops.nt_kernel_plan([dict(A=a_win, W=wp, bias=b.float().to(dev), out=out, c_batch_stride=out.stride(0), c_row_stride=out.stride(1),
+                                    c_rows_out=T)])[0] == 2
+    o = Lm.conv_fwd(xd, wp, b.float().to(dev), 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=mask.to(dev), res=res.to(dev), out2=out2, out=out)
+    y = torch.relu(F.conv1d(x, w, b, padding=d, dilation=d)[:, :, :T])
+    ref = cl(y) * mask.double()
+    assert rel(o, ref) < 1e-5
+    ref2 = torch.relu(o.double().cpu() + res.double())
+    assert float((out2.double().cpu() - ref2).abs().max()) <= 1e-6 * float(ref2.abs().max())
+    # input-gradient form: dx[t] = dy[t] . W[:, :, 1] + dy[t + d] . W[:, :, 0] (rows past the clip read as zero), gated, accumulated
+    dy = torch.randn(B, T, Cc, generator=g)
+    gate = torch.relu(torch.randn(B * T, Cc, generator=g))
+    base = torch.randn(B * T, Cc, generator=g)
+    wT = torch.cat([w[:, :, 1].t().contiguous(), w[:, :, 0].t().contiguous()], dim=1).float()      # [Ci][2 Co]: taps (t, t + d)
+    dyd = dy.to(dev)
+    a_back = Win.taps(dyd, 2, shift=0, dil=d, rows_out=T)
+    acc = base.to(dev).clone()
+    probs = [dict(A=a_back, W=wT.to(dev), bias=None, out=acc, gate=gate.to(dev), accumulate=True)]
+    assert ops.nt_kernel_plan(probs)[0] == 2
+    ops.gemm_nt_group(probs)
+    dyp = torch.cat([dy.double(), torch.zeros(B, d, Cc, dtype=torch.float64)], dim=1)
+    full = dyp[:, :T] @ w[:, :, 1] + dyp[:, d:d + T] @ w[:, :, 0]                                   # (B, T, Ci)
+    refb = base.double() + full.reshape(B * T, Cc) * (gate > 0).double()
+    assert rel(acc, refb) < 1e-5
+    assert torch.equal(acc.cpu()[gate == 0], base[gate == 0])
+    # K-concatenated weights over a two-"tap" window: dx = dgi_fwd @ W_fwd + dgi_rev @ W_rev at the stacked size
+    Mh, Kh, N = 13056, 448, 600
+    dgi = (torch.randn(2, Mh, Kh, generator=g)).to(dev)
+    wbuf = (torch.randn(3, N, Kh, generator=g) * 0.1).to(dev)
+    a_cat = Win(dgi, batches=1, batch_stride=0, row_stride=Kh, rows_in=2 * Mh, rows_out=Mh, cw=Kh, K=2 * Kh, dil=Mh)
+    outc = torch.full((Mh, N), float("nan"), device=dev)
+    assert ops.nt_kernel_plan([dict(A=a_cat, W=wbuf[0], bias=None, out=outc, b_seg=(Kh, 2 * N * Kh))])[0] == 2
+    ops.gemm_nt(a_cat, wbuf[0], None, outc, b_seg=(Kh, 2 * N * Kh))
+    refc = dgi[0].double().cpu() @ wbuf[0].double().cpu().t() + dgi[1].double().cpu() @ wbuf[2].double().cpu().t()
+    assert rel(outc, refc) < 1e-5
+
+
 def test_bf16_math_mode_tier(pkg, dev):
     """tg_set_math_mode(1): the big forward / input-gradient products take bf16 operands (one MFMA per product, fp32 accumulate).
     Op-level error at the bf16 level (and clearly different from the fp32 result: the mode really switches), and one full GAN

@@ -1,0 +1,32 @@
+"""In-situ ablation of the mover-wave NT kernel (128 x 192 tile) on the grouped GRU input projection 2 x [13056 x 900 x 600]: which role costs
+what, and how much of it overlaps.  Needs the lab library (make -C <package>/csrc lab).  TG_MW_ABL bit 0 drops the MFMAs, bit 1 the movers'
+split arithmetic + LDS stores, bit 2 the global operand loads, bit 3 the matrix waves' fragment reads, bit 4 the epilogue's global traffic.
+Ablated launches compute garbage by construction."""
+import importlib, os, sys, torch
+sys.path.insert(0, '/root/repo')
+pkg = importlib.import_module("gesture-generation-from-trimodal-context_amd")
+lab = os.path.join(os.path.dirname(pkg._lib.LIB_PATH), "libtrimodal_hip_lab.so")
+assert os.path.exists(lab), "build the lab library first: make -C gesture-generation-from-trimodal-context_amd/csrc lab"
+pkg._lib.LIB_PATH = lab
+ops, Win = pkg.ops, pkg.ops.Win
+dev = torch.device("cuda:0")
+def t(fn, iters=500):
+    for _ in range(20): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+M, N, K = 13056, 900, 600
+x = torch.randn(M, K, device=dev)
+ws = [torch.randn(N, K, device=dev) * 0.05 for _ in range(2)]
+outs = [torch.empty(M, N, device=dev) for _ in range(2)]
+probs = [dict(A=Win.plain(x), W=w, bias=None, out=o) for w, o in zip(ws, outs)]
+assert ops.nt_kernel_plan(probs) == (2, 128, 192)
+names = {0: "full kernel", 1: "no MFMA", 2: "movers: loads only (no split, no LDS stores)", 3: "no MFMA, movers loads only", 4: "no global loads",
+         6: "movers idle (no loads, no split, no stores)", 7: "fragment reads + barriers + epilogue", 8: "no fragment reads",
+         9: "no MFMA, no fragment reads (movers alone)", 15: "barriers + epilogue only", 16: "no epilogue traffic", 31: "barriers + LDS epilogue only"}
+for abl in (0, 1, 2, 3, 4, 6, 7, 8, 9, 15, 16, 31, 0):
+    os.environ["TG_MW_ABL"] = str(abl)
+    us = t(lambda: ops.gemm_nt_group(probs))
+    print(f"ABL {abl:2d}  {names[abl]:50s} {us:7.1f} us", flush=True)

@@ -1,0 +1,75 @@
+"""Same-process A/B of the big forward products: mover-wave kernel (csrc/gemm_mw.hip) against the staged-slab kernel
+(csrc/gemm_split.hip), interleaved rounds, sustained launches on random data (cdna_hip_programming.md 5.4 rules 24 / 25).
+
+    python3 tools/nt_mw_probe.py [rounds] > gpurun_out/<tag>_nt_mw_probe.txt
+Shapes: the stacked forward of the B = 128 iteration (13056 rows): both directions' GRU input projections as one group (K = 600 and the
+first layer's K = 108), one TCN conv with its causal window + dropout scale epilogue, and backward-sized products (4352 rows)."""
+import importlib
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, "/root/repo")
+pkg = importlib.import_module("gesture-generation-from-trimodal-context_amd")
+ops, Win, Lm = pkg.ops, pkg.ops.Win, pkg.layers
+dev = torch.device("cuda:0")
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+
+
+def timed(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def group(M, N, K, n):
+    x = torch.randn(M, K, device=dev)
+    ws = [torch.randn(N, K, device=dev) * 0.05 for _ in range(n)]
+    bs = [torch.randn(N, device=dev) for _ in range(n)]
+    outs = [torch.empty(M, N, device=dev) for _ in range(n)]
+    probs = [dict(A=Win.plain(x), W=w, bias=b, out=o) for w, b, o in zip(ws, bs, outs)]
+    return probs, 2.0 * M * N * K * n, (x, ws, bs, outs)
+
+
+def tcn(B, T, C, d):
+    x = torch.randn(B, T, C, device=dev)
+    wp = torch.randn(C, 2 * C, device=dev) * 0.05
+    b = torch.randn(C, device=dev)
+    mask = (torch.rand(B, T, C, device=dev) > 0.3).float() / 0.7
+    out = torch.empty(B, T, C, device=dev)
+    probs = [dict(A=Win.conv(x, 2, pad=d, dil=d, rows_out=T), W=wp, bias=b, out=out, act_slope=0.0, out_scale=mask,
+                  c_batch_stride=out.stride(0), c_row_stride=out.stride(1), c_rows_out=T)]
+    return probs, 2.0 * B * T * C * 2 * C, (x, wp, b, mask, out)
+
+
+cases = [("gru proj 2 x [13056 x 900 x 600]", group(13056, 900, 600, 2)),
+         ("gru proj 2 x [13056 x 900 x 108]", group(13056, 900, 108, 2)),
+         ("tcn conv  [13056 x 300 x 600] d=4", tcn(384, 34, 300, 4)),
+         ("dgrad     [4352 x 600 x 1800]", group(4352, 600, 1800, 1)),
+         ("dgrad tcn [4352 x 300 x 600]", group(4352, 300, 600, 1))]
+print(f"# tools/nt_mw_probe.py: {rounds} interleaved rounds x 100 launches, us per launch (median / min), fp32-equivalent TFLOP/s at the median")
+for name, (probs, flops, keep) in cases:
+    res = {}
+    plans = {}
+    for on in (False, True):
+        ops.set_nt_mover_waves(on)
+        plans[on] = ops.nt_kernel_plan(probs)
+        for _ in range(10):
+            ops.gemm_nt_group(probs)
+    ref = None
+    for r in range(rounds):
+        for on in (False, True):
+            ops.set_nt_mover_waves(on)
+            res.setdefault(on, []).append(timed(lambda: ops.gemm_nt_group(probs), 100))
+    ops.set_nt_mover_waves(None)
+    line = f"{name:36s}"
+    for on in (False, True):
+        med, mn = statistics.median(res[on]), min(res[on])
+        line += f" | plan {plans[on]} {med:7.1f} / {mn:7.1f} us {flops / med / 1e6:6.1f} TF"
+    line += f" | ratio {statistics.median(res[True]) / statistics.median(res[False]):.3f}"
+    print(line, flush=True)
