@@ -24,7 +24,7 @@ class NtProblem(C.Structure):
     """struct tg_gemm_nt_problem"""
     _fields_ = [("A", Window), ("Bw", P), ("ldb", I64), ("b_seg_k", I32), ("reserved", I32), ("b_seg_stride", I64), ("bias", P), ("C", P),
                 ("c_batch_stride", I64), ("c_row_stride", I64), ("c_rows_out", I32), ("M", I32), ("N", I32), ("act_slope", F32),
-                ("accumulate", I32), ("out_scale", P), ("b_planes", P), ("b_plane_stride", I64), ("b_kp", I32), ("reserved2", I32),
+                ("accumulate", I32), ("out_scale", P), ("reserved_ptr", P), ("reserved_i64", I64), ("reserved_i32", I32), ("reserved2", I32),
                 ("gate", P), ("res", P), ("C2", P), ("res_slope", F32), ("reserved3", I32)]
 
 
@@ -120,7 +120,7 @@ SIGNATURES = {
     "tg_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, P, P],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

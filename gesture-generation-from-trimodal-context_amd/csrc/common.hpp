@@ -87,9 +87,6 @@ struct NtProb {
     const float* res;        // ... and / or a second output C2 = act2(C + res), slope res_slope; all addressed like C
     float* C2;
     float res_slope;
-    const __bf16* Bpl;       // optional pre-split weight operand: planes [3][>= N rows][Kp] bf16 (gemm_planes.hip), bpl_plane elements apart
-    long bpl_plane;
-    int Kp;
     unsigned a_bytes, b_bytes;   // byte extents of the A tensor / the weights from their base pointers (gemm_mw.hip buffer descriptors; filled by its launcher)
 };
 
@@ -163,8 +160,12 @@ __device__ __forceinline__ void split3_bits(float x, unsigned& hi, unsigned& mid
 // upper halves of two fp32 words -> one dword holding two bf16 (first element in the low half)
 __device__ __forceinline__ unsigned pack_hi16(unsigned first, unsigned second) { return __builtin_amdgcn_perm(second, first, 0x07060302u); }
 
-// one 8-column piece of a plane buffer ([3][rows + 1][cwp] bf16, see gemm_planes.hip): columns c .. c + 7 of row r of an fp32 matrix
-// [rows][cw] (row stride ldx), zero past cw and in the extra row `rows`
+// Plane buffer of an fp32 matrix [rows][cw] (gemm_planes.hip): three bf16 planes (hi / mid / lo), each SLAB-TILED -- [cwp / 32 slabs][rows + 1]
+// [32 columns], cwp = cw rounded up to 32, zero past cw and in the extra row `rows` of every slab.  One 32-deep K slab of 16 consecutive
+// rows is then 1 KB of contiguous memory: a single LDS-DMA instruction fetches it as eight whole cache lines (with row-major planes the
+// same instruction touched 16 half lines 2 cwp bytes apart and cost the CU's address unit ~60 cycles: profiles/r3_g_nt_mw_probe.txt).
+__device__ __host__ __forceinline__ long plane_tiled_off(long r, int c, int rows) { return ((long)(c >> 5) * (rows + 1) + r) * 32 + (c & 31); }
+// one 8-column piece of such a buffer: columns c .. c + 7 (c % 8 == 0) of row r of the fp32 matrix (row stride ldx)
 typedef unsigned tg_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split3_write_piece(const float* __restrict__ x, long ldx, int rows, int cw, int cwp, __bf16* __restrict__ planes,
                                                    long plane_stride, long r, int c, bool vec) {
@@ -180,7 +181,7 @@ __device__ __forceinline__ void split3_write_piece(const float* __restrict__ x, 
     unsigned h[8], m[8], l[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) split3_bits(v[q], h[q], m[q], l[q]);
-    const long o = r * cwp + c;
+    const long o = plane_tiled_off(r, c, rows);
     *reinterpret_cast<tg_u32x4*>(planes + o) = tg_u32x4{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])};
     *reinterpret_cast<tg_u32x4*>(planes + plane_stride + o) = tg_u32x4{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])};
     *reinterpret_cast<tg_u32x4*>(planes + 2 * plane_stride + o) = tg_u32x4{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])};

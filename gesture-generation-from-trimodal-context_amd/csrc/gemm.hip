@@ -762,13 +762,9 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
     p.Bw = q.Bw; p.ldb = (long)q.ldb; p.b_seg_k = seg; p.b_seg_stride = q.b_seg_k > 0 ? (long)q.b_seg_stride : 0;
     p.bias = q.bias; p.mul = q.out_scale; p.C = q.C; p.cbs = (long)q.c_batch_stride; p.crs = (long)q.c_row_stride; p.cR = q.c_rows_out;
     p.M = q.M; p.N = q.N; p.slope = q.act_slope; p.accumulate = q.accumulate; p.n_nt = 0;
-    p.Bpl = nullptr; p.bpl_plane = 0; p.Kp = 0; p.a_bytes = p.b_bytes = 0;
-    if (q.b_planes) {
-        TG_REQUIRE(q.b_seg_k == 0 && q.b_kp % 32 == 0 && q.b_kp >= q.A.K && q.b_plane_stride >= (int64_t)q.N * q.b_kp && q.b_plane_stride % 8 == 0 &&
-                       aligned16(q.b_planes) && (int64_t)(q.N + 1) * q.b_kp < (1LL << 30),
-                   "tg_gemm_nt: bad weight planes (problem %d): b_kp=%d must be a multiple of 32 >= K=%d, one weight matrix, aligned", idx, q.b_kp, q.A.K);
-        p.Bpl = reinterpret_cast<const __bf16*>(q.b_planes); p.bpl_plane = (long)q.b_plane_stride; p.Kp = q.b_kp;
-    }
+    p.a_bytes = p.b_bytes = 0;
+    TG_REQUIRE(q.reserved_ptr == nullptr && q.reserved_i64 == 0 && q.reserved_i32 == 0,
+               "tg_gemm_nt: reserved fields must be zero (problem %d): pre-split weights go through tg_gemm_nt_planes_group", idx);
     TG_REQUIRE((q.res == nullptr) == (q.C2 == nullptr), "tg_gemm_nt: res and C2 go together (problem %d)", idx);
     p.gate = q.gate; p.res = q.res; p.C2 = q.C2; p.res_slope = q.res_slope;
     p.vec_c = (q.N % 4 == 0) && (q.c_batch_stride % 4 == 0) && (q.c_row_stride % 4 == 0) && aligned16(q.C) &&

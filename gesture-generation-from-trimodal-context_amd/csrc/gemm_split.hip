@@ -62,8 +62,6 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
 // RING = register sets of global loads in flight (slabs fetched ahead): 1 = the next slab only, 2 = two slabs ahead (+ 4 (TM + TN)
 // VGPRs; the loads of a slab then have two MFMA sections to land instead of one)
 // OCC = waves per SIMD the register allocation is held to (HIP's second launch-bounds argument; 1 = unconstrained)
-// BPL: the weight operand arrives PRE-SPLIT (NtProb::Bpl, bf16 x 3 planes written once per optimiser step by layers.WeightPrep): its
-// staging is three 16-byte loads -> three 16-byte LDS stores per piece and no arithmetic -- the activation operand is still split while staged.
 // ABL (lab builds only, -DTG_LAB_ABLATE, tools/nt_ablate.py; results are WRONG by construction): bit 0 drops the MFMAs, bit 1 the split
 // arithmetic, bit 2 the LDS fragment reads, bit 3 the global operand loads -- what each phase costs in situ and how much of it overlaps
 // FAST: every problem of the group has a window WITHOUT padding (every (row, tap) inside the tensor: nt_fast_ok below), operands addressable
@@ -72,10 +70,8 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
 // SGPR base, the tap / segment walk is one compare-and-select per thread and slab, and only the K tail slab selects zeros.  The generic
 // loop spends ~110 of its 284 vector instructions per slab on exactly that (ISA count, 128 x 96 tile) and is vector-issue bound next to its
 // 72 MFMAs (tools/nt_ablate.py: every 160 vector instructions removed = 30 us of the 182 us launch).
-template <int TM, int TN, int SPLITS, int DB, int RING = 1, int OCC = 1, bool BPL = false, int ABL = 0, bool FAST = false>
+template <int TM, int TN, int SPLITS, int DB, int RING = 1, int OCC = 1, int ABL = 0, bool FAST = false>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g) {
-    static_assert(!BPL || (SPLITS == 3 && RING == 1), "pre-split weights: the bf16 x 3 arithmetic, one slab of loads in flight");
-    static_assert(!FAST || !BPL, "fast addressing: fp32 operands");
     const int pi = group_find(g, blockIdx.x);
     const NtProb& pr = g.p[pi];
     const Win A = pr.A;
@@ -137,22 +133,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
         b_ptr[q] = Bw + (long)(b_ok[q] ? n : (FAST ? N - 1 : 0)) * ldb;
         b_base[q] = (unsigned)((long)(b_ok[q] ? n : N - 1) * ldb * 4);
     }
-    // pre-split weights: thread t owns 16-byte slot (t & 3) of weight rows (t >> 2) + 64 h of every plane (gemm_planes.hip staging map)
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    constexpr int GBF = BN / 64, GBN = GBF + ((BN % 64) ? 1 : 0);
-    const bool bp_half_on = t < 128;
-    int bp_off[GBN > 0 ? GBN : 1], bp_dst[GBN > 0 ? GBN : 1];
-    u32x4_t gbp[3][GBN > 0 ? GBN : 1];
-    if constexpr (BPL) {
-#pragma unroll
-        for (int h = 0; h < GBN; ++h) {
-            const int row = (h < GBF || bp_half_on) ? (t >> 2) + 64 * h : (t >> 2);
-            int n = n0 + row;
-            n = n < N ? n : N - 1;                          // columns past N: any valid row (the epilogue drops them)
-            bp_off[h] = n * pr.Kp + 8 * (t & 3);
-            bp_dst[h] = (BM + row) * SP_LD + ((8 * (t & 3)) ^ sp_swz(row));
-        }
-    }
     int kk = sp / A.cw, c = sp - (sp / A.cw) * A.cw;          // tap / channel of this thread's piece, advanced by 32 per slab
     int bsg = sp / b_seg_k, bc = sp - (sp / b_seg_k) * b_seg_k;   // weight segment / column inside it, likewise
     // FAST: byte offset of this thread's piece inside its row (tap walk folded in), and what a tap / segment wrap adds to it
@@ -194,19 +174,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
             else ga[set][q] = *reinterpret_cast<const f32x4*>(ok ? A.ptr + a_off[q] + (long)sr * A.rs + c : A.ptr);
             ma |= ok ? (1u << q) : 0u;
         }
-        if constexpr (BPL) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int h = 0; h < GBN; ++h) gbp[s][h] = *reinterpret_cast<const u32x4_t*>(pr.Bpl + s * pr.bpl_plane + k0 + bp_off[h]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < NPB; ++q) {
-                const bool ok = b_ok[q] && inb;
-                if constexpr (ABL & 8) gb[set][q] = f32x4{.5f + lane, .25f, .125f + k0, 1.f};
-                else gb[set][q] = *reinterpret_cast<const f32x4*>(ok ? b_ptr[q] + bsg * b_seg_stride + bc : Bw);
-                mb |= ok ? (1u << q) : 0u;
-            }
+        for (int q = 0; q < NPB; ++q) {
+            const bool ok = b_ok[q] && inb;
+            if constexpr (ABL & 8) gb[set][q] = f32x4{.5f + lane, .25f, .125f + k0, 1.f};
+            else gb[set][q] = *reinterpret_cast<const f32x4*>(ok ? b_ptr[q] + bsg * b_seg_stride + bc : Bw);
+            mb |= ok ? (1u << q) : 0u;
         }
         ga_ok[set] = ma; gb_ok[set] = mb;
         c += 32;
@@ -242,32 +215,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
 #pragma unroll
             for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][sr0 + 32 * q][sp_w]) = o[s];
         }
-        if constexpr (BPL) {
-            __bf16* const lb = &lds[buf][0][0][0];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
+        for (int q = 0; q < NPB; ++q) {
+            u32x2 o[NS];
+            if constexpr (ABL & 2) {
 #pragma unroll
-                for (int h = 0; h < GBF; ++h) *reinterpret_cast<u32x4_t*>(lb + s * (BM + BN) * SP_LD + bp_dst[h]) = gbp[s][h];
-            }
-            if constexpr (GBN > GBF) {
-                if (bp_half_on) {
+                for (int s = 0; s < NS; ++s) o[s] = u32x2{__float_as_uint(gb[set][q][1]), __float_as_uint(gb[set][q][3])};
+            } else if constexpr (!MASKED) split4<SPLITS>(gb[set][q], o);
+            else
+            split4<SPLITS>((gb_ok[set] >> q) & 1u ? gb[set][q] : f32x4{0.f, 0.f, 0.f, 0.f}, o);
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4_t*>(lb + s * (BM + BN) * SP_LD + bp_dst[GBN - 1]) = gbp[s][GBN - 1];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < NPB; ++q) {
-                u32x2 o[NS];
-                if constexpr (ABL & 2) {
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) o[s] = u32x2{__float_as_uint(gb[set][q][1]), __float_as_uint(gb[set][q][3])};
-                } else if constexpr (!MASKED) split4<SPLITS>(gb[set][q], o);
-                else
-                split4<SPLITS>((gb_ok[set] >> q) & 1u ? gb[set][q] : f32x4{0.f, 0.f, 0.f, 0.f}, o);
-#pragma unroll
-                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][BM + sr0 + 32 * q][sp_w]) = o[s];
-            }
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&lds[buf][s][BM + sr0 + 32 * q][sp_w]) = o[s];
         }
         __syncthreads();
         if (k0 + 32 * RING < K) fetch(set_c, k0 + 32 * RING);
@@ -749,10 +707,7 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
     bool fast = fast_on != 0 && g_math_mode == 0 && ring >= 1 && ring <= 2;
     for (int i = 0; i < g.n && fast; ++i) fast = nt_fast_ok(g.p[i]);
     if (fast) {
-        for (int i = 0; i < g.n; ++i) fast = fast && g.p[i].Bpl == nullptr;
-    }
-    if (fast) {
-#define TG_FAST(TM_, TN_, DB_, R_, O_) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, 3, DB_, R_, O_, false, 0, true>), grid, dim3(256), 0, s, g)
+#define TG_FAST(TM_, TN_, DB_, R_, O_) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, 3, DB_, R_, O_, 0, true>), grid, dim3(256), 0, s, g)
         if (tl.tm == 4 && tl.tn == 3) { if (ring == 2) TG_FAST(4, 3, 0, 2, 3); else TG_FAST(4, 3, 0, 1, 3); }
         else if (tl.tm == 4 && tl.tn == 2) { if (ring == 2) TG_FAST(4, 2, 0, 2, 4); else TG_FAST(4, 2, 0, 1, 4); }
         else if (tl.tm == 2 && tl.tn == 3) { if (ring == 2) TG_FAST(2, 3, 1, 2, 1); else TG_FAST(2, 3, 1, 1, 1); }
@@ -765,16 +720,12 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
         const char* e = getenv("TG_NT_ABL");
         const int abl = e ? atoi(e) : 0;
         if (abl && tl.tm == 4 && tl.tn == 3 && g_math_mode == 0) {
-#define TG_ABL(A_) case A_: hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 3, 0, 1, 3, false, A_>), grid, dim3(256), 0, s, g); return check_launch("tg_gemm_nt(split, ablated)")
+#define TG_ABL(A_) case A_: hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 3, 0, 1, 3, A_>), grid, dim3(256), 0, s, g); return check_launch("tg_gemm_nt(split, ablated)")
             switch (abl) { TG_ABL(1); TG_ABL(2); TG_ABL(3); TG_ABL(4); TG_ABL(5); TG_ABL(7); TG_ABL(8); TG_ABL(9); TG_ABL(11); TG_ABL(15); default: break; }
 #undef TG_ABL
         }
     }
 #endif
-    bool planes = g_math_mode == 0 && ring != 2;
-    for (int i = 0; i < g.n; ++i) planes = planes && g.p[i].Bpl != nullptr;
-    if (planes && tl.tm == 4 && tl.tn == 3) { hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 3, 0, 1, 3, true>), grid, dim3(256), 0, s, g); return check_launch("tg_gemm_nt(split, weight planes)"); }
-    if (planes && tl.tm == 4 && tl.tn == 2) { hipLaunchKernelGGL((gemm_nt_split_kernel<4, 2, 3, 0, 1, 4, true>), grid, dim3(256), 0, s, g); return check_launch("tg_gemm_nt(split, weight planes)"); }
     if (g_math_mode == 1) TG_SPLIT_MENU(1);
     else TG_SPLIT_MENU(3);
 #undef TG_SPLIT_MENU

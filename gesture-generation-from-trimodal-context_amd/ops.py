@@ -80,7 +80,7 @@ class Win:
 
 
 def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, M=None,
-                b_seg=None, out_scale=None, w_planes=None, gate=None, res=None, out2=None, res_slope=0.0):
+                b_seg=None, out_scale=None, gate=None, res=None, out2=None, res_slope=0.0):
     """Checked tg_gemm_nt_problem.  b_seg = (seg_k, seg_stride_floats): K-concatenated weights, W is the first [N, seg_k] segment and
     segment s starts seg_stride_floats * s floats after it (the caller keeps every segment alive).
     Epilogue extensions (big-product path only, nt_ext_supported): gate -- keep the result where gate > 0, zero elsewhere; res + out2 --
@@ -121,9 +121,6 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
         q.gate = gate.data_ptr()
     if res is not None:
         q.res, q.C2, q.res_slope = res.data_ptr(), out2.data_ptr(), float(res_slope)
-    if w_planes is not None:                   # Planes of W (split3_planes / layers.weight_planes): the big-product kernels skip the weight split
-        assert b_seg is None and w_planes.rows == N and w_planes.cw == A.K and w_planes.t.is_cuda, (w_planes.rows, N, w_planes.cw, A.K)
-        q.b_planes, q.b_plane_stride, q.b_kp = w_planes.t.data_ptr(), w_planes.plane_stride, w_planes.cwp
     return q
 
 
@@ -179,17 +176,17 @@ def gemm_nt_group(problems):
 
 # ------------------------------------------------------------------------------------------------- pre-split (bf16 x 3 planes) operands
 # csrc/gemm_planes.hip: the fp32-accurate bf16 x 3 product with both operands split ONCE into hi / mid / lo planes instead of by every tile
-# that stages them.  Opt-in (TG_GEMM_PLANES=1): measured on the GRU input projection (2 x [13056 x 900 x 600]) it removes the split
-# arithmetic (4.8 -> 1.9 vector instructions per MFMA) but moves 6 instead of 4 bytes per operand element from L2 to the CUs (25.4 M
-# against 14.7 M 64-byte requests per launch, profiles/r2_r_pmc_planes.txt) and ends up level with the split-while-staging kernel
-# (175 + 13 us for the split pass against 168 us inside the captured iteration).
-GEMM_PLANES = os.environ.get("TG_GEMM_PLANES", "0") != "0"
-# hybrid: only the WEIGHT operand pre-split (planes refreshed once per optimiser step), the activation still split while staged
-NT_WEIGHT_PLANES = os.environ.get("TG_NT_WEIGHT_PLANES", "0") != "0"
+# that stages them: weights once per optimiser step (layers.WeightPrep), activations by one pass (split3_planes).  On the many-row products
+# of the stacked forward the planes are consumed by persistent workgroups whose mover waves fetch them global -> LDS by DMA while the
+# matrix waves multiply (no split arithmetic competing with the MFMAs for the SIMDs' issue ports).  TG_GEMM_PLANES=0: fp32 operands, split
+# while staged (gemm_mw.hip / gemm_split.hip).
+GEMM_PLANES = os.environ.get("TG_GEMM_PLANES", "1") != "0"
 
 
 class Planes:
-    """bf16 x 3 planes of an fp32 matrix [rows][cw]: tensor [3][rows + 1][cwp] bf16 (cwp = cw rounded up to 32; row `rows` is zero)."""
+    """bf16 x 3 planes of an fp32 matrix [rows][cw]: 3 x (rows + 1) x cwp bf16 (cwp = cw rounded up to 32), each plane slab-tiled
+    [cwp / 32][rows + 1][32] with an all-zero row `rows` in every slab (include/trimodal_hip.h).  `t` is that memory as a flat-ish
+    [3][rows + 1][cwp] tensor: index it through element_view(), never as a row-major matrix."""
     __slots__ = ("t", "rows", "cw", "cwp")
 
     def __init__(self, t, rows, cw, cwp):
@@ -198,6 +195,10 @@ class Planes:
     @property
     def plane_stride(self):
         return (self.rows + 1) * self.cwp
+
+    def element_view(self):
+        """[3][rows + 1][cwp] view in matrix order (a permuted view of the tiled memory, for tests)."""
+        return self.t.view(3, self.cwp // 32, self.rows + 1, 32).permute(0, 2, 1, 3).reshape(3, self.rows + 1, self.cwp)
 
 
 def planes_cwp(cw):
@@ -219,7 +220,8 @@ def split3_planes(x2d, out=None):
 
 def _np_problem(A: Planes, Bp: Planes, bias, out, *, taps=1, batches=1, batch_rows=0, rows_in=None, rows_out=None, row_step=1, shift=0, dil=1,
                 act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, out_scale=None):
-    """Checked tg_gemm_nt_planes_problem.  A: activation planes (window over its rows), Bp: weight planes of [N * taps rows][cw]."""
+    """Checked tg_gemm_nt_planes_problem.  A: activation planes (window over its rows), Bp: weight planes of the [taps * N rows][cw] matrix with
+    row = tap * N + n (for a Conv1d weight (Co, Ci, kw): split3_planes(w.permute(2, 0, 1).reshape(kw * Co, Ci)))."""
     _f32(out, "out")
     assert A.cwp == Bp.cwp and A.cw == Bp.cw and Bp.rows % taps == 0, (A.cw, Bp.cw, Bp.rows, taps)
     N = Bp.rows // taps

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 2
+#define TG_ABI_VERSION 3
 
 int tg_version(void);
 const char* tg_last_error(void);
@@ -87,9 +87,9 @@ typedef struct tg_gemm_nt_problem {
     int32_t accumulate;
     const float* out_scale;    /* NULL, or an element-wise multiplier applied after the activation, addressed like C: the inverted-dropout
                                   scale mask of F.dropout(relu(conv(x))) (model/tcn.py:22-29) rides in the epilogue */
-    const void* b_planes;      /* NULL, or the bf16 x 3 planes of Bw ([3][N + 1][b_kp] bf16 as written by tg_split3_planes, b_kp = K rounded up */
-    int64_t b_plane_stride;    /*   to 32, planes b_plane_stride elements apart): the big-product kernels then stage the weight operand */
-    int32_t b_kp, reserved2;   /*   without splitting it (one weight matrix only: b_seg_k == 0) */
+    const void* reserved_ptr;  /* must be NULL / 0 (ABI 2 carried optional pre-split weight planes here; pre-split operands now go through */
+    int64_t reserved_i64;      /*   tg_gemm_nt_planes_group, both operands) */
+    int32_t reserved_i32, reserved2;
     /* Epilogue extensions (big-product path only, tg_gemm_nt_ext_supported): what the reference computes right after the product in
      * model/tcn.py:27-45 without another pass over the tensor.  All three are addressed like C.
      *   gate : the result (after act / out_scale) is kept where gate > 0 and zeroed elsewhere -- ReLU backward through the tensor the
@@ -125,8 +125,11 @@ int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bi
 
 /* ---- tg_gemm_nt on pre-split operands (csrc/gemm_planes.hip): same products and epilogue as tg_gemm_nt, fp32-accurate on the bf16
  * matrix cores, but both operands arrive as three bf16 planes (x = hi + mid + lo exactly) so the main loop does no split arithmetic.
- * Plane buffer of an fp32 matrix [rows][cw]: [3][rows + 1][cwp] bf16 (cwp = cw rounded up to a multiple of 32, zero columns; row `rows`
- * all zero), planes `plane_stride` ELEMENTS apart.  tg_split3_planes writes one from fp32. */
+ * Plane buffer of an fp32 matrix [rows][cw]: three bf16 planes `plane_stride` ELEMENTS apart, each SLAB-TILED: [cwp / 32][rows + 1][32]
+ * (cwp = cw rounded up to a multiple of 32; element (r, c) at ((c / 32) * (rows + 1) + r) * 32 + c % 32; zero past cw and in row `rows`
+ * of every slab), so that one 32-deep K slab of 16 consecutive rows is 1 KB of contiguous memory.  tg_split3_planes writes one from fp32.
+ * With many rows and tiles that fill the chip the product runs on persistent 512-thread workgroups whose mover waves bring both
+ * operands global -> LDS by DMA while the matrix waves multiply (gemm_np_mw_kernel); otherwise on the 256-thread staged kernel. */
 int tg_split3_planes(const float* x, int64_t ldx, int32_t rows, int32_t cw, void* planes, int32_t cwp, int64_t plane_stride, void* stream);
 typedef struct tg_gemm_nt_planes_problem {
     const void* A;             /* planes of the activation buffer, a_rows (+ the zero row) rows of cwp channels */
@@ -135,7 +138,7 @@ typedef struct tg_gemm_nt_planes_problem {
     int64_t a_batch_rows;      /* row window as in tg_window, in ROWS of the buffer: output row m = (batch b, r) reads source rows */
     int32_t rows_in, rows_out; /*   b * a_batch_rows + r * row_step + shift + tap * dil, tap = 0 .. taps - 1 (zero outside [0, rows_in)) */
     int32_t row_step, shift, dil, taps;
-    const void* B;             /* planes of the weights [3][N][taps][cwp] (tg_split3_planes over the N * taps rows of cw of a packed weight) */
+    const void* B;             /* planes of the weights as a [taps * N rows][cw] matrix, row = tap * N + n (tg_split3_planes over w.permute(kw, Co, Ci)) */
     int64_t b_plane_stride;
     const float* bias;
     float* C;

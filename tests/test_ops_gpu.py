@@ -871,16 +871,22 @@ def test_wav_front_conv_bn_lrelu_fused(pkg, dev, B, L, stride, pad, groups):
 
 # ------------------------------------------------------------------------------------------------ pre-split (bf16 x 3 planes) GEMM
 def test_split3_planes_are_exact(pkg, dev):
-    """hi + mid + lo == x bit for bit, every term a bf16; padding columns and the extra row are zero."""
+    """hi + mid + lo == x bit for bit, every term a bf16; padding columns and the extra row are zero; the memory is slab-tiled
+    ([cwp / 32][rows + 1][32] per plane: include/trimodal_hip.h)."""
     ops = pkg.ops
     x = (rnd(37, 108, seed=51) * torch.logspace(-6, 6, 108)).to(dev)
     pl = ops.split3_planes(x)
-    assert pl.cwp == 128 and tuple(pl.t.shape) == (3, 38, 128)
-    s = pl.t[0].double() + pl.t[1].double() + pl.t[2].double()
+    assert pl.cwp == 128 and pl.t.numel() == 3 * 38 * 128
+    ev = pl.element_view()                                                 # [3][rows + 1][cwp] in matrix order
+    s = ev[0].double() + ev[1].double() + ev[2].double()
     assert torch.equal(s[:37, :108].float(), x) and float(s[:37, 108:].abs().max()) == 0 and float(s[37].abs().max()) == 0
+    # the layout itself: slab 2 (columns 64..95) of row 5 sits at ((2 * 38 + 5) * 32) elements into the plane
+    raw = pl.t.view(3, -1)
+    assert torch.equal(raw[0, (2 * 38 + 5) * 32:(2 * 38 + 5) * 32 + 32].double() + raw[1, (2 * 38 + 5) * 32:(2 * 38 + 5) * 32 + 32].double()
+                       + raw[2, (2 * 38 + 5) * 32:(2 * 38 + 5) * 32 + 32].double(), x[5, 64:96].double())
     xs = torch.zeros(50, 200, device=dev); xs[:, 3:111] = rnd(50, 108, seed=52).to(dev)
-    pv = ops.split3_planes(xs[:, 3:111])                                   # unaligned strided view: scalar path
-    assert torch.equal((pv.t[0].double() + pv.t[1].double() + pv.t[2].double())[:50, :108].float(), xs[:, 3:111])
+    pv = ops.split3_planes(xs[:, 3:111]).element_view()                    # unaligned strided view: scalar path
+    assert torch.equal((pv[0].double() + pv[1].double() + pv[2].double())[:50, :108].float(), xs[:, 3:111])
 
 
 @pytest.mark.parametrize("M,N,K", [(13056, 900, 600), (4352, 300, 108), (1030, 52, 70), (2048, 96, 32)])
@@ -903,20 +909,6 @@ def test_gemm_nt_planes_is_fp32_accurate(pkg, dev, M, N, K):
     assert rel(out[0], ref2) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(13056, 900, 600), (13056, 900, 108), (13056, 300, 600), (2100, 130, 70)])
-def test_gemm_nt_split_with_presplit_weights_is_bit_identical(pkg, dev, M, N, K):
-    """Hybrid staging (weight operand from bf16 x 3 planes, activation split while staged): the planes hold exactly the terms the kernel would
-    have computed, so the result is bit for bit that of the plain call (128 x 96 and 128 x 64 tiles; other tiles ignore the planes)."""
-    ops, Win = pkg.ops, pkg.ops.Win
-    x = (rnd(M, K, seed=61) * torch.logspace(-3, 3, K)).to(dev)
-    w, b = (rnd(N, K, seed=62, scale=0.1)).to(dev), rnd(N, seed=63).to(dev)
-    o0, o1 = torch.empty(M, N, device=dev), torch.full((M, N), float("nan"), device=dev)
-    ops.gemm_nt(Win.plain(x), w, b, o0, act_slope=0.3)
-    ops.gemm_nt(Win.plain(x), w, b, o1, act_slope=0.3, w_planes=ops.split3_planes(w))
-    assert torch.equal(o0, o1)
-    assert rel(o0, F.leaky_relu(x.double().cpu() @ w.double().cpu().t() + b.double().cpu(), 0.3)) < 1e-5
-
-
 def test_gemm_nt_planes_conv_window(pkg, dev):
     """Dilated causal conv (model/tcn.py) as a two-tap row window over the plane buffer: rows before the sequence start read the zero row."""
     ops = pkg.ops
@@ -927,12 +919,47 @@ def test_gemm_nt_planes_conv_window(pkg, dev):
     ref = F.conv1d(x.double(), w.double(), bias.double(), padding=d, dilation=d)[:, :, :T]          # Chomp1d
     xcl = cl(x).to(dev)                                                                              # (B, T, Ci)
     a_pl = ops.split3_planes(xcl.view(B * T, Ci))
-    wp = w.permute(0, 2, 1).contiguous().to(dev)                                                     # [Co][tap][Ci]: tap-major packed weight
-    b_pl = ops.split3_planes(wp.view(Co * 2, Ci))
+    wp = w.permute(2, 0, 1).contiguous().to(dev)                                                     # [tap][Co][Ci]: row = tap * Co + n
+    b_pl = ops.split3_planes(wp.view(2 * Co, Ci))
     out = torch.empty(B * T, Co, device=dev)
     ops.gemm_nt_planes_group([dict(A=a_pl, Bp=b_pl, bias=bias.to(dev), out=out, taps=2, batches=B, batch_rows=T, rows_in=T, rows_out=T,
                                    shift=-d, dil=d)])
     assert rel(out.view(B, T, Co), cl(ref)) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(13000, 900, 600), (13056, 900, 108), (13056, 300, 600)])
+def test_gemm_nt_planes_mover_wave_dma_kernel(pkg, dev, M, N, K):
+    """The pre-split product at the stacked forward's sizes runs on gemm_np_mw_kernel (csrc/gemm_planes.hip: persistent 512-thread
+    workgroups, both operands by LDS-DMA into a double-buffered image, matrix waves that only read fragments and multiply): two-problem
+    groups (both GRU directions, multimodal_context_net.py:98-99), ragged M / N / K, 8-decade operands against fp64, then the conv-window
+    form at B_s = 384 (rows before the clip read the plane buffer's zero row)."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * torch.pow(10.0, torch.randint(-4, 4, (M, 1), generator=g).float())).to(dev)
+    w = [(torch.randn(N, K, generator=g) * 0.1).to(dev) for _ in range(2)]
+    b = [torch.randn(N, generator=g).to(dev) for _ in range(2)]
+    a_pl = ops.split3_planes(x)
+    out = torch.full((2, M, N), float("nan"), device=dev)
+    ops.gemm_nt_planes_group([dict(A=a_pl, Bp=ops.split3_planes(w[i]), bias=b[i], out=out[i], act_slope=0.3) for i in range(2)])
+    for i in range(2):
+        ref = F.leaky_relu(x.double().cpu() @ w[i].double().cpu().t() + b[i].double().cpu(), 0.3)
+        assert _row_err(out[i], ref) < 1e-5
+    mask = (torch.rand(M, N, generator=g) > 0.3).float().to(dev) * 1.25
+    base = out[0].clone()
+    ops.gemm_nt_planes_group([dict(A=a_pl, Bp=ops.split3_planes(w[1]), bias=None, out=out[0], accumulate=True, out_scale=mask)])
+    ref2 = base.double().cpu() + (x.double().cpu() @ w[1].double().cpu().t()) * mask.double().cpu()
+    assert _row_err(out[0], ref2) < 1e-5
+    if K == 600 and N == 300:
+        B, T, Ci, Co, d = 384, 34, 300, 300, 8
+        xc = torch.randn(B, Ci, T, generator=g)
+        wc = torch.randn(Co, Ci, 2, generator=g) * 0.05
+        bias = torch.randn(Co, generator=g)
+        ref = F.conv1d(xc.double(), wc.double(), bias.double(), padding=d, dilation=d)[:, :, :T]
+        xcl = cl(xc).to(dev)
+        o = torch.full((B * T, Co), float("nan"), device=dev)
+        ops.gemm_nt_planes_group([dict(A=ops.split3_planes(xcl.view(B * T, Ci)), Bp=ops.split3_planes(wc.permute(2, 0, 1).contiguous().to(dev).view(2 * Co, Ci)),
+                                       bias=bias.to(dev), out=o, taps=2, batches=B, batch_rows=T, rows_in=T, rows_out=T, shift=-d, dil=d)])
+        assert rel(o.view(B, T, Co), cl(ref)) < 1e-5
 
 
 @pytest.mark.parametrize("B,T1", [(3, 217), (5, 1313), (2, 7891)])
