@@ -149,6 +149,75 @@ def time_kernel(fn, iters=50, warm=5):
 PEAK_HBM = 8.0e12                  # /opt/skills/guides/MI355X_MICROARCH.md, "HBM3E peak BW" (spec; 6.29 TB/s measured for a float4 copy)
 
 
+def decode_kernel_roofline(pkg, device, batch):
+    """Dominant kernel of the eval forward (one per GRU layer, 4 per window): the persistent cluster GRU recurrence at B = utterances per GPU
+    (no stacking, nothing saved).  Same accounting as the training line's roofline."""
+    ops = pkg.ops
+    H = 300
+    gi = torch.randn(2, batch, T, 3 * H, device=device) * 0.1
+    w = [torch.randn(3 * H, H, device=device) * 0.05 for _ in range(2)]
+    b = [torch.randn(3 * H, device=device) * 0.05 for _ in range(2)]
+    y = torch.empty(batch, T, 2 * H, device=device)
+    dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, None), iters=20)
+    ops.check_async_errors()
+    flops = (T - 1) * 2 * batch * H * 3 * H * 2
+    return {"kernel": "gru_seq_fwd_cluster_x3_kernel (eval, B = utterances)", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": None, "launch_us": dt * 1e6, "flop_per_launch": flops,
+            "us_per_step": dt * 1e6 / T, "note": "latency-bound per-step hand-off chain of the recurrence; fp32-accurate product on the bf16 matrix cores"}
+
+
+def cpu_baseline_decode(batch, budget_s=15.0, max_windows=8):
+    """The oracle's eval forward (CPU port of multimodal_context_net.py:110-160, ATen fp32 kernels) on `batch` windows at a time."""
+    from oracle import ref_model as O
+    O.FAST = True
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
+    gst = O.make_generator_state(0, V, S)
+    g = torch.Generator().manual_seed(6)
+    text = torch.zeros(batch, T, dtype=torch.int64)
+    text[:, ::5] = torch.randint(4, V, (batch, len(range(0, T, 5))), generator=g)
+    audio = 0.1 * torch.randn(batch, A, generator=g)
+    pre = torch.zeros(batch, T, D + 1)
+    vid = torch.randint(1, S, (batch,), generator=g)
+    with torch.no_grad():
+        O.generator_forward(gst, pre, text, audio, vid, training=False, rand=O.Rand(seed=1), fast_gru=True)
+        t0 = time.perf_counter()
+        n = 0
+        while n < max_windows and (n == 0 or time.perf_counter() - t0 < budget_s):
+            O.generator_forward(gst, pre, text, audio, vid, training=False, rand=O.Rand(seed=2 + n), fast_gru=True)
+            n += 1
+    dt = (time.perf_counter() - t0) / n
+    O.FAST = False
+    return {"value": batch * T / dt, "unit": "pose-frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} window steps of {batch} utterances (eval forward only) after 1 warm-up, fp32 ATen kernels, {dt:.2f} s per step"}
+
+
+def cpu_baseline_ae(batch, budget_s=10.0, max_steps=20):
+    """The oracle's autoencoder training iteration (CPU port of train_feature_extractor.py:54-97) at the same batch."""
+    from oracle import ref_model as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
+    st, opt = O.make_autoencoder_state(2), {}
+    poses = 0.1 * torch.randn(batch, T, D, generator=torch.Generator().manual_seed(7))
+    O.ae_train_iter(st, opt, poses)
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_steps and (n == 0 or time.perf_counter() - t0 < budget_s):
+        O.ae_train_iter(st, opt, poses)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": batch / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{n} training iterations at batch {batch} after 1 warm-up, fp32 ATen kernels, {dt * 1e3:.1f} ms per iteration"}
+
+
 def dominant_kernel_roofline(pkg, device, batch):
     """The single kernel with the largest share of the iteration (profiles/r2_*_by_shape.txt): the persistent cluster-synchronised GRU
     recurrence of the generator's stacked forward, gru_seq_fwd_cluster_x3_kernel<2> at B = 3*batch, H = 300, T = 34 -- one launch per
@@ -260,7 +329,11 @@ def decode_bench(pkg, a, args, G, device, world, rank):
     line = None
     if rank == 0:
         fps = world * a.batch * T * a.steps / dt
+        extra = {"roofline": decode_kernel_roofline(pkg, device, a.batch)}
+        if world == 1 and not a.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_baseline_decode(a.batch)
         line = (json.dumps({
+            **extra,
             "metric": "inference pose-frames/sec (batched 34-frame synthesis windows)", "value": fps, "unit": "pose-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -314,7 +387,11 @@ def ae_bench(pkg, a, args, device, world, rank):
     assert lv == lv and lv < 1e6
     line = None
     if rank == 0:
+        extra = {}
+        if world == 1 and not a.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_baseline_ae(a.batch)
         line = (json.dumps({
+            **extra,
             "metric": "FGD autoencoder training clips/sec", "value": world * a.batch * a.steps / dt, "unit": "clips/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -341,6 +418,7 @@ def main():
     ap.add_argument("--host-input", action="store_true",
                     help="feed every iteration from host memory through data.DeviceBatchFeeder (PCIe-inclusive rate for DESIGN.md; "
                          "never the headline value)")
+    ap.add_argument("--no-feed-overlap", action="store_true", help="--host-input: copy straight into the step's inputs on the compute stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path (graph segments + RCCL) even with one rank")
     a = ap.parse_args()
@@ -401,7 +479,7 @@ def main():
     if a.host_input:
         assert not a.no_graph, "--host-input drives the captured step"
         data = importlib.import_module(PKG + ".data")
-        feeder = data.DeviceBatchFeeder(*step.static)
+        feeder = data.DeviceBatchFeeder(*step.static, static_flat=step.static_flat, overlap=not a.no_feed_overlap)
         pool = [tuple(t.cpu() for t in synthetic_batch(a.batch, 4321 + 17 * i + rank, device)) for i in range(4)]
         pool = [(t, p_, au, v) for (t, au, p_, v) in pool]          # feeder.put(text, vec, audio, vid)
         feeder.put(*pool[0])

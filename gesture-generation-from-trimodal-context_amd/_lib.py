@@ -24,7 +24,7 @@ class NtProblem(C.Structure):
     """struct tg_gemm_nt_problem"""
     _fields_ = [("A", Window), ("Bw", P), ("ldb", I64), ("b_seg_k", I32), ("reserved", I32), ("b_seg_stride", I64), ("bias", P), ("C", P),
                 ("c_batch_stride", I64), ("c_row_stride", I64), ("c_rows_out", I32), ("M", I32), ("N", I32), ("act_slope", F32),
-                ("accumulate", I32), ("out_scale", P), ("reserved_ptr", P), ("reserved_i64", I64), ("reserved_i32", I32), ("reserved2", I32),
+                ("accumulate", I32), ("out_scale", P), ("b_planes", P), ("b_plane_stride", I64), ("b_rows", I32), ("b_row0", I32),
                 ("gate", P), ("res", P), ("C2", P), ("res_slope", F32), ("reserved3", I32)]
 
 
@@ -144,6 +144,8 @@ def load():
     lib.tg_gemm_nt_ext_supported.argtypes = [C.POINTER(NtProblem)]
     lib.tg_gemm_nt_kernel_plan.restype = C.c_int32
     lib.tg_gemm_nt_kernel_plan.argtypes = [C.POINTER(NtProblem), I32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.tg_gemm_tn_kernel_plan.restype = C.c_int32
+    lib.tg_gemm_tn_kernel_plan.argtypes = [C.POINTER(TnProblem), I32]
     lib.tg_bn_fused_supported.restype = C.c_int32
     lib.tg_bn_fused_supported.argtypes = [I32, I32, I32]
     lib.tg_set_math_mode.restype = C.c_int

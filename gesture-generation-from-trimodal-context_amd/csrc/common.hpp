@@ -88,6 +88,9 @@ struct NtProb {
     float* C2;
     float res_slope;
     unsigned a_bytes, b_bytes;   // byte extents of the A tensor / the weights from their base pointers (gemm_mw.hip buffer descriptors; filled by its launcher)
+    const __bf16* Bpl;           // optional pre-split weights: plane 0 of a slab-tiled plane buffer (plane_tiled_off) that holds Bw's N rows of K columns
+    long bpl_plane;              //   from buffer row b_row0 on; planes bpl_plane elements apart; b_slab_rows = rows of the buffer + 1 (its zero row last)
+    int b_slab_rows, b_row0;
 };
 
 struct NtGroup {
@@ -106,6 +109,7 @@ struct TnProb {
     float* partial;
     float* dbias;
     int vec_y, vec_a, n_nt, n_kt;
+    unsigned a_bytes, y_bytes;   // byte extents of the A tensor / dY from their base pointers (gemm_tn_mw.hip buffer descriptors; filled by its planner)
 };
 
 struct TnGroup {

@@ -657,6 +657,8 @@ using namespace tg;
 extern "C" int tg_get_math_mode(void);
 int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s);
 int tg_gemm_tn_split_launch(const TnGroup& g, int total_wgs, int tnw, int tkw, hipStream_t s);
+bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid);
+int tg_gemm_tn_mw_launch(const TnGroup& g, int grid, hipStream_t s);
 static bool use_split_path() {
     static int x3 = -1;
     if (x3 < 0) {
@@ -763,8 +765,15 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
     p.bias = q.bias; p.mul = q.out_scale; p.C = q.C; p.cbs = (long)q.c_batch_stride; p.crs = (long)q.c_row_stride; p.cR = q.c_rows_out;
     p.M = q.M; p.N = q.N; p.slope = q.act_slope; p.accumulate = q.accumulate; p.n_nt = 0;
     p.a_bytes = p.b_bytes = 0;
-    TG_REQUIRE(q.reserved_ptr == nullptr && q.reserved_i64 == 0 && q.reserved_i32 == 0,
-               "tg_gemm_nt: reserved fields must be zero (problem %d): pre-split weights go through tg_gemm_nt_planes_group", idx);
+    p.Bpl = nullptr; p.bpl_plane = 0; p.b_slab_rows = 0; p.b_row0 = 0;
+    if (q.b_planes) {
+        const int64_t kp = ((int64_t)q.A.K + 31) / 32 * 32;
+        TG_REQUIRE(q.b_seg_k == 0 && q.b_rows >= q.N && q.b_row0 >= 0 && q.b_row0 + (int64_t)q.N <= q.b_rows && aligned16(q.b_planes) &&
+                       q.b_plane_stride >= ((int64_t)q.b_rows + 1) * kp && q.b_plane_stride % 8 == 0 && ((int64_t)q.b_rows + 1) * kp < (1LL << 30),
+                   "tg_gemm_nt: bad weight planes (problem %d): one weight matrix, its N=%d rows inside the buffer's %d, plane stride >= (rows + 1) * K "
+                   "rounded up to 32, 16-byte aligned", idx, q.N, q.b_rows);
+        p.Bpl = reinterpret_cast<const __bf16*>(q.b_planes); p.bpl_plane = (long)q.b_plane_stride; p.b_slab_rows = q.b_rows + 1; p.b_row0 = q.b_row0;
+    }
     TG_REQUIRE((q.res == nullptr) == (q.C2 == nullptr), "tg_gemm_nt: res and C2 go together (problem %d)", idx);
     p.gate = q.gate; p.res = q.res; p.C2 = q.C2; p.res_slope = q.res_slope;
     p.vec_c = (q.N % 4 == 0) && (q.c_batch_stride % 4 == 0) && (q.c_row_stride % 4 == 0) && aligned16(q.C) &&
@@ -903,7 +912,8 @@ static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int group_ti
     return 0;
 }
 
-extern "C" int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, void* stream) {
+// plan_only != nullptr: decide the kernel (0 f32-MFMA, 1 bf16 x 3 staged slabs, 2 bf16 x 3 mover waves) and return without launching
+static int tn_group_impl(const tg_gemm_tn_problem* problems, int32_t n, void* stream, int32_t* plan_only) {
     TG_REQUIRE(problems && n >= 1 && n <= TG_MAX_GROUP, "tg_gemm_tn_group: 1..%d problems", TG_MAX_GROUP);
     TnGroup g;
     g.n = n;
@@ -940,6 +950,14 @@ extern "C" int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, v
     for (int i = n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
     for (int i = n; i < TG_MAX_GROUP; ++i) g.p[i] = g.p[0];
     hipStream_t s = (hipStream_t)stream;
+    if (x3 && !two_pass) {          // big gradients whose 192 x 160 tiles fill the chip: mover-wave kernel (gemm_tn_mw.hip)
+        int grid = 0, mw_splits[TG_MAX_GROUP];
+        if (tg_gemm_tn_mw_plan(g, mw_splits, &grid)) {
+            if (plan_only) { *plan_only = 2; return 0; }
+            return tg_gemm_tn_mw_launch(g, grid, s);
+        }
+    }
+    if (plan_only) { *plan_only = x3 ? 1 : 0; return 0; }
     if (x3) {
         if (int e = tg_gemm_tn_split_launch(g, wg, tnw, tkw, s)) return e;
     } else {
@@ -951,6 +969,16 @@ extern "C" int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, v
             launch_tn_reduce(p.partial, splits[i], p.N, p.A.K, p.A.cw, p.out_kw, p.dW, p.ldw, s);
         }
     return check_launch("tg_gemm_tn");
+}
+
+extern "C" int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, void* stream) { return tn_group_impl(problems, n, stream, nullptr); }
+
+extern "C" int32_t tg_gemm_tn_kernel_plan(const tg_gemm_tn_problem* problems, int32_t n) {
+    int32_t plan = -1;
+    if (!problems || n < 1 || n > TG_MAX_GROUP) return -1;
+    for (int i = 0; i < n; ++i)
+        if (!problems[i].dY || !problems[i].dW || !problems[i].A.ptr) return -1;
+    return tn_group_impl(problems, n, nullptr, &plan) == 0 ? plan : -1;
 }
 
 extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,

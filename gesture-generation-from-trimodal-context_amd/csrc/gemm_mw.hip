@@ -3,28 +3,31 @@
 // gemm_split.hip's kernels stage a slab, barrier, multiply, barrier: their own ablation (profiles/r2_nt_ablate.txt) shows the matrix
 // section ADDING its time to the staging skeleton (182 = 111 + 71 us on [13056 x 1800 x 600]) -- every wave alternates between a
 // load / split / LDS-store phase and a 72-MFMA phase, and the three resident workgroups of a CU fall into step.  Here the two jobs
-// belong to different waves of one 512-thread workgroup (what the H = 64 recurrence's mover waves proved, gru_h64.hip):
-//   * waves 4-7 (movers, one per SIMD) own ALL global traffic of the main loop: they fetch the fp32 operand slabs two slabs ahead into
-//     two register sets, split every value exactly into its three bf16 terms and store the planes of slab s + 1 into the other half of a
-//     double-buffered LDS image while
-//   * waves 0-3 (one per SIMD) read their fragments of slab s from LDS and issue nothing but ds_read_b128 and MFMAs: 6 TM TN
-//     v_mfma_f32_16x16x32_bf16 per slab and wave (144 for the 128 x 192 tile = 2304 cycles of matrix pipe).
-// One workgroup barrier per slab.  The workgroups are PERSISTENT (one per CU, each walks tiles blockIdx, blockIdx + grid, ...): the
-// movers' slab stream runs on across tile boundaries, and the matrix waves write a finished tile straight from their accumulators
-// (product taken transposed, C^T = W . X^T, so a lane holds four consecutive output columns of one row: 16-byte stores) and start
-// the next tile while those stores drain -- the first, non-persistent form of this kernel spent 10 of every 44 us per tile outside
-// the slab loop (first-slab latency 2.5, accumulator tile through LDS 0.8, all 256 CUs writing their tiles in the same 5 us, 1.6
-// between workgroups: profiles/r3_d_mw_timeline_0.txt).  A mover shares its SIMD's issue port with one matrix wave: an MFMA holds the port for 8 of its 16
-// cycles (MI355X_MICROARCH.md, vector-instruction ISSUE cost), which leaves the mover ~2 vector instructions per MFMA -- the 128 x 192
-// tile needs ~270 per slab (10 loads, 40 values x 5.5 split instructions, 30 LDS stores) against 288 such slots.  A bigger tile is what
-// makes that fit: staging work grows with BM + BN, matrix work with BM x BN, and the L2 -> CU bytes per flop fall by 1.6 x against the
-// 128 x 96 tile.  LDS: 2 x 3 planes x (BM + BN) rows x 64 B = 120 KB (128 x 192): one workgroup per CU.
+// belong to different waves of one PERSISTENT 512-thread workgroup per CU (what the H = 64 recurrence's mover waves proved, gru_h64.hip):
+//   * waves 4-7 (movers, one per SIMD) own all operand traffic.  The ACTIVATION operand arrives as fp32: they fetch its slabs three
+//     slabs ahead into two register sets, split every value exactly into its three bf16 terms and store the planes of slab n + 1 into
+//     a double-buffered LDS image.  The WEIGHT operand arrives PRE-SPLIT (bf16 x 3 planes in the slab-tiled layout of common.hpp,
+//     written once per optimiser step by layers.WeightPrep / once per forward for the weight-normed convs): it goes global -> LDS by
+//     DMA (buffer_load_dwordx4 ... lds, 1 KB = 16 rows x 64 B per instruction, no registers, no arithmetic) into a ring of three slots,
+//     two slabs ahead.
+//   * waves 0-3 (one per SIMD) read their fragments of slab n from LDS and issue nothing but ds_read_b128 and MFMAs: 6 TM TN
+//     v_mfma_f32_16x16x32_bf16 per slab and wave (144 for the 128 x 192 tile = 2304 cycles of matrix pipe), software-pipelined by hand:
+//     the fragments of column tile j + 1 are in flight during the 24 MFMAs of column j, and the next slab's first fragments during the
+//     last column's -- the wave reaches the slab's barrier five sixths of the way through its MFMAs, the moment its last read is back.
+// One workgroup barrier per slab.  Why the weights are pre-split: with both operands fp32 the movers ran ~300 vector instructions per
+// slab on SIMDs whose issue ports the matrix waves hold half of the time, and both roles waited for each other (4 500 cycles per slab
+// against 2 304 of matrix pipe, profiles/r3_f_mw_roles.txt); the weight operand is 60 % of a 128 x 192 slab.  Why not both: all-DMA
+// operands need 58 GB/s per CU from L2 at the matrix pipe's pace, at the ceiling of what a CU takes in (profiles/r3_h_nt_mw_probe.txt:
+// 150 us against 165).
+// The matrix waves write a finished tile straight from their accumulators (product taken transposed, C^T = W . X^T, so a lane holds four
+// consecutive output columns of one row: 16-byte stores) and start the next tile while those stores drain.
 //
-// Addressing: every operand piece is a bounds-checked BUFFER load (raw_buffer_load_b128) whose voffset is either the piece's byte
-// offset or a value past num_records -- padding rows of a conv window, rows past M / N and the K tail all read as zero with no select
+// Addressing of the activation: every piece is a bounds-checked BUFFER load (raw_buffer_load_b128) whose voffset is either the piece's
+// byte offset or a value past num_records -- padding rows of a conv window, rows past M and the K tail all read as zero with no select
 // and no predicated load (static vector-memory counts), so one instantiation serves plain and padded windows.
-// Precondition (host): both operands are addressable with 31-bit byte offsets from their base pointers, pieces never straddle a tap
-// or a weight segment (cw % 4 == 0, b_seg_k % 4 == 0), C on the vectorisable layout.  Everything else stays on gemm_split.hip.
+// Weight rows past N read the plane buffer's zero row.
+// Precondition (host): the activation is addressable with 31-bit byte offsets, pieces never straddle a tap (cw % 4 == 0), ONE weight
+// matrix [N][K] with planes (no K-concatenated segments), C on the vectorisable layout.  Everything else stays on gemm_split.hip.
 #include "common.hpp"
 #include <stdlib.h>
 #include <type_traits>
@@ -37,6 +40,7 @@ namespace tg {
 
 constexpr unsigned MW_RSRC3 = 0x00020000u;
 constexpr unsigned MW_OOB = 0x80000000u;            // voffset of a piece that must read as zero (>= num_records: extents are < 2^31)
+typedef __attribute__((address_space(3))) void mw_lds_void;
 
 template <int NS>
 __device__ __forceinline__ void mw_split4(const f32x4 v, u32x2 (&out)[NS]) {
@@ -59,23 +63,44 @@ __device__ __forceinline__ void mw_split4(const f32x4 v, u32x2 (&out)[NS]) {
     }
 }
 
-
-#ifdef TG_LAB_ABLATE
-__device__ unsigned long long mw_role_cycles[512 * 4];
-#endif
-
 __device__ __forceinline__ int mw_swz(int row) { return ((row >> 3) & 1) << 4; }      // as gemm_split.hip: XOR for a bf16 column index
 
-// Workgroup tile (32 TM) x (32 TN); matrix waves 0-3 as 2 x 2, wave tile (16 TM) x (16 TN).
+// a buffer descriptor whose every input is PROVABLY wave-uniform to the compiler (cdna_hip_programming.md T20: otherwise each buffer
+// operation is wrapped in a readfirstlane / saveexec "waterfall" loop)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), MW_RSRC3);
+}
+// one DMA: 64 lanes x 16 bytes from the buffer (per-lane byte offset `voff`, uniform `soff`) to 1 KB of LDS at byte offset `lds_off` of smem
+// (the address-space cast only exists in the device pass: the host pass of this template would otherwise drop the kernel's launch stub)
+__device__ __forceinline__ void mw_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* smem, unsigned lds_off, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (mw_lds_void*)(smem + lds_off), 16, voff, soff, 0, 0);
+#endif
+}
+
+#ifdef TG_LAB_ABLATE
+__device__ unsigned long long mw_role_cycles[512 * 24];      // [workgroup][wave 0..11][waited, lifetime]
+#endif
+
+// Workgroup = 12 waves: matrix waves 0-7 as WMW x WNW (two per SIMD: ONE wave issuing back-to-back MFMAs gets ~19-21 cycles per
+// v_mfma_f32_16x16x32_bf16, two share the pipe at its 16, profiles/r2_mfma_rate.txt), wave tile (16 TM) x (16 TN); mover waves 8-11, one per SIMD.
+// Workgroup tile (16 TM WMW) x (16 TN WNW).  NS = 3: bf16 x 3; NS = 1: plain bf16 operands (the activation rounded to nearest, the weights' hi
+// plane).
 // ABL (lab builds only, -DTG_LAB_ABLATE, tools/mw_ablate.py; results are WRONG by construction): bit 0 drops the MFMAs, bit 1 the movers'
-// split arithmetic + LDS stores, bit 2 the global operand loads, bit 4 the epilogue's global traffic
-template <int TM, int TN, int NS, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm_nt_mw_kernel(const NtGroup g) {
-    constexpr int BM = 32 * TM, BN = 32 * TN, ROWS = BM + BN;
-    constexpr int PLANE = ROWS * 32;                           // bf16 elements of one plane of one slab
-    constexpr int BUF = NS * PLANE;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF * 2];
-    __bf16* const lds = reinterpret_cast<__bf16*>(smem);
+// split arithmetic + LDS stores, bit 2 the activation's global loads, bit 3 the weight DMAs, bit 4 the epilogue's global traffic
+template <int TM, int TN, int WMW, int WNW, int NS, int ABL = 0>
+__global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
+    static_assert(WMW * WNW == 8, "eight matrix waves");
+    constexpr int BM = 16 * TM * WMW, BN = 16 * TN * WNW;
+    constexpr int NPA = BM / 32;                                            // 16-byte activation pieces per mover thread and slab
+    static_assert(BM % 32 == 0 && BN % 16 == 0, "tile shape");
+    constexpr int A_PLANE = BM * 64, A_BUF = NS * A_PLANE;                // bytes
+    constexpr int B_PLANE = BN * 64, B_BUF = NS * B_PLANE;
+    constexpr int B_BASE = 2 * A_BUF;                                      // [A buffer 0 | A buffer 1 | B slot 0 | B slot 1 | B slot 2]
+    constexpr int GB = BN / 16, MAXGB = (GB + 3) / 4;                      // 16-row DMA groups of the weight tile; per mover wave
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BUF + 3 * B_BUF];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int total_tiles = g.wg_begin[TG_MAX_GROUP];         // incl. the padding ids that round every problem's range up to a multiple of 8
@@ -107,45 +132,42 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mw_kernel(const NtGroup g) {
 #else
 #define MW_TIMED_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
-#define MW_BARRIER_MOVER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); MW_TIMED_BARRIER(); asm volatile("" ::: "memory"); } while (0)
-#define MW_BARRIER_MATRIX() do { asm volatile("" ::: "memory"); MW_TIMED_BARRIER(); asm volatile("" ::: "memory"); } while (0)
     using set0 = std::integral_constant<int, 0>;
     using set1 = std::integral_constant<int, 1>;
 
-    if (wave >= 4) {
-        // ============================================================================================ movers (waves 4-7)
-        // thread mt owns the 16-byte piece (mt & 7) of slab rows (mt >> 3) + 32 q: 8 consecutive lanes cover one 128-byte row piece.
-        // The FETCH cursor (tile vb_f, slab s_f) runs three slabs ahead of the slab the matrix waves multiply.
-        const int mt = t & 255;
+    if (wave >= 8) {
+        // ============================================================================================ movers (waves 8-11)
+        const int mw = wave - 8;
+        // ---- activation: thread mt owns the 16-byte piece (mt & 7) of slab rows (mt >> 3) + 32 q: 8 consecutive lanes cover one 128-byte
+        // row piece.  Its cursor (tile vb_a, slab s_a) runs three slabs ahead of the slab the matrix waves multiply.
+        const int mt = t - 512;
         const int sp = 4 * (mt & 7), sr0 = mt >> 3;
-        const int sp_w = sp ^ mw_swz(sr0);
-        int vb_f = blockIdx.x - G, s_f = 0, nslab_f = 0;
-        bool live = true;                                      // false once the cursor has run past this workgroup's last tile
-        unsigned a_boff[TM], b_boff[TN];
-        int a_r[TM];
-        bool a_ok[TM], b_ok[TN];
-        unsigned rs4 = 0, kb = 0, kb_wrap = 0;
-        int kk = 0, c = 0, bc = 0, kcur = 0, K_f = 0, a_cw = 4, a_dil = 0, a_rows_in = 0, seg_k = 4;
-        __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.p[0].A.ptr), 0, 0, MW_RSRC3);
-        __amdgpu_buffer_rsrc_t b_rsrc = a_rsrc;
-        auto next_tile = [&]() {
+        const int sp_wb = (sp ^ mw_swz(sr0)) * 2;                              // byte offset of the piece's 8-byte slot inside its 64-byte row
+        int vb_a = blockIdx.x - G, s_a = 0, nslab_a = 0;
+        bool live_a = true;                                    // false once the cursor has run past this workgroup's last tile
+        unsigned a_boff[NPA];
+        int a_r[NPA];
+        bool a_ok[NPA];
+        unsigned rs4 = 0;
+        int kk = 0, c = 0, kcur = 0, K_a = 0, a_cw = 4, a_dil = 0, a_rows_in = 0;
+        const float* a_ptr = g.p[0].A.ptr;
+        unsigned a_bytes = 0;
+        auto next_tile_a = [&]() {
             int pi = 0, m0 = 0, n0 = 0;
             do {
-                vb_f += G;
-                if (vb_f >= total_tiles) { live = false; break; }
-            } while (!decode(vb_f, pi, m0, n0, nslab_f));
-            s_f = 0;
-            if (!live) {
+                vb_a += G;
+                if (vb_a >= total_tiles) { live_a = false; break; }
+            } while (!decode(vb_a, pi, m0, n0, nslab_a));
+            s_a = 0;
+            if (!live_a) {
 #pragma unroll
-                for (int q = 0; q < TM; ++q) a_ok[q] = false;
-#pragma unroll
-                for (int q = 0; q < TN; ++q) b_ok[q] = false;
+                for (int q = 0; q < NPA; ++q) a_ok[q] = false;
                 return;
             }
             const NtProb& pr = g.p[pi];
             const Win A = pr.A;
 #pragma unroll
-            for (int q = 0; q < TM; ++q) {
+            for (int q = 0; q < NPA; ++q) {
                 const int m = m0 + sr0 + 32 * q;
                 a_ok[q] = m < pr.M;
                 const int mm = a_ok[q] ? m : 0;
@@ -153,132 +175,229 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mw_kernel(const NtGroup g) {
                 a_boff[q] = (unsigned)(((long)b * A.bs) * 4);
                 a_r[q] = (mm - b * A.rows_out) * A.step + A.shift;
             }
-#pragma unroll
-            for (int q = 0; q < TN; ++q) {
-                const int n = n0 + sr0 + 32 * q;
-                b_ok[q] = n < pr.N;
-                b_boff[q] = (unsigned)(((long)(b_ok[q] ? n : 0) * pr.ldb) * 4);
-            }
             rs4 = (unsigned)(A.rs * 4);
-            a_cw = A.cw; a_dil = A.dil; a_rows_in = A.rows_in; K_f = A.K; seg_k = pr.b_seg_k;
-            // tap / channel of this thread's piece in the A window and weight segment / column in B, advanced by one slab per fetch
-            kk = sp / a_cw; c = sp - kk * a_cw;
-            const int bsg = sp / seg_k;
-            bc = sp - bsg * seg_k;
-            kb = (unsigned)(((long)bsg * pr.b_seg_stride + bc) * 4);
-            kb_wrap = (unsigned)((pr.b_seg_stride - seg_k) * 4);
+            a_cw = A.cw; a_dil = A.dil; a_rows_in = A.rows_in; K_a = A.K;
+            kk = sp / a_cw; c = sp - kk * a_cw;                // tap / channel of this thread's piece, advanced by one slab per fetch
             kcur = sp;
-            a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.ptr), 0, pr.a_bytes, MW_RSRC3);
-            b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.Bw), 0, pr.b_bytes, MW_RSRC3);
+            a_ptr = A.ptr; a_bytes = pr.a_bytes;
         };
-        u32x4 ga[2][TM], gb[2][TN];
+        u32x4 ga[2][NPA];
         auto fetch = [&](auto set_c) {
             constexpr int set = decltype(set_c)::value;
-            const bool inb = kcur < K_f;
+            const __amdgpu_buffer_rsrc_t a_rsrc = mw_rsrc(a_ptr, a_bytes);
+            const bool inb = kcur < K_a;
             const unsigned c4 = (unsigned)(c * 4);
 #pragma unroll
-            for (int q = 0; q < TM; ++q) {
+            for (int q = 0; q < NPA; ++q) {
                 const int sr = a_r[q] + kk * a_dil;
                 const bool ok = a_ok[q] & inb & ((unsigned)sr < (unsigned)a_rows_in);
                 if constexpr (ABL & 4) ga[set][q] = u32x4{0x3f800000u + (unsigned)lane, 0x40000000u, 0x3fc00000u + (unsigned)kcur, ok ? 0x3e800000u : 0u};
                 else ga[set][q] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, ok ? a_boff[q] + (unsigned)sr * rs4 + c4 : MW_OOB, 0, 0);
             }
-#pragma unroll
-            for (int q = 0; q < TN; ++q) {
-                if constexpr (ABL & 4) gb[set][q] = u32x4{0x3f000000u + (unsigned)lane, 0x3e000000u, 0x3f400000u + kb, (b_ok[q] & inb) ? 0x3e800000u : 0u};
-                else gb[set][q] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (b_ok[q] & inb) ? b_boff[q] + kb : MW_OOB, 0, 0);
-            }
             kcur += 32;
             c += 32;
             while (c >= a_cw) { c -= a_cw; ++kk; }
-            bc += 32; kb += 128u;
-            while (bc >= seg_k) { bc -= seg_k; kb += kb_wrap; }
-            if (live && ++s_f >= nslab_f) next_tile();         // (wave-uniform)
+            if (live_a && ++s_a >= nslab_a) next_tile_a();     // (wave-uniform)
         };
         auto stage = [&](auto set_c, int buf) {
             constexpr int set = decltype(set_c)::value;
-            __bf16* const lb = lds + buf * BUF;
+            unsigned char* const lb = smem + buf * A_BUF;
             if constexpr (ABL & 2) {                              // loaded values stay live (the loads must still be waited for), nothing else
 #pragma unroll
-                for (int q = 0; q < TM; ++q) asm volatile("" :: "v"(ga[set][q]));
-#pragma unroll
-                for (int q = 0; q < TN; ++q) asm volatile("" :: "v"(gb[set][q]));
+                for (int q = 0; q < NPA; ++q) asm volatile("" :: "v"(ga[set][q]));
                 return;
             }
 #pragma unroll
-            for (int q = 0; q < TM; ++q) {
+            for (int q = 0; q < NPA; ++q) {
                 u32x2 o[NS];
                 mw_split4<NS>(__builtin_bit_cast(f32x4, ga[set][q]), o);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(lb + s * PLANE + (sr0 + 32 * q) * 32 + sp_w) = o[s];
-            }
-#pragma unroll
-            for (int q = 0; q < TN; ++q) {
-                u32x2 o[NS];
-                mw_split4<NS>(__builtin_bit_cast(f32x4, gb[set][q]), o);
-#pragma unroll
-                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(lb + s * PLANE + (BM + sr0 + 32 * q) * 32 + sp_w) = o[s];
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(lb + s * A_PLANE + (sr0 + 32 * q) * 64 + sp_wb) = o[s];
             }
         };
-        next_tile();                                           // first tile of this workgroup (or none)
-        fetch(set0{});                                         // slab 0
-        fetch(set1{});                                         // slab 1
-        stage(set0{}, 0);
-        fetch(set0{});                                         // slab 2
-        MW_BARRIER_MOVER();
-        // step n: the matrix waves multiply slab n out of buffer n & 1; slab n + 1 is staged into the other buffer (read last during
-        // step n - 1) and slab n + 3 fetched into the register set that has just been emptied
-        int n = 0;
-        while (n < total) {
-            if (n + 1 < total) stage(set1{}, 1);
-            fetch(set1{});
-            MW_BARRIER_MOVER();
-            if (++n >= total) break;
-            if (n + 1 < total) stage(set0{}, 0);
-            fetch(set0{});
-            MW_BARRIER_MOVER();
-            ++n;
-        }
-    } else {
-        // ============================================================================================ matrix waves (0-3)
-        const int wm = (wave >> 1) & 1, wn = wave & 1;
-        const int r16 = lane & 15, kq = lane >> 4;
-        const int fcol = (8 * kq) ^ mw_swz(r16);
-        f32x4 acc[TM][TN];
-        // acc[i][j] = (W tile j) . (X tile i)^T: the weight fragment is the MFMA's A operand, so the lane's four accumulator values are
-        // output row (i, r16), columns (j, 4 kq .. 4 kq + 3)
-        auto multiply = [&](int buf) {
-            const __bf16* const lb = lds + buf * BUF;
-            bf16x8 fa[NS][TM];
+        // ---- weights: this wave moves the 16-row groups mw, mw + 4, mw + 8 of the tile's BN rows, NS planes each, one DMA per (group,
+        // plane) and slab.  Its cursor (tile vb_b, slab s_b) runs two slabs ahead.
+        const int grow = lane >> 2;                                            // row inside a 16-row group
+        const unsigned chunk_b = (unsigned)(((lane & 3) ^ (((grow >> 3) & 1) << 1)) * 16);   // SOURCE chunk of this lane's LDS slot (swizzle on the source)
+        int vb_b = blockIdx.x - G, s_b = 0, nslab_b = 0;
+        bool live_b = true;
+        unsigned b_voff[MAXGB];
+        unsigned b_slab_b = 0, b_bytes = 0;                                    // bytes per 32-column slab of a plane; per plane
+        const __bf16* b_ptr = g.p[0].Bpl;
+        long b_plane = 0;
+        auto next_tile_b = [&]() {
+            int pi = 0, m0 = 0, n0 = 0;
+            do {
+                vb_b += G;
+                if (vb_b >= total_tiles) { live_b = false; break; }
+            } while (!decode(vb_b, pi, m0, n0, nslab_b));
+            s_b = 0;
+            if (!live_b) return;
+            const NtProb& pr = g.p[pi];
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
+            for (int u = 0; u < MAXGB; ++u) {
+                const int n = n0 + 16 * (mw + 4 * u) + grow;
+                b_voff[u] = (unsigned)(n < pr.N ? pr.b_row0 + n : pr.b_slab_rows - 1) * 64u + chunk_b;      // rows past N: the buffer's zero row
+            }
+            b_slab_b = (unsigned)pr.b_slab_rows * 64u;
+            b_bytes = b_slab_b * (unsigned)((pr.A.K + 31) >> 5);
+            b_ptr = pr.Bpl; b_plane = pr.bpl_plane;
+        };
+        auto dma = [&](int slot) -> bool {                                     // the cursor's slab -> ring slot `slot`; false when nothing is left
+            if (!live_b) return false;
+            if constexpr (!(ABL & 8)) {
+                const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s_b * (int)b_slab_b);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(lb + s * PLANE + (wm * (16 * TM) + i * 16 + r16) * 32 + fcol);
+                for (int s = 0; s < NS; ++s) {
+                    const __amdgpu_buffer_rsrc_t rs = mw_rsrc(b_ptr + s * b_plane, b_bytes);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bf16x8 fb[NS];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(lb + s * PLANE + (BM + wn * (16 * TN) + j * 16 + r16) * 32 + fcol);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    f32x4 cc = acc[i][j];
-                    if constexpr (ABL & 1) {               // fragments stay live, no matrix instruction
-                        asm volatile("" :: "v"(fb[0]), "v"(fb[NS - 1]), "v"(fb[NS / 2]), "v"(fa[0][i]), "v"(fa[NS - 1][i]), "v"(fa[NS / 2][i]));
-                        continue;
+                    for (int u = 0; u < MAXGB; ++u) {
+                        const int grp = mw + 4 * u;
+                        if (grp >= GB) continue;                               // wave-uniform
+                        mw_dma16(rs, smem, (unsigned)(B_BASE + slot * B_BUF + s * B_PLANE + grp * 1024), b_voff[u], soff);
                     }
-                    if constexpr (NS == 3) {               // smallest terms first
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[2][i], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2], fa[0][i], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[1][i], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[1][i], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[0][i], cc, 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[0][i], cc, 0, 0, 0);
                 }
             }
+            if (++s_b >= nslab_b) next_tile_b();
+            return true;
         };
-        MW_BARRIER_MATRIX();
-        int n = 0;
+        constexpr int ND_MIN = NS * (GB / 4);                                  // fewest DMAs a mover wave issues per slab
+
+        next_tile_a();
+        next_tile_b();
+        fetch(set0{});                                         // slab 0
+        fetch(set1{});                                         // slab 1 (past this workgroup's work: every piece out of range, zeros, no traffic)
+        dma(0);                                                // slabs 0, 1 of the weights
+        dma(1);
+        stage(set0{}, 0);
+        fetch(set0{});                                         // slab 2
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        MW_TIMED_BARRIER();
+        asm volatile("" ::: "memory");
+        // step n: the matrix waves multiply slab n (activation buffer n & 1, weight slot n % 3).  Slab n + 1 of the activation is staged into
+        // the other buffer (read last during step n - 1), slab n + 3 fetched into the register set just emptied, slab n + 2 of the weights
+        // sent to the slot slab n - 1 has left; before the step's barrier the weights of slab n + 1 (sent one step ago) must have landed:
+        // everything this wave issued after them -- one fetch, one slab of DMAs -- may stay in flight.
+        int n = 0, slot2 = 2;                                  // slot2 = (n + 2) % 3
+        auto step = [&](auto set_c, int abuf) {
+            if (n + 1 < total) stage(set_c, abuf);
+            fetch(set_c);
+            const bool sent = dma(slot2);
+            if (sent) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPA + ND_MIN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPA) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MW_TIMED_BARRIER();
+            asm volatile("" ::: "memory");
+            ++n;
+            slot2 = slot2 == 2 ? 0 : slot2 + 1;
+        };
+        while (n < total) {
+            step(set1{}, 1);
+            if (n >= total) break;
+            step(set0{}, 0);
+        }
+    } else {
+        // ============================================================================================ matrix waves (0-7)
+        const int wm = wave / WNW, wn = wave % WNW;
+        const int r16 = lane & 15, kq = lane >> 4;
+        const int fa_off = (wm * (16 * TM) + r16) * 64 + ((8 * kq) ^ mw_swz(r16)) * 2;                 // byte offset of the lane's first A fragment
+        const int fb_off = B_BASE + (wn * (16 * TN) + r16) * 64 + ((8 * kq) ^ mw_swz(r16)) * 2;        // ... and first B fragment (slot 0)
+        f32x4 acc[TM][TN];
+        auto load_fb = [&](bf16x8 (&fb)[NS], int slot_, int j) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(smem + slot_ * B_BUF + s * B_PLANE + j * 1024 + fb_off);
+        };
+        // acc[i][j] += (W tile j) . (X tile i)^T for row tiles [I0, I1): the weight fragment is the MFMA's A operand, so the lane's four accumulator
+        // values are output row (i, r16), columns (j, 4 kq .. 4 kq + 3)
+        bf16x8 fa[NS][TM];
+        auto load_fa_row = [&](int abuf, auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) fa[s][i] = *reinterpret_cast<const bf16x8*>(smem + abuf * A_BUF + s * A_PLANE + i * 1024 + fa_off);
+        };
+        auto mma_rows = [&](const bf16x8 (&fb)[NS], auto j_c, auto i0_c, auto i1_c) {
+            constexpr int j = decltype(j_c)::value, I0 = decltype(i0_c)::value, I1 = decltype(i1_c)::value;
+            if constexpr (ABL & 1) {                   // fragments stay live, no matrix instruction
+#pragma unroll
+                for (int i = I0; i < I1; ++i) asm volatile("" :: "v"(fb[0]), "v"(fb[NS - 1]), "v"(fa[0][i]), "v"(fa[NS - 1][i]));
+                return;
+            }
+            // term-major over the row tiles: the MFMAs that accumulate into one tile are I1 - I0 issues apart (smallest terms first)
+            if constexpr (NS == 3) {
+#pragma unroll
+                for (int i = I0; i < I1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[2][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = I0; i < I1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2], fa[0][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = I0; i < I1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[1][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = I0; i < I1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[1][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = I0; i < I1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[0][i], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = I0; i < I1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[0][i], acc[i][j], 0, 0, 0);
+        };
+        int n = 0, slot = 0;                                   // global slab counter; slot = n % 3
+        bf16x8 fbr[2][NS];
+        // one slab: fa holds its A fragments, fbr[0] its first B fragment.  The fragments of column j + 1 are read during the MFMAs of column
+        // j; before the last column every read of this slab is back -> barrier -> the NEXT slab's first B fragment goes out at once and its A
+        // fragments row tile by row tile, each into the registers the last column's MFMAs of that row tile have just read.  The next slab is
+        // simply slab n + 1 of this workgroup's sequence (also across a tile boundary; after the very last slab the reads fetch bytes
+        // nobody uses), so the loop body has no conditional loads.  An odd TN reloads column 0 at the slab's start instead (fbr parity).
+        auto slab = [&]() {
+            const int nslot = slot == 2 ? 0 : slot + 1;
+            constexpr bool EVEN = (TN & 1) == 0;
+            if constexpr (!EVEN) load_fb(fbr[0], slot, 0);
+            auto col = [&](auto j_c) {
+                constexpr int j = decltype(j_c)::value;
+                constexpr int cb = j & 1;
+                if constexpr (j + 1 < TN) {
+                    load_fb(fbr[cb ^ 1], slot, j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_rows(fbr[cb], j_c, std::integral_constant<int, 0>{}, std::integral_constant<int, TM>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    MW_TIMED_BARRIER();
+                    asm volatile("" ::: "memory");
+                    if constexpr (EVEN) load_fb(fbr[cb ^ 1], nslot, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int nbuf = (n + 1) & 1;
+                    auto row = [&](auto i_c) {
+                        constexpr int i = decltype(i_c)::value;
+                        mma_rows(fbr[cb], j_c, i_c, std::integral_constant<int, i + 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_fa_row(nbuf, i_c);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    row(std::integral_constant<int, 0>{});
+                    if constexpr (TM > 1) row(std::integral_constant<int, 1>{});
+                    if constexpr (TM > 2) row(std::integral_constant<int, 2>{});
+                    if constexpr (TM > 3) row(std::integral_constant<int, 3>{});
+                    static_assert(TM <= 4, "row tiles per wave");
+                }
+            };
+            col(std::integral_constant<int, 0>{});
+            if constexpr (TN > 1) col(std::integral_constant<int, 1>{});
+            if constexpr (TN > 2) col(std::integral_constant<int, 2>{});
+            if constexpr (TN > 3) col(std::integral_constant<int, 3>{});
+            if constexpr (TN > 4) col(std::integral_constant<int, 4>{});
+            if constexpr (TN > 5) col(std::integral_constant<int, 5>{});
+            static_assert(TN <= 6, "column tiles per wave");
+            ++n;
+            slot = nslot;
+        };
+        asm volatile("" ::: "memory");
+        MW_TIMED_BARRIER();
+        asm volatile("" ::: "memory");
+        // slab 0's first fragments (the loop prefetches every later slab's)
+        load_fa_row(0, std::integral_constant<int, 0>{});
+        if constexpr (TM > 1) load_fa_row(0, std::integral_constant<int, 1>{});
+        if constexpr (TM > 2) load_fa_row(0, std::integral_constant<int, 2>{});
+        if constexpr (TM > 3) load_fa_row(0, std::integral_constant<int, 3>{});
+        load_fb(fbr[0], 0, 0);
         for (int vb = blockIdx.x; vb < total_tiles; vb += G) {
             int pi, m0, n0, nslab;
             if (!decode(vb, pi, m0, n0, nslab)) continue;
@@ -286,11 +405,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mw_kernel(const NtGroup g) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < nslab; ++s) {
-                multiply(n & 1);
-                MW_BARRIER_MATRIX();                           // this slab's fragments are in registers; the movers may refill its buffer
-                ++n;
-            }
+            for (int s = 0; s < nslab; ++s) slab();
             // ---- epilogue straight from the accumulators: bias, activation, dropout scale, gate, accumulate, second output; every access a
             // 16-byte piece of one output row (an instruction covers 16 rows x 64 bytes).  The stores drain while the next tile runs.
             const NtProb& pr = g.p[pi];
@@ -319,48 +434,51 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mw_kernel(const NtGroup g) {
                 const bool cok = col < N;                      // N % 4 == 0: a piece is inside or outside as a whole
                 const int cc0 = cok ? col : 0;
                 const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + cc0) : z4;
-                f32x4 mv[TM], gv[TM], rv[TM], cv[TM];
+                constexpr int RB = TM > 2 ? 2 : TM;            // row tiles per batch: the batch's reads first, from always-valid addresses
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {                 // every read of the column group first, from always-valid addresses
-                    const long o = ro[i] + cc0;
-                    if (mul) mv[i] = *reinterpret_cast<const f32x4*>(mul + o);
-                    if (gate) gv[i] = *reinterpret_cast<const f32x4*>(gate + o);
-                    if (res) rv[i] = *reinterpret_cast<const f32x4*>(res + o);
-                    if (accumulate) cv[i] = *reinterpret_cast<const f32x4*>(C + o);
-                }
+                for (int i0 = 0; i0 < TM; i0 += RB) {
+                    f32x4 mv[RB], gv[RB], rv[RB], cv[RB];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const long o = ro[i] + cc0;
-                    f32x4 v = acc[i][j] + bv;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q], slope);
-                    if (mul) v *= mv[i];
-                    if (gate) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = gv[i][q] > 0.f ? v[q] : 0.f;
+                    for (int u = 0; u < RB; ++u) {
+                        const long o = ro[i0 + u] + cc0;
+                        if (mul) mv[u] = *reinterpret_cast<const f32x4*>(mul + o);
+                        if (gate) gv[u] = *reinterpret_cast<const f32x4*>(gate + o);
+                        if (res) rv[u] = *reinterpret_cast<const f32x4*>(res + o);
+                        if (accumulate) cv[u] = *reinterpret_cast<const f32x4*>(C + o);
                     }
-                    if (accumulate) v += cv[i];
-                    const bool ok = rok[i] & cok;
-                    if constexpr (ABL & 16) { if (v[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(C + o) = v; continue; }
-                    if (ok) *reinterpret_cast<f32x4*>(C + o) = v;
-                    if (res) {
-                        f32x4 w = v + rv[i];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) w[q] = act_fn(w[q], slope2);
-                        if (ok) *reinterpret_cast<f32x4*>(C2 + o) = w;
+                    for (int u = 0; u < RB; ++u) {
+                        const int i = i0 + u;
+                        const long o = ro[i] + cc0;
+                        f32x4 v = acc[i][j] + bv;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q], slope);
+                        if (mul) v *= mv[u];
+                        if (gate) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = gv[u][q] > 0.f ? v[q] : 0.f;
+                        }
+                        if (accumulate) v += cv[u];
+                        const bool ok = rok[i] & cok;
+                        if constexpr (ABL & 16) { if (v[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(C + o) = v; continue; }
+                        if (ok) *reinterpret_cast<f32x4*>(C + o) = v;
+                        if (res) {
+                            f32x4 w = v + rv[u];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) w[q] = act_fn(w[q], slope2);
+                            if (ok) *reinterpret_cast<f32x4*>(C2 + o) = w;
+                        }
                     }
                 }
             }
         }
     }
 #ifdef TG_LAB_ABLATE
-    if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 512) {
-        mw_role_cycles[blockIdx.x * 4 + (wave >> 2) * 2 + 0] = waited;
-        mw_role_cycles[blockIdx.x * 4 + (wave >> 2) * 2 + 1] = __builtin_amdgcn_s_memtime() - t_begin;
+    if (lane == 0 && blockIdx.x < 512) {
+        mw_role_cycles[blockIdx.x * 24 + wave * 2 + 0] = waited;
+        mw_role_cycles[blockIdx.x * 24 + wave * 2 + 1] = __builtin_amdgcn_s_memtime() - t_begin;
     }
 #endif
-#undef MW_BARRIER_MOVER
-#undef MW_BARRIER_MATRIX
 #undef MW_TIMED_BARRIER
 }
 
@@ -389,7 +507,7 @@ static bool mw_extents(NtProb& p) {
     return true;
 }
 
-struct MwTile { int tm, tn; };
+struct MwTile { int tm, tn; };          // workgroup tile in units of 32 rows / columns
 
 // Tile choice.  The mover-wave kernel runs ONE workgroup per CU; it pays when its tiles fill most of the 256 CUs at least once:
 //   * 128 x 192: N = 900 -> 5 column tiles (6.7 % padding); the stacked forward's two GRU projections are 1020 tiles = 3.98 rounds
@@ -430,7 +548,7 @@ static bool mw_pick_tile(const NtGroup& g, MwTile* out) {
 bool tg_gemm_nt_mw_eligible(NtGroup& g, int* tm, int* tn) {
     for (int i = 0; i < g.n; ++i) {
         NtProb& p = g.p[i];
-        if (!p.vec_c || p.A.cw % 4 != 0 || p.b_seg_k % 4 != 0 || p.A.K % 4 != 0) return false;
+        if (!p.vec_c || p.A.cw % 4 != 0 || p.A.K % 4 != 0 || p.Bpl == nullptr || p.b_seg_k != p.A.K) return false;
         if (!mw_extents(p)) return false;
     }
     MwTile tl;
@@ -460,19 +578,20 @@ int tg_gemm_nt_mw_launch(NtGroup& g, int tm, int tn, int splits, hipStream_t s) 
         const char* e = getenv("TG_MW_ABL");
         const int abl = e ? atoi(e) : 0;
         if (abl && tm == 4 && tn == 6 && splits == 3) {
-#define TG_ABL(A_) case A_: hipLaunchKernelGGL((gemm_nt_mw_kernel<4, 6, 3, A_>), grid, dim3(512), 0, s, g); return check_launch("tg_gemm_nt(mover waves, ablated)")
-            switch (abl) { TG_ABL(1); TG_ABL(2); TG_ABL(3); TG_ABL(4); TG_ABL(6); TG_ABL(7); TG_ABL(16); TG_ABL(23); default: break; }
+#define TG_ABL(A_) case A_: hipLaunchKernelGGL((gemm_nt_mw_kernel<4, 3, 2, 4, 3, A_>), grid, dim3(768), 0, s, g); return check_launch("tg_gemm_nt(mover waves, ablated)")
+            switch (abl) { TG_ABL(1); TG_ABL(2); TG_ABL(6); TG_ABL(8); TG_ABL(14); TG_ABL(15); TG_ABL(16); default: break; }
 #undef TG_ABL
         }
     }
 #endif
-#define TG_MW(TM_, TN_)                                                                                        \
-    do {                                                                                                       \
-        if (splits == 3) hipLaunchKernelGGL((gemm_nt_mw_kernel<TM_, TN_, 3>), grid, dim3(512), 0, s, g);       \
-        else hipLaunchKernelGGL((gemm_nt_mw_kernel<TM_, TN_, 1>), grid, dim3(512), 0, s, g);                   \
+    // 128 x 192: matrix waves 2 x 4, wave tile 64 x 48; 128 x 160: 4 x 2, wave tile 32 x 80
+#define TG_MW(TM_, TN_, WM_, WN_)                                                                                          \
+    do {                                                                                                                   \
+        if (splits == 3) hipLaunchKernelGGL((gemm_nt_mw_kernel<TM_, TN_, WM_, WN_, 3>), grid, dim3(768), 0, s, g);         \
+        else hipLaunchKernelGGL((gemm_nt_mw_kernel<TM_, TN_, WM_, WN_, 1>), grid, dim3(768), 0, s, g);                     \
     } while (0)
-    if (tm == 4 && tn == 6) TG_MW(4, 6);
-    else if (tm == 4 && tn == 5) TG_MW(4, 5);
+    if (tm == 4 && tn == 6) TG_MW(4, 3, 2, 4);
+    else if (tm == 4 && tn == 5) TG_MW(2, 5, 4, 2);
     else TG_REQUIRE(false, "tg_gemm_nt(mover waves): no %d x %d tile", bm, bn);
 #undef TG_MW
     return check_launch("tg_gemm_nt(mover waves)");

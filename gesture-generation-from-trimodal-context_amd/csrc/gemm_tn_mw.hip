@@ -1,0 +1,404 @@
+// tg_gemm_tn, the big weight gradients: dW[n][k] += sum_m dY[m][n] * A(m, k) on the bf16 matrix cores at fp32 accuracy (bf16 x 3), with MOVER
+// WAVES -- the weight-gradient counterpart of gemm_mw.hip.
+//
+// gemm_tn_split_kernel (gemm_split.hip) runs 64 x 64 / 128 x 64 tiles on 256-thread workgroups whose waves stage, barrier, multiply,
+// barrier: 89 TFLOP/s on the four weight gradients of a GRU layer, bound by re-reading its two row-major operands (~940 MB of L2 traffic
+// per group launch).  Here one PERSISTENT 768-thread workgroup per CU owns a 192 x 160 tile of dW (2.3 x fewer
+// operand bytes per flop) and walks work items (problem, tile, row split):
+//   * mover waves 8-11 (one per SIMD) fetch the fp32 slabs of dY and of the A window (32 rows of the reduction) two slabs ahead into
+//     registers, split every value exactly into three bf16 terms and store the planes row-major into a double-buffered LDS image;
+//   * matrix waves 0-7 (two per SIMD, 4 (n) x 2 (k), wave tile 48 x 80) read their fragments TRANSPOSED (ds_read_b64_tr_b16: eight
+//     consecutive rows of one column per lane, tr_image.hpp) and issue nothing but those reads and MFMAs -- 90 per wave and slab, the next
+//     row tile's fragments in flight under the current one's MFMAs, the next slab's k fragments reloaded one by one under the last row tile's.
+// One workgroup barrier per slab; the slab stream runs on across items.  Row splits are combined with float atomics straight from the
+// accumulators (the tile menu keeps the group at one item per CU: 29 MB of atomics for a GRU layer's four gradients instead of 91).
+// The bias gradient costs nothing: a tile whose k range has a padding column past K stages a column of ONES there, so the product's
+// column K is sum_m dY[m][n] = dbias[n] (exact: 1.0 = its own hi term).
+// Out-of-range pieces (rows past the item's range, columns past N / K, window padding) are bounds-checked buffer loads that return zero.
+#include "common.hpp"
+#include "tr_image.hpp"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace tg {
+
+constexpr unsigned TW_RSRC3 = 0x00020000u;
+constexpr unsigned TW_OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tw_rsrc(const void* base, unsigned bytes) {     // provably wave-uniform descriptor (guide T20)
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), TW_RSRC3);
+}
+
+__device__ __forceinline__ void tw_split4(const f32x4 v, u32x2 (&out)[3]) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xf = v[i];
+        split3_bits(xf, h[i], m[i], l[i]);
+    }
+    out[0] = u32x2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])};
+    out[1] = u32x2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])};
+    out[2] = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
+}
+
+// wave tile (16 TNT) x (16 TKT) of dW; matrix waves WNW (n) x WKW (k); workgroup tile BN x BK
+template <int TNT, int TKT, int WNW, int WKW>
+__global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
+    static_assert(WNW * WKW == 8, "eight matrix waves");
+    constexpr int BN = 16 * TNT * WNW, BK = 16 * TKT * WKW;
+    using YI = TrImage<BN>;
+    using XI = TrImage<BK>;
+    constexpr int LDN = YI::LD, LDK = XI::LD;
+    constexpr int PY = BN / 4, PX = BK / 4;                    // 4-column pieces per slab row
+    constexpr int NPY = 32 * PY / 256, NPX = 32 * PX / 256;    // pieces per mover thread and slab
+    static_assert(32 * PY % 256 == 0 && 32 * PX % 256 == 0, "whole pieces per mover thread");
+    constexpr int Y_PLANE = 32 * LDN, X_PLANE = 32 * LDK;      // bf16 elements
+    __shared__ __attribute__((aligned(16))) __bf16 ys[2][3][Y_PLANE];
+    __shared__ __attribute__((aligned(16))) __bf16 xs[2][3][X_PLANE];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int total_items = g.wg_begin[TG_MAX_GROUP];
+    const int G = gridDim.x;
+
+    // work item `vb` -> problem, tile origin, row range; false for a padding id
+    auto decode = [&](int vb, int& pi, int& n0, int& k0, int& m_begin, int& m_end) -> bool {
+        pi = group_find(g, vb);
+        const TnProb& pr = g.p[pi];
+        const int lid = xcd_chunked_id(vb - g.wg_begin[pi], g.wg_begin[pi + 1] - g.wg_begin[pi]);
+        const int tn_n = lid % pr.n_nt, tn_k = (lid / pr.n_nt) % pr.n_kt, tn_s = lid / (pr.n_nt * pr.n_kt);
+        n0 = tn_n * BN; k0 = tn_k * BK;
+        m_begin = tn_s * pr.rows_per_split;
+        m_end = min(pr.M, m_begin + pr.rows_per_split);
+        return m_begin < pr.M;
+    };
+    int total = 0;                                             // slabs this workgroup walks (both roles count the same barriers)
+    for (int vb = blockIdx.x; vb < total_items; vb += G) {
+        int pi, n0, k0, mb, me;
+        if (decode(vb, pi, n0, k0, mb, me)) total += (me - mb + 31) >> 5;
+    }
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+
+    if (wave >= 8) {
+        // ============================================================================================ movers (waves 8-11)
+        const int mt = t - 512;
+        int yrow[NPY], ycol[NPY], ypos[NPY], xrow[NPX], xcol[NPX], xpos[NPX];
+#pragma unroll
+        for (int i = 0; i < NPY; ++i) {
+            const int p = mt + 256 * i;
+            yrow[i] = p / PY; ycol[i] = 4 * (p - yrow[i] * PY); ypos[i] = YI::at(yrow[i], ycol[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const int p = mt + 256 * i;
+            xrow[i] = p / PX; xcol[i] = 4 * (p - xrow[i] * PX); xpos[i] = XI::at(xrow[i], xcol[i]);
+        }
+        // fetch cursor: item vb_f, slab s_f of nslab_f; runs three slabs ahead of the slab the matrix waves multiply
+        int vb_f = blockIdx.x - G, s_f = 0, nslab_f = 0, m_cur = 0, m_end_f = 0;
+        bool live = true;
+        unsigned y_off[NPY];                                   // byte offset of (row m_begin + yrow, column n0 + ycol) in dY
+        bool y_cok[NPY];
+        unsigned x_cb[NPX];                                    // byte offset of the piece's channel inside a source row
+        int x_tapd[NPX], x_mb[NPX], x_mr[NPX], x_one[NPX];     // tap row displacement; batch / row of the piece's m; element that is the ones column (or -1)
+        bool x_ok[NPX];
+        unsigned y_slab_b = 0;                                 // bytes between slabs in dY
+        const float* y_ptr = g.p[0].dY;
+        const float* a_ptr = g.p[0].A.ptr;
+        unsigned y_bytes = 0, a_bytes = 0, rs4 = 0;
+        long a_bs = 0;
+        int a_rows_out = 1, a_rows_in = 0, a_step = 1;
+        auto next_item = [&]() {
+            int pi = 0, n0 = 0, k0 = 0, mb = 0, me = 0;        // (locals: a captured variable passed by reference here ends up in scratch memory)
+            do {
+                vb_f += G;
+                if (vb_f >= total_items) { live = false; break; }
+            } while (!decode(vb_f, pi, n0, k0, mb, me));
+            m_end_f = me;
+            s_f = 0;
+            if (!live) {
+#pragma unroll
+                for (int i = 0; i < NPY; ++i) y_cok[i] = false;
+#pragma unroll
+                for (int i = 0; i < NPX; ++i) { x_ok[i] = false; x_one[i] = -1; }
+                m_cur = 0; m_end_f = 0;
+                return;
+            }
+            const TnProb& pr = g.p[pi];
+            const Win A = pr.A;
+            nslab_f = (m_end_f - mb + 31) >> 5;
+            m_cur = mb;
+#pragma unroll
+            for (int i = 0; i < NPY; ++i) {
+                y_cok[i] = n0 + ycol[i] < pr.N;
+                y_off[i] = (unsigned)(((long)(mb + yrow[i]) * pr.ldy + n0 + ycol[i]) * 4);
+            }
+            const bool bias_here = pr.dbias != nullptr && k0 <= A.K && A.K < k0 + BK;       // this tile holds the padding column K
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                const int ak = k0 + xcol[i];
+                x_ok[i] = ak < A.K;
+                const int kc = x_ok[i] ? ak : 0;
+                const int tap = kc / A.cw;
+                x_cb[i] = (unsigned)((kc - tap * A.cw) * 4);
+                x_tapd[i] = A.shift + tap * A.dil;
+                const int m = mb + xrow[i];
+                x_mb[i] = m / A.rows_out;
+                x_mr[i] = m - x_mb[i] * A.rows_out;
+                x_one[i] = (bias_here && ak <= A.K && A.K < ak + 4) ? A.K - ak : -1;
+            }
+            y_slab_b = (unsigned)(32 * pr.ldy * 4);
+            y_ptr = pr.dY; y_bytes = pr.y_bytes;
+            a_ptr = A.ptr; a_bytes = pr.a_bytes; rs4 = (unsigned)(A.rs * 4); a_bs = A.bs;
+            a_rows_out = A.rows_out; a_rows_in = A.rows_in; a_step = A.step;
+        };
+        u32x4 gy[NPY], gx[NPX];
+        unsigned rowok = 0;                                    // bit i = X piece i's row lies inside the item's range (ones column)
+        int one_el[NPX];                                       // the ones column belongs to the item the registers were FETCHED for
+        auto fetch = [&]() {
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) one_el[i] = x_one[i];
+            const __amdgpu_buffer_rsrc_t yr = tw_rsrc(y_ptr, y_bytes), ar = tw_rsrc(a_ptr, a_bytes);
+            const unsigned ysoff = (unsigned)__builtin_amdgcn_readfirstlane(s_f * (int)y_slab_b);
+#pragma unroll
+            for (int i = 0; i < NPY; ++i) {
+                const bool ok = y_cok[i] & (m_cur + yrow[i] < m_end_f);
+                gy[i] = __builtin_amdgcn_raw_buffer_load_b128(yr, ok ? y_off[i] : TW_OOB, ysoff, 0);
+            }
+            unsigned rk = 0u;
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                const int sr = x_mr[i] * a_step + x_tapd[i];
+                const bool rin = m_cur + xrow[i] < m_end_f;
+                const bool ok = x_ok[i] & rin & ((unsigned)sr < (unsigned)a_rows_in);
+                gx[i] = __builtin_amdgcn_raw_buffer_load_b128(ar, ok ? (unsigned)(x_mb[i] * a_bs * 4) + (unsigned)sr * rs4 + x_cb[i] : TW_OOB, 0, 0);
+                rk |= rin ? (1u << i) : 0u;
+                x_mr[i] += 32;
+                while (x_mr[i] >= a_rows_out) { x_mr[i] -= a_rows_out; ++x_mb[i]; }
+            }
+            rowok = rk;
+            m_cur += 32;
+            if (live && ++s_f >= nslab_f) next_item();
+        };
+        auto stage = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < NPY; ++i) {
+                u32x2 o[3];
+                tw_split4(__builtin_bit_cast(f32x4, gy[i]), o);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x2*>(&ys[buf][s][0] + ypos[i]) = o[s];
+            }
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                f32x4 v = __builtin_bit_cast(f32x4, gx[i]);
+                const int e = ((rowok >> i) & 1u) ? one_el[i] : -1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = e == q ? 1.0f : v[q];
+                u32x2 o[3];
+                tw_split4(v, o);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x2*>(&xs[buf][s][0] + xpos[i]) = o[s];
+            }
+        };
+        next_item();
+        fetch();                                               // slab 0
+        stage(0);
+        fetch();                                               // slab 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // step n: the matrix waves multiply slab n out of buffer n & 1; slab n + 1 (fetched during step n - 1) is staged into the other
+        // buffer (read last during step n - 1) and slab n + 2 fetched into the registers just emptied: a full step for its loads to land
+        for (int n = 0; n < total; ++n) {
+            if (n + 1 < total) stage((n + 1) & 1);
+            fetch();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    } else {
+        // ============================================================================================ matrix waves (0-7)
+        const int wn = wave / WKW, wk = wave % WKW;
+        const int r16 = lane & 15, kq = lane >> 4;
+        f32x4 acc[TNT][TKT];
+        bf16x8 fa[2][3], fb[3][TKT];
+        auto load_fa = [&](bf16x8 (&f)[3], int buf, int nt) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) f[s] = YI::frag(&ys[buf][s][0], wn * (16 * TNT) + nt * 16, r16, kq);
+        };
+        auto load_fb = [&](int buf, auto kt_c) {
+            constexpr int kt = decltype(kt_c)::value;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) fb[s][kt] = XI::frag(&xs[buf][s][0], wk * (16 * TKT) + kt * 16, r16, kq);
+        };
+        auto mma = [&](const bf16x8 (&f)[3], auto nt_c, auto kt_c) {       // the six significant partial products, smallest first
+            constexpr int nt = decltype(nt_c)::value, kt = decltype(kt_c)::value;
+            f32x4 cc = acc[nt][kt];
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], fb[0][kt], cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], fb[2][kt], cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], fb[1][kt], cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], fb[0][kt], cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], fb[1][kt], cc, 0, 0, 0);
+            acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], fb[0][kt], cc, 0, 0, 0);
+        };
+        int n = 0;
+        // one slab: fb holds its k fragments.  Row tile nt + 1's fragments are read during the MFMAs of row tile nt; before the last row tile
+        // every read of this slab is back -> barrier -> under the last row tile's MFMAs the NEXT slab's k fragments are reloaded one by one,
+        // each right after the MFMAs that read the old one (the next slab is slab n + 1 of the workgroup's sequence, also across items)
+        auto slab = [&]() {
+            const int buf = n & 1, nbuf = buf ^ 1;
+            load_fa(fa[0], buf, 0);
+            auto rowtile = [&](auto nt_c) {
+                constexpr int nt = decltype(nt_c)::value;
+                if constexpr (nt + 1 < TNT) {
+                    load_fa(fa[(nt + 1) & 1], buf, nt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(fa[nt & 1], nt_c, std::integral_constant<int, 0>{});
+                    if constexpr (TKT > 1) mma(fa[nt & 1], nt_c, std::integral_constant<int, 1>{});
+                    if constexpr (TKT > 2) mma(fa[nt & 1], nt_c, std::integral_constant<int, 2>{});
+                    if constexpr (TKT > 3) mma(fa[nt & 1], nt_c, std::integral_constant<int, 3>{});
+                    if constexpr (TKT > 4) mma(fa[nt & 1], nt_c, std::integral_constant<int, 4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    auto one = [&](auto kt_c) {
+                        mma(fa[nt & 1], nt_c, kt_c);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_fb(nbuf, kt_c);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    one(std::integral_constant<int, 0>{});
+                    if constexpr (TKT > 1) one(std::integral_constant<int, 1>{});
+                    if constexpr (TKT > 2) one(std::integral_constant<int, 2>{});
+                    if constexpr (TKT > 3) one(std::integral_constant<int, 3>{});
+                    if constexpr (TKT > 4) one(std::integral_constant<int, 4>{});
+                    static_assert(TKT <= 5, "k tiles per wave");
+                }
+            };
+            rowtile(std::integral_constant<int, 0>{});
+            if constexpr (TNT > 1) rowtile(std::integral_constant<int, 1>{});
+            if constexpr (TNT > 2) rowtile(std::integral_constant<int, 2>{});
+            static_assert(TNT <= 3, "row tiles per wave");
+            ++n;
+        };
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_fb(0, std::integral_constant<int, 0>{});          // slab 0's k fragments (the loop reloads every later slab's)
+        if constexpr (TKT > 1) load_fb(0, std::integral_constant<int, 1>{});
+        if constexpr (TKT > 2) load_fb(0, std::integral_constant<int, 2>{});
+        if constexpr (TKT > 3) load_fb(0, std::integral_constant<int, 3>{});
+        if constexpr (TKT > 4) load_fb(0, std::integral_constant<int, 4>{});
+        for (int vb = blockIdx.x; vb < total_items; vb += G) {
+            int pi, n0, k0, m_begin, m_end;
+            if (!decode(vb, pi, n0, k0, m_begin, m_end)) continue;
+#pragma unroll
+            for (int i = 0; i < TNT; ++i)
+#pragma unroll
+                for (int j = 0; j < TKT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int nslab = (m_end - m_begin + 31) >> 5;
+            for (int s = 0; s < nslab; ++s) slab();
+            // ---- combine: float atomics (or the split's partial tile) straight from the accumulators; column K of a biased problem is dbias
+            const TnProb& pr = g.p[pi];
+            const int N = pr.N, K = pr.A.K, cw = pr.A.cw, out_kw = pr.out_kw;
+            float* __restrict__ dW = pr.dW;
+            float* __restrict__ partial = pr.partial;
+            float* __restrict__ dbias = pr.dbias;
+            const long ldw = pr.ldw;
+            const int tn_s = m_begin / pr.rows_per_split;
+#pragma unroll
+            for (int nt = 0; nt < TNT; ++nt)
+#pragma unroll
+                for (int kt = 0; kt < TKT; ++kt) {
+                    const int kcol = k0 + wk * (16 * TKT) + kt * 16 + r16;
+                    const long off = out_kw > 0 ? (long)(kcol % cw) * out_kw + kcol / cw : (long)kcol;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int nrow = n0 + wn * (16 * TNT) + nt * 16 + kq * 4 + i;
+                        if (nrow >= N) continue;
+                        if (kcol < K) {
+                            if (partial) partial[((long)tn_s * N + nrow) * K + kcol] = acc[nt][kt][i];
+                            else atomicAdd(&dW[(long)nrow * ldw + off], acc[nt][kt][i]);
+                        } else if (kcol == K && dbias) {
+                            atomicAdd(&dbias[nrow], acc[nt][kt][i]);
+                        }
+                    }
+                }
+        }
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+// Plan for the mover-wave kernel, or false when the group should stay on gemm_tn_split_kernel.  Fills n_nt / n_kt / rows_per_split / extents
+// of every problem and the workgroup ranges; *grid receives the launch size.
+bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid) {
+    static const int env_on = [] { const char* e = getenv("TG_TN_MW"); return e ? atoi(e) : 1; }();
+    if (!env_on) return false;
+    constexpr int BN = 192, BK = 160;
+    long tiles = 0;
+    for (int i = 0; i < g.n; ++i) {
+        TnProb& p = g.p[i];
+        const Win& A = p.A;
+        if (!p.vec_y || !p.vec_a || p.N % 4 != 0 || A.K % 4 != 0 || p.N < 150 || A.K < 150 || p.M < 2048) return false;
+        if (p.dbias && A.K % BK == 0) return false;                               // no padding column for the ones trick
+        if (p.partial) return false;                                              // two-pass combines keep their own split plan (gemm.hip tn_plan)
+        if (A.bs < 0 || A.rs < 0 || A.rows_out <= 0 || p.ldy < p.N) return false;
+        const long batches = cdiv(p.M, A.rows_out);
+        const long a_el = (batches - 1) * A.bs + (long)(A.rows_in - 1) * A.rs + A.cw;
+        const long y_el = (long)(p.M - 1) * p.ldy + p.N;
+        if (a_el <= 0 || a_el >= (1l << 29) || y_el >= (1l << 29)) return false;
+        p.a_bytes = (unsigned)(a_el * 4);
+        p.y_bytes = (unsigned)(y_el * 4);
+        tiles += (long)cdiv(p.N, BN) * cdiv(A.K, BK);
+    }
+    static const int n_cu = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus >= 8 ? cus / 8 * 8 : 8;
+    }();
+    // one item per CU for the group as a whole: row splits = CUs / tiles (every split costs one float atomic per output element), at
+    // least 256 rows each
+    long items = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const TnProb& p = g.p[i];
+        int s = (int)(n_cu / tiles);
+        if (s < 1) s = 1;
+        const int cap = cdiv(p.M, 256);
+        if (s > cap) s = cap;
+        items += (long)cdiv(p.N, BN) * cdiv(p.A.K, BK) * s;
+    }
+    if (items < n_cu / 2) return false;                                           // would leave most of the chip idle
+    int wg = 0;
+    for (int i = 0; i < g.n; ++i) {
+        TnProb& p = g.p[i];
+        int s = (int)(n_cu / tiles);
+        if (s < 1) s = 1;
+        const int cap = cdiv(p.M, 256);
+        if (s > cap) s = cap;
+        int rows = cdiv(p.M, s);
+        rows = (rows + 31) / 32 * 32;
+        p.rows_per_split = rows;
+        splits_out[i] = cdiv(p.M, rows);
+        p.n_nt = cdiv(p.N, BN); p.n_kt = cdiv(p.A.K, BK);
+        g.wg_begin[i] = wg;
+        wg += (p.n_nt * p.n_kt * splits_out[i] + 7) / 8 * 8;
+    }
+    for (int i = g.n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
+    *grid = wg < n_cu ? wg : n_cu;
+    return true;
+}
+
+int tg_gemm_tn_mw_launch(const TnGroup& g, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2>), dim3(grid), dim3(768), 0, s, g);
+    return check_launch("tg_gemm_tn(mover waves)");
+}

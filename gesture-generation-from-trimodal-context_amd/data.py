@@ -175,29 +175,55 @@ class SyntheticSpeechMotionDataset(torch.utils.data.Dataset):
         return sample_to_tensors(self.raw(idx), self.lang, self.n_poses, self.fps)
 
 
+def packed_like(tensors, device=None, pin=False):
+    """One flat byte buffer holding a copy-shaped twin of every tensor (256-byte aligned pieces) -> (flat uint8 tensor, views).  A batch kept
+    this way moves host -> device or device -> device as ONE copy instead of one per tensor."""
+    offs, off = [], 0
+    for t in tensors:
+        offs.append(off)
+        off += (t.numel() * t.element_size() + 255) // 256 * 256
+    flat = torch.empty(off, dtype=torch.uint8, device="cpu" if pin else (device or tensors[0].device))
+    if pin:
+        flat = flat.pin_memory()
+    views = tuple(flat[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for o, t in zip(offs, tensors))
+    return flat, views
+
+
 class DeviceBatchFeeder:
     """Host -> device staging for a static-shape training step (the `.to(device)` calls of train.py:172-183).
 
-    `static` are the device tensors a GraphedGanStep was captured on (GraphedGanStep.static).  put(batch) copies a collated batch
-    into a free pinned host slot (two slots) and enqueues its asynchronous host-to-device copy; ready() makes the batch the
-    step's input.  Two modes:
-      * overlap=False (default): the copy goes straight into the static tensors on the compute stream, stream-ordered behind the
-        previous replay: +0.4 ms per iteration at B = 128 (19 MB at ~50 GiB/s), nothing else on the GPU is disturbed;
-      * overlap=True: the copy goes into a device staging slot on a separate copy stream while the current iteration runs, and
-        ready() moves staging -> static with device-to-device copies.  Measured on MI355X / ROCm 7.2: 10.06 vs 10.03 ms per
-        iteration -- no gain (the copy beside a replay of chip-filling kernels stretches the replay by what it saves), kept as
-        an option."""
+    `static` are the device tensors a GraphedGanStep was captured on (GraphedGanStep.static); with `static_flat` (GraphedGanStep.static_flat,
+    the one buffer they are views of) every move below is a single copy.  put(batch) copies a collated batch into a free pinned host
+    slot (two slots) and enqueues its asynchronous host-to-device copy; ready() makes the batch the step's input.  Two modes:
+      * overlap=True (default when static_flat is given): the host -> device copy (19 MB at B = 128) runs on a separate copy stream into a
+        device staging slot while the current iteration runs; ready() moves staging -> static with ONE device-to-device copy on the
+        compute stream (microseconds), so the iteration never waits for PCIe;
+      * overlap=False: the copy goes straight into the static tensors on the compute stream, stream-ordered behind the previous replay:
+        +0.4 ms per iteration at B = 128 (19 MB at ~50 GiB/s)."""
 
-    def __init__(self, static_text, static_audio, static_target, static_vid, overlap=False):
+    def __init__(self, static_text, static_audio, static_target, static_vid, overlap=None, static_flat=None):
         self.static = (static_text, static_audio, static_target, static_vid)
         self.dev = static_text.device
-        self.overlap = overlap
-        self.pinned = [tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in self.static) for _ in range(2)]
+        self.flat = static_flat
+        if static_flat is not None:
+            lo = static_flat.data_ptr()
+            assert all(lo <= t.data_ptr() < lo + static_flat.numel() for t in self.static), "static tensors must be views of static_flat"
+        self.overlap = (static_flat is not None) if overlap is None else bool(overlap)
         self.h2d_done = [None, None]          # per slot: host -> device copy finished (pinned slot reusable)
         self.i = 0
         self.pending = None
-        if overlap:
-            self.staging = [tuple(torch.empty_like(t) for t in self.static) for _ in range(2)]
+        if self.flat is not None:
+            offs = [t.data_ptr() - self.flat.data_ptr() for t in self.static]
+            carve = lambda f: tuple(f[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for o, t in zip(offs, self.static))
+            self.pinned_flat = [torch.empty(self.flat.numel(), dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self.pinned = [carve(f) for f in self.pinned_flat]
+        else:
+            self.pinned = [tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in self.static) for _ in range(2)]
+        if self.overlap:
+            if self.flat is not None:
+                self.staging_flat = [torch.empty_like(self.flat) for _ in range(2)]
+            else:
+                self.staging = [tuple(torch.empty_like(t) for t in self.static) for _ in range(2)]
             self.stream = torch.cuda.Stream(device=self.dev)
             self.d2d_done = [None, None]      # per slot: staging -> static copy finished (staging slot reusable)
 
@@ -213,8 +239,11 @@ class DeviceBatchFeeder:
             with torch.cuda.stream(self.stream):
                 if self.d2d_done[slot] is not None:
                     self.stream.wait_event(self.d2d_done[slot])   # the staging slot has been drained into the static tensors
-                for dst, src in zip(self.staging[slot], self.pinned[slot]):
-                    dst.copy_(src, non_blocking=True)
+                if self.flat is not None:
+                    self.staging_flat[slot].copy_(self.pinned_flat[slot], non_blocking=True)
+                else:
+                    for dst, src in zip(self.staging[slot], self.pinned[slot]):
+                        dst.copy_(src, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
                 self.h2d_done[slot] = ev
@@ -226,14 +255,20 @@ class DeviceBatchFeeder:
         cur = torch.cuda.current_stream(self.dev)
         if self.overlap:
             cur.wait_event(self.h2d_done[slot])
-            for dst, src in zip(self.static, self.staging[slot]):
-                dst.copy_(src, non_blocking=True)
+            if self.flat is not None:
+                self.flat.copy_(self.staging_flat[slot], non_blocking=True)        # one device-to-device copy
+            else:
+                for dst, src in zip(self.static, self.staging[slot]):
+                    dst.copy_(src, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(cur)
             self.d2d_done[slot] = ev
         else:
-            for dst, src in zip(self.static, self.pinned[slot]):
-                dst.copy_(src, non_blocking=True)              # stream-ordered behind the previous replay's reads
+            if self.flat is not None:
+                self.flat.copy_(self.pinned_flat[slot], non_blocking=True)
+            else:
+                for dst, src in zip(self.static, self.pinned[slot]):
+                    dst.copy_(src, non_blocking=True)              # stream-ordered behind the previous replay's reads
             ev = torch.cuda.Event()
             ev.record(cur)
             self.h2d_done[slot] = ev

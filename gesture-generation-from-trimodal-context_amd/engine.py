@@ -240,6 +240,10 @@ class GeneratorEngine(_Engine):
         # as the input-gradient operand [Ci][2 Co] (model/tcn.py:19,25)
         names = [f"{te}.tcn.network.{i}.{c}" for i in range(self.n_layers) for c in ("conv1", "conv2")]
         wps, wts = ops.weight_norm_fwd_batch([P[n + ".weight_v"] for n in names], [P[n + ".weight_g"] for n in names], want_t=training)
+        # many-row forward (the stacked calls of a training iteration): the eight packed weights pre-split in ONE pass, so that the convs run on
+        # the mover-wave kernel (csrc/gemm_mw.hip: weights global -> LDS by DMA); conv j's rows start at j * Co of the plane buffer
+        Co_w = wps.shape[1]
+        w_pl = ops.split3_planes(wps.view(len(names) * Co_w, wps.shape[2])) if (ops.GEMM_PLANES and Bs * T >= 8192) else None
         # the eight dropout masks of the block convs: injected (tests) or ONE draw launch; each rides in its conv's GEMM epilogue
         sites = [f"{tag}.tcn{i}.drop{ci + 1}" for i in range(self.n_layers) for ci in range(2)]
         masks = [None] * len(sites)
@@ -269,9 +273,10 @@ class GeneratorEngine(_Engine):
                 if ci == 1 and fuse_res:
                     y = torch.empty_like(cur)
                     o = L.conv_fwd(h, wps[j], P[names[j] + ".bias"], 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=m, res=cur, out2=y,
-                                   res_slope=0.0)
+                                   res_slope=0.0, w_planes=w_pl, w_row0=j * Co_w)
                 else:
-                    o = L.conv_fwd(h, wps[j], P[names[j] + ".bias"], 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=m)
+                    o = L.conv_fwd(h, wps[j], P[names[j] + ".bias"], 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=m, w_planes=w_pl,
+                                   w_row0=j * Co_w)
                 blk[f"in{ci}"], blk[f"wt{ci}"], blk[f"o{ci}"], blk[f"m{ci}"] = h, (wts[j] if wts is not None else None), o, m
                 h = o
             if y is None:

@@ -186,7 +186,7 @@ def conv_out_len(L, kw, stride=1, pad=0, dil=1):
 
 
 def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=1.0, rows_out=None, out_scale=None, res=None, out2=None,
-             res_slope=0.0):
+             res_slope=0.0, w_planes=None, w_row0=0):
     """x: (B, L, Ci) view; w_packed: [Co, kw*Ci]; out: (B, Lout, Co) view (may be a channel slice of a wider buffer).
     res / out2 (ops.nt_ext_supported only): out2 = leaky_relu(out + res, res_slope) written by the same launch."""
     B, L, _ = x.shape
@@ -197,7 +197,7 @@ def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=
     assert tuple(out.shape) == (B, Lo, Co) and out.stride(2) == 1
     A = Win.conv(x, kw, stride=stride, pad=pad, dil=dil, rows_out=Lo)
     ops.gemm_nt(A, w_packed, b, out, act_slope=act_slope, c_batch_stride=out.stride(0), c_row_stride=out.stride(1),
-                c_rows_out=Lo, out_scale=out_scale, res=res, out2=out2, res_slope=res_slope)
+                c_rows_out=Lo, out_scale=out_scale, res=res, out2=out2, res_slope=res_slope, w_planes=w_planes, w_row0=w_row0)
     return out
 
 
@@ -414,7 +414,7 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     for l in range(n_layers):
         Kin = cur.shape[2]
         gi = empty(2, B, T, 3 * H, like=x)
-        if ops.GEMM_PLANES and B * T >= 8192 and H > 64 and Kin >= 256:
+        if ops.GEMM_PLANES_BOTH and B * T >= 8192 and H > 64 and Kin >= 256:
             # pre-split operands (many-row projections of the stacked forward): the layer input is split into bf16 x 3 planes once (not by each of
             # the column tiles that stage it), the weights once per optimiser step (WeightPrep); mover waves then DMA both into LDS
             a_pl = ops.split3_planes(cur.view(B * T, Kin))
@@ -422,8 +422,11 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
                                            out=gi[d].view(B * T, 3 * H)) for d, sfx in enumerate(("", "_reverse"))])
         else:
             a_win = Win.plain(cur.view(B * T, Kin))
+            # many-row projections (the stacked forward): pre-split weights let the mover-wave kernel take them (csrc/gemm_mw.hip)
+            wpl = (lambda w: weight_planes(w)) if (ops.GEMM_PLANES and B * T >= 8192 and H > 64) else (lambda w: None)
             ops.gemm_nt_group([dict(A=a_win, W=P[f"{prefix}.weight_ih_l{l}{sfx}"], bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
-                                    out=gi[d].view(B * T, 3 * H)) for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
+                                    out=gi[d].view(B * T, 3 * H), w_planes=wpl(P[f"{prefix}.weight_ih_l{l}{sfx}"]))
+                               for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
         y = empty(B, T, 2 * H, like=x)
         sv = empty(2, B, T, 4 * H, like=x) if save else None
         whh = (P[f"{prefix}.weight_hh_l{l}"], P[f"{prefix}.weight_hh_l{l}_reverse"])

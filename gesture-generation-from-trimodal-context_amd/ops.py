@@ -80,7 +80,7 @@ class Win:
 
 
 def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, M=None,
-                b_seg=None, out_scale=None, gate=None, res=None, out2=None, res_slope=0.0):
+                b_seg=None, out_scale=None, gate=None, res=None, out2=None, res_slope=0.0, w_planes=None, w_row0=0):
     """Checked tg_gemm_nt_problem.  b_seg = (seg_k, seg_stride_floats): K-concatenated weights, W is the first [N, seg_k] segment and
     segment s starts seg_stride_floats * s floats after it (the caller keeps every segment alive).
     Epilogue extensions (big-product path only, nt_ext_supported): gate -- keep the result where gate > 0, zero elsewhere; res + out2 --
@@ -108,6 +108,9 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
     q.bias = bias.data_ptr() if bias is not None else None
     q.C, q.c_batch_stride, q.c_row_stride, q.c_rows_out = out.data_ptr(), c_batch_stride, c_row_stride, c_rows_out
     q.M, q.N, q.act_slope, q.accumulate = M, N, float(act_slope), int(bool(accumulate))
+    if w_planes is not None:                   # Planes that hold W's rows from w_row0 on (split3_planes / layers.weight_planes): mover-wave kernel
+        assert b_seg is None and w_planes.cw == A.K and 0 <= w_row0 and w_row0 + N <= w_planes.rows and w_planes.t.is_cuda, (w_planes.rows, N, w_planes.cw, A.K)
+        q.b_planes, q.b_plane_stride, q.b_rows, q.b_row0 = w_planes.t.data_ptr(), w_planes.plane_stride, w_planes.rows, int(w_row0)
     if out_scale is not None:                  # element-wise multiplier applied after the activation, addressed exactly like `out`
         _f32(out_scale, "out_scale")
         assert out_scale.shape == out.shape and out_scale.stride() == out.stride(), (out_scale.shape, out.shape)
@@ -181,6 +184,9 @@ def gemm_nt_group(problems):
 # matrix waves multiply (no split arithmetic competing with the MFMAs for the SIMDs' issue ports).  TG_GEMM_PLANES=0: fp32 operands, split
 # while staged (gemm_mw.hip / gemm_split.hip).
 GEMM_PLANES = os.environ.get("TG_GEMM_PLANES", "1") != "0"
+# both operands pre-split (tg_gemm_nt_planes_group, all-DMA movers): measured no faster than pre-split weights + fp32 activations on the GRU
+# projections (a CU cannot take in 6 bytes per operand element at the matrix pipe's pace) and it costs a split pass: opt-in
+GEMM_PLANES_BOTH = os.environ.get("TG_GEMM_PLANES_BOTH", "0") != "0"
 
 
 class Planes:
@@ -330,6 +336,14 @@ def gemm_tn_group(problems):
     keep = []
     arr = (_lib.TnProblem * len(problems))(*[_tn_problem(keep=keep, **p)[0] for p in problems])
     call("tg_gemm_tn_group", arr, len(problems), _stream())
+
+
+def tn_kernel_plan(problems):
+    """0 = f32-MFMA tiles, 1 = bf16 x 3 staged slabs (gemm_split.hip), 2 = bf16 x 3 mover waves (gemm_tn_mw.hip) for a group given as
+    gemm_tn_group's list of dicts."""
+    keep = []
+    arr = (_lib.TnProblem * len(problems))(*[_tn_problem(keep=keep, **p)[0] for p in problems])
+    return int(_lib.load().tg_gemm_tn_kernel_plan(arr, len(problems)))
 
 
 def colsum(X, out, *, accumulate=True):

@@ -73,6 +73,8 @@ class GanTrainer:
         self.g_opt = FusedAdam(self.G, lr=self.hp["learning_rate"], betas=(0.5, 0.999))
         self.d_opt = FusedAdam(self.D, lr=self.hp["learning_rate"] * self.hp["discriminator_lr_weight"], betas=(0.5, 0.999))
         self.grad_sync = grad_sync          # ddp.GradSync or None
+        self.keep_tape = False              # tests: keep the last stacked generator forward's tape in self.last_tape (holds its activations alive)
+        self.last_tape = None
         self.prep = L.WeightPrep()          # transposed / packed weight operands, refreshed once per optimiser step
         self._cut = None                    # set by GraphedGanStep while capturing: cuts the graph at sync points
 
@@ -165,6 +167,8 @@ class GanTrainer:
         text_s = in_text.contiguous().repeat(ng, 1) if ng > 1 else in_text.contiguous()
         res = G.forward(pre_s, text_s, in_audio.float(), vid_s, training=True, groups=ng, save=True,
                         inject=_stack_inject(inject, tags, "g"), tag="g", save_rows=(i2 * B, B))     # only call g2 is differentiated (:50-88)
+        if self.keep_tape:
+            self.last_tape = res["tape"]
         sl = lambda t, i: None if t is None else t[i * B:(i + 1) * B]
         st = dict(B=B, target=target, res=res, i2=i2, ng=ng, out2=sl(res["out"], i2), out3=sl(res["out"], ng - 1),
                   z2=sl(res["z"], i2), z3=sl(res["z"], ng - 1), mu2=sl(res["mu"], i2), lv2=sl(res["logvar"], i2))
@@ -241,7 +245,12 @@ class GraphedGanStep:
             capture_collectives = os.environ.get("TG_DDP_CAPTURE", "1") != "0"
         self.capture_collectives = bool(capture_collectives) and trainer.grad_sync is not None
         self.trainer, self.epoch = trainer, epoch
-        self.static = [t.clone() for t in (in_text, in_audio, target, vid)]
+        # the step's inputs live in ONE buffer (views): a feeder moves a whole batch in with a single copy (data.DeviceBatchFeeder)
+        from .data import packed_like
+        self.static_flat, views = packed_like((in_text, in_audio, target, vid))
+        self.static = list(views)
+        for dst, src in zip(self.static, (in_text, in_audio, target, vid)):
+            dst.copy_(src)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                                   # warm-up outside capture (allocator, lazy init)

@@ -87,9 +87,10 @@ typedef struct tg_gemm_nt_problem {
     int32_t accumulate;
     const float* out_scale;    /* NULL, or an element-wise multiplier applied after the activation, addressed like C: the inverted-dropout
                                   scale mask of F.dropout(relu(conv(x))) (model/tcn.py:22-29) rides in the epilogue */
-    const void* reserved_ptr;  /* must be NULL / 0 (ABI 2 carried optional pre-split weight planes here; pre-split operands now go through */
-    int64_t reserved_i64;      /*   tg_gemm_nt_planes_group, both operands) */
-    int32_t reserved_i32, reserved2;
+    const void* b_planes;      /* NULL, or Bw PRE-SPLIT: plane 0 of a slab-tiled bf16 x 3 plane buffer (see tg_split3_planes below) of b_rows rows */
+    int64_t b_plane_stride;    /*   and K columns whose rows b_row0 .. b_row0 + N - 1 are Bw's (planes b_plane_stride elements apart; one weight */
+    int32_t b_rows, b_row0;    /*   matrix only: b_seg_k == 0).  Many-row products then run on the mover-wave kernel (csrc/gemm_mw.hip): the weights go
+                                    global -> LDS by DMA, only the activation is split while staged.  Ignored by the other kernels (Bw is still read). */
     /* Epilogue extensions (big-product path only, tg_gemm_nt_ext_supported): what the reference computes right after the product in
      * model/tcn.py:27-45 without another pass over the tensor.  All three are addressed like C.
      *   gate : the result (after act / out_scale) is kept where gate > 0 and zeroed elsewhere -- ReLU backward through the tensor the
@@ -172,6 +173,9 @@ typedef struct tg_gemm_tn_problem {
 } tg_gemm_tn_problem;
 /* tg_gemm_tn_group: up to 8 independent weight gradients in ONE launch (the four of a GRU layer: W_ih / W_hh of both directions). */
 int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, void* stream);
+/* which kernel the group would run on, without launching: 0 = f32-MFMA tiles, 1 = bf16 x 3 staged slabs (gemm_split.hip), 2 = bf16 x 3 mover
+ * waves (gemm_tn_mw.hip: persistent 768-thread workgroups, 192 x 160 tiles); -1 invalid.  Test / profiling aid like tg_gemm_nt_kernel_plan. */
+int32_t tg_gemm_tn_kernel_plan(const tg_gemm_tn_problem* problems, int32_t n);
 int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, float* dW, int64_t ldw, int32_t M, int32_t N,
                int32_t out_kw, float* dbias, float* ws, int64_t ws_floats, void* stream);
 

@@ -175,6 +175,20 @@ def wav_encoder(st, audio, training, prefix="audio_encoder.feat_extractor"):
     return x.transpose(1, 2)
 
 
+def wav_preacts(st, audio, prefix="audio_encoder.feat_extractor"):
+    """The three train-mode BatchNorm outputs of WavEncoder (multimodal_context_net.py:13-21), i.e. the LeakyReLU PRE-activations, channel-first
+    (B, C, L), without touching the running statistics.  Test aid: where a pre-activation is within rounding of zero, two correct
+    implementations may take different sides of the LeakyReLU (a 'gate flip'), which moves the gradients below it discontinuously."""
+    outs = []
+    x = audio.unsqueeze(1)
+    for conv, bn, stride, pad in ((0, 1, 5, 1600), (3, 4, 6, 0), (6, 7, 6, 0)):
+        x = F.conv1d(x, st[f"{prefix}.{conv}.weight"], st[f"{prefix}.{conv}.bias"], stride=stride, padding=pad)
+        pre = batch_norm(x, st, f"{prefix}.{bn}", True, update_stats=False)
+        outs.append(pre.detach())
+        x = leaky(pre, 0.3)
+    return outs
+
+
 def tcn_block(x, st, prefix, dilation, p_drop, training, rand, tag):
     """TemporalBlock (model/tcn.py:16-46) on (B,C,T): two weight-normed causal dilated k=2 convs,
     each ReLU + dropout, then relu(out + x).  Causal = pad d both sides, chomp the last d."""

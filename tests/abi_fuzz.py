@@ -57,6 +57,7 @@ def fuzz(lib_path=None):
     assert lib.tg_gemm_nt_ext_supported(None) == 0
     assert lib.tg_gemm_nt_kernel_plan(None, 1, None, None) == -1 and lib.tg_gemm_nt_kernel_plan(None, 0, None, None) == -1
     assert lib.tg_set_nt_mover_waves(7) != 0 and lib.tg_set_nt_mover_waves(-2) != 0 and lib.tg_set_nt_mover_waves(-1) == 0
+    assert lib.tg_gemm_tn_kernel_plan(None, 1) == -1 and lib.tg_gemm_tn_kernel_plan((L.TnProblem * 2)(), 2) == -1
     zeroed = (L.NtProblem * 2)()
     assert lib.tg_gemm_nt_kernel_plan(zeroed, 2, None, None) == -1 and lib.tg_gemm_nt_kernel_plan(zeroed, 99, None, None) == -1
     assert lib.tg_bn_fused_supported(0, 0, 0) == 0 and lib.tg_bn_fused_supported(4096, 16, 2) == 1

@@ -134,6 +134,20 @@ def run_train_parity(pkg, dev, batch=4, epochs=(0, 11), n_words=512, n_speakers=
     return worst
 
 
+def wav_gate_flips(tape, preacts, near=2e-6):
+    """LeakyReLU gates of the audio encoder: HIP path against the fp64 oracle.  tape: GanTrainer.last_tape of the iteration; preacts:
+    oracle.wav_preacts on the same weights and audio.  Returns per layer (elements, near-ties |pre| < near (normalised pre-activations are O(1)),
+    elements where the HIP path's post-activation has the other sign)."""
+    out = []
+    for li, pre in enumerate(preacts, start=1):
+        x = tape["wav"][li][0]                                   # (Ba, L, C) channel-last post-activation = the input of conv li + 1
+        mine = x[:pre.shape[0]].detach().double().cpu().transpose(1, 2)
+        assert mine.shape == pre.shape, (mine.shape, pre.shape)
+        flips = int(((mine > 0) != (pre > 0)).sum())
+        out.append((pre.numel(), int((pre.abs() < near).sum()), flips))
+    return out
+
+
 class _NoDrop(O.Rand):
     def keep_mask(self, name, shape, p, dtype=torch.float32):
         m = torch.ones(shape, dtype=dtype)

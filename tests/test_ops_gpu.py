@@ -571,7 +571,15 @@ def test_gemm_nt_epilogue_gate_and_residual_output(pkg, dev, M, N, K):
 
 
 def _row_err(out, ref):
-    return float(((out.double().cpu() - ref).abs() / ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)).max())
+    """max over rows of |out - ref| / max|ref row| (rows of the big-shape tests span eight decades); fp64, on the reference's device."""
+    o = out.double().to(ref.device)
+    return float(((o - ref).abs() / ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)).max())
+
+
+def _mm64(x, w):
+    """x @ w^T in fp64 ON THE GPU (torch / rocBLAS dgemm: an independent fp64 reference; the 13 056-row products take seconds per call on the
+    host cores and made the suite twice as long)."""
+    return x.double() @ w.double().t()
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(13000, 900, 600, (128, 192)), (13056, 900, 108, (128, 192)), (13056, 300, 600, (128, 160)),
@@ -588,16 +596,22 @@ def test_gemm_nt_mover_wave_kernel_is_fp32_accurate(pkg, dev, M, N, K, tile):
     bs = [torch.randn(N, generator=g) for _ in range(2)]
     xd = x.to(dev)
     outs = [torch.full((M, N + 8), float("nan"), device=dev) for _ in range(2)]
-    probs = [dict(A=Win.plain(xd), W=w.to(dev), bias=b.to(dev), out=o[:, 4:4 + N], act_slope=0.3) for w, b, o in zip(ws, bs, outs)]
+    wd = [w.to(dev) for w in ws]
+    probs = [dict(A=Win.plain(xd), W=w, bias=b.to(dev), out=o[:, 4:4 + N], act_slope=0.3, w_planes=ops.split3_planes(w)) for w, b, o in zip(wd, bs, outs)]
+    assert ops.nt_kernel_plan([{k: v for k, v in p.items() if k != "w_planes"} for p in probs])[0] == 1      # without pre-split weights: staged-slab kernel
     plan = ops.nt_kernel_plan(probs)
     assert plan == (2,) + tile, plan                          # this test is about the mover-wave kernel: fail if the dispatcher chose another
     ops.gemm_nt_group(probs)
-    for w, b, o in zip(ws, bs, outs):
-        ref = F.leaky_relu(x.double() @ w.double().t() + b.double(), 0.3)
+    for w, b, o in zip(wd, bs, outs):
+        ref = F.leaky_relu(_mm64(xd, w) + b.to(dev).double(), 0.3)
         assert _row_err(o[:, 4:4 + N], ref) < 1e-5
         assert bool(torch.isnan(o[:, :4]).all()) and bool(torch.isnan(o[:, 4 + N:]).all())
-    ops.gemm_nt(Win.plain(xd), ws[0].to(dev), None, outs[0][:, 4:4 + N], accumulate=True)
-    ref2 = F.leaky_relu(x.double() @ ws[0].double().t() + bs[0].double(), 0.3) + x.double() @ ws[0].double().t()
+    # the weights' rows may sit anywhere inside a bigger plane buffer (w_row0): both matrices stacked in one buffer, accumulate form
+    both = ops.split3_planes(torch.cat(wd, 0))
+    acc_p = [dict(A=Win.plain(xd), W=wd[1], bias=None, out=outs[0][:, 4:4 + N], accumulate=True, w_planes=both, w_row0=N)]
+    assert ops.nt_kernel_plan(acc_p)[0] == 2
+    ops.gemm_nt_group(acc_p)
+    ref2 = F.leaky_relu(_mm64(xd, wd[0]) + bs[0].to(dev).double(), 0.3) + _mm64(xd, wd[1])
     assert _row_err(outs[0][:, 4:4 + N], ref2) < 1e-5
 
 
@@ -618,9 +632,11 @@ def test_gemm_nt_mover_wave_kernel_windows_and_epilogues(pkg, dev):
     wp = Lm.pack_conv_weight(w.float().to(dev))
     a_win = Win.conv(xd, 2, pad=d, dil=d, rows_out=T)
     out, out2 = torch.full((B, T, Cc), float("nan"), device=dev), torch.full((B, T, Cc), float("nan"), device=dev)
+    wpl = ops.split3_planes(wp)
     assert ops.nt_kernel_plan([dict(A=a_win, W=wp, bias=b.float().to(dev), out=out, c_batch_stride=out.stride(0), c_row_stride=out.stride(1),
-                                    c_rows_out=T)])[0] == 2
-    o = Lm.conv_fwd(xd, wp, b.float().to(dev), 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=mask.to(dev), res=res.to(dev), out2=out2, out=out)
+                                    c_rows_out=T, w_planes=wpl)])[0] == 2
+    o = Lm.conv_fwd(xd, wp, b.float().to(dev), 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=mask.to(dev), res=res.to(dev), out2=out2, out=out,
+                    w_planes=wpl)
     y = torch.relu(F.conv1d(x, w, b, padding=d, dilation=d)[:, :, :T])
     ref = cl(y) * mask.double()
     assert rel(o, ref) < 1e-5
@@ -634,7 +650,8 @@ def test_gemm_nt_mover_wave_kernel_windows_and_epilogues(pkg, dev):
     dyd = dy.to(dev)
     a_back = Win.taps(dyd, 2, shift=0, dil=d, rows_out=T)
     acc = base.to(dev).clone()
-    probs = [dict(A=a_back, W=wT.to(dev), bias=None, out=acc, gate=gate.to(dev), accumulate=True)]
+    wTd = wT.to(dev)
+    probs = [dict(A=a_back, W=wTd, bias=None, out=acc, gate=gate.to(dev), accumulate=True, w_planes=ops.split3_planes(wTd))]
     assert ops.nt_kernel_plan(probs)[0] == 2
     ops.gemm_nt_group(probs)
     dyp = torch.cat([dy.double(), torch.zeros(B, d, Cc, dtype=torch.float64)], dim=1)
@@ -648,10 +665,10 @@ def test_gemm_nt_mover_wave_kernel_windows_and_epilogues(pkg, dev):
     wbuf = (torch.randn(3, N, Kh, generator=g) * 0.1).to(dev)
     a_cat = Win(dgi, batches=1, batch_stride=0, row_stride=Kh, rows_in=2 * Mh, rows_out=Mh, cw=Kh, K=2 * Kh, dil=Mh)
     outc = torch.full((Mh, N), float("nan"), device=dev)
-    assert ops.nt_kernel_plan([dict(A=a_cat, W=wbuf[0], bias=None, out=outc, b_seg=(Kh, 2 * N * Kh))])[0] == 2
+    assert ops.nt_kernel_plan([dict(A=a_cat, W=wbuf[0], bias=None, out=outc, b_seg=(Kh, 2 * N * Kh))])[0] == 1        # weight segments: staged-slab kernel
     ops.gemm_nt(a_cat, wbuf[0], None, outc, b_seg=(Kh, 2 * N * Kh))
-    refc = dgi[0].double().cpu() @ wbuf[0].double().cpu().t() + dgi[1].double().cpu() @ wbuf[2].double().cpu().t()
-    assert rel(outc, refc) < 1e-5
+    refc = _mm64(dgi[0], wbuf[0]) + _mm64(dgi[1], wbuf[2])
+    assert float((outc.double() - refc).abs().max() / refc.abs().max()) < 1e-5
 
 
 def test_bf16_math_mode_tier(pkg, dev):
@@ -780,6 +797,51 @@ def test_gemm_tn_split_bf16x3_path_is_fp32_accurate(pkg, dev, M, N, K):
     assert rel(db, dy.double().sum(0)) < 1e-5
     ops.gemm_tn(dy.to(dev), Win.plain(x.to(dev)), dw, dbias=db)
     assert float(((dw.double().cpu() - 2 * ref).abs() / scale).max()) < 1e-5
+
+
+def test_gemm_tn_mover_wave_kernel(pkg, dev):
+    """csrc/gemm_tn_mw.hip on the groups it is chosen for: the four weight gradients of a GRU layer at B = 128 (dW_ih, dW_hh of both
+    directions with their bias gradients -- the bias gradient rides in the product as a column of ones; multimodal_context_net.py:98-99
+    backward) and a text-encoder-sized group over a two-tap conv window with padding (model/tcn.py:19-46 backward), against fp64:
+    accumulation into non-zero dW / dbias, ragged M (row splits), N and K tails, 8-decade operands."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    g = torch.Generator().manual_seed(21)
+    M, H = 4352 - 37, 300
+    dgi = [(torch.randn(M, 3 * H, generator=g) * torch.pow(10.0, torch.randint(-3, 3, (M, 1), generator=g).float())).to(dev) for _ in range(2)]
+    x = torch.randn(M, 2 * H, generator=g).to(dev)
+    hp = torch.randn(M, H, generator=g).to(dev)
+    probs, refs = [], []
+    for d in range(2):
+        for A, Kc in ((x, 2 * H), (hp, H)):
+            dW = torch.randn(3 * H, Kc, generator=g).to(dev)
+            db = torch.randn(3 * H, generator=g).to(dev)
+            refs.append((dW.double() + dgi[d].double().t() @ A.double(), db.double() + dgi[d].double().sum(0)))
+            probs.append(dict(dY=dgi[d], A=Win.plain(A), dW=dW, dbias=db))
+    assert ops.tn_kernel_plan(probs) == 2
+    ops.gemm_tn_group(probs)
+    for p, (rw, rb) in zip(probs, refs):
+        e_w = float((p["dW"].double() - rw).abs().max() / rw.abs().max())
+        e_b = float((p["dbias"].double() - rb).abs().max() / rb.abs().max())
+        assert e_w < 1e-5 and e_b < 1e-5, (e_w, e_b)
+    # conv window with causal padding: dW[co][tap * Ci + ci] += sum_(b, t) dy[b][t][co] * x[b][t - (1 - tap) * d][ci]  (zero before the clip)
+    B, T, C, d = 128, 34, 300, 4
+    xs = torch.randn(B, T, C, generator=g).to(dev)
+    cprobs, crefs = [], []
+    for j in range(3):
+        dy = torch.randn(B * T, C, generator=g).to(dev)
+        dW = torch.zeros(C, 2 * C, device=dev)
+        db = torch.zeros(C, device=dev)
+        xpad = torch.cat([torch.zeros(B, d, C, device=dev, dtype=torch.float64), xs.double()], dim=1)            # row t + d = x[t]
+        a_cat = torch.cat([xpad[:, :T], xpad[:, d:d + T]], dim=2).reshape(B * T, 2 * C)                             # taps (t - d, t)
+        crefs.append((dy.double().t() @ a_cat, dy.double().sum(0)))
+        cprobs.append(dict(dY=dy, A=Win.conv(xs, 2, pad=d, dil=d, rows_out=T), dW=dW, dbias=db))
+    assert ops.tn_kernel_plan(cprobs) == 2
+    ops.gemm_tn_group(cprobs)
+    for p, (rw, rb) in zip(cprobs, crefs):
+        assert float((p["dW"].double() - rw).abs().max() / rw.abs().max()) < 1e-5
+        assert float((p["dbias"].double() - rb).abs().max() / rb.abs().max()) < 1e-5
+    # small groups stay on the staged-slab kernel
+    assert ops.tn_kernel_plan([dict(dY=dgi[0][:1100, :52], A=Win.plain(x[:1100, :76]), dW=torch.zeros(52, 76, device=dev))]) in (0, 1)
 
 
 def test_gemm_tn_split_with_conv_window(pkg, dev):
@@ -942,12 +1004,12 @@ def test_gemm_nt_planes_mover_wave_dma_kernel(pkg, dev, M, N, K):
     out = torch.full((2, M, N), float("nan"), device=dev)
     ops.gemm_nt_planes_group([dict(A=a_pl, Bp=ops.split3_planes(w[i]), bias=b[i], out=out[i], act_slope=0.3) for i in range(2)])
     for i in range(2):
-        ref = F.leaky_relu(x.double().cpu() @ w[i].double().cpu().t() + b[i].double().cpu(), 0.3)
+        ref = F.leaky_relu(_mm64(x, w[i]) + b[i].double(), 0.3)
         assert _row_err(out[i], ref) < 1e-5
     mask = (torch.rand(M, N, generator=g) > 0.3).float().to(dev) * 1.25
     base = out[0].clone()
     ops.gemm_nt_planes_group([dict(A=a_pl, Bp=ops.split3_planes(w[1]), bias=None, out=out[0], accumulate=True, out_scale=mask)])
-    ref2 = base.double().cpu() + (x.double().cpu() @ w[1].double().cpu().t()) * mask.double().cpu()
+    ref2 = base.double() + _mm64(x, w[1]) * mask.double()
     assert _row_err(out[0], ref2) < 1e-5
     if K == 600 and N == 300:
         B, T, Ci, Co, d = 384, 34, 300, 300, 8

@@ -32,7 +32,7 @@ def group(M, N, K, n):
     ws = [torch.randn(N, K, device=dev) * 0.05 for _ in range(n)]
     bs = [torch.randn(N, device=dev) for _ in range(n)]
     outs = [torch.empty(M, N, device=dev) for _ in range(n)]
-    probs = [dict(A=Win.plain(x), W=w, bias=b, out=o) for w, b, o in zip(ws, bs, outs)]
+    probs = [dict(A=Win.plain(x), W=w, bias=b, out=o, w_planes=ops.split3_planes(w)) for w, b, o in zip(ws, bs, outs)]
     return probs, 2.0 * M * N * K * n, (x, ws, bs, outs)
 
 
@@ -42,7 +42,7 @@ def tcn(B, T, C, d):
     b = torch.randn(C, device=dev)
     mask = (torch.rand(B, T, C, device=dev) > 0.3).float() / 0.7
     out = torch.empty(B, T, C, device=dev)
-    probs = [dict(A=Win.conv(x, 2, pad=d, dil=d, rows_out=T), W=wp, bias=b, out=out, act_slope=0.0, out_scale=mask,
+    probs = [dict(A=Win.conv(x, 2, pad=d, dil=d, rows_out=T), W=wp, bias=b, out=out, act_slope=0.0, out_scale=mask, w_planes=ops.split3_planes(wp),
                   c_batch_stride=out.stride(0), c_row_stride=out.stride(1), c_rows_out=T)]
     return probs, 2.0 * B * T * C * 2 * C, (x, wp, b, mask, out)
 
