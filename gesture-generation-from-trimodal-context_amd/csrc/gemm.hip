@@ -658,7 +658,7 @@ extern "C" int tg_get_math_mode(void);
 int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s);
 int tg_gemm_tn_split_launch(const TnGroup& g, int total_wgs, int tnw, int tkw, hipStream_t s);
 bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid);
-int tg_gemm_tn_mw_launch(const TnGroup& g, int grid, hipStream_t s);
+int tg_gemm_tn_mw_launch(const TnGroup& g, int grid, int splits, hipStream_t s);
 static bool use_split_path() {
     static int x3 = -1;
     if (x3 < 0) {
@@ -919,12 +919,14 @@ static int tn_group_impl(const tg_gemm_tn_problem* problems, int32_t n, void* st
     g.n = n;
     // bf16 x 3 kernel (gemm_split.hip) when every problem is on the vectorisable layout and long enough to amortise its 32-row slabs
     bool x3 = use_split_path() && tg_get_math_mode() == 0;
+    bool mw_ok = use_split_path();                                     // the mover-wave kernel also has the plain-bf16 form (math mode 1)
     bool two_pass = false;            // workspaces are sized for the 64 x 64 tile's split plan (tg_gemm_tn_ws_floats)
     for (int i = 0; i < n; ++i) {
         const tg_gemm_tn_problem& q = problems[i];
         TG_REQUIRE(q.A.ptr && q.A.cw > 0 && q.A.K > 0 && q.N > 0, "tg_gemm_tn: bad arguments (problem %d)", i);
         const bool vec = (q.ldy % 4 == 0) && aligned16(q.dY) && (q.A.cw % 4 == 0) && (q.A.batch_stride % 4 == 0) && (q.A.row_stride % 4 == 0) && aligned16(q.A.ptr);
         x3 = x3 && vec && q.N % 4 == 0 && q.A.K % 4 == 0 && q.M >= 1024 && q.N >= 48 && q.A.K >= 48;
+        mw_ok = mw_ok && vec;
         two_pass = two_pass || q.ws != nullptr;
     }
     // tile (tools/tn_tile_lab.py, profiles/r2_tn_tile_lab.txt): 64 x 64, or 128 x 64 when every problem has >= 512 output rows; 128 x 128
@@ -950,11 +952,11 @@ static int tn_group_impl(const tg_gemm_tn_problem* problems, int32_t n, void* st
     for (int i = n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
     for (int i = n; i < TG_MAX_GROUP; ++i) g.p[i] = g.p[0];
     hipStream_t s = (hipStream_t)stream;
-    if (x3 && !two_pass) {          // big gradients whose 192 x 160 tiles fill the chip: mover-wave kernel (gemm_tn_mw.hip)
+    if (mw_ok && !two_pass) {       // big gradients whose 192 x 160 tiles fill the chip: mover-wave kernel (gemm_tn_mw.hip), bf16 x 3 or plain bf16
         int grid = 0, mw_splits[TG_MAX_GROUP];
         if (tg_gemm_tn_mw_plan(g, mw_splits, &grid)) {
             if (plan_only) { *plan_only = 2; return 0; }
-            return tg_gemm_tn_mw_launch(g, grid, s);
+            return tg_gemm_tn_mw_launch(g, grid, tg_get_math_mode() == 1 ? 1 : 3, s);
         }
     }
     if (plan_only) { *plan_only = x3 ? 1 : 0; return 0; }

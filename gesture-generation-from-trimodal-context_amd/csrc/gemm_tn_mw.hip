@@ -34,20 +34,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tw_rsrc(const void* base, unsi
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), TW_RSRC3);
 }
 
-__device__ __forceinline__ void tw_split4(const f32x4 v, u32x2 (&out)[3]) {
+template <int NS>
+__device__ __forceinline__ void tw_split4(const f32x4 v, u32x2 (&out)[NS]) {
+    if constexpr (NS == 1) {                         // plain bf16 tier (math mode 1): round to nearest even
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 r;
+        r[0] = (__bf16)v[0]; r[1] = (__bf16)v[1]; r[2] = (__bf16)v[2]; r[3] = (__bf16)v[3];
+        out[0] = __builtin_bit_cast(u32x2, r);
+        return;
+    }
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float xf = v[i];
         split3_bits(xf, h[i], m[i], l[i]);
     }
-    out[0] = u32x2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])};
-    out[1] = u32x2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])};
-    out[2] = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
+    if constexpr (NS == 3) {
+        out[0] = u32x2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])};
+        out[1] = u32x2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])};
+        out[2] = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
+    }
 }
 
-// wave tile (16 TNT) x (16 TKT) of dW; matrix waves WNW (n) x WKW (k); workgroup tile BN x BK
-template <int TNT, int TKT, int WNW, int WKW>
+// wave tile (16 TNT) x (16 TKT) of dW; matrix waves WNW (n) x WKW (k); workgroup tile BN x BK.  NS = 3: bf16 x 3 (fp32-accurate); NS = 1: plain
+// bf16 operands (math mode 1)
+template <int TNT, int TKT, int WNW, int WKW, int NS>
 __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
     static_assert(WNW * WKW == 8, "eight matrix waves");
     constexpr int BN = 16 * TNT * WNW, BK = 16 * TKT * WKW;
@@ -58,8 +69,8 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
     constexpr int NPY = 32 * PY / 256, NPX = 32 * PX / 256;    // pieces per mover thread and slab
     static_assert(32 * PY % 256 == 0 && 32 * PX % 256 == 0, "whole pieces per mover thread");
     constexpr int Y_PLANE = 32 * LDN, X_PLANE = 32 * LDK;      // bf16 elements
-    __shared__ __attribute__((aligned(16))) __bf16 ys[2][3][Y_PLANE];
-    __shared__ __attribute__((aligned(16))) __bf16 xs[2][3][X_PLANE];
+    __shared__ __attribute__((aligned(16))) __bf16 ys[2][NS][Y_PLANE];
+    __shared__ __attribute__((aligned(16))) __bf16 xs[2][NS][X_PLANE];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int total_items = g.wg_begin[TG_MAX_GROUP];
@@ -187,10 +198,10 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
         auto stage = [&](int buf) {
 #pragma unroll
             for (int i = 0; i < NPY; ++i) {
-                u32x2 o[3];
-                tw_split4(__builtin_bit_cast(f32x4, gy[i]), o);
+                u32x2 o[NS];
+                tw_split4<NS>(__builtin_bit_cast(f32x4, gy[i]), o);
 #pragma unroll
-                for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x2*>(&ys[buf][s][0] + ypos[i]) = o[s];
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&ys[buf][s][0] + ypos[i]) = o[s];
             }
 #pragma unroll
             for (int i = 0; i < NPX; ++i) {
@@ -198,10 +209,10 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
                 const int e = ((rowok >> i) & 1u) ? one_el[i] : -1;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = e == q ? 1.0f : v[q];
-                u32x2 o[3];
-                tw_split4(v, o);
+                u32x2 o[NS];
+                tw_split4<NS>(v, o);
 #pragma unroll
-                for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x2*>(&xs[buf][s][0] + xpos[i]) = o[s];
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&xs[buf][s][0] + xpos[i]) = o[s];
             }
         };
         next_item();
@@ -225,24 +236,26 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
         const int wn = wave / WKW, wk = wave % WKW;
         const int r16 = lane & 15, kq = lane >> 4;
         f32x4 acc[TNT][TKT];
-        bf16x8 fa[2][3], fb[3][TKT];
-        auto load_fa = [&](bf16x8 (&f)[3], int buf, int nt) {
+        bf16x8 fa[2][NS], fb[NS][TKT];
+        auto load_fa = [&](bf16x8 (&f)[NS], int buf, int nt) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) f[s] = YI::frag(&ys[buf][s][0], wn * (16 * TNT) + nt * 16, r16, kq);
+            for (int s = 0; s < NS; ++s) f[s] = YI::frag(&ys[buf][s][0], wn * (16 * TNT) + nt * 16, r16, kq);
         };
         auto load_fb = [&](int buf, auto kt_c) {
             constexpr int kt = decltype(kt_c)::value;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) fb[s][kt] = XI::frag(&xs[buf][s][0], wk * (16 * TKT) + kt * 16, r16, kq);
+            for (int s = 0; s < NS; ++s) fb[s][kt] = XI::frag(&xs[buf][s][0], wk * (16 * TKT) + kt * 16, r16, kq);
         };
-        auto mma = [&](const bf16x8 (&f)[3], auto nt_c, auto kt_c) {       // the six significant partial products, smallest first
+        auto mma = [&](const bf16x8 (&f)[NS], auto nt_c, auto kt_c) {       // the six significant partial products, smallest first
             constexpr int nt = decltype(nt_c)::value, kt = decltype(kt_c)::value;
             f32x4 cc = acc[nt][kt];
-            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], fb[0][kt], cc, 0, 0, 0);
-            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], fb[2][kt], cc, 0, 0, 0);
-            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], fb[1][kt], cc, 0, 0, 0);
-            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], fb[0][kt], cc, 0, 0, 0);
-            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], fb[1][kt], cc, 0, 0, 0);
+            if constexpr (NS == 3) {
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], fb[0][kt], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], fb[2][kt], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], fb[1][kt], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], fb[0][kt], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], fb[1][kt], cc, 0, 0, 0);
+            }
             acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], fb[0][kt], cc, 0, 0, 0);
         };
         int n = 0;
@@ -398,7 +411,8 @@ bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid) {
     return true;
 }
 
-int tg_gemm_tn_mw_launch(const TnGroup& g, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2>), dim3(grid), dim3(768), 0, s, g);
+int tg_gemm_tn_mw_launch(const TnGroup& g, int grid, int splits, hipStream_t s) {
+    if (splits == 3) hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 3>), dim3(grid), dim3(768), 0, s, g);
+    else hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 1>), dim3(grid), dim3(768), 0, s, g);
     return check_launch("tg_gemm_tn(mover waves)");
 }

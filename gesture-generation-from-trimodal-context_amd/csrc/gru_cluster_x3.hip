@@ -63,8 +63,25 @@ __device__ __forceinline__ void xc_split4(const f32x4 v, u32x2 (&out)[3]) {
     out[2] = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
 }
 
+// plain-bf16 tier (math mode 1): one term per operand, rounded to nearest even; plane 0 of the exchange buffer carries it
+__device__ __forceinline__ bf16x8 xc_rne8(const f32x4 a, const f32x4 b) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = (__bf16)a[i]; r[4 + i] = (__bf16)b[i]; }
+    return r;
+}
+__device__ __forceinline__ u32x2 xc_rne4(const f32x4 v) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (__bf16)v[i];
+    return __builtin_bit_cast(u32x2, r);
+}
+
 // wa: hi and mid planes of the weight fragment (registers); w_lo: its lo plane (read back from LDS: it feeds one MFMA in six)
-__device__ __forceinline__ f32x4 xc_mma(const bf16x8 (&wa)[2], const bf16x8 w_lo, const bf16x8 (&fb)[3], f32x4 acc) {
+template <int NS>
+__device__ __forceinline__ f32x4 xc_mma(const bf16x8 (&wa)[2], const bf16x8 w_lo, const bf16x8 (&fb)[NS], f32x4 acc) {
+    if constexpr (NS == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo, fb[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], fb[1], acc, 0, 0, 0);
@@ -95,7 +112,7 @@ __device__ __forceinline__ bool xc_wait(gu32x* cl_flags, int CW, int lane, unsig
 
 // exchange buffer (bytes): [slot 2][dir 2][block][plane 3][b_pad rows][32 units] bf16; block = member (forward) or gate * CW + member
 // (backward); plane_bytes = b_pad * 64
-template <int MT>
+template <int MT, int NS>
 __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
     const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
@@ -141,7 +158,8 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
                 const f32x4 a = (ok && k < H) ? *reinterpret_cast<const f32x4*>(src) : z;          // H % 4 == 0
                 const f32x4 b = (ok && k + 4 < H) ? *reinterpret_cast<const f32x4*>(src + 4) : z;
                 bf16x8 pl[3];
-                xc_split8(a, b, pl);
+                if constexpr (NS == 1) { pl[0] = xc_rne8(a, b); pl[1] = pl[2] = pl[0]; }
+                else xc_split8(a, b, pl);
                 wa[g][p][0] = pl[0]; wa[g][p][1] = pl[1];
                 wlo[wave][g * XC_SPS + p][lane] = pl[2];
             }
@@ -219,14 +237,14 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
             __syncthreads();                        // the other waves load only behind the polling wave's barrier
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // compiler ordering only; every load below is sc1
             const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes;
-            bf16x8 fb[XC_SPS][MT][3];
+            bf16x8 fb[XC_SPS][MT][NS];
 #pragma unroll
             for (int p = 0; p < XC_SPS; ++p)
                 if (p < s_cnt) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int s = 0; s < 3; ++s) {
+                        for (int s = 0; s < NS; ++s) {
                             // lane part in the VGPR offset (one register for all 18 loads), wave-uniform part in the scalar offset
                             const int soff = off0 + ((s_beg + p) * 3 + s) * plane_bytes + (b0 + i * 16) * 64;
                             fb[p][i][s] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, r16 * 64 + kq * 16, soff, 16));   // aux 16 = sc1
@@ -238,7 +256,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int g = 0; g < 3; ++g) acc[i][g] = xc_mma(wa[g][p], wlo[wave][g * XC_SPS + p][lane], fb[p][i], acc[i][g]);
+                        for (int g = 0; g < 3; ++g) acc[i][g] = xc_mma<NS>(wa[g][p], wlo[wave][g * XC_SPS + p][lane], fb[p][i], acc[i][g]);
                 }
         }
 #pragma unroll
@@ -271,10 +289,11 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
             // publish h_t as three bf16 planes: 8-byte write-through stores; the 8 threads of a row cover its 64 bytes, a wave's 8 rows
             // four whole 128-byte lines per plane
             u32x2 pl[3];
-            xc_split4(h, pl);
+            if constexpr (NS == 1) pl[0] = xc_rne4(h);
+            else xc_split4(h, pl);
             const int woff = (dir * 2 + (step & 1)) * slot_bytes + m * 3 * plane_bytes + row * 64 + ug * 8;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], hx_rsrc, woff + s * plane_bytes, 0, 16);
+            for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], hx_rsrc, woff + s * plane_bytes, 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY wave drains its stores before the flag
         __syncthreads();                                       // (also: `red` is free again)
@@ -303,6 +322,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
 constexpr int XC_KSB = 8;             // K slices, backward
 constexpr int XC_SPB8 = 4;            // k-steps per slice, backward: ceil(30 / 8)
 
+template <int NS>
 __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     const float* __restrict__ dY, const float* __restrict__ dy_mask, const float* __restrict__ Y, const float* __restrict__ save, long save_ds,
     const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh, long dg_ds,
@@ -349,7 +369,8 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
                 const f32x4 a = (ok && ku < H) ? *reinterpret_cast<const f32x4*>(src) : z;
                 const f32x4 b = (ok && ku + 4 < H) ? *reinterpret_cast<const f32x4*>(src + 4) : z;
                 bf16x8 pl[3];
-                xc_split8(a, b, pl);
+                if constexpr (NS == 1) { pl[0] = xc_rne8(a, b); pl[1] = pl[2] = pl[0]; }
+                else xc_split8(a, b, pl);
                 wa[u][p][0] = pl[0]; wa[u][p][1] = pl[1];
                 wlo[wave][u * XC_SPB8 + p][lane] = pl[2];
             }
@@ -415,19 +436,19 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes + b0 * 64;
-            bf16x8 fb[XC_SPB8][3];
+            bf16x8 fb[XC_SPB8][NS];
 #pragma unroll
             for (int p = 0; p < XC_SPB8; ++p)
                 if (p < s_cnt) {
 #pragma unroll
-                    for (int s = 0; s < 3; ++s)
+                    for (int s = 0; s < NS; ++s)
                         fb[p][s] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(gx_rsrc, r16 * 64 + kq * 16, off0 + ((s_beg + p) * 3 + s) * plane_bytes, 16));
                 }
 #pragma unroll
             for (int p = 0; p < XC_SPB8; ++p)
                 if (p < s_cnt) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[u] = xc_mma(wa[u][p], wlo[wave][u * XC_SPB8 + p][lane], fb[p], acc[u]);
+                    for (int u = 0; u < 2; ++u) acc[u] = xc_mma<NS>(wa[u][p], wlo[wave][u * XC_SPB8 + p][lane], fb[p], acc[u]);
                 }
         }
         red[ks][0][lane] = acc[0];
@@ -452,15 +473,18 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
             // publish this step's dgh tile: blocks (gate 0..2, member m), three bf16 planes each
             const int woff = (dir * 2 + (step & 1)) * slot_bytes + row * 64 + ug * 8;
             u32x2 pl[3];
-            xc_split4(g_r, pl);
+            if constexpr (NS == 1) pl[0] = xc_rne4(g_r);
+            else xc_split4(g_r, pl);
 #pragma unroll
-            for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((0 * CW + m) * 3 + s) * plane_bytes, 0, 16);
-            xc_split4(g_z, pl);
+            for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((0 * CW + m) * 3 + s) * plane_bytes, 0, 16);
+            if constexpr (NS == 1) pl[0] = xc_rne4(g_z);
+            else xc_split4(g_z, pl);
 #pragma unroll
-            for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((1 * CW + m) * 3 + s) * plane_bytes, 0, 16);
-            xc_split4(g_nr, pl);
+            for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((1 * CW + m) * 3 + s) * plane_bytes, 0, 16);
+            if constexpr (NS == 1) pl[0] = xc_rne4(g_nr);
+            else xc_split4(g_nr, pl);
 #pragma unroll
-            for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((2 * CW + m) * 3 + s) * plane_bytes, 0, 16);
+            for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((2 * CW + m) * 3 + s) * plane_bytes, 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -483,6 +507,8 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
 
 using namespace tg;
 
+extern "C" int tg_get_math_mode(void);
+
 // exchange-buffer bytes of the two kernels (the flag block in front of it is laid out by gru_cluster.hip)
 int64_t tg_gru_x3_fwd_exchange_bytes(int b_pad, int cw) { return 4LL * cw * 3 * b_pad * 64; }
 int64_t tg_gru_x3_bwd_exchange_bytes(int b_pad, int cw) { return 4LL * 3 * cw * 3 * b_pad * 64; }
@@ -491,19 +517,23 @@ int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, c
                          float* save, long save_ds, const float* drop_mask, float* y_drop, void* hx, unsigned* flags, unsigned* tmo, int B, int T,
                          int H, int n_bt, int cw, int b_pad, int save_row0, int save_rows, hipStream_t s) {
     dim3 grid(2 * n_bt * cw);
-    if (mt == 1)
-        hipLaunchKernelGGL(gru_seq_fwd_cluster_x3_kernel<1>, grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, drop_mask, y_drop,
-                           hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows);
-    else
-        hipLaunchKernelGGL(gru_seq_fwd_cluster_x3_kernel<2>, grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, drop_mask, y_drop,
-                           hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows);
+    const bool bf16 = tg_get_math_mode() == 1;            // plain bf16 operands: one MFMA per product, one exchange plane
+#define TG_XF(MT_, NS_) hipLaunchKernelGGL((gru_seq_fwd_cluster_x3_kernel<MT_, NS_>), grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, \
+                                           drop_mask, y_drop, hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows)
+    if (mt == 1) { if (bf16) TG_XF(1, 1); else TG_XF(1, 3); }
+    else { if (bf16) TG_XF(2, 1); else TG_XF(2, 3); }
+#undef TG_XF
     return check_launch("tg_gru_forward_cluster(x3)");
 }
 
 int tg_gru_x3_bwd_launch(const float* dy, const float* dy_mask, const float* y, const float* save, long save_ds, const float* wt0, const float* wt1, float* dgi,
                          float* dgh, long dg_ds, void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
                          hipStream_t s) {
-    hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, dy_mask, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
-                       flags, tmo, B, T, H, n_bt, cw, b_pad);
+    if (tg_get_math_mode() == 1)
+        hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel<1>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, dy_mask, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
+                           flags, tmo, B, T, H, n_bt, cw, b_pad);
+    else
+        hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel<3>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, dy_mask, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
+                           flags, tmo, B, T, H, n_bt, cw, b_pad);
     return check_launch("tg_gru_backward_cluster(x3)");
 }

@@ -36,7 +36,15 @@ constexpr int HX_LD = HS + 8;          // bf16 per LDS row of the h planes (144 
 constexpr int DG_LD = 3 * HS + 8;      // bf16 per LDS row of the gate-gradient planes (400 B)
 
 // eight consecutive fp32 -> three bf16x8 fragments (hi / mid / lo planes)
-__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8 (&out)[3]) {
+// bf16m (wave-uniform, math mode 1 = plain bf16 operands): plane 0 holds the value rounded to nearest even and is the only plane multiplied
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8 (&out)[3], int bf16m) {
+    if (bf16m) {
+        bf16x8 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r[i] = (__bf16)a[i]; r[4 + i] = (__bf16)b[i]; }
+        out[0] = out[1] = out[2] = r;
+        return;
+    }
     unsigned h[8], m[8], l[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -50,7 +58,15 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8 (&ou
 }
 
 // four consecutive fp32 -> three 8-byte LDS words (4 bf16 each)
-__device__ __forceinline__ void split4_store(const f32x4 v, __bf16* p0, __bf16* p1, __bf16* p2) {
+__device__ __forceinline__ void split4_store(const f32x4 v, __bf16* p0, __bf16* p1, __bf16* p2, int bf16m) {
+    if (bf16m) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = (__bf16)v[i];
+        *reinterpret_cast<u32x2*>(p0) = __builtin_bit_cast(u32x2, r);
+        return;
+    }
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -76,7 +92,8 @@ __device__ __forceinline__ void pin_fragment(bf16x8& v) {
 
 // acc += W (A operand, split planes wa[0..2]) x h (B operand, split planes fb[0..2]); the six significant partial products,
 // smallest first
-__device__ __forceinline__ f32x4 mma_x3(const bf16x8 (&wa)[3], const bf16x8 (&fb)[3], f32x4 acc) {
+__device__ __forceinline__ f32x4 mma_x3(const bf16x8 (&wa)[3], const bf16x8 (&fb)[3], f32x4 acc, int bf16m) {
+    if (bf16m) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2], fb[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], fb[1], acc, 0, 0, 0);
@@ -122,7 +139,7 @@ template <bool SAVE, bool DROP, int D>
 __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
     const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
-    const float* __restrict__ drop_mask, float* __restrict__ y_drop, int B, int T) {
+    const float* __restrict__ drop_mask, float* __restrict__ y_drop, int B, int T, int bf16m) {
     __shared__ __attribute__((aligned(16))) __bf16 hs[2][3][16][HX_LD];
     const int dir = blockIdx.y;
     const float* whh = dir ? whh1 : whh0;
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float* p = whh + (long)(g * HS + 16 * wave + r16) * HS + 32 * ks + 8 * kq;
-            split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[g][ks]);
+            split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[g][ks], bf16m);
 #pragma unroll
             for (int s = 0; s < 3; ++s) pin_fragment(wa[g][ks][s]);
         }
@@ -201,7 +218,7 @@ __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
 #pragma unroll
             for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&hs[rb][s][r16][32 * ks + 8 * kq]);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = mma_x3(wa[g][ks], fb, acc[g]);
+            for (int g = 0; g < 3; ++g) acc[g] = mma_x3(wa[g][ks], fb, acc[g], bf16m);
         }
         TG_STAMP(step, 1);                               // fragments read, MFMAs issued
         __builtin_amdgcn_sched_barrier(0);
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
         const int wb = step & 1;
         TG_FORCE(h[0]); TG_FORCE(h[1]); TG_FORCE(h[2]); TG_FORCE(h[3]);
         TG_STAMP(step, 4);                               // gates done
-        split4_store(h, &hs[wb][0][r16][u0], &hs[wb][1][r16][u0], &hs[wb][2][r16][u0]);
+        split4_store(h, &hs[wb][0][r16][u0], &hs[wb][1][r16][u0], &hs[wb][2][r16][u0], bf16m);
         TG_STAMP(step, 5);                               // h_t split and in LDS (stores complete)
         d_h = h; d_r = r4; d_z = z4; d_n = n4; d_hn = hn4;
         if constexpr (DROP) d_hm = h * nxm[j];
@@ -261,7 +278,7 @@ template <bool SAVE, bool DROP>
 __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
     const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
-    const float* __restrict__ drop_mask, float* __restrict__ y_drop, int B, int T) {
+    const float* __restrict__ drop_mask, float* __restrict__ y_drop, int B, int T, int bf16m) {
     __shared__ __attribute__((aligned(16))) __bf16 hs[2][3][16][HX_LD];
     __shared__ __attribute__((aligned(16))) float obuf[2][16][OB_LD];
     __shared__ __attribute__((aligned(16))) float ibuf[2][16][IB_LD];
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float* p = whh + (long)(g * HS + 16 * wave + r16) * HS + 32 * ks + 8 * kq;
-            split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[g][ks]);
+            split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[g][ks], bf16m);
 #pragma unroll
             for (int s = 0; s < 3; ++s) pin_fragment(wa[g][ks][s]);
         }
@@ -385,7 +402,7 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
 #pragma unroll
             for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&hs[rb][s][r16][32 * ks + 8 * kq]);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = mma_x3(wa[g][ks], fb, acc[g]);
+            for (int g = 0; g < 3; ++g) acc[g] = mma_x3(wa[g][ks], fb, acc[g], bf16m);
         }
         f32x4 h, r4, z4, n4, hn4;
 #pragma unroll
@@ -398,7 +415,7 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
             r4[q] = r; z4[q] = z; n4[q] = n; hn4[q] = hn;
         }
         hp = h;
-        split4_store(h, &hs[wb][0][r16][u0], &hs[wb][1][r16][u0], &hs[wb][2][r16][u0]);
+        split4_store(h, &hs[wb][0][r16][u0], &hs[wb][1][r16][u0], &hs[wb][2][r16][u0], bf16m);
         float* orow = &obuf[wb][r16][u0];
         *reinterpret_cast<f32x4*>(orow) = h;
         if constexpr (DROP) *reinterpret_cast<f32x4*>(orow + HS) = h * gm;
@@ -419,7 +436,7 @@ template <bool MASK, int D>
 __global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
     const float* __restrict__ dY, const float* __restrict__ dy_mask, const float* __restrict__ Y, const float* __restrict__ save,
     long save_ds, const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh,
-    long dg_ds, int B, int T) {
+    long dg_ds, int B, int T, int bf16m) {
     __shared__ __attribute__((aligned(16))) __bf16 dgs[2][3][16][DG_LD];
     const int dir = blockIdx.y;
     const float* wt = dir ? wt1 : wt0;
@@ -430,7 +447,7 @@ __global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
         const float* p = wt + (long)(16 * wave + r16) * (3 * HS) + 32 * ks + 8 * kq;
-        split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[ks]);
+        split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[ks], bf16m);
 #pragma unroll
         for (int s = 0; s < 3; ++s) pin_fragment(wa[ks][s]);
     }
@@ -472,7 +489,7 @@ __global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
             bf16x8 fb[3];
 #pragma unroll
             for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&dgs[rb][s][r16][32 * ks + 8 * kq]);
-            acc = mma_x3(wa[ks], fb, acc);
+            acc = mma_x3(wa[ks], fb, acc, bf16m);
         }
         f32x4 g_r, g_z, g_n, g_nr;
 #pragma unroll
@@ -488,9 +505,9 @@ __global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
             g_r[q] = dr; g_z[q] = dz; g_n[q] = dn; g_nr[q] = dn * r;
         }
         const int wb = step & 1;
-        split4_store(g_r, &dgs[wb][0][r16][u0], &dgs[wb][1][r16][u0], &dgs[wb][2][r16][u0]);
-        split4_store(g_z, &dgs[wb][0][r16][HS + u0], &dgs[wb][1][r16][HS + u0], &dgs[wb][2][r16][HS + u0]);
-        split4_store(g_nr, &dgs[wb][0][r16][2 * HS + u0], &dgs[wb][1][r16][2 * HS + u0], &dgs[wb][2][r16][2 * HS + u0]);
+        split4_store(g_r, &dgs[wb][0][r16][u0], &dgs[wb][1][r16][u0], &dgs[wb][2][r16][u0], bf16m);
+        split4_store(g_z, &dgs[wb][0][r16][HS + u0], &dgs[wb][1][r16][HS + u0], &dgs[wb][2][r16][HS + u0], bf16m);
+        split4_store(g_nr, &dgs[wb][0][r16][2 * HS + u0], &dgs[wb][1][r16][2 * HS + u0], &dgs[wb][2][r16][2 * HS + u0], bf16m);
         float* gi_o = dgi + dir * dg_ds + (rbase + tau) * (3 * HS) + u0;
         float* gh_o = dgh + dir * dg_ds + (rbase + tau) * (3 * HS) + u0;
         *reinterpret_cast<f32x4*>(gi_o) = g_r; *reinterpret_cast<f32x4*>(gi_o + HS) = g_z; *reinterpret_cast<f32x4*>(gi_o + 2 * HS) = g_n;
@@ -515,7 +532,7 @@ template <bool MASK>
 __global__ __launch_bounds__(512) void gru_h64_bwd2_kernel(
     const float* __restrict__ dY, const float* __restrict__ dy_mask, const float* __restrict__ Y, const float* __restrict__ save,
     long save_ds, const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh,
-    long dg_ds, int B, int T) {
+    long dg_ds, int B, int T, int bf16m) {
     constexpr int NARR = MASK ? 7 : 6;                       // operand arrays per row: dy, (mask), r, z, n, hn, h_prev
     constexpr int BI_LD = NARR * HS + 4;
     __shared__ __attribute__((aligned(16))) __bf16 dgs[2][3][16][DG_LD];
@@ -609,7 +626,7 @@ __global__ __launch_bounds__(512) void gru_h64_bwd2_kernel(
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
         const float* p = wt + (long)(16 * wave + r16) * (3 * HS) + 32 * ks + 8 * kq;
-        split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[ks]);
+        split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[ks], bf16m);
 #pragma unroll
         for (int s = 0; s < 3; ++s) pin_fragment(wa[ks][s]);
     }
@@ -632,7 +649,7 @@ __global__ __launch_bounds__(512) void gru_h64_bwd2_kernel(
             bf16x8 fb[3];
 #pragma unroll
             for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&dgs[rb][s][r16][32 * ks + 8 * kq]);
-            acc = mma_x3(wa[ks], fb, acc);
+            acc = mma_x3(wa[ks], fb, acc, bf16m);
         }
         f32x4 g_r, g_z, g_n, g_nr;
 #pragma unroll
@@ -647,9 +664,9 @@ __global__ __launch_bounds__(512) void gru_h64_bwd2_kernel(
             dhz[q] = dh * z;
             g_r[q] = dr; g_z[q] = dz; g_n[q] = dn; g_nr[q] = dn * r;
         }
-        split4_store(g_r, &dgs[wb][0][r16][u0], &dgs[wb][1][r16][u0], &dgs[wb][2][r16][u0]);
-        split4_store(g_z, &dgs[wb][0][r16][HS + u0], &dgs[wb][1][r16][HS + u0], &dgs[wb][2][r16][HS + u0]);
-        split4_store(g_nr, &dgs[wb][0][r16][2 * HS + u0], &dgs[wb][1][r16][2 * HS + u0], &dgs[wb][2][r16][2 * HS + u0]);
+        split4_store(g_r, &dgs[wb][0][r16][u0], &dgs[wb][1][r16][u0], &dgs[wb][2][r16][u0], bf16m);
+        split4_store(g_z, &dgs[wb][0][r16][HS + u0], &dgs[wb][1][r16][HS + u0], &dgs[wb][2][r16][HS + u0], bf16m);
+        split4_store(g_nr, &dgs[wb][0][r16][2 * HS + u0], &dgs[wb][1][r16][2 * HS + u0], &dgs[wb][2][r16][2 * HS + u0], bf16m);
         float* orow = &obuf[wb][r16][u0];
         *reinterpret_cast<f32x4*>(orow) = g_r;
         *reinterpret_cast<f32x4*>(orow + HS) = g_z;
@@ -662,6 +679,8 @@ __global__ __launch_bounds__(512) void gru_h64_bwd2_kernel(
 }  // namespace tg
 
 using namespace tg;
+
+extern "C" int tg_get_math_mode(void);
 
 // TG_H64_RING = 1 | 2 | 4: depth of the operand prefetch ring.  Default 1: measured at B = 128 / 256, T = 28 (tools/h64_probe.py,
 // profiles/r2_j_h64_probe.txt) one step of look-ahead is enough once the loop has no lane predicates (fwd 32 us), deeper rings cost
@@ -684,7 +703,7 @@ extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const 
 // prefetch ring depth: the deepest of 4 / 2 / 1 that divides T
 #define TG_H64_FWD(SAVE_, DROP_, D_)                                                                                                        \
     hipLaunchKernelGGL((gru_h64_fwd_kernel<SAVE_, DROP_, D_>), dim3(cdiv(B, 16), 2), dim3(256), 0, (hipStream_t)stream, gi, (long)gi_dir_stride, \
-                       w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask, y_drop, B, T)
+                       w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask, y_drop, B, T, tg_get_math_mode() == 1)
 #define TG_H64_FWD_D(D_)                                  \
     do {                                                  \
         if (save && drop_mask) TG_H64_FWD(true, true, D_);    \
@@ -698,7 +717,7 @@ extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const 
     if (movers && T >= 3) {
 #define TG_H64_FWD2(SAVE_, DROP_)                                                                                                          \
     hipLaunchKernelGGL((gru_h64_fwd2_kernel<SAVE_, DROP_>), dim3(cdiv(B, 16), 2), dim3(512), 0, (hipStream_t)stream, gi, (long)gi_dir_stride, \
-                       w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask, y_drop, B, T)
+                       w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask, y_drop, B, T, tg_get_math_mode() == 1)
         if (save && drop_mask) TG_H64_FWD2(true, true);
         else if (save) TG_H64_FWD2(true, false);
         else if (drop_mask) TG_H64_FWD2(false, true);
@@ -734,7 +753,7 @@ extern "C" int tg_gru_h64_backward(const float* dy, const float* dy_mask, const 
                "tg_gru_h64_backward: operands must be 16-byte aligned");
 #define TG_H64_BWD(MASK_, D_)                                                                                                          \
     hipLaunchKernelGGL((gru_h64_bwd_kernel<MASK_, D_>), dim3(cdiv(B, 16), 2), dim3(256), 0, (hipStream_t)stream, dy, dy_mask, y, save, \
-                       (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T)
+                       (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T, tg_get_math_mode() == 1)
 #define TG_H64_BWD_D(D_)                       \
     do {                                       \
         if (dy_mask) TG_H64_BWD(true, D_);     \
@@ -744,9 +763,9 @@ extern "C" int tg_gru_h64_backward(const float* dy, const float* dy_mask, const 
     const int movers = movers_env ? atoi(movers_env) : 1;
     if (movers && T >= 3) {
         if (dy_mask) hipLaunchKernelGGL((gru_h64_bwd2_kernel<true>), dim3(cdiv(B, 16), 2), dim3(512), 0, (hipStream_t)stream, dy, dy_mask, y, save,
-                                        (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T);
+                                        (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T, tg_get_math_mode() == 1);
         else hipLaunchKernelGGL((gru_h64_bwd2_kernel<false>), dim3(cdiv(B, 16), 2), dim3(512), 0, (hipStream_t)stream, dy, dy_mask, y, save,
-                                (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T);
+                                (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T, tg_get_math_mode() == 1);
         return check_launch("tg_gru_h64_backward");
     }
     const int ring = h64_ring();

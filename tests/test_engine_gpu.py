@@ -141,7 +141,8 @@ def test_train_iter_matches_reference_golden(pkg, dev):
                     assert int(v) == int(g[pre + k]), k            # Q2: G (2,1)/(3,..) and D 1/3 updates per iteration
 
 
-def test_full_size_step_matches_reference_golden_b128(pkg, dev):
+def _golden_b128_step(pkg, dev):
+    """One iteration of the g3 fixture (B = 128, epoch 11, every dropout off, the reference's own eps / perm draws) through GanTrainer."""
     g = load("g3_train_b128.npz")
     V, S, B = int(g["n_words"]), int(g["n_speakers"]), int(g["batch"])
     gst, dst = O.make_generator_state(int(g["g_seed"]), V, S), O.make_discriminator_state(int(g["d_seed"]))
@@ -150,7 +151,6 @@ def test_full_size_step_matches_reference_golden_b128(pkg, dev):
     D.engine  # built lazily
     tr = pkg.GanTrainer(G, D, args)
     tr.keep_tape = True
-    pre = O.wav_preacts(O.clone_state(gst, torch.float64), audio.double())       # fp64 LeakyReLU pre-activations of the audio encoder (21 M elements)
     inj = {f"{t}.eps": torch.from_numpy(e).to(dev) for t, e in zip(("g1", "g2", "g3"), g["eps"])}
     inj["perm"] = torch.from_numpy(g["perm"]).to(dev)
     for t in ("g1", "g2", "g3"):                          # golden run: every dropout off
@@ -161,6 +161,12 @@ def test_full_size_step_matches_reference_golden_b128(pkg, dev):
         for l in range(3):
             inj[f"{t}.gru.drop{l}"] = torch.ones(B, 28, 128, device=dev)
     ret = tr.train_iter(11, text.to(dev), audio.to(dev), poses.to(dev), vid.to(dev), inject=inj).to_dict()
+    return g, gst, audio, G, D, tr, ret
+
+
+def test_full_size_step_matches_reference_golden_b128(pkg, dev):
+    g, gst, audio, G, D, tr, ret = _golden_b128_step(pkg, dev)
+    pre = O.wav_preacts(O.clone_state(gst, torch.float64), audio.double())       # fp64 LeakyReLU pre-activations of the audio encoder (21 M elements)
     for k, v in zip(g["loss_keys"], g["loss_vals"]):
         assert abs(ret[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, ret[k], v)
     # the evidence behind the 5e-3 allowance below: how many LeakyReLU gates of the audio encoder sit within rounding of zero in fp64, and
@@ -193,6 +199,72 @@ def test_full_size_step_matches_reference_golden_b128(pkg, dev):
                 assert rel(v, g[pre + k]) < 1e-5, k
             if k.endswith("num_batches_tracked"):
                 assert int(v) == int(g[pre + k])
+
+
+def test_bf16_tier_full_size_step_within_bf16_tolerances(pkg, dev):
+    """tg_set_math_mode(1) at the size the tier is for: the g3 fixture's B = 128 iteration with plain-bf16 operands in every big product
+    (NT / TN mover-wave kernels, both GRU recurrences) against the reference's own fp32 golden: losses within 2e-2, every gradient's norm
+    and 64 sampled entries within 5e-2 (SURVEY Q14's bf16 tolerances).  The same step differs from the fp32 tier's by more than 1e-4
+    somewhere, so the mode really switches at this size."""
+    ops = pkg.ops
+    try:
+        ops.set_math_mode("bf16")
+        g, gst, audio, G, D, tr, ret = _golden_b128_step(pkg, dev)
+    finally:
+        ops.set_math_mode("f32")
+    worst_loss = max(abs(ret[k] - v) / max(1.0, abs(v)) for k, v in zip(g["loss_keys"], g["loss_vals"]))
+    _, Gg, _ = tr.G.views()
+    worst = {}
+    for k, gr in Gg.items():
+        if k in ZERO_GRAD_KEYS:
+            continue
+        nrm = float(gr.double().norm())
+        e_n = abs(nrm - float(g["ggn/" + k])) / (float(g["ggn/" + k]) + 1e-30)
+        mine = gr.reshape(-1).cpu().numpy()[sample_idx(gr.numel(), 64)]
+        e_s = float(np.abs(mine - g["gg/" + k]).max()) / float(gr.abs().max())
+        worst[k] = (e_n, e_s)
+    kn, ks = max(worst, key=lambda k: worst[k][0]), max(worst, key=lambda k: worst[k][1])
+    print(f"bf16 tier at B = 128 vs the reference's fp32 golden: worst loss error {worst_loss:.1e}; worst gradient norm error "
+          f"{worst[kn][0]:.1e} ({kn}); worst sampled-entry error {worst[ks][1]:.1e} ({ks})")
+    assert worst_loss < 2e-2, worst_loss
+    assert worst[kn][0] < 5e-2 and worst[ks][1] < 5e-2, (kn, worst[kn], ks, worst[ks])
+    assert worst[ks][1] > 1e-4, "bf16 mode left the B = 128 step at fp32 accuracy: the tier did not switch"
+
+
+def test_bf16_tier_fgd_within_one_percent_of_fp32(pkg, dev, tmp_path):
+    """The evaluation metric the reference's headline table reports (FGD, scripts/train.py:234-329 + model/embedding_space_evaluator.py)
+    under the bf16 tier: evaluate_testset over two batches of 128 clips with the g8 evaluator, once per math mode.  FGD within 1 %, the
+    other returned metrics within 2e-2."""
+    from importlib import import_module
+    em = import_module(pkg.__name__ + ".eval_metrics")
+    fgd = import_module(pkg.__name__ + ".fgd")
+    from harness import fixture_lang
+    g = load("g8_evaluate_testset.npz")
+    V, S = int(g["n_words"]), int(g["n_speakers"])
+    gst = O.make_generator_state(int(g["g_seed"]), V, S, z_mode=None)
+    args = make_args(z_type="none", model="multimodal_context", mean_dir_vec=[float(x) for x in g["mean_dir_vec"]])
+    G = pkg.PoseGenerator(args, 27, V, 300, None, None).to(dev)
+    G.load_state_dict(O.clone_state(gst), strict=True)
+    ckpt = _ae_checkpoint(pkg, tmp_path, int(g["ae_seed"]))
+    loader = []
+    for i in range(2):
+        text, audio, _, poses = O.make_batch(900 + i, 128, V, S)
+        loader.append((torch.tensor([0]), torch.tensor([0]), text, torch.zeros(128, 34, 30), poses, audio, torch.zeros(128, 1), {}))
+    rets = {}
+    try:
+        for mode in ("f32", "bf16"):
+            pkg.ops.set_math_mode(mode)
+            evaluator = fgd.EmbeddingSpaceEvaluator(args, ckpt, fixture_lang(pkg.Vocab, V), dev)
+            G.train(True)
+            rets[mode] = dict(em.evaluate_testset(loader, G, None, evaluator, args))
+    finally:
+        pkg.ops.set_math_mode("f32")
+    a, b = rets["f32"], rets["bf16"]
+    print("evaluate_testset, fp32 tier:", {k: float(v) for k, v in a.items()}, "bf16 tier:", {k: float(v) for k, v in b.items()})
+    assert abs(b["frechet"] - a["frechet"]) <= 1e-2 * abs(a["frechet"]), (a["frechet"], b["frechet"])
+    for k in a:
+        assert abs(b[k] - a[k]) <= 2e-2 * abs(a[k]), (k, a[k], b[k])
+    assert any(b[k] != a[k] for k in a)
 
 
 def test_module_api_autograd_bridge(pkg, dev):
