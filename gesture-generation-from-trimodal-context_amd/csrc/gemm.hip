@@ -918,7 +918,7 @@ static int tn_group_impl(const tg_gemm_tn_problem* problems, int32_t n, void* st
     TnGroup g;
     g.n = n;
     // bf16 x 3 kernel (gemm_split.hip) when every problem is on the vectorisable layout and long enough to amortise its 32-row slabs
-    bool x3 = use_split_path() && tg_get_math_mode() == 0;
+    bool x3 = use_split_path();                                        // weight gradients without a mover-wave plan stay bf16 x 3 in both math modes
     bool mw_ok = use_split_path();                                     // the mover-wave kernel also has the plain-bf16 form (math mode 1)
     bool two_pass = false;            // workspaces are sized for the 64 x 64 tile's split plan (tg_gemm_tn_ws_floats)
     for (int i = 0; i < n; ++i) {

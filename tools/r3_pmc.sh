@@ -1,0 +1,29 @@
+#!/bin/bash
+# rocprofv3 --pmc passes (one counter group per pass, never combined with tracing), run on the GPU box from the repo root:
+#   bash tools/r3_pmc.sh  ->  gpurun_out/r3_pmc_*.txt
+export TMPDIR=/tmp
+out=gpurun_out
+mkdir -p $out
+pass() {   # pass <tag> <script> <kernel substring> <counters...>
+  tag=$1; script=$2; sub=$3; shift 3
+  rm -rf /tmp/pmc_$tag
+  rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$tag -- python3 $script > /dev/null 2>&1
+  python3 tools/pmc_summary.py /tmp/pmc_$tag "$sub" 1
+}
+{
+echo "# rocprofv3 --pmc <counters> --output-format csv -- python3 tools/gru_pmc.py   (separate passes; B=384, H=300, T=34, gates saved for rows [128, 256) only; first launch skipped)"
+pass g1 tools/gru_pmc.py gru_seq_fwd_cluster FETCH_SIZE
+pass g2 tools/gru_pmc.py gru_seq_fwd_cluster WRITE_SIZE
+pass g3 tools/gru_pmc.py gru_seq_fwd_cluster SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY
+} > $out/r3_pmc_gru_fwd_cluster_x3.txt
+{
+echo "# rocprofv3 --pmc <counters> --output-format csv -- python3 tools/mw_pmc.py   (nt 2 x [13056 x 900 x 600] weights pre-split; tn 2 x [4352 x 900 x 600] + bias; first launch skipped)"
+for k in gemm_nt_mw_kernel gemm_tn_mw_kernel; do
+echo "## $k"
+pass m1 tools/mw_pmc.py $k FETCH_SIZE
+pass m2 tools/mw_pmc.py $k WRITE_SIZE
+pass m3 tools/mw_pmc.py $k SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY
+pass m4 tools/mw_pmc.py $k SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16
+done
+} > $out/r3_pmc_gemm_mw.txt
+cat $out/r3_pmc_gru_fwd_cluster_x3.txt $out/r3_pmc_gemm_mw.txt
