@@ -94,3 +94,25 @@ for name, (probs, flops, keep) in cases:
         line += f" | plan {plans[on]} {med:7.1f} / {mn:7.1f} us {flops / med / 1e6:6.1f} TF"
     line += f" | ratio {statistics.median(res[True]) / statistics.median(res[False]):.3f}"
     print(line, flush=True)
+
+# the text encoder's convs as the iteration sees them: operands and outputs of every launch on COLD lines (24 rotating buffer sets, 1.9 GB, past
+# the 256 MB Infinity Cache); conv1 = ReLU + dropout scale, conv2 = the same + the block's closing relu(out + x) as second output
+NSET = 24
+Bc, Tc, Cc = 384, 34, 300
+wp = torch.randn(Cc, 2 * Cc, device=dev) * 0.05
+bc = torch.randn(Cc, device=dev)
+wpl = ops.split3_planes(wp)
+sets = [dict(x=torch.randn(Bc, Tc, Cc, device=dev), m=(torch.rand(Bc, Tc, Cc, device=dev) > 0.3).float() / 0.7, r=torch.randn(Bc, Tc, Cc, device=dev),
+             o=torch.empty(Bc, Tc, Cc, device=dev), o2=torch.empty(Bc, Tc, Cc, device=dev)) for _ in range(NSET)]
+def conv_probs(st, second):
+    kw = dict(res=st["r"], out2=st["o2"], res_slope=0.0) if second else {}
+    return [dict(A=Win.conv(st["x"], 2, pad=4, dil=4, rows_out=Tc), W=wp, bias=bc, out=st["o"], act_slope=0.0, out_scale=st["m"], w_planes=wpl,
+                 c_batch_stride=st["o"].stride(0), c_row_stride=st["o"].stride(1), c_rows_out=Tc, **kw)]
+for second in (False, True):
+    plist = [conv_probs(st, second) for st in sets]
+    def sweep():
+        for pr in plist:
+            ops.gemm_nt_group(pr)
+    sweep()
+    ts = [timed(sweep, 4) / NSET for _ in range(rounds)]
+    print(f"tcn conv{2 if second else 1} cold  [13056 x 300 x 600] d=4 | plan {ops.nt_kernel_plan(plist[0])} {statistics.median(ts):7.1f} / {min(ts):7.1f} us per launch", flush=True)
