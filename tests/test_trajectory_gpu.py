@@ -76,8 +76,8 @@ def test_five_consecutive_iterations_match_fp64_oracle(pkg, dev):
     # A flipped LeakyReLU gate in the audio encoder (a pre-activation within rounding of zero lands on the other side in fp32) moves the
     # gradients below it discontinuously -- by ~1 / sqrt(positions summed) of a tensor's max -- and every later
     # iteration inherits the difference through Adam.  So: every tensor OUTSIDE the audio encoder must stay within 1e-4 of the fp64
-    # trajectory (1e-4 on exp_avg, 2e-4 on exp_avg_sq); the audio encoder's tensors too if no gate flipped, and within 5e-2 if one did (the
-    # count is printed above).
+    # trajectory (1e-4 on exp_avg, 2e-4 on exp_avg_sq) if no gate flipped; if one did (the count is printed above) the audio encoder's
+    # tensors within 5e-2 and the others, which see the changed audio features, within 5e-4.
     wk, bad = {}, []
     for net, slab_obj, ostate, real in (("G.", gs, ga, real_g), ("D.", ds, da, real_d)):
         mv = _views(slab_obj)
@@ -89,7 +89,8 @@ def test_five_consecutive_iterations_match_fp64_oracle(pkg, dev):
             em = float((m.double().cpu() - om)[r].abs().max() / om.abs().max().clamp_min(1e-30))
             ev = float((v.double().cpu() - ov)[r].abs().max() / ov.abs().max().clamp_min(1e-30))
             wk[net + k] = (em, ev)
-            tol = 5e-2 if (k.startswith("audio_encoder") and total_flips > 0) else 1e-4
+            # (a flipped gate also moves the audio features the GRU reads, hence every tensor downstream, by a few 1e-5: measured <= 1.1e-4)
+            tol = (5e-2 if k.startswith("audio_encoder") else 5e-4) if total_flips > 0 else 1e-4
             if em > tol or ev > 2 * tol:                       # the second moment is a square: twice the gradient's relative error
                 bad.append((net + k, em, ev, tol))
     print(f"optimiser state after the last iteration (normalised max error per tensor, exp_avg / exp_avg_sq); {total_flips} flipped gates in all:")
