@@ -25,7 +25,8 @@ class NtProblem(C.Structure):
     _fields_ = [("A", Window), ("Bw", P), ("ldb", I64), ("b_seg_k", I32), ("reserved", I32), ("b_seg_stride", I64), ("bias", P), ("C", P),
                 ("c_batch_stride", I64), ("c_row_stride", I64), ("c_rows_out", I32), ("M", I32), ("N", I32), ("act_slope", F32),
                 ("accumulate", I32), ("out_scale", P), ("b_planes", P), ("b_plane_stride", I64), ("b_rows", I32), ("b_row0", I32),
-                ("gate", P), ("res", P), ("C2", P), ("res_slope", F32), ("reserved3", I32)]
+                ("gate", P), ("res", P), ("C2", P), ("res_slope", F32), ("drop_site", U32), ("drop_state", P), ("drop_index0", I64),
+                ("drop_p", F32), ("reserved4", I32)]
 
 
 class TnProblem(C.Structure):
@@ -81,6 +82,8 @@ SIGNATURES = {
     "tg_add_relu": [P, P, P, I64, P],
     "tg_act_mask_bwd": [P, P, P, F32, P, I64, P],
     "tg_act_mask_bwd2": [P, P, P, P, F32, P, P, I64, P],
+    "tg_act_mask_bwd_drop": [P, P, F32, P, U32, I64, F32, P, I64, P],
+    "tg_act_mask_bwd2_drop": [P, P, P, F32, P, U32, I64, F32, P, P, I64, P],
     "tg_mul": [P, P, P, I64, P],
     "tg_axpy": [P, P, F32, I32, I64, P],
     "tg_copy2d": [P, I64, P, I64, I32, I32, I32, P],
@@ -120,7 +123,7 @@ SIGNATURES = {
     "tg_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, P, P],
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

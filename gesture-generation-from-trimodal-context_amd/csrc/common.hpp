@@ -76,6 +76,10 @@ struct NtProb {
     int b_seg_k;             // (== K: one weight matrix)
     const float* bias;
     const float* mul;        // optional element-wise multiplier applied after the activation (a dropout scale mask), addressed like C
+    const uint64_t* drop_state;  // ... or that mask REGENERATED (dropout_scale4) from element index drop_index0 + offset in C; big-product kernels, vec_c
+    long drop_index0;
+    unsigned drop_site;
+    float drop_p;
     float* C;
     long cbs, crs;
     int cR, M, N;
@@ -212,5 +216,17 @@ __device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t idx, uint32_t
 }
 
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+// elements 4 idx4 .. 4 idx4 + 3 of the inverted-dropout scale mask tg_dropout_mask(.., p, st, site) writes: the consumers of a dropout
+// regenerate it from the element index instead of reading a stored mask (forward and backward see the same draw: st is only advanced by
+// tg_iter_begin)
+__device__ __forceinline__ f32x4 dropout_scale4(const uint64_t* __restrict__ st, uint32_t site, float p, uint64_t idx4) {
+    uint32_t r[4];
+    philox4x32(st[0], idx4, site, (uint32_t)st[1], r);
+    const float keep = 1.f / (1.f - p);
+    f32x4 m;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = u01(r[q]) >= p ? keep : 0.f;
+    return m;
+}
 
 }  // namespace tg

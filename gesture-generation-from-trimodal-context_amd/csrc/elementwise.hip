@@ -38,17 +38,27 @@ __global__ void add_relu_vkernel(const V* __restrict__ a, const V* __restrict__ 
         y[i] = o;
     }
 }
+// the dropout scale of both gate kernels below: a stored mask, or (f32x4 form only) regenerated from the element index (dropout_scale4)
+struct DropSpec {
+    const uint64_t* st;
+    long idx4_0;           // index0 / 4
+    unsigned site;
+    float p;
+};
 template <typename V>
-__global__ void act_mask_bwd_kernel(const V* __restrict__ dy, const V* __restrict__ y, const V* __restrict__ mask, float slope, V* __restrict__ dx, long n) {
+__global__ void act_mask_bwd_kernel(const V* __restrict__ dy, const V* __restrict__ y, const V* __restrict__ mask, float slope, V* __restrict__ dx, long n,
+                                    DropSpec drop) {
     constexpr int W = sizeof(V) / 4;
     GRID_STRIDE(i, n) {
         const V dv = dy[i], yv = y[i];
         V mv = dv;
         if (mask) mv = mask[i];
+        if constexpr (W == 4) { if (drop.st) mv = dropout_scale4(drop.st, drop.site, drop.p, (unsigned long)(drop.idx4_0 + i)); }
+        const bool scaled = mask || drop.st;
         V o;
         for (int q = 0; q < W; ++q) {
             float g = ((const float*)&dv)[q] * (((const float*)&yv)[q] > 0.f ? 1.f : slope);
-            if (mask) g *= ((const float*)&mv)[q];
+            if (scaled) g *= ((const float*)&mv)[q];
             ((float*)&o)[q] = g;
         }
         dx[i] = o;
@@ -58,17 +68,19 @@ __global__ void act_mask_bwd_kernel(const V* __restrict__ dy, const V* __restric
 // residual branch -- and dc = dsum * (o > 0 ? 1 : slope) * mask, the gradient at the block's second conv
 template <typename V>
 __global__ void act_mask_bwd2_kernel(const V* __restrict__ dy, const V* __restrict__ y, const V* __restrict__ o, const V* __restrict__ mask, float slope,
-                                     V* __restrict__ dsum, V* __restrict__ dc, long n) {
+                                     V* __restrict__ dsum, V* __restrict__ dc, long n, DropSpec drop) {
     constexpr int W = sizeof(V) / 4;
     GRID_STRIDE(i, n) {
         const V dv = dy[i], yv = y[i], ov = o[i];
         V mv = dv;
         if (mask) mv = mask[i];
+        if constexpr (W == 4) { if (drop.st) mv = dropout_scale4(drop.st, drop.site, drop.p, (unsigned long)(drop.idx4_0 + i)); }
+        const bool scaled = mask || drop.st;
         V s_, c_;
         for (int q = 0; q < W; ++q) {
             const float g = ((const float*)&dv)[q] * (((const float*)&yv)[q] > 0.f ? 1.f : 0.f);
             float h = g * (((const float*)&ov)[q] > 0.f ? 1.f : slope);
-            if (mask) h *= ((const float*)&mv)[q];
+            if (scaled) h *= ((const float*)&mv)[q];
             ((float*)&s_)[q] = g;
             ((float*)&c_)[q] = h;
         }
@@ -579,16 +591,36 @@ int tg_add_relu(const float* a, const float* b, float* y, int64_t n, void* strea
 }
 int tg_act_mask_bwd(const float* dy, const float* y, const float* mask, float slope, float* dx, int64_t n, void* stream) {
     TG_REQUIRE(dy && y && dx && n >= 0, "tg_act_mask_bwd: bad arguments");
+    const DropSpec none = {nullptr, 0, 0u, 0.f};
     if (n % 4 == 0 && aligned16(dy) && aligned16(y) && aligned16(dx) && (!mask || aligned16(mask)))
-        EW(act_mask_bwd_kernel<f32x4>, n / 4, (const f32x4*)dy, (const f32x4*)y, (const f32x4*)mask, slope, (f32x4*)dx, (long)n / 4);
-    else EW(act_mask_bwd_kernel<float>, n, dy, y, mask, slope, dx, (long)n);
+        EW(act_mask_bwd_kernel<f32x4>, n / 4, (const f32x4*)dy, (const f32x4*)y, (const f32x4*)mask, slope, (f32x4*)dx, (long)n / 4, none);
+    else EW(act_mask_bwd_kernel<float>, n, dy, y, mask, slope, dx, (long)n, none);
     return check_launch("tg_act_mask_bwd");
+}
+int tg_act_mask_bwd_drop(const float* dy, const float* y, float p, const uint64_t* rng_state, uint32_t site, int64_t index0, float slope, float* dx,
+                         int64_t n, void* stream) {
+    TG_REQUIRE(dy && y && dx && rng_state && n >= 0 && n % 4 == 0 && index0 >= 0 && index0 % 4 == 0 && p >= 0.f && p < 1.f && aligned16(dy) &&
+                   aligned16(y) && aligned16(dx), "tg_act_mask_bwd_drop: bad arguments (n, index0 multiples of 4, 16-byte aligned pointers, 0 <= p < 1)");
+    const DropSpec drop = {rng_state, (long)(index0 / 4), site, p};
+    EW(act_mask_bwd_kernel<f32x4>, n / 4, (const f32x4*)dy, (const f32x4*)y, (const f32x4*)nullptr, slope, (f32x4*)dx, (long)n / 4, drop);
+    return check_launch("tg_act_mask_bwd_drop");
+}
+int tg_act_mask_bwd2_drop(const float* dy, const float* y, const float* o, float p, const uint64_t* rng_state, uint32_t site, int64_t index0, float slope,
+                          float* dsum, float* dc, int64_t n, void* stream) {
+    TG_REQUIRE(dy && y && o && dsum && dc && rng_state && n >= 0 && n % 4 == 0 && index0 >= 0 && index0 % 4 == 0 && p >= 0.f && p < 1.f &&
+                   aligned16(dy) && aligned16(y) && aligned16(o) && aligned16(dsum) && aligned16(dc),
+               "tg_act_mask_bwd2_drop: bad arguments (n, index0 multiples of 4, 16-byte aligned pointers, 0 <= p < 1)");
+    const DropSpec drop = {rng_state, (long)(index0 / 4), site, p};
+    EW(act_mask_bwd2_kernel<f32x4>, n / 4, (const f32x4*)dy, (const f32x4*)y, (const f32x4*)o, (const f32x4*)nullptr, slope, (f32x4*)dsum, (f32x4*)dc,
+       (long)n / 4, drop);
+    return check_launch("tg_act_mask_bwd2_drop");
 }
 int tg_act_mask_bwd2(const float* dy, const float* y, const float* o, const float* mask, float slope, float* dsum, float* dc, int64_t n, void* stream) {
     TG_REQUIRE(dy && y && o && dsum && dc && n >= 0, "tg_act_mask_bwd2: bad arguments");
     if (n % 4 == 0 && aligned16(dy) && aligned16(y) && aligned16(o) && aligned16(dsum) && aligned16(dc) && (!mask || aligned16(mask)))
-        EW(act_mask_bwd2_kernel<f32x4>, n / 4, (const f32x4*)dy, (const f32x4*)y, (const f32x4*)o, (const f32x4*)mask, slope, (f32x4*)dsum, (f32x4*)dc, (long)n / 4);
-    else EW(act_mask_bwd2_kernel<float>, n, dy, y, o, mask, slope, dsum, dc, (long)n);
+        EW(act_mask_bwd2_kernel<f32x4>, n / 4, (const f32x4*)dy, (const f32x4*)y, (const f32x4*)o, (const f32x4*)mask, slope, (f32x4*)dsum, (f32x4*)dc, (long)n / 4,
+           DropSpec{nullptr, 0, 0u, 0.f});
+    else EW(act_mask_bwd2_kernel<float>, n, dy, y, o, mask, slope, dsum, dc, (long)n, DropSpec{nullptr, 0, 0u, 0.f});
     return check_launch("tg_act_mask_bwd2");
 }
 int tg_zero(void* p, int64_t bytes, void* stream) {

@@ -681,7 +681,7 @@ static bool nt_vec(const NtProb& p) {
     return (w.cw % 4 == 0) && (w.K % 4 == 0) && (w.bs % 4 == 0) && (w.rs % 4 == 0) && aligned16(w.ptr) && (p.ldb % 4 == 0) && aligned16(p.Bw) &&
            (p.b_seg_k % 4 == 0) && (p.b_seg_stride % 4 == 0);
 }
-static bool nt_has_ext(const NtProb& p) { return p.gate != nullptr || p.res != nullptr; }
+static bool nt_has_ext(const NtProb& p) { return p.gate != nullptr || p.res != nullptr || p.drop_state != nullptr; }
 static int nt_family(const NtProb& p) {
     if (nt_vec(p) && p.N >= 48 && p.M >= 1024 && p.A.K >= 64) return 0;
     return p.N <= 32 ? 1 : 2;
@@ -711,7 +711,7 @@ static int nt_launch(NtGroup& g, hipStream_t s) {
     }
     if (fam == 0 && use_split_path()) return tg_gemm_nt_split_launch(g, s);
     for (int i = 0; i < g.n; ++i)
-        TG_REQUIRE(!nt_has_ext(g.p[i]), "tg_gemm_nt: gate / res / C2 need the big-product split path (tg_gemm_nt_ext_supported; problem %d)", i);
+        TG_REQUIRE(!nt_has_ext(g.p[i]), "tg_gemm_nt: gate / res / C2 / regenerated dropout need the big-product split path (tg_gemm_nt_ext_supported; problem %d)", i);
     if (fam == 0) {
         int Mx = 0, Nx = 0;
         for (int i = 0; i < g.n; ++i) { Mx = Mx > g.p[i].M ? Mx : g.p[i].M; Nx = Nx > g.p[i].N ? Nx : g.p[i].N; }
@@ -762,6 +762,9 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
                (long)q.ldb, idx);
     p.A = to_win(&q.A);
     p.Bw = q.Bw; p.ldb = (long)q.ldb; p.b_seg_k = seg; p.b_seg_stride = q.b_seg_k > 0 ? (long)q.b_seg_stride : 0;
+    TG_REQUIRE(q.drop_state == nullptr || (q.out_scale == nullptr && q.drop_index0 >= 0 && q.drop_index0 % 4 == 0 && q.drop_p >= 0.f && q.drop_p < 1.f),
+               "tg_gemm_nt: regenerated dropout (problem %d) excludes out_scale and needs drop_index0 %% 4 == 0, 0 <= drop_p < 1", idx);
+    p.drop_state = q.drop_state; p.drop_index0 = (long)q.drop_index0; p.drop_site = q.drop_site; p.drop_p = q.drop_p;
     p.bias = q.bias; p.mul = q.out_scale; p.C = q.C; p.cbs = (long)q.c_batch_stride; p.crs = (long)q.c_row_stride; p.cR = q.c_rows_out;
     p.M = q.M; p.N = q.N; p.slope = q.act_slope; p.accumulate = q.accumulate; p.n_nt = 0;
     p.a_bytes = p.b_bytes = 0;

@@ -411,6 +411,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
             const NtProb& pr = g.p[pi];
             const float* __restrict__ bias = pr.bias;
             const float* __restrict__ mul = pr.mul;
+            const uint64_t* __restrict__ drop = pr.drop_state;
             const float* __restrict__ gate = pr.gate;
             const float* __restrict__ res = pr.res;
             float* __restrict__ C2 = pr.C2;
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                     for (int u = 0; u < RB; ++u) {
                         const long o = ro[i0 + u] + cc0;
                         if (mul) mv[u] = *reinterpret_cast<const f32x4*>(mul + o);
+                        else if (drop) mv[u] = dropout_scale4(drop, pr.drop_site, pr.drop_p, (unsigned long)(pr.drop_index0 + o) >> 2);
                         if (gate) gv[u] = *reinterpret_cast<const f32x4*>(gate + o);
                         if (res) rv[u] = *reinterpret_cast<const f32x4*>(res + o);
                         if (accumulate) cv[u] = *reinterpret_cast<const f32x4*>(C + o);
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                         f32x4 v = acc[i][j] + bv;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q], slope);
-                        if (mul) v *= mv[u];
+                        if (mul || drop) v *= mv[u];
                         if (gate) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) v[q] = gv[u][q] > 0.f ? v[q] : 0.f;

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
     const int b_seg_k = pr.b_seg_k;
     const float* __restrict__ bias = pr.bias;
     const float* __restrict__ mul = pr.mul;
+    const uint64_t* __restrict__ drop = pr.drop_state;       // (vec_c only: checked by the launcher)
     const float* __restrict__ gate = pr.gate;
     const float* __restrict__ res = pr.res;
     float* __restrict__ C2 = pr.C2;
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
                 o[u] = ok[u] ? (long)cb * cbs + (long)cr * crs + col : 0;
                 bv[u] = bias ? *reinterpret_cast<const f32x4*>(bias + (ok[u] ? col : 0)) : z4;
                 if (mul) mv[u] = *reinterpret_cast<const f32x4*>(mul + o[u]);
+                else if (drop) mv[u] = dropout_scale4(drop, pr.drop_site, pr.drop_p, (unsigned long)(pr.drop_index0 + o[u]) >> 2);
                 if (gate) gv[u] = *reinterpret_cast<const f32x4*>(gate + o[u]);
                 if (res) rv[u] = *reinterpret_cast<const f32x4*>(res + o[u]);
                 if (accumulate) cv[u] = *reinterpret_cast<const f32x4*>(C + o[u]);
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_split_kernel(const NtGroup g
                 f32x4 v = *reinterpret_cast<const f32x4*>(&ct[rl * CLD + 4 * c4]) + bv[u];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q], slope);
-                if (mul) v *= mv[u];
+                if (mul || drop) v *= mv[u];
                 if (gate) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = gv[u][q] > 0.f ? v[q] : 0.f;
@@ -646,6 +648,9 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
         int tm = 0, tn = 0;
         if (tg_gemm_nt_mw_eligible(g, &tm, &tn)) return tg_gemm_nt_mw_launch(g, tm, tn, g_math_mode == 1 ? 1 : 3, s);
     }
+    for (int i = 0; i < g.n; ++i)
+        TG_REQUIRE(g.p[i].drop_state == nullptr || g.p[i].vec_c, "tg_gemm_nt: regenerated dropout needs a vectorisable C (N %% 4 == 0, strides %% 4 == 0, "
+                   "16-byte aligned; problem %d)", i);
     int Mx = 0, Nx = 0;
     for (int i = 0; i < g.n; ++i) { Mx = Mx > g.p[i].M ? Mx : g.p[i].M; Nx = Nx > g.p[i].N ? Nx : g.p[i].N; }
     const SplitTile tl = split_pick_tile(Mx * g.n, Nx);

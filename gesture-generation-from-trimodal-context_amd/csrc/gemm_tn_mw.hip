@@ -92,8 +92,6 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
         int pi, n0, k0, mb, me;
         if (decode(vb, pi, n0, k0, mb, me)) total += (me - mb + 31) >> 5;
     }
-    using set0 = std::integral_constant<int, 0>;
-    using set1 = std::integral_constant<int, 1>;
 
     if (wave >= 8) {
         // ============================================================================================ movers (waves 8-11)

@@ -79,6 +79,50 @@ class Win:
                    cw=Cc, K=n_taps * Cc, row_step=1, shift=shift, dil=dil)
 
 
+class Drop:
+    """An inverted-dropout scale mask that is never stored: its consumers regenerate element i as element index0 + i of the draw
+    dropout_mask(mask, p, state, site) would write (Philox keyed by the element index; `state` only advances in iter_begin, so the forward
+    and backward consumers of one F.dropout see the same mask).  Accepted wherever the big-product GEMMs take `out_scale` and by
+    act_mask_bwd / act_mask_bwd2; `shape` is the shape of the tensor it scales (checked like a mask tensor's)."""
+
+    def __init__(self, state, site, p, shape, index0=0):
+        assert state.dtype == torch.int64 and state.is_cuda and state.numel() >= 2 and 0.0 <= p < 1.0
+        self.state, self.site, self.p, self.shape, self.index0 = state, int(site), float(p), tuple(shape), int(index0)
+
+    def numel(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    def __getitem__(self, rows):
+        """Leading-dimension slice (a contiguous range of batch rows), as mask[rows] of the stored form."""
+        assert isinstance(rows, slice) and rows.step in (None, 1)
+        b0, b1, _ = rows.indices(self.shape[0])
+        inner = self.numel() // self.shape[0]
+        return Drop(self.state, self.site, self.p, (b1 - b0,) + self.shape[1:], self.index0 + b0 * inner)
+
+    def reshape(self, *shape):
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else tuple(shape)
+        n = self.numel()
+        if -1 in shape:
+            known = 1
+            for s in shape:
+                known *= s if s != -1 else 1
+            shape = tuple(n // known if s == -1 else s for s in shape)
+        assert Drop(self.state, self.site, self.p, shape).numel() == n
+        return Drop(self.state, self.site, self.p, shape, self.index0)
+
+    def contiguous(self):
+        return self
+
+    def materialize(self):
+        """The stored form (tests): the draw's elements index0 .. index0 + numel."""
+        full = torch.empty(self.index0 + self.numel(), device=self.state.device)
+        dropout_mask(full, self.p, self.state, self.site)
+        return full[self.index0:].view(self.shape).clone()
+
+
 def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, M=None,
                 b_seg=None, out_scale=None, gate=None, res=None, out2=None, res_slope=0.0, w_planes=None, w_row0=0):
     """Checked tg_gemm_nt_problem.  b_seg = (seg_k, seg_stride_floats): K-concatenated weights, W is the first [N, seg_k] segment and
@@ -111,7 +155,11 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
     if w_planes is not None:                   # Planes that hold W's rows from w_row0 on (split3_planes / layers.weight_planes): mover-wave kernel
         assert b_seg is None and w_planes.cw == A.K and 0 <= w_row0 and w_row0 + N <= w_planes.rows and w_planes.t.is_cuda, (w_planes.rows, N, w_planes.cw, A.K)
         q.b_planes, q.b_plane_stride, q.b_rows, q.b_row0 = w_planes.t.data_ptr(), w_planes.plane_stride, w_planes.rows, int(w_row0)
-    if out_scale is not None:                  # element-wise multiplier applied after the activation, addressed exactly like `out`
+    if isinstance(out_scale, Drop):            # the dropout scale regenerated in the epilogue: `out` must be the contiguous tensor the mask was drawn for
+        assert out_scale.numel() == M * N and out_scale.index0 % 4 == 0 and N % 4 == 0, (out_scale.shape, M, N)
+        assert c_row_stride == N and (c_rows_out >= M or c_batch_stride == c_rows_out * c_row_stride), "regenerated dropout needs a contiguous output"
+        q.drop_state, q.drop_site, q.drop_index0, q.drop_p = out_scale.state.data_ptr(), out_scale.site, out_scale.index0, out_scale.p
+    elif out_scale is not None:                # element-wise multiplier applied after the activation, addressed exactly like `out`
         _f32(out_scale, "out_scale")
         assert out_scale.shape == out.shape and out_scale.stride() == out.stride(), (out_scale.shape, out.shape)
         q.out_scale = out_scale.data_ptr()
@@ -656,12 +704,21 @@ def add_relu(a, b, y):
 
 
 def act_mask_bwd(dy, y, mask, slope, dx):
+    if isinstance(mask, Drop):
+        n = _same(dy, y, dx)
+        assert mask.numel() == n
+        call("tg_act_mask_bwd_drop", _p(dy), _p(y), mask.p, _p(mask.state), mask.site, mask.index0, float(slope), _p(dx), n, _stream()); return dx
     n = _same(dy, y, dx) if mask is None else _same(dy, y, mask, dx)
     call("tg_act_mask_bwd", _p(dy), _p(y), _p(mask), float(slope), _p(dx), n, _stream()); return dx
 
 
 def act_mask_bwd2(dy, y, o, mask, slope, dsum, dc):
     """(dsum, dc): dsum = dy * (y > 0), dc = dsum * (o > 0 ? 1 : slope) * mask -- both gates of a residual block's backward in one pass."""
+    if isinstance(mask, Drop):
+        n = _same(dy, y, o, dsum, dc)
+        assert mask.numel() == n
+        call("tg_act_mask_bwd2_drop", _p(dy), _p(y), _p(o), mask.p, _p(mask.state), mask.site, mask.index0, float(slope), _p(dsum), _p(dc), n, _stream())
+        return dsum, dc
     n = _same(dy, y, o, dsum, dc) if mask is None else _same(dy, y, o, mask, dsum, dc)
     call("tg_act_mask_bwd2", _p(dy), _p(y), _p(o), _p(mask), float(slope), _p(dsum), _p(dc), n, _stream()); return dsum, dc
 

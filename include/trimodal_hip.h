@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3
+#define TG_ABI_VERSION 4
 
 int tg_version(void);
 const char* tg_last_error(void);
@@ -101,7 +101,16 @@ typedef struct tg_gemm_nt_problem {
     const float* res;
     float* C2;
     float res_slope;
-    int32_t reserved3;
+    /* ABI 4 -- the dropout scale REGENERATED instead of read (no mask tensor, no draw launch): with drop_state != NULL (out_scale must be
+     * NULL) the multiplier of the element at offset o from C (in elements, o as C is addressed) is element drop_index0 + o of the draw
+     * tg_dropout_mask(mask, n, drop_p, drop_state, drop_site) would write -- Philox4x32-10 keyed by the element index, so forward and
+     * backward consumers of one F.dropout (model/tcn.py:22-29) see the same mask without storing it.  Needs the big-product path
+     * (tg_gemm_nt_ext_supported), a vectorisable C and drop_index0 % 4 == 0; refused with an error elsewhere. */
+    uint32_t drop_site;
+    const uint64_t* drop_state;
+    int64_t drop_index0;
+    float drop_p;
+    int32_t reserved4;
 } tg_gemm_nt_problem;
 /* tg_gemm_nt_group: up to 8 independent tg_gemm_nt products in ONE launch (both GRU directions' input projections, the stride
  * phases of a conv input-gradient ...).  All problems must fall into the same kernel family as problem 0 (big / narrow / small);
@@ -364,6 +373,13 @@ int tg_act_mask_bwd2(const float* dy, const float* y, const float* o, const floa
 /* dx = dy * mask * (y > 0 ? 1 : slope); mask may be NULL (=1).  Backward of act() followed by dropout. */
 int tg_act_mask_bwd(const float* dy, const float* y, const float* mask, float slope, float* dx, int64_t n,
                     void* stream);
+/* The same two with the dropout scale REGENERATED: the multiplier of element i is element index0 + i of the draw
+ * tg_dropout_mask(mask, n, p, rng_state, site) would write (see tg_gemm_nt_problem.drop_state).  n and index0 multiples of 4, 16-byte
+ * aligned pointers.  model/tcn.py:22-29 backward without a stored mask. */
+int tg_act_mask_bwd_drop(const float* dy, const float* y, float p, const uint64_t* rng_state, uint32_t site, int64_t index0, float slope,
+                         float* dx, int64_t n, void* stream);
+int tg_act_mask_bwd2_drop(const float* dy, const float* y, const float* o, float p, const uint64_t* rng_state, uint32_t site, int64_t index0,
+                          float slope, float* dsum, float* dc, int64_t n, void* stream);
 /* y = x * mask  (nn.Dropout with a materialised inverted-dropout mask: 0 or 1/(1-p)). */
 int tg_mul(const float* x, const float* mask, float* y, int64_t n, void* stream);
 /* y (+)= alpha * x. */

@@ -671,6 +671,58 @@ def test_gemm_nt_mover_wave_kernel_windows_and_epilogues(pkg, dev):
     assert float((outc.double() - refc).abs().max() / refc.abs().max()) < 1e-5
 
 
+def test_regenerated_dropout_equals_stored_mask(pkg, dev):
+    """ops.Drop: the text encoder's dropout scale masks are not stored -- the conv epilogues (mover-wave and staged-slab kernels), the gated
+    input-gradient epilogue and act_mask_bwd / act_mask_bwd2 regenerate their elements from the counter RNG (model/tcn.py:22-29 forward and
+    backward).  Every consumer must produce BIT-IDENTICAL results to the stored mask of the same draw (tg_dropout_mask), including on the row
+    slice the backward works on and at a non-zero index offset (conv j of the eight shares one site)."""
+    ops, Win, Lm = pkg.ops, pkg.ops.Win, pkg.layers
+    g = torch.Generator().manual_seed(21)
+    B, T, Cc, d = 384, 34, 300, 2
+    state = ops.new_rng_state(1234, dev)
+    drop = ops.Drop(state, 7, 0.3, (B, T, Cc), index0=2 * B * T * Cc)
+    mask = drop.materialize()
+    assert mask.shape == (B, T, Cc) and 0.25 < float((mask == 0).float().mean()) < 0.35 and float(mask.max()) == pytest.approx(1 / 0.7)
+    x = torch.randn(B, T, Cc, generator=g).to(dev)
+    wp = (torch.randn(Cc, 2 * Cc, generator=g) * 0.05).to(dev)
+    b = torch.randn(Cc, generator=g).to(dev)
+    wpl = ops.split3_planes(wp)
+    res = torch.randn(B, T, Cc, generator=g).to(dev)
+    outs = []
+    for m in (mask, drop):                                  # forward conv on the mover-wave kernel, with the residual second output
+        o, o2 = torch.empty(B, T, Cc, device=dev), torch.empty(B, T, Cc, device=dev)
+        probs = [dict(A=Win.conv(x, 2, pad=d, dil=d, rows_out=T), W=wp, bias=b, out=o, act_slope=0.0, out_scale=m, res=res, out2=o2, res_slope=0.0,
+                      c_batch_stride=o.stride(0), c_row_stride=o.stride(1), c_rows_out=T, w_planes=wpl)]
+        assert ops.nt_kernel_plan(probs)[0] == 2
+        ops.gemm_nt_group(probs)
+        outs.append((o, o2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][0] == 0).float().mean()) > 0.25
+    # backward forms on the rows of the differentiated call
+    rows = slice(128, 256)
+    M = 128 * T
+    dy, y, o1 = (torch.randn(M, Cc, generator=g).to(dev) for _ in range(3))
+    wT = (torch.randn(Cc, 2 * Cc, generator=g) * 0.05).to(dev)
+    dc3 = torch.randn(128, T, Cc, generator=g).to(dev)
+    gate = torch.relu(torch.randn(M, Cc, generator=g)).to(dev)
+    got = []
+    for m in (mask, drop):
+        mr = m[rows].reshape(M, -1)
+        dsum, dc = ops.act_mask_bwd2(dy, y, o1, mr, 0.0, torch.empty_like(dy), torch.empty_like(dy))
+        dx = ops.act_mask_bwd(dy, y, mr, 0.0, torch.empty_like(dy))
+        dh = torch.empty(M, Cc, device=dev)
+        pr = [dict(A=Win.taps(dc3, 2, shift=d, dil=-d, rows_out=T), W=wT, bias=None, out=dh, out_scale=mr, gate=gate)]
+        assert ops.nt_kernel_plan(pr)[0] == 1               # 4 352 rows: staged-slab kernel
+        ops.gemm_nt_group(pr)
+        got.append((dsum, dc, dx, dh))
+    for a, b_ in zip(*got):
+        assert torch.equal(a, b_)
+    # refused where no kernel regenerates it (a small product), loudly
+    xs, ws, os_ = torch.randn(64, 64, device=dev), torch.randn(32, 64, device=dev), torch.empty(64, 32, device=dev)
+    with pytest.raises(Exception):
+        ops.gemm_nt(Win.plain(xs), ws, None, os_, out_scale=ops.Drop(state, 7, 0.3, (64, 32)))
+
+
 def test_bf16_math_mode_tier(pkg, dev):
     """tg_set_math_mode(1): the big forward / input-gradient products take bf16 operands (one MFMA per product, fp32 accumulate).
     Op-level error at the bf16 level (and clearly different from the fp32 result: the mode really switches), and one full GAN
