@@ -462,7 +462,7 @@ __global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restr
             f32x4 m;
 #pragma unroll
             for (int q = 0; q < 4; ++q) m[q] = u01(r[q]) >= p ? keep : 0.f;
-            reinterpret_cast<f32x4*>(mask)[i] = m;
+            if (mask) reinterpret_cast<f32x4*>(mask)[i] = m;       // (NULL: the consumers regenerate it, ops.Drop)
             reinterpret_cast<f32x4*>(y)[i] = xv * m;
         } else {
             philox4x32(seed, (uint64_t)i, site, step, r);
@@ -471,7 +471,7 @@ __global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restr
                 const long e = i * 4 + q;
                 if (e < n) {
                     const float m = u01(r[q]) >= p ? keep : 0.f;
-                    mask[e] = m;
+                    if (mask) mask[e] = m;
                     y[e] = x[e] * m;
                 }
             }
@@ -746,7 +746,7 @@ int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, 
     return check_launch("tg_dropout_mask");
 }
 int tg_dropout_apply(const float* x, float* y, float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream) {
-    TG_REQUIRE(x && y && mask && rng_state && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout_apply: bad arguments");
+    TG_REQUIRE(x && y && rng_state && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout_apply: bad arguments");
     if (n % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(mask)) EW(dropout_apply_kernel<true>, n / 4, x, y, mask, (long)n, p, rng_state, site);
     else EW(dropout_apply_kernel<false>, (n + 3) / 4, x, y, mask, (long)n, p, rng_state, site);
     return check_launch("tg_dropout_apply");

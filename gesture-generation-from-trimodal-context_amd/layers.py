@@ -448,13 +448,17 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
                 mask = inject[name]
                 cur = ops.mul(y, mask, torch.empty_like(y))
             elif p_drop > 0:
-                cur, mask = ops.dropout_apply(y, p_drop, rng.state, rng.site(name))     # draw + apply in one pass
+                # draw + apply in one pass; big batches: the mask is not stored, the input-gradient GEMM's epilogue regenerates it (ops.Drop)
+                cur, mask = ops.dropout_apply(y, p_drop, rng.state, rng.site(name), store_mask=not (DROP_REGEN and B * T >= 8192))
             else:
                 cur = y
         else:
             cur = y
         tape.masks.append(mask)
     return cur, tape
+
+
+DROP_REGEN = __import__("os").environ.get("TG_TCN_DROP_REGEN", "1") != "0"      # dropout masks regenerated by their consumers (ops.Drop) at big batches
 
 
 class Fork:
@@ -523,7 +527,7 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
             if ops.gru_fused_dropout(nb, H, bwd=True):
                 dy_mask = tape.masks[l][rows].contiguous()         # multiplied in while the recurrence kernel loads dy
             else:
-                dy = ops.mul(dy, tape.masks[l][rows].contiguous(), torch.empty_like(dy))
+                dy = ops.mul(dy.contiguous(), tape.masks[l][rows].contiguous(), torch.empty_like(dy))
         scaled = False
         wt = tuple(transpose2d(P[f"{prefix}.weight_hh_l{l}{s}"]) for s in ("", "_reverse"))
         dgi, dgh = empty(2, nb, T, 3 * H, like=dy), empty(2, nb, T, 3 * H, like=dy)

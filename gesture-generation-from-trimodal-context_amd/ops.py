@@ -724,6 +724,8 @@ def act_mask_bwd2(dy, y, o, mask, slope, dsum, dc):
 
 
 def mul(x, mask, y):
+    if isinstance(mask, Drop):                 # x * regenerated mask = act_mask_bwd with slope 1 (the gate factor is then 1 everywhere)
+        return act_mask_bwd(x, x, mask, 1.0, y)
     call("tg_mul", _p(x), _p(mask), _p(y), _same(x, mask, y), _stream()); return y
 
 
@@ -877,10 +879,15 @@ def dropout_mask(mask, p, state, site):
     return mask
 
 
-def dropout_apply(x, p, state, site):
-    """(y, mask) with mask drawn as dropout_mask does and y = x * mask, one pass."""
+def dropout_apply(x, p, state, site, store_mask=True):
+    """(y, mask) with mask drawn as dropout_mask does and y = x * mask, one pass.  store_mask=False: the mask is not written; the second
+    return value is the Drop its backward consumers regenerate it from (x.numel() % 4 == 0)."""
     _flat(x, "x")
-    y, mask = torch.empty_like(x), torch.empty_like(x)
+    y = torch.empty_like(x)
+    if not store_mask and x.numel() % 4 == 0:
+        call("tg_dropout_apply", _p(x), _p(y), None, x.numel(), float(p), _p(_i64(state, "rng_state")), int(site), _stream())
+        return y, Drop(state, site, p, x.shape)
+    mask = torch.empty_like(x)
     call("tg_dropout_apply", _p(x), _p(y), _p(mask), x.numel(), float(p), _p(_i64(state, "rng_state")), int(site), _stream())
     return y, mask
 

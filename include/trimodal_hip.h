@@ -444,7 +444,8 @@ int tg_rng_advance(uint64_t* rng_state, void* stream);
  * (tg_adam_step then runs with the counter already advanced); any pointer may be NULL, not all. */
 int tg_iter_begin(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, void* stream);
 int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream);
-/* Draw the same mask and apply it in one pass: mask as tg_dropout_mask, y[i] = x[i] * mask[i] (F.dropout, train mode). */
+/* Draw the same mask and apply it in one pass: mask as tg_dropout_mask, y[i] = x[i] * mask[i] (F.dropout, train mode).  mask may be NULL
+ * (ABI 4): the mask is not stored, its later consumers regenerate it (tg_gemm_nt_problem.drop_state, tg_act_mask_bwd_drop). */
 int tg_dropout_apply(const float* x, float* y, float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site,
                      void* stream);
 int tg_normal(float* out, int64_t n, const uint64_t* rng_state, uint32_t site, void* stream);

@@ -717,6 +717,14 @@ def test_regenerated_dropout_equals_stored_mask(pkg, dev):
         got.append((dsum, dc, dx, dh))
     for a, b_ in zip(*got):
         assert torch.equal(a, b_)
+    # draw-and-apply without storing the mask (embedding dropout, the generator GRU's inter-layer dropout): same y, same mask when regenerated,
+    # and x * mask through the regenerating multiply
+    xe = torch.randn(B, T, Cc, generator=g).to(dev)
+    y1, m1 = ops.dropout_apply(xe, 0.1, state, 9)
+    y2, d2 = ops.dropout_apply(xe, 0.1, state, 9, store_mask=False)
+    assert isinstance(d2, ops.Drop) and torch.equal(y1, y2) and torch.equal(d2.materialize(), m1)
+    dyr = torch.randn(M, Cc, generator=g).to(dev)
+    assert torch.equal(ops.mul(dyr, d2[rows].reshape(M, -1).contiguous(), torch.empty_like(dyr)), dyr * m1[rows].reshape(M, -1))
     # refused where no kernel regenerates it (a small product), loudly
     xs, ws, os_ = torch.randn(64, 64, device=dev), torch.randn(32, 64, device=dev), torch.empty(64, 32, device=dev)
     with pytest.raises(Exception):
