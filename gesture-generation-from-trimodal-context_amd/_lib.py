@@ -82,6 +82,7 @@ SIGNATURES = {
     "tg_add_relu": [P, P, P, I64, P],
     "tg_act_mask_bwd": [P, P, P, F32, P, I64, P],
     "tg_act_mask_bwd2": [P, P, P, P, F32, P, P, I64, P],
+    "tg_iter_head": [P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, I32, P, U32, P, P],
     "tg_act_mask_bwd_drop": [P, P, F32, P, U32, I64, F32, P, I64, P],
     "tg_act_mask_bwd2_drop": [P, P, P, F32, P, U32, I64, F32, P, P, I64, P],
     "tg_mul": [P, P, P, I64, P],

@@ -421,6 +421,78 @@ __global__ void iter_begin_kernel(uint64_t* rng_a, uint64_t* rng_b, int32_t* cnt
     if (cnt_a) *cnt_a += 1;
     if (cnt_b) *cnt_b += 1;
 }
+// The whole head of a GAN iteration in ONE launch (it was seven: counters, make_pre_seq, randperm, gather, and three ATen copies that
+// stacked the inputs of the generator calls -- 4.7 us each inside the captured iteration).  Workgroup 0: the counters of tg_iter_begin, then
+// (speaker mode) the permutation of the diversity term drawn from rng_a at its NEW step (or the injected one), and the stacked speaker ids
+// [vid] * (copies - 1) + [vid[perm]] (or vid in every copy when nothing is permuted).  Every other workgroup: the stacked seed poses
+// (tg_make_pre_seq, `copies` times) and the stacked word ids.
+__global__ __launch_bounds__(1024) void iter_head_kernel(uint64_t* rng_a, uint64_t* rng_b, int32_t* cnt_a, int32_t* cnt_b, const float* __restrict__ target,
+                                                         float* __restrict__ pre, int B, int T, int D, int n_pre, int copies,
+                                                         const int64_t* __restrict__ text, int64_t* __restrict__ text_s,
+                                                         const int64_t* __restrict__ vid, int64_t* __restrict__ vid_s, int permute_last,
+                                                         const int64_t* __restrict__ perm_in, uint32_t perm_site, int64_t* __restrict__ perm_out) {
+    if (blockIdx.x == 0) {
+        __shared__ uint64_t keys[1024];
+        __shared__ int perm_sh[1024];
+        const int i = threadIdx.x;
+        if (i == 0) {
+            if (rng_a) rng_a[1] += 1;
+            if (rng_b) rng_b[1] += 1;
+            if (cnt_a) *cnt_a += 1;
+            if (cnt_b) *cnt_b += 1;
+            __threadfence();
+        }
+        __syncthreads();
+        if (!vid_s) return;
+        if (permute_last) {
+            if (perm_in) {
+                if (i < B) perm_sh[i] = (int)perm_in[i];
+            } else {
+                if (i < B) {
+                    uint32_t r[4];
+                    const uint64_t seed = __hip_atomic_load(rng_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t step = __hip_atomic_load(rng_a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the value thread 0 just wrote
+                    philox4x32(seed, (uint64_t)i, perm_site, (uint32_t)step, r);
+                    keys[i] = ((uint64_t)r[0] << 32) | r[1];
+                }
+                __syncthreads();
+                if (i < B) {                               // exactly randperm_kernel
+                    const uint64_t k = keys[i];
+                    int rank = 0;
+                    for (int j = 0; j < B; ++j) rank += (keys[j] < k) || (keys[j] == k && j < i);
+                    perm_sh[rank] = i;
+                }
+            }
+            __syncthreads();
+            if (i < B && perm_out) perm_out[i] = perm_sh[i];
+        }
+        if (i < B) {
+            const int64_t v = vid[i];
+            for (int c = 0; c < copies; ++c) {
+                int64_t o = v;
+                if (permute_last && c == copies - 1) {
+                    const int p = perm_sh[i];
+                    o = (p >= 0 && p < B) ? vid[p] : 0;        // as gather_i64_kernel
+                }
+                vid_s[(long)c * B + i] = o;
+            }
+        }
+        return;
+    }
+    const long per = (long)B * T * (D + 1), n = per * copies;
+    const long tid = (long)(blockIdx.x - 1) * blockDim.x + threadIdx.x, nth = (long)(gridDim.x - 1) * blockDim.x;
+    for (long i = tid; i < n; i += nth) {
+        const long e = i % per;
+        const int c = (int)(e % (D + 1));
+        const long bt = e / (D + 1);
+        const int t = (int)(bt % T);
+        pre[i] = t < n_pre ? (c < D ? target[bt * D + c] : 1.f) : 0.f;
+    }
+    if (text_s) {
+        const long pt = (long)B * T, nt = pt * copies;
+        for (long i = tid; i < nt; i += nth) text_s[i] = text[i % pt];
+    }
+}
 // VEC: n % 4 == 0 and 16-byte aligned pointers (checked by the launcher): one 16-byte access per array and Philox draw instead of four
 // scalar ones (the GRU inter-layer dropout moved 93 MB at 2.7 TB/s through the scalar form)
 template <bool VEC>
@@ -733,6 +805,19 @@ int tg_iter_begin(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_
     TG_REQUIRE(rng_a || rng_b || adam_step_a || adam_step_b, "tg_iter_begin: nothing to advance");
     hipLaunchKernelGGL(iter_begin_kernel, dim3(1), dim3(1), 0, ST, rng_a, rng_b, adam_step_a, adam_step_b);
     return check_launch("tg_iter_begin");
+}
+int tg_iter_head(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, const float* target, float* pre_stacked, int32_t B,
+                 int32_t T, int32_t D, int32_t n_pre, int32_t copies, const int64_t* text, int64_t* text_stacked, const int64_t* vid,
+                 int64_t* vid_stacked, int32_t permute_last, const int64_t* perm_in, uint32_t perm_site, int64_t* perm_out, void* stream) {
+    TG_REQUIRE(target && pre_stacked && B > 0 && T > 0 && D > 0 && n_pre >= 0 && copies >= 1, "tg_iter_head: bad arguments");
+    TG_REQUIRE((text == nullptr) == (text_stacked == nullptr) && (vid == nullptr) == (vid_stacked == nullptr), "tg_iter_head: text / vid and their stacked outputs go together");
+    TG_REQUIRE(!vid || B <= 1024, "tg_iter_head: B=%d speaker ids must fit one workgroup (<= 1024)", B);
+    TG_REQUIRE(!permute_last || (vid && (perm_in || rng_a)), "tg_iter_head: a drawn permutation needs vid and rng_a");
+    const long n = (long)B * T * (D + 1) * copies;
+    const int blocks = 1 + (int)((n + 4095) / 4096 < 255 ? (n + 4095) / 4096 : 255);
+    hipLaunchKernelGGL(iter_head_kernel, dim3(blocks < 2 ? 2 : blocks), dim3(1024), 0, ST, rng_a, rng_b, adam_step_a, adam_step_b, target, pre_stacked, B, T, D,
+                       n_pre, copies, text, text_stacked, vid, vid_stacked, permute_last, perm_in, perm_site, perm_out);
+    return check_launch("tg_iter_head");
 }
 int tg_rng_advance(uint64_t* rng_state, void* stream) {
     TG_REQUIRE(rng_state, "tg_rng_advance: null");

@@ -39,10 +39,13 @@ __global__ __launch_bounds__(256) void gan_d_loss_kernel(const float* __restrict
 }
 
 // stage 1: one workgroup per clip -> ws[b] = P_b (pose smooth-L1 sum vs the shuffled-speaker output),
-// ws[B+b] = mean_c |z - z_rand|, ws[2B+b] = sum smooth-L1((out - target)/0.1)
+// ws[B+b] = mean_c |z - z_rand|, ws[2B+b] = sum smooth-L1((out - target)/0.1); and the clip's rows of d_out: the diversity term's
+// coefficient depends on this clip's P_b and z distance only, so
+//   d_out = w_h * sl1'((o-t)/0.1) / (B*TD) + coef_b * sl1'((o-orand)/0.05),  coef_b = d(w_d * div_reg)/dP_b (0 where the ratio is clamped)
+// needs no other workgroup (it was a third launch after the scalar stage)
 __global__ __launch_bounds__(256) void gan_g_stage1(const float* __restrict__ o, const float* __restrict__ t, const float* __restrict__ orand,
                                                     const float* __restrict__ z, const float* __restrict__ zr, int B, int TD, int Z,
-                                                    float* __restrict__ ws) {
+                                                    float* __restrict__ ws, float w_h, float w_d, float* __restrict__ d_out) {
     __shared__ float sh[4];
     const int b = blockIdx.x;
     float p = 0.f, h = 0.f, zl = 0.f;
@@ -56,6 +59,14 @@ __global__ __launch_bounds__(256) void gan_g_stage1(const float* __restrict__ o,
     h = block_sum256(h, sh);
     zl = block_sum256(zl, sh);
     if (threadIdx.x == 0) { ws[b] = p; ws[B + b] = zl / (float)Z; ws[2 * B + b] = h; }
+    const float den = zl / (float)Z + 1.0e-5f;
+    const float coef = (-(p / den) < -1000.f) ? 0.f : (-1.f / den) * w_d * (1.f / (float)B);        // as stage 2 forms it
+    const float hn = w_h / (float)((long)B * TD);
+    for (int i = threadIdx.x; i < TD; i += 256) {
+        const long e = (long)b * TD + i;
+        const float ov = o[e];
+        d_out[e] = hn * dsl1((ov - t[e]) / 0.1f) + coef * dsl1((ov - orand[e]) / 0.05f);
+    }
 }
 
 // stage 2 (one workgroup): scalars, per-clip div_reg coefficient (overwrites ws[b]), d_mu, d_logvar, d_logit
@@ -96,18 +107,6 @@ __global__ __launch_bounds__(256) void gan_g_stage2(const float* __restrict__ mu
         const float ge = -gen * invB;
         sc[0] = huber; sc[1] = kl; sc[2] = dv; sc[3] = ge;
         sc[4] = w_h * huber + w_k * kl + w_d * dv + (use_gan ? w_g * ge : 0.f);
-    }
-}
-
-// stage 3: d_out = w_h * sl1'((o-t)/0.1) / (B*TD) + coef_b * sl1'((o-orand)/0.05)
-__global__ void gan_g_stage3(const float* __restrict__ o, const float* __restrict__ t, const float* __restrict__ orand, const float* __restrict__ ws,
-                             int B, int TD, float w_h, float* __restrict__ d_out) {
-    const long n = (long)B * TD;
-    const float hn = w_h / (float)n;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / TD);
-        const float ov = o[i];
-        d_out[i] = hn * dsl1((ov - t[i]) / 0.1f) + ws[b] * dsl1((ov - orand[i]) / 0.05f);
     }
 }
 
@@ -305,10 +304,9 @@ int tg_gan_g_loss(const float* out_pose, const float* target, const float* out_r
     TG_REQUIRE(out_pose && target && out_rand && z && z_rand && mu && logvar && logit_out && ws && scalars && d_out && d_mu &&
                    d_logvar && d_logit_out, "tg_gan_g_loss: null pointer");
     TG_REQUIRE(B > 0 && TD > 0 && Z > 0, "tg_gan_g_loss: bad sizes");
-    hipLaunchKernelGGL(gan_g_stage1, dim3(B), dim3(256), 0, ST, out_pose, target, out_rand, z, z_rand, B, TD, Z, ws);
+    hipLaunchKernelGGL(gan_g_stage1, dim3(B), dim3(256), 0, ST, out_pose, target, out_rand, z, z_rand, B, TD, Z, ws, w_huber, w_div, d_out);
     hipLaunchKernelGGL(gan_g_stage2, dim3(1), dim3(256), 0, ST, mu, logvar, logit_out, B, TD, Z, w_huber, w_kld, w_div, w_gan, use_gan, ws,
                        scalars, d_mu, d_logvar, d_logit_out);
-    hipLaunchKernelGGL(gan_g_stage3, dim3(ew_grid((long)B * TD)), dim3(256), 0, ST, out_pose, target, out_rand, ws, B, TD, w_huber, d_out);
     return check_launch("tg_gan_g_loss");
 }
 

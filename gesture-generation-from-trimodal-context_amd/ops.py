@@ -865,6 +865,28 @@ def rng_advance(state):
     call("tg_rng_advance", _p(_i64(state, "rng_state")), _stream())
 
 
+def iter_head(rng_a, rng_b, step_a, step_b, target, n_pre, copies, text=None, vid=None, permute_last=False, perm_in=None, perm_site=0):
+    """tg_iter_head: counters + stacked seed poses / word ids / speaker ids of a GAN iteration, one launch.  Returns (pre_s, text_s, vid_s)."""
+    for r in (rng_a, rng_b):
+        assert r is None or _i64(r, "rng_state") is r
+    for c in (step_a, step_b):
+        assert c is None or (c.is_cuda and c.dtype == torch.int32)
+    _flat(target, "target"); B, T, D = target.shape
+    pre = torch.empty(copies * B, T, D + 1, device=target.device)
+    text_s = vid_s = None
+    if text is not None:
+        _i64(text, "text"); assert tuple(text.shape) == (B, T)
+        text_s = torch.empty(copies * B, T, dtype=torch.int64, device=target.device)
+    if vid is not None:
+        _i64(vid, "vid"); assert vid.numel() == B
+        vid_s = torch.empty(copies * B, dtype=torch.int64, device=target.device)
+    if perm_in is not None:
+        _i64(perm_in, "perm"); assert perm_in.numel() == B
+    call("tg_iter_head", _p(rng_a), _p(rng_b), _p(step_a), _p(step_b), _p(target), _p(pre), B, T, D, int(n_pre), int(copies), _p(text), _p(text_s),
+         _p(vid), _p(vid_s), int(bool(permute_last)), _p(perm_in), int(perm_site), None, _stream())
+    return pre, text_s, vid_s
+
+
 def iter_begin(rng_a, rng_b, step_a, step_b):
     """Advance up to two RNG states and up to two Adam step counters in one launch (None = skip)."""
     for r in (rng_a, rng_b):

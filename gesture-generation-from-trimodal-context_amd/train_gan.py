@@ -145,26 +145,16 @@ class GanTrainer:
         if G.use_side_stream and ops.GRU_CLUSTER and os.environ.get("TG_SIDE_STREAM") != "2":      # "2": lab switch, measure anyway
             raise RuntimeError("TG_SIDE_STREAM=1 cannot be combined with the cluster-synchronised GRU kernels (set TG_GRU_CLUSTER=0): "
                                "side-stream kernels beside them break the co-residency their hand-off relies on")
-        # both RNG step counters and the Adam step counters of the optimisers that step in this iteration: one launch
-        ops.iter_begin(G.rng.state, D.rng.state, self.g_opt.slab.step, self.d_opt.slab.step if post else None)
         target = target.contiguous().float()
-        pre = ops.make_pre_seq(target, torch.empty(B, target.shape[1], target.shape[2] + 1, device=dev), self.hp["n_pre_poses"])
         speaker = self.G.z_mode == "speaker"
         tags = (["g1"] if post else []) + ["g2"] + (["g3"] if self.use_reg else [])
         ng, i2 = len(tags), tags.index("g2")
-        vid_s = None
-        if speaker:
-            vid = vid.contiguous()
-            parts = [vid] * (ng - 1 if self.use_reg else ng)
-            if self.use_reg:
-                if inject is not None and "perm" in inject:
-                    perm = inject["perm"].to(dev).long().contiguous()
-                else:
-                    perm = ops.randperm(torch.empty(B, dtype=torch.int64, device=dev), G.rng.state, G.rng.site("perm"))
-                parts.append(ops.gather_i64(vid, perm, torch.empty_like(vid)))
-            vid_s = torch.cat(parts) if len(parts) > 1 else parts[0]
-        pre_s = pre.repeat(ng, 1, 1) if ng > 1 else pre                # data movement only
-        text_s = in_text.contiguous().repeat(ng, 1) if ng > 1 else in_text.contiguous()
+        # ONE launch: both RNG step counters and the Adam step counters of the optimisers that step in this iteration; the seed poses, word
+        # ids and speaker ids of the ng stacked generator calls, the last call's ids shuffled by the diversity term's permutation (:67-72)
+        perm_in = inject["perm"].to(dev).long().contiguous() if (inject is not None and "perm" in inject) else None
+        pre_s, text_s, vid_s = ops.iter_head(G.rng.state, D.rng.state, self.g_opt.slab.step, self.d_opt.slab.step if post else None, target,
+                                             self.hp["n_pre_poses"], ng, text=in_text.contiguous(), vid=vid.contiguous() if speaker else None,
+                                             permute_last=speaker and self.use_reg, perm_in=perm_in, perm_site=G.rng.site("perm"))
         res = G.forward(pre_s, text_s, in_audio.float(), vid_s, training=True, groups=ng, save=True,
                         inject=_stack_inject(inject, tags, "g"), tag="g", save_rows=(i2 * B, B))     # only call g2 is differentiated (:50-88)
         if self.keep_tape:
@@ -203,11 +193,11 @@ class GanTrainer:
         # the fused loss kernel covers every z_type through its weights: terms the reference leaves out (:59-84) get weight 0
         # and neutral operands (out_rand = out, z_rand = z, mu = logvar = 0)
         speaker_terms = self.G.z_mode == "speaker" and self.use_reg
-        zero_z = ops.zeros(B, 16, device=dev)
+        zero_z = ops.zeros(B, 16, device=dev) if not (speaker_terms and self.use_reg) else None      # neutral operand of the terms left out
         mu2, lv2 = (st["mu2"].contiguous(), st["lv2"].contiguous()) if speaker_terms else (zero_z, zero_z)
         z2, z3 = (st["z2"].contiguous(), st["z3"].contiguous()) if self.use_reg else (zero_z, zero_z)
         out3 = st["out3"].contiguous() if self.use_reg else out2
-        d_mu, d_lv = torch.empty_like(zero_z), torch.empty_like(zero_z)
+        d_mu, d_lv = torch.empty(B, 16, device=dev), torch.empty(B, 16, device=dev)
         ops.gan_g_loss(out2, st["target"], out3, z2, z3, mu2, lv2, dres["logit"].view(-1),
                        (hp["loss_regression_weight"], hp["loss_kld_weight"] if speaker_terms else 0.0,
                         hp["loss_reg_weight"] if self.use_reg else 0.0, hp["loss_gan_weight"]),

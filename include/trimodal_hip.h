@@ -443,6 +443,14 @@ int tg_rng_advance(uint64_t* rng_state, void* stream);
 /* start of a training iteration in one launch: rng_state[1] += 1 for up to two RNG states and += 1 for up to two Adam step counters
  * (tg_adam_step then runs with the counter already advanced); any pointer may be NULL, not all. */
 int tg_iter_begin(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, void* stream);
+/* The head of one train_iter_gan call (scripts/train_eval/train_gan.py:13-30,50,67-72) in ONE launch: tg_iter_begin's counters; the seed
+ * poses of the `copies` stacked generator calls (tg_make_pre_seq, pre_stacked [copies][B][T][D + 1]); the word ids copied `copies` times
+ * (text [B][T] -> text_stacked, both may be NULL); the speaker ids [vid] * (copies - 1) + [last] (vid [B] -> vid_stacked [copies][B], both
+ * may be NULL) where last = vid[perm] if permute_last -- perm = torch.randperm(B) of :69 drawn as tg_randperm(.., rng_a at its NEW step,
+ * perm_site) or given (perm_in, tests), also written to perm_out when non-NULL -- and vid otherwise.  B <= 1024 with speaker ids. */
+int tg_iter_head(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, const float* target, float* pre_stacked, int32_t B,
+                 int32_t T, int32_t D, int32_t n_pre, int32_t copies, const int64_t* text, int64_t* text_stacked, const int64_t* vid,
+                 int64_t* vid_stacked, int32_t permute_last, const int64_t* perm_in, uint32_t perm_site, int64_t* perm_out, void* stream);
 int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream);
 /* Draw the same mask and apply it in one pass: mask as tg_dropout_mask, y[i] = x[i] * mask[i] (F.dropout, train mode).  mask may be NULL
  * (ABI 4): the mask is not stored, its later consumers regenerate it (tg_gemm_nt_problem.drop_state, tg_act_mask_bwd_drop). */

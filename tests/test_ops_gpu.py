@@ -731,6 +731,37 @@ def test_regenerated_dropout_equals_stored_mask(pkg, dev):
         ops.gemm_nt(Win.plain(xs), ws, None, os_, out_scale=ops.Drop(state, 7, 0.3, (64, 32)))
 
 
+def test_iter_head_equals_the_separate_launches(pkg, dev):
+    """tg_iter_head (the head of train_iter_gan, train_gan.py:13-30,50,67-72, one launch) against the seven launches it replaces: counters,
+    stacked seed poses, stacked word ids, stacked speaker ids with the last copy shuffled by the permutation drawn at the NEW rng step."""
+    ops = pkg.ops
+    B, T, D, ng = 128, 34, 27, 3
+    g = torch.Generator().manual_seed(3)
+    target = torch.randn(B, T, D, generator=g).to(dev)
+    text = torch.randint(0, 20000, (B, T), generator=g).to(dev)
+    vid = torch.randint(0, 1370, (B,), generator=g).to(dev)
+    for permute, injected in ((True, False), (True, True), (False, False)):
+        ra, rb = ops.new_rng_state(11, dev), ops.new_rng_state(12, dev)
+        ra2, rb2 = ra.clone(), rb.clone()
+        ca, cb = torch.zeros((), dtype=torch.int32, device=dev), torch.zeros((), dtype=torch.int32, device=dev)
+        ca2, cb2 = ca.clone(), cb.clone()
+        perm_in = torch.randperm(B, generator=g).to(dev) if injected else None
+        pre_s, text_s, vid_s = ops.iter_head(ra, rb, ca, cb, target, 4, ng, text=text, vid=vid, permute_last=permute, perm_in=perm_in, perm_site=5)
+        ops.iter_begin(ra2, rb2, ca2, cb2)
+        pre = ops.make_pre_seq(target, torch.empty(B, T, D + 1, device=dev), 4)
+        perm = perm_in if injected else ops.randperm(torch.empty(B, dtype=torch.int64, device=dev), ra2, 5)
+        last = ops.gather_i64(vid, perm, torch.empty_like(vid)) if permute else vid
+        assert torch.equal(ra, ra2) and torch.equal(rb, rb2) and int(ca) == int(ca2) == 1 and int(cb) == int(cb2) == 1
+        assert torch.equal(pre_s, pre.repeat(ng, 1, 1)) and torch.equal(text_s, text.repeat(ng, 1))
+        assert torch.equal(vid_s, torch.cat([vid] * (ng - 1) + [last]))
+        if permute and not injected:
+            assert sorted(perm.tolist()) == list(range(B)) and perm.tolist() != list(range(B))
+    # no speaker ids, one copy, only one counter
+    ra = ops.new_rng_state(11, dev)
+    pre_s, text_s, vid_s = ops.iter_head(ra, None, None, None, target, 4, 1, text=text)
+    assert vid_s is None and int(ra[1]) == 1 and torch.equal(pre_s, ops.make_pre_seq(target, torch.empty(B, T, D + 1, device=dev), 4))
+
+
 def test_bf16_math_mode_tier(pkg, dev):
     """tg_set_math_mode(1): the big forward / input-gradient products take bf16 operands (one MFMA per product, fp32 accumulate).
     Op-level error at the bf16 level (and clearly different from the fp32 result: the mode really switches), and one full GAN
