@@ -72,7 +72,7 @@ SIGNATURES = {
     "tg_wav_front_apply": [P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, P, P],
     "tg_wav_front_backward": [P, P, P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, I64, P, P, P, P, P],
     "tg_wav_front_backward_fused": [P, I32, P, P, P, I64, I32, I32, P, P, I32, I32, I32, P, P, P, P, F32, P, I64, P, P, P, P, P],
-    "tg_speaker_fwd": [P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, I64, I32, P],
+    "tg_speaker_fwd": [P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, I64, I32, P, U32, P],
     "tg_speaker_bwd": [P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, I32, P],
     "tg_wav_conv2_wgrad": [P, P, I32, I32, I32, P, I64, P, P, P],
     "tg_out_mlp_compose": [P, P, P, P, I32, I32, I32, I32, P, P, P, P],
@@ -82,7 +82,8 @@ SIGNATURES = {
     "tg_add_relu": [P, P, P, I64, P],
     "tg_act_mask_bwd": [P, P, P, F32, P, I64, P],
     "tg_act_mask_bwd2": [P, P, P, P, F32, P, P, I64, P],
-    "tg_iter_head": [P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, I32, P, U32, P, P],
+    "tg_embed_gather_drop": [P, P, P, I32, I32, I32, F32, P, U32, P],
+    "tg_iter_head": [P, P, P, P, P, P, I64, I32, I32, I32, I32, I32, P, P, P, P, I32, P, U32, P, P],
     "tg_act_mask_bwd_drop": [P, P, F32, P, U32, I64, F32, P, I64, P],
     "tg_act_mask_bwd2_drop": [P, P, P, F32, P, U32, I64, F32, P, P, I64, P],
     "tg_mul": [P, P, P, I64, P],

@@ -173,6 +173,22 @@ __global__ void embed_gather_kernel(const float* __restrict__ table, const int64
         out[i] = (id >= 0 && id < n_rows) ? table[id * D + c] : 0.f;
     }
 }
+// the look-up followed by F.dropout (multimodal_context_net.py:47-52) in one pass, four columns per thread (D % 4 == 0, 16-byte aligned table
+// rows): out = table[idx] * mask, the mask being element i of the draw tg_dropout_mask(.., p, st, site) would write -- not stored, the
+// backward regenerates it (tg_act_mask_bwd_drop)
+__global__ void embed_gather_drop_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out, int n_idx, int D,
+                                         int n_rows, float p, const uint64_t* __restrict__ st, uint32_t site) {
+    const int d4 = D / 4;
+    const long n4 = (long)n_idx * d4;
+    GRID_STRIDE(i, n4) {
+        const long r = i / d4;
+        const int c4 = (int)(i - r * d4);
+        const int64_t id = idx[r];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (id >= 0 && id < n_rows) v = reinterpret_cast<const f32x4*>(table + id * D)[c4];
+        reinterpret_cast<f32x4*>(out)[i] = v * dropout_scale4(st, site, p, (unsigned long)i);
+    }
+}
 // Dense embedding gradient.  The padded text input is mostly index 0: consecutive look-ups with the same
 // index are summed in registers and flushed with ONE atomic per run, so the hot PAD row sees n_idx/CHUNK atomics per
 // column instead of thousands.
@@ -427,7 +443,7 @@ __global__ void iter_begin_kernel(uint64_t* rng_a, uint64_t* rng_b, int32_t* cnt
 // [vid] * (copies - 1) + [vid[perm]] (or vid in every copy when nothing is permuted).  Every other workgroup: the stacked seed poses
 // (tg_make_pre_seq, `copies` times) and the stacked word ids.
 __global__ __launch_bounds__(1024) void iter_head_kernel(uint64_t* rng_a, uint64_t* rng_b, int32_t* cnt_a, int32_t* cnt_b, const float* __restrict__ target,
-                                                         float* __restrict__ pre, int B, int T, int D, int n_pre, int copies,
+                                                         float* __restrict__ pre, long pre_ld, int B, int T, int D, int n_pre, int copies,
                                                          const int64_t* __restrict__ text, int64_t* __restrict__ text_s,
                                                          const int64_t* __restrict__ vid, int64_t* __restrict__ vid_s, int permute_last,
                                                          const int64_t* __restrict__ perm_in, uint32_t perm_site, int64_t* __restrict__ perm_out) {
@@ -486,7 +502,7 @@ __global__ __launch_bounds__(1024) void iter_head_kernel(uint64_t* rng_a, uint64
         const int c = (int)(e % (D + 1));
         const long bt = e / (D + 1);
         const int t = (int)(bt % T);
-        pre[i] = t < n_pre ? (c < D ? target[bt * D + c] : 1.f) : 0.f;
+        pre[(i / (D + 1)) * pre_ld + c] = t < n_pre ? (c < D ? target[bt * D + c] : 1.f) : 0.f;      // row (copy, b, t) of the stacked output
     }
     if (text_s) {
         const long pt = (long)B * T, nt = pt * copies;
@@ -745,6 +761,13 @@ int tg_embed_gather(const float* table, const int64_t* idx, float* out, int32_t 
     EW(embed_gather_kernel, (long)n_idx * D, table, idx, out, n_idx, D, n_rows);
     return check_launch("tg_embed_gather");
 }
+int tg_embed_gather_drop(const float* table, const int64_t* idx, float* out, int32_t n_idx, int32_t D, int32_t n_rows, float p, const uint64_t* rng_state,
+                         uint32_t site, void* stream) {
+    TG_REQUIRE(table && idx && out && rng_state && n_idx > 0 && D > 0 && D % 4 == 0 && n_rows > 0 && p >= 0.f && p < 1.f && aligned16(table) && aligned16(out),
+               "tg_embed_gather_drop: bad arguments (D %% 4 == 0, 16-byte aligned table / out, 0 <= p < 1)");
+    EW(embed_gather_drop_kernel, (long)n_idx * (D / 4), table, idx, out, n_idx, D, n_rows, p, rng_state, site);
+    return check_launch("tg_embed_gather_drop");
+}
 int tg_embed_scatter_add(const float* dout, const int64_t* idx, float* dtable, int32_t n_idx, int32_t D, int32_t n_rows, void* stream) {
     TG_REQUIRE(dout && idx && dtable && n_idx > 0 && D > 0 && n_rows > 0, "tg_embed_scatter_add: bad arguments");
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(cdiv(n_idx, SCATTER_CHUNK)), dim3(256), 0, ST, dout, idx, dtable, n_idx, D, n_rows);
@@ -806,16 +829,16 @@ int tg_iter_begin(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_
     hipLaunchKernelGGL(iter_begin_kernel, dim3(1), dim3(1), 0, ST, rng_a, rng_b, adam_step_a, adam_step_b);
     return check_launch("tg_iter_begin");
 }
-int tg_iter_head(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, const float* target, float* pre_stacked, int32_t B,
-                 int32_t T, int32_t D, int32_t n_pre, int32_t copies, const int64_t* text, int64_t* text_stacked, const int64_t* vid,
+int tg_iter_head(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, const float* target, float* pre_stacked, int64_t pre_ld,
+                 int32_t B, int32_t T, int32_t D, int32_t n_pre, int32_t copies, const int64_t* text, int64_t* text_stacked, const int64_t* vid,
                  int64_t* vid_stacked, int32_t permute_last, const int64_t* perm_in, uint32_t perm_site, int64_t* perm_out, void* stream) {
-    TG_REQUIRE(target && pre_stacked && B > 0 && T > 0 && D > 0 && n_pre >= 0 && copies >= 1, "tg_iter_head: bad arguments");
+    TG_REQUIRE(target && pre_stacked && B > 0 && T > 0 && D > 0 && n_pre >= 0 && copies >= 1 && pre_ld >= D + 1, "tg_iter_head: bad arguments");
     TG_REQUIRE((text == nullptr) == (text_stacked == nullptr) && (vid == nullptr) == (vid_stacked == nullptr), "tg_iter_head: text / vid and their stacked outputs go together");
     TG_REQUIRE(!vid || B <= 1024, "tg_iter_head: B=%d speaker ids must fit one workgroup (<= 1024)", B);
     TG_REQUIRE(!permute_last || (vid && (perm_in || rng_a)), "tg_iter_head: a drawn permutation needs vid and rng_a");
     const long n = (long)B * T * (D + 1) * copies;
     const int blocks = 1 + (int)((n + 4095) / 4096 < 255 ? (n + 4095) / 4096 : 255);
-    hipLaunchKernelGGL(iter_head_kernel, dim3(blocks < 2 ? 2 : blocks), dim3(1024), 0, ST, rng_a, rng_b, adam_step_a, adam_step_b, target, pre_stacked, B, T, D,
+    hipLaunchKernelGGL(iter_head_kernel, dim3(blocks < 2 ? 2 : blocks), dim3(1024), 0, ST, rng_a, rng_b, adam_step_a, adam_step_b, target, pre_stacked, (long)pre_ld, B, T, D,
                        n_pre, copies, text, text_stacked, vid, vid_stacked, permute_last, perm_in, perm_site, perm_out);
     return check_launch("tg_iter_head");
 }

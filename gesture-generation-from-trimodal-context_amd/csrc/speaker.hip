@@ -13,9 +13,9 @@ constexpr int SZ = 16;                 // style vector size (fixed by the refere
 __global__ __launch_bounds__(256) void speaker_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ vid, int n_rows,
                                                           const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wmu,
                                                           const float* __restrict__ bmu, const float* __restrict__ wlv, const float* __restrict__ blv,
-                                                          const float* __restrict__ eps, float* __restrict__ se, float* __restrict__ zc,
+                                                          float* __restrict__ eps, float* __restrict__ se, float* __restrict__ zc,
                                                           float* __restrict__ mu, float* __restrict__ lv, float* __restrict__ z, int B,
-                                                          float* __restrict__ rep, long rep_ld, int T) {
+                                                          float* __restrict__ rep, long rep_ld, int T, const uint64_t* __restrict__ st, uint32_t site) {
     const int j = threadIdx.x & 15;
     const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int bb = b < B ? b : B - 1;                    // whole 16-lane groups take part in the shuffles
@@ -31,7 +31,19 @@ __global__ __launch_bounds__(256) void speaker_fwd_kernel(const float* __restric
     const float c = linear(w1, b1, s);
     const float m = linear(wmu, bmu, c);
     const float l = linear(wlv, blv, c);
-    const float e = eps[bb * SZ + j];
+    float e;
+    if (st) {                                            // element bb * 16 + j of tg_normal(eps, B * 16, st, site), bit for bit (normal_kernel)
+        const long el = (long)bb * SZ + j;
+        uint32_t r[4];
+        philox4x32(st[0], (uint64_t)(el >> 2), site, (uint32_t)st[1], r);
+        const int q = (int)(el & 3) >> 1;
+        const float rad = sqrtf(-2.f * logf(u01(r[2 * q])));
+        const float ang = 6.283185307179586f * u01(r[2 * q + 1]);
+        e = (el & 1) ? rad * sinf(ang) : rad * cosf(ang);
+        if (b < B) eps[el] = e;
+    } else {
+        e = eps[bb * SZ + j];
+    }
     const float zz = m + e * expf(0.5f * l);
     if (b < B) {
         const long o = (long)b * SZ + j;
@@ -112,12 +124,12 @@ __global__ __launch_bounds__(1024) void speaker_bwd_kernel(const float* __restri
 using namespace tg;
 
 extern "C" int tg_speaker_fwd(const float* table, const int64_t* vid, int32_t n_rows, const float* w1, const float* b1, const float* wmu, const float* bmu,
-                              const float* wlv, const float* blv, const float* eps, float* se, float* zc, float* mu, float* logvar, float* z,
-                              int32_t B, float* rep, int64_t rep_ld, int32_t T, void* stream) {
+                              const float* wlv, const float* blv, float* eps, float* se, float* zc, float* mu, float* logvar, float* z,
+                              int32_t B, float* rep, int64_t rep_ld, int32_t T, const uint64_t* rng_state, uint32_t site, void* stream) {
     TG_REQUIRE(table && vid && w1 && b1 && wmu && bmu && wlv && blv && eps && se && zc && mu && logvar && z && B > 0 && n_rows > 0, "tg_speaker_fwd: bad arguments");
     TG_REQUIRE(rep == nullptr || (T > 0 && rep_ld >= SZ), "tg_speaker_fwd: bad repeat target");
     hipLaunchKernelGGL(speaker_fwd_kernel, dim3(cdiv(B, 16)), dim3(256), 0, (hipStream_t)stream, table, vid, n_rows, w1, b1, wmu, bmu, wlv, blv, eps, se, zc, mu,
-                       logvar, z, B, rep, (long)rep_ld, T);
+                       logvar, z, B, rep, (long)rep_ld, T, rng_state, site);
     return check_launch("tg_speaker_fwd");
 }
 

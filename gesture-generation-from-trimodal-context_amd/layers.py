@@ -227,21 +227,24 @@ def conv_wgrad(dy, x, dW, db, kw, *, stride=1, pad=0, dil=1, defer=None):
         ops.colsum(dy2, db, accumulate=True)
 
 
-def conv_dgrad(dy, w, L_in, *, stride=1):
+def conv_dgrad(dy, w, L_in, *, stride=1, out=None, accumulate=False):
     """Input gradient of Conv1d(stride, no padding, dilation 1).  dy: (B, Lout, Co) view; w: (Co, Ci, kw).
-    One GEMM per phase r = p % stride: dx[b, stride*q + r] = sum_j dy[b, q - j] . Wr[:, j, :]  (zero taps outside)."""
+    One GEMM per phase r = p % stride: dx[b, stride*q + r] = sum_j dy[b, q - j] . Wr[:, j, :]  (zero taps outside).
+    out (B, L_in, Ci) contiguous + accumulate: the result is added to it (the pose gradient of the GAN term onto the regression term's)."""
     B, Lo, Co = dy.shape
     _, Ci, kw = w.shape
     J = (kw + stride - 1) // stride
     packed = dgrad_pack(w, stride)
-    dx = empty(B, L_in, Ci, like=w)
+    if out is not None:
+        assert tuple(out.shape) == (B, L_in, Ci) and out.is_contiguous()
+    dx = out if out is not None else empty(B, L_in, Ci, like=w)
     probs = []
     for r in range(stride):
         nq = (L_in - r + stride - 1) // stride
         if nq <= 0:
             continue
         probs.append(dict(A=Win.taps(dy, J, shift=0, dil=-1, rows_out=nq), W=packed[r], bias=None, out=dx[:, r:, :],
-                          c_batch_stride=dx.stride(0), c_row_stride=stride * Ci, c_rows_out=nq))
+                          c_batch_stride=dx.stride(0), c_row_stride=stride * Ci, c_rows_out=nq, accumulate=bool(accumulate and out is not None)))
     ops.gemm_nt_group(probs)                     # the stride phases write disjoint rows of dx: one launch
     return dx
 

@@ -791,6 +791,15 @@ def embed_gather(table, idx, out):
     call("tg_embed_gather", _p(table), _p(idx), _p(out), idx.numel(), D, n_rows, _stream()); return out
 
 
+def embed_gather_drop(table, idx, out, p, state, site):
+    """(out, Drop): out = table[idx] * dropout mask (F.dropout after the look-up, one pass; the mask is not stored)."""
+    _flat(table, "table"); _i64(idx, "idx"); _flat(out, "out")
+    n_rows, D = table.shape
+    assert out.numel() == idx.numel() * D and D % 4 == 0
+    call("tg_embed_gather_drop", _p(table), _p(idx), _p(out), idx.numel(), D, n_rows, float(p), _p(_i64(state, "rng_state")), int(site), _stream())
+    return out, Drop(state, site, p, out.shape)
+
+
 def embed_scatter_add(dout, idx, dtable):
     _flat(dout, "dout"); _i64(idx, "idx"); _flat(dtable, "dtable")
     n_rows, D = dtable.shape
@@ -865,14 +874,18 @@ def rng_advance(state):
     call("tg_rng_advance", _p(_i64(state, "rng_state")), _stream())
 
 
-def iter_head(rng_a, rng_b, step_a, step_b, target, n_pre, copies, text=None, vid=None, permute_last=False, perm_in=None, perm_site=0):
-    """tg_iter_head: counters + stacked seed poses / word ids / speaker ids of a GAN iteration, one launch.  Returns (pre_s, text_s, vid_s)."""
+def iter_head(rng_a, rng_b, step_a, step_b, target, n_pre, copies, text=None, vid=None, permute_last=False, perm_in=None, perm_site=0, row_floats=None):
+    """tg_iter_head: counters + stacked seed poses / word ids / speaker ids of a GAN iteration, one launch.  Returns (pre_s, text_s, vid_s).
+    row_floats > D + 1: pre_s is the [:, :, :D + 1] view of a fresh (copies * B, T, row_floats) buffer -- the generator's GRU input rows, whose
+    pose columns are then already in place (GeneratorEngine.forward recognises the view and skips its copy)."""
     for r in (rng_a, rng_b):
         assert r is None or _i64(r, "rng_state") is r
     for c in (step_a, step_b):
         assert c is None or (c.is_cuda and c.dtype == torch.int32)
     _flat(target, "target"); B, T, D = target.shape
-    pre = torch.empty(copies * B, T, D + 1, device=target.device)
+    ld = D + 1 if row_floats is None else int(row_floats)
+    assert ld >= D + 1
+    pre = torch.empty(copies * B, T, ld, device=target.device)
     text_s = vid_s = None
     if text is not None:
         _i64(text, "text"); assert tuple(text.shape) == (B, T)
@@ -882,9 +895,9 @@ def iter_head(rng_a, rng_b, step_a, step_b, target, n_pre, copies, text=None, vi
         vid_s = torch.empty(copies * B, dtype=torch.int64, device=target.device)
     if perm_in is not None:
         _i64(perm_in, "perm"); assert perm_in.numel() == B
-    call("tg_iter_head", _p(rng_a), _p(rng_b), _p(step_a), _p(step_b), _p(target), _p(pre), B, T, D, int(n_pre), int(copies), _p(text), _p(text_s),
+    call("tg_iter_head", _p(rng_a), _p(rng_b), _p(step_a), _p(step_b), _p(target), _p(pre), ld, B, T, D, int(n_pre), int(copies), _p(text), _p(text_s),
          _p(vid), _p(vid_s), int(bool(permute_last)), _p(perm_in), int(perm_site), None, _stream())
-    return pre, text_s, vid_s
+    return pre[:, :, :D + 1], text_s, vid_s
 
 
 def iter_begin(rng_a, rng_b, step_a, step_b):
@@ -939,8 +952,9 @@ def reparam_bwd(dz, logvar, eps, dmu, dlogvar):
 SPEAKER_FUSED = os.environ.get("TG_SPEAKER_FUSED", "1") != "0"
 
 
-def speaker_fwd(table, vid, w1, b1, wmu, bmu, wlv, blv, eps, rep=None, T=0):
-    """Fused speaker path forward -> (se, zc, mu, logvar, z), each [B, 16]; rep: 2-D view [B * T, 16] (row stride free) that receives z per frame."""
+def speaker_fwd(table, vid, w1, b1, wmu, bmu, wlv, blv, eps, rep=None, T=0, draw=None):
+    """Fused speaker path forward -> (se, zc, mu, logvar, z), each [B, 16]; rep: 2-D view [B * T, 16] (row stride free) that receives z per frame.
+    draw = (rng_state, site): eps is an OUTPUT, drawn in the same launch exactly as normal(eps, state, site) would."""
     _flat(table, "table"); _i64(vid, "vid"); _flat(eps, "eps")
     B = vid.numel()
     assert table.shape[1] == 16 and tuple(eps.shape) == (B, 16)
@@ -953,7 +967,7 @@ def speaker_fwd(table, vid, w1, b1, wmu, bmu, wlv, blv, eps, rep=None, T=0):
     if rep is not None:
         _chk2d(rep, B * T, 16, "rep"); rep_ld = rep.stride(0)
     call("tg_speaker_fwd", _p(table), _p(vid), table.shape[0], _p(w1), _p(b1), _p(wmu), _p(bmu), _p(wlv), _p(blv), _p(eps), *[_p(o) for o in outs], B,
-         _p(rep), rep_ld, int(T), _stream())
+         _p(rep), rep_ld, int(T), _p(_i64(draw[0], "rng_state")) if draw is not None else None, int(draw[1]) if draw is not None else 0, _stream())
     return outs
 
 

@@ -154,7 +154,8 @@ class GanTrainer:
         perm_in = inject["perm"].to(dev).long().contiguous() if (inject is not None and "perm" in inject) else None
         pre_s, text_s, vid_s = ops.iter_head(G.rng.state, D.rng.state, self.g_opt.slab.step, self.d_opt.slab.step if post else None, target,
                                              self.hp["n_pre_poses"], ng, text=in_text.contiguous(), vid=vid.contiguous() if speaker else None,
-                                             permute_last=speaker and self.use_reg, perm_in=perm_in, perm_site=G.rng.site("perm"))
+                                             permute_last=speaker and self.use_reg, perm_in=perm_in, perm_site=G.rng.site("perm"),
+                                             row_floats=G.in_size)         # the seed poses land in the GRU input rows directly
         res = G.forward(pre_s, text_s, in_audio.float(), vid_s, training=True, groups=ng, save=True,
                         inject=_stack_inject(inject, tags, "g"), tag="g", save_rows=(i2 * B, B))     # only call g2 is differentiated (:50-88)
         if self.keep_tape:
@@ -205,8 +206,7 @@ class GanTrainer:
         if not speaker_terms:
             d_mu = d_lv = None
         if post:
-            d_poses = D.backward(dres["tape"], d_logit.view(B, 1), param_grads=False, need_dposes=True)
-            ops.axpy(d_poses, d_out, 1.0, accumulate=True)
+            D.backward(dres["tape"], d_logit.view(B, 1), param_grads=False, need_dposes=True, dposes_into=d_out)      # d_out += dD/dposes (:86-88)
         self._assert_no_pending_exchange()                    # the generator's backward recurrences come next
         on_ready = (lambda prefixes: self._sync("bucket", G.slab, prefixes)) if self.grad_sync is not None else None
         G.backward(st["res"]["tape"], d_out, d_mu, d_lv, b0=st["i2"] * B, nb=B, on_ready=on_ready)

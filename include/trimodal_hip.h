@@ -303,12 +303,13 @@ int tg_bn2_backward(const float* dy, const float* x, float* dx, int32_t rows_per
 
 /* ---- speaker / style path (model/multimodal_context_net.py:83-95,125-137; embedding_net.py:10-13), fused ------------------------------
  * forward: se = table[vid], zc = W1 se + b1, mu = Wmu zc + bmu, logvar = Wlv zc + blv, z = mu + eps * exp(0.5 logvar) (all [B][16]); with
- * rep != NULL also rep[(b * T + t) * rep_ld + j] = z[b][j] (the style columns of the GRU input).
+ * rep != NULL also rep[(b * T + t) * rep_ld + j] = z[b][j] (the style columns of the GRU input).  eps is read when rng_state == NULL and
+ * WRITTEN otherwise (ABI 4): drawn as tg_normal(eps, B * 16, rng_state, site) would, in the same launch (torch.randn_like of :92).
  * backward (nb <= tg_speaker_bwd_max_rows()): dz [nb][16] = gradient w.r.t. z; d_mu_in / d_logvar_in: direct gradients or NULL; every
  * parameter gradient accumulates; dtable rows meet in float atomics. */
 int tg_speaker_fwd(const float* table, const int64_t* vid, int32_t n_rows, const float* w1, const float* b1, const float* wmu, const float* bmu,
-                   const float* wlv, const float* blv, const float* eps, float* se, float* zc, float* mu, float* logvar, float* z,
-                   int32_t B, float* rep, int64_t rep_ld, int32_t T, void* stream);
+                   const float* wlv, const float* blv, float* eps, float* se, float* zc, float* mu, float* logvar, float* z,
+                   int32_t B, float* rep, int64_t rep_ld, int32_t T, const uint64_t* rng_state, uint32_t site, void* stream);
 int32_t tg_speaker_bwd_max_rows(void);
 int tg_speaker_bwd(const float* dz, const float* d_mu_in, const float* d_logvar_in, const float* logvar, const float* eps, const float* zc,
                    const float* se, const int64_t* vid, int32_t n_rows, const float* w1, const float* wmu, const float* wlv, float* dw1,
@@ -405,6 +406,11 @@ int tg_make_pre_seq(const float* target, float* pre, int32_t B, int32_t T, int32
 /* out[i*D + :] = table[idx[i]*D + :]  (nn.Embedding, multimodal_context_net.py:40,89). */
 int tg_embed_gather(const float* table, const int64_t* idx, float* out, int32_t n_idx, int32_t D, int32_t n_rows,
                     void* stream);
+/* The look-up followed by F.dropout(p) (multimodal_context_net.py:47-52, train mode) in one pass: out = table[idx] * mask, mask = the draw
+ * tg_dropout_mask(mask, n_idx * D, p, rng_state, site) would write; it is not stored -- the backward regenerates it (tg_act_mask_bwd_drop with
+ * slope 1).  D % 4 == 0, 16-byte aligned table and out. */
+int tg_embed_gather_drop(const float* table, const int64_t* idx, float* out, int32_t n_idx, int32_t D, int32_t n_rows, float p,
+                         const uint64_t* rng_state, uint32_t site, void* stream);
 /* dtable[idx[i]*D + :] += dout[i*D + :]  (dense embedding gradient; accumulates). */
 int tg_embed_scatter_add(const float* dout, const int64_t* idx, float* dtable, int32_t n_idx, int32_t D,
                          int32_t n_rows, void* stream);
@@ -444,12 +450,13 @@ int tg_rng_advance(uint64_t* rng_state, void* stream);
  * (tg_adam_step then runs with the counter already advanced); any pointer may be NULL, not all. */
 int tg_iter_begin(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, void* stream);
 /* The head of one train_iter_gan call (scripts/train_eval/train_gan.py:13-30,50,67-72) in ONE launch: tg_iter_begin's counters; the seed
- * poses of the `copies` stacked generator calls (tg_make_pre_seq, pre_stacked [copies][B][T][D + 1]); the word ids copied `copies` times
+ * poses of the `copies` stacked generator calls (tg_make_pre_seq, pre_stacked [copies][B][T] rows of D + 1 floats, pre_ld floats apart:
+ * pre_ld > D + 1 writes them straight into the pose columns of the GRU input rows); the word ids copied `copies` times
  * (text [B][T] -> text_stacked, both may be NULL); the speaker ids [vid] * (copies - 1) + [last] (vid [B] -> vid_stacked [copies][B], both
  * may be NULL) where last = vid[perm] if permute_last -- perm = torch.randperm(B) of :69 drawn as tg_randperm(.., rng_a at its NEW step,
  * perm_site) or given (perm_in, tests), also written to perm_out when non-NULL -- and vid otherwise.  B <= 1024 with speaker ids. */
-int tg_iter_head(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, const float* target, float* pre_stacked, int32_t B,
-                 int32_t T, int32_t D, int32_t n_pre, int32_t copies, const int64_t* text, int64_t* text_stacked, const int64_t* vid,
+int tg_iter_head(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, const float* target, float* pre_stacked, int64_t pre_ld,
+                 int32_t B, int32_t T, int32_t D, int32_t n_pre, int32_t copies, const int64_t* text, int64_t* text_stacked, const int64_t* vid,
                  int64_t* vid_stacked, int32_t permute_last, const int64_t* perm_in, uint32_t perm_site, int64_t* perm_out, void* stream);
 int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream);
 /* Draw the same mask and apply it in one pass: mask as tg_dropout_mask, y[i] = x[i] * mask[i] (F.dropout, train mode).  mask may be NULL

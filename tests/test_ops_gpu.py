@@ -725,6 +725,12 @@ def test_regenerated_dropout_equals_stored_mask(pkg, dev):
     assert isinstance(d2, ops.Drop) and torch.equal(y1, y2) and torch.equal(d2.materialize(), m1)
     dyr = torch.randn(M, Cc, generator=g).to(dev)
     assert torch.equal(ops.mul(dyr, d2[rows].reshape(M, -1).contiguous(), torch.empty_like(dyr)), dyr * m1[rows].reshape(M, -1))
+    # embedding look-up + dropout in one pass == look-up, then the stored-mask dropout of the same site
+    table = torch.randn(2000, Cc, generator=g).to(dev)
+    idx = torch.randint(-1, 2000, (B * T,), generator=g).to(dev)
+    ye, de = ops.embed_gather_drop(table, idx, torch.empty(B, T, Cc, device=dev), 0.1, state, 9)
+    emb = ops.embed_gather(table, idx, torch.empty(B, T, Cc, device=dev))
+    assert torch.equal(ye, emb * m1) and torch.equal(de.materialize(), m1)
     # refused where no kernel regenerates it (a small product), loudly
     xs, ws, os_ = torch.randn(64, 64, device=dev), torch.randn(32, 64, device=dev), torch.empty(64, 32, device=dev)
     with pytest.raises(Exception):
@@ -756,6 +762,10 @@ def test_iter_head_equals_the_separate_launches(pkg, dev):
         assert torch.equal(vid_s, torch.cat([vid] * (ng - 1) + [last]))
         if permute and not injected:
             assert sorted(perm.tolist()) == list(range(B)) and perm.tolist() != list(range(B))
+    # seed poses written straight into the pose columns of wider rows (the GRU input buffer)
+    ra = ops.new_rng_state(11, dev)
+    pre_w, _, _ = ops.iter_head(ra, None, None, None, target, 4, ng, text=text, row_floats=108)
+    assert pre_w.stride() == (T * 108, 108, 1) and torch.equal(pre_w, ops.make_pre_seq(target, torch.empty(B, T, D + 1, device=dev), 4).repeat(ng, 1, 1))
     # no speaker ids, one copy, only one counter
     ra = ops.new_rng_state(11, dev)
     pre_s, text_s, vid_s = ops.iter_head(ra, None, None, None, target, 4, 1, text=text)
@@ -1155,6 +1165,13 @@ def test_speaker_path_fused_forward_backward(pkg, dev):
     for got, ref in ((se, se_r), (zc, zc_r), (mu, mu_r), (lv, lv_r), (z, z_r)):
         assert rel(got, ref) < 1e-5
     assert torch.equal(rep[:, 5:21].view(B, T, 16), z[:, None, :].expand(B, T, 16)) and bool(torch.isnan(rep[:, :5]).all()) and bool(torch.isnan(rep[:, 21:]).all())
+    # eps drawn inside the launch (torch.randn_like of :92) == tg_normal with the same state and site, then the explicit-eps form: bit for bit
+    st = ops.new_rng_state(77, dev)
+    eps_ref = ops.normal(torch.empty(B, 16, device=dev), st, 4)
+    eps_out = torch.full((B, 16), float("nan"), device=dev)
+    drawn = ops.speaker_fwd(d(table), d(vid), d(w1), d(b1), d(wmu), d(bmu), d(wlv), d(blv), eps_out, draw=(st, 4))
+    given = ops.speaker_fwd(d(table), d(vid), d(w1), d(b1), d(wmu), d(bmu), d(wlv), d(blv), eps_ref)
+    assert torch.equal(eps_out, eps_ref) and all(torch.equal(a, b_) for a, b_ in zip(drawn, given))
     dz, dmu_in, dlv_in = rnd(B, 16, seed=100), rnd(B, 16, seed=101, scale=0.1), rnd(B, 16, seed=102, scale=0.1)
     loss = (z_r * dz.double()).sum() + (mu_r * dmu_in.double()).sum() + (lv_r * dlv_in.double()).sum()
     grads = torch.autograd.grad(loss, P, retain_graph=True)

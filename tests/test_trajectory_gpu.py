@@ -115,9 +115,14 @@ def test_five_consecutive_iterations_match_fp64_oracle(pkg, dev):
     assert int(dsd["pre_conv.1.num_batches_tracked"]) == 1 * n_warm + 3 * n_post
 
 
-def test_graph_replayed_five_times_equals_five_eager_iterations(pkg, dev):
+def test_graph_replayed_five_times_equals_five_eager_iterations(pkg, dev, monkeypatch):
     """A GraphedGanStep replayed 5 times lands on the same parameters as 5 eager iterations started from the same state with the same
-    device RNG seeds (draws come from the device-side Philox counters, which advance identically on both paths)."""
+    device RNG seeds (draws come from the device-side Philox counters, which advance identically on both paths).
+    The weight-gradient products run with their deterministic two-pass combine here (ops.TN_TWO_PASS_ROWS = 0): with the float-atomic combine
+    the two runs differ by the ORDER of those sums, and at B = 8 whole tensors of the text encoder have rounding-noise gradients that Adam's
+    first steps turn into +-lr moves -- one full-suite run in six then had 5-10 % of a conv's entries apart by > 0.01 lr (the run-to-run
+    spread of the atomics has its own test, test_atomic_weight_gradient_combine_run_to_run_spread)."""
+    monkeypatch.setattr(pkg.ops, "TN_TWO_PASS_ROWS", 0)
     V, S, B = 64, 9, 8
     gst, dst = O.make_generator_state(7, V, S), O.make_discriminator_state(8)
     text, audio, vid, poses = (t.to(dev) for t in O.make_batch(11, B, V, S))
