@@ -1,6 +1,6 @@
 """One training iteration as an ordered kernel timeline, from a rocprofv3 --kernel-trace CSV.
 
-usage: iter_timeline.py <rocprof dir> <out.txt> [marker kernel = iter_begin_kernel] [iteration index from the end = 3]
+usage: iter_timeline.py <rocprof dir> <out.txt> [marker kernel = iter_head_kernel] [iteration index from the end = 3]
 
 The iteration boundaries are the launches of the marker kernel that opens every iteration (the generator's RNG advance).  For the
 chosen iteration prints every launch in start order: start offset, duration, gap to the previous kernel's end, name, grid; then
@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 d, out = sys.argv[1], sys.argv[2]
-marker = sys.argv[3] if len(sys.argv) > 3 else "iter_begin_kernel"
+marker = sys.argv[3] if len(sys.argv) > 3 else "iter_head_kernel"
 back = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 rows = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
