@@ -267,6 +267,44 @@ def test_bf16_tier_fgd_within_one_percent_of_fp32(pkg, dev, tmp_path):
     assert any(b[k] != a[k] for k in a)
 
 
+def test_full_size_iteration_regenerated_dropout_equals_stored_masks(pkg, dev, monkeypatch):
+    """One B = 128 GAN iteration with the device RNG twice from identical state: dropout masks regenerated by their consumers (ops.Drop: the
+    default at this size) against the stored-mask path (TG_TCN_DROP_REGEN=0).  Same draws on both paths -- the Philox counter is the element
+    index -- so losses agree to float-atomic noise and every gradient to 5e-5 of its maximum (measured 7e-6): the engine's bookkeeping (index offset of conv j in
+    the site's draw, the row slice of the differentiated call, embedding and GRU inter-layer dropouts) is right at full size."""
+    from importlib import import_module
+    Lm = pkg.layers
+    eng_cls = import_module(pkg.__name__ + ".engine")._Engine
+    V, S, B = 256, 17, 128
+    gst, dst = O.make_generator_state(3, V, S), O.make_discriminator_state(4)
+    text, audio, vid, poses = (t.to(dev) for t in O.make_batch(5, B, V, S))
+    monkeypatch.setattr(pkg.ops, "TN_TWO_PASS_ROWS", 0)            # deterministic weight-gradient combine: the comparison is about the masks
+    runs = {}
+    for regen in (True, False):
+        monkeypatch.setattr(eng_cls, "tcn_drop_regen", regen)
+        monkeypatch.setattr(Lm, "DROP_REGEN", regen)
+        args, G, D = build_models(pkg, dev, gst, dst, V, S)
+        tr = pkg.GanTrainer(G, D, args)
+        tr.G.rng.state[0] = 5; tr.D.rng.state[0] = 6
+        tr.keep_tape = True
+        losses = tr.train_iter(11, text, audio, poses, vid).to_dict()
+        m0 = tr.last_tape["tcn"][0]["m0"]
+        assert isinstance(m0, pkg.ops.Drop) == regen
+        runs[regen] = (losses, {k: v.detach().clone() for k, v in tr.G.views()[1].items()}, {k: v.detach().clone() for k, v in tr.D.views()[1].items()})
+    a, b = runs[True], runs[False]
+    for k in a[0]:
+        assert abs(a[0][k] - b[0][k]) <= 1e-6 * max(1.0, abs(b[0][k])), (k, a[0][k], b[0][k])
+    worst = 0.0
+    for mine, ref in ((a[1], b[1]), (a[2], b[2])):
+        for k, r in ref.items():
+            if k in ZERO_GRAD_KEYS or float(r.abs().max()) == 0:
+                continue
+            e = float((mine[k] - r).abs().max()) / float(r.abs().max())
+            worst = max(worst, e)
+            assert e <= 5e-5, (k, e)                   # (measured 7e-6: the remaining float atomics -- embedding scatter, bias sums)
+    print(f"regenerated vs stored dropout masks at B = 128: worst gradient difference {worst:.1e}")
+
+
 def test_module_api_autograd_bridge(pkg, dev):
     """The reference's own loop style: module(...) calls + torch losses + loss.backward() + torch.optim.Adam."""
     V, S, B = 64, 9, 4
