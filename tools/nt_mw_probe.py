@@ -116,3 +116,29 @@ for second in (False, True):
     sweep()
     ts = [timed(sweep, 4) / NSET for _ in range(rounds)]
     print(f"tcn conv{2 if second else 1} cold  [13056 x 300 x 600] d=4 | plan {ops.nt_kernel_plan(plist[0])} {statistics.median(ts):7.1f} / {min(ts):7.1f} us per launch", flush=True)
+
+# which stream's cold lines cost what (conv1 form = ReLU + dropout scale): every combination of {activation, mask, output} rotating over the 24
+# sets (cold) or pinned to set 0 (warm)
+print("# cold-line attribution, conv1 form: us per launch with the named streams COLD (rotating buffers), the others warm")
+for cold in ((), ("x",), ("m",), ("o",), ("x", "m"), ("x", "o"), ("m", "o"), ("x", "m", "o")):
+    plist = []
+    for st in sets:
+        pick = lambda k: st[k] if k in cold else sets[0][k]
+        o = pick("o")
+        plist.append([dict(A=Win.conv(pick("x"), 2, pad=4, dil=4, rows_out=Tc), W=wp, bias=bc, out=o, act_slope=0.0, out_scale=pick("m"), w_planes=wpl,
+                           c_batch_stride=o.stride(0), c_row_stride=o.stride(1), c_rows_out=Tc)])
+    def sweep():
+        for pr in plist:
+            ops.gemm_nt_group(pr)
+    sweep()
+    ts = [timed(sweep, 4) / NSET for _ in range(rounds)]
+    print(f"  cold: {'+'.join(cold) if cold else 'none':8s} {statistics.median(ts):7.1f} us", flush=True)
+# no mask at all (bias + ReLU only), everything cold
+plist = [[dict(A=Win.conv(st["x"], 2, pad=4, dil=4, rows_out=Tc), W=wp, bias=bc, out=st["o"], act_slope=0.0, w_planes=wpl,
+               c_batch_stride=st["o"].stride(0), c_row_stride=st["o"].stride(1), c_rows_out=Tc)] for st in sets]
+def sweep():
+    for pr in plist:
+        ops.gemm_nt_group(pr)
+sweep()
+ts = [timed(sweep, 4) / NSET for _ in range(rounds)]
+print(f"  no mask operand, x + o cold: {statistics.median(ts):7.1f} us", flush=True)
