@@ -83,6 +83,7 @@ SIGNATURES = {
     "tg_act_mask_bwd": [P, P, P, F32, P, I64, P],
     "tg_act_mask_bwd2": [P, P, P, P, F32, P, P, I64, P],
     "tg_embed_gather_drop": [P, P, P, I32, I32, I32, F32, P, U32, P],
+    "tg_d_preconv_fwd": [P] * 27 + [I64, I32, I32, F32, F32, P],
     "tg_iter_head": [P, P, P, P, P, P, I64, I32, I32, I32, I32, I32, P, P, P, P, I32, P, U32, P, P],
     "tg_act_mask_bwd_drop": [P, P, F32, P, U32, I64, F32, P, I64, P],
     "tg_act_mask_bwd2_drop": [P, P, P, F32, P, U32, I64, F32, P, P, I64, P],
@@ -172,6 +173,10 @@ def load():
     lib.tg_bn2_supported.argtypes = [I32, I32]
     lib.tg_bn2_ws_doubles.restype = C.c_int64
     lib.tg_bn2_ws_doubles.argtypes = [I32, I32, I32]
+    lib.tg_d_preconv_fwd_supported.restype = C.c_int32
+    lib.tg_d_preconv_fwd_supported.argtypes = [I32, I32]
+    lib.tg_d_preconv_ws_bytes.restype = C.c_int64
+    lib.tg_d_preconv_ws_bytes.argtypes = [I32]
     for q, at in (("tg_wav_conv2_wgrad_ws_floats", []), ("tg_wav_front_ws_doubles", []), ("tg_wav_front_fstat_doubles", []), ("tg_wav_front_gate_words", [I32, I32])):
         getattr(lib, q).restype = C.c_int64
         getattr(lib, q).argtypes = at

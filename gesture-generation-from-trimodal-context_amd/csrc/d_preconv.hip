@@ -1,0 +1,326 @@
+// ConvDiscriminator.pre_conv (model/multimodal_context_net.py:214-220), train-mode forward, ONE launch:
+//     Conv1d(27, 16, 3) -> BatchNorm1d(16) -> LeakyReLU(True) -> Conv1d(16, 8, 3) -> BatchNorm1d(8) -> LeakyReLU(True) -> Conv1d(8, 8, 3)
+// (nn.LeakyReLU(True) sets negative_slope = 1.0: the identity, reference README.md:122).  The generic path runs it as seven launches -- three
+// window GEMMs and two two-launch BatchNorms -- on tensors of 0.1-0.5 MB: 48-52 us of which ~35 are launch-to-launch latency.  Here every
+// workgroup owns CLIPS clips of one statistics group from the poses to the GRU input: its slices of the three conv outputs live in LDS, and the
+// only thing the workgroups exchange are the BatchNorm partial sums (16 + 8 channels x (sum, sum of squares), fp64), through a device-wide
+// barrier after conv1 and after conv2.
+//
+// The barrier follows the cluster GRU's hand-off protocol (gru_cluster_x3.hip): partial sums leave with write-through (sc1) stores and are
+// drained (s_waitcnt vmcnt(0)) before the workgroup's relaxed agent-scope arrival; everybody spins (bounded, s_sleep) on the arrival counter and
+// then reads the partials with sc1 loads.  No device-scope fence (on an 8-XCD part each one is an L2 write-back: the BatchNorm last-arriver
+// experiment, profiles/r3_ae_bn2_last_arriver_rejected.txt).  Counters: ws[0] sticky timeout, ws[1..3] arrivals of barrier 1 / barrier 2 / exit;
+// the last workgroup to arrive at barrier 2 re-zeroes counter 1 (nobody spins on it any more), the last to exit counters 2 and 3: the
+// workspace is zero ONCE, before its first use, and again after every launch.  All workgroups must be co-resident: grid <= CU count, checked.
+//
+// Everything the generic backward needs is written exactly where the generic forward writes it: c1 / c2 (conv outputs, the BatchNorms'
+// saved inputs), y1 / y2 (their outputs = the next conv's input), mean / rstd per group, the running statistics updated in call order by
+// workgroup 0 (momentum 0.1, unbiased variance, num_batches_tracked += groups).  fp32 FMA in a fixed order, statistics in fp64.
+#include "common.hpp"
+
+namespace tg {
+
+constexpr int DP_T0 = 34, DP_D = 27, DP_C1 = 16, DP_C2 = 8, DP_C3 = 8, DP_KW = 3;
+constexpr int DP_T1 = DP_T0 - 2, DP_T2 = DP_T1 - 2, DP_T3 = DP_T2 - 2;        // 32, 30, 28
+constexpr int DP_CLIPS = 4;                                                  // clips per workgroup
+constexpr unsigned DP_SPIN_LIMIT = 1u << 24;
+typedef __attribute__((address_space(1))) unsigned dp_gu32;
+
+struct DPreconvArgs {
+    const float* x;                  // [Bs][34][27]
+    const float *w1, *b1, *g1, *be1; // conv1 (16, 27, 3), bias; BN1 gamma, beta
+    const float *w2, *b2, *g2, *be2; // conv2 (8, 16, 3); BN2
+    const float *w3, *b3;            // conv3 (8, 8, 3)
+    float *c1, *y1, *c2, *y2, *c3;   // [Bs][32][16] x 2, [Bs][30][8] x 2, [Bs][28][8]
+    float *mean1, *rstd1, *mean2, *rstd2;        // [groups][16], [groups][8]
+    float *rm1, *rv1, *rm2, *rv2;    // running statistics (may be NULL together)
+    int64_t *nbt1, *nbt2;
+    double* part;                    // [2 layers][n workgroups][2][16] partial sums
+    unsigned* ws;                    // [4] timeout, arrivals
+    int Bs, groups, per;             // per = Bs / groups clips per statistics group
+    float eps, momentum;
+};
+
+// one device-wide barrier: arrive on ws[idx] (after this workgroup's sc1 stores have drained), spin until all n have
+__device__ __forceinline__ bool dp_barrier(unsigned* ws, int idx, unsigned n) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        dp_gu32* c = (dp_gu32*)(ws + idx);
+        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int good = 1;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > DP_SPIN_LIMIT) { __hip_atomic_store((dp_gu32*)ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); good = 0; break; }
+        }
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+// the partial sums cross workgroups (and XCDs, whose L2s are not coherent with each other) inside one launch: relaxed agent-scope atomic
+// stores / loads, i.e. write-through and L2-coherent accesses, ordered against the arrival counter by the drain in dp_barrier
+__device__ __forceinline__ void dp_store_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double dp_load_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(256) void d_preconv_fwd_kernel(const DPreconvArgs a) {
+    __shared__ __attribute__((aligned(16))) float sx[DP_CLIPS][DP_T0][DP_D + 1];          // poses of this workgroup's clips (rows padded to 28 floats, pad = 0)
+    __shared__ __attribute__((aligned(16))) float s1[DP_CLIPS][DP_T1][DP_C1];              // conv1 output, then BN1 output
+    __shared__ __attribute__((aligned(16))) float s2[DP_CLIPS][DP_T2][DP_C2];              // conv2 output, then BN2 output
+    __shared__ __attribute__((aligned(16))) float sw1[DP_C1][DP_KW][DP_D + 1], sw2[DP_C2][DP_KW][DP_C1], sw3[DP_C3][DP_KW][DP_C2];
+    __shared__ double red[2][256], tot[2][DP_C1];
+    __shared__ float sc[4][DP_C1];                            // mean, rstd, gamma, beta of the current BatchNorm for this workgroup's group
+    // Only the workgroups with block id = 0 mod 8 take part -- as observed they all land on ONE XCD, i.e. behind one L2, where a hand-off
+    // (coherent store -> arrival -> poll -> coherent load) costs ~0.8 us per hop as in the cluster GRU; spread over the eight XCDs the same
+    // protocol meets at the memory side and took ~5 us per hop (25 us per launch).  Speed only: any placement gives the same results.
+    if (blockIdx.x & 7) return;
+    const int wid = blockIdx.x >> 3;
+    const int t = threadIdx.x;
+    const int nwg = (gridDim.x >> 3) - 1;                     // the last workgroup only keeps the running statistics (below)
+    const int wpg = a.per / DP_CLIPS;                         // workgroups per statistics group
+    const int g = wid / wpg, b0 = wid * DP_CLIPS;        // first clip (groups are contiguous clip ranges)
+
+    const bool keeper = (int)wid == nwg;
+    // ---- BatchNorm statistics of this workgroup's group (every workgroup of the group computes them: same order, same bits).  The partials
+    // of the group's workgroups are read by ALL 256 threads -- thread (channel, slice) takes every (256 / C)-th workgroup, then the slices are
+    // summed in order: one round trip of the coherent loads instead of a dependent chain of 2 x 32 of them per thread (48 us per launch).
+    auto totals = [&](int layer, int gg, int C) {             // -> red[0][c], red[1][c] for c < C
+        const int S = 256 / C, c = t % C, sl = t / C;
+        const double* p = a.part + ((long)layer * nwg + (long)gg * wpg) * 2 * DP_C1;
+        double s = 0.0, ss = 0.0;
+        for (int w = sl; w < wpg; w += S) {
+            s += dp_load_sc1(p + (long)w * 2 * DP_C1 + c);
+            ss += dp_load_sc1(p + (long)w * 2 * DP_C1 + DP_C1 + c);
+        }
+        __syncthreads();                                      // (red may still be read by the previous user)
+        red[0][t] = s; red[1][t] = ss;
+        __syncthreads();
+        if (t < C) {
+            double ta = 0.0, tb = 0.0;
+            for (int q = 0; q < S; ++q) { ta += red[0][q * C + t]; tb += red[1][q * C + t]; }
+            tot[0][t] = ta; tot[1][t] = tb;
+        }
+        __syncthreads();
+    };
+    auto stats = [&](int layer, int C, int rows_per_clip, float* mean, float* rstd, float* rm, float* rv, int64_t* nbt, const float* gamma,
+                     const float* beta) {
+        const double n = (double)a.per * rows_per_clip;
+        if (!keeper) totals(layer, g, C);
+        if (!keeper && t < C) {
+            const double m = tot[0][t] / n;
+            double var = tot[1][t] / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float rs = (float)(1.0 / sqrt(var + (double)a.eps));
+            const float mf = (float)m;
+            sc[0][t] = mf; sc[1][t] = rs; sc[2][t] = gamma[t]; sc[3][t] = beta[t];
+            if (wid % wpg == 0) { mean[g * C + t] = mf; rstd[g * C + t] = rs; }
+        }
+        if (keeper && rm) {                                   // running statistics in call order (groups = successive forward calls)
+            float m_ = 0.f, v_ = 0.f;
+            if (t < C) { m_ = rm[t]; v_ = rv[t]; }
+            for (int gg = 0; gg < a.groups; ++gg) {
+                totals(layer, gg, C);
+                if (t < C) {
+                    const double m = tot[0][t] / n;
+                    double var = tot[1][t] / n - m * m;
+                    if (var < 0.0) var = 0.0;
+                    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+                    m_ = (1.f - a.momentum) * m_ + a.momentum * (float)m;
+                    v_ = (1.f - a.momentum) * v_ + a.momentum * (float)unbiased;
+                }
+            }
+            if (t < C) { rm[t] = m_; rv[t] = v_; }
+        }
+        if (keeper && t == 0 && nbt) *nbt += a.groups;
+        __syncthreads();
+    };
+    // ---- the keeper workgroup: arrives at both barriers (so that nobody re-zeroes a counter it still reads) and updates the running
+    // statistics of BatchNorm 1 while the others run conv2, of BatchNorm 2 while they run conv3 -- in workgroup 0 the 2 x groups extra round
+    // trips of coherent loads sat on every workgroup's path to the next barrier
+    if (keeper) {
+        if (!dp_barrier(a.ws, 1, nwg + 1)) return;
+        stats(0, DP_C1, DP_T1, a.mean1, a.rstd1, a.rm1, a.rv1, a.nbt1, a.g1, a.be1);
+        if (!dp_barrier(a.ws, 2, nwg + 1)) return;
+        if (t == 0) __hip_atomic_store((dp_gu32*)(a.ws + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stats(1, DP_C2, DP_T2, a.mean2, a.rstd2, a.rm2, a.rv2, a.nbt2, a.g2, a.be2);
+        if (t == 0) {
+            dp_gu32* c = (dp_gu32*)(a.ws + 3);
+            if (__hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nwg) {
+                __hip_atomic_store((dp_gu32*)(a.ws + 2), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    // ---- stage poses and weights
+    for (int i = t; i < DP_CLIPS * DP_T0 * DP_D; i += 256) {
+        const int c = i % DP_D, r = i / DP_D;
+        sx[r / DP_T0][r % DP_T0][c] = a.x[(long)b0 * DP_T0 * DP_D + i];
+    }
+    if (t < DP_CLIPS * DP_T0) sx[t / DP_T0][t % DP_T0][DP_D] = 0.f;               // the pad column (read by the 16-byte fragments below)
+    if (t < DP_C1 * DP_KW) sw1[t / DP_KW][t % DP_KW][DP_D] = 0.f;
+    for (int i = t; i < DP_C1 * DP_D * DP_KW; i += 256) { const int k = i % DP_KW, ci = (i / DP_KW) % DP_D, co = i / (DP_KW * DP_D); sw1[co][k][ci] = a.w1[i]; }
+    for (int i = t; i < DP_C2 * DP_C1 * DP_KW; i += 256) { const int k = i % DP_KW, ci = (i / DP_KW) % DP_C1, co = i / (DP_KW * DP_C1); sw2[co][k][ci] = a.w2[i]; }
+    for (int i = t; i < DP_C3 * DP_C2 * DP_KW; i += 256) { const int k = i % DP_KW, ci = (i / DP_KW) % DP_C2, co = i / (DP_KW * DP_C2); sw3[co][k][ci] = a.w3[i]; }
+    __syncthreads();
+
+    // ---- conv1: thread = (channel co, rows rg, rg + 16, ..: the four row groups of a wave read four consecutive frames -- distinct LDS banks
+    // with 28-float rows; eight consecutive rows per thread put them 224 floats = 7 x 32 banks apart)
+    {
+        const int co = t & 15, r0 = t >> 4;                   // 128 rows = 4 clips x 32 frames; thread rows r0 + 16 r
+        float acc[8];
+        const float bias = a.b1[co];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = bias;
+        // 16-byte LDS fragments, fully unrolled: 21 weight + 168 pose reads per thread, all independent (the rolled scalar loop waited out an
+        // LDS round trip per (tap, channel): 81 of them)
+#pragma unroll
+        for (int k = 0; k < DP_KW; ++k)
+#pragma unroll
+            for (int c4 = 0; c4 < (DP_D + 1) / 4; ++c4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(&sw1[co][k][4 * c4]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int row = r0 + 16 * r;
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(&sx[row >> 5][(row & 31) + k][4 * c4]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[r] = __builtin_fmaf(xv[q], w[q], acc[r]);
+                }
+            }
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = r0 + 16 * r;
+            s1[row >> 5][row & 31][co] = acc[r];                  // (c1 goes to global memory after the barrier, with y1: nothing but the
+            s += acc[r]; ss += (double)acc[r] * acc[r];           //  partial sums is in flight when the workgroup drains its stores)
+        }
+        red[0][t] = s; red[1][t] = ss;
+    }
+    __syncthreads();
+    if (t < DP_C1) {                                          // this workgroup's partial sums, fixed order
+        double s = 0.0, ss = 0.0;
+        for (int q = 0; q < 16; ++q) { s += red[0][q * 16 + t]; ss += red[1][q * 16 + t]; }
+        double* o = a.part + ((long)wid * 2) * DP_C1;
+        dp_store_sc1(o + t, s);
+        dp_store_sc1(o + DP_C1 + t, ss);
+    }
+    if (!dp_barrier(a.ws, 1, nwg + 1)) return;
+
+    stats(0, DP_C1, DP_T1, a.mean1, a.rstd1, a.rm1, a.rv1, a.nbt1, a.g1, a.be1);
+    for (int i = t; i < DP_CLIPS * DP_T1 * DP_C1; i += 256) {  // y1 = BN1(c1) (LeakyReLU(True) = identity)
+        const int c = i & 15;
+        float* p = &s1[0][0][0] + i;
+        const float cv = *p;
+        const float y = (cv - sc[0][c]) * sc[1][c] * sc[2][c] + sc[3][c];        // association of bn_apply_kernel / bn2_fwd_apply_kernel
+        *p = y;
+        a.c1[(long)b0 * DP_T1 * DP_C1 + i] = cv;
+        a.y1[(long)b0 * DP_T1 * DP_C1 + i] = y;
+    }
+    __syncthreads();
+
+    // ---- conv2: 4 clips x 30 frames x 8 channels = 960 outputs
+    {
+        double s = 0.0, ss = 0.0;
+        for (int i = t; i < DP_CLIPS * DP_T2 * DP_C2; i += 256) {
+            const int co = i & 7, r = i >> 3, cl = r / DP_T2, tt = r - cl * DP_T2;
+            float acc = a.b2[co];
+#pragma unroll
+            for (int k = 0; k < DP_KW; ++k)
+#pragma unroll
+                for (int c4 = 0; c4 < DP_C1 / 4; ++c4) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(&s1[cl][tt + k][4 * c4]), w = *reinterpret_cast<const f32x4*>(&sw2[co][k][4 * c4]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(xv[q], w[q], acc);
+                }
+            s2[cl][tt][co] = acc;
+            s += acc; ss += (double)acc * acc;
+        }
+        red[0][t] = s; red[1][t] = ss;                        // thread t always owns channel t & 7 (256 % 8 == 0)
+    }
+    __syncthreads();
+    if (t < DP_C2) {
+        double s = 0.0, ss = 0.0;
+        for (int q = 0; q < 32; ++q) { s += red[0][q * 8 + t]; ss += red[1][q * 8 + t]; }
+        double* o = a.part + (((long)nwg + wid) * 2) * DP_C1;
+        dp_store_sc1(o + t, s);
+        dp_store_sc1(o + DP_C1 + t, ss);
+    }
+    if (!dp_barrier(a.ws, 2, nwg + 1)) return;
+    if (t == 0) {                                             // everybody has left barrier 1: its counter goes back to zero (once)
+        // (the workgroup that observes the full count FIRST is not unique, any one store of zero is right; nobody adds to it again)
+        __hip_atomic_store((dp_gu32*)(a.ws + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    stats(1, DP_C2, DP_T2, a.mean2, a.rstd2, a.rm2, a.rv2, a.nbt2, a.g2, a.be2);
+    for (int i = t; i < DP_CLIPS * DP_T2 * DP_C2; i += 256) {
+        const int c = i & 7;
+        float* p = &s2[0][0][0] + i;
+        const float cv = *p;
+        const float y = (cv - sc[0][c]) * sc[1][c] * sc[2][c] + sc[3][c];
+        *p = y;
+        a.c2[(long)b0 * DP_T2 * DP_C2 + i] = cv;
+        a.y2[(long)b0 * DP_T2 * DP_C2 + i] = y;
+    }
+    __syncthreads();
+
+    // ---- conv3: 4 clips x 28 frames x 8 channels
+    for (int i = t; i < DP_CLIPS * DP_T3 * DP_C3; i += 256) {
+        const int co = i & 7, r = i >> 3, cl = r / DP_T3, tt = r - cl * DP_T3;
+        float acc = a.b3[co];
+#pragma unroll
+        for (int k = 0; k < DP_KW; ++k)
+#pragma unroll
+            for (int c4 = 0; c4 < DP_C2 / 4; ++c4) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(&s2[cl][tt + k][4 * c4]), w = *reinterpret_cast<const f32x4*>(&sw3[co][k][4 * c4]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(xv[q], w[q], acc);
+            }
+        a.c3[(long)b0 * DP_T3 * DP_C3 + i] = acc;
+    }
+    // ---- exit count: the last workgroup to leave re-zeroes the counters of barrier 2 and of the exit
+    __syncthreads();
+    if (t == 0) {
+        dp_gu32* c = (dp_gu32*)(a.ws + 3);
+        if (__hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nwg) {      // nwg + 1 leave
+            __hip_atomic_store((dp_gu32*)(a.ws + 2), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" int32_t tg_d_preconv_fwd_supported(int32_t Bs, int32_t groups) {
+    if (Bs <= 0 || groups <= 0 || Bs % groups != 0 || (Bs / groups) % DP_CLIPS != 0) return 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return Bs / DP_CLIPS + 1 <= cus / 8 * 3 ? 1 : 0;           // every workgroup co-resident on ONE XCD (three per CU by LDS: 47 KB each)
+}
+extern "C" int64_t tg_d_preconv_ws_bytes(int32_t Bs) { return 16 + (int64_t)2 * (Bs / DP_CLIPS) * 2 * DP_C1 * 8; }
+
+extern "C" int tg_d_preconv_fwd(const float* poses, const float* w1, const float* b1, const float* gamma1, const float* beta1, const float* w2,
+                                const float* b2, const float* gamma2, const float* beta2, const float* w3, const float* b3, float* c1, float* y1,
+                                float* c2, float* y2, float* c3, float* mean1, float* rstd1, float* mean2, float* rstd2, float* running_mean1,
+                                float* running_var1, int64_t* nbt1, float* running_mean2, float* running_var2, int64_t* nbt2, void* ws,
+                                int64_t ws_bytes, int32_t Bs, int32_t groups, float eps, float momentum, void* stream) {
+    TG_REQUIRE(poses && w1 && b1 && gamma1 && beta1 && w2 && b2 && gamma2 && beta2 && w3 && b3 && c1 && y1 && c2 && y2 && c3 && mean1 && rstd1 &&
+                   mean2 && rstd2 && ws, "tg_d_preconv_fwd: null pointer");
+    TG_REQUIRE(tg_d_preconv_fwd_supported(Bs, groups), "tg_d_preconv_fwd: Bs=%d groups=%d unsupported (clips per group a multiple of %d, Bs / %d "
+               "workgroups co-resident)", Bs, groups, DP_CLIPS, DP_CLIPS);
+    TG_REQUIRE((running_mean1 == nullptr) == (running_var1 == nullptr) && (running_mean2 == nullptr) == (running_var2 == nullptr),
+               "tg_d_preconv_fwd: running mean and variance go together");
+    TG_REQUIRE(ws_bytes >= tg_d_preconv_ws_bytes(Bs) && aligned16(ws), "tg_d_preconv_fwd: workspace too small or unaligned");
+    DPreconvArgs a;
+    a.x = poses; a.w1 = w1; a.b1 = b1; a.g1 = gamma1; a.be1 = beta1; a.w2 = w2; a.b2 = b2; a.g2 = gamma2; a.be2 = beta2; a.w3 = w3; a.b3 = b3;
+    a.c1 = c1; a.y1 = y1; a.c2 = c2; a.y2 = y2; a.c3 = c3; a.mean1 = mean1; a.rstd1 = rstd1; a.mean2 = mean2; a.rstd2 = rstd2;
+    a.rm1 = running_mean1; a.rv1 = running_var1; a.rm2 = running_mean2; a.rv2 = running_var2; a.nbt1 = nbt1; a.nbt2 = nbt2;
+    a.ws = reinterpret_cast<unsigned*>(ws);
+    a.part = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + 16);
+    a.Bs = Bs; a.groups = groups; a.per = Bs / groups; a.eps = eps; a.momentum = momentum;
+    hipLaunchKernelGGL(d_preconv_fwd_kernel, dim3(8 * (Bs / DP_CLIPS + 1)), dim3(256), 0, (hipStream_t)stream, a);      // + the keeper; 1 id in 8 works
+    return check_launch("tg_d_preconv_fwd");
+}

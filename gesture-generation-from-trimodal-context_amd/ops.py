@@ -421,9 +421,41 @@ def _gru_cluster_ws(dev, B, H, bwd=False):
     return ws
 
 
+_dpre_ws = {}             # (device, Bs) -> zero-initialised workspace of the fused discriminator front end (timeout word first)
+D_PRECONV_FUSED = os.environ.get("TG_D_PRECONV_FUSED", "1") != "0"
+
+
+def d_preconv_fwd_supported(Bs, groups):
+    return D_PRECONV_FUSED and bool(_lib.load().tg_d_preconv_fwd_supported(int(Bs), int(groups)))
+
+
+def d_preconv_fwd(poses, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, rm1, rv1, nbt1, rm2, rv2, nbt2, groups, eps=1e-5, momentum=0.1):
+    """ConvDiscriminator.pre_conv, train-mode forward, one launch -> dict(c1, y1, c2, y2, c3, mean1, rstd1, mean2, rstd2) (tg_d_preconv_fwd)."""
+    _flat(poses, "poses"); Bs = poses.shape[0]
+    assert tuple(poses.shape[1:]) == (34, 27) and tuple(w1.shape) == (16, 27, 3) and tuple(w2.shape) == (8, 16, 3) and tuple(w3.shape) == (8, 8, 3)
+    for t_ in (w1, b1, g1, be1, w2, b2, g2, be2, w3, b3):
+        _flat(t_, "parameter")
+    dev = poses.device
+    key = (dev.type, dev.index, Bs)
+    if key not in _dpre_ws:
+        _dpre_ws[key] = torch.zeros(_lib.load().tg_d_preconv_ws_bytes(Bs) // 4, dtype=torch.int32, device=dev)
+    ws = _dpre_ws[key]
+    e = lambda *shape: torch.empty(*shape, device=dev)
+    o = dict(c1=e(Bs, 32, 16), y1=e(Bs, 32, 16), c2=e(Bs, 30, 8), y2=e(Bs, 30, 8), c3=e(Bs, 28, 8), mean1=e(groups, 16), rstd1=e(groups, 16),
+             mean2=e(groups, 8), rstd2=e(groups, 8))
+    call("tg_d_preconv_fwd", _p(poses), _p(w1), _p(b1), _p(g1), _p(be1), _p(w2), _p(b2), _p(g2), _p(be2), _p(w3), _p(b3), _p(o["c1"]), _p(o["y1"]),
+         _p(o["c2"]), _p(o["y2"]), _p(o["c3"]), _p(o["mean1"]), _p(o["rstd1"]), _p(o["mean2"]), _p(o["rstd2"]), _p(rm1), _p(rv1), _p(nbt1), _p(rm2),
+         _p(rv2), _p(nbt2), _p(ws), ws.numel() * 4, Bs, int(groups), float(eps), float(momentum), _stream())
+    return o
+
+
 def check_async_errors():
     """Raise if a bounded spin of a persistent kernel timed out since the last check (synchronises; tests, bench, loss read-out,
     every CHECK_EVERY replays of a captured step).  The timeout word is sticky on the device: only this function clears it."""
+    for key, ws in _dpre_ws.items():
+        if int(ws[0].item()) != 0:
+            ws.zero_()              # counters of the aborted launch are out of step: back to the state of a fresh allocation
+            raise RuntimeError(f"fused discriminator front end timed out at a device-wide barrier (device, Bs) = {key}; results are invalid")
     for key, ws in _gru_ws.items():
         if int(ws[0].item()) != 0:
             info = ws[:14].tolist()

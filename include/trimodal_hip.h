@@ -301,6 +301,20 @@ int tg_bn2_backward(const float* dy, const float* x, float* dx, int32_t rows_per
                     const float* rstd, const float* gamma, const float* beta, float act_slope, double* ws, int64_t ws_doubles,
                     float* dgamma, float* dbeta, void* stream);
 
+/* ---- ConvDiscriminator.pre_conv, train-mode forward in ONE launch (model/multimodal_context_net.py:214-220: Conv1d(27,16,3) -> BN(16) ->
+ * LeakyReLU(True) = identity -> Conv1d(16,8,3) -> BN(8) -> identity -> Conv1d(8,8,3); poses [Bs][34][27] channel-last, `groups` stacked
+ * forward calls with their own batch statistics).  Writes what the separate launches write: the conv outputs c1 [Bs][32][16], c2 [Bs][30][8],
+ * c3 [Bs][28][8], the BatchNorm outputs y1 / y2 (same shapes as c1 / c2), mean / rstd [groups][C], and updates the running statistics in call
+ * order (either pair may be NULL).  ws: tg_d_preconv_ws_bytes(Bs) bytes, 16-byte aligned, ZERO before the first use and left zero by every
+ * launch (workgroups of one launch meet at two device-wide barriers: one launch at a time per workspace; a timeout sets ws[0], sticky). */
+int32_t tg_d_preconv_fwd_supported(int32_t Bs, int32_t groups);
+int64_t tg_d_preconv_ws_bytes(int32_t Bs);
+int tg_d_preconv_fwd(const float* poses, const float* w1, const float* b1, const float* gamma1, const float* beta1, const float* w2,
+                     const float* b2, const float* gamma2, const float* beta2, const float* w3, const float* b3, float* c1, float* y1,
+                     float* c2, float* y2, float* c3, float* mean1, float* rstd1, float* mean2, float* rstd2, float* running_mean1,
+                     float* running_var1, int64_t* nbt1, float* running_mean2, float* running_var2, int64_t* nbt2, void* ws,
+                     int64_t ws_bytes, int32_t Bs, int32_t groups, float eps, float momentum, void* stream);
+
 /* ---- speaker / style path (model/multimodal_context_net.py:83-95,125-137; embedding_net.py:10-13), fused ------------------------------
  * forward: se = table[vid], zc = W1 se + b1, mu = Wmu zc + bmu, logvar = Wlv zc + blv, z = mu + eps * exp(0.5 logvar) (all [B][16]); with
  * rep != NULL also rep[(b * T + t) * rep_ld + j] = z[b][j] (the style columns of the GRU input).  eps is read when rng_state == NULL and

@@ -305,6 +305,40 @@ def test_full_size_iteration_regenerated_dropout_equals_stored_masks(pkg, dev, m
     print(f"regenerated vs stored dropout masks at B = 128: worst gradient difference {worst:.1e}")
 
 
+@pytest.mark.parametrize("Bs,groups", [(256, 2), (128, 1), (8, 2), (12, 3)])
+def test_fused_discriminator_front_end_equals_separate_launches(pkg, dev, monkeypatch, Bs, groups):
+    """tg_d_preconv_fwd (ConvDiscriminator.pre_conv, multimodal_context_net.py:214-220, train mode, one launch with two device-wide barriers)
+    against the seven launches it replaces (three window GEMMs + two two-launch BatchNorms): every tensor the backward reads from the tape,
+    the GRU input, the batch statistics per group, the running statistics and num_batches_tracked.  Run three times on one workspace: the
+    barrier counters are left at zero by every launch."""
+    dst = O.make_discriminator_state(4)
+    poses = (torch.randn(Bs, 34, 27, generator=torch.Generator().manual_seed(Bs)) * 0.7).to(dev)
+    outs = {}
+    for fused in (False, True):
+        monkeypatch.setattr(pkg.ops, "D_PRECONV_FUSED", fused)
+        D = pkg.ConvDiscriminator(27)
+        D.load_state_dict(O.clone_state(dst, torch.float32), strict=True)
+        D = D.to(dev)
+        eng = D.engine
+        for rep_ in range(3 if fused else 1):
+            if rep_:
+                D.load_state_dict(O.clone_state(dst, torch.float32), strict=True)
+            res = eng.forward(poses, training=True, groups=groups, save=True)
+        tp = res["tape"]
+        (x0, st1), (y1, st2), (y2, _) = tp["convs"]
+        assert x0.data_ptr() == tp["poses"].data_ptr()
+        sd = D.state_dict()
+        outs[fused] = dict(c1=st1.x, mean1=st1.mean, rstd1=st1.rstd, y1=y1, c2=st2.x, mean2=st2.mean, rstd2=st2.rstd, y2=y2, logit=res["logit"],
+                           **{k: v.clone() for k, v in sd.items() if "running" in k or "tracked" in k})
+    pkg.ops.check_async_errors()
+    for k, ref in outs[False].items():
+        got = outs[True][k]
+        if "tracked" in k:
+            assert int(got) == int(ref) == groups, k
+        else:
+            assert got.shape == ref.shape and rel(got, ref.double().cpu()) < 1e-5, (k, rel(got, ref.double().cpu()))
+
+
 def test_module_api_autograd_bridge(pkg, dev):
     """The reference's own loop style: module(...) calls + torch losses + loss.backward() + torch.optim.Adam."""
     V, S, B = 64, 9, 4
