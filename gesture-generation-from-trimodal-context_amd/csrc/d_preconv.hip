@@ -155,49 +155,77 @@ __global__ __launch_bounds__(256) void d_preconv_fwd_kernel(const DPreconvArgs a
         }
         return;
     }
-    // ---- stage poses and weights
-    for (int i = t; i < DP_CLIPS * DP_T0 * DP_D; i += 256) {
-        const int c = i % DP_D, r = i / DP_D;
-        sx[r / DP_T0][r % DP_T0][c] = a.x[(long)b0 * DP_T0 * DP_D + i];
-    }
-    if (t < DP_CLIPS * DP_T0) sx[t / DP_T0][t % DP_T0][DP_D] = 0.f;               // the pad column (read by the 16-byte fragments below)
-    if (t < DP_C1 * DP_KW) sw1[t / DP_KW][t % DP_KW][DP_D] = 0.f;
-    for (int i = t; i < DP_C1 * DP_D * DP_KW; i += 256) { const int k = i % DP_KW, ci = (i / DP_KW) % DP_D, co = i / (DP_KW * DP_D); sw1[co][k][ci] = a.w1[i]; }
-    for (int i = t; i < DP_C2 * DP_C1 * DP_KW; i += 256) { const int k = i % DP_KW, ci = (i / DP_KW) % DP_C1, co = i / (DP_KW * DP_C1); sw2[co][k][ci] = a.w2[i]; }
-    for (int i = t; i < DP_C3 * DP_C2 * DP_KW; i += 256) { const int k = i % DP_KW, ci = (i / DP_KW) % DP_C2, co = i / (DP_KW * DP_C2); sw3[co][k][ci] = a.w3[i]; }
-    __syncthreads();
-
-    // ---- conv1: thread = (channel co, rows rg, rg + 16, ..: the four row groups of a wave read four consecutive frames -- distinct LDS banks
-    // with 28-float rows; eight consecutive rows per thread put them 224 floats = 7 x 32 banks apart)
+    // ---- stage poses and weights: every global load is issued before the first LDS store (rolled "load, store" loops paid one memory round
+    // trip per iteration: 7.5 of the kernel's 25 us)
     {
-        const int co = t & 15, r0 = t >> 4;                   // 128 rows = 4 clips x 32 frames; thread rows r0 + 16 r
-        float acc[8];
-        const float bias = a.b1[co];
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + (long)b0 * DP_T0 * DP_D);       // 4 clips x 918 floats: 16-byte aligned (b0 % 4 == 0)
+        constexpr int NX4 = DP_CLIPS * DP_T0 * DP_D / 4;                                         // 918
+        f32x4 xr[4];
+        float w1r[6], w2r[2], w3r = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = bias;
-        // 16-byte LDS fragments, fully unrolled: 21 weight + 168 pose reads per thread, all independent (the rolled scalar loop waited out an
-        // LDS round trip per (tap, channel): 81 of them)
+        for (int q = 0; q < 4; ++q) { const int i = t + 256 * q; xr[q] = x4[i < NX4 ? i : 0]; }
 #pragma unroll
-        for (int k = 0; k < DP_KW; ++k)
+        for (int q = 0; q < 6; ++q) { const int i = t + 256 * q; w1r[q] = a.w1[i < DP_C1 * DP_D * DP_KW ? i : 0]; }
 #pragma unroll
-            for (int c4 = 0; c4 < (DP_D + 1) / 4; ++c4) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(&sw1[co][k][4 * c4]);
+        for (int q = 0; q < 2; ++q) { const int i = t + 256 * q; w2r[q] = a.w2[i < DP_C2 * DP_C1 * DP_KW ? i : 0]; }
+        if (t < DP_C3 * DP_C2 * DP_KW) w3r = a.w3[t];
+        if (t < DP_CLIPS * DP_T0) sx[t / DP_T0][t % DP_T0][DP_D] = 0.f;           // the pad column (k = 27 of every tap: multiplied by a zero weight)
+        if (t < DP_C1 * DP_KW) sw1[t / DP_KW][t % DP_KW][DP_D] = 0.f;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int row = r0 + 16 * r;
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(&sx[row >> 5][(row & 31) + k][4 * c4]);
+        for (int q = 0; q < 4; ++q) {
+            const int i4 = t + 256 * q;
+            if (i4 < NX4) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[r] = __builtin_fmaf(xv[q], w[q], acc[r]);
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * i4 + e, c = i % DP_D, r = i / DP_D;
+                    sx[r / DP_T0][r % DP_T0][c] = xr[q][e];
                 }
             }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int i = t + 256 * q;
+            if (i < DP_C1 * DP_D * DP_KW) { const int k = i % DP_KW, ci = (i / DP_KW) % DP_D, co = i / (DP_KW * DP_D); sw1[co][k][ci] = w1r[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = t + 256 * q;
+            if (i < DP_C2 * DP_C1 * DP_KW) { const int k = i % DP_KW, ci = (i / DP_KW) % DP_C1, co = i / (DP_KW * DP_C1); sw2[co][k][ci] = w2r[q]; }
+        }
+        if (t < DP_C3 * DP_C2 * DP_KW) { const int k = t % DP_KW, ci = (t / DP_KW) % DP_C2, co = t / (DP_KW * DP_C2); sw3[co][k][ci] = w3r; }
+    }
+    __syncthreads();
+
+    // ---- conv1 on the f32 matrix cores: [128 rows = 4 clips x 32 frames] x [16 channels] x [K = 3 taps x 28 (27 + zero pad)] as 8 row tiles x 21
+    // k-steps of v_mfma_f32_16x16x4_f32, two row tiles per wave.  A(row, k) = pose row (clip, frame + tap), channel ci, straight from LDS; B(k, co)
+    // = the lane's 21 weights in registers.  (As 648 FMAs per thread on 16-byte LDS fragments the conv was LDS-bandwidth bound: 3.4 us.)
+    {
+        const int lane = t & 63, wave = t >> 6, r16 = lane & 15, kq = lane >> 4;
+        float bw[21];
+#pragma unroll
+        for (int ks = 0; ks < 21; ++ks) { const int k = 4 * ks + kq; bw[ks] = sw1[r16][k / (DP_D + 1)][k % (DP_D + 1)]; }
+        const float bias = a.b1[r16];
+        f32x4 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (2 * wave + i) * 16 + r16;         // this lane's A row
+            const float* xrow = &sx[row >> 5][row & 31][0];    // taps are consecutive 28-float rows
+            acc[i] = f32x4{bias, bias, bias, bias};
+#pragma unroll
+            for (int ks = 0; ks < 21; ++ks) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xrow[4 * ks + kq], bw[ks], acc[i], 0, 0, 0);
+        }
+        // accumulator register q of the lane = output row 4 kq + q of the tile, channel r16
         double s = 0.0, ss = 0.0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int row = r0 + 16 * r;
-            s1[row >> 5][row & 31][co] = acc[r];                  // (c1 goes to global memory after the barrier, with y1: nothing but the
-            s += acc[r]; ss += (double)acc[r] * acc[r];           //  partial sums is in flight when the workgroup drains its stores)
-        }
-        red[0][t] = s; red[1][t] = ss;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = (2 * wave + i) * 16 + 4 * kq + q;
+                const float v = acc[i][q];
+                s1[row >> 5][row & 31][r16] = v;                  // (c1 goes to global memory after the barrier, with y1: nothing but the
+                s += v; ss += (double)v * v;                      //  partial sums is in flight when the workgroup drains its stores)
+            }
+        red[0][t] = s; red[1][t] = ss;                        // t = 16 (4 wave + kq) + channel
     }
     __syncthreads();
     if (t < DP_C1) {                                          // this workgroup's partial sums, fixed order
