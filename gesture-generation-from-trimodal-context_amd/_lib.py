@@ -83,6 +83,7 @@ SIGNATURES = {
     "tg_act_mask_bwd": [P, P, P, F32, P, I64, P],
     "tg_act_mask_bwd2": [P, P, P, P, F32, P, P, I64, P],
     "tg_embed_gather_drop": [P, P, P, I32, I32, I32, F32, P, U32, P],
+    "tg_d_preconv_bwd": [P] * 26 + [I32, P, I64, I32, I32, P],
     "tg_d_preconv_fwd": [P] * 27 + [I64, I32, I32, F32, F32, P],
     "tg_iter_head": [P, P, P, P, P, P, I64, I32, I32, I32, I32, I32, P, P, P, P, I32, P, U32, P, P],
     "tg_act_mask_bwd_drop": [P, P, F32, P, U32, I64, F32, P, I64, P],

@@ -318,6 +318,275 @@ __global__ __launch_bounds__(256) void d_preconv_fwd_kernel(const DPreconvArgs a
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------- backward
+// The same block backwards, ONE launch: from the gradient at the GRU input (d c3) to the parameter gradients of the three convs and two
+// BatchNorms and, optionally, the pose gradient.  Same work split (a workgroup owns DP_CLIPS clips), same two device-wide barriers -- here
+// for the two sums every train-mode BatchNorm backward needs over its whole statistics group (sum dy, sum dy xhat).  The parameter-gradient
+// partials of a workgroup (1 904 numbers) are added to the gradient tensors with float atomics, as the generic path does for these tiny
+// conv gradients.  LeakyReLU(True) is the identity: dz = dy.
+struct DPreconvBwdArgs {
+    const float* dc3;                // [nb][28][8]
+    const float *x, *c1, *y1, *c2, *y2;          // the forward's tape, rows of the nb clips
+    const float *mean1, *rstd1, *mean2, *rstd2;  // [groups][C] of exactly these clips' groups
+    const float *w1, *w2, *w3, *g1, *g2;
+    float *dw1, *db1, *dg1, *dbe1, *dw2, *db2, *dg2, *dbe2, *dw3, *db3;      // all NULL: no parameter gradients
+    float* dposes;                   // NULL, or [nb][34][27]
+    int dposes_accumulate;
+    double* part;                    // [2 layers][n workgroups][2][16]
+    unsigned* ws;
+    int nb, groups, per;
+};
+
+__global__ __launch_bounds__(256) void d_preconv_bwd_kernel(const DPreconvBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float sx[DP_CLIPS][DP_T0][DP_D + 1];
+    __shared__ __attribute__((aligned(16))) float sc1[DP_CLIPS][DP_T1][DP_C1];      // c1 -> xhat1, later d c1
+    __shared__ __attribute__((aligned(16))) float sy1[DP_CLIPS][DP_T1][DP_C1];      // y1
+    __shared__ __attribute__((aligned(16))) float sd1[DP_CLIPS][DP_T1][DP_C1];      // d y1
+    __shared__ __attribute__((aligned(16))) float sc2[DP_CLIPS][DP_T2][DP_C2];      // c2 -> xhat2, later d c2
+    __shared__ __attribute__((aligned(16))) float sy2[DP_CLIPS][DP_T2][DP_C2];
+    __shared__ __attribute__((aligned(16))) float sd2[DP_CLIPS][DP_T2][DP_C2];      // d y2
+    __shared__ __attribute__((aligned(16))) float sd3[DP_CLIPS][DP_T3][DP_C3];      // d c3
+    __shared__ float sw1[DP_C1][DP_D][DP_KW], sw2[DP_C2][DP_C1][DP_KW], sw3[DP_C3][DP_C2][DP_KW];      // reference layout (Co, Ci, kw)
+    __shared__ double red[2][256], tot[2][DP_C1];
+    __shared__ float sc[3][DP_C1];                            // m1 = sum dy / n, m2 = sum dy xhat / n, gamma rstd
+    const int t = threadIdx.x, wid = blockIdx.x, nwg = gridDim.x;
+    const int wpg = a.per / DP_CLIPS, g = wid / wpg, b0 = wid * DP_CLIPS;
+    const bool pg = a.dw1 != nullptr;
+
+    // ---- stage the tape (loads first, then LDS stores)
+    {
+        const long o3 = (long)b0 * DP_T3 * DP_C3, o2 = (long)b0 * DP_T2 * DP_C2, o1 = (long)b0 * DP_T1 * DP_C1;
+        constexpr int N3 = DP_CLIPS * DP_T3 * DP_C3 / 4, N2 = DP_CLIPS * DP_T2 * DP_C2 / 4, N1 = DP_CLIPS * DP_T1 * DP_C1 / 4, NX4 = DP_CLIPS * DP_T0 * DP_D / 4;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 v3 = t < N3 ? reinterpret_cast<const f32x4*>(a.dc3 + o3)[t] : z4;
+        const f32x4 vc2 = t < N2 ? reinterpret_cast<const f32x4*>(a.c2 + o2)[t] : z4, vy2 = t < N2 ? reinterpret_cast<const f32x4*>(a.y2 + o2)[t] : z4;
+        f32x4 vc1[2], vy1[2], xr[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { vc1[q] = reinterpret_cast<const f32x4*>(a.c1 + o1)[t + 256 * q]; vy1[q] = reinterpret_cast<const f32x4*>(a.y1 + o1)[t + 256 * q]; }
+        static_assert(N1 == 512, "two 16-byte pieces of c1 / y1 per thread");
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + (long)b0 * DP_T0 * DP_D);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = t + 256 * q; xr[q] = x4[i < NX4 ? i : 0]; }
+        float w1r[6], w2r[2], w3r = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { const int i = t + 256 * q; w1r[q] = a.w1[i < DP_C1 * DP_D * DP_KW ? i : 0]; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int i = t + 256 * q; w2r[q] = a.w2[i < DP_C2 * DP_C1 * DP_KW ? i : 0]; }
+        if (t < DP_C3 * DP_C2 * DP_KW) w3r = a.w3[t];
+        if (t < N3) reinterpret_cast<f32x4*>(&sd3[0][0][0])[t] = v3;
+        if (t < N2) {
+            // xhat2 = (c2 - mean) rstd, channel = (4 t) % 8 .. + 3
+            const int c0 = (4 * t) & 7;
+            f32x4 xh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xh[q] = (vc2[q] - a.mean2[g * DP_C2 + c0 + q]) * a.rstd2[g * DP_C2 + c0 + q];
+            reinterpret_cast<f32x4*>(&sc2[0][0][0])[t] = xh;
+            reinterpret_cast<f32x4*>(&sy2[0][0][0])[t] = vy2;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c0 = (4 * (t + 256 * q)) & 15;
+            f32x4 xh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xh[e] = (vc1[q][e] - a.mean1[g * DP_C1 + c0 + e]) * a.rstd1[g * DP_C1 + c0 + e];
+            reinterpret_cast<f32x4*>(&sc1[0][0][0])[t + 256 * q] = xh;
+            reinterpret_cast<f32x4*>(&sy1[0][0][0])[t + 256 * q] = vy1[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i4 = t + 256 * q;
+            if (i4 < NX4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int i = 4 * i4 + e, c = i % DP_D, r = i / DP_D; sx[r / DP_T0][r % DP_T0][c] = xr[q][e]; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { const int i = t + 256 * q; if (i < DP_C1 * DP_D * DP_KW) (&sw1[0][0][0])[i] = w1r[q]; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int i = t + 256 * q; if (i < DP_C2 * DP_C1 * DP_KW) (&sw2[0][0][0])[i] = w2r[q]; }
+        if (t < DP_C3 * DP_C2 * DP_KW) (&sw3[0][0][0])[t] = w3r;
+    }
+    __syncthreads();
+
+    // ---- conv3: weight / bias gradient partials (straight to the gradient tensors), input gradient d y2
+    if (pg) {
+        if (t < DP_C3 * DP_C2 * DP_KW) {                      // dW3[co][ci][k] = sum_{clip, frame} d c3[frame][co] y2[frame + k][ci]
+            const int k = t % DP_KW, ci = (t / DP_KW) % DP_C2, co = t / (DP_KW * DP_C2);
+            float acc = 0.f;
+            for (int cl = 0; cl < DP_CLIPS; ++cl)
+                for (int f = 0; f < DP_T3; ++f) acc = __builtin_fmaf(sd3[cl][f][co], sy2[cl][f + k][ci], acc);
+            atomicAdd(a.dw3 + t, acc);
+        } else if (t < DP_C3 * DP_C2 * DP_KW + DP_C3) {
+            const int co = t - DP_C3 * DP_C2 * DP_KW;
+            float acc = 0.f;
+            for (int cl = 0; cl < DP_CLIPS; ++cl)
+                for (int f = 0; f < DP_T3; ++f) acc += sd3[cl][f][co];
+            atomicAdd(a.db3 + co, acc);
+        }
+    }
+    {
+        double s = 0.0, ss = 0.0;                             // BatchNorm 2 backward sums of this thread's channel (t & 7)
+        for (int i = t; i < DP_CLIPS * DP_T2 * DP_C2; i += 256) {
+            const int ci = i & 7, r = i >> 3, cl = r / DP_T2, f = r - cl * DP_T2;
+            float acc = 0.f;                                  // d y2[f][ci] = sum_{k, co} d c3[f - k][co] W3[co][ci][k]
+#pragma unroll
+            for (int k = 0; k < DP_KW; ++k) {
+                const int fo = f - k;
+                if (fo >= 0 && fo < DP_T3) {
+#pragma unroll
+                    for (int co = 0; co < DP_C3; ++co) acc = __builtin_fmaf(sd3[cl][fo][co], sw3[co][ci][k], acc);
+                }
+            }
+            sd2[cl][f][ci] = acc;
+            s += acc; ss += (double)acc * sc2[cl][f][ci];
+        }
+        red[0][t] = s; red[1][t] = ss;
+    }
+    __syncthreads();
+    if (t < DP_C2) {
+        double s = 0.0, ss = 0.0;
+        for (int q = 0; q < 32; ++q) { s += red[0][q * 8 + t]; ss += red[1][q * 8 + t]; }
+        double* o = a.part + (((long)nwg + wid) * 2) * DP_C1;
+        dp_store_sc1(o + t, s);
+        dp_store_sc1(o + DP_C1 + t, ss);
+    }
+    if (!dp_barrier(a.ws, 1, nwg)) return;
+
+    auto totals = [&](int layer, int C) {                     // sums of this workgroup's group -> tot[0 / 1][c]
+        const int S = 256 / C, c = t % C, sl = t / C;
+        const double* p = a.part + ((long)layer * nwg + (long)g * wpg) * 2 * DP_C1;
+        double s = 0.0, ss = 0.0;
+        for (int w = sl; w < wpg; w += S) { s += dp_load_sc1(p + (long)w * 2 * DP_C1 + c); ss += dp_load_sc1(p + (long)w * 2 * DP_C1 + DP_C1 + c); }
+        __syncthreads();
+        red[0][t] = s; red[1][t] = ss;
+        __syncthreads();
+        if (t < C) {
+            double ta = 0.0, tb = 0.0;
+            for (int q = 0; q < S; ++q) { ta += red[0][q * C + t]; tb += red[1][q * C + t]; }
+            tot[0][t] = ta; tot[1][t] = tb;
+        }
+        __syncthreads();
+    };
+    // ---- BatchNorm 2 backward: d c2 = gamma rstd (d y2 - mean(d y2) - xhat mean(d y2 xhat)); d gamma += sum d y2 xhat, d beta += sum d y2
+    totals(1, DP_C2);
+    if (t < DP_C2) {
+        const double n = (double)a.per * DP_T2;
+        sc[0][t] = (float)(tot[0][t] / n); sc[1][t] = (float)(tot[1][t] / n); sc[2][t] = a.g2[t] * a.rstd2[g * DP_C2 + t];
+        if (pg && wid % wpg == 0) { atomicAdd(a.dg2 + t, (float)tot[1][t]); atomicAdd(a.dbe2 + t, (float)tot[0][t]); }
+    }
+    __syncthreads();
+    for (int i = t; i < DP_CLIPS * DP_T2 * DP_C2; i += 256) {
+        const int c = i & 7;
+        float* xh = &sc2[0][0][0] + i;
+        *xh = sc[2][c] * ((&sd2[0][0][0])[i] - sc[0][c] - *xh * sc[1][c]);                      // sc2 now holds d c2
+    }
+    __syncthreads();
+
+    // ---- conv2: gradients, d y1, BatchNorm 1 sums
+    if (pg) {
+        for (int e = t; e < DP_C2 * DP_C1 * DP_KW + DP_C2; e += 256) {
+            if (e < DP_C2 * DP_C1 * DP_KW) {
+                const int k = e % DP_KW, ci = (e / DP_KW) % DP_C1, co = e / (DP_KW * DP_C1);
+                float acc = 0.f;
+                for (int cl = 0; cl < DP_CLIPS; ++cl)
+                    for (int f = 0; f < DP_T2; ++f) acc = __builtin_fmaf(sc2[cl][f][co], sy1[cl][f + k][ci], acc);
+                atomicAdd(a.dw2 + e, acc);
+            } else {
+                const int co = e - DP_C2 * DP_C1 * DP_KW;
+                float acc = 0.f;
+                for (int cl = 0; cl < DP_CLIPS; ++cl)
+                    for (int f = 0; f < DP_T2; ++f) acc += sc2[cl][f][co];
+                atomicAdd(a.db2 + co, acc);
+            }
+        }
+    }
+    {
+        double s = 0.0, ss = 0.0;                             // channel t & 15
+        for (int i = t; i < DP_CLIPS * DP_T1 * DP_C1; i += 256) {
+            const int ci = i & 15, r = i >> 4, cl = r >> 5, f = r & 31;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < DP_KW; ++k) {
+                const int fo = f - k;
+                if (fo >= 0 && fo < DP_T2) {
+#pragma unroll
+                    for (int co = 0; co < DP_C2; ++co) acc = __builtin_fmaf(sc2[cl][fo][co], sw2[co][ci][k], acc);
+                }
+            }
+            sd1[cl][f][ci] = acc;
+            s += acc; ss += (double)acc * sc1[cl][f][ci];
+        }
+        red[0][t] = s; red[1][t] = ss;
+    }
+    __syncthreads();
+    if (t < DP_C1) {
+        double s = 0.0, ss = 0.0;
+        for (int q = 0; q < 16; ++q) { s += red[0][q * 16 + t]; ss += red[1][q * 16 + t]; }
+        double* o = a.part + ((long)wid * 2) * DP_C1;
+        dp_store_sc1(o + t, s);
+        dp_store_sc1(o + DP_C1 + t, ss);
+    }
+    if (!dp_barrier(a.ws, 2, nwg)) return;
+    if (t == 0) __hip_atomic_store((dp_gu32*)(a.ws + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    totals(0, DP_C1);
+    if (t < DP_C1) {
+        const double n = (double)a.per * DP_T1;
+        sc[0][t] = (float)(tot[0][t] / n); sc[1][t] = (float)(tot[1][t] / n); sc[2][t] = a.g1[t] * a.rstd1[g * DP_C1 + t];
+        if (pg && wid % wpg == 0) { atomicAdd(a.dg1 + t, (float)tot[1][t]); atomicAdd(a.dbe1 + t, (float)tot[0][t]); }
+    }
+    __syncthreads();
+    for (int i = t; i < DP_CLIPS * DP_T1 * DP_C1; i += 256) {
+        const int c = i & 15;
+        float* xh = &sc1[0][0][0] + i;
+        *xh = sc[2][c] * ((&sd1[0][0][0])[i] - sc[0][c] - *xh * sc[1][c]);                      // sc1 now holds d c1
+    }
+    __syncthreads();
+
+    // ---- conv1: gradients, pose gradient
+    if (pg) {
+        for (int e = t; e < DP_C1 * DP_D * DP_KW + DP_C1; e += 256) {
+            if (e < DP_C1 * DP_D * DP_KW) {
+                const int k = e % DP_KW, ci = (e / DP_KW) % DP_D, co = e / (DP_KW * DP_D);
+                float acc = 0.f;
+                for (int cl = 0; cl < DP_CLIPS; ++cl)
+                    for (int f = 0; f < DP_T1; ++f) acc = __builtin_fmaf(sc1[cl][f][co], sx[cl][f + k][ci], acc);
+                atomicAdd(a.dw1 + e, acc);
+            } else {
+                const int co = e - DP_C1 * DP_D * DP_KW;
+                float acc = 0.f;
+                for (int cl = 0; cl < DP_CLIPS; ++cl)
+                    for (int f = 0; f < DP_T1; ++f) acc += sc1[cl][f][co];
+                atomicAdd(a.db1 + co, acc);
+            }
+        }
+    }
+    if (a.dposes) {
+        float* dp = a.dposes + (long)b0 * DP_T0 * DP_D;
+        for (int i = t; i < DP_CLIPS * DP_T0 * DP_D; i += 256) {
+            const int ci = i % DP_D, r = i / DP_D, cl = r / DP_T0, f = r - cl * DP_T0;
+            float acc = a.dposes_accumulate ? dp[i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < DP_KW; ++k) {
+                const int fo = f - k;
+                if (fo >= 0 && fo < DP_T1) {
+#pragma unroll
+                    for (int co = 0; co < DP_C1; ++co) acc = __builtin_fmaf(sc1[cl][fo][co], sw1[co][ci][k], acc);
+                }
+            }
+            dp[i] = acc;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        dp_gu32* c = (dp_gu32*)(a.ws + 3);
+        if (__hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nwg - 1) {
+            __hip_atomic_store((dp_gu32*)(a.ws + 2), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -351,4 +620,30 @@ extern "C" int tg_d_preconv_fwd(const float* poses, const float* w1, const float
     a.Bs = Bs; a.groups = groups; a.per = Bs / groups; a.eps = eps; a.momentum = momentum;
     hipLaunchKernelGGL(d_preconv_fwd_kernel, dim3(8 * (Bs / DP_CLIPS + 1)), dim3(256), 0, (hipStream_t)stream, a);      // + the keeper; 1 id in 8 works
     return check_launch("tg_d_preconv_fwd");
+}
+
+extern "C" int tg_d_preconv_bwd(const float* dc3, const float* poses, const float* c1, const float* y1, const float* c2, const float* y2,
+                                const float* mean1, const float* rstd1, const float* mean2, const float* rstd2, const float* w1, const float* w2,
+                                const float* w3, const float* gamma1, const float* gamma2, float* dw1, float* db1, float* dgamma1, float* dbeta1,
+                                float* dw2, float* db2, float* dgamma2, float* dbeta2, float* dw3, float* db3, float* dposes,
+                                int32_t dposes_accumulate, void* ws, int64_t ws_bytes, int32_t nb, int32_t groups, void* stream) {
+    TG_REQUIRE(dc3 && poses && c1 && y1 && c2 && y2 && mean1 && rstd1 && mean2 && rstd2 && w1 && w2 && w3 && gamma1 && gamma2 && ws,
+               "tg_d_preconv_bwd: null pointer");
+    const bool all = dw1 && db1 && dgamma1 && dbeta1 && dw2 && db2 && dgamma2 && dbeta2 && dw3 && db3;
+    const bool none = !dw1 && !db1 && !dgamma1 && !dbeta1 && !dw2 && !db2 && !dgamma2 && !dbeta2 && !dw3 && !db3;
+    TG_REQUIRE(all || none, "tg_d_preconv_bwd: the ten parameter gradients go together (all or none)");
+    TG_REQUIRE(all || dposes, "tg_d_preconv_bwd: nothing to compute");
+    TG_REQUIRE(tg_d_preconv_fwd_supported(nb, groups), "tg_d_preconv_bwd: nb=%d groups=%d unsupported", nb, groups);
+    TG_REQUIRE(ws_bytes >= tg_d_preconv_ws_bytes(nb) && aligned16(ws) && aligned16(dc3) && aligned16(poses) && aligned16(c1) && aligned16(y1) &&
+                   aligned16(c2) && aligned16(y2), "tg_d_preconv_bwd: workspace too small or unaligned operands");
+    DPreconvBwdArgs a;
+    a.dc3 = dc3; a.x = poses; a.c1 = c1; a.y1 = y1; a.c2 = c2; a.y2 = y2; a.mean1 = mean1; a.rstd1 = rstd1; a.mean2 = mean2; a.rstd2 = rstd2;
+    a.w1 = w1; a.w2 = w2; a.w3 = w3; a.g1 = gamma1; a.g2 = gamma2;
+    a.dw1 = dw1; a.db1 = db1; a.dg1 = dgamma1; a.dbe1 = dbeta1; a.dw2 = dw2; a.db2 = db2; a.dg2 = dgamma2; a.dbe2 = dbeta2; a.dw3 = dw3; a.db3 = db3;
+    a.dposes = dposes; a.dposes_accumulate = dposes_accumulate;
+    a.ws = reinterpret_cast<unsigned*>(ws);
+    a.part = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + 16);
+    a.nb = nb; a.groups = groups; a.per = nb / groups;
+    hipLaunchKernelGGL(d_preconv_bwd_kernel, dim3(nb / DP_CLIPS), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("tg_d_preconv_bwd");
 }

@@ -449,6 +449,26 @@ def d_preconv_fwd(poses, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, rm1, rv1, nbt
     return o
 
 
+def d_preconv_bwd(dc3, poses, c1, y1, c2, y2, mean1, rstd1, mean2, rstd2, w1, w2, w3, g1, g2, grads, dposes, dposes_accumulate, groups):
+    """ConvDiscriminator.pre_conv backward, one launch (tg_d_preconv_bwd).  grads: None or the ten gradient tensors (dw1, db1, dgamma1, dbeta1,
+    dw2, db2, dgamma2, dbeta2, dw3, db3), accumulated into; dposes: None or (nb, 34, 27), added to when dposes_accumulate."""
+    nb = dc3.shape[0]
+    for t_ in (dc3, poses, c1, y1, c2, y2, mean1, rstd1, mean2, rstd2):
+        _flat(t_, "operand")
+    assert tuple(dc3.shape) == (nb, 28, 8) and tuple(poses.shape) == (nb, 34, 27) and tuple(c1.shape) == (nb, 32, 16) and tuple(c2.shape) == (nb, 30, 8)
+    assert mean1.numel() == groups * 16 and mean2.numel() == groups * 8
+    dev = dc3.device
+    key = (dev.type, dev.index, nb)
+    if key not in _dpre_ws:
+        _dpre_ws[key] = torch.zeros(_lib.load().tg_d_preconv_ws_bytes(nb) // 4, dtype=torch.int32, device=dev)
+    ws = _dpre_ws[key]
+    gp = [_p(None)] * 10 if grads is None else [_p(_flat(g_, "grad")) for g_ in grads]
+    assert len(gp) == 10
+    call("tg_d_preconv_bwd", _p(dc3), _p(poses), _p(c1), _p(y1), _p(c2), _p(y2), _p(mean1), _p(rstd1), _p(mean2), _p(rstd2), _p(w1), _p(w2), _p(w3),
+         _p(g1), _p(g2), *gp, _p(dposes), int(bool(dposes_accumulate)), _p(ws), ws.numel() * 4, nb, int(groups), _stream())
+    return dposes
+
+
 def check_async_errors():
     """Raise if a bounded spin of a persistent kernel timed out since the last check (synchronises; tests, bench, loss read-out,
     every CHECK_EVERY replays of a captured step).  The timeout word is sticky on the device: only this function clears it."""

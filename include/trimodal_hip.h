@@ -315,6 +315,15 @@ int tg_d_preconv_fwd(const float* poses, const float* w1, const float* b1, const
                      float* running_var1, int64_t* nbt1, float* running_mean2, float* running_var2, int64_t* nbt2, void* ws,
                      int64_t ws_bytes, int32_t Bs, int32_t groups, float eps, float momentum, void* stream);
 
+/* The same block backwards in ONE launch: dc3 [nb][28][8] = gradient at the GRU input; the forward's tensors of the same nb clips (whole
+ * statistics groups; mean / rstd of exactly those groups); parameter gradients ACCUMULATE (float atomics) -- the ten pointers are all given
+ * or all NULL; dposes (NULL, or [nb][34][27]) receives the pose gradient, added to its content when dposes_accumulate.  Same workspace rule. */
+int tg_d_preconv_bwd(const float* dc3, const float* poses, const float* c1, const float* y1, const float* c2, const float* y2,
+                     const float* mean1, const float* rstd1, const float* mean2, const float* rstd2, const float* w1, const float* w2,
+                     const float* w3, const float* gamma1, const float* gamma2, float* dw1, float* db1, float* dgamma1, float* dbeta1,
+                     float* dw2, float* db2, float* dgamma2, float* dbeta2, float* dw3, float* db3, float* dposes,
+                     int32_t dposes_accumulate, void* ws, int64_t ws_bytes, int32_t nb, int32_t groups, void* stream);
+
 /* ---- speaker / style path (model/multimodal_context_net.py:83-95,125-137; embedding_net.py:10-13), fused ------------------------------
  * forward: se = table[vid], zc = W1 se + b1, mu = Wmu zc + bmu, logvar = Wlv zc + blv, z = mu + eps * exp(0.5 logvar) (all [B][16]); with
  * rep != NULL also rep[(b * T + t) * rep_ld + j] = z[b][j] (the style columns of the GRU input).  eps is read when rng_state == NULL and

@@ -339,6 +339,44 @@ def test_fused_discriminator_front_end_equals_separate_launches(pkg, dev, monkey
             assert got.shape == ref.shape and rel(got, ref.double().cpu()) < 1e-5, (k, rel(got, ref.double().cpu()))
 
 
+@pytest.mark.parametrize("Bs,groups,b0,nb,pg,dposes", [(256, 2, 0, 256, True, False), (128, 1, 0, 128, False, True), (12, 3, 4, 8, True, True)])
+def test_fused_discriminator_front_end_backward_equals_separate_launches(pkg, dev, monkeypatch, Bs, groups, b0, nb, pg, dposes):
+    """tg_d_preconv_bwd (the block of multimodal_context_net.py:214-220 backwards, one launch) against the generic chain (conv input / weight
+    gradients + two-launch BatchNorm backward): every parameter gradient of pre_conv, the pose gradient (plain and accumulated into a given
+    tensor), on all rows and on a sub-range of whole statistics groups; the whole discriminator backward runs around it (GRU, head)."""
+    dst = O.make_discriminator_state(4)
+    gen = torch.Generator().manual_seed(Bs + nb)
+    poses = (torch.randn(Bs, 34, 27, generator=gen) * 0.7).to(dev)
+    d_logit = torch.randn(nb, 1, generator=gen).to(dev)
+    base = torch.randn(nb, 34, 27, generator=gen).to(dev)
+    outs = {}
+    for fused in (False, True):
+        monkeypatch.setattr(pkg.ops, "D_PRECONV_FUSED", fused)
+        D = pkg.ConvDiscriminator(27)
+        D.load_state_dict(O.clone_state(dst, torch.float32), strict=True)
+        D = D.to(dev)
+        eng = D.engine
+        eng.rng.state[0] = 9
+        res = eng.forward(poses, training=True, groups=groups, save=True)
+        eng.slab.ensure().zero_grad()
+        into = base.clone()
+        got = eng.backward(res["tape"], d_logit, b0=b0, nb=nb, param_grads=pg, need_dposes=dposes, dposes_into=into if dposes else None)
+        plain = eng.backward(res["tape"], d_logit, b0=b0, nb=nb, param_grads=False, need_dposes=True) if dposes else None
+        outs[fused] = ({k: v.detach().clone() for k, v in eng.views()[1].items() if k.startswith("pre_conv")}, got, plain)
+    pkg.ops.check_async_errors()
+    ga, da, pa = outs[False]
+    gb, db, pb = outs[True]
+    for k, r in ga.items():
+        sc = float(r.abs().max())
+        if pg and k not in ZERO_GRAD_KEYS:
+            assert sc > 0 and float((gb[k] - r).abs().max()) <= 1e-5 * sc, (k, float((gb[k] - r).abs().max()) / sc)
+        if not pg:
+            assert float(gb[k].abs().max()) == 0 == sc, k
+    if dposes:
+        assert rel(db, da.double().cpu()) < 1e-5 and rel(pb, pa.double().cpu()) < 1e-5
+        assert float((db - base - pb).abs().max()) <= 1e-6 * float(base.abs().max())      # accumulated form = base + plain form (to fp32 rounding of base)
+
+
 def test_module_api_autograd_bridge(pkg, dev):
     """The reference's own loop style: module(...) calls + torch losses + loss.backward() + torch.optim.Adam."""
     V, S, B = 64, 9, 4
