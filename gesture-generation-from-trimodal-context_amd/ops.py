@@ -812,6 +812,15 @@ def sum_rows(src, dst, B, T, *, accumulate=False):
     call("tg_sum_rows", _p(src), src.stride(0), _p(dst), dst.stride(0), B, T, cols, int(accumulate), _stream()); return dst
 
 
+def narrow8_pair(a0, a1, w0, w1, out):
+    """out [M, 8] = a0 [M, K] @ w0 [K, 8] + a1 [M, K] @ w1 [K, 8] (tg_narrow8_pair)."""
+    for t_ in (a0, a1, w0, w1, out):
+        _flat(t_, "operand")
+    M, K = a0.shape
+    assert a1.shape == a0.shape and tuple(w0.shape) == (K, 8) == tuple(w1.shape) and tuple(out.shape) == (M, 8) and K % 4 == 0
+    call("tg_narrow8_pair", _p(a0), _p(a1), _p(w0), _p(w1), _p(out), M, K, _stream()); return out
+
+
 def add_halves(y, o):
     _flat(y, "y"); _flat(o, "o"); H = o.shape[-1]; M = o.numel() // H
     assert y.numel() == 2 * o.numel()

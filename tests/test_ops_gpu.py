@@ -772,6 +772,18 @@ def test_iter_head_equals_the_separate_launches(pkg, dev):
     assert vid_s is None and int(ra[1]) == 1 and torch.equal(pre_s, ops.make_pre_seq(target, torch.empty(B, T, D + 1, device=dev), 4))
 
 
+@pytest.mark.parametrize("M,K", [(7168, 192), (3584, 192), (37, 64)])
+def test_narrow8_pair_matches_fp64(pkg, dev, M, K):
+    """tg_narrow8_pair: dx = dgi_fwd W_ih_fwd + dgi_rev W_ih_rev for a GRU layer with 8 input channels (the discriminator's nn.GRU(8, 64),
+    multimodal_context_net.py:222-223 backward), W_ih as stored ([3H][8])."""
+    ops = pkg.ops
+    a0, a1 = rnd(M, K, seed=1).to(dev), rnd(M, K, seed=2).to(dev)
+    w0, w1 = rnd(K, 8, seed=3, scale=0.2).to(dev), rnd(K, 8, seed=4, scale=0.2).to(dev)
+    out = ops.narrow8_pair(a0, a1, w0, w1, torch.full((M, 8), float("nan"), device=dev))
+    ref = a0.double() @ w0.double() + a1.double() @ w1.double()
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
 def test_bf16_math_mode_tier(pkg, dev):
     """tg_set_math_mode(1): the big forward / input-gradient products take bf16 operands (one MFMA per product, fp32 accumulate).
     Op-level error at the bf16 level (and clearly different from the fp32 result: the mode really switches), and one full GAN
