@@ -94,6 +94,7 @@ SIGNATURES = {
     "tg_repeat_rows": [P, I64, P, I64, I32, I32, I32, P],
     "tg_sum_rows": [P, I64, P, I64, I32, I32, I32, I32, P],
     "tg_add_halves": [P, P, I32, I32, P],
+    "tg_sum_parts": [P, I64, I32, P, I64, P],
     "tg_narrow8_pair": [P, P, P, P, P, I32, I32, P],
     "tg_dup_halves": [P, P, I32, I32, P],
     "tg_make_pre_seq": [P, P, I32, I32, I32, I32, P],

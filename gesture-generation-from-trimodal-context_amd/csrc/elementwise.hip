@@ -773,6 +773,21 @@ int tg_narrow8_pair(const float* a0, const float* a1, const float* w0, const flo
     hipLaunchKernelGGL(narrow8_pair_kernel, dim3((M + 31) / 32), dim3(256), (size_t)2 * K * 8 * sizeof(float), ST, a0, a1, w0, w1, out, M, K);
     return check_launch("tg_narrow8_pair");
 }
+// out = p[0] + p[1] + .. + p[parts - 1], `parts` arrays of n floats `stride` floats apart (the K-split partial products of a many-slab input
+// gradient, combined in a fixed order)
+__global__ void sum_parts_kernel(const float* __restrict__ p, long stride, int parts, float* __restrict__ out, long n4) {
+    GRID_STRIDE(i, n4) {
+        f32x4 acc = reinterpret_cast<const f32x4*>(p)[i];
+        for (int q = 1; q < parts; ++q) acc += reinterpret_cast<const f32x4*>(p + q * stride)[i];
+        reinterpret_cast<f32x4*>(out)[i] = acc;
+    }
+}
+int tg_sum_parts(const float* parts, int64_t stride, int32_t n_parts, float* out, int64_t n, void* stream) {
+    TG_REQUIRE(parts && out && n_parts >= 1 && n > 0 && n % 4 == 0 && stride % 4 == 0 && stride >= n && aligned16(parts) && aligned16(out),
+               "tg_sum_parts: bad arguments (n, stride multiples of 4, 16-byte aligned)");
+    EW(sum_parts_kernel, n / 4, parts, (long)stride, n_parts, out, (long)n / 4);
+    return check_launch("tg_sum_parts");
+}
 int tg_add_halves(const float* y, float* o, int32_t M, int32_t H, void* stream) {
     TG_REQUIRE(y && o && M > 0 && H > 0, "tg_add_halves: bad arguments");
     EW(add_halves_kernel, (long)M * H, y, o, (long)M, H);

@@ -461,6 +461,7 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     return cur, tape
 
 
+KSPLIT_DX = int(__import__("os").environ.get("TG_KSPLIT_DX", "2"))      # K pieces per direction of the first GRU layer's input gradient (0: off)
 DROP_REGEN = __import__("os").environ.get("TG_TCN_DROP_REGEN", "1") != "0"      # dropout masks regenerated by their consumers (ops.Drop) at big batches
 
 
@@ -558,7 +559,22 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
             dx = empty(nb * T, Kin, like=dy)
             wt_ih = [transpose2d(P[f"{prefix}.weight_ih_l{l}{sfx}"]) for sfx in ("", "_reverse")]          # [Kin][3H] each
             seg = (wt_ih[1].data_ptr() - wt_ih[0].data_ptr()) // 4
-            if nb * T >= 1024 and Kin >= 48 and (wt_ih[1].data_ptr() - wt_ih[0].data_ptr()) % 16 == 0:
+            ksplit = KSPLIT_DX if (l == 0 and nb * T >= 1024 and 48 <= Kin and Kin % 4 == 0 and (3 * H) % 4 == 0 and H > 64) else 0
+            if ksplit:
+                # few output columns, long reduction (the first layer: N = in_size = 108, K = 6H = 1 800: 136 tiles of 57 slabs on 256 CUs):
+                # the K range of each direction cut in `ksplit` pieces, all pieces as problems of ONE launch into partial buffers, then a
+                # fixed-order sum -- 2 * ksplit times the workgroups, each with a 1 / ksplit as long dependent slab chain
+                parts = empty(2 * ksplit, nb * T, Kin, like=dy)
+                kp = (3 * H // ksplit + 3) // 4 * 4
+                probs = []
+                for d in range(2):
+                    a2, w2 = dgi[d].view(nb * T, 3 * H), wt_ih[d]
+                    for q in range(ksplit):
+                        k0, k1 = q * kp, min(3 * H, (q + 1) * kp)
+                        probs.append(dict(A=Win.plain(a2[:, k0:k1]), W=w2[:, k0:k1], bias=None, out=parts[d * ksplit + q]))
+                ops.gemm_nt_group(probs)
+                ops.sum_parts(parts, dx)
+            elif nb * T >= 1024 and Kin >= 48 and (wt_ih[1].data_ptr() - wt_ih[0].data_ptr()) % 16 == 0:
                 # dx = [dgi_fwd | dgi_rev] @ [W_ih_fwd ; W_ih_rev]: ONE product over the concatenated K = 6H -- the two directions are
                 # two "taps" of the A window (dgi is [2][nb*T][3H]) and two segments of the weight operand.  The inter-layer dropout's
                 # backward (the layer below's mask) rides in the epilogue instead of a separate multiply pass.

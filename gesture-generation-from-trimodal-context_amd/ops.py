@@ -812,6 +812,13 @@ def sum_rows(src, dst, B, T, *, accumulate=False):
     call("tg_sum_rows", _p(src), src.stride(0), _p(dst), dst.stride(0), B, T, cols, int(accumulate), _stream()); return dst
 
 
+def sum_parts(parts, out):
+    """out = parts[0] + parts[1] + ..: parts (n_parts, ...) contiguous, out of the shape of one part (tg_sum_parts)."""
+    _flat(parts, "parts"); _flat(out, "out")
+    assert parts.numel() == parts.shape[0] * out.numel()
+    call("tg_sum_parts", _p(parts), out.numel(), parts.shape[0], _p(out), out.numel(), _stream()); return out
+
+
 def narrow8_pair(a0, a1, w0, w1, out):
     """out [M, 8] = a0 [M, K] @ w0 [K, 8] + a1 [M, K] @ w1 [K, 8] (tg_narrow8_pair)."""
     for t_ in (a0, a1, w0, w1, out):

@@ -422,6 +422,8 @@ int tg_sum_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t 
                 int32_t accumulate, void* stream);
 /* o[m*H + j] = y[m*2H + j] + y[m*2H + H + j]  (multimodal_context_net.py:156,242). */
 int tg_add_halves(const float* y, float* o, int32_t M, int32_t H, void* stream);
+/* out[i] = sum_q parts[q * stride + i], i < n (n, stride multiples of 4; 16-byte aligned): K-split partial products combined in a fixed order. */
+int tg_sum_parts(const float* parts, int64_t stride, int32_t n_parts, float* out, int64_t n, void* stream);
 /* out [M][8] = a0 [M][K] . w0 [K][8] + a1 [M][K] . w1 [K][8] (K % 4 == 0, contiguous operands, 16-byte aligned a0 / a1): the input gradient of a
  * bidirectional GRU layer with 8 input channels, dx = dgi_fwd W_ih_fwd + dgi_rev W_ih_rev (the discriminator's nn.GRU(8, 64), :222-223). */
 int tg_narrow8_pair(const float* a0, const float* a1, const float* w0, const float* w1, float* out, int32_t M, int32_t K, void* stream);
