@@ -171,6 +171,7 @@ class GanTrainer:
     def phase_d_step(self, st, inject):
         D, B = self.D, st["B"]
         D.slab.ensure().zero_grad()
+        self._assert_no_pending_exchange()                    # the fused front-end kernels (csrc/d_preconv.hip) meet at device-wide barriers
         both = torch.cat([st["target"], st["out1"]])                   # D(real) first, then D(fake.detach())
         dres = D.forward(both, training=True, groups=2, save=True, inject=_stack_inject(inject, ["d_real", "d_fake"], "d"), tag="d")
         logit = dres["logit"].view(-1)
@@ -187,6 +188,7 @@ class GanTrainer:
         dev = st["target"].device
         G.slab.ensure().zero_grad()
         out2 = st["out2"].contiguous()
+        self._assert_no_pending_exchange()
         dres = D.forward(out2, training=True, groups=1, save=post, inject=inject, tag="d_out")   # runs in warm-up too (:55)
         d_out = torch.empty_like(out2)
         d_logit = torch.empty(B, device=dev)
