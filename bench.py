@@ -116,9 +116,23 @@ def build(pkg, device, seed=0):
     return args, G, Dn
 
 
+_REAL_STDOUT = None          # a duplicate of fd 1 while fd 1 itself points at stderr (data-parallel runs: see quiet_stdout)
+
+
+def quiet_stdout():
+    """From here until finish(): everything written to fd 1 -- RCCL prints a version banner on C stdout when its first communicator comes up --
+    goes to stderr, so that stdout carries the ONE JSON line and nothing else."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 def finish(line, dist_on):
-    """Tear the process group down, flush what native libraries buffered on C stdout (RCCL prints a version banner there), then
-    print the ONE JSON line (rank 0) as the last line of stdout."""
+    """Tear the process group down, flush what native libraries buffered on C stdout, give stdout back, then print the ONE JSON line
+    (rank 0) as the only line of stdout."""
+    global _REAL_STDOUT
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -128,6 +142,10 @@ def finish(line, dist_on):
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+    if _REAL_STDOUT is not None:
+        os.dup2(_REAL_STDOUT, 1)
+        os.close(_REAL_STDOUT)
+        _REAL_STDOUT = None
     if line is not None:
         print(line, flush=True)
 
@@ -454,6 +472,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        quiet_stdout()
         dist.init_process_group("nccl", device_id=device)
         ddp = importlib.import_module(PKG + ".ddp")
         grad_sync = ddp.GradSync()
@@ -474,8 +493,8 @@ def main():
         if grad_sync is not None:
             ddp_info = {"ranks": grad_sync.world, "collectives": "eager", "rejected": []}
     elif grad_sync is not None:
-        # captured collectives are tried first and must reproduce an eager iteration on every rank; otherwise all ranks fall back,
-        # in-process, to graph segments with eager collectives (train_gan.checked_ddp_step)
+        # graph segments with eager RCCL collectives between them (default; TG_DDP_CAPTURE=1 tries collectives captured inside the graph first):
+        # the chosen form must reproduce an eager iteration on every rank, otherwise all ranks fall back in-process (train_gan.checked_ddp_step)
         tg = importlib.import_module(PKG + ".train_gan")
         step, ddp_info = tg.checked_ddp_step(trainer, a.epoch, text, audio, poses, vid, warmup_iters=2,
                                              log=(lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else None)

@@ -231,10 +231,13 @@ class GraphedGanStep:
     def __init__(self, trainer: GanTrainer, epoch, in_text, in_audio, target, vid, warmup_iters=2, capture_collectives=None):
         """capture_collectives (data parallel only): True = the RCCL all-reduces are captured INTO the graph (one graph per iteration,
         no host work between segments); False = graph segments cut at the exchange points, collectives issued eagerly between them.
-        Default: environment TG_DDP_CAPTURE (1 unless set to 0)."""
+        Default: environment TG_DDP_CAPTURE (0 unless set to 1).  Segments are the default since round 3: with collectives recorded inside a
+        capture, RCCL's watchdog thread was seen to abort the process ("operation not permitted on an event last recorded in a capturing
+        stream" from WorkNCCL::isCompleted -- an event of torch's cache that a captured collective had recorded, queried later through an
+        eager one); it cannot be caught in Python, and costs more than the 1.3 % the single graph saves."""
         import os
         if capture_collectives is None:
-            capture_collectives = os.environ.get("TG_DDP_CAPTURE", "1") != "0"
+            capture_collectives = os.environ.get("TG_DDP_CAPTURE", "0") != "0"
         self.capture_collectives = bool(capture_collectives) and trainer.grad_sync is not None
         self.trainer, self.epoch = trainer, epoch
         # the step's inputs live in ONE buffer (views): a feeder moves a whole batch in with a single copy (data.DeviceBatchFeeder)
@@ -321,7 +324,7 @@ def checked_ddp_step(trainer: GanTrainer, epoch, in_text, in_audio, target, vid,
     dev = target.device
     say = log or (lambda *_: None)
     if modes is None:
-        modes = ["captured", "segments"] if os.environ.get("TG_DDP_CAPTURE", "1") != "0" else ["segments"]
+        modes = ["captured", "segments"] if os.environ.get("TG_DDP_CAPTURE", "0") != "0" else ["segments"]      # (see GraphedGanStep)
     snap = trainer.snapshot()
     ref = trainer.train_iter(epoch, in_text, in_audio, target, vid).to_dict()
     trainer.restore(snap)
