@@ -137,15 +137,29 @@ def run_train_parity(pkg, dev, batch=4, epochs=(0, 11), n_words=512, n_speakers=
 def wav_gate_flips(tape, preacts, near=2e-6):
     """LeakyReLU gates of the audio encoder: HIP path against the fp64 oracle.  tape: GanTrainer.last_tape of the iteration; preacts:
     oracle.wav_preacts on the same weights and audio.  Returns per layer (elements, near-ties |pre| < near (normalised pre-activations are O(1)),
-    elements where the HIP path's post-activation has the other sign)."""
+    elements where the HIP path's post-activation has the other sign, those of them whose fp64 pre-activation is NOT a near-tie)."""
     out = []
     for li, pre in enumerate(preacts, start=1):
         x = tape["wav"][li][0]                                   # (Ba, L, C) channel-last post-activation = the input of conv li + 1
         mine = x[:pre.shape[0]].detach().double().cpu().transpose(1, 2)
         assert mine.shape == pre.shape, (mine.shape, pre.shape)
-        flips = int(((mine > 0) != (pre > 0)).sum())
-        out.append((pre.numel(), int((pre.abs() < near).sum()), flips))
+        flipped = (mine > 0) != (pre > 0)
+        out.append((pre.numel(), int((pre.abs() < near).sum()), int(flipped.sum()), int((flipped & (pre.abs() >= near)).sum())))
     return out
+
+
+MAX_GATE_FLIPS = 8
+
+
+def assert_gate_flips_are_near_ties(flips, what=""):
+    """The allowance for flipped LeakyReLU gates is for fp64 near-ties only, and only a handful of them:
+    `flips` = wav_gate_flips results (one list per iteration or a single list).  Returns the total number of flipped gates."""
+    per_layer = [f for fl in flips for f in (fl if isinstance(fl[0], tuple) else [fl])]
+    total = sum(f[2] for f in per_layer)
+    real = sum(f[3] for f in per_layer)
+    assert real == 0, f"{what}: {real} audio-encoder gates differ from the fp64 oracle's where the pre-activation is not within 2e-6 of zero: {per_layer}"
+    assert total <= MAX_GATE_FLIPS, f"{what}: {total} flipped near-tie gates (cap {MAX_GATE_FLIPS}): {per_layer}"
+    return total
 
 
 class _NoDrop(O.Rand):

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
-from harness import O, ZERO_GRAD_KEYS, build_models, grad_errors, make_args, rel, run_train_parity, sample_idx, to_device_inject, wav_gate_flips
+from harness import O, ZERO_GRAD_KEYS, assert_gate_flips_are_near_ties, build_models, grad_errors, make_args, rel, run_train_parity, sample_idx, to_device_inject, wav_gate_flips
 
 pytestmark = pytest.mark.gpu
 
@@ -174,6 +174,7 @@ def test_full_size_step_matches_reference_golden_b128(pkg, dev):
     fl = wav_gate_flips(tr.last_tape, pre)
     print("audio-encoder LeakyReLU gates at B = 128 (layer 1, 2, 3): elements", [f[0] for f in fl], "near-ties |pre| < 2e-6", [f[1] for f in fl],
           "gates that differ from the fp64 oracle's", [f[2] for f in fl])
+    assert_gate_flips_are_near_ties(fl, "B = 128 golden step")       # the 5e-3 allowance below is for a handful of fp64 near-ties only
     _, Gg, _ = tr.G.views()
     bad = []
     for k, gr in Gg.items():
@@ -189,6 +190,7 @@ def test_full_size_step_matches_reference_golden_b128(pkg, dev):
         # moves the heavily cancelling sums behind these gradients by up to ~3e-3 of their max (measured on CPU: feeding
         # ATen's own BN1 output into an fp64 tail changes BN2.bias' gradient by 3.3e-3) while norms stay within 1e-5.
         # Element-wise 5e-3 for the tensors below a LeakyReLU of the audio encoder, 1e-4 everywhere else.
+        # (not conditional on n_flips: the golden is the reference's own fp32 run, whose gates can differ from the fp64 oracle's as well)
         tol_s, tol_n = (5e-3, 1e-3) if k.startswith("audio_encoder") else (1e-4, 1e-4)
         if e_n > tol_n or e_s > tol_s:
             bad.append((k, e_n, e_s))

@@ -7,7 +7,8 @@ import pytest
 import torch
 
 from oracle import ref_model as O
-from tests.harness import ZERO_GRAD_KEYS, build_models, grad_errors, make_args, rel, to_device_inject, wav_gate_flips
+from tests.harness import (ZERO_GRAD_KEYS, assert_gate_flips_are_near_ties, build_models, grad_errors, make_args, rel, sample_idx,
+                           to_device_inject, wav_gate_flips)
 
 pytestmark = pytest.mark.gpu
 
@@ -66,7 +67,8 @@ def test_five_consecutive_iterations_match_fp64_oracle(pkg, dev):
         fl = flips_iter[it]
         print(f"  iteration {it} (epoch {EPOCHS[it]}): worst G gradient error {ge:.1e} ({gk}), D {de:.1e} ({dk}); audio-encoder LeakyReLU gates "
               f"that differ from the fp64 oracle's (layer 1, 2, 3): {[f[2] for f in fl]} of {[f[0] for f in fl]}, near-ties {[f[1] for f in fl]}")
-    total_flips = sum(f[2] for fl in flips_iter for f in fl)
+    # the wide tolerances below are unlocked by flipped gates ONLY when those are a handful of fp64 near-ties (|pre| < 2e-6): anything else is a bug
+    total_flips = assert_gate_flips_are_near_ties(flips_iter, "five-iteration trajectory")
     assert worst_loss <= 1e-4, per_iter
 
     # ---- optimiser state after the last iteration: step counters, first and second moments
@@ -173,3 +175,153 @@ def test_graph_replayed_five_times_equals_five_eager_iterations(pkg, dev, monkey
             assert int(sd[k]) == int(r), k
         elif "running_var" in k:
             assert rel(sd[k], r) <= 1e-5, k
+
+
+class _LaunchLog:
+    """Records which C entry points an iteration calls and, for the grouped GEMM launches, the kernel plan the library picks for them
+    (tg_gemm_nt_kernel_plan / tg_gemm_tn_kernel_plan: 2 = the mover-wave kernels)."""
+
+    def __init__(self, pkg):
+        self.ops, self.lib = pkg.ops, pkg._lib.load()
+        self.names, self.nt, self.tn = [], [], []
+
+    def __enter__(self):
+        import ctypes as C
+        self._orig = self.ops.call
+
+        def call(name, *args):
+            self.names.append(name)
+            if name == "tg_gemm_nt_group":
+                arr, n = args[0], int(args[1])
+                q0 = arr if n == 1 and not hasattr(arr, "__len__") else arr
+                tm, tn = C.c_int32(0), C.c_int32(0)
+                plan = int(self.lib.tg_gemm_nt_kernel_plan(q0, n, C.byref(tm), C.byref(tn)))
+                first = arr._obj if hasattr(arr, "_obj") else arr[0]
+                self.nt.append((plan, int(first.M), int(first.N), int(first.A.K), n))
+            elif name == "tg_gemm_tn_group":
+                arr, n = args[0], int(args[1])
+                plan = int(self.lib.tg_gemm_tn_kernel_plan(arr, n))
+                first = arr._obj if hasattr(arr, "_obj") else arr[0]
+                self.tn.append((plan, int(first.M), int(first.N), n))
+            return self._orig(name, *args)
+        self.ops.call = call
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.call = self._orig
+        return False
+
+
+def test_full_size_trajectory_b128_dropout_on_matches_fp64_oracle(pkg, dev):
+    """The configuration bench.py times (B = 128 clips per iteration, every dropout ON) stepped THREE consecutive iterations -- epochs 10, 11,
+    11: one warm-up-phase iteration, then two full GAN iterations (train_eval/train_gan.py:13-103) -- against the fp64 oracle stepping the
+    same state, with every random draw (dropout masks, eps, the speaker permutation) recorded by oracle.Rand and injected.  Compared per
+    iteration: losses, every gradient's norm and 64 sampled entries; after the last one: Adam's step counters and moments (sampled),
+    BatchNorm buffers and counters.  The launch log proves that this ran on the kernel set of the headline number: the mover-wave NT / TN
+    GEMMs at the stacked forward's 13 056 rows and the cluster-synchronised recurrences at B = 384 / 128 (injected masks ride in the same
+    epilogues as regenerated ones: test_full_size_iteration_regenerated_dropout_equals_stored_masks ties the two bit for bit)."""
+    V, S, B = 2000, 17, 128
+    epochs = (10, 11, 11)
+    gst0, dst0 = O.make_generator_state(3, V, S), O.make_discriminator_state(4)
+    og, od = O.clone_state(gst0, torch.float64), O.clone_state(dst0, torch.float64)
+    ga, da = {}, {}
+    args, G, D = build_models(pkg, dev, gst0, dst0, V, S, make_args())
+    tr = pkg.GanTrainer(G, D, args)
+    tr.keep_tape = True
+    assert pkg.ops.get_math_mode() == "f32"
+    flips_iter, report = [], []
+    real_g, real_d = {}, {}
+    log = _LaunchLog(pkg)
+    for it, epoch in enumerate(epochs):
+        text, audio, vid, poses = O.make_batch(700 + it, B, V, S)
+        rand = O.Rand(seed=3017 + it)
+        pre = O.wav_preacts(og, audio.double())
+        oret, extra = O.train_iter_gan(og, od, ga, da, epoch, text, audio.double(), poses.double(), vid, rand, dict(O.HP), want_grads=True)
+        inj = to_device_inject(rand.rec, dev)
+        with log:
+            ret = tr.train_iter(epoch, text.to(dev), audio.to(dev), poses.to(dev), vid.to(dev), inject=inj).to_dict()
+        del inj
+        assert sorted(ret) == sorted(oret), (it, ret, oret)
+        fl = wav_gate_flips(tr.last_tape, pre)
+        flips_iter.append(fl)
+        n_fl = sum(f[2] for f in fl)
+        e_loss = max(abs(ret[k] - oret[k]) / max(abs(oret[k]), 1e-6) for k in oret)
+        assert e_loss <= 1e-4, (it, ret, oret)
+        rows = []
+        for net, eng, grads in (("G.", tr.G, extra["g_grads"]), ("D.", tr.D, extra.get("d_grads") if epoch > 10 else None)):
+            if grads is None:
+                continue
+            _, Gv, _ = eng.views()
+            for k, r in grads.items():
+                if r is None or k in ZERO_GRAD_KEYS:
+                    continue
+                mine = Gv[k].detach().double().cpu()
+                e_n = abs(float(mine.norm()) - float(r.norm())) / (float(r.norm()) + 1e-30)
+                idx = torch.from_numpy(sample_idx(r.numel(), 64))
+                e_s = float((mine.reshape(-1)[idx] - r.reshape(-1)[idx]).abs().max() / r.abs().max().clamp_min(1e-30))
+                rows.append((net + k, e_n, e_s))
+        # a flipped near-tie gate of the audio encoder moves the cancelling sums below it by up to ~3e-3 of their max and the audio features
+        # every downstream tensor reads by a few 1e-5 (DESIGN.md section 7 (ii)); with no flip so far everything is held to 1e-4
+        flipped_so_far = sum(f[2] for fl_ in flips_iter for f in fl_) > 0
+        bad = [(k, e_n, e_s) for k, e_n, e_s in rows
+               if e_n > ((1e-3 if "audio_encoder" in k else 2e-4) if flipped_so_far else 1e-4) or
+               e_s > ((5e-3 if "audio_encoder" in k else 5e-4) if flipped_so_far else 1e-4)]
+        wk = max(rows, key=lambda r: max(r[1], r[2]))
+        report.append(f"iteration {it} (epoch {epoch}): loss error {e_loss:.1e}; worst gradient {wk[0]} norm {wk[1]:.1e} sampled {wk[2]:.1e}; "
+                      f"gate flips (layer 1, 2, 3) {[f[2] for f in fl]} of {[f[0] for f in fl]}, near-ties {[f[1] for f in fl]}")
+        print(report[-1])
+        assert not bad, (it, n_fl, bad)
+        for store, grads in ((real_g, extra["g_grads"]), (real_d, extra.get("d_grads", {}))):
+            for k, g in grads.items():
+                if g is None or k in ZERO_GRAD_KEYS:
+                    continue
+                r = g.abs() > 1e-4 * g.abs().max()
+                store[k] = r if k not in store else (store[k] & r)
+    total_flips = assert_gate_flips_are_near_ties(flips_iter, "full-size trajectory")
+
+    # ---- the kernel set of the headline number ran: mover-wave NT products on the stacked forward's 3 * 128 * 34 rows, mover-wave weight
+    # gradients, the cluster-synchronised recurrences (forward at B = 384 = kernel <MT = 2, NS = 3>, backward at B = 128)
+    big_nt = [p for p in log.nt if p[1] == 3 * B * 34 and p[0] == 2]
+    assert len(big_nt) >= 3 * (4 + 8), log.nt                        # per iteration: 4 GRU projection groups + 8 text-encoder convs
+    assert sum(1 for p in log.tn if p[0] == 2) >= 3 * 4, log.tn      # per iteration: the four GRU layers' weight-gradient groups (+ text encoder)
+    assert log.names.count("tg_gru_forward_cluster_rows") == 3 * 4 and log.names.count("tg_gru_backward_cluster") == 3 * 4
+    assert "tg_gru_forward" not in log.names and "tg_gru_backward" not in log.names
+    assert pkg._lib.load().tg_gru_cluster_supported(3 * B, 300) and pkg._lib.load().tg_gru_cluster_bwd_supported(B, 300)
+    pkg.ops.check_async_errors()
+
+    # ---- optimiser state after the last iteration
+    gs, ds = tr.G.slab.ensure(), tr.D.slab.ensure()
+    assert int(gs.step.item()) == ga["step"] == len(epochs)
+    assert int(ds.step.item()) == da["step"] == sum(e > 10 for e in epochs)
+    wk, bad = {}, []
+    for net, slab_obj, ostate, real in (("G.", gs, ga, real_g), ("D.", ds, da, real_d)):
+        mv = _views(slab_obj)
+        for k, r in real.items():
+            if "m." + k not in ostate or not bool(r.any()):
+                continue
+            m, v = mv[k]
+            om, ov = ostate["m." + k], ostate["v." + k]
+            em = float((m.double().cpu() - om)[r].abs().max() / om.abs().max().clamp_min(1e-30))
+            ev = float((v.double().cpu() - ov)[r].abs().max() / ov.abs().max().clamp_min(1e-30))
+            wk[net + k] = (em, ev)
+            tol = (5e-3 if k.startswith("audio_encoder") else 5e-4) if total_flips > 0 else 1e-4
+            if em > tol or ev > 2 * tol:
+                bad.append((net + k, em, ev, tol))
+    print(f"optimiser state after iteration {len(epochs) - 1} (normalised max error, exp_avg / exp_avg_sq); {total_flips} flipped near-tie gates in all:")
+    for k, e in sorted(wk.items(), key=lambda kv: -kv[1][0])[:6]:
+        print(f"  {k}: {e[0]:.1e} / {e[1]:.1e}")
+    assert not bad, bad
+
+    # ---- BatchNorm buffers and counters (SURVEY Q2)
+    gsd, dsd = G.state_dict(), D.state_dict()
+    for sd, o in ((gsd, og), (dsd, od)):
+        for k in o:
+            if k.endswith("num_batches_tracked"):
+                assert int(sd[k]) == int(o[k]), (k, int(sd[k]), int(o[k]))
+            elif "running_var" in k:
+                assert rel(sd[k], o[k]) <= 1e-4, (k, rel(sd[k], o[k]))
+            elif "running_mean" in k:
+                assert float((sd[k].double().cpu() - o[k]).abs().max()) <= 3e-3, k
+    n_warm, n_post = sum(e <= 10 for e in epochs), sum(e > 10 for e in epochs)
+    assert int(gsd["audio_encoder.feat_extractor.1.num_batches_tracked"]) == 2 * n_warm + 3 * n_post
+    assert int(dsd["pre_conv.1.num_batches_tracked"]) == 1 * n_warm + 3 * n_post
