@@ -459,6 +459,9 @@ def main():
     if world != a.gpus:
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} in the environment (unset it to let bench.py start its own ranks, "
                  f"or launch with torch.distributed.run --nproc-per-node {a.gpus})")
+    if world > 1 or a.force_ddp:
+        # before the first HIP call: hardware queues for RCCL's stream beside the compute stream (ddp.configure_environment explains)
+        importlib.import_module(PKG + ".ddp").configure_environment()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -469,6 +472,7 @@ def main():
     grad_sync = None
     if world > 1 or a.force_ddp:
         import torch.distributed as dist
+        assert int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8, "ddp.configure_environment() must run before the first HIP call"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")

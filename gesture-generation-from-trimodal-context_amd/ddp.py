@@ -8,13 +8,30 @@ contiguous range of the flat gradient slab, all-reduced asynchronously on RCCL's
 keeps the compute stream busy; the optimiser step waits on the outstanding work.  xGMI is point-to-point (7 links per
 GPU): few large messages keep every link busy without per-tensor launch overhead.
 """
+import os
+import warnings
+
 import torch
 import torch.distributed as dist
+
+HW_QUEUES = 8
+
+
+def configure_environment():
+    """Call BEFORE the first HIP call of the process (bench.py does; a training script should too).  ROCm maps HIP streams onto
+    GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin; with the handful of streams a process creates (capture, warm-up, RCCL's)
+    the collective's stream regularly lands on the compute stream's queue, and a gradient bucket's RCCL kernel then runs IN LINE with the
+    graph segment behind it instead of beside it.  Measured on one rank (tools/ddp_overlap_probe.sh, profiles/r4_l_ddp_overlap.txt): with 4
+    queues every segment started ~10 us after the bucket's kernel had finished; with 8 it starts 35-40 us before."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(HW_QUEUES))
 
 
 class GradSync:
     def __init__(self, group=None, chunk_floats=8 * 1024 * 1024):
         assert dist.is_initialized(), "init_process_group first"
+        if dist.get_backend(group) == "nccl" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < HW_QUEUES:
+            warnings.warn("GPU_MAX_HW_QUEUES < 8: RCCL's stream may share a hardware queue with the compute stream, which serialises every "
+                          "gradient bucket with the backward it is meant to overlap (call ddp.configure_environment() before the first HIP call)")
         self.group = group
         self.world = dist.get_world_size(group)
         self.chunk = int(chunk_floats)
@@ -41,7 +58,16 @@ class GradSync:
 
     @staticmethod
     def bucket_range(slab, prefixes):
-        """Contiguous [start, end) of the slab covered by the parameters under the given top-level names."""
+        """Contiguous [start, end) of the slab covered by the parameters under the given top-level names (cached on the slab: the replay
+        loop of a segmented step asks for it between two graph launches; a slab's layout is fixed at construction)."""
+        cache = slab.__dict__.setdefault("_bucket_ranges", {})
+        key = tuple(prefixes)
+        if key not in cache:
+            cache[key] = GradSync._bucket_range(slab, prefixes)
+        return cache[key]
+
+    @staticmethod
+    def _bucket_range(slab, prefixes):
         lo, hi = None, None
         live = [(n, p, o) for n, p, o in zip(slab.names, slab.params, slab.offsets) if n not in slab.frozen]   # frozen: no gradient
         for name, p, off in live:
@@ -62,6 +88,10 @@ class GradSync:
         elif kind == "bucket":                 # one backward-order bucket, left in flight
             lo, hi = self.bucket_range(action[1], action[2])
             self._launch(action[1].grad[lo:hi])
+        elif kind == "bucket_wait":            # the LAST bucket of a backward: launched and awaited in one action (one graph cut instead of two)
+            lo, hi = self.bucket_range(action[1], action[2])
+            self._launch(action[1].grad[lo:hi])
+            self.wait()
         elif kind == "wait":
             self.wait()
         else:

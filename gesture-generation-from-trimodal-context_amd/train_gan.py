@@ -210,12 +210,20 @@ class GanTrainer:
         if post:
             D.backward(dres["tape"], d_logit.view(B, 1), param_grads=False, need_dposes=True, dposes_into=d_out)      # d_out += dD/dposes (:86-88)
         self._assert_no_pending_exchange()                    # the generator's backward recurrences come next
-        on_ready = (lambda prefixes: self._sync("bucket", G.slab, prefixes)) if self.grad_sync is not None else None
-        G.backward(st["res"]["tape"], d_out, d_mu, d_lv, b0=st["i2"] * B, nb=B, on_ready=on_ready)
+        # the audio encoder's bucket is the backward's last (engine.GeneratorEngine.backward): launched and awaited in ONE action, so that a
+        # segmented graph is cut once there, not twice around an empty segment
+        self._waited = False
+        def on_ready(prefixes):
+            last = tuple(prefixes) == ("audio_encoder",)
+            self._sync("bucket_wait" if last else "bucket", G.slab, prefixes)
+            self._waited = last
+        G.backward(st["res"]["tape"], d_out, d_mu, d_lv, b0=st["i2"] * B, nb=B, on_ready=on_ready if self.grad_sync is not None else None)
 
     # ---- phase 4: generator update (train_gan.py:92)
     def phase_g_update(self):
-        self._sync("wait")
+        if not getattr(self, "_waited", False):
+            self._sync("wait")
+        self._waited = False
         self.g_opt.step(counter_advanced=True)
 
 

@@ -162,15 +162,30 @@ def gru_stack(x, st, prefix, n_layers, p_drop, training, rand: Rand, tag, fast=F
 
 
 # --------------------------------------------------------------------------- generator
+# Test aid (tests/test_trajectory_gpu.py): {layer 1 | 2 | 3: (flat indices into the (B, C, L) pre-activation, bool sides)} -- LeakyReLU gates
+# of the audio encoder that take the GIVEN side instead of sign(pre-activation).  The tests pass the side the HIP path took for the handful
+# of elements whose fp64 pre-activation is within rounding of zero (both sides are correct evaluations of the reference there); None = off.
+wav_gate_override = None
+
+
+def _leaky_gated(x, slope, layer):
+    ov = None if wav_gate_override is None else wav_gate_override.get(layer)
+    if ov is None or ov[0].numel() == 0:
+        return leaky(x, slope)
+    gate = (x >= 0).reshape(-1).clone()
+    gate[ov[0]] = ov[1]
+    return torch.where(gate.view(x.shape), x, x * slope)
+
+
 def wav_encoder(st, audio, training, prefix="audio_encoder.feat_extractor"):
     """WavEncoder (multimodal_context_net.py:9-28): (B,A) -> (B,34,32)."""
     x = audio.unsqueeze(1)
     x = F.conv1d(x, st[f"{prefix}.0.weight"], st[f"{prefix}.0.bias"], stride=5, padding=1600)
-    x = leaky(batch_norm(x, st, f"{prefix}.1", training), 0.3)
+    x = _leaky_gated(batch_norm(x, st, f"{prefix}.1", training), 0.3, 1)
     x = F.conv1d(x, st[f"{prefix}.3.weight"], st[f"{prefix}.3.bias"], stride=6)
-    x = leaky(batch_norm(x, st, f"{prefix}.4", training), 0.3)
+    x = _leaky_gated(batch_norm(x, st, f"{prefix}.4", training), 0.3, 2)
     x = F.conv1d(x, st[f"{prefix}.6.weight"], st[f"{prefix}.6.bias"], stride=6)
-    x = leaky(batch_norm(x, st, f"{prefix}.7", training), 0.3)
+    x = _leaky_gated(batch_norm(x, st, f"{prefix}.7", training), 0.3, 3)
     x = F.conv1d(x, st[f"{prefix}.9.weight"], st[f"{prefix}.9.bias"], stride=6)
     return x.transpose(1, 2)
 

@@ -137,28 +137,52 @@ def run_train_parity(pkg, dev, batch=4, epochs=(0, 11), n_words=512, n_speakers=
 def wav_gate_flips(tape, preacts, near=2e-6):
     """LeakyReLU gates of the audio encoder: HIP path against the fp64 oracle.  tape: GanTrainer.last_tape of the iteration; preacts:
     oracle.wav_preacts on the same weights and audio.  Returns per layer (elements, near-ties |pre| < near (normalised pre-activations are O(1)),
-    elements where the HIP path's post-activation has the other sign, those of them whose fp64 pre-activation is NOT a near-tie)."""
+    elements where the HIP path's post-activation has the other sign, the largest fp64 |pre| among those)."""
     out = []
     for li, pre in enumerate(preacts, start=1):
         x = tape["wav"][li][0]                                   # (Ba, L, C) channel-last post-activation = the input of conv li + 1
         mine = x[:pre.shape[0]].detach().double().cpu().transpose(1, 2)
         assert mine.shape == pre.shape, (mine.shape, pre.shape)
         flipped = (mine > 0) != (pre > 0)
-        out.append((pre.numel(), int((pre.abs() < near).sum()), int(flipped.sum()), int((flipped & (pre.abs() >= near)).sum())))
+        out.append((pre.numel(), int((pre.abs() < near).sum()), int(flipped.sum()), float(pre.abs()[flipped].max()) if bool(flipped.any()) else 0.0))
+    return out
+
+
+def wav_gate_sides(tape, preacts):
+    """{layer: (flat indices into the oracle's (B, C, L) pre-activation, the side the HIP path took)} for the gates that differ from the fp64
+    oracle's -- the form oracle.ref_model.wav_gate_override takes."""
+    out = {}
+    for li, pre in enumerate(preacts, start=1):
+        x = tape["wav"][li][0]
+        mine = x[:pre.shape[0]].detach().double().cpu().transpose(1, 2)
+        flipped = ((mine > 0) != (pre > 0)).reshape(-1)
+        idx = flipped.nonzero().view(-1)
+        out[li] = (idx, (mine.reshape(-1)[idx] > 0))
     return out
 
 
 MAX_GATE_FLIPS = 8
+NEAR_TIE_FRESH, NEAR_TIE_AFTER_FLIP = 2e-6, 5e-4
 
 
 def assert_gate_flips_are_near_ties(flips, what=""):
-    """The allowance for flipped LeakyReLU gates is for fp64 near-ties only, and only a handful of them:
-    `flips` = wav_gate_flips results (one list per iteration or a single list).  Returns the total number of flipped gates."""
-    per_layer = [f for fl in flips for f in (fl if isinstance(fl[0], tuple) else [fl])]
-    total = sum(f[2] for f in per_layer)
-    real = sum(f[3] for f in per_layer)
-    assert real == 0, f"{what}: {real} audio-encoder gates differ from the fp64 oracle's where the pre-activation is not within 2e-6 of zero: {per_layer}"
-    assert total <= MAX_GATE_FLIPS, f"{what}: {total} flipped near-tie gates (cap {MAX_GATE_FLIPS}): {per_layer}"
+    """The allowance for flipped LeakyReLU gates is for a handful of fp64 NEAR-TIES, nothing else.  `flips`:
+    wav_gate_flips results, one list per iteration in order (or a single iteration's list).  While both sides still step identical
+    weights a gate may differ only where the fp64 pre-activation is within 2e-6 of zero (fp32 rounding of an O(1) value).  Once a gate
+    has flipped, the audio encoder's gradients of that iteration differ by up to ~7e-3 of their max, Adam carries that into the weights
+    (lr * 7e-3 per entry) and the NEXT iterations' pre-activations differ by ~1e-4: from then on the window is 5e-4.  At most 8 flips in
+    all.  Returns the total number of flipped gates."""
+    iters = flips if isinstance(flips[0], list) else [flips]
+    total, window = 0, NEAR_TIE_FRESH
+    for it, fl in enumerate(iters):
+        for li, f in enumerate(fl, start=1):
+            assert f[2] == 0 or f[3] < window, (f"{what}: iteration {it}, audio-encoder layer {li}: {f[2]} gates differ from the fp64 oracle's, the "
+                                                f"largest at |pre-activation| = {f[3]:.2e} -- not a near-tie (window {window:.0e}): {iters}")
+        n = sum(f[2] for f in fl)
+        total += n
+        if n:
+            window = NEAR_TIE_AFTER_FLIP
+    assert total <= MAX_GATE_FLIPS, f"{what}: {total} flipped near-tie gates (cap {MAX_GATE_FLIPS}): {iters}"
     return total
 
 

@@ -140,3 +140,122 @@ def test_frozen_word_embedding_leaves_optimiser_and_buckets(pkg):
         lo, hi = ddp.GradSync.bucket_range(slab, ("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder"))
         assert hi <= slab.n_train                                  # the 48 KB word table is not exchanged
         assert sorted(G.state_dict()) == sorted(pkg.PoseGenerator(make_args(), 27, 40, 300, emb, pkg.Vocab.speakers(5)).state_dict())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# GanTrainer.train_iter end to end on two gloo ranks, the HIP engines replaced by CPU stand-ins: what is under test is the trainer's
+# own exchange schedule (train_gan.py: 'all' on the discriminator slab between its backward and its Adam, the generator's buckets in
+# backward order as on_ready names them, 'wait' before the generator's Adam) running over a REAL process group.
+def _fake_trainer_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module(PKG)
+        ddp = importlib.import_module(PKG + ".ddp")
+        tg = importlib.import_module(PKG + ".train_gan")
+        from tests.harness import make_args
+        args = make_args()
+        G = _make_generator(pkg)
+        D = pkg.ConvDiscriminator(27)
+        order = []
+        B = 4
+        grad_of = lambda slab, seed: torch.randn(slab.numel, generator=torch.Generator().manual_seed(seed))
+        BUCKETS = (("out", "gru"), ("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder"), ("audio_encoder",))
+
+        class FakeG:                                   # the parts of engine.GeneratorEngine the trainer touches
+            z_mode, use_side_stream, in_size = "speaker", False, 108
+            def __init__(self, mod): self.slab = importlib.import_module(PKG + ".params").ParamSlab(mod); self.rng = type("R", (), {"state": None, "site": lambda s, n: 1})()
+            def forward(self, pre, text, audio, vid, **kw):
+                n = pre.shape[0]
+                return {"out": torch.zeros(n, 34, 27), "z": torch.zeros(n, 16), "mu": torch.zeros(n, 16), "logvar": torch.zeros(n, 16), "tape": {}}
+            def backward(self, tape, d_out, d_mu, d_lv, *, b0, nb, on_ready):
+                s = self.slab
+                full = grad_of(s, 1000 + rank)          # this rank's gradient; a bucket's entries become final right before on_ready names it
+                for bk in BUCKETS:
+                    lo, hi = ddp.GradSync.bucket_range(s, bk)
+                    s.grad[lo:hi] = full[lo:hi]
+                    order.append(("ready", bk))
+                    on_ready(bk)
+
+        class FakeD:
+            def __init__(self, mod): self.slab = importlib.import_module(PKG + ".params").ParamSlab(mod); self.rng = type("R", (), {"state": None})()
+            def forward(self, poses, **kw): return {"logit": torch.zeros(poses.shape[0], 1), "tape": {}}
+            def backward(self, tape, d_logit, **kw):
+                if kw.get("param_grads", True):
+                    self.slab.grad.copy_(grad_of(self.slab, 2000 + rank))
+                    order.append(("d_backward",))
+
+        class FakeOps:                                  # train_gan's direct kernel calls
+            @staticmethod
+            def iter_head(*a, **kw):
+                ng = a[6]
+                return torch.zeros(ng * B, 34, 28), torch.zeros(ng * B, 34, dtype=torch.long), torch.zeros(ng * B, dtype=torch.long)
+            @staticmethod
+            def gan_d_loss(*a): pass
+            @staticmethod
+            def gan_g_loss(*a): pass
+            @staticmethod
+            def zeros(*shape, device, dtype=torch.float32): return torch.zeros(*shape, dtype=dtype)
+            @staticmethod
+            def check_async_errors(): pass
+            @staticmethod
+            def zero_(t): return t.zero_()
+
+        class FakeAdam:
+            def __init__(self, eng, **kw): self.engine, self.seen = eng, None
+            @property
+            def slab(self): return self.engine.slab
+            def step(self, counter_advanced=False):
+                self.seen = self.engine.slab.grad.clone()            # what the optimiser would consume
+                order.append(("adam", "G" if isinstance(self.engine, FakeG) else "D"))
+
+        class FakePrep:
+            def add_slab(self, *a): pass
+            def refresh(self, *a): pass
+            def active(self):
+                import contextlib
+                return contextlib.nullcontext()
+
+        object.__setattr__(G, "_engine", FakeG(G))          # the modules build their engines lazily behind a property
+        object.__setattr__(D, "_engine", FakeD(D))
+        tg.ops, tg.FusedAdam = FakeOps, FakeAdam
+        importlib.import_module(PKG + ".params").ops = FakeOps          # ParamSlab.zero_grad
+        tg.L = type("FakeL", (), {"WeightPrep": FakePrep})
+        sync = ddp.GradSync(chunk_floats=1 << 18)
+        real_run = sync.run
+        sync.run = lambda action: (order.append(("sync", action[0], tuple(action[2]) if action[0].startswith("bucket") else None)), real_run(action))[1]
+        tr = tg.GanTrainer(G, D, args, grad_sync=sync)
+        tr.train_iter(11, torch.zeros(B, 34, dtype=torch.long), torch.zeros(B, 100), torch.zeros(B, 34, 27), torch.zeros(B, dtype=torch.long))
+        exp_g = sum(grad_of(G.engine.slab, 1000 + r) for r in range(world)) / world
+        exp_d = sum(grad_of(D.engine.slab, 2000 + r) for r in range(world)) / world
+        covered = torch.zeros(G.engine.slab.numel, dtype=torch.bool)
+        for bk in BUCKETS:
+            lo, hi = ddp.GradSync.bucket_range(G.engine.slab, bk)
+            covered[lo:hi] = True
+        err_g = float((tr.g_opt.seen - exp_g)[covered].abs().max())
+        err_d = float((tr.d_opt.seen - exp_d).abs().max())
+        out.put((rank, order, err_g, err_d, len(sync.pending)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_iter_exchange_schedule_over_gloo_world2():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fake_trainer_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    text_bucket = ("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder")
+    want = [("d_backward",), ("sync", "all", None), ("adam", "D"),
+            ("ready", ("out", "gru")), ("sync", "bucket", ("out", "gru")),
+            ("ready", text_bucket), ("sync", "bucket", text_bucket),
+            ("ready", ("audio_encoder",)), ("sync", "bucket_wait", ("audio_encoder",)), ("adam", "G")]
+    for rank, order, err_g, err_d, pending in res:
+        assert order == want, (rank, order)
+        assert err_g < 1e-6 and err_d < 1e-6 and pending == 0, (rank, err_g, err_d, pending)      # both optimisers consumed the MEAN gradient

@@ -718,6 +718,58 @@ def test_data_parallel_graph_segments_single_rank(pkg, dev, tmp_path):
             dist.destroy_process_group()
 
 
+def test_gradient_buckets_leave_in_backward_order_beside_the_backward(pkg, dev):
+    """Where the data-parallel trainer starts each gradient exchange (scripts/train.py:93-96 -> ddp.GradSync; SURVEY 8e: "as each bucket's
+    gradients are final"): a recording stand-in for GradSync notes, at every sync action, how many C entry points the iteration had called
+    so far.  {out, gru} must leave right behind the last backward recurrence of the generator -- BEFORE the text encoder's backward
+    (tg_act_mask_bwd2, the weight-norm backward, the embedding scatter) and the audio encoder's -- {text, speaker} behind the embedding
+    scatter, {audio} last, 'wait' before the generator's Adam; the discriminator's whole slab between its backward and its Adam.  No
+    bucket is in flight when a cluster-synchronised kernel starts (the trainer asserts it; here it is checked from the log)."""
+    V, S, B = 2000, 17, 128
+    gst, dst = O.make_generator_state(5, V, S), O.make_discriminator_state(6)
+    args, G, Dn = build_models(pkg, dev, gst, dst, V, S)
+    text, audio, vid, poses = (t.to(dev) for t in O.make_batch(21, B, V, S))
+    calls, marks = [], []
+
+    class Recorder:
+        world, pending = 1, []
+        def run(self, action):
+            marks.append((action[0], tuple(action[2]) if action[0].startswith("bucket") else None, len(calls)))
+
+    orig = pkg.ops.call
+    def call(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    tr = pkg.GanTrainer(G, Dn, args, grad_sync=Recorder())
+    pkg.ops.call = call
+    try:
+        tr.train_iter(11, text, audio, poses, vid).to_dict()
+    finally:
+        pkg.ops.call = orig
+    kinds = [(m[0], m[1]) for m in marks]
+    assert kinds == [("all", None), ("bucket", ("out", "gru")), ("bucket", ("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder")),
+                     ("bucket_wait", ("audio_encoder",))], kinds
+    at = {m[1] or m[0]: m[2] for m in marks}
+    last = lambda name: max(i for i, c in enumerate(calls) if c == name)
+    first_after = lambda name, i0: min(i for i, c in enumerate(calls) if c == name and i >= i0)
+    adam = [i for i, c in enumerate(calls) if c == "tg_adam_step"]
+    assert len(adam) == 2 and at["all"] <= adam[0] < at[("out", "gru")] and at[("audio_encoder",)] <= adam[1]
+    i_gru = at[("out", "gru")]
+    assert last("tg_gru_backward_cluster") < i_gru                                   # every cluster recurrence is behind the first bucket
+    assert all(c not in ("tg_gru_forward_cluster_rows", "tg_gru_backward_cluster", "tg_d_preconv_fwd", "tg_d_preconv_bwd") for c in calls[i_gru:])
+    # the text encoder's backward, the speaker path's and the audio encoder's all come AFTER {out, gru} has left
+    for name in ("tg_act_mask_bwd2", "tg_weight_norm_bwd_batch", "tg_embed_scatter_add", "tg_speaker_bwd", "tg_wav_conv2_wgrad"):
+        assert first_after(name, 0) > i_gru or name not in calls[:i_gru], name
+        assert name in calls[i_gru:], name
+    i_text = at[("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder")]
+    assert last("tg_embed_scatter_add") < i_text and last("tg_weight_norm_bwd_batch") < i_text and last("tg_speaker_bwd") < i_text
+    assert first_after("tg_wav_conv2_wgrad", 0) > i_text and last("tg_wav_conv2_wgrad") < at[("audio_encoder",)]
+    n_between = i_text - i_gru
+    print(f"{{out, gru}} leaves at launch {i_gru} of {len(calls)}; {n_between} launches of the text-encoder / speaker backward and "
+          f"{at[('audio_encoder',)] - i_text} of the audio encoder's run beside it")
+    assert n_between >= 20
+
+
 def test_reference_checkpoint_runs_on_gpu(pkg, dev):
     """The checkpoint written by the reference's own classes (tests/golden/g7_reference_checkpoint.bin: hidden_size 8, 1 layer,
     13 words, 5 speakers) loads through checkpoint.load_checkpoint_and_model and its eval forward matches the oracle run on the

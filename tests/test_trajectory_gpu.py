@@ -7,8 +7,8 @@ import pytest
 import torch
 
 from oracle import ref_model as O
-from tests.harness import (ZERO_GRAD_KEYS, assert_gate_flips_are_near_ties, build_models, grad_errors, make_args, rel, sample_idx,
-                           to_device_inject, wav_gate_flips)
+from tests.harness import (MAX_GATE_FLIPS, NEAR_TIE_FRESH, ZERO_GRAD_KEYS, assert_gate_flips_are_near_ties, build_models, grad_errors, make_args, rel, sample_idx,
+                           to_device_inject, wav_gate_flips, wav_gate_sides)
 
 pytestmark = pytest.mark.gpu
 
@@ -232,10 +232,12 @@ def test_full_size_trajectory_b128_dropout_on_matches_fp64_oracle(pkg, dev):
     flips_iter, report = [], []
     real_g, real_d = {}, {}
     log = _LaunchLog(pkg)
+    import copy
     for it, epoch in enumerate(epochs):
         text, audio, vid, poses = O.make_batch(700 + it, B, V, S)
         rand = O.Rand(seed=3017 + it)
         pre = O.wav_preacts(og, audio.double())
+        before = copy.deepcopy((og, od, ga, da))                     # the oracle's complete training state at the start of the iteration
         oret, extra = O.train_iter_gan(og, od, ga, da, epoch, text, audio.double(), poses.double(), vid, rand, dict(O.HP), want_grads=True)
         inj = to_device_inject(rand.rec, dev)
         with log:
@@ -245,6 +247,22 @@ def test_full_size_trajectory_b128_dropout_on_matches_fp64_oracle(pkg, dev):
         fl = wav_gate_flips(tr.last_tape, pre)
         flips_iter.append(fl)
         n_fl = sum(f[2] for f in fl)
+        if n_fl:
+            # At this size the audio encoder evaluates 23 M LeakyReLU gates per forward, ~30 of them on pre-activations within 2e-6 of zero, where
+            # the fp32 path may take the other side -- both sides are correct evaluations of the reference there, but the gradients below differ
+            # by up to ~3e-3 and the two weight trajectories would drift apart (more flips every iteration).  The oracle therefore REPEATS the
+            # iteration from the same state and the same draws with exactly those near-tie gates on the side the HIP path took
+            # (oracle.wav_gate_override; asserted near-ties right below), and that run is the reference and the state that is carried on.
+            assert max(f[3] for f in fl) < NEAR_TIE_FRESH and n_fl <= MAX_GATE_FLIPS, (it, fl)
+            for dst_, src_ in zip((og, od, ga, da), before):
+                dst_.clear(); dst_.update(src_)
+            O.wav_gate_override = wav_gate_sides(tr.last_tape, pre)
+            try:
+                oret, extra = O.train_iter_gan(og, od, ga, da, epoch, text, audio.double(), poses.double(), vid, O.Rand(seed=3017 + it), dict(O.HP),
+                                               want_grads=True)
+            finally:
+                O.wav_gate_override = None
+        del before
         e_loss = max(abs(ret[k] - oret[k]) / max(abs(oret[k]), 1e-6) for k in oret)
         assert e_loss <= 1e-4, (it, ret, oret)
         rows = []
@@ -260,12 +278,8 @@ def test_full_size_trajectory_b128_dropout_on_matches_fp64_oracle(pkg, dev):
                 idx = torch.from_numpy(sample_idx(r.numel(), 64))
                 e_s = float((mine.reshape(-1)[idx] - r.reshape(-1)[idx]).abs().max() / r.abs().max().clamp_min(1e-30))
                 rows.append((net + k, e_n, e_s))
-        # a flipped near-tie gate of the audio encoder moves the cancelling sums below it by up to ~3e-3 of their max and the audio features
-        # every downstream tensor reads by a few 1e-5; with no flip so far everything is held to 1e-4
-        flipped_so_far = sum(f[2] for fl_ in flips_iter for f in fl_) > 0
-        bad = [(k, e_n, e_s) for k, e_n, e_s in rows
-               if e_n > ((1e-3 if "audio_encoder" in k else 2e-4) if flipped_so_far else 1e-4) or
-               e_s > ((5e-3 if "audio_encoder" in k else 5e-4) if flipped_so_far else 1e-4)]
+        # (with the near-tie gates aligned, every tensor -- the audio encoder's included -- is held to 1e-4)
+        bad = [(k, e_n, e_s) for k, e_n, e_s in rows if e_n > 1e-4 or e_s > 1e-4]
         wk = max(rows, key=lambda r: max(r[1], r[2]))
         report.append(f"iteration {it} (epoch {epoch}): loss error {e_loss:.1e}; worst gradient {wk[0]} norm {wk[1]:.1e} sampled {wk[2]:.1e}; "
                       f"gate flips (layer 1, 2, 3) {[f[2] for f in fl]} of {[f[0] for f in fl]}, near-ties {[f[1] for f in fl]}")
@@ -277,12 +291,14 @@ def test_full_size_trajectory_b128_dropout_on_matches_fp64_oracle(pkg, dev):
                     continue
                 r = g.abs() > 1e-4 * g.abs().max()
                 store[k] = r if k not in store else (store[k] & r)
-    total_flips = assert_gate_flips_are_near_ties(flips_iter, "full-size trajectory")
+    total_flips = sum(f[2] for fl_ in flips_iter for f in fl_)
+    assert total_flips <= 3 * MAX_GATE_FLIPS, flips_iter
 
     # ---- the kernel set of the headline number ran: mover-wave NT products on the stacked forward's 3 * 128 * 34 rows, mover-wave weight
     # gradients, the cluster-synchronised recurrences (forward at B = 384 = kernel <MT = 2, NS = 3>, backward at B = 128)
+    n_post = sum(e > 10 for e in epochs)                             # the warm-up-phase iteration stacks two generator calls (8 704 rows), the others three
     big_nt = [p for p in log.nt if p[1] == 3 * B * 34 and p[0] == 2]
-    assert len(big_nt) >= 3 * (4 + 8), log.nt                        # per iteration: 4 GRU projection groups + 8 text-encoder convs
+    assert len(big_nt) == n_post * (4 + 8), log.nt                   # per post-warm-up iteration: 4 GRU projection groups + 8 text-encoder convs
     assert sum(1 for p in log.tn if p[0] == 2) >= 3 * 4, log.tn      # per iteration: the four GRU layers' weight-gradient groups (+ text encoder)
     assert log.names.count("tg_gru_forward_cluster_rows") == 3 * 4 and log.names.count("tg_gru_backward_cluster") == 3 * 4
     assert "tg_gru_forward" not in log.names and "tg_gru_backward" not in log.names
@@ -304,7 +320,7 @@ def test_full_size_trajectory_b128_dropout_on_matches_fp64_oracle(pkg, dev):
             em = float((m.double().cpu() - om)[r].abs().max() / om.abs().max().clamp_min(1e-30))
             ev = float((v.double().cpu() - ov)[r].abs().max() / ov.abs().max().clamp_min(1e-30))
             wk[net + k] = (em, ev)
-            tol = (5e-3 if k.startswith("audio_encoder") else 5e-4) if total_flips > 0 else 1e-4
+            tol = 1e-4
             if em > tol or ev > 2 * tol:
                 bad.append((net + k, em, ev, tol))
     print(f"optimiser state after iteration {len(epochs) - 1} (normalised max error, exp_avg / exp_avg_sq); {total_flips} flipped near-tie gates in all:")
