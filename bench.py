@@ -360,6 +360,7 @@ def decode_bench(pkg, a, args, G, device, world, rank):
             **extra,
             "metric": "inference pose-frames/sec (batched 34-frame synthesis windows)", "value": fps, "unit": "pose-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "latency_us_per_window": dt / a.steps * 1e6,          # --batch 1 = the reference's own call (synthesize.py:131: one utterance)
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthesize.py window loop (BASELINE.json configs[3]): PoseGenerator eval forward + seed hand-over + cross-fade",
                        "utterances_per_gpu": a.batch, "frames": T, "hipgraph": not a.no_graph, "parallelism": f"replicas x{world}"},
@@ -443,6 +444,9 @@ def main():
                     help="feed every iteration from host memory through data.DeviceBatchFeeder (PCIe-inclusive rate for DESIGN.md; "
                          "never the headline value)")
     ap.add_argument("--no-feed-overlap", action="store_true", help="--host-input: copy straight into the step's inputs on the compute stream")
+    ap.add_argument("--host-records", action="store_true",
+                    help="feed every iteration from RAW stored samples through data.DeviceRecordFeeder: host packs records, one H2D copy, the "
+                         "per-sample assembly of SpeechMotionDataset.__getitem__ + collate runs on the device (never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path (graph segments + RCCL) even with one rank")
     a = ap.parse_args()
@@ -519,6 +523,24 @@ def main():
             _k[0] += 1
             feeder.put(*pool[_k[0] % len(pool)])                    # next batch's host->device copy overlaps this iteration
             return plain_step()
+    if a.host_records:
+        assert not a.no_graph and not a.host_input, "--host-records drives the captured step"
+        data = importlib.import_module(PKG + ".data")
+        lang = pkg.Vocab("words")
+        for i in range(V - 4):
+            lang.index_word(f"w{i}")
+        spk = pkg.Vocab.speakers(S)
+        ds = data.SyntheticSpeechMotionDataset(4 * a.batch, lang, spk, seed=7 + rank)
+        raw_pool = [[ds.raw(i) for i in range(k * a.batch, (k + 1) * a.batch)] for k in range(4)]
+        rfeeder = data.DeviceRecordFeeder(*step.static, lang, spk)
+        rfeeder.put(raw_pool[0])
+        plain_step2 = step
+
+        def step(_k=[0]):
+            rfeeder.ready()
+            _k[0] += 1
+            rfeeder.put(raw_pool[_k[0] % len(raw_pool)])            # packing + H2D of the next batch overlap this iteration
+            return plain_step2()
     for _ in range(a.warmup):
         losses = step()
 
@@ -545,7 +567,7 @@ def main():
         step_peak = PEAK_BF16_MFMA if a.dtype == "bf16" else PEAK_F32_MFMA
         out = {
             "metric": "training clips/sec (34-frame, 27-dim pose), " + ("post-warm-up GAN iteration" if a.epoch > 10 else "warm-up-phase iteration (epoch <= loss_warmup)")
-                      + (" [host-fed, PCIe-inclusive]" if a.host_input else ""),
+                      + (" [host-fed, PCIe-inclusive]" if a.host_input else "") + (" [host-fed raw records, device-side batch assembly]" if a.host_records else ""),
             "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",

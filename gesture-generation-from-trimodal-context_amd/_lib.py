@@ -99,6 +99,7 @@ SIGNATURES = {
     "tg_dup_halves": [P, P, I32, I32, P],
     "tg_make_pre_seq": [P, P, I32, I32, I32, I32, P],
     "tg_embed_gather": [P, P, P, I32, I32, I32, P],
+    "tg_assemble_batch": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, P, P, P, P, P],
     "tg_embed_scatter_add": [P, P, P, I32, I32, I32, P],
     "tg_permute3": [P, P, I32, I32, I32, I32, I32, I32, P],
     "tg_conv_dgrad_pack": [P, P, I32, I32, I32, I32, P],
@@ -129,7 +130,7 @@ SIGNATURES = {
     "tg_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, P, P],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -8,6 +8,10 @@ with word_seq = [[word, start_s, end_s], ...] and aux_info = {'vid', 'start_time
 consumes; `DeviceBatchFeeder` replaces the `.to(device)` calls of the training loop with pinned staging buffers and asynchronous
 copies into static device tensors on a copy stream, double-buffered, so that the host-to-device transfer of batch i+1 overlaps
 iteration i of a hipGraph-replayed step (GraphedGanStep reads the same static tensors every replay).
+`DeviceRecordFeeder` goes one step further (round 4): the host only PACKS the stored samples' raw arrays (audio as stored, the first
+n_poses direction-vector frames, (word index, onset) pairs, times, speaker index) into one pinned buffer; the per-sample assembly of
+`__getitem__` -- extend_word_seq, make_audio_fixed_length, the slicing -- and the collate run on the device in one launch
+(ops.assemble_batch -> tg_assemble_batch, csrc/assemble.hip), writing the step's static inputs in place.
 """
 import numpy as np
 import torch
@@ -272,3 +276,107 @@ class DeviceBatchFeeder:
             ev = torch.cuda.Event()
             ev.record(cur)
             self.h2d_done[slot] = ev
+
+
+# ------------------------------------------------------------------------------------------------------------------ raw records
+class RecordLayout:
+    """Fixed-capacity layout of one batch of RAW sample records inside a flat byte buffer (pinned host slot and its device twin share
+    it): audio [B * audio_len] f32 (a clip ships min(len, audio_len) samples -- what lies behind audio_len is truncated by
+    make_audio_fixed_length anyway), audio_off [B + 1] i64, vec [B * n_poses * D] f32, vec_off [B + 1] i64, word_idx / word_onset
+    [B][w_max], n_words / n_ext [B] i32, times [B][2] f64, vid [B] i64."""
+    FIELDS = (("audio", "float32"), ("audio_off", "int64"), ("vec", "float32"), ("vec_off", "int64"), ("word_idx", "int64"),
+              ("word_onset", "float64"), ("times", "float64"), ("vid", "int64"), ("n_words", "int32"), ("n_ext", "int32"))
+
+    def __init__(self, batch, n_poses, pose_floats, audio_len, w_max=64):
+        self.B, self.n_poses, self.D, self.A, self.w_max = batch, n_poses, pose_floats, audio_len, w_max
+        shapes = {"audio": (batch * audio_len,), "audio_off": (batch + 1,), "vec": (batch * n_poses * pose_floats,), "vec_off": (batch + 1,),
+                  "word_idx": (batch, w_max), "word_onset": (batch, w_max), "times": (batch, 2), "vid": (batch,), "n_words": (batch,),
+                  "n_ext": (batch,)}
+        self.items, off = [], 0
+        for name, dt in self.FIELDS:
+            n = int(np.prod(shapes[name])) * np.dtype(dt).itemsize
+            self.items.append((name, dt, shapes[name], off, n))
+            off += (n + 255) // 256 * 256
+        self.nbytes = off
+
+    def views(self, flat):
+        """name -> typed view of a flat uint8 buffer (numpy array for host buffers given as numpy, torch tensor otherwise)."""
+        out = {}
+        for name, dt, shape, off, n in self.items:
+            piece = flat[off:off + n]
+            out[name] = piece.view(dt).reshape(shape) if isinstance(flat, np.ndarray) else piece.view(getattr(torch, dt)).view(shape)
+        return out
+
+    def pack(self, samples, lang_model, speaker_model, host):
+        """Raw stored samples [word_seq, pose_seq, vec_seq, audio, spectrogram, aux_info] -> the views `host` of a pinned slot.  Host work per
+        clip: two memcpys and the dictionary look-ups (word -> index, video id -> speaker index); no padding, no per-frame loop, no stacking."""
+        assert len(samples) == self.B
+        a_off = v_off = 0
+        for b, smp in enumerate(samples):
+            word_seq, _, vec_seq, audio, _, aux = smp
+            audio = np.asarray(audio, dtype=np.float32).reshape(-1)
+            na = min(audio.shape[0], self.A)
+            host["audio_off"][b] = a_off
+            host["audio"][a_off:a_off + na] = audio[:na]
+            a_off += na
+            vec = np.asarray(vec_seq, dtype=np.float32)
+            assert vec.shape[0] >= self.n_poses, "a stored sample holds at least n_poses frames (data_preprocessor.py:84)"
+            nv = self.n_poses * self.D
+            host["vec_off"][b] = v_off
+            host["vec"][v_off:v_off + nv] = vec[:self.n_poses].reshape(-1)
+            v_off += nv
+            nw = len(word_seq)
+            assert nw <= self.w_max, f"{nw} words in one clip: raise RecordLayout w_max"
+            host["n_words"][b], host["n_ext"][b] = nw, vec.shape[0]
+            for w, word in enumerate(word_seq):
+                host["word_idx"][b, w] = lang_model.get_word_index(word[0])
+                host["word_onset"][b, w] = word[1]
+            host["times"][b, 0], host["times"][b, 1] = aux["start_time"], aux["end_time"]
+            host["vid"][b] = speaker_model.word2index[aux["vid"]] if speaker_model is not None and hasattr(speaker_model, "word2index") else 0
+        host["audio_off"][self.B], host["vec_off"][self.B] = a_off, v_off
+
+
+class DeviceRecordFeeder:
+    """DeviceBatchFeeder for RAW records: put(samples) packs a batch of stored samples into a pinned slot (RecordLayout.pack) and enqueues
+    ONE host-to-device copy on a copy stream; ready() runs the assembly kernel on the compute stream, which writes the captured step's
+    static inputs (in_text, in_audio, target, vid) in place -- the role of SpeechMotionDataset.__getitem__ + default_collate_fn + the
+    `.to(device)` calls of train.py:169-183, with the per-sample work on the device."""
+
+    def __init__(self, static_text, static_audio, static_target, static_vid, lang_model, speaker_model, w_max=64, remove_word_timing=False):
+        self.static = (static_text, static_audio, static_target, static_vid)
+        self.dev = static_text.device
+        B, n_poses = static_text.shape
+        self.layout = RecordLayout(B, n_poses, static_target.shape[2], static_audio.shape[1], w_max)
+        self.lang, self.spk, self.rwt = lang_model, speaker_model, remove_word_timing
+        self.pinned = [torch.empty(self.layout.nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.host = [self.layout.views(p.numpy()) for p in self.pinned]
+        self.devbuf = [torch.empty(self.layout.nbytes, dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self.rec = [self.layout.views(d) for d in self.devbuf]
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.h2d_done, self.used = [None, None], [None, None]
+        self.i, self.pending = 0, None
+
+    def put(self, samples):
+        slot = self.i
+        self.i ^= 1
+        if self.h2d_done[slot] is not None:
+            self.h2d_done[slot].synchronize()                 # the pinned slot is free again
+        self.layout.pack(samples, self.lang, self.spk, self.host[slot])
+        with torch.cuda.stream(self.stream):
+            if self.used[slot] is not None:
+                self.stream.wait_event(self.used[slot])       # the assembly kernel that read this device slot has run
+            self.devbuf[slot].copy_(self.pinned[slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.h2d_done[slot] = ev
+        self.pending = slot
+
+    def ready(self):
+        from . import ops
+        slot = self.pending
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(self.h2d_done[slot])
+        ops.assemble_batch(self.rec[slot], *self.static, remove_word_timing=self.rwt)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.used[slot] = ev

@@ -859,6 +859,25 @@ def embed_gather(table, idx, out):
     call("tg_embed_gather", _p(table), _p(idx), _p(out), idx.numel(), D, n_rows, _stream()); return out
 
 
+def assemble_batch(rec, out_text, out_audio, out_vec, out_vid, *, remove_word_timing=False):
+    """Raw per-clip records on the device (data.RecordLayout views of one flat buffer) -> the training step's input tensors, in place:
+    SpeechMotionDataset.__getitem__ + default_collate_fn for the whole batch in one launch (tg_assemble_batch)."""
+    B, n_poses = out_text.shape
+    A = out_audio.shape[1]
+    Dp = out_vec.shape[2]
+    assert out_text.dtype == torch.int64 and out_vid.dtype == torch.int64 and out_text.is_contiguous() and out_audio.is_contiguous() and out_vec.is_contiguous()
+    assert tuple(out_audio.shape) == (B, A) and tuple(out_vec.shape) == (B, n_poses, Dp) and out_vid.numel() == B
+    _f32(out_audio, "out_audio"); _f32(out_vec, "out_vec"); _f32(rec["audio"], "audio"); _f32(rec["vec"], "vec")
+    Wmax = rec["word_idx"].shape[1]
+    assert rec["audio_off"].numel() == B + 1 and rec["vec_off"].numel() == B + 1 and tuple(rec["word_idx"].shape) == (B, Wmax) == tuple(rec["word_onset"].shape)
+    assert rec["word_idx"].dtype == torch.int64 and rec["word_onset"].dtype == torch.float64 and rec["times"].dtype == torch.float64
+    assert rec["n_words"].dtype == torch.int32 and rec["n_ext"].dtype == torch.int32 and rec["vid"].dtype == torch.int64
+    assert rec["audio"].numel() >= 1 and rec["vec"].numel() >= B * n_poses * Dp
+    call("tg_assemble_batch", _p(rec["audio"]), _p(rec["audio_off"]), _p(rec["vec"]), _p(rec["vec_off"]), _p(rec["word_idx"]), _p(rec["word_onset"]),
+         _p(rec["n_words"]), _p(rec["times"]), _p(rec["n_ext"]), _p(rec["vid"]), B, Wmax, n_poses, Dp, A, int(bool(remove_word_timing)),
+         _p(out_text), _p(out_audio), _p(out_vec), _p(out_vid), _stream())
+
+
 def embed_gather_drop(table, idx, out, p, state, site):
     """(out, Drop): out = table[idx] * dropout mask (F.dropout after the look-up, one pass; the mask is not stored)."""
     _flat(table, "table"); _i64(idx, "idx"); _flat(out, "out")

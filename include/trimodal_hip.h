@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 4
+#define TG_ABI_VERSION 5
 
 int tg_version(void);
 const char* tg_last_error(void);
@@ -431,6 +431,20 @@ int tg_narrow8_pair(const float* a0, const float* a1, const float* w0, const flo
 int tg_dup_halves(const float* d_o, float* dy, int32_t M, int32_t H, void* stream);
 /* pre[b][t][:D] = t < n_pre ? target[b][t][:] : 0 ; pre[b][t][D] = t < n_pre  (train_eval/train_gan.py:20-22). */
 int tg_make_pre_seq(const float* target, float* pre, int32_t B, int32_t T, int32_t D, int32_t n_pre, void* stream);
+/* Batch assembly on the device (ABI 5): SpeechMotionDataset.__getitem__ after the LMDB read (data_loader/lmdb_data_loader.py:107-171) and
+ * default_collate_fn's stacking (:43-53) for B clips in one launch, from RAW per-clip records.
+ *   audio_raw / audio_off [B + 1]: the stored audio of the clips back to back, clip b = [audio_off[b], audio_off[b + 1]) (any length);
+ *   vec_raw / vec_off [B + 1] (offsets in floats): the stored direction vectors, at least n_poses frames per clip; n_ext [B] or NULL: the stored
+ *   frame count vec_seq.shape[0] of each sample (NULL: (vec_off[b + 1] - vec_off[b]) / pose_floats, i.e. the whole sequence was shipped);
+ *   word_idx / word_onset [B][Wmax], n_words [B]: vocabulary index (lang_model.get_word_index, resolved on the host) and onset time of each word;
+ *   times [B][2]: aux_info start_time, end_time; vid_in [B] or NULL: speaker index (train.py:178-183).
+ * Writes in_text [B][n_poses] (extend_word_seq :115-140, fp64 as the reference's doubles; remove_word_timing != 0: words evenly spread),
+ * in_audio [B][audio_len] (utils/data_utils.py:68-74: truncate or numpy 'symmetric' padding), target [B][n_poses][pose_floats]
+ * (vec_seq[0:n_poses]) and vid [B] -- bit for bit what the host path produces. */
+int tg_assemble_batch(const float* audio_raw, const int64_t* audio_off, const float* vec_raw, const int64_t* vec_off, const int64_t* word_idx,
+                      const double* word_onset, const int32_t* n_words, const double* times, const int32_t* n_ext, const int64_t* vid_in, int32_t B, int32_t Wmax,
+                      int32_t n_poses, int32_t pose_floats, int32_t audio_len, int32_t remove_word_timing, int64_t* out_text, float* out_audio,
+                      float* out_vec, int64_t* out_vid, void* stream);
 /* out[i*D + :] = table[idx[i]*D + :]  (nn.Embedding, multimodal_context_net.py:40,89). */
 int tg_embed_gather(const float* table, const int64_t* idx, float* out, int32_t n_idx, int32_t D, int32_t n_rows,
                     void* stream);

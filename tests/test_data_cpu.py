@@ -171,3 +171,74 @@ def test_convert_dir_vec_to_pose_and_speaker_lookup(pkg):
     assert C.get_speaker_model(holder(z_obj=spk)) is spk and C.get_speaker_model(holder(module=holder(z_obj=spk))) is spk
     assert C.get_speaker_model(holder(z_obj=1)) is None and C.get_speaker_model(holder(z_obj=None)) is None
     assert C.get_speaker_model(holder()) is None
+
+
+def _assemble_reference(rec, B, n_poses, D_, A, remove_word_timing=False):
+    """numpy restatement of tg_assemble_batch (csrc/assemble.hip) over the packed records: what the device kernel must produce."""
+    text = np.zeros((B, n_poses), dtype=np.int64)
+    audio = np.zeros((B, A), dtype=np.float32)
+    vec = np.zeros((B, n_poses, D_), dtype=np.float32)
+    for b in range(B):
+        a0, a1 = int(rec["audio_off"][b]), int(rec["audio_off"][b + 1])
+        n = a1 - a0
+        i = np.arange(A)
+        j = i % (2 * n)
+        audio[b] = rec["audio"][a0:a1][np.where(j < n, j, 2 * n - 1 - j)]
+        v0 = int(rec["vec_off"][b])
+        vec[b] = rec["vec"][v0:v0 + n_poses * D_].reshape(n_poses, D_)
+        start, end = float(rec["times"][b, 0]), float(rec["times"][b, 1])
+        sample_end = start + (end - start) * n_poses / int(rec["n_ext"][b])
+        fd = (sample_end - start) / n_poses
+        nw = int(rec["n_words"][b])
+        idxs = [max(0, int(np.floor((float(rec["word_onset"][b, w]) - start) / fd))) for w in range(nw)]
+        if remove_word_timing:
+            cnt = sum(1 for ix in idxs if ix < n_poses)
+            space = int(n_poses / (cnt + 1))
+            for k in range(cnt):
+                text[b, (k + 1) * space] = rec["word_idx"][b, k]
+        else:
+            for w, ix in enumerate(idxs):
+                if ix < n_poses:
+                    text[b, ix] = rec["word_idx"][b, w]
+    return text, audio, vec, np.asarray(rec["vid"]).copy()
+
+
+def test_raw_record_packing_reproduces_getitem_and_collate(pkg):
+    """data.RecordLayout.pack: stored samples -> raw records (the form data.DeviceRecordFeeder ships to the device).  The numpy restatement
+    of the assembly kernel over those records equals SpeechMotionDataset.__getitem__ + default_collate_fn (lmdb_data_loader.py:43-53,
+    107-171) bit for bit -- on the reference's own g10 samples and on synthetic clips with short, exact and long audio, words before the clip
+    start and past its end, shared frames, and remove_word_timing."""
+    D = _mods(pkg)
+    g = load("g10_dataset.npz")
+    samples = dataset_samples(g)
+    lang = fixture_lang(pkg.Vocab, int(g["vocab_size"]))
+    ds = D.SpeechMotionDataset(samples, 34, 10, 15)
+    ds.set_lang_model(lang)
+    items = [ds[i] for i in range(len(samples))]
+    text, vec, audio, vid = D.collate(items, ds.speaker_model)
+    L = D.RecordLayout(len(samples), 34, 27, 36267)
+    host = L.views(np.zeros(L.nbytes, dtype=np.uint8))
+    L.pack(samples, lang, ds.speaker_model, host)
+    t2, a2, v2, s2 = _assemble_reference(host, len(samples), 34, 27, 36267)
+    assert np.array_equal(t2, text.numpy()) and np.array_equal(a2, audio.numpy()) and np.array_equal(v2, vec.numpy()) and np.array_equal(s2, vid.numpy())
+    # synthetic clips + hand-made edge cases
+    lang2 = _lang(pkg, [f"w{i}" for i in range(50)])
+    spk = pkg.Vocab.speakers(9)
+    syn = D.SyntheticSpeechMotionDataset(13, lang2, spk, seed=5)
+    raws = [list(syn.raw(i)) for i in range(13)]
+    raws[0][3] = raws[0][3][:20000]                                 # short audio: symmetric padding, more than one reflection
+    raws[1][3] = raws[1][3][:36267]                                 # exactly the expected length
+    raws[2][3] = raws[2][3][:9000]                                  # very short: the padding wraps around several times
+    st = raws[3][5]["start_time"]
+    raws[3][0] = [["w1", st - 3.0, st - 2.9], ["w2", st + 0.01, st + 0.2], ["w3", st + 0.02, st + 0.3], ["nope", st + 1.0, st + 1.2], ["w4", st + 50.0, st + 51.0]]
+    raws[4][0] = []                                                 # no words at all
+    for rwt in (False, True):
+        ref = [D.sample_to_tensors(r, lang2, 34, 15, remove_word_timing=rwt) for r in raws]
+        text, vec, audio, vid = D.collate(ref, spk)
+        L = D.RecordLayout(len(raws), 34, 27, 36267, w_max=16)
+        host = L.views(np.zeros(L.nbytes, dtype=np.uint8))
+        L.pack(raws, lang2, spk, host)
+        assert int(host["audio_off"][-1]) <= len(raws) * 36267 and int(host["n_ext"][0]) == raws[0][2].shape[0]
+        t2, a2, v2, s2 = _assemble_reference(host, len(raws), 34, 27, 36267, remove_word_timing=rwt)
+        assert np.array_equal(t2, text.numpy()), rwt
+        assert np.array_equal(a2, audio.numpy()) and np.array_equal(v2, vec.numpy()) and np.array_equal(s2, vid.numpy())
