@@ -14,6 +14,8 @@
 // published, [member][plane][row][32 units], 64 bytes per row and plane -- a wave's epilogue stores cover whole 128-byte lines.
 // Per wave and step: <= 108 bf16 MFMAs of 16 cycles instead of 120 f32 MFMAs of 32.
 #include "common.hpp"
+#include <type_traits>
+#include <utility>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -21,16 +23,22 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace tg {
 
+template <int N, typename Fn, int... I>
+__device__ __forceinline__ void xc_static_for_impl(Fn&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename Fn>
+__device__ __forceinline__ void xc_static_for(Fn&& f) { xc_static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
 typedef __attribute__((address_space(1))) unsigned gu32x;
 
 constexpr int XC_UNITS = 32;          // hidden units per workgroup = one 32-deep k-step of the product
 constexpr int XC_FLAG_STRIDE = 16;    // flag words per cluster (one 64-byte line)
-constexpr int XC_KS = 4;              // K slices (waves along K)
-constexpr int XC_SPS = 3;             // k-steps per slice, forward: ceil(10 / 4)
 constexpr unsigned XC_SPIN_LIMIT = 1u << 26;
 constexpr int XC_GEN_WORD = 15;       // generation word of a cluster's 16-word flag line (members use words 0 .. CW - 1 <= 9)
 constexpr int XC_POLL_WAVE = 7;       // of 8; epilogue threads live in waves 0 .. 3 (forward) / 0 .. 1 (backward)
 constexpr unsigned XC_RSRC3 = 0x00020000u;
+#ifndef XC_SAME_XCD_FAST
+#define XC_SAME_XCD_FAST 1            // 0: always the write-through protocol (A/B builds: make CXXFLAGS+=-DXC_SAME_XCD_FAST=0)
+#endif
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ f32x4 as_f32x4(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
@@ -90,13 +98,30 @@ __device__ __forceinline__ f32x4 xc_mma(const bf16x8 (&wa)[2], const bf16x8 w_lo
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[0], acc, 0, 0, 0);
 }
 
+// Flag words carry the publishing workgroup's XCD in their low four bits: value = (generation + step + 1) << 4 | xcc.  A cluster whose
+// members all sit on ONE XCD -- which is how the dispatcher is observed to place them, but a fact only once it has been READ, from
+// HW_REG_XCC_ID -- shares one L2: its members then publish with PLAIN stores (the line stays in that L2; acknowledged by the L2) instead of
+// write-through sc1 stores (the line is dropped from L2 and the consumers' loads go to the fabric: MI355X_MICROARCH.md, "stores of each
+// flavour").  Consumers load with sc1 (L1 bypass) either way.  Every member derives the decision from the same ten flag words of step 0, so
+// the cluster switches together; a cluster that straddles XCDs keeps the write-through protocol for the whole launch.
+__device__ __forceinline__ unsigned xc_my_xcc() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 15u;
+}
+__device__ __forceinline__ unsigned xc_flag_value(unsigned count, unsigned xcc) { return (count << 4) | xcc; }
+
 // bounded poll of the cluster's flag words by ONE wave (relaxed sc1 loads + s_sleep); returns false after a timeout (diagnostics
-// written to the sticky timeout block)
-__device__ __forceinline__ bool xc_wait(gu32x* cl_flags, int CW, int lane, unsigned want, unsigned* tmo, int step) {
+// written to the sticky timeout block).  *same_xcd: every member's flag carries this workgroup's XCD.
+__device__ __forceinline__ bool xc_wait(gu32x* cl_flags, int CW, int lane, unsigned want, unsigned* tmo, int step, unsigned my_xcc, bool* same_xcd) {
     unsigned spins = 0;
+    const unsigned want4 = want << 4;
     for (;;) {
-        const unsigned v = lane < CW ? __hip_atomic_load(cl_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
-        if (__all((int)(v - want) >= 0)) return true;        // generations wrap: compare the difference
+        const unsigned v = lane < CW ? __hip_atomic_load(cl_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (want4 | my_xcc);
+        if (__all((int)(v - want4) >= 0)) {                  // generations wrap: compare the difference (the XCD bits only add 0 .. 15)
+            *same_xcd = __all((v & 15u) == my_xcc);
+            return true;
+        }
         __builtin_amdgcn_s_sleep(1);
         if (++spins > XC_SPIN_LIMIT) {                    // wave-uniform
             if (lane == 0) {
@@ -105,6 +130,7 @@ __device__ __forceinline__ bool xc_wait(gu32x* cl_flags, int CW, int lane, unsig
             }
             if (lane < CW) __hip_atomic_store((gu32x*)tmo + 4 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0) __hip_atomic_store((gu32x*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *same_xcd = false;
             return false;
         }
     }
@@ -112,14 +138,27 @@ __device__ __forceinline__ bool xc_wait(gu32x* cl_flags, int CW, int lane, unsig
 
 // exchange buffer (bytes): [slot 2][dir 2][block][plane 3][b_pad rows][32 units] bf16; block = member (forward) or gate * CW + member
 // (backward); plane_bytes = b_pad * 64
-template <int MT, int NS>
+// ABL (lab build only, -DTG_LAB_ABL, tools/gru_cluster_ablate.py; wrong results by construction): bit 0 no flag wait, bit 1 no fragment loads,
+// bit 2 no MFMAs, bit 3 no K-slice reduction / gate arithmetic, bit 4 no publishing stores, bit 5 no output stores / prefetch, bit 6 no drain
+// (Round 4, measured and not kept: a "pair" form -- KS = 2 K slices, 256-thread workgroups of ONE batch tile, two per CU, so that one
+// cluster's MFMAs run while the other sits in its hand-off.  At B = 384 it took 202 us per launch against 165: five k-steps per wave
+// need 120 registers of resident weights, the kernel spilled 23 of them into the step loop, only three k-steps of fragment loads fit in
+// flight, and the two workgroups of a CU fall into step rather than apart.  profiles/r4_p_pair_rejected.txt)
+template <int MT, int NS, int ABL = 0>
 __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
     const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
     const float* __restrict__ drop_mask, float* __restrict__ y_drop, void* hx, unsigned* flags, unsigned* tmo, int B, int T, int H,
     int n_bt, int CW, int b_pad, int save_row0, int save_rows) {
-    __shared__ __attribute__((aligned(16))) f32x4 red[XC_KS][2][MT][3][64];
-    __shared__ __attribute__((aligned(16))) bf16x8 wlo[8][3 * XC_SPS][64];       // lo plane of every wave's weight fragments (lane-private slots)
+    constexpr int KS = 4;                                 // K slices = waves along K; a workgroup has 2 KS waves (two 16-unit tiles x KS slices)
+    constexpr int SPS = (10 + KS - 1) / KS;               // k-steps per K slice (CW <= 10)
+    constexpr int POLL_WAVE = 2 * KS - 1;                 // a wave without epilogue threads (they live in waves 0 .. 2 MT - 1)
+    static_assert(2 * MT <= POLL_WAVE, "the polling wave owns no epilogue threads");
+    __shared__ __attribute__((aligned(16))) f32x4 red[KS][2][MT][3][64];
+    __shared__ __attribute__((aligned(16))) bf16x8 wlo[2 * KS][3 * SPS][64];       // lo plane of every wave's weight fragments (lane-private slots)
+    __shared__ int same_xcd_s;
+    const unsigned my_xcc = xc_my_xcc();
+    bool fast = false;                                   // plain-store publishing: set at step 1 when the whole cluster sits on this XCD
     const int n_cl = 2 * n_bt;
     int cl, m;
     if (n_cl % 8 == 0) {        // members of one cluster on block ids of one residue mod 8: same XCD as observed (speed only)
@@ -134,24 +173,24 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
     const float* bhh = dir ? bhh1 : bhh0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: K-slice bounds and exchange offsets stay in SGPRs
-    const int ut = wave & 1, ks = wave >> 1;
+    const int ut = wave & 1, ks = wave >> 1;                  // ks < KS
     const int r16 = lane & 15, kq = lane >> 4;
     const int b0 = bt * (16 * MT);
 
     // k-steps (= member blocks) of this wave's K slice: CW steps dealt as evenly as possible over the 4 slices
-    const int s_base = CW / XC_KS, s_rem = CW % XC_KS;
+    const int s_base = CW / KS, s_rem = CW % KS;
     const int s_cnt = s_base + (ks < s_rem ? 1 : 0);
     const int s_beg = ks * s_base + (ks < s_rem ? ks : s_rem);
 
     // W_hh rows (gate g, unit 32 m + 16 ut + r16), k = 32 (s_beg + p) + 8 kq .. +7: pre-split A fragments, resident
-    bf16x8 wa[3][XC_SPS][2];
+    bf16x8 wa[3][SPS][2];
     {
         const int j = m * XC_UNITS + ut * 16 + r16;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int p = 0; p < XC_SPS; ++p) {
+            for (int p = 0; p < SPS; ++p) {
                 const int k = 32 * (s_beg + p) + 8 * kq;
                 const float* src = whh + (long)(g * H + j) * H + k;
                 const bool ok = p < s_cnt && j < H;
@@ -161,7 +200,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
                 if constexpr (NS == 1) { pl[0] = xc_rne8(a, b); pl[1] = pl[2] = pl[0]; }
                 else xc_split8(a, b, pl);
                 wa[g][p][0] = pl[0]; wa[g][p][1] = pl[1];
-                wlo[wave][g * XC_SPS + p][lane] = pl[2];
+                wlo[wave][g * SPS + p][lane] = pl[2];
             }
     }
     // ---- epilogue role: thread e < 128 * MT finalises batch row (e / 8) of the tile, hidden units 4 * (e % 8) .. +3 of the slice
@@ -220,7 +259,9 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
         if (drop_mask) mkn = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(dm_rsrc, y_v, tl * 2 * H * 4, 0));
     };
     if (epi_wave) prefetch(0);
-
+    // (Round 4, measured and not kept: the step's output stores and the next gi prefetch issued one step LATE, behind the next step's fragment
+    // loads, so that they drain under the MFMAs instead of sitting in front of those loads -- 161 -> 172 us per launch at B = 384, backward
+    // 3.60 -> 3.83 us per step: vector-memory traffic inside the MFMA phase costs more than behind the flag.  profiles/r4_r_deferred_outputs_rejected.txt)
     for (int step = 0; step < T; ++step) {
         const int tau = dir ? T - 1 - step : step;
         f32x4 acc[MT][3];
@@ -233,31 +274,45 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
             // the polling wave is one WITHOUT epilogue threads: its memory queue holds no output stores / prefetch loads of the previous
             // step, so the first poll returns after one L2 round trip (vmcnt counts in order: wave 0 would see its flag loads return
             // only behind its own stores)
-            if (wave == XC_POLL_WAVE && !aborted) aborted = !xc_wait(cl_flags, CW, lane, gen + (unsigned)step, tmo, step);
+            if (wave == POLL_WAVE && !aborted) {
+                bool same = true;
+                if constexpr (!(ABL & 1)) aborted = !xc_wait(cl_flags, CW, lane, gen + (unsigned)step, tmo, step, my_xcc, &same);
+                if (step == 1 && lane == 0) same_xcd_s = same && XC_SAME_XCD_FAST;
+            }
             __syncthreads();                        // the other waves load only behind the polling wave's barrier
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // compiler ordering only; every load below is sc1
+            if (step == 1) fast = __builtin_amdgcn_readfirstlane(same_xcd_s) != 0;
             const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes;
-            bf16x8 fb[XC_SPS][MT][NS];
+            // fragments of at most three k-steps are in flight / live at a time: k-step p + 3 is requested into the registers of k-step p once
+            // that one's MFMAs are issued (KS = 2: five k-steps per wave -- all fifteen fragments live at once spilled the resident weights)
+            constexpr int FW = SPS > 3 ? 3 : SPS;
+            bf16x8 fb[FW][MT][NS];
+            auto load_kstep = [&](auto pc) {
+                constexpr int p = decltype(pc)::value;
 #pragma unroll
-            for (int p = 0; p < XC_SPS; ++p)
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        // lane part in the VGPR offset (one register for all loads), wave-uniform part in the scalar offset
+                        const int soff = off0 + ((s_beg + p) * 3 + s) * plane_bytes + (b0 + i * 16) * 64;
+                        if constexpr (ABL & 2) fb[p % FW][i][s] = as_bf16x8(u32x4{(unsigned)soff, 1u, 2u, 3u});
+                        else fb[p % FW][i][s] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, r16 * 64 + kq * 16, soff, 16));   // aux 16 = sc1
+                    }
+            };
+            xc_static_for<FW>([&](auto pc) { if (decltype(pc)::value < s_cnt) load_kstep(pc); });
+            xc_static_for<SPS>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
                 if (p < s_cnt) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) {
-                            // lane part in the VGPR offset (one register for all 18 loads), wave-uniform part in the scalar offset
-                            const int soff = off0 + ((s_beg + p) * 3 + s) * plane_bytes + (b0 + i * 16) * 64;
-                            fb[p][i][s] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, r16 * 64 + kq * 16, soff, 16));   // aux 16 = sc1
+                        for (int g = 0; g < 3; ++g) {
+                            if constexpr (ABL & 4) { u32x4 t_ = __builtin_bit_cast(u32x4, fb[p % FW][i][0]); asm volatile("" :: "v"(t_)); }
+                            else acc[i][g] = xc_mma<NS>(wa[g][p], wlo[wave][g * SPS + p][lane], fb[p % FW][i], acc[i][g]);
                         }
                 }
-#pragma unroll
-            for (int p = 0; p < XC_SPS; ++p)
-                if (p < s_cnt) {
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) acc[i][g] = xc_mma<NS>(wa[g][p], wlo[wave][g * XC_SPS + p][lane], fb[p][i], acc[i][g]);
-                }
+                if constexpr (p + FW < SPS) { if (p + FW < s_cnt) load_kstep(std::integral_constant<int, p + FW>{}); }
+            });
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -271,13 +326,16 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 f32x4 s = red[0][e_ut][e_mt][g][e_lane];
+                if constexpr (!(ABL & 8)) {
 #pragma unroll
-                for (int q = 1; q < XC_KS; ++q) s += red[q][e_ut][e_mt][g][e_lane];
+                    for (int q = 1; q < KS; ++q) s += red[q][e_ut][e_mt][g][e_lane];
+                }
                 gh[g] = s;
             }
             mk = mkn;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if constexpr (ABL & 8) { h[q] = gn[0][q] + gh[0][q] + gh[1][q] + gh[2][q]; r4[q] = z4[q] = n4[q] = hn4[q] = h[q]; continue; }
                 const float hn = gh[2][q] + bh[2][q];
                 const float r = gate_sigmoid(gn[0][q] + bh[0][q] + gh[0][q]);
                 const float z = gate_sigmoid(gn[1][q] + bh[1][q] + gh[1][q]);
@@ -292,13 +350,19 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
             if constexpr (NS == 1) pl[0] = xc_rne4(h);
             else xc_split4(h, pl);
             const int woff = (dir * 2 + (step & 1)) * slot_bytes + m * 3 * plane_bytes + row * 64 + ug * 8;
+            if constexpr (ABL & 16) { asm volatile("" :: "v"(pl[0]), "v"(woff)); }
+            else if (fast) {                                   // one XCD: the line stays in the shared L2
 #pragma unroll
-            for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], hx_rsrc, woff + s * plane_bytes, 0, 16);
+                for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], hx_rsrc, woff + s * plane_bytes, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], hx_rsrc, woff + s * plane_bytes, 0, 16);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY wave drains its stores before the flag
+        if constexpr (!(ABL & 64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY wave drains its stores before the flag
         __syncthreads();                                       // (also: `red` is free again)
-        if (threadIdx.x == 0 && T >= 2) __hip_atomic_store(my_flag, gen + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (epi_wave) {                                        // outputs for later kernels and the next step's inputs: off the critical path
+        if (threadIdx.x == 0 && T >= 2) __hip_atomic_store(my_flag, xc_flag_value(gen + (unsigned)(step + 1), my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (epi_wave && !(ABL & 32)) {                         // outputs for later kernels and the next step's inputs: off the critical path
             __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(h), y_rsrc, y_v, tau * 2 * H * 4, 0);
             if (y_drop) __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(h * mk), yd_rsrc, y_v, tau * 2 * H * 4, 0);   // fused inter-layer dropout
             if (save) {
@@ -329,6 +393,9 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int CW, int b_pad) {
     __shared__ __attribute__((aligned(16))) f32x4 red[XC_KSB][2][64];
     __shared__ __attribute__((aligned(16))) bf16x8 wlo[8][2 * XC_SPB8][64];
+    __shared__ int same_xcd_s;
+    const unsigned my_xcc = xc_my_xcc();
+    bool fast = false;                                   // see the forward kernel
     const int n_cl = 2 * n_bt;
     int cl, m;
     if (n_cl % 8 == 0) {
@@ -427,14 +494,18 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
         hp = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(y_rsrc, has_prev ? y_v : OOB, (has_prev ? tp : 0) * 2 * H * 4, 0));   // h_prev = 0 at the sequence end
     };
     if (epi_wave) prefetch(0);
-
     for (int step = 0; step < T; ++step) {
         const int tau = dir ? step : T - 1 - step;
         f32x4 acc[2] = {zero, zero};
         if (step > 0) {
-            if (wave == XC_POLL_WAVE && !aborted) aborted = !xc_wait(cl_flags, CW, lane, gen + (unsigned)step, tmo, step);
+            if (wave == XC_POLL_WAVE && !aborted) {
+                bool same;
+                aborted = !xc_wait(cl_flags, CW, lane, gen + (unsigned)step, tmo, step, my_xcc, &same);
+                if (step == 1 && lane == 0) same_xcd_s = same && XC_SAME_XCD_FAST;
+            }
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (step == 1) fast = __builtin_amdgcn_readfirstlane(same_xcd_s) != 0;
             const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes + b0 * 64;
             bf16x8 fb[XC_SPB8][NS];
 #pragma unroll
@@ -445,11 +516,12 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
                         fb[p][s] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(gx_rsrc, r16 * 64 + kq * 16, off0 + ((s_beg + p) * 3 + s) * plane_bytes, 16));
                 }
 #pragma unroll
-            for (int p = 0; p < XC_SPB8; ++p)
+            for (int p = 0; p < XC_SPB8; ++p) {
                 if (p < s_cnt) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) acc[u] = xc_mma<NS>(wa[u][p], wlo[wave][u * XC_SPB8 + p][lane], fb[p], acc[u]);
                 }
+            }
         }
         red[ks][0][lane] = acc[0];
         red[ks][1][lane] = acc[1];
@@ -472,23 +544,24 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
             }
             // publish this step's dgh tile: blocks (gate 0..2, member m), three bf16 planes each
             const int woff = (dir * 2 + (step & 1)) * slot_bytes + row * 64 + ug * 8;
-            u32x2 pl[3];
-            if constexpr (NS == 1) pl[0] = xc_rne4(g_r);
-            else xc_split4(g_r, pl);
+            u32x2 pl[3][3];
+            if constexpr (NS == 1) { pl[0][0] = xc_rne4(g_r); pl[1][0] = xc_rne4(g_z); pl[2][0] = xc_rne4(g_nr); }
+            else { xc_split4(g_r, pl[0]); xc_split4(g_z, pl[1]); xc_split4(g_nr, pl[2]); }
+            if (fast) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((0 * CW + m) * 3 + s) * plane_bytes, 0, 16);
-            if constexpr (NS == 1) pl[0] = xc_rne4(g_z);
-            else xc_split4(g_z, pl);
+                for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((1 * CW + m) * 3 + s) * plane_bytes, 0, 16);
-            if constexpr (NS == 1) pl[0] = xc_rne4(g_nr);
-            else xc_split4(g_nr, pl);
+                    for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[g][s], gx_rsrc, woff + ((g * CW + m) * 3 + s) * plane_bytes, 0, 0);
+            } else {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[s], gx_rsrc, woff + ((2 * CW + m) * 3 + s) * plane_bytes, 0, 16);
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b64(pl[g][s], gx_rsrc, woff + ((g * CW + m) * 3 + s) * plane_bytes, 0, 16);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0 && T >= 2) __hip_atomic_store(my_flag, gen + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0 && T >= 2) __hip_atomic_store(my_flag, xc_flag_value(gen + (unsigned)(step + 1), my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (epi_wave) {
             const int go = tau * H3 * 4;
             __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_r), gi_rsrc, dg_v, go, 0);
@@ -518,8 +591,23 @@ int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, c
                          int H, int n_bt, int cw, int b_pad, int save_row0, int save_rows, hipStream_t s) {
     dim3 grid(2 * n_bt * cw);
     const bool bf16 = tg_get_math_mode() == 1;            // plain bf16 operands: one MFMA per product, one exchange plane
-#define TG_XF(MT_, NS_) hipLaunchKernelGGL((gru_seq_fwd_cluster_x3_kernel<MT_, NS_>), grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, \
-                                           drop_mask, y_drop, hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows)
+#define TG_XF(MT_, NS_) hipLaunchKernelGGL((gru_seq_fwd_cluster_x3_kernel<MT_, NS_>), grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, \
+                                           save_ds, drop_mask, y_drop, hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows)
+#ifdef TG_LAB_ABL
+    {
+        const char* ae = getenv("TG_XC_ABL");
+        const int abl = ae ? atoi(ae) : 0;
+        if (abl && mt == 2 && !bf16) {
+#define TG_XF_ABL(A_) case A_: hipLaunchKernelGGL((gru_seq_fwd_cluster_x3_kernel<2, 3, A_>), grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, \
+                                           drop_mask, y_drop, hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows); return check_launch("tg_gru_forward_cluster(x3, ablated)");
+            switch (abl) {
+                TG_XF_ABL(1) TG_XF_ABL(2) TG_XF_ABL(4) TG_XF_ABL(8) TG_XF_ABL(16) TG_XF_ABL(32) TG_XF_ABL(64) TG_XF_ABL(80) TG_XF_ABL(3) TG_XF_ABL(7) TG_XF_ABL(15) TG_XF_ABL(31) TG_XF_ABL(127) TG_XF_ABL(6) TG_XF_ABL(96) TG_XF_ABL(81)
+                default: break;
+            }
+#undef TG_XF_ABL
+        }
+    }
+#endif
     if (mt == 1) { if (bf16) TG_XF(1, 1); else TG_XF(1, 3); }
     else { if (bf16) TG_XF(2, 1); else TG_XF(2, 3); }
 #undef TG_XF
