@@ -449,6 +449,8 @@ def main():
                          "per-sample assembly of SpeechMotionDataset.__getitem__ + collate runs on the device (never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path (graph segments + RCCL) even with one rank")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="tg_set_deterministic(1): fixed-order combines everywhere, bit-reproducible runs (cost line for DESIGN.md; never the headline value)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -472,6 +474,7 @@ def main():
     pkg = importlib.import_module(PKG)
     pkg._lib.load()
     pkg.ops.set_math_mode(a.dtype)
+    pkg.ops.set_deterministic(a.deterministic)
 
     grad_sync = None
     if world > 1 or a.force_ddp:
@@ -567,7 +570,7 @@ def main():
         step_peak = PEAK_BF16_MFMA if a.dtype == "bf16" else PEAK_F32_MFMA
         out = {
             "metric": "training clips/sec (34-frame, 27-dim pose), " + ("post-warm-up GAN iteration" if a.epoch > 10 else "warm-up-phase iteration (epoch <= loss_warmup)")
-                      + (" [host-fed, PCIe-inclusive]" if a.host_input else "") + (" [host-fed raw records, device-side batch assembly]" if a.host_records else ""),
+                      + (" [host-fed, PCIe-inclusive]" if a.host_input else "") + (" [host-fed raw records, device-side batch assembly]" if a.host_records else "") + (" [deterministic mode]" if a.deterministic else ""),
             "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",

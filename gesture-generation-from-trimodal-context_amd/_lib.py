@@ -161,6 +161,9 @@ def load():
     lib.tg_set_math_mode.restype = C.c_int
     lib.tg_set_math_mode.argtypes = [I32]
     lib.tg_get_math_mode.restype = C.c_int
+    lib.tg_set_deterministic.restype = C.c_int
+    lib.tg_set_deterministic.argtypes = [I32]
+    lib.tg_get_deterministic.restype = C.c_int
     lib.tg_set_nt_mover_waves.restype = C.c_int
     lib.tg_set_nt_mover_waves.argtypes = [I32]
     lib.tg_gru_cluster_fused_dropout.restype = C.c_int32

@@ -30,6 +30,9 @@ inline int check_launch(const char* what) {
         }                                  \
     } while (0)
 
+extern "C" int tg_get_deterministic(void);
+inline bool deterministic() { return tg_get_deterministic() != 0; }
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -220,6 +220,55 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
         if (cur >= 0 && cur < n_rows) atomicAdd(&dtable[cur * D + c], acc);
     }
 }
+// Deterministic form (tg_set_deterministic): the one-wave workgroup i owns index i.  If an earlier position holds the same id it does nothing;
+// otherwise it is the id's FIRST occurrence: the wave collects the later positions of that id IN ORDER (64 positions per ballot, 1 024 per LDS
+// list -- the padding id of a word batch occurs thousands of times) and adds those rows, in position order, to the table row: no atomics, one
+// writer per row, a fixed summation order.  D <= 512 (eight columns per lane).
+constexpr int SCATTER_DET_LIST = 1024;
+__global__ __launch_bounds__(64) void embed_scatter_det_kernel(const float* __restrict__ dout, const int64_t* __restrict__ idx,
+                                                               float* __restrict__ dtable, int n_idx, int D, int n_rows) {
+    __shared__ int pos[SCATTER_DET_LIST];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int64_t id = idx[i];
+    if (id < 0 || id >= n_rows) return;
+    for (int j0 = 0; j0 < i; j0 += 64) {                  // an earlier occurrence owns the row
+        const int j = j0 + lane;
+        if (__any(j < i && idx[j] == id)) return;
+    }
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = lane + 64 * q < D ? dout[(long)i * D + lane + 64 * q] : 0.f;
+    int j0 = i + 1;
+    while (j0 < n_idx) {
+        int n = 0;                                        // the next (up to) 1 024 occurrences, in order
+        for (; j0 < n_idx && n + 64 <= SCATTER_DET_LIST; j0 += 64) {
+            const int j = j0 + lane;
+            const bool hit = j < n_idx && idx[j] == id;
+            const unsigned long long m = __ballot(hit);
+            if (hit) pos[n + __popcll(m & ((1ull << lane) - 1ull))] = j;
+            n += __popcll(m);
+        }
+        __syncthreads();
+        for (int q4 = 0; q4 < n; q4 += 4) {               // four independent row loads in flight per column; added in list order
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long r = pos[min(q4 + u, n - 1)];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[u][q] = (q4 + u < n && lane + 64 * q < D) ? dout[r * D + lane + 64 * q] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += v[u][q];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (lane + 64 * q < D) dtable[id * D + lane + 64 * q] += acc[q];
+}
+
 __global__ void permute3_kernel(const float* __restrict__ in, float* __restrict__ out, int d0, int d1, int d2, int p0, int p1, int p2) {
     const int d[3] = {d0, d1, d2};
     const int o0 = d[p0], o1 = d[p1], o2 = d[p2];
@@ -836,6 +885,11 @@ int tg_embed_gather_drop(const float* table, const int64_t* idx, float* out, int
 }
 int tg_embed_scatter_add(const float* dout, const int64_t* idx, float* dtable, int32_t n_idx, int32_t D, int32_t n_rows, void* stream) {
     TG_REQUIRE(dout && idx && dtable && n_idx > 0 && D > 0 && n_rows > 0, "tg_embed_scatter_add: bad arguments");
+    if (deterministic()) {
+        TG_REQUIRE(D <= 512, "tg_embed_scatter_add (deterministic): D = %d > 512", D);
+        hipLaunchKernelGGL(embed_scatter_det_kernel, dim3(n_idx), dim3(64), 0, ST, dout, idx, dtable, n_idx, D, n_rows);
+        return check_launch("tg_embed_scatter_add(deterministic)");
+    }
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(cdiv(n_idx, SCATTER_CHUNK)), dim3(256), 0, ST, dout, idx, dtable, n_idx, D, n_rows);
     return check_launch("tg_embed_scatter_add");
 }

@@ -648,6 +648,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     if (rp == 0 && n < N) atomicAdd(&out[n], red[0][cidx] + red[1][cidx] + red[2][cidx] + red[3][cidx]);
 }
 
+// Deterministic column sums (tg_set_deterministic): one workgroup per 64 columns walks ALL rows (16 row lanes per column, fp64), the lanes'
+// sums meet in LDS in lane order; no split over workgroups, no atomics.
+__global__ __launch_bounds__(1024) void colsum_det_kernel(const float* __restrict__ X, long ldx, int M, int N, float* __restrict__ out, int accumulate) {
+    __shared__ double red[16][64];
+    const int cidx = threadIdx.x & 63, rp = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + cidx;
+    double s = 0.0;
+    if (n < N) {
+        int m = rp;
+        for (; m + 7 * 16 < M; m += 8 * 16) {             // eight independent loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = X[(long)(m + 16 * u) * ldx + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; m < M; m += 16) s += X[(long)m * ldx + n];
+    }
+    red[rp][cidx] = s;
+    __syncthreads();
+    if (rp == 0 && n < N) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += red[q][cidx];
+        out[n] = (accumulate ? out[n] : 0.f) + (float)t;
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -997,6 +1024,10 @@ extern "C" int tg_gemm_tn(const float* dY, int64_t ldy, const tg_window* A, floa
 extern "C" int tg_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream) {
     TG_REQUIRE(X && out && M > 0 && N > 0 && ldx >= N, "tg_colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (deterministic()) {
+        hipLaunchKernelGGL(colsum_det_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, s, X, (long)ldx, M, N, out, accumulate);
+        return check_launch("tg_colsum(deterministic)");
+    }
     if (!accumulate) {
         if (zero_async(out, sizeof(float) * (size_t)N, s)) return 1;
     }

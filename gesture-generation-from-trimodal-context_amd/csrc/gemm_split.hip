@@ -608,6 +608,11 @@ extern "C" int tg_set_math_mode(int32_t mode) {
 
 extern "C" int tg_get_math_mode(void) { return g_math_mode; }
 
+// Deterministic mode: every cross-workgroup combine in a fixed order (no float atomics) -- two runs from the same state are bit-identical.
+static int g_deterministic = 0;
+extern "C" int tg_set_deterministic(int32_t on) { g_deterministic = on ? 1 : 0; return 0; }
+extern "C" int tg_get_deterministic(void) { return g_deterministic; }
+
 // Tile menu (tools/gemm_split_lab.hip on the shapes of the training step).  Single-buffered 128-row tiles run two workgroups per CU
 // and win when the grid has at least ~2 workgroups per CU (the stacked forward, M = 13056); the backward shapes (M = 4352) have too
 // few 128-row tiles for that and run 64-row double-buffered tiles instead (476 x [64 x 96] for N = 600: 50 us against 59 for 238 x

@@ -32,8 +32,6 @@ template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int HS = 64;
-constexpr int HX_LD = HS + 8;          // bf16 per LDS row of the h planes (144 B: 16-byte aligned, rows spread over the banks)
-constexpr int DG_LD = 3 * HS + 8;      // bf16 per LDS row of the gate-gradient planes (400 B)
 
 // eight consecutive fp32 -> three bf16x8 fragments (hi / mid / lo planes)
 // bf16m (wave-uniform, math mode 1 = plain bf16 operands): plane 0 holds the value rounded to nearest even and is the only plane multiplied
@@ -90,24 +88,11 @@ __device__ __forceinline__ void pin_fragment(bf16x8& v) {
     v = __builtin_bit_cast(bf16x8, t);
 }
 
-// acc += W (A operand, split planes wa[0..2]) x h (B operand, split planes fb[0..2]); the six significant partial products,
-// smallest first
-__device__ __forceinline__ f32x4 mma_x3(const bf16x8 (&wa)[3], const bf16x8 (&fb)[3], f32x4 acc, int bf16m) {
-    if (bf16m) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2], fb[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], fb[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], fb[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[1], acc, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[0], acc, 0, 0, 0);
-}
-
 // Lab build only (-DTG_LAB_STAMP, make lab, tools/h64_stamps.py): s_memtime stamps of workgroup (0, 0), wave 0 at the phase boundaries of every
 // step, into a device array read back through tg_lab_h64_read_stamps.  The stamp's own s_waitcnt lgkmcnt(0) also drains LDS operations, so
 // a phase that ends in LDS stores includes their completion.  The product build contains none of this.
 #ifdef TG_LAB_STAMP
 __device__ unsigned long long tg_h64_stamps[64][8];
-__device__ int tg_h64_lab_mode;          // bit 0: skip the per-step output stores, bit 1: skip the operand prefetch (timing ablation, wrong results)
 #define TG_STAMP(step_, i_)                                                                   \
     do {                                                                                      \
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64 && (step_) < 64) {         \
@@ -129,143 +114,12 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// No lane-dependent control flow inside the step loop: hipcc counts outstanding vector-memory operations statically, and a predicated
-// load or store makes the count dynamic -- it then drains EVERYTHING (s_waitcnt vmcnt(0)) before the next use of a prefetched value,
-// which put one full store round trip (~1.2 us) on every step of the first version (1.6 us per step, of which 0.25 us MFMA).  So:
-// rows past the batch are CLAMPED to the last row (those lanes recompute row B - 1 bit for bit and store the same values to the same
-// addresses), the optional outputs are template parameters, the prefetch of the step after the last re-reads a valid address, and
-// step 0 multiplies a zeroed LDS tile instead of branching around the product.
-template <bool SAVE, bool DROP, int D>
-__global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
-    const float* __restrict__ gi, long gi_ds, const float* __restrict__ whh0, const float* __restrict__ whh1,
-    const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ Y, float* __restrict__ save, long save_ds,
-    const float* __restrict__ drop_mask, float* __restrict__ y_drop, int B, int T, int bf16m) {
-    __shared__ __attribute__((aligned(16))) __bf16 hs[2][3][16][HX_LD];
-    const int dir = blockIdx.y;
-    const float* whh = dir ? whh1 : whh0;
-    const float* bhh = dir ? bhh1 : bhh0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-
-    // W_hh rows (gate g, unit 16 wave + r16), k = 32 ks + 8 kq .. +7 -> pre-split A fragments, resident for the whole sequence
-    bf16x8 wa[3][2][3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const float* p = whh + (long)(g * HS + 16 * wave + r16) * HS + 32 * ks + 8 * kq;
-            split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[g][ks], bf16m);
-#pragma unroll
-            for (int s = 0; s < 3; ++s) pin_fragment(wa[g][ks][s]);
-        }
-    // gate-epilogue role: batch row b0 + r16 (clamped), hidden units u0 .. u0 + 3
-    const int u0 = 16 * wave + 4 * kq;
-    const int row = min((int)blockIdx.x * 16 + r16, B - 1);
-    const long rbase = (long)row * T;
-    f32x4 bh[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) bh[g] = *reinterpret_cast<const f32x4*>(bhh + g * HS + u0);
-    f32x4 hp = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    // h_{-1} = 0: the tile step 0 reads
-    for (int i = threadIdx.x; i < 3 * 16 * HX_LD / 2; i += 256) reinterpret_cast<unsigned*>(&hs[1][0][0][0])[i] = 0u;
-
-    // operands that do not depend on the recurrence: ring of D register sets, set j holds step s with s % D == j
-    f32x4 nx[D][3], nxm[D];
-    auto prefetch = [&](auto set_c, int step_l) {
-        constexpr int j = decltype(set_c)::value;
-#ifdef TG_LAB_STAMP
-        if ((tg_h64_lab_mode & 2) && step_l >= D) return;
-#endif
-        const int sl = step_l < T ? step_l : T - 1;          // past the end: re-read a valid address, never used
-        const int tau_l = dir ? T - 1 - sl : sl;
-        const float* gp = gi + dir * gi_ds + (rbase + tau_l) * (3 * HS) + u0;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) nx[j][g] = *reinterpret_cast<const f32x4*>(gp + g * HS);
-        if constexpr (DROP) nxm[j] = *reinterpret_cast<const f32x4*>(drop_mask + (rbase + tau_l) * (2 * HS) + dir * HS + u0);
-    };
-    // Outputs of a step are held in registers and stored in the NEXT step, right after that step's MFMAs are issued: a workgroup's 40
-    // 16-byte vector-memory instructions per step (6 stores + 4 prefetch loads per wave) take the CU's address unit several hundred cycles
-    // to accept (tools/h64_stamps.py: 530-1850 of a step's cycles were spent ISSUING them, between the gates and the barrier, i.e. on the
-    // recurrence's critical path); behind the MFMA issue they drain while the matrix pipe works.  The first flush (step 0) writes zeros to
-    // step 0's own addresses, overwritten in order by the real values one step later -- the number of outstanding operations stays static.
-    f32x4 d_h = zero, d_hm = zero, d_r = zero, d_z = zero, d_n = zero, d_hn = zero;
-    long d_o = (rbase + (dir ? T - 1 : 0)) * (2 * HS) + dir * HS + u0;
-    long d_s = (rbase + (dir ? T - 1 : 0)) * (4 * HS) + u0;
-    auto flush = [&]() {
-#ifdef TG_LAB_STAMP
-        if (tg_h64_lab_mode & 1) return;
-#endif
-        *reinterpret_cast<f32x4*>(Y + d_o) = d_h;
-        if constexpr (DROP) *reinterpret_cast<f32x4*>(y_drop + d_o) = d_hm;
-        if constexpr (SAVE) {
-            float* sp = save + dir * save_ds + d_s;
-            *reinterpret_cast<f32x4*>(sp) = d_r;
-            *reinterpret_cast<f32x4*>(sp + HS) = d_z;
-            *reinterpret_cast<f32x4*>(sp + 2 * HS) = d_n;
-            *reinterpret_cast<f32x4*>(sp + 3 * HS) = d_hn;
-        }
-    };
-    auto do_step = [&](auto set_c, int step) {
-        constexpr int j = decltype(set_c)::value;
-        const int tau = dir ? T - 1 - step : step;
-        f32x4 acc[3] = {zero, zero, zero};
-        const int rb = (step + 1) & 1;
-        TG_STAMP(step, 0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fb[3];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&hs[rb][s][r16][32 * ks + 8 * kq]);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = mma_x3(wa[g][ks], fb, acc[g], bf16m);
-        }
-        TG_STAMP(step, 1);                               // fragments read, MFMAs issued
-        __builtin_amdgcn_sched_barrier(0);
-        flush();                                         // the previous step's outputs: issued in the shadow of the MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        TG_STAMP(step, 2);                               // global stores issued
-        TG_FORCE(acc[0][3]); TG_FORCE(acc[1][3]); TG_FORCE(acc[2][3]);
-        TG_STAMP(step, 3);                               // MFMA results back
-        f32x4 h, r4, z4, n4, hn4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float hn = acc[2][q] + bh[2][q];
-            const float r = gate_sigmoid(nx[j][0][q] + acc[0][q] + bh[0][q]);
-            const float z = gate_sigmoid(nx[j][1][q] + acc[1][q] + bh[1][q]);
-            const float n = gate_tanh(nx[j][2][q] + r * hn);
-            h[q] = (1.f - z) * n + z * hp[q];
-            r4[q] = r; z4[q] = z; n4[q] = n; hn4[q] = hn;
-        }
-        hp = h;
-        const int wb = step & 1;
-        TG_FORCE(h[0]); TG_FORCE(h[1]); TG_FORCE(h[2]); TG_FORCE(h[3]);
-        TG_STAMP(step, 4);                               // gates done
-        split4_store(h, &hs[wb][0][r16][u0], &hs[wb][1][r16][u0], &hs[wb][2][r16][u0], bf16m);
-        TG_STAMP(step, 5);                               // h_t split and in LDS (stores complete)
-        d_h = h; d_r = r4; d_z = z4; d_n = n4; d_hn = hn4;
-        if constexpr (DROP) d_hm = h * nxm[j];
-        d_o = (rbase + tau) * (2 * HS) + dir * HS + u0;
-        d_s = (rbase + tau) * (4 * HS) + u0;
-        __builtin_amdgcn_sched_barrier(0);
-        prefetch(set_c, step + D);           // refill the set just consumed: D steps of compute hide the load latency
-        __builtin_amdgcn_sched_barrier(0);
-        TG_STAMP(step, 6);
-        lds_barrier();                       // h_t complete in LDS (and everybody is done with the buffer written next step)
-        TG_STAMP(step, 7);                   // past the barrier
-    };
-    static_for<D>([&](auto j) { prefetch(j, decltype(j)::value); });
-    lds_barrier();
-    for (int step0 = 0; step0 < T; step0 += D)               // T % D == 0 (host)
-        static_for<D>([&](auto j) { do_step(j, step0 + decltype(j)::value); });
-    flush();                                                 // the last step's outputs
-}
-
-// ---- forward, second form: the recurrence waves touch no global memory ------------------------------------------------------------
-// tools/h64_ablate.py: the six 16-byte output stores per step cost the recurrence 0.4-0.6 us of a 1.25 us step -- not bandwidth (24 KB per
-// step) but ISSUE: each store instruction of a wave covers 16 rows x 64 bytes (half cache lines), the CU's one address unit takes ~60
-// cycles per such instruction, four waves issue them at the same moment, and a wave that is issuing cannot run its dependent chain.  Here
-// the workgroup has EIGHT waves: waves 0-3 are the recurrence exactly as above, except that a step's operands (gi, dropout mask) come out
+// ---- forward: recurrence waves that touch no global memory + mover waves -----------------------------------------------------------
+// Round 2 (profiles/r2_h64_ablate.txt; the single-role kernel it studied was removed in round 4): six 16-byte output stores per step cost the
+// recurrence 0.4-0.6 us of a 1.25 us step -- not bandwidth (24 KB per step) but ISSUE: each store instruction of a wave covers 16 rows x 64
+// bytes (half cache lines), the CU's one address unit takes ~60 cycles per such instruction, four waves issue them at the same moment, and a
+// wave that is issuing cannot run its dependent chain.  So the workgroup has EIGHT waves: waves 0-3 are the recurrence (wave w owns hidden
+// units [16 w, 16 w + 16) of the three gates, weights resident as pre-split A fragments), whose step operands (gi, dropout mask) come out
 // of LDS and its outputs (h, h * mask, r, z, n, W_hn h + b) go into LDS; waves 4-7 move data: they store finished output records from LDS
 // to global memory -- each lane a 16-byte piece of a row's contiguous record, so a store instruction covers whole lines -- and stage the
 // operands of step t + 1 into LDS from registers loaded two steps earlier.  Both kinds of wave meet at the one LDS-only barrier per step
@@ -285,7 +139,7 @@ __global__ __launch_bounds__(256) void gru_h64_fwd_kernel(
 //     MFMA group cut the loop into basic blocks the scheduler could not interleave across.
 // LDS rows of the exchanged bf16 planes in the mover-wave kernels: unpadded (128 / 384 bytes), 16-byte slot index XOR (row & 7).  By the bank
 // model of MI355X_MICROARCH.md (ds_read_b128: four fixed 16-lane groups over 64 banks; ds_write_b64: 16 contiguous lanes over 32 banks) the
-// padded rows of the single-role kernels (144 / 400 bytes) serve every fragment read in 8 LDS cycles (2-way), these in 4; the 8-byte stores
+// padded rows these kernels started with (144 / 400 bytes) serve every fragment read in 8 LDS cycles (2-way), these in 4; the 8-byte stores
 // stay 2-way (hidden behind the store's register transfer).  The backward reads 72 fragments per step and workgroup: 288 LDS cycles saved.
 constexpr int HX2_LD = HS, DG2_LD = 3 * HS;
 __device__ __forceinline__ int swz_col(int row, int col) { return (((col >> 3) ^ (row & 7)) << 3) | (col & 7); }      // bf16 column -> swizzled column
@@ -614,102 +468,11 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
     lds_barrier();
 }
 
-// Backward through time, same ownership.  dh_{t} needs dgh_{t+1} @ W_hh (contraction over the 192 gate rows): taken transposed like
-// the forward, A = W_hh^T rows [16 wave, 16 wave + 16) (pre-split, 6 k-steps x 3 planes in registers), B = the previous step's
-// gate-gradient tile from LDS (three bf16 planes, double-buffered; zero for the first step).
-template <bool MASK, int D>
-__global__ __launch_bounds__(256) void gru_h64_bwd_kernel(
-    const float* __restrict__ dY, const float* __restrict__ dy_mask, const float* __restrict__ Y, const float* __restrict__ save,
-    long save_ds, const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh,
-    long dg_ds, int B, int T, int bf16m) {
-    __shared__ __attribute__((aligned(16))) __bf16 dgs[2][3][16][DG_LD];
-    const int dir = blockIdx.y;
-    const float* wt = dir ? wt1 : wt0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-
-    bf16x8 wa[6][3];
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
-        const float* p = wt + (long)(16 * wave + r16) * (3 * HS) + 32 * ks + 8 * kq;
-        split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[ks], bf16m);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) pin_fragment(wa[ks][s]);
-    }
-    const int u0 = 16 * wave + 4 * kq;
-    const int row = min((int)blockIdx.x * 16 + r16, B - 1);        // clamped: see the forward kernel
-    const long rbase = (long)row * T;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 dhz = zero;                           // dh * z of the step processed before (a carried copy of the LOADED z would keep the set's
-                                                // registers alive across its refill and cost a copy + wait at the end of every block)
-    for (int i = threadIdx.x; i < 3 * 16 * DG_LD / 2; i += 256) reinterpret_cast<unsigned*>(&dgs[1][0][0][0])[i] = 0u;
-
-    // ring of D register sets (see the forward kernel): dy (x mask), r, z, n, W_hn h + b_hn, h_prev of the set's step
-    f32x4 n_dy[D], n_mk[D], n_r[D], n_z[D], n_n[D], n_hn[D], n_hp[D];
-    float n_keep[D];
-    auto prefetch = [&](auto set_c, int step_l) {
-        constexpr int j = decltype(set_c)::value;
-        const int sl = step_l < T ? step_l : T - 1;
-        const int tau_l = dir ? sl : T - 1 - sl;
-        const int tp = dir ? tau_l + 1 : tau_l - 1;
-        const bool hasp = tp >= 0 && tp < T;
-        const long o = (rbase + tau_l) * (2 * HS) + dir * HS + u0;
-        const float* sp = save + dir * save_ds + (rbase + tau_l) * (4 * HS) + u0;
-        n_dy[j] = *reinterpret_cast<const f32x4*>(dY + o);
-        if constexpr (MASK) n_mk[j] = *reinterpret_cast<const f32x4*>(dy_mask + o);
-        n_r[j] = *reinterpret_cast<const f32x4*>(sp);
-        n_z[j] = *reinterpret_cast<const f32x4*>(sp + HS);
-        n_n[j] = *reinterpret_cast<const f32x4*>(sp + 2 * HS);
-        n_hn[j] = *reinterpret_cast<const f32x4*>(sp + 3 * HS);
-        n_hp[j] = *reinterpret_cast<const f32x4*>(Y + (rbase + (hasp ? tp : tau_l)) * (2 * HS) + dir * HS + u0);   // always a valid address
-        n_keep[j] = hasp ? 1.f : 0.f;
-    };
-    auto do_step = [&](auto set_c, int step) {
-        constexpr int j = decltype(set_c)::value;
-        const int tau = dir ? step : T - 1 - step;
-        f32x4 acc = zero;
-        const int rb = (step + 1) & 1;
-#pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {
-            bf16x8 fb[3];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&dgs[rb][s][r16][32 * ks + 8 * kq]);
-            acc = mma_x3(wa[ks], fb, acc, bf16m);
-        }
-        f32x4 g_r, g_z, g_n, g_nr;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float dyq = n_dy[j][q];
-            if constexpr (MASK) dyq *= n_mk[j][q];
-            const float r = n_r[j][q], z = n_z[j][q], n = n_n[j][q], hn = n_hn[j][q], hp = n_hp[j][q] * n_keep[j];
-            const float dh = dyq + acc[q] + dhz[q];                   // step 0: zero tile, dhz = 0
-            const float dn = dh * (1.f - z) * (1.f - n * n);
-            const float dz = dh * (hp - n) * z * (1.f - z);
-            const float dr = dn * hn * r * (1.f - r);
-            dhz[q] = dh * z;
-            g_r[q] = dr; g_z[q] = dz; g_n[q] = dn; g_nr[q] = dn * r;
-        }
-        const int wb = step & 1;
-        split4_store(g_r, &dgs[wb][0][r16][u0], &dgs[wb][1][r16][u0], &dgs[wb][2][r16][u0], bf16m);
-        split4_store(g_z, &dgs[wb][0][r16][HS + u0], &dgs[wb][1][r16][HS + u0], &dgs[wb][2][r16][HS + u0], bf16m);
-        split4_store(g_nr, &dgs[wb][0][r16][2 * HS + u0], &dgs[wb][1][r16][2 * HS + u0], &dgs[wb][2][r16][2 * HS + u0], bf16m);
-        float* gi_o = dgi + dir * dg_ds + (rbase + tau) * (3 * HS) + u0;
-        float* gh_o = dgh + dir * dg_ds + (rbase + tau) * (3 * HS) + u0;
-        *reinterpret_cast<f32x4*>(gi_o) = g_r; *reinterpret_cast<f32x4*>(gi_o + HS) = g_z; *reinterpret_cast<f32x4*>(gi_o + 2 * HS) = g_n;
-        *reinterpret_cast<f32x4*>(gh_o) = g_r; *reinterpret_cast<f32x4*>(gh_o + HS) = g_z; *reinterpret_cast<f32x4*>(gh_o + 2 * HS) = g_nr;
-        __builtin_amdgcn_sched_barrier(0);
-        prefetch(set_c, step + D);
-        __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();
-    };
-    static_for<D>([&](auto j) { prefetch(j, decltype(j)::value); });
-    lds_barrier();
-    for (int step0 = 0; step0 < T; step0 += D)               // T % D == 0 (host)
-        static_for<D>([&](auto j) { do_step(j, step0 + decltype(j)::value); });
-}
-
-// ---- backward, second form: recurrence waves + movers (see gru_h64_fwd2_kernel) ------------------------------------------------------
-// Per step the single-role kernel issues 7 loads and 6 stores of 16 bytes per lane; here waves 4-7 stage the step's operand record
+// ---- backward through time: recurrence waves + movers (see gru_h64_fwd2_kernel) ----------------------------------------------------
+// dh_t needs dgh_{t+1} @ W_hh (contraction over the 192 gate rows): taken transposed like the forward, A = W_hh^T rows [16 wave, 16 wave + 16)
+// (pre-split, 6 k-steps x 3 planes in registers), B = the previous step's gate-gradient tile from LDS (three bf16 planes, double-buffered; zero
+// for the first step).
+// A step needs 7 loads and 6 stores of 16 bytes per lane: waves 4-7 stage the step's operand record
 // [dy | mask | r | z | n | W_hn h + b | h_prev] into LDS two steps ahead and store the gate-gradient record [dr | dz | dn | dn r] of an
 // earlier step as the two contiguous 768-byte rows dgi = [dr, dz, dn], dgh = [dr, dz, dn r].
 // Round 4, as in the forward: fragments first and at priority, the movers late; everything of the gate arithmetic that does not need the
@@ -955,9 +718,6 @@ using namespace tg;
 
 extern "C" int tg_get_math_mode(void);
 
-// TG_H64_RING = 1 | 2 | 4: depth of the operand prefetch ring.  Default 1: measured at B = 128 / 256, T = 28 (tools/h64_probe.py,
-// profiles/r2_j_h64_probe.txt) one step of look-ahead is enough once the loop has no lane predicates (fwd 32 us), deeper rings cost
-// registers and code size for nothing (36 us at depth 2 and 4)
 // Batch rows per workgroup of the mover-wave kernels.  8 (the product's other eight batch columns repeat them) while that still leaves at most
 // one workgroup per CU: what bounds these kernels next to the step's dependent chain is the traffic of ONE CU's memory pipe -- a 16-row
 // workgroup moves 40 KB (forward) / 52 KB (backward) per step through it (tools/h64_ablate2.py, profiles/r4_g_h64_ablate2.txt: the backward
@@ -966,12 +726,6 @@ static int h64_rows(int B) {
     const char* e = getenv("TG_H64_ROWS");          // read per call: tests and probes compare both
     if (e && (atoi(e) == 8 || atoi(e) == 16)) return atoi(e);
     return 2 * cdiv(B, 8) <= 256 ? 8 : 16;
-}
-
-static int h64_ring() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TG_H64_RING"); v = e ? atoi(e) : 1; }
-    return v;
 }
 
 extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev,
@@ -983,21 +737,7 @@ extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const 
     TG_REQUIRE(aligned16(gi) && aligned16(w_hh_fwd) && aligned16(w_hh_rev) && aligned16(b_hh_fwd) && aligned16(b_hh_rev) && aligned16(y) &&
                (save == nullptr || aligned16(save)) && (drop_mask == nullptr || (aligned16(drop_mask) && aligned16(y_drop))) &&
                gi_dir_stride % 4 == 0 && save_dir_stride % 4 == 0, "tg_gru_h64_forward: operands must be 16-byte aligned");
-// prefetch ring depth: the deepest of 4 / 2 / 1 that divides T
-#define TG_H64_FWD(SAVE_, DROP_, D_)                                                                                                        \
-    hipLaunchKernelGGL((gru_h64_fwd_kernel<SAVE_, DROP_, D_>), dim3(cdiv(B, 16), 2), dim3(256), 0, (hipStream_t)stream, gi, (long)gi_dir_stride, \
-                       w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask, y_drop, B, T, tg_get_math_mode() == 1)
-#define TG_H64_FWD_D(D_)                                  \
-    do {                                                  \
-        if (save && drop_mask) TG_H64_FWD(true, true, D_);    \
-        else if (save) TG_H64_FWD(true, false, D_);           \
-        else if (drop_mask) TG_H64_FWD(false, true, D_);      \
-        else TG_H64_FWD(false, false, D_);                    \
-    } while (0)
-    // second form (movers): default; TG_H64_MOVERS=0 keeps the single-role kernel
-    const char* const movers_env = getenv("TG_H64_MOVERS");          // read per call: the parity tests run both forms in one process
-    const int movers = movers_env ? atoi(movers_env) : 1;
-    if (movers && T >= 3) {
+    {
 #define TG_H64_FWD2(SAVE_, DROP_, NS_, RW_)                                                                                                     \
     hipLaunchKernelGGL((gru_h64_fwd2_kernel<SAVE_, DROP_, NS_, RW_>), dim3(cdiv(B, RW_), 2), dim3(512), 0, (hipStream_t)stream, gi,           \
                        (long)gi_dir_stride, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, y, save, (long)save_dir_stride, drop_mask, y_drop, B, T)
@@ -1040,19 +780,9 @@ extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const 
 #undef TG_H64_FWD2
         return check_launch("tg_gru_h64_forward");
     }
-    const int ring = h64_ring();
-    if (T % 4 == 0 && ring >= 4) TG_H64_FWD_D(4);
-    else if (T % 2 == 0 && ring >= 2) TG_H64_FWD_D(2);
-    else TG_H64_FWD_D(1);
-#undef TG_H64_FWD_D
-#undef TG_H64_FWD
-    return check_launch("tg_gru_h64_forward");
 }
 
 #ifdef TG_LAB_STAMP
-extern "C" int tg_lab_h64_set_mode(int mode) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(tg::tg_h64_lab_mode), &mode, sizeof(int)) == hipSuccess ? 0 : 1;
-}
 extern "C" int tg_lab_h64_read_stamps(unsigned long long* out) {      // out: [64][8]
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(tg::tg_h64_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : 1;
 }
@@ -1066,17 +796,7 @@ extern "C" int tg_gru_h64_backward(const float* dy, const float* dy_mask, const 
     TG_REQUIRE(aligned16(dy) && aligned16(y) && aligned16(save) && aligned16(w_hh_t_fwd) && aligned16(w_hh_t_rev) && aligned16(dgi) &&
                aligned16(dgh) && (dy_mask == nullptr || aligned16(dy_mask)) && save_dir_stride % 4 == 0 && dg_dir_stride % 4 == 0,
                "tg_gru_h64_backward: operands must be 16-byte aligned");
-#define TG_H64_BWD(MASK_, D_)                                                                                                          \
-    hipLaunchKernelGGL((gru_h64_bwd_kernel<MASK_, D_>), dim3(cdiv(B, 16), 2), dim3(256), 0, (hipStream_t)stream, dy, dy_mask, y, save, \
-                       (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T, tg_get_math_mode() == 1)
-#define TG_H64_BWD_D(D_)                       \
-    do {                                       \
-        if (dy_mask) TG_H64_BWD(true, D_);     \
-        else TG_H64_BWD(false, D_);            \
-    } while (0)
-    const char* const movers_env = getenv("TG_H64_MOVERS");          // read per call: the parity tests run both forms in one process
-    const int movers = movers_env ? atoi(movers_env) : 1;
-    if (movers && T >= 3) {
+    {
 #define TG_H64_BWD2_RW(MASK_, NS_, RW_)                                                                                                        \
     hipLaunchKernelGGL((gru_h64_bwd2_kernel<MASK_, NS_, RW_>), dim3(cdiv(B, RW_), 2), dim3(512), 0, (hipStream_t)stream, dy, dy_mask, y, save, \
                        (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, B, T)
@@ -1111,11 +831,4 @@ extern "C" int tg_gru_h64_backward(const float* dy, const float* dy_mask, const 
 #undef TG_H64_BWD2_RW
         return check_launch("tg_gru_h64_backward");
     }
-    const int ring = h64_ring();
-    if (T % 4 == 0 && ring >= 4) TG_H64_BWD_D(4);
-    else if (T % 2 == 0 && ring >= 2) TG_H64_BWD_D(2);
-    else TG_H64_BWD_D(1);
-#undef TG_H64_BWD_D
-#undef TG_H64_BWD
-    return check_launch("tg_gru_h64_backward");
 }

@@ -243,6 +243,44 @@ __global__ __launch_bounds__(256) void d_head_fwd_kernel(const float* __restrict
 
 // backward of the head for d_logit (gradient w.r.t. the pre-sigmoid output): dy [B][T][2H] (both halves equal), and -- when
 // param_grads -- dW1 / db1 / dW2 / db2 accumulated with one atomic per workgroup and entry.
+// Deterministic form of the parameter gradients (tg_set_deterministic): ONE workgroup of 16 waves walks the clips (wave w: clips w, w + 16, ...),
+// the waves' sums meet in LDS in wave order, plain += into the gradient -- no atomics.  The input gradient dy is written as below.
+__global__ __launch_bounds__(1024) void d_head_bwd_det_kernel(const float* __restrict__ d_logit, const float* __restrict__ y,
+                                                              const float* __restrict__ l1, const float* __restrict__ w1,
+                                                              const float* __restrict__ w2, float* __restrict__ dy, float* __restrict__ dw1,
+                                                              float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2, int B,
+                                                              int T, int H) {
+    __shared__ float s_w1[16][64], s_w2[16][64], s_b[16][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float a_w1 = 0.f, a_w2 = 0.f, a_b1 = 0.f, a_b2 = 0.f;
+    for (int b = wv; b < B; b += 16) {
+        const float dl = d_logit[b];
+        a_b2 += dl;
+        if (lane < T) a_w2 += dl * l1[(long)b * T + lane];
+        for (int t = 0; t < T; ++t) {
+            const float dl1 = dl * w2[t];
+            a_b1 += dl1;
+            if (lane < H) {
+                const long o = ((long)b * T + t) * (2 * H) + lane;
+                const float dv = dl1 * w1[lane];
+                a_w1 += dl1 * (y[o] + y[o + H]);
+                dy[o] = dv;
+                dy[o + H] = dv;
+            }
+        }
+    }
+    s_w1[wv][lane] = a_w1; s_w2[wv][lane] = a_w2;
+    if (lane == 0) { s_b[wv][0] = a_b1; s_b[wv][1] = a_b2; }
+    __syncthreads();
+    if (wv == 0) {
+        float t1 = 0.f, t2 = 0.f, b1 = 0.f, b2 = 0.f;
+        for (int q = 0; q < 16; ++q) { t1 += s_w1[q][lane]; t2 += s_w2[q][lane]; b1 += s_b[q][0]; b2 += s_b[q][1]; }
+        if (lane < H) dw1[lane] += t1;
+        if (lane < T) dw2[lane] += t2;
+        if (lane == 0) { *db1 += b1; *db2 += b2; }
+    }
+}
+
 __global__ __launch_bounds__(256) void d_head_bwd_kernel(const float* __restrict__ d_logit, const float* __restrict__ y,
                                                          const float* __restrict__ l1, const float* __restrict__ w1,
                                                          const float* __restrict__ w2, float* __restrict__ dy, float* __restrict__ dw1,
@@ -321,6 +359,10 @@ int tg_d_head_bwd(const float* d_logit, const float* y, const float* l1, const f
     TG_REQUIRE(d_logit && y && l1 && w1 && w2 && dy && B > 0 && T > 0 && T <= 64 && H > 0 && H <= 64, "tg_d_head_bwd: bad arguments (T, H <= 64)");
     TG_REQUIRE((dw1 != nullptr) == (db1 != nullptr) && (dw1 != nullptr) == (dw2 != nullptr) && (dw1 != nullptr) == (db2 != nullptr),
                "tg_d_head_bwd: parameter gradients are all given or all NULL");
+    if (dw1 && deterministic()) {
+        hipLaunchKernelGGL(d_head_bwd_det_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_logit, y, l1, w1, w2, dy, dw1, db1, dw2, db2, B, T, H);
+        return check_launch("tg_d_head_bwd(deterministic)");
+    }
     hipLaunchKernelGGL(d_head_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, d_logit, y, l1, w1, w2, dy, dw1, db1, dw2, db2, B,
                        T, H);
     return check_launch("tg_d_head_bwd");

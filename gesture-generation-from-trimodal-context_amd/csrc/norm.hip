@@ -396,9 +396,11 @@ __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_bwd_kernel(
 __global__ __launch_bounds__(256) void bn2_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, long rows_per_group, int C,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
-                                                          double* __restrict__ part) {
+                                                          double* __restrict__ part, int det) {
     // dy == nullptr: (sum x, sum x^2); else (sum dz, sum dz xhat) with dz = dy act'(z), statistics of group blockIdx.y at mean/rstd + g C
+    // det (tg_set_deterministic): the threads' sums meet in LDS in thread order instead of through fp64 LDS atomics
     __shared__ double sh[2][256];
+    __shared__ double sh_det[256][8];
     const int g = blockIdx.y, P = gridDim.x;
     const long total4 = rows_per_group * C / 4;
     const long base4 = (long)g * total4;
@@ -433,8 +435,20 @@ __global__ __launch_bounds__(256) void bn2_partial_kernel(const float* __restric
             }
         }
     }
+    if (det) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { atomicAdd(&sh[0][c0 + q], s[q]); atomicAdd(&sh[1][c0 + q], ss[q]); }
+        for (int q = 0; q < 4; ++q) { sh_det[threadIdx.x][q] = s[q]; sh_det[threadIdx.x][4 + q] = ss[q]; }
+        __syncthreads();
+        if ((int)threadIdx.x < C) {                    // channel c lives in the threads t == (c >> 2) mod (C / 4), slot c & 3 (step % C == 0: fixed per thread)
+            const int c = threadIdx.x;
+            double a = 0.0, b = 0.0;
+            for (int t = c >> 2; t < 256; t += C / 4) { a += sh_det[t][c & 3]; b += sh_det[t][4 + (c & 3)]; }
+            sh[0][c] = a; sh[1][c] = b;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { atomicAdd(&sh[0][c0 + q], s[q]); atomicAdd(&sh[1][c0 + q], ss[q]); }
+    }
     __syncthreads();
     if ((int)threadIdx.x < C) {
         double* o = part + (((long)g * P + blockIdx.x) * 2) * C;
@@ -720,7 +734,7 @@ extern "C" int tg_bn2_train(const float* x, float* y, int32_t rows_per_group, in
     hipStream_t s = (hipStream_t)stream;
     const int P = bn2_parts(rows_per_group, C);
     hipLaunchKernelGGL(bn2_partial_kernel, dim3(P, groups), dim3(256), 0, s, x, (const float*)nullptr, (long)rows_per_group, C, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1.f, ws);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1.f, ws, deterministic() ? 1 : 0);
     int Pa;
     const double* tot = bn2_combine(ws, P, C, groups, &Pa, s);
     hipLaunchKernelGGL(bn2_fwd_apply_kernel, dim3(P, groups), dim3(256), 0, s, x, y, (long)rows_per_group, C, groups, tot, Pa, mean, rstd, running_mean,
@@ -736,7 +750,7 @@ extern "C" int tg_bn2_backward(const float* dy, const float* x, float* dx, int32
     TG_REQUIRE(ws_doubles >= tg_bn2_ws_doubles(rows_per_group, C, groups), "tg_bn2_backward: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int P = bn2_parts(rows_per_group, C);
-    hipLaunchKernelGGL(bn2_partial_kernel, dim3(P, groups), dim3(256), 0, s, x, dy, (long)rows_per_group, C, mean, rstd, gamma, beta, act_slope, ws);
+    hipLaunchKernelGGL(bn2_partial_kernel, dim3(P, groups), dim3(256), 0, s, x, dy, (long)rows_per_group, C, mean, rstd, gamma, beta, act_slope, ws, deterministic() ? 1 : 0);
     int Pa;
     const double* tot = bn2_combine(ws, P, C, groups, &Pa, s);
     hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3(P, groups), dim3(256), 0, s, dy, x, dx, (long)rows_per_group, C, groups, tot, Pa, mean, rstd, gamma, beta,

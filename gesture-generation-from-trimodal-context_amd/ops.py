@@ -343,6 +343,17 @@ def get_math_mode():
 TN_TWO_PASS_ROWS = 32768     # reductions at least this long combine their partials in fp64 (deterministic) instead of atomics
 
 
+def set_deterministic(on):
+    """tg_set_deterministic: fixed-order combines everywhere (no float atomics) -- two runs from the same state are bit-identical.  Here:
+    every weight-gradient product takes the two-pass workspace and its bias gradient goes through colsum; the engines take the generic
+    forms of the two fused backward kernels that combine by atomics (speaker_bwd_supported, engine.DiscriminatorEngine.backward)."""
+    call("tg_set_deterministic", int(bool(on)))
+
+
+def deterministic():
+    return bool(_lib.load().tg_get_deterministic())
+
+
 def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None):
     _f32(dY, "dY"); _f32(dW, "dW")
     assert dY.dim() == 2 and dY.stride(1) == 1 and dY.shape[0] == A.M, (dY.shape, A.M)
@@ -353,7 +364,7 @@ def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None):
     if (M - 1) * dY.stride(0) + N - 1 >= _room(dY):
         raise ValueError("gemm_tn: dY exceeds its tensor")
     ws, nws = None, 0
-    if M >= TN_TWO_PASS_ROWS or (out_kw > 0 and M >= 1024 and N * A.K >= 8192):
+    if M >= TN_TWO_PASS_ROWS or (out_kw > 0 and M >= 1024 and N * A.K >= 8192) or deterministic():
         # two-pass (partial tiles + fp64 combine): long reductions for accuracy, and every conv-layout output (out_kw > 0) of >= 8 K entries
         # (the discriminator's 16 x 81 ... 8 x 24 conv gradients are a few hundred atomics: the combine launch cost more than it saved):
         # the permuted (Co, Ci, kw) scatter makes the one-pass float atomics uncoalesced (measured 224 -> 39 us on the audio
@@ -370,10 +381,25 @@ def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None):
     return q, ws
 
 
+def _det_bias(problems):
+    """Deterministic mode: the kernels combine bias gradients by float atomics, so they are taken out of the products and summed by
+    colsum (one workgroup per 64 columns, fixed order)."""
+    if not deterministic():
+        return problems
+    out = []
+    for p in problems:
+        if p.get("dbias") is not None:
+            colsum(p["dY"], p["dbias"], accumulate=True)
+            p = dict(p, dbias=None)
+        out.append(p)
+    return out
+
+
 def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
     """dW[n, perm(k)] += sum_m dY[m, n] * A(m, k); dbias[n] += sum_m dY[m, n] when given.
     dY: 2-D view [M, N]; dW: contiguous, N rows of K floats."""
-    q, ws = _tn_problem(dY, A, dW, out_kw=out_kw, dbias=dbias)
+    p, = _det_bias([dict(dY=dY, A=A, dW=dW, out_kw=out_kw, dbias=dbias)])
+    q, ws = _tn_problem(**p)
     call("tg_gemm_tn_group", C.byref(q), 1, _stream())
     return dW
 
@@ -381,6 +407,7 @@ def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
 def gemm_tn_group(problems):
     """Several independent weight gradients in ONE launch.  problems: list of dicts with the arguments of gemm_tn."""
     assert 1 <= len(problems) <= _lib.MAX_GROUP
+    problems = _det_bias(problems)
     keep = []
     arr = (_lib.TnProblem * len(problems))(*[_tn_problem(keep=keep, **p)[0] for p in problems])
     call("tg_gemm_tn_group", arr, len(problems), _stream())
@@ -1059,7 +1086,8 @@ def speaker_fwd(table, vid, w1, b1, wmu, bmu, wlv, blv, eps, rep=None, T=0, draw
 
 
 def speaker_bwd_supported(nb):
-    return SPEAKER_FUSED and nb <= _lib.load().tg_speaker_bwd_max_rows()
+    # (deterministic mode: the fused kernel scatters the speaker-embedding gradient with float atomics -> the generic chain of launches)
+    return SPEAKER_FUSED and nb <= _lib.load().tg_speaker_bwd_max_rows() and not deterministic()
 
 
 def speaker_bwd(dz, d_mu, d_logvar, logvar, eps, zc, se, vid, w1, wmu, wlv, dw1, db1, dwmu, dbmu, dwlv, dblv, dtable):

@@ -27,6 +27,15 @@ extern "C" {
 #define TG_ABI_VERSION 5
 
 int tg_version(void);
+
+/* Deterministic mode (ABI 5).  on != 0: every combine across workgroups runs in a fixed order -- weight-gradient splits through the two-pass
+ * fp64 reduce (the caller passes a workspace for every problem and takes bias gradients through tg_colsum), embedding scatters with one
+ * writer per table row, the discriminator head's parameter gradients and tg_colsum by one workgroup, BatchNorm partial sums in thread order --
+ * so two runs from the same state give bit-identical results (the reference on CPU is reproducible given a seed; float atomics are not).
+ * The fused discriminator front-end backward (tg_d_preconv_bwd) and the fused speaker backward (tg_speaker_bwd) combine by float atomics and
+ * are not to be called in this mode (the host mirror takes their generic forms).  Process-wide, like tg_set_math_mode. */
+int tg_set_deterministic(int32_t on);
+int tg_get_deterministic(void);
 const char* tg_last_error(void);
 
 /* Math mode of the GEMM-shaped kernels (process-wide, like cublasSetMathMode):

@@ -204,6 +204,24 @@ def wav_preacts(st, audio, prefix="audio_encoder.feat_extractor"):
     return outs
 
 
+# Test aids (tests/test_trajectory_gpu.py), as wav_gate_override above but for the text encoder's ReLUs, site names "<tag>.relu1|2|3" with
+# tag = e.g. "g2.tcn0": relu_gate_log (a dict) collects every site's pre-activation; relu_gate_override {site: (flat indices, bool sides)}
+# puts the listed gates on the GIVEN side.  None = off.
+relu_gate_log = None
+relu_gate_override = None
+
+
+def _relu_gated(x, site):
+    if relu_gate_log is not None:
+        relu_gate_log[site] = x.detach()
+    ov = None if relu_gate_override is None else relu_gate_override.get(site)
+    if ov is None or ov[0].numel() == 0:
+        return torch.relu(x)
+    gate = (x > 0).reshape(-1).clone()
+    gate[ov[0]] = ov[1]
+    return torch.where(gate.view(x.shape), x, torch.zeros_like(x))
+
+
 def tcn_block(x, st, prefix, dilation, p_drop, training, rand, tag):
     """TemporalBlock (model/tcn.py:16-46) on (B,C,T): two weight-normed causal dilated k=2 convs,
     each ReLU + dropout, then relu(out + x).  Causal = pad d both sides, chomp the last d."""
@@ -213,10 +231,10 @@ def tcn_block(x, st, prefix, dilation, p_drop, training, rand, tag):
         w = weight_norm_weight(st[f"{prefix}.{name}.weight_g"], st[f"{prefix}.{name}.weight_v"])
         out = F.conv1d(out, w, st[f"{prefix}.{name}.bias"], stride=1, padding=dilation, dilation=dilation)
         out = out[:, :, :T]
-        out = torch.relu(out)
+        out = _relu_gated(out, f"{tag}.relu{ci + 1}")
         if training:
             out = out * rand.keep_mask(f"{tag}.drop{ci + 1}", tuple(out.shape), p_drop, out.dtype)
-    return torch.relu(out + x)
+    return _relu_gated(out + x, f"{tag}.relu3")
 
 
 def text_encoder(st, in_text, n_layers, p_drop, training, rand, tag, prefix="text_encoder"):

@@ -161,6 +161,27 @@ def wav_gate_sides(tape, preacts):
     return out
 
 
+def tcn_gate_sides(tape, gate_log, call, B, tag="g2", rel_window=5e-6):
+    """ReLU gates of the text encoder, HIP path against the fp64 oracle, for the stacked generator call number `call` (rows call * B ..) whose
+    oracle run logged its pre-activations under `tag` (oracle.relu_gate_log).  Returns ({site: (flat indices, HIP sides)} for the gates that
+    differ -- the form oracle.relu_gate_override takes -- and [(site, flips, largest |pre-activation| among them relative to the site's
+    max, window)]).  A gate behind a dropped element (dropout scale 0) cannot be observed and does not matter: skipped."""
+    sides, report = {}, []
+    rows = slice(call * B, (call + 1) * B)
+    for i, blk in enumerate(tape["tcn"]):
+        for k, (act, mask) in enumerate(((blk["o0"], blk["m0"]), (blk["o1"], blk["m1"]), (blk["y"], None)), start=1):
+            site = f"{tag}.tcn{i}.relu{k}"
+            pre = gate_log[site]                                                   # (B, C, T) fp64
+            mine = act[rows].detach().double().cpu().transpose(1, 2)
+            valid = torch.ones_like(pre, dtype=torch.bool) if mask is None else (mask[rows].detach().cpu().transpose(1, 2) > 0)
+            flipped = (valid & ((mine > 0) != (pre > 0))).reshape(-1)
+            idx = flipped.nonzero().view(-1)
+            if idx.numel():
+                sides[site] = (idx, mine.reshape(-1)[idx] > 0)
+                report.append((site, int(idx.numel()), float(pre.reshape(-1)[idx].abs().max() / pre.abs().max()), rel_window))
+    return sides, report
+
+
 MAX_GATE_FLIPS = 8
 NEAR_TIE_FRESH, NEAR_TIE_AFTER_FLIP = 2e-6, 5e-4
 

@@ -811,15 +811,14 @@ def test_bf16_math_mode_tier(pkg, dev):
         ops.set_math_mode(2)
 
 
-@pytest.mark.parametrize("B,movers,T,rows", [(5, 1, 28, 8), (70, 1, 28, 8), (256, 1, 28, 8), (70, 1, 28, 16), (256, 1, 28, 16), (70, 0, 28, 0), (256, 0, 28, 0),
-                                             (33, 1, 7, 8), (33, 1, 3, 16), (33, 1, 3, 8), (17, 1, 2, 8), (1100, 1, 5, 0)])
-def test_gru_h64_stack_with_fused_dropout(pkg, dev, B, movers, T, rows, monkeypatch):
+@pytest.mark.parametrize("B,T,rows", [(5, 28, 8), (70, 28, 8), (256, 28, 8), (70, 28, 16), (256, 28, 16), (33, 7, 8), (33, 3, 16), (33, 3, 8), (17, 2, 8),
+                                      (17, 2, 16), (9, 1, 8), (1100, 5, 0)])
+def test_gru_h64_stack_with_fused_dropout(pkg, dev, B, T, rows, monkeypatch):
     """The discriminator's GRU stack (4 layers, H = 64) with injected inter-layer dropout masks against a layer-by-layer
     nn.GRU fp64 reference that multiplies the same masks in between: forward output, input gradient, every weight gradient.  The
-    masks ride inside the recurrence kernels (y_drop = y * mask in the forward, dy * mask in the backward load).  Both forms of the
-    kernels (mover waves -- the default -- and the single-role workgroup, TG_H64_MOVERS=0), both workgroup sizes of the mover-wave kernels (8
-    and 16 batch rows, TG_H64_ROWS; 0 = the library's choice: 16 above 1 024 rows), odd and very short sequences, ragged batch tiles."""
-    monkeypatch.setenv("TG_H64_MOVERS", str(movers))
+    masks ride inside the recurrence kernels (y_drop = y * mask in the forward, dy * mask in the backward load).  Both workgroup sizes of the
+    kernels (8 and 16 batch rows, TG_H64_ROWS; 0 = the library's choice: 16 above 1 024 rows), odd and very short sequences (down to one
+    step), ragged batch tiles."""
     if rows:
         monkeypatch.setenv("TG_H64_ROWS", str(rows))
     else:
