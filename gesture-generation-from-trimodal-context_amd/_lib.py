@@ -35,14 +35,6 @@ class TnProblem(C.Structure):
                 ("dbias", P), ("ws", P), ("ws_floats", I64)]
 
 
-class NtPlanesProblem(C.Structure):
-    """struct tg_gemm_nt_planes_problem"""
-    _fields_ = [("A", P), ("a_plane_stride", I64), ("a_rows", I32), ("cwp", I32), ("a_batch_rows", I64), ("rows_in", I32), ("rows_out", I32),
-                ("row_step", I32), ("shift", I32), ("dil", I32), ("taps", I32), ("B", P), ("b_plane_stride", I64), ("bias", P), ("C", P),
-                ("c_batch_stride", I64), ("c_row_stride", I64), ("c_rows_out", I32), ("M", I32), ("N", I32), ("act_slope", F32),
-                ("accumulate", I32), ("out_scale", P)]
-
-
 MAX_GROUP = 8
 
 # name -> argtypes (all return int); mirrors include/trimodal_hip.h one to one
@@ -50,7 +42,6 @@ SIGNATURES = {
     "tg_gemm_nt": [WP, P, I64, P, P, I64, I64, I32, I32, I32, F32, I32, P],
     "tg_gemm_nt_group": [C.POINTER(NtProblem), I32, P],
     "tg_gemm_tn_group": [C.POINTER(TnProblem), I32, P],
-    "tg_gemm_nt_planes_group": [C.POINTER(NtPlanesProblem), I32, P],
     "tg_split3_planes": [P, I64, I32, I32, P, I32, I64, P],
     "tg_gemm_tn": [P, I64, WP, P, I64, I32, I32, I32, P, P, I64, P],
     "tg_colsum": [P, I64, I32, I32, P, I32, P],
@@ -85,7 +76,7 @@ SIGNATURES = {
     "tg_embed_gather_drop": [P, P, P, I32, I32, I32, F32, P, U32, P],
     "tg_d_preconv_bwd": [P] * 26 + [I32, P, I64, I32, I32, P],
     "tg_d_preconv_fwd": [P] * 27 + [I64, I32, I32, F32, F32, P],
-    "tg_iter_head": [P, P, P, P, P, P, I64, I32, I32, I32, I32, I32, P, P, P, P, I32, P, U32, P, P],
+    "tg_iter_head": [P, P, P, P, P, P, I64, I32, I32, I32, I32, I32, P, P, P, P, I32, P, U32, P, P, P],
     "tg_act_mask_bwd_drop": [P, P, F32, P, U32, I64, F32, P, I64, P],
     "tg_act_mask_bwd2_drop": [P, P, P, F32, P, U32, I64, F32, P, P, I64, P],
     "tg_mul": [P, P, P, I64, P],

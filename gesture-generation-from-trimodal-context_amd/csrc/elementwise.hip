@@ -495,7 +495,8 @@ __global__ __launch_bounds__(1024) void iter_head_kernel(uint64_t* rng_a, uint64
                                                          float* __restrict__ pre, long pre_ld, int B, int T, int D, int n_pre, int copies,
                                                          const int64_t* __restrict__ text, int64_t* __restrict__ text_s,
                                                          const int64_t* __restrict__ vid, int64_t* __restrict__ vid_s, int permute_last,
-                                                         const int64_t* __restrict__ perm_in, uint32_t perm_site, int64_t* __restrict__ perm_out) {
+                                                         const int64_t* __restrict__ perm_in, uint32_t perm_site, int64_t* __restrict__ perm_out,
+                                                         float* __restrict__ target_copy) {
     if (blockIdx.x == 0) {
         __shared__ uint64_t keys[1024];
         __shared__ int perm_sh[1024];
@@ -556,6 +557,10 @@ __global__ __launch_bounds__(1024) void iter_head_kernel(uint64_t* rng_a, uint64
     if (text_s) {
         const long pt = (long)B * T, nt = pt * copies;
         for (long i = tid; i < nt; i += nth) text_s[i] = text[i % pt];
+    }
+    if (target_copy) {
+        const long nc = (long)B * T * D;
+        for (long i = tid; i < nc; i += nth) target_copy[i] = target[i];
     }
 }
 // VEC: n % 4 == 0 and 16-byte aligned pointers (checked by the launcher): one 16-byte access per array and Philox draw instead of four
@@ -951,7 +956,8 @@ int tg_iter_begin(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_
 }
 int tg_iter_head(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, const float* target, float* pre_stacked, int64_t pre_ld,
                  int32_t B, int32_t T, int32_t D, int32_t n_pre, int32_t copies, const int64_t* text, int64_t* text_stacked, const int64_t* vid,
-                 int64_t* vid_stacked, int32_t permute_last, const int64_t* perm_in, uint32_t perm_site, int64_t* perm_out, void* stream) {
+                 int64_t* vid_stacked, int32_t permute_last, const int64_t* perm_in, uint32_t perm_site, int64_t* perm_out, float* target_copy,
+                 void* stream) {
     TG_REQUIRE(target && pre_stacked && B > 0 && T > 0 && D > 0 && n_pre >= 0 && copies >= 1 && pre_ld >= D + 1, "tg_iter_head: bad arguments");
     TG_REQUIRE((text == nullptr) == (text_stacked == nullptr) && (vid == nullptr) == (vid_stacked == nullptr), "tg_iter_head: text / vid and their stacked outputs go together");
     TG_REQUIRE(!vid || B <= 1024, "tg_iter_head: B=%d speaker ids must fit one workgroup (<= 1024)", B);
@@ -959,7 +965,7 @@ int tg_iter_head(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t
     const long n = (long)B * T * (D + 1) * copies;
     const int blocks = 1 + (int)((n + 4095) / 4096 < 255 ? (n + 4095) / 4096 : 255);
     hipLaunchKernelGGL(iter_head_kernel, dim3(blocks < 2 ? 2 : blocks), dim3(1024), 0, ST, rng_a, rng_b, adam_step_a, adam_step_b, target, pre_stacked, (long)pre_ld, B, T, D,
-                       n_pre, copies, text, text_stacked, vid, vid_stacked, permute_last, perm_in, perm_site, perm_out);
+                       n_pre, copies, text, text_stacked, vid, vid_stacked, permute_last, perm_in, perm_site, perm_out, target_copy);
     return check_launch("tg_iter_head");
 }
 int tg_rng_advance(uint64_t* rng_state, void* stream) {

@@ -757,9 +757,7 @@ static int nt_launch(NtGroup& g, hipStream_t s) {
         const int wgs = fam == 1 ? nt_layout(g, 128, 32) : nt_layout(g, 64, 64);
         const dim3 grid(wgs);
         const bool deep = wgs < 1024 && Kx >= 256;        // operand ring of 4 k-steps: small grid, long reduction (see the kernel)
-        static const int mid_ring = [] { const char* e = getenv("TG_NT_NARROW_RING"); return e ? atoi(e) : 1; }();      // lab switch: ring depth of the chip-filling narrow grids with K >= 64
-        static const int ksplit_on = [] { const char* e = getenv("TG_NT_KSPLIT"); return e ? atoi(e) : 1; }();
-        if (fam == 1 && vec && ksplit_on && wgs < 256 && Kx >= 256) {
+        if (fam == 1 && vec && wgs < 256 && Kx >= 256) {
             // few rows, long reduction: one 32 x 32 tile per workgroup, its four waves split K (see the kernel)
             const dim3 grid4(nt_layout(g, 32, 32));
             hipLaunchKernelGGL((gemm_nt_kernel<true, 1, 1, 2, 4>), grid4, dim3(256), 0, s, g);
@@ -767,8 +765,6 @@ static int nt_launch(NtGroup& g, hipStream_t s) {
         }
         if (fam == 1) {
             if (vec && deep) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 4>), grid, dim3(256), 0, s, g);
-            else if (vec && mid_ring == 2 && Kx >= 64) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 2>), grid, dim3(256), 0, s, g);
-            else if (vec && mid_ring == 4 && Kx >= 64) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 4>), grid, dim3(256), 0, s, g);
             else if (vec)    hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 1>), grid, dim3(256), 0, s, g);
             else             hipLaunchKernelGGL((gemm_nt_kernel<false, 4, 1, 1>), grid, dim3(256), 0, s, g);
         } else {
@@ -916,10 +912,8 @@ static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int group_ti
         // grouped launch, atomic combine: the group as a whole fills the chip, so each problem needs fewer row splits -- and every split
         // costs one float atomic per output element (memory-side, ~1.3 TB/s chip-wide: 14 splits of the four GRU weight gradients
         // were 91 MB of atomics, a third of the launch).  Aim at ~768 workgroups for the group, at least 256 rows per split.
-        static int target_wgs = -1;          // lab switch TG_TN_WGS: workgroups aimed at per grouped launch
-        if (target_wgs < 0) { const char* e = getenv("TG_TN_WGS"); target_wgs = e ? atoi(e) : 768; }      // sweep of the final round-2 build: 768 beats 512 / 1024 / 1536 / 2048 by ~0.5 % of the iteration
-        static int target_wgs22 = -1;        // the 64 x 64 tile's own target (two workgroups per CU by LDS: 512 slots)
-        if (target_wgs22 < 0) { const char* e = getenv("TG_TN_WGS22"); target_wgs22 = e ? atoi(e) : 2000; }      // same-box sweep of the final build: 768 / 1200 / 2000 / 3200 -> 5.467 / 5.444 / 5.434 / 5.453 ms per iteration
+        constexpr int target_wgs = 768;      // workgroups aimed at per grouped launch (sweep of the final round-2 build: 768 beats 512 / 1024 / 1536 / 2048 by ~0.5 % of the iteration)
+        constexpr int target_wgs22 = 2000;   // the 64 x 64 tile's own target (two workgroups per CU by LDS; same-box sweep 768 / 1200 / 2000 / 3200 -> 5.467 / 5.444 / 5.434 / 5.453 ms per iteration)
         int s2 = cdiv(bn == 64 ? target_wgs22 : target_wgs, group_tiles);
         const int cap = cdiv(q.M, 256);
         if (s2 > cap) s2 = cap;

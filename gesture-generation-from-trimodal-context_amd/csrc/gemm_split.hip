@@ -59,7 +59,8 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[SPLITS]) {
 
 // C(m, n) = act(sum_k A(m,k) * Bw[n][k] + bias[n]) (+ C).  A: fp32 row window (vectorisable layout: checked by the caller),
 // Bw: fp32 [N][ldb].  Same contract as gemm_nt_big_kernel (gemm.hip).
-// RING = register sets of global loads in flight (slabs fetched ahead): 1 = the next slab only, 2 = two slabs ahead (+ 4 (TM + TN)
+// RING = register sets of global loads in flight (slabs fetched ahead): 1 = the next slab only (the only depth still instantiated: two slabs
+// ahead measured no gain on any shape of the iteration and was dropped from the menu in round 4), 2 = two slabs ahead (+ 4 (TM + TN)
 // VGPRs; the loads of a slab then have two MFMA sections to land instead of one)
 // OCC = waves per SIMD the register allocation is held to (HIP's second launch-bounds argument; 1 = unconstrained)
 // ABL (lab builds only, -DTG_LAB_ABLATE, tools/nt_ablate.py; results are WRONG by construction): bit 0 drops the MFMAs, bit 1 the split
@@ -668,14 +669,11 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
     }
     for (int i = g.n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
     const dim3 grid(wg);
-    static const int ring = [] { const char* e = getenv("TG_NT_RING"); return e ? atoi(e) : 1; }();      // slabs of loads in flight (1 or 2)
     // the 128-row tiles held to 3 (128 x 96: 180 -> 162 VGPRs) / 4 (128 x 64) waves per SIMD: three workgroups per CU instead of two, 119.7 ->
-    // 116.5 us on [13056 x 900 x 600], 6.29 -> 6.24 ms per iteration (TG_NT_OCC=0 keeps the unconstrained allocation)
-    static const int occ = [] { const char* e = getenv("TG_NT_OCC"); return e ? atoi(e) : 1; }();
+    // 116.5 us on [13056 x 900 x 600], 6.29 -> 6.24 ms per iteration
 #define TG_SPLIT(TM_, TN_, SP_, DB_)                                                                                   \
     do {                                                                                                               \
-        if (ring == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_, 2>), grid, dim3(256), 0, s, g);    \
-        else if (occ && TM_ == 4 && SP_ == 3) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_, 1, (TM_ == 4 && SP_ == 3) ? (TN_ == 3 ? 3 : 4) : 1>), grid, dim3(256), 0, s, g); \
+        if (TM_ == 4 && SP_ == 3) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_, 1, (TM_ == 4 && SP_ == 3) ? (TN_ == 3 ? 3 : 4) : 1>), grid, dim3(256), 0, s, g); \
         else hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, SP_, DB_, 1>), grid, dim3(256), 0, s, g);              \
     } while (0)
 #define TG_SPLIT_MENU(SP_)                                              \
@@ -687,14 +685,14 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
     } while (0)
     // fast addressing (see the kernel's FAST note): decided for the group as a whole
     static const int fast_on = [] { const char* e = getenv("TG_NT_FAST"); return e ? atoi(e) : 1; }();
-    bool fast = fast_on != 0 && g_math_mode == 0 && ring >= 1 && ring <= 2;
+    bool fast = fast_on != 0 && g_math_mode == 0;
     for (int i = 0; i < g.n && fast; ++i) fast = nt_fast_ok(g.p[i]);
     if (fast) {
 #define TG_FAST(TM_, TN_, DB_, R_, O_) hipLaunchKernelGGL((gemm_nt_split_kernel<TM_, TN_, 3, DB_, R_, O_, 0, true>), grid, dim3(256), 0, s, g)
-        if (tl.tm == 4 && tl.tn == 3) { if (ring == 2) TG_FAST(4, 3, 0, 2, 3); else TG_FAST(4, 3, 0, 1, 3); }
-        else if (tl.tm == 4 && tl.tn == 2) { if (ring == 2) TG_FAST(4, 2, 0, 2, 4); else TG_FAST(4, 2, 0, 1, 4); }
-        else if (tl.tm == 2 && tl.tn == 3) { if (ring == 2) TG_FAST(2, 3, 1, 2, 1); else TG_FAST(2, 3, 1, 1, 1); }
-        else { if (ring == 2) TG_FAST(2, 2, 1, 2, 1); else TG_FAST(2, 2, 1, 1, 1); }
+        if (tl.tm == 4 && tl.tn == 3) TG_FAST(4, 3, 0, 1, 3);
+        else if (tl.tm == 4 && tl.tn == 2) TG_FAST(4, 2, 0, 1, 4);
+        else if (tl.tm == 2 && tl.tn == 3) TG_FAST(2, 3, 1, 1, 1);
+        else TG_FAST(2, 2, 1, 1, 1);
 #undef TG_FAST
         return check_launch("tg_gemm_nt(split, fast addressing)");
     }

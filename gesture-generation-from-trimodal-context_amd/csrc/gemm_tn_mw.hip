@@ -360,7 +360,7 @@ bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid) {
     for (int i = 0; i < g.n; ++i) {
         TnProb& p = g.p[i];
         const Win& A = p.A;
-        static const int min_k = [] { const char* e = getenv("TG_TN_MW_MINK"); return e ? atoi(e) : 100; }();      // K = 108: the GRU's first layer (68 % of a 160-wide tile)
+        constexpr int min_k = 100;      // K = 108: the GRU's first layer (68 % of a 160-wide tile)
         if (!p.vec_y || !p.vec_a || p.N % 4 != 0 || A.K % 4 != 0 || p.N < 150 || A.K < min_k || p.M < 2048) return false;
         if (p.dbias && A.K % BK == 0) return false;                               // no padding column for the ones trick
         if (p.partial) return false;                                              // two-pass combines keep their own split plan (gemm.hip tn_plan)

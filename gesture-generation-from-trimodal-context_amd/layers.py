@@ -417,19 +417,12 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     for l in range(n_layers):
         Kin = cur.shape[2]
         gi = empty(2, B, T, 3 * H, like=x)
-        if ops.GEMM_PLANES_BOTH and B * T >= 8192 and H > 64 and Kin >= 256:
-            # pre-split operands (many-row projections of the stacked forward): the layer input is split into bf16 x 3 planes once (not by each of
-            # the column tiles that stage it), the weights once per optimiser step (WeightPrep); mover waves then DMA both into LDS
-            a_pl = ops.split3_planes(cur.view(B * T, Kin))
-            ops.gemm_nt_planes_group([dict(A=a_pl, Bp=weight_planes(P[f"{prefix}.weight_ih_l{l}{sfx}"]), bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
-                                           out=gi[d].view(B * T, 3 * H)) for d, sfx in enumerate(("", "_reverse"))])
-        else:
-            a_win = Win.plain(cur.view(B * T, Kin))
-            # many-row projections (the stacked forward): pre-split weights let the mover-wave kernel take them (csrc/gemm_mw.hip)
-            wpl = (lambda w: weight_planes(w)) if (ops.GEMM_PLANES and B * T >= 8192 and H > 64) else (lambda w: None)
-            ops.gemm_nt_group([dict(A=a_win, W=P[f"{prefix}.weight_ih_l{l}{sfx}"], bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
-                                    out=gi[d].view(B * T, 3 * H), w_planes=wpl(P[f"{prefix}.weight_ih_l{l}{sfx}"]))
-                               for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
+        a_win = Win.plain(cur.view(B * T, Kin))
+        # many-row projections (the stacked forward): pre-split weights let the mover-wave kernel take them (csrc/gemm_mw.hip)
+        wpl = (lambda w: weight_planes(w)) if (ops.GEMM_PLANES and B * T >= 8192 and H > 64) else (lambda w: None)
+        ops.gemm_nt_group([dict(A=a_win, W=P[f"{prefix}.weight_ih_l{l}{sfx}"], bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
+                                out=gi[d].view(B * T, 3 * H), w_planes=wpl(P[f"{prefix}.weight_ih_l{l}{sfx}"]))
+                           for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
         y = empty(B, T, 2 * H, like=x)
         sv = empty(2, B, T, 4 * H, like=x) if save else None
         whh = (P[f"{prefix}.weight_hh_l{l}"], P[f"{prefix}.weight_hh_l{l}_reverse"])
@@ -461,8 +454,8 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     return cur, tape
 
 
-KSPLIT_DX = int(__import__("os").environ.get("TG_KSPLIT_DX", "2"))      # K pieces per direction of the first GRU layer's input gradient (0: off)
-DROP_REGEN = __import__("os").environ.get("TG_TCN_DROP_REGEN", "1") != "0"      # dropout masks regenerated by their consumers (ops.Drop) at big batches
+KSPLIT_DX = 2      # K pieces per direction of the first GRU layer's input gradient (0: off)
+DROP_REGEN = True      # dropout masks regenerated by their consumers (ops.Drop) at big batches
 
 
 class Fork:

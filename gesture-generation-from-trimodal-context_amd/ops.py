@@ -5,7 +5,6 @@ Shape / dtype / bounds checks live in this layer so that a wrong call raises in 
 the GPU (kernels themselves only guard their own tile edges).
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -175,19 +174,16 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
     return q
 
 
-NT_EPILOGUE_EXT = os.environ.get("TG_NT_EPILOGUE_EXT", "1") != "0"
-
-
 def nt_ext_supported(A: Win, W, out, **kw):
     """True when gemm_nt(A, W, ..., out) would run on a kernel that implements the gate / res / out2 epilogue extensions."""
-    if not NT_EPILOGUE_EXT or not out.is_cuda:
+    if not out.is_cuda:
         return False
     q = _nt_problem(A, W, None, out, **kw)
     return bool(_lib.load().tg_gemm_nt_ext_supported(C.byref(q)))
 
 
 def set_nt_mover_waves(on):
-    """True / False: force the mover-wave kernel on / off; None: back to the environment default (TG_NT_MW, on)."""
+    """True / False: force the mover-wave kernel on / off; None: back to the default (on)."""
     call("tg_set_nt_mover_waves", -1 if on is None else int(bool(on)))
 
 
@@ -225,16 +221,10 @@ def gemm_nt_group(problems):
         i = j
 
 
-# ------------------------------------------------------------------------------------------------- pre-split (bf16 x 3 planes) operands
-# csrc/gemm_planes.hip: the fp32-accurate bf16 x 3 product with both operands split ONCE into hi / mid / lo planes instead of by every tile
-# that stages them: weights once per optimiser step (layers.WeightPrep), activations by one pass (split3_planes).  On the many-row products
-# of the stacked forward the planes are consumed by persistent workgroups whose mover waves fetch them global -> LDS by DMA while the
-# matrix waves multiply (no split arithmetic competing with the MFMAs for the SIMDs' issue ports).  TG_GEMM_PLANES=0: fp32 operands, split
-# while staged (gemm_mw.hip / gemm_split.hip).
-GEMM_PLANES = os.environ.get("TG_GEMM_PLANES", "1") != "0"
-# both operands pre-split (tg_gemm_nt_planes_group, all-DMA movers): measured no faster than pre-split weights + fp32 activations on the GRU
-# projections (a CU cannot take in 6 bytes per operand element at the matrix pipe's pace) and it costs a split pass: opt-in
-GEMM_PLANES_BOTH = os.environ.get("TG_GEMM_PLANES_BOTH", "0") != "0"
+# ------------------------------------------------------------------------------------------------- pre-split (bf16 x 3 planes) weights
+# csrc/planes.hip: weight matrices split ONCE per optimiser step (layers.WeightPrep) into hi / mid / lo bf16 planes; on the many-row products
+# of the stacked forward the mover waves of gemm_mw.hip fetch them global -> LDS by DMA while the matrix waves multiply.
+GEMM_PLANES = True
 
 
 class Planes:
@@ -270,46 +260,6 @@ def split3_planes(x2d, out=None):
     assert tuple(t.shape) == (3, rows + 1, cwp) and t.is_contiguous() and t.dtype == torch.bfloat16
     call("tg_split3_planes", _p(x2d), x2d.stride(0), rows, cw, C.c_void_p(t.data_ptr()), cwp, (rows + 1) * cwp, _stream())
     return Planes(t, rows, cw, cwp)
-
-
-def _np_problem(A: Planes, Bp: Planes, bias, out, *, taps=1, batches=1, batch_rows=0, rows_in=None, rows_out=None, row_step=1, shift=0, dil=1,
-                act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, out_scale=None):
-    """Checked tg_gemm_nt_planes_problem.  A: activation planes (window over its rows), Bp: weight planes of the [taps * N rows][cw] matrix with
-    row = tap * N + n (for a Conv1d weight (Co, Ci, kw): split3_planes(w.permute(2, 0, 1).reshape(kw * Co, Ci)))."""
-    _f32(out, "out")
-    assert A.cwp == Bp.cwp and A.cw == Bp.cw and Bp.rows % taps == 0, (A.cw, Bp.cw, Bp.rows, taps)
-    N = Bp.rows // taps
-    rows_in = A.rows if rows_in is None else rows_in
-    rows_out = rows_in if rows_out is None else rows_out
-    M = batches * rows_out
-    assert (batches - 1) * batch_rows + rows_in <= A.rows
-    if bias is not None:
-        _f32(bias, "bias"); assert bias.numel() == N and bias.is_contiguous()
-    if c_row_stride is None:
-        assert out.dim() == 2 and out.stride(1) == 1 and tuple(out.shape) == (M, N), (out.shape, M, N)
-        c_batch_stride, c_row_stride, c_rows_out = 0, out.stride(0), M
-    nb = (M + c_rows_out - 1) // c_rows_out
-    if (nb - 1) * c_batch_stride + (c_rows_out - 1) * c_row_stride + N - 1 >= _room(out):
-        raise ValueError("gemm_nt_planes: output exceeds its tensor")
-    q = _lib.NtPlanesProblem()
-    q.A, q.a_plane_stride, q.a_rows, q.cwp = A.t.data_ptr(), A.plane_stride, A.rows, A.cwp
-    q.a_batch_rows, q.rows_in, q.rows_out, q.row_step, q.shift, q.dil, q.taps = batch_rows, rows_in, rows_out, row_step, shift, dil, taps
-    q.B, q.b_plane_stride = Bp.t.data_ptr(), Bp.plane_stride
-    q.bias = bias.data_ptr() if bias is not None else None
-    q.C, q.c_batch_stride, q.c_row_stride, q.c_rows_out = out.data_ptr(), c_batch_stride, c_row_stride, c_rows_out
-    q.M, q.N, q.act_slope, q.accumulate = M, N, float(act_slope), int(bool(accumulate))
-    if out_scale is not None:
-        _f32(out_scale, "out_scale")
-        assert out_scale.shape == out.shape and out_scale.stride() == out.stride()
-        q.out_scale = out_scale.data_ptr()
-    return q
-
-
-def gemm_nt_planes_group(problems):
-    """Independent products on pre-split operands in ONE launch.  problems: dicts with the arguments of _np_problem (A, Bp, bias, out, ...)."""
-    assert 1 <= len(problems) <= _lib.MAX_GROUP
-    arr = (_lib.NtPlanesProblem * len(problems))(*[_np_problem(**p) for p in problems])
-    call("tg_gemm_nt_planes_group", arr, len(problems), _stream())
 
 
 def zero_(t):
@@ -431,9 +381,9 @@ def colsum(X, out, *, accumulate=True):
 
 
 # ------------------------------------------------------------------------------------------------- GRU
-# persistent cluster-synchronised recurrence (csrc/gru_cluster.hip): on by default where it fits; TG_GRU_CLUSTER=0 keeps the
-# per-step launches.  One workspace per (device, B, H): flag words + exchange buffer; its first word is the timeout marker.
-GRU_CLUSTER = os.environ.get("TG_GRU_CLUSTER", "1") != "0"
+# persistent cluster-synchronised recurrence (csrc/gru_cluster.hip + gru_cluster_x3.hip) where it fits (tests set GRU_CLUSTER = False to
+# reach the per-step launches, the path of batches with more than 256 workgroups).  One workspace per (device, B, H): flag words + exchange buffer; its first word is the timeout marker.
+GRU_CLUSTER = True
 _gru_ws = {}
 
 
@@ -449,7 +399,7 @@ def _gru_cluster_ws(dev, B, H, bwd=False):
 
 
 _dpre_ws = {}             # (device, Bs) -> zero-initialised workspace of the fused discriminator front end (timeout word first)
-D_PRECONV_FUSED = os.environ.get("TG_D_PRECONV_FUSED", "1") != "0"
+D_PRECONV_FUSED = True            # tests compare with the unfused chain
 
 
 def d_preconv_fwd_supported(Bs, groups):
@@ -517,16 +467,10 @@ def check_async_errors():
 
 def gru_fused_dropout(B, H, bwd=False):
     """True when the recurrence kernel that will run for (B, H) applies the inter-layer dropout itself (drop_mask / dy_mask)."""
-    if H == 64:
-        return True
-    # the cluster kernels can do it too (drop_mask / y_drop, dy_mask), but measured on the generator (B = 384, H = 300) the mask read +
-    # y_drop write inside the latency-critical persistent kernel cost as much as the separate fused draw-and-apply pass saved
-    # (211 -> 233 us per launch against 33 us): opt-in with TG_GRU_FUSED_DROPOUT=1
-    if os.environ.get("TG_GRU_FUSED_DROPOUT", "0") == "0":
-        return False
-    lib = _lib.load()
-    fits = lib.tg_gru_cluster_bwd_supported(B, H) if bwd else lib.tg_gru_cluster_supported(B, H)
-    return bool(GRU_CLUSTER and H > 64 and fits and lib.tg_gru_cluster_fused_dropout())
+    # H = 64 only.  The cluster kernels accept drop_mask / y_drop / dy_mask too (C-ABI; tests call them directly), but measured on the generator
+    # (B = 384, H = 300) the mask read + y_drop write inside the latency-critical persistent kernel cost as much as the separate fused
+    # draw-and-apply pass saved (211 -> 233 us per launch against 33 us), so the layer code does not use that.
+    return H == 64
 
 
 def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None, save_rows=None):
@@ -551,14 +495,14 @@ def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None, save_rows=
     if GRU_CLUSTER and H > 64 and _lib.load().tg_gru_cluster_supported(B, H):
         if drop_mask is not None:
             _flat(drop_mask, "drop_mask"); _flat(y_drop, "y_drop")
-            assert tuple(drop_mask.shape) == tuple(y.shape) == tuple(y_drop.shape) and gru_fused_dropout(B, H)
+            assert tuple(drop_mask.shape) == tuple(y.shape) == tuple(y_drop.shape)
         ws = _gru_cluster_ws(gi.device, B, H)
         r0, rn = (0, B) if save_rows is None else (int(save_rows[0]), int(save_rows[1]))
         assert 0 <= r0 and rn >= 0 and r0 + rn <= B
         call("tg_gru_forward_cluster_rows", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
              B * T * 4 * H, _p(drop_mask), _p(y_drop), C.c_void_p(ws.data_ptr()), ws.numel() * 4, B, T, H, r0, rn, _stream())
         return y
-    assert drop_mask is None and y_drop is None, "fused dropout: H = 64 or the bf16x3 cluster kernels only (ops.gru_fused_dropout)"
+    assert drop_mask is None and y_drop is None, "fused dropout: H = 64 or the cluster kernels only"
     call("tg_gru_forward", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
          B * T * 4 * H, B, T, H, _stream())
     return y
@@ -586,12 +530,12 @@ def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None, dy
         return
     if GRU_CLUSTER and H > 64 and _lib.load().tg_gru_cluster_bwd_supported(nb, H):
         if dy_mask is not None:
-            _flat(dy_mask, "dy_mask"); assert tuple(dy_mask.shape) == tuple(dy.shape) and gru_fused_dropout(nb, H, bwd=True)
+            _flat(dy_mask, "dy_mask"); assert tuple(dy_mask.shape) == tuple(dy.shape)
         ws = _gru_cluster_ws(dy.device, nb, H, bwd=True)
         call("tg_gru_backward_cluster", _p(dy), _p(dy_mask), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
              _p(dgi), _p(dgh), nb * T * 3 * H, C.c_void_p(ws.data_ptr()), ws.numel() * 4, nb, T, H, _stream())
         return
-    assert dy_mask is None, "fused dropout backward: H = 64 or the bf16x3 cluster kernels only (ops.gru_fused_dropout)"
+    assert dy_mask is None, "fused dropout backward: H = 64 or the cluster kernels only"
     call("tg_gru_backward", _p(dy), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
          _p(dgi), _p(dgh), nb * T * 3 * H, _p(dh_scratch), nb, T, H, _stream())
 
@@ -676,10 +620,10 @@ def bn_backward(dy2d, x2d, dx2d, mean, rstd, gamma, beta, act_slope, ws, dgamma,
 
 
 # ------------------------------------------------------------------------------------------------- WavEncoder front end
-# Conv1d(1, 16, 15) -> BatchNorm1d(16) -> LeakyReLU on raw audio without the pre-BatchNorm tensor (csrc/audio.hip); TG_WAV_FUSED=0 keeps
-# the generic window-GEMM + BatchNorm launches
-WAV_FUSED = os.environ.get("TG_WAV_FUSED", "1") != "0"
-WAV_FUSED_DGRAD = os.environ.get("TG_WAV_FUSED_DGRAD", "1") != "0"      # backward also forms conv2's input gradient inside the reduction
+# Conv1d(1, 16, 15) -> BatchNorm1d(16) -> LeakyReLU on raw audio without the pre-BatchNorm tensor (csrc/audio.hip); other shapes
+# take the generic window-GEMM + BatchNorm launches
+WAV_FUSED = True
+WAV_FUSED_DGRAD = True      # backward also forms conv2's input gradient inside the reduction
 _wav_ws = {}
 
 
@@ -988,10 +932,12 @@ def rng_advance(state):
     call("tg_rng_advance", _p(_i64(state, "rng_state")), _stream())
 
 
-def iter_head(rng_a, rng_b, step_a, step_b, target, n_pre, copies, text=None, vid=None, permute_last=False, perm_in=None, perm_site=0, row_floats=None):
+def iter_head(rng_a, rng_b, step_a, step_b, target, n_pre, copies, text=None, vid=None, permute_last=False, perm_in=None, perm_site=0, row_floats=None,
+              target_copy=None):
     """tg_iter_head: counters + stacked seed poses / word ids / speaker ids of a GAN iteration, one launch.  Returns (pre_s, text_s, vid_s).
     row_floats > D + 1: pre_s is the [:, :, :D + 1] view of a fresh (copies * B, T, row_floats) buffer -- the generator's GRU input rows, whose
-    pose columns are then already in place (GeneratorEngine.forward recognises the view and skips its copy)."""
+    pose columns are then already in place (GeneratorEngine.forward recognises the view and skips its copy).
+    target_copy ((B, T, D), optional): receives a copy of target (the real half of the discriminator's stacked input)."""
     for r in (rng_a, rng_b):
         assert r is None or _i64(r, "rng_state") is r
     for c in (step_a, step_b):
@@ -1009,8 +955,10 @@ def iter_head(rng_a, rng_b, step_a, step_b, target, n_pre, copies, text=None, vi
         vid_s = torch.empty(copies * B, dtype=torch.int64, device=target.device)
     if perm_in is not None:
         _i64(perm_in, "perm"); assert perm_in.numel() == B
+    if target_copy is not None:
+        _flat(target_copy, "target_copy"); assert tuple(target_copy.shape) == (B, T, D)
     call("tg_iter_head", _p(rng_a), _p(rng_b), _p(step_a), _p(step_b), _p(target), _p(pre), ld, B, T, D, int(n_pre), int(copies), _p(text), _p(text_s),
-         _p(vid), _p(vid_s), int(bool(permute_last)), _p(perm_in), int(perm_site), None, _stream())
+         _p(vid), _p(vid_s), int(bool(permute_last)), _p(perm_in), int(perm_site), None, _p(target_copy), _stream())
     return pre[:, :, :D + 1], text_s, vid_s
 
 
@@ -1063,7 +1011,7 @@ def reparam_bwd(dz, logvar, eps, dmu, dlogvar):
     call("tg_reparam_bwd", _p(dz), _p(logvar), _p(eps), _p(dmu), _p(dlogvar), _same(dz, logvar, eps, dmu, dlogvar), _stream())
 
 
-SPEAKER_FUSED = os.environ.get("TG_SPEAKER_FUSED", "1") != "0"
+SPEAKER_FUSED = True
 
 
 def speaker_fwd(table, vid, w1, b1, wmu, bmu, wlv, blv, eps, rep=None, T=0, draw=None):
@@ -1106,7 +1054,7 @@ def speaker_bwd(dz, d_mu, d_logvar, logvar, eps, zc, se, vid, w1, wmu, wlv, dw1,
          _p(dw1), _p(db1), _p(dwmu), _p(dbmu), _p(dwlv), _p(dblv), _p(dtable), nb, _stream())
 
 
-OUT_MLP_COMPOSED = os.environ.get("TG_OUT_MLP_COMPOSED", "1") != "0"
+OUT_MLP_COMPOSED = True
 
 
 def out_mlp_compose(w1, b1, w2, b2, dup=1):

@@ -142,8 +142,8 @@ class GanTrainer:
         B = target.shape[0]
         dev = target.device
         self._assert_no_pending_exchange()
-        if G.use_side_stream and ops.GRU_CLUSTER and os.environ.get("TG_SIDE_STREAM") != "2":      # "2": lab switch, measure anyway
-            raise RuntimeError("TG_SIDE_STREAM=1 cannot be combined with the cluster-synchronised GRU kernels (set TG_GRU_CLUSTER=0): "
+        if G.use_side_stream and ops.GRU_CLUSTER:
+            raise RuntimeError("use_side_stream cannot be combined with the cluster-synchronised GRU kernels (ops.GRU_CLUSTER): "
                                "side-stream kernels beside them break the co-residency their hand-off relies on")
         target = target.contiguous().float()
         speaker = self.G.z_mode == "speaker"
@@ -152,19 +152,24 @@ class GanTrainer:
         # ONE launch: both RNG step counters and the Adam step counters of the optimisers that step in this iteration; the seed poses, word
         # ids and speaker ids of the ng stacked generator calls, the last call's ids shuffled by the diversity term's permutation (:67-72)
         perm_in = inject["perm"].to(dev).long().contiguous() if (inject is not None and "perm" in inject) else None
+        # the discriminator step reads [target ; out1] (:30-31): one buffer, the head launch copies the target into its first B rows and the
+        # generator's last layer writes its poses behind them, so the concatenation never runs
+        d_in = torch.empty((1 + ng) * B, *target.shape[1:], device=dev) if post else None
         pre_s, text_s, vid_s = ops.iter_head(G.rng.state, D.rng.state, self.g_opt.slab.step, self.d_opt.slab.step if post else None, target,
                                              self.hp["n_pre_poses"], ng, text=in_text.contiguous(), vid=vid.contiguous() if speaker else None,
                                              permute_last=speaker and self.use_reg, perm_in=perm_in, perm_site=G.rng.site("perm"),
-                                             row_floats=G.in_size)         # the seed poses land in the GRU input rows directly
+                                             row_floats=G.in_size,         # the seed poses land in the GRU input rows directly
+                                             target_copy=d_in[:B] if post else None)
         res = G.forward(pre_s, text_s, in_audio.float(), vid_s, training=True, groups=ng, save=True,
-                        inject=_stack_inject(inject, tags, "g"), tag="g", save_rows=(i2 * B, B))     # only call g2 is differentiated (:50-88)
+                        inject=_stack_inject(inject, tags, "g"), tag="g", save_rows=(i2 * B, B),     # only call g2 is differentiated (:50-88)
+                        out_into=d_in[B:] if post else None)
         if self.keep_tape:
             self.last_tape = res["tape"]
         sl = lambda t, i: None if t is None else t[i * B:(i + 1) * B]
         st = dict(B=B, target=target, res=res, i2=i2, ng=ng, out2=sl(res["out"], i2), out3=sl(res["out"], ng - 1),
                   z2=sl(res["z"], i2), z3=sl(res["z"], ng - 1), mu2=sl(res["mu"], i2), lv2=sl(res["logvar"], i2))
         if post:
-            st["out1"] = sl(res["out"], 0)
+            st["d_in"] = d_in[:2 * B]                                   # [target ; out1]: D(real) first, then D(fake.detach())
         return st
 
     # ---- phase 2: discriminator step (train_gan.py:27-43)
@@ -172,8 +177,7 @@ class GanTrainer:
         D, B = self.D, st["B"]
         D.slab.ensure().zero_grad()
         self._assert_no_pending_exchange()                    # the fused front-end kernels (csrc/d_preconv.hip) meet at device-wide barriers
-        both = torch.cat([st["target"], st["out1"]])                   # D(real) first, then D(fake.detach())
-        dres = D.forward(both, training=True, groups=2, save=True, inject=_stack_inject(inject, ["d_real", "d_fake"], "d"), tag="d")
+        dres = D.forward(st["d_in"], training=True, groups=2, save=True, inject=_stack_inject(inject, ["d_real", "d_fake"], "d"), tag="d")
         logit = dres["logit"].view(-1)
         d_logit = torch.empty_like(logit)
         st["d_scalar"] = torch.empty(1, device=logit.device)

@@ -142,32 +142,11 @@ int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bi
                int64_t c_batch_stride, int64_t c_row_stride, int32_t c_rows_out, int32_t M, int32_t N,
                float act_slope, int32_t accumulate, void* stream);
 
-/* ---- tg_gemm_nt on pre-split operands (csrc/gemm_planes.hip): same products and epilogue as tg_gemm_nt, fp32-accurate on the bf16
- * matrix cores, but both operands arrive as three bf16 planes (x = hi + mid + lo exactly) so the main loop does no split arithmetic.
- * Plane buffer of an fp32 matrix [rows][cw]: three bf16 planes `plane_stride` ELEMENTS apart, each SLAB-TILED: [cwp / 32][rows + 1][32]
- * (cwp = cw rounded up to a multiple of 32; element (r, c) at ((c / 32) * (rows + 1) + r) * 32 + c % 32; zero past cw and in row `rows`
- * of every slab), so that one 32-deep K slab of 16 consecutive rows is 1 KB of contiguous memory.  tg_split3_planes writes one from fp32.
- * With many rows and tiles that fill the chip the product runs on persistent 512-thread workgroups whose mover waves bring both
- * operands global -> LDS by DMA while the matrix waves multiply (gemm_np_mw_kernel); otherwise on the 256-thread staged kernel. */
+/* ---- pre-split operand planes (csrc/planes.hip).  Plane buffer of an fp32 matrix [rows][cw]: three bf16 planes (x = hi + mid + lo exactly)
+ * `plane_stride` ELEMENTS apart, each SLAB-TILED: [cwp / 32][rows + 1][32] (cwp = cw rounded up to a multiple of 32; element (r, c) at
+ * ((c / 32) * (rows + 1) + r) * 32 + c % 32; zero past cw and in row `rows` of every slab), so that one 32-deep K slab of 16 consecutive rows
+ * is 1 KB of contiguous memory.  tg_gemm_nt_problem.b_planes takes weights in this form (mover-wave kernel, csrc/gemm_mw.hip). */
 int tg_split3_planes(const float* x, int64_t ldx, int32_t rows, int32_t cw, void* planes, int32_t cwp, int64_t plane_stride, void* stream);
-typedef struct tg_gemm_nt_planes_problem {
-    const void* A;             /* planes of the activation buffer, a_rows (+ the zero row) rows of cwp channels */
-    int64_t a_plane_stride;
-    int32_t a_rows, cwp;
-    int64_t a_batch_rows;      /* row window as in tg_window, in ROWS of the buffer: output row m = (batch b, r) reads source rows */
-    int32_t rows_in, rows_out; /*   b * a_batch_rows + r * row_step + shift + tap * dil, tap = 0 .. taps - 1 (zero outside [0, rows_in)) */
-    int32_t row_step, shift, dil, taps;
-    const void* B;             /* planes of the weights as a [taps * N rows][cw] matrix, row = tap * N + n (tg_split3_planes over w.permute(kw, Co, Ci)) */
-    int64_t b_plane_stride;
-    const float* bias;
-    float* C;
-    int64_t c_batch_stride, c_row_stride;
-    int32_t c_rows_out, M, N;
-    float act_slope;
-    int32_t accumulate;
-    const float* out_scale;
-} tg_gemm_nt_planes_problem;
-int tg_gemm_nt_planes_group(const tg_gemm_nt_planes_problem* problems, int32_t n, void* stream);
 
 /* tg_gemm_tn (weight gradient, accumulates): dW[n*ldw + perm(k)] += sum_m dY[m*ldy + n] * A(m, k).
  *   out_kw == 0: perm(k) = k.  out_kw == K/cw: perm(k) = (k % cw) * out_kw + k / cw, i.e. the gradient lands in
@@ -505,10 +484,13 @@ int tg_iter_begin(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_
  * pre_ld > D + 1 writes them straight into the pose columns of the GRU input rows); the word ids copied `copies` times
  * (text [B][T] -> text_stacked, both may be NULL); the speaker ids [vid] * (copies - 1) + [last] (vid [B] -> vid_stacked [copies][B], both
  * may be NULL) where last = vid[perm] if permute_last -- perm = torch.randperm(B) of :69 drawn as tg_randperm(.., rng_a at its NEW step,
- * perm_site) or given (perm_in, tests), also written to perm_out when non-NULL -- and vid otherwise.  B <= 1024 with speaker ids. */
+ * perm_site) or given (perm_in, tests), also written to perm_out when non-NULL -- and vid otherwise.  B <= 1024 with speaker ids.
+ * target_copy (ABI 5; NULL, or [B][T][D]): receives a copy of target -- the "real" half of the discriminator's stacked input, so that
+ * torch.cat((target, out_dir_vec.detach())) of :30-31 needs no launch of its own (the generator writes its half behind it). */
 int tg_iter_head(uint64_t* rng_a, uint64_t* rng_b, int32_t* adam_step_a, int32_t* adam_step_b, const float* target, float* pre_stacked, int64_t pre_ld,
                  int32_t B, int32_t T, int32_t D, int32_t n_pre, int32_t copies, const int64_t* text, int64_t* text_stacked, const int64_t* vid,
-                 int64_t* vid_stacked, int32_t permute_last, const int64_t* perm_in, uint32_t perm_site, int64_t* perm_out, void* stream);
+                 int64_t* vid_stacked, int32_t permute_last, const int64_t* perm_in, uint32_t perm_site, int64_t* perm_out, float* target_copy,
+                 void* stream);
 int tg_dropout_mask(float* mask, int64_t n, float p, const uint64_t* rng_state, uint32_t site, void* stream);
 /* Draw the same mask and apply it in one pass: mask as tg_dropout_mask, y[i] = x[i] * mask[i] (F.dropout, train mode).  mask may be NULL
  * (ABI 4): the mask is not stored, its later consumers regenerate it (tg_gemm_nt_problem.drop_state, tg_act_mask_bwd_drop). */

@@ -770,6 +770,10 @@ def test_iter_head_equals_the_separate_launches(pkg, dev):
     ra = ops.new_rng_state(11, dev)
     pre_s, text_s, vid_s = ops.iter_head(ra, None, None, None, target, 4, 1, text=text)
     assert vid_s is None and int(ra[1]) == 1 and torch.equal(pre_s, ops.make_pre_seq(target, torch.empty(B, T, D + 1, device=dev), 4))
+    # the real half of the discriminator's stacked input, copied by the same launch (torch.cat of train_gan.py:30-31)
+    d_in = torch.full((3 * B, T, D), -7.0, device=dev)
+    ops.iter_head(ops.new_rng_state(11, dev), None, None, None, target, 4, 2, text=text, target_copy=d_in[:B])
+    assert torch.equal(d_in[:B], target) and bool((d_in[B:] == -7.0).all())
 
 
 @pytest.mark.parametrize("M,K", [(7168, 192), (3584, 192), (37, 64)])
@@ -1066,79 +1070,6 @@ def test_split3_planes_are_exact(pkg, dev):
     xs = torch.zeros(50, 200, device=dev); xs[:, 3:111] = rnd(50, 108, seed=52).to(dev)
     pv = ops.split3_planes(xs[:, 3:111]).element_view()                    # unaligned strided view: scalar path
     assert torch.equal((pv[0].double() + pv[1].double() + pv[2].double())[:50, :108].float(), xs[:, 3:111])
-
-
-@pytest.mark.parametrize("M,N,K", [(13056, 900, 600), (4352, 300, 108), (1030, 52, 70), (2048, 96, 32)])
-def test_gemm_nt_planes_is_fp32_accurate(pkg, dev, M, N, K):
-    """tg_gemm_nt_planes_group vs fp64 on operands spanning eight decades: the fp32 gate (1e-5), tile edges in M and N, K padding, grouped
-    launch, bias / activation / accumulate / out_scale epilogue."""
-    ops = pkg.ops
-    x = (rnd(M, K, seed=53) * torch.logspace(-4, 4, K)).to(dev)
-    w = [(rnd(N, K, seed=54 + i, scale=0.1) * torch.logspace(2, -2, K)).to(dev) for i in range(2)]
-    b = [rnd(N, seed=56 + i).to(dev) for i in range(2)]
-    ref = [F.leaky_relu(x.double().cpu() @ w[i].double().cpu().t() + b[i].double().cpu(), 0.3) for i in range(2)]
-    a_pl = ops.split3_planes(x)
-    out = torch.full((2, M, N), float("nan"), device=dev)
-    ops.gemm_nt_planes_group([dict(A=a_pl, Bp=ops.split3_planes(w[i]), bias=b[i], out=out[i], act_slope=0.3) for i in range(2)])
-    assert rel(out[0], ref[0]) < 1e-5 and rel(out[1], ref[1]) < 1e-5, (rel(out[0], ref[0]), rel(out[1], ref[1]))
-    mask = (torch.rand(M, N, generator=torch.Generator().manual_seed(5)) > 0.3).float().to(dev) * 1.25
-    base = out[0].clone()
-    ops.gemm_nt_planes_group([dict(A=a_pl, Bp=ops.split3_planes(w[1]), bias=None, out=out[0], accumulate=True, out_scale=mask)])
-    ref2 = base.double().cpu() + (x.double().cpu() @ w[1].double().cpu().t()) * mask.double().cpu()
-    assert rel(out[0], ref2) < 1e-5
-
-
-def test_gemm_nt_planes_conv_window(pkg, dev):
-    """Dilated causal conv (model/tcn.py) as a two-tap row window over the plane buffer: rows before the sequence start read the zero row."""
-    ops = pkg.ops
-    B, T, Ci, Co, d = 40, 34, 300, 300, 4
-    x = rnd(B, Ci, T, seed=58)
-    w = rnd(Co, Ci, 2, seed=59, scale=0.05)
-    bias = rnd(Co, seed=60)
-    ref = F.conv1d(x.double(), w.double(), bias.double(), padding=d, dilation=d)[:, :, :T]          # Chomp1d
-    xcl = cl(x).to(dev)                                                                              # (B, T, Ci)
-    a_pl = ops.split3_planes(xcl.view(B * T, Ci))
-    wp = w.permute(2, 0, 1).contiguous().to(dev)                                                     # [tap][Co][Ci]: row = tap * Co + n
-    b_pl = ops.split3_planes(wp.view(2 * Co, Ci))
-    out = torch.empty(B * T, Co, device=dev)
-    ops.gemm_nt_planes_group([dict(A=a_pl, Bp=b_pl, bias=bias.to(dev), out=out, taps=2, batches=B, batch_rows=T, rows_in=T, rows_out=T,
-                                   shift=-d, dil=d)])
-    assert rel(out.view(B, T, Co), cl(ref)) < 1e-5
-
-
-@pytest.mark.parametrize("M,N,K", [(13000, 900, 600), (13056, 900, 108), (13056, 300, 600)])
-def test_gemm_nt_planes_mover_wave_dma_kernel(pkg, dev, M, N, K):
-    """The pre-split product at the stacked forward's sizes runs on gemm_np_mw_kernel (csrc/gemm_planes.hip: persistent 512-thread
-    workgroups, both operands by LDS-DMA into a double-buffered image, matrix waves that only read fragments and multiply): two-problem
-    groups (both GRU directions, multimodal_context_net.py:98-99), ragged M / N / K, 8-decade operands against fp64, then the conv-window
-    form at B_s = 384 (rows before the clip read the plane buffer's zero row)."""
-    ops = pkg.ops
-    g = torch.Generator().manual_seed(M + N + K)
-    x = (torch.randn(M, K, generator=g) * torch.pow(10.0, torch.randint(-4, 4, (M, 1), generator=g).float())).to(dev)
-    w = [(torch.randn(N, K, generator=g) * 0.1).to(dev) for _ in range(2)]
-    b = [torch.randn(N, generator=g).to(dev) for _ in range(2)]
-    a_pl = ops.split3_planes(x)
-    out = torch.full((2, M, N), float("nan"), device=dev)
-    ops.gemm_nt_planes_group([dict(A=a_pl, Bp=ops.split3_planes(w[i]), bias=b[i], out=out[i], act_slope=0.3) for i in range(2)])
-    for i in range(2):
-        ref = F.leaky_relu(_mm64(x, w[i]) + b[i].double(), 0.3)
-        assert _row_err(out[i], ref) < 1e-5
-    mask = (torch.rand(M, N, generator=g) > 0.3).float().to(dev) * 1.25
-    base = out[0].clone()
-    ops.gemm_nt_planes_group([dict(A=a_pl, Bp=ops.split3_planes(w[1]), bias=None, out=out[0], accumulate=True, out_scale=mask)])
-    ref2 = base.double() + _mm64(x, w[1]) * mask.double()
-    assert _row_err(out[0], ref2) < 1e-5
-    if K == 600 and N == 300:
-        B, T, Ci, Co, d = 384, 34, 300, 300, 8
-        xc = torch.randn(B, Ci, T, generator=g)
-        wc = torch.randn(Co, Ci, 2, generator=g) * 0.05
-        bias = torch.randn(Co, generator=g)
-        ref = F.conv1d(xc.double(), wc.double(), bias.double(), padding=d, dilation=d)[:, :, :T]
-        xcl = cl(xc).to(dev)
-        o = torch.full((B * T, Co), float("nan"), device=dev)
-        ops.gemm_nt_planes_group([dict(A=ops.split3_planes(xcl.view(B * T, Ci)), Bp=ops.split3_planes(wc.permute(2, 0, 1).contiguous().to(dev).view(2 * Co, Ci)),
-                                       bias=bias.to(dev), out=o, taps=2, batches=B, batch_rows=T, rows_in=T, rows_out=T, shift=-d, dil=d)])
-        assert rel(o.view(B, T, Co), cl(ref)) < 1e-5
 
 
 @pytest.mark.parametrize("B,T1", [(3, 217), (5, 1313), (2, 7891)])

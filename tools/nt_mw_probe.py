@@ -52,27 +52,6 @@ cases = [("gru proj 2 x [13056 x 900 x 600]", group(13056, 900, 600, 2)),
          ("tcn conv  [13056 x 300 x 600] d=4", tcn(384, 34, 300, 4)),
          ("dgrad     [4352 x 600 x 1800]", group(4352, 600, 1800, 1)),
          ("dgrad tcn [4352 x 300 x 600]", group(4352, 300, 600, 1))]
-def planes_case(M, N, K, n):
-    x = torch.randn(M, K, device=dev)
-    ws = [torch.randn(N, K, device=dev) * 0.05 for _ in range(n)]
-    bs = [torch.randn(N, device=dev) for _ in range(n)]
-    outs = [torch.empty(M, N, device=dev) for _ in range(n)]
-    a_pl = ops.split3_planes(x)
-    b_pl = [ops.split3_planes(w) for w in ws]
-    probs = [dict(A=a_pl, Bp=bp, bias=b, out=o) for bp, b, o in zip(b_pl, bs, outs)]
-    return x, a_pl, probs, 2.0 * M * N * K * n
-
-
-print("# pre-split operands (csrc/gemm_planes.hip, mover waves + LDS-DMA): product alone | the activation's split pass | sum, us (median of 7 x 100)")
-for name, (M, N, K, n) in (("gru proj 2 x [13056 x 900 x 600]", (13056, 900, 600, 2)), ("gru proj 2 x [13056 x 900 x 108]", (13056, 900, 108, 2)),
-                           ("tcn-sized  [13056 x 300 x 600]", (13056, 300, 600, 1))):
-    x, a_pl, probs, flops = planes_case(M, N, K, n)
-    for _ in range(10):
-        ops.gemm_nt_planes_group(probs)
-    tp = statistics.median(timed(lambda: ops.gemm_nt_planes_group(probs), 100) for _ in range(7))
-    ts = statistics.median(timed(lambda: ops.split3_planes(x, out=a_pl.t), 100) for _ in range(7))
-    print(f"{name:36s} | {tp:7.1f} us {flops / tp / 1e6:6.1f} TF | split {ts:6.1f} us | {tp + ts:7.1f} us {flops / (tp + ts) / 1e6:6.1f} TF", flush=True)
-
 print(f"# tools/nt_mw_probe.py: {rounds} interleaved rounds x 100 launches, us per launch (median / min), fp32-equivalent TFLOP/s at the median")
 for name, (probs, flops, keep) in cases:
     res = {}
