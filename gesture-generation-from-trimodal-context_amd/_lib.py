@@ -35,6 +35,13 @@ class TnProblem(C.Structure):
                 ("dbias", P), ("ws", P), ("ws_floats", I64)]
 
 
+class AeStepArgs(C.Structure):
+    """struct tg_ae_step_args"""
+    _fields_ = [("x", P), ("params", P), ("grads", P), ("off", I32 * 44), ("running_mean", P * 8), ("running_var", P * 8),
+                ("num_batches_tracked", P * 8), ("ws", P), ("ws_bytes", I64), ("loss", P), ("recon", P), ("feat", P), ("step", P), ("B", I32),
+                ("bn_eps", F32), ("momentum", F32), ("last_phase", I32)]
+
+
 MAX_GROUP = 8
 
 # name -> argtypes (all return int); mirrors include/trimodal_hip.h one to one
@@ -42,6 +49,7 @@ SIGNATURES = {
     "tg_gemm_nt": [WP, P, I64, P, P, I64, I64, I32, I32, I32, F32, I32, P],
     "tg_gemm_nt_group": [C.POINTER(NtProblem), I32, P],
     "tg_gemm_tn_group": [C.POINTER(TnProblem), I32, P],
+    "tg_ae_train_step": [C.POINTER(AeStepArgs), P],
     "tg_split3_planes": [P, I64, I32, I32, P, I32, I64, P],
     "tg_gemm_tn": [P, I64, WP, P, I64, I32, I32, I32, P, P, I64, P],
     "tg_colsum": [P, I64, I32, I32, P, I32, P],
@@ -175,6 +183,10 @@ def load():
     lib.tg_d_preconv_fwd_supported.argtypes = [I32, I32]
     lib.tg_d_preconv_ws_bytes.restype = C.c_int64
     lib.tg_d_preconv_ws_bytes.argtypes = [I32]
+    lib.tg_ae_step_supported.restype = C.c_int32
+    lib.tg_ae_step_supported.argtypes = [I32]
+    lib.tg_ae_step_ws_bytes.restype = C.c_int64
+    lib.tg_ae_step_ws_bytes.argtypes = [I32]
     for q, at in (("tg_wav_conv2_wgrad_ws_floats", []), ("tg_wav_front_ws_doubles", []), ("tg_wav_front_fstat_doubles", []), ("tg_wav_front_gate_words", [I32, I32])):
         getattr(lib, q).restype = C.c_int64
         getattr(lib, q).argtypes = at

@@ -1,0 +1,793 @@
+// FGD autoencoder training step (scripts/train_feature_extractor.py:54-97 on model/embedding_net.py:42-82,165-217, 34-frame branch,
+// variational_encoding = False) as EIGHTEEN launches instead of ~105.
+//
+// The step is latency bound: 1.05 M MAC per clip forward, 128 clips, but eight train-mode BatchNorms whose batch statistics (forward) and
+// gradient sums (backward) each force a device-wide dependency.  The generic path pays 4.4-17 us per launch for window GEMMs on a few
+// workgroups, three-launch BatchNorms, permutes and weight packs (0.71 ms per step).  Here the step is cut ONLY where a BatchNorm needs the
+// whole batch: sixteen such cuts -> phases 1..17, one CLIP per 512-thread workgroup, everything between two cuts fused:
+//     [finish the previous BatchNorm from its fp64 sums] -> normalise + LeakyReLU -> conv / transposed conv / linear layers up to the next
+//     BatchNorm -> per-channel partial sums of this workgroup's clip -> fp64 atomics
+// and the same backwards (BatchNorm backward from the sums of g and g * xhat, weight gradient of the layer as a per-clip partial, input
+// gradient through the layers down to the previous BatchNorm, its g and the two sums).  Kernel boundaries, not in-kernel grid barriers: a
+// dependent boundary costs ~1.5 us, a device-wide barrier 4-7 (MI355X_MICROARCH.md, price list), and nothing has to be co-resident.
+// Phase 18 (314 workgroups, its own partition) turns the per-clip conv partials and the saved linear-layer vectors into the gradient slab:
+// linear weight gradients as (8 rows x 64 columns) tiles reduced over the batch inside one workgroup, conv partials summed over clips in a
+// fixed order, BatchNorm gamma / beta gradients straight from the backward sums; it also copies the loss, advances the Adam step counter and
+// re-zeroes the sums.  tg_adam_step then updates the slab as for every other network.  No float atomics on gradients: two runs are bit-identical
+// up to the fp64 atomics of the statistics.
+//
+// Arithmetic: fp32 FMA on the vector ALU (the layers are 4-64 channels wide with 12-38 positions: an MFMA tile would be mostly padding), one
+// clip's activations in LDS, weights staged into LDS per layer in the [tap * Cin + ci][co] order the inner loop reads (lanes = output
+// channels: conflict-free; the input row is a broadcast 16-byte read).  Statistics in fp64.
+#include "common.hpp"
+
+namespace tg {
+
+constexpr int AE_NT = 512;
+constexpr int AE_WLD = 16640;            // staged weights: at most 256 rows of 64 + 1 floats (net.2: Conv1d(64, 64, 4))
+constexpr int AE_BUF = 2048;             // one activation buffer (largest tensor of a clip: 30 x 64)
+constexpr int AE_NBUF = 5;
+
+// per-clip record of the activation workspace (floats)
+constexpr int A_C0 = 0;                  // pre-BatchNorm conv outputs, channel-last
+constexpr int A_C1 = A_C0 + 32 * 32;
+constexpr int A_C2 = A_C1 + 30 * 64;
+constexpr int A_FLAT = A_C2 + 14 * 64;   // net.3 output flattened channel-major (torch flatten(1) of (B, 32, 12))
+constexpr int A_F1 = A_FLAT + 384;       // out_net.0 output (pre-BatchNorm) ...
+constexpr int A_Y1F = A_F1 + 256;        // ... and normalised (the next linear layer's input)
+constexpr int A_F2 = A_Y1F + 256;
+constexpr int A_Y2F = A_F2 + 128;
+constexpr int A_F3 = A_Y2F + 128;
+constexpr int A_MU = A_F3 + 32;
+constexpr int A_P0 = A_MU + 32;
+constexpr int A_YP = A_P0 + 64;
+constexpr int A_P3 = A_YP + 64;
+constexpr int A_T0 = A_P3 + 136;
+constexpr int A_T1 = A_T0 + 36 * 32;
+constexpr int A_G = A_T1 + 38 * 32;      // gradient handed from one backward phase to the next (g = dL/d(BatchNorm output))
+constexpr int A_DP3 = A_G + 1920;        // gradients at the linear layers' outputs (for their weight gradients, phase 18)
+constexpr int A_DP0 = A_DP3 + 136;
+constexpr int A_DMU = A_DP0 + 64;
+constexpr int A_DF3 = A_DMU + 32;
+constexpr int A_DF2 = A_DF3 + 32;
+constexpr int A_DF1 = A_DF2 + 128;
+constexpr int AE_ACT = A_DF1 + 256;
+
+// per-clip record of the conv weight / bias gradient partials (floats), each segment laid out like its parameter
+constexpr int Q_E0W = 0;
+constexpr int Q_E0B = Q_E0W + 32 * 27 * 3;
+constexpr int Q_E1W = Q_E0B + 32;
+constexpr int Q_E1B = Q_E1W + 64 * 32 * 3;
+constexpr int Q_E2W = Q_E1B + 64;
+constexpr int Q_E2B = Q_E2W + 64 * 64 * 4;
+constexpr int Q_E3W = Q_E2B + 64;
+constexpr int Q_E3B = Q_E3W + 32 * 64 * 3;
+constexpr int Q_T0W = Q_E3B + 32;
+constexpr int Q_T0B = Q_T0W + 4 * 32 * 3;
+constexpr int Q_T1W = Q_T0B + 32;
+constexpr int Q_T1B = Q_T1W + 32 * 32 * 3;
+constexpr int Q_C6W = Q_T1B + 32;
+constexpr int Q_C6B = Q_C6W + 32 * 32 * 3;
+constexpr int Q_C7W = Q_C6B + 32;
+constexpr int Q_C7B = Q_C7W + 27 * 32 * 3;
+constexpr int AE_PART = Q_C7B + 28;
+static_assert(AE_ACT % 4 == 0 && AE_PART % 4 == 0, "16-byte rows");
+
+// parameter order of tg_ae_step_args.off
+enum {
+    P_E0W, P_E0B, P_BN0G, P_BN0B, P_E1W, P_E1B, P_BN1G, P_BN1B, P_E2W, P_E2B, P_BN2G, P_BN2B, P_E3W, P_E3B,
+    P_F1W, P_F1B, P_BN3G, P_BN3B, P_F2W, P_F2B, P_BN4G, P_BN4B, P_F3W, P_F3B, P_MUW, P_MUB,
+    P_D0W, P_D0B, P_BN5G, P_BN5B, P_D1W, P_D1B, P_T0W, P_T0B, P_BN6G, P_BN6B, P_T1W, P_T1B, P_BN7G, P_BN7B,
+    P_C6W, P_C6B, P_C7W, P_C7B, P_COUNT
+};
+static_assert(P_COUNT == 44, "tg_ae_step_args.off");
+
+constexpr int AE_SLOTS = 17;             // 8 forward statistics, 8 backward sums, the loss; [slot][2][256] doubles
+
+struct AeArgs {
+    const float* x;
+    float *P, *G;
+    int off[P_COUNT];
+    float* rm[8];
+    float* rv[8];
+    long long* nbt[8];
+    double* sums;
+    float* act;
+    float* part;
+    float *loss, *recon, *feat;
+    int* step;
+    int B;
+    float bn_eps, momentum;
+};
+
+struct AeLds {
+    float* wl;
+    float* b[AE_NBUF];
+    float *mean, *rstd, *ga, *be, *mg, *mgx;
+    float* red;                           // [2][AE_NT]
+};
+constexpr int AE_LDS_FLOATS = AE_WLD + AE_NBUF * AE_BUF + 6 * 256 + 2 * AE_NT;
+
+__device__ __forceinline__ AeLds ae_lds(float* smem) {
+    AeLds l;
+    l.wl = smem;
+    for (int i = 0; i < AE_NBUF; ++i) l.b[i] = smem + AE_WLD + i * AE_BUF;
+    float* s = smem + AE_WLD + AE_NBUF * AE_BUF;
+    l.mean = s; l.rstd = s + 256; l.ga = s + 512; l.be = s + 768; l.mg = s + 1024; l.mgx = s + 1280;
+    l.red = s + 1536;
+    return l;
+}
+
+__device__ __forceinline__ float ae_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// n floats (n % 4 == 0), 16-byte aligned on both sides
+__device__ __forceinline__ void ae_load(float* __restrict__ dst, const float* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n / 4; i += AE_NT) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+    __syncthreads();
+}
+__device__ __forceinline__ void ae_store(float* __restrict__ dst, const float* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n / 4; i += AE_NT) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+}
+// the clip's poses [34][27] -> LDS [34][CP], padding columns zero
+template <int CP>
+__device__ __forceinline__ void ae_load_x(float* __restrict__ dst, const float* __restrict__ x) {
+    for (int i = threadIdx.x; i < 34 * CP; i += AE_NT) {
+        const int r = i / CP, c = i - r * CP;
+        dst[i] = c < 27 ? x[r * 27 + c] : 0.f;
+    }
+    __syncthreads();
+}
+
+// BatchNorm `bn` from the fp64 sums of `slot`: mean / rstd / gamma / beta of its C channels into LDS; optionally (workgroup 0, forward
+// phases) the running statistics (momentum, unbiased variance, num_batches_tracked += 1)
+template <int C>
+__device__ __forceinline__ void ae_bn_prepare(const AeArgs& a, const AeLds& l, int bn, int slot, double n_el, int p_gamma, bool update_running) {
+    for (int c = threadIdx.x; c < C; c += AE_NT) {
+        const double* s = a.sums + (size_t)slot * 512;
+        const double m = s[c] / n_el;
+        double var = s[256 + c] / n_el - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)a.bn_eps));
+        l.mean[c] = mf; l.rstd[c] = rs;
+        l.ga[c] = a.P[a.off[p_gamma] + c];
+        l.be[c] = a.P[a.off[p_gamma + 1] + c];
+        if (update_running && blockIdx.x == 0 && a.rm[bn] != nullptr) {
+            const double unbiased = n_el > 1.0 ? var * n_el / (n_el - 1.0) : var;
+            a.rm[bn][c] = (1.f - a.momentum) * a.rm[bn][c] + a.momentum * mf;
+            a.rv[bn][c] = (1.f - a.momentum) * a.rv[bn][c] + a.momentum * (float)unbiased;
+            if (c == 0 && a.nbt[bn] != nullptr) *a.nbt[bn] += 1;
+        }
+    }
+    __syncthreads();
+}
+// the sums of the backward: mg = sum(g) / n, mgx = sum(g * xhat) / n
+template <int C>
+__device__ __forceinline__ void ae_bwd_means(const AeArgs& a, const AeLds& l, int slot, double n_el) {
+    for (int c = threadIdx.x; c < C; c += AE_NT) {
+        const double* s = a.sums + (size_t)slot * 512;
+        l.mg[c] = (float)(s[c] / n_el);
+        l.mgx[c] = (float)(s[256 + c] / n_el);
+    }
+    __syncthreads();
+}
+// dst = LeakyReLU(BatchNorm(src)), [n / C][C]
+template <int C>
+__device__ __forceinline__ void ae_bn_act(const AeLds& l, float* __restrict__ dst, const float* __restrict__ src, int n, float slope) {
+    for (int i = threadIdx.x; i < n; i += AE_NT) {
+        const int c = i & (C - 1);
+        dst[i] = ae_lrelu((src[i] - l.mean[c]) * l.rstd[c] * l.ga[c] + l.be[c], slope);
+    }
+    __syncthreads();
+}
+// g = dy * act'(BatchNorm(raw)) in place (dy -> g)
+template <int C>
+__device__ __forceinline__ void ae_act_bwd(const AeLds& l, float* __restrict__ dy, const float* __restrict__ raw, int n, float slope) {
+    for (int i = threadIdx.x; i < n; i += AE_NT) {
+        const int c = i & (C - 1);
+        const float bnv = (raw[i] - l.mean[c]) * l.rstd[c] * l.ga[c] + l.be[c];
+        dy[i] = bnv > 0.f ? dy[i] : dy[i] * slope;
+    }
+    __syncthreads();
+}
+// BatchNorm backward in place: g -> dc = gamma * rstd * (g - mg - xhat * mgx)
+template <int C>
+__device__ __forceinline__ void ae_bn_bwd(const AeLds& l, float* __restrict__ g, const float* __restrict__ raw, int n) {
+    for (int i = threadIdx.x; i < n; i += AE_NT) {
+        const int c = i & (C - 1);
+        const float xh = (raw[i] - l.mean[c]) * l.rstd[c];
+        g[i] = l.ga[c] * l.rstd[c] * (g[i] - l.mg[c] - xh * l.mgx[c]);
+    }
+    __syncthreads();
+}
+// per-channel sums of the clip's [L][C] tensor -> fp64 atomics.  BWD: (sum g, sum g * xhat) with xhat from `raw`; else (sum v, sum v^2)
+template <int L, int C, bool BWD>
+__device__ __forceinline__ void ae_chan_sums(const AeLds& l, const float* __restrict__ v, const float* __restrict__ raw, double* __restrict__ slot) {
+    static_assert(AE_NT % C == 0, "channels per workgroup");
+    constexpr int PARTS = AE_NT / C;
+    const int c = threadIdx.x % C, part = threadIdx.x / C;
+    float s0 = 0.f, s1 = 0.f;
+    for (int r = part; r < L; r += PARTS) {
+        const float x = v[r * C + c];
+        s0 += x;
+        if constexpr (BWD) s1 += x * ((raw[r * C + c] - l.mean[c]) * l.rstd[c]);
+        else s1 += x * x;
+    }
+    l.red[threadIdx.x] = s0; l.red[AE_NT + threadIdx.x] = s1;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int p = 0; p < PARTS; ++p) { t0 += (double)l.red[p * C + threadIdx.x]; t1 += (double)l.red[AE_NT + p * C + threadIdx.x]; }
+        atomicAdd(slot + threadIdx.x, t0);
+        atomicAdd(slot + 256 + threadIdx.x, t1);
+    }
+    __syncthreads();
+}
+
+// ---- the one multiply routine of the conv-shaped layers -------------------------------------------------------------------------------
+// out[p][n] = bias[n] + sum_{kk < KW, m < CINP} in[p * S + kk - PAD][m] * wl[(kk * CINP + m) * (N + 1) + n]   (rows outside [0, LIN) are zero)
+// in: LDS [LIN][CINP], out: LDS [LOUT][N].  Thread = (output channel n, position group): lanes of a wave share the input row.
+template <int LIN, int CINP, int LOUT, int N, int KW, int S, int PAD>
+__device__ __forceinline__ void ae_conv(const float* __restrict__ in, const float* __restrict__ wl, const float* __restrict__ bias, int n_bias,
+                                        float* __restrict__ out) {
+    static_assert(AE_NT % N == 0 && CINP % 4 == 0, "thread map");
+    constexpr int PG = AE_NT / N, PP = (LOUT + PG - 1) / PG, WS = N + 1;
+    constexpr bool SAFE = PAD == 0 && (LOUT - 1) * S + KW - 1 < LIN;
+    const int n = threadIdx.x % N, pg = threadIdx.x / N;
+    float acc[PP];
+    const float b0 = (bias != nullptr && n < n_bias) ? bias[n] : 0.f;
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) acc[pp] = b0;
+    for (int kk = 0; kk < KW; ++kk) {
+#pragma unroll 2
+        for (int m = 0; m < CINP; m += 4) {
+            const float* wp = wl + (kk * CINP + m) * WS + n;
+            const float w0 = wp[0], w1 = wp[WS], w2 = wp[2 * WS], w3 = wp[3 * WS];
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const int p = pg + pp * PG;
+                const int row = p * S + kk - PAD;
+                if (p < LOUT && (SAFE || (row >= 0 && row < LIN))) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(in + row * CINP + m);
+                    acc[pp] = fmaf(x[0], w0, fmaf(x[1], w1, fmaf(x[2], w2, fmaf(x[3], w3, acc[pp]))));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+        const int p = pg + pp * PG;
+        if (p < LOUT) out[p * N + n] = acc[pp];
+    }
+    __syncthreads();
+}
+// its weight gradient for one clip, in the staged layout: dwl[(kk * CINP + m) * (N + 1) + n] = sum_p dout[p][n] * in[p * S + kk - PAD][m]
+template <int LIN, int CINP, int LOUT, int N, int KW, int S, int PAD>
+__device__ __forceinline__ void ae_wgrad(const float* __restrict__ in, const float* __restrict__ dout, float* __restrict__ dwl) {
+    static_assert(AE_NT % N == 0, "thread map");
+    constexpr int GRP = AE_NT / N, KM = KW * CINP, NJ = (KM + GRP - 1) / GRP, WS = N + 1;
+    constexpr bool SAFE = PAD == 0 && (LOUT - 1) * S + KW - 1 < LIN;
+    const int n = threadIdx.x % N, g = threadIdx.x / N;
+    float acc[NJ];
+    int ioff[NJ], kro[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int km = g + j * GRP;
+        if (km >= KM) km = KM - 1;                 // (computed and dropped)
+        const int kk = km / CINP, m = km - kk * CINP;
+        kro[j] = kk - PAD;
+        ioff[j] = (kk - PAD) * CINP + m;
+        acc[j] = 0.f;
+    }
+    for (int p = 0; p < LOUT; ++p) {
+        const float d = dout[p * N + n];
+        const float* ip = in + p * S * CINP;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int row = p * S + kro[j];
+            if (SAFE || (row >= 0 && row < LIN)) acc[j] = fmaf(d, ip[ioff[j]], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int km = g + j * GRP;
+        if (km < KM) dwl[km * WS + n] = acc[j];
+    }
+    __syncthreads();
+}
+// bias gradient of the clip: db[n] = sum_p dout[p][n], n < N; entries [n_valid, n_store) are written as zero
+template <int LOUT, int N>
+__device__ __forceinline__ void ae_bias_grad(const float* __restrict__ dout, float* __restrict__ part, int n_store) {
+    if ((int)threadIdx.x < n_store) {
+        float s = 0.f;
+        for (int p = 0; p < LOUT; ++p) s += dout[p * N + threadIdx.x];
+        part[threadIdx.x] = s;
+    }
+}
+
+// weight index maps: parameter element idx -> (kk, m, n) of the staged layout
+// Conv1d weight (CO, CI, KW) as the forward operand: kk = k, m = ci, n = co
+template <int CI, int KW> struct MapConvFwd {
+    __device__ static void at(int idx, int& kk, int& m, int& n) { const int k = idx % KW, r = idx / KW; kk = k; m = r % CI; n = r / CI; }
+};
+// Conv1d weight (CO, CI, KW) as the input-gradient operand (taps reversed, channel roles swapped): kk = KW - 1 - k, m = co, n = ci
+template <int CI, int KW> struct MapConvDgrad {
+    __device__ static void at(int idx, int& kk, int& m, int& n) { const int k = idx % KW, r = idx / KW; kk = KW - 1 - k; n = r % CI; m = r / CI; }
+};
+// ConvTranspose1d weight (CI, CO, KW) as the forward operand: out[q] = sum_k x[q - k] W[:, :, k] -> kk = KW - 1 - k with PAD = KW - 1
+template <int CO, int KW> struct MapConvTFwd {
+    __device__ static void at(int idx, int& kk, int& m, int& n) { const int k = idx % KW, r = idx / KW; kk = KW - 1 - k; n = r % CO; m = r / CO; }
+};
+// ConvTranspose1d weight (CI, CO, KW) as the input-gradient operand: dx[p] = sum_k dy[p + k] W[:, :, k]^T -> kk = k, m = co, n = ci
+template <int CO, int KW> struct MapConvTDgrad {
+    __device__ static void at(int idx, int& kk, int& m, int& n) { const int k = idx % KW, r = idx / KW; kk = k; m = r % CO; n = r / CO; }
+};
+
+template <int CINP, int N, class MAP>
+__device__ __forceinline__ void ae_stage(const float* __restrict__ W, int numel, float* __restrict__ wl, int rows, bool zero_first) {
+    constexpr int WS = N + 1;
+    if (zero_first) {
+        for (int i = threadIdx.x; i < rows * WS; i += AE_NT) wl[i] = 0.f;
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < numel; idx += AE_NT) {
+        int kk, m, n;
+        MAP::at(idx, kk, m, n);
+        wl[(kk * CINP + m) * WS + n] = W[idx];
+    }
+    __syncthreads();
+}
+template <int CINP, int N, class MAP>
+__device__ __forceinline__ void ae_unstage(float* __restrict__ part, int numel, const float* __restrict__ dwl) {
+    constexpr int WS = N + 1;
+    for (int idx = threadIdx.x; idx < numel; idx += AE_NT) {
+        int kk, m, n;
+        MAP::at(idx, kk, m, n);
+        part[idx] = dwl[(kk * CINP + m) * WS + n];
+    }
+    __syncthreads();
+}
+
+// ---- linear layers of one clip --------------------------------------------------------------------------------------------------------
+// out[n] = b[n] + sum_k W[n][k] x[k]: a wave per output row, lanes along k (coalesced 16-byte weight reads), shuffle reduction
+template <int K, int N>
+__device__ __forceinline__ void ae_fc(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ x, float* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int n = wave; n < N; n += AE_NT / 64) {
+        float s = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)n * K + k);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
+            s = fmaf(w[0], xv[0], fmaf(w[1], xv[1], fmaf(w[2], xv[2], fmaf(w[3], xv[3], s))));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) out[n] = s + b[n];
+    }
+    __syncthreads();
+}
+// dx[k] = sum_n W[n][k] dy[n]: a thread per four k and a slice of n, slices summed through LDS (scratch: >= AE_BUF floats)
+template <int K, int N>
+__device__ __forceinline__ void ae_fc_dgrad(const float* __restrict__ W, const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ scratch) {
+    constexpr int KQ = K / 4, NG0 = AE_NT / KQ, NG = NG0 < N ? NG0 : N, PER = (N + NG - 1) / NG;
+    static_assert(NG * K <= AE_BUF, "scratch");
+    const int kq = threadIdx.x % KQ, ng = threadIdx.x / KQ;
+    if (ng < NG) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int n0 = ng * PER, n1 = n0 + PER < N ? n0 + PER : N;
+#pragma unroll 4
+        for (int n = n0; n < n1; ++n) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)n * K + 4 * kq);
+            const float d = dy[n];
+            acc[0] = fmaf(w[0], d, acc[0]); acc[1] = fmaf(w[1], d, acc[1]); acc[2] = fmaf(w[2], d, acc[2]); acc[3] = fmaf(w[3], d, acc[3]);
+        }
+        *reinterpret_cast<f32x4*>(scratch + ng * K + 4 * kq) = acc;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += AE_NT) {
+        float s = 0.f;
+        for (int q = 0; q < NG; ++q) s += scratch[q * K + k];
+        dx[k] = s;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float ae_sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// ---- phases 1..17 ----------------------------------------------------------------------------------------------------------------------
+template <int PH>
+__global__ __launch_bounds__(AE_NT) void ae_phase_kernel(const AeArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[AE_LDS_FLOATS];
+    const AeLds l = ae_lds(smem);
+    const int clip = blockIdx.x;
+    float* const act = a.act + (size_t)clip * AE_ACT;
+    float* const part = a.part + (size_t)clip * AE_PART;
+    const float* const x = a.x + (size_t)clip * 34 * 27;
+    const double nB = (double)a.B;
+    float *B0 = l.b[0], *B1 = l.b[1], *B2 = l.b[2], *B3 = l.b[3], *B4 = l.b[4];
+    auto W = [&](int p) { return a.P + a.off[p]; };
+    auto slot = [&](int s) { return a.sums + (size_t)s * 512; };
+
+    if constexpr (PH == 1) {                    // poses -> net.0 conv
+        ae_load_x<28>(B0, x);
+        ae_stage<28, 32, MapConvFwd<27, 3>>(W(P_E0W), 32 * 27 * 3, l.wl, 3 * 28, true);
+        ae_conv<34, 28, 32, 32, 3, 1, 0>(B0, l.wl, W(P_E0B), 32, B1);
+        ae_store(act + A_C0, B1, 32 * 32);
+        ae_chan_sums<32, 32, false>(l, B1, nullptr, slot(0));
+    } else if constexpr (PH == 2) {             // BN0 + LeakyReLU(0.2) -> net.1 conv
+        ae_load(B0, act + A_C0, 32 * 32);
+        ae_bn_prepare<32>(a, l, 0, 0, nB * 32, P_BN0G, true);
+        ae_bn_act<32>(l, B1, B0, 32 * 32, 0.2f);
+        ae_stage<32, 64, MapConvFwd<32, 3>>(W(P_E1W), 64 * 32 * 3, l.wl, 0, false);
+        ae_conv<32, 32, 30, 64, 3, 1, 0>(B1, l.wl, W(P_E1B), 64, B2);
+        ae_store(act + A_C1, B2, 30 * 64);
+        ae_chan_sums<30, 64, false>(l, B2, nullptr, slot(1));
+    } else if constexpr (PH == 3) {             // BN1 -> net.2 conv (k 4, stride 2)
+        ae_load(B0, act + A_C1, 30 * 64);
+        ae_bn_prepare<64>(a, l, 1, 1, nB * 30, P_BN1G, true);
+        ae_bn_act<64>(l, B1, B0, 30 * 64, 0.2f);
+        ae_stage<64, 64, MapConvFwd<64, 4>>(W(P_E2W), 64 * 64 * 4, l.wl, 0, false);
+        ae_conv<30, 64, 14, 64, 4, 2, 0>(B1, l.wl, W(P_E2B), 64, B2);
+        ae_store(act + A_C2, B2, 14 * 64);
+        ae_chan_sums<14, 64, false>(l, B2, nullptr, slot(2));
+    } else if constexpr (PH == 4) {             // BN2 -> net.3 conv -> flatten -> out_net.0
+        ae_load(B0, act + A_C2, 14 * 64);
+        ae_bn_prepare<64>(a, l, 2, 2, nB * 14, P_BN2G, true);
+        ae_bn_act<64>(l, B1, B0, 14 * 64, 0.2f);
+        ae_stage<64, 32, MapConvFwd<64, 3>>(W(P_E3W), 32 * 64 * 3, l.wl, 0, false);
+        ae_conv<14, 64, 12, 32, 3, 1, 0>(B1, l.wl, W(P_E3B), 32, B2);
+        for (int i = threadIdx.x; i < 384; i += AE_NT) B3[i] = B2[(i % 12) * 32 + i / 12];       // flat[c * 12 + l] = c4[l][c]
+        __syncthreads();
+        ae_store(act + A_FLAT, B3, 384);
+        ae_fc<384, 256>(W(P_F1W), W(P_F1B), B3, B4);
+        ae_store(act + A_F1, B4, 256);
+        ae_chan_sums<1, 256, false>(l, B4, nullptr, slot(3));
+    } else if constexpr (PH == 5) {             // BN3 (LeakyReLU(True): slope 1) -> out_net.3
+        ae_load(B0, act + A_F1, 256);
+        ae_bn_prepare<256>(a, l, 3, 3, nB, P_BN3G, true);
+        ae_bn_act<256>(l, B1, B0, 256, 1.f);
+        ae_store(act + A_Y1F, B1, 256);
+        ae_fc<256, 128>(W(P_F2W), W(P_F2B), B1, B2);
+        ae_store(act + A_F2, B2, 128);
+        ae_chan_sums<1, 128, false>(l, B2, nullptr, slot(4));
+    } else if constexpr (PH == 6) {             // BN4 -> out_net.6 -> fc_mu (z = mu) -> decoder.pre_net.0
+        ae_load(B0, act + A_F2, 128);
+        ae_bn_prepare<128>(a, l, 4, 4, nB, P_BN4G, true);
+        ae_bn_act<128>(l, B1, B0, 128, 1.f);
+        ae_store(act + A_Y2F, B1, 128);
+        ae_fc<128, 32>(W(P_F3W), W(P_F3B), B1, B2);
+        ae_store(act + A_F3, B2, 32);
+        ae_fc<32, 32>(W(P_MUW), W(P_MUB), B2, B3);
+        ae_store(act + A_MU, B3, 32);
+        if (a.feat != nullptr) ae_store(a.feat + (size_t)clip * 32, B3, 32);
+        ae_fc<32, 64>(W(P_D0W), W(P_D0B), B3, B4);
+        ae_store(act + A_P0, B4, 64);
+        ae_chan_sums<1, 64, false>(l, B4, nullptr, slot(5));
+    } else if constexpr (PH == 7) {             // BN5 -> pre_net.3 -> view(4, 34) -> net.0 transposed conv
+        ae_load(B0, act + A_P0, 64);
+        ae_bn_prepare<64>(a, l, 5, 5, nB, P_BN5G, true);
+        ae_bn_act<64>(l, B1, B0, 64, 1.f);
+        ae_store(act + A_YP, B1, 64);
+        ae_fc<64, 136>(W(P_D1W), W(P_D1B), B1, B2);
+        ae_store(act + A_P3, B2, 136);
+        for (int i = threadIdx.x; i < 136; i += AE_NT) B3[i] = B2[(i & 3) * 34 + (i >> 2)];       // x0[l][c] = p3[c * 34 + l]
+        __syncthreads();
+        ae_stage<4, 32, MapConvTFwd<32, 3>>(W(P_T0W), 4 * 32 * 3, l.wl, 0, false);
+        ae_conv<34, 4, 36, 32, 3, 1, 2>(B3, l.wl, W(P_T0B), 32, B4);
+        ae_store(act + A_T0, B4, 36 * 32);
+        ae_chan_sums<36, 32, false>(l, B4, nullptr, slot(6));
+    } else if constexpr (PH == 8) {             // BN6 -> net.3 transposed conv
+        ae_load(B0, act + A_T0, 36 * 32);
+        ae_bn_prepare<32>(a, l, 6, 6, nB * 36, P_BN6G, true);
+        ae_bn_act<32>(l, B1, B0, 36 * 32, 0.2f);
+        ae_stage<32, 32, MapConvTFwd<32, 3>>(W(P_T1W), 32 * 32 * 3, l.wl, 0, false);
+        ae_conv<36, 32, 38, 32, 3, 1, 2>(B1, l.wl, W(P_T1B), 32, B2);
+        ae_store(act + A_T1, B2, 38 * 32);
+        ae_chan_sums<38, 32, false>(l, B2, nullptr, slot(7));
+    } else if constexpr (PH == 9) {             // BN7 -> net.6, net.7 -> loss -> back through net.7, net.6 to BN7's output gradient
+        ae_load(B0, act + A_T1, 38 * 32);
+        ae_bn_prepare<32>(a, l, 7, 7, nB * 38, P_BN7G, true);
+        ae_bn_act<32>(l, B1, B0, 38 * 32, 0.2f);                                                  // B1 = y(T1): net.6's input
+        ae_stage<32, 32, MapConvFwd<32, 3>>(W(P_C6W), 32 * 32 * 3, l.wl, 0, false);
+        ae_conv<38, 32, 36, 32, 3, 1, 0>(B1, l.wl, W(P_C6B), 32, B2);                             // B2 = c6
+        ae_stage<32, 32, MapConvFwd<32, 3>>(W(P_C7W), 27 * 32 * 3, l.wl, 3 * 32, true);
+        ae_conv<36, 32, 34, 32, 3, 1, 0>(B2, l.wl, W(P_C7B), 27, B3);                             // B3 = recon [34][32], columns 27.. zero
+        if (a.recon != nullptr)
+            for (int i = threadIdx.x; i < 34 * 27; i += AE_NT) a.recon[(size_t)clip * 918 + i] = B3[(i / 27) * 32 + i % 27];
+        ae_load_x<32>(B4, x);
+        for (int i = threadIdx.x; i < 34 * 32; i += AE_NT) B4[i] = B3[i] - B4[i];                 // e = recon - target (padding columns 0)
+        __syncthreads();
+        {   // L1 + L1 of the frame differences, mean over (frame, joint) per clip, summed over the batch (:63-72)
+            const float w1 = 1.f / (34.f * 27.f), w2 = 1.f / (33.f * 27.f);
+            float s = 0.f;
+            for (int i = threadIdx.x; i < 34 * 32; i += AE_NT) {
+                const int t = i >> 5;
+                const float e = B4[i];
+                float g = ae_sgn(e) * w1;
+                s += fabsf(e) * w1;
+                if (t >= 1) { const float d = e - B4[i - 32]; s += fabsf(d) * w2; g += ae_sgn(d) * w2; }
+                if (t + 1 < 34) { const float d = B4[i + 32] - e; g -= ae_sgn(d) * w2; }
+                B3[i] = g;                                                                         // d(loss) / d(recon)
+            }
+            l.red[threadIdx.x] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tot = 0.0;
+                for (int i = 0; i < AE_NT; ++i) tot += (double)l.red[i];
+                atomicAdd(slot(16), tot);
+            }
+            __syncthreads();
+        }
+        // net.7: weight / bias gradient, input gradient
+        ae_wgrad<36, 32, 34, 32, 3, 1, 0>(B2, B3, l.wl);
+        ae_unstage<32, 32, MapConvFwd<32, 3>>(part + Q_C7W, 27 * 32 * 3, l.wl);
+        ae_bias_grad<34, 32>(B3, part + Q_C7B, 28);
+        ae_stage<32, 32, MapConvDgrad<32, 3>>(W(P_C7W), 27 * 32 * 3, l.wl, 3 * 32, true);
+        ae_conv<34, 32, 36, 32, 3, 1, 2>(B3, l.wl, nullptr, 0, B4);                               // B4 = d c6
+        // net.6
+        ae_wgrad<38, 32, 36, 32, 3, 1, 0>(B1, B4, l.wl);
+        ae_unstage<32, 32, MapConvFwd<32, 3>>(part + Q_C6W, 32 * 32 * 3, l.wl);
+        ae_bias_grad<36, 32>(B4, part + Q_C6B, 32);
+        ae_stage<32, 32, MapConvDgrad<32, 3>>(W(P_C6W), 32 * 32 * 3, l.wl, 0, false);
+        ae_conv<36, 32, 38, 32, 3, 1, 2>(B4, l.wl, nullptr, 0, B2);                               // B2 = d y(T1)
+        ae_act_bwd<32>(l, B2, B0, 38 * 32, 0.2f);
+        ae_store(act + A_G, B2, 38 * 32);
+        ae_chan_sums<38, 32, true>(l, B2, B0, slot(8));
+    } else if constexpr (PH == 10) {            // BN7 backward -> net.3 (transposed conv) -> BN6's output gradient
+        ae_load(B0, act + A_G, 38 * 32);
+        ae_load(B1, act + A_T1, 38 * 32);
+        ae_bn_prepare<32>(a, l, 7, 7, nB * 38, P_BN7G, false);
+        ae_bwd_means<32>(a, l, 8, nB * 38);
+        ae_bn_bwd<32>(l, B0, B1, 38 * 32);                                                        // B0 = d t1
+        ae_load(B2, act + A_T0, 36 * 32);
+        ae_bn_prepare<32>(a, l, 6, 6, nB * 36, P_BN6G, false);
+        ae_bn_act<32>(l, B3, B2, 36 * 32, 0.2f);                                                  // B3 = y(T0): the layer's input
+        ae_wgrad<36, 32, 38, 32, 3, 1, 2>(B3, B0, l.wl);
+        ae_unstage<32, 32, MapConvTFwd<32, 3>>(part + Q_T1W, 32 * 32 * 3, l.wl);
+        ae_bias_grad<38, 32>(B0, part + Q_T1B, 32);
+        ae_stage<32, 32, MapConvTDgrad<32, 3>>(W(P_T1W), 32 * 32 * 3, l.wl, 0, false);
+        ae_conv<38, 32, 36, 32, 3, 1, 0>(B0, l.wl, nullptr, 0, B4);                               // B4 = d y(T0)
+        ae_act_bwd<32>(l, B4, B2, 36 * 32, 0.2f);
+        ae_store(act + A_G, B4, 36 * 32);
+        ae_chan_sums<36, 32, true>(l, B4, B2, slot(9));
+    } else if constexpr (PH == 11) {            // BN6 backward -> net.0 (transposed conv) -> pre_net.3 -> BN5's output gradient
+        ae_load(B0, act + A_G, 36 * 32);
+        ae_load(B1, act + A_T0, 36 * 32);
+        ae_bn_prepare<32>(a, l, 6, 6, nB * 36, P_BN6G, false);
+        ae_bwd_means<32>(a, l, 9, nB * 36);
+        ae_bn_bwd<32>(l, B0, B1, 36 * 32);                                                        // B0 = d t0
+        ae_load(B2, act + A_P3, 136);
+        for (int i = threadIdx.x; i < 136; i += AE_NT) B3[i] = B2[(i & 3) * 34 + (i >> 2)];       // x0[l][c]
+        __syncthreads();
+        ae_wgrad<34, 4, 36, 32, 3, 1, 2>(B3, B0, l.wl);
+        ae_unstage<4, 32, MapConvTFwd<32, 3>>(part + Q_T0W, 4 * 32 * 3, l.wl);
+        ae_bias_grad<36, 32>(B0, part + Q_T0B, 32);
+        ae_stage<32, 4, MapConvTDgrad<32, 3>>(W(P_T0W), 4 * 32 * 3, l.wl, 0, false);
+        ae_conv<36, 32, 34, 4, 3, 1, 0>(B0, l.wl, nullptr, 0, B4);                                // B4 = d x0 [34][4]
+        for (int i = threadIdx.x; i < 136; i += AE_NT) B2[i] = B4[(i % 34) * 4 + i / 34];         // d p3[c * 34 + l]
+        __syncthreads();
+        ae_store(act + A_DP3, B2, 136);
+        ae_fc_dgrad<64, 136>(W(P_D1W), B2, B3, B4);                                               // B3 = d yp = g (slope 1)
+        ae_store(act + A_G, B3, 64);
+        ae_load(B1, act + A_P0, 64);
+        ae_bn_prepare<64>(a, l, 5, 5, nB, P_BN5G, false);
+        ae_chan_sums<1, 64, true>(l, B3, B1, slot(10));
+    } else if constexpr (PH == 12) {            // BN5 backward -> pre_net.0 -> fc_mu -> out_net.6 -> BN4's output gradient
+        ae_load(B0, act + A_G, 64);
+        ae_load(B1, act + A_P0, 64);
+        ae_bn_prepare<64>(a, l, 5, 5, nB, P_BN5G, false);
+        ae_bwd_means<64>(a, l, 10, nB);
+        ae_bn_bwd<64>(l, B0, B1, 64);                                                             // B0 = d p0
+        ae_store(act + A_DP0, B0, 64);
+        ae_fc_dgrad<32, 64>(W(P_D0W), B0, B2, B4);                                                // B2 = d mu
+        ae_store(act + A_DMU, B2, 32);
+        ae_fc_dgrad<32, 32>(W(P_MUW), B2, B3, B4);                                                // B3 = d f3
+        ae_store(act + A_DF3, B3, 32);
+        ae_fc_dgrad<128, 32>(W(P_F3W), B3, B0, B4);                                               // B0 = d y2f = g
+        ae_store(act + A_G, B0, 128);
+        ae_load(B1, act + A_F2, 128);
+        ae_bn_prepare<128>(a, l, 4, 4, nB, P_BN4G, false);
+        ae_chan_sums<1, 128, true>(l, B0, B1, slot(11));
+    } else if constexpr (PH == 13) {            // BN4 backward -> out_net.3 -> BN3's output gradient
+        ae_load(B0, act + A_G, 128);
+        ae_load(B1, act + A_F2, 128);
+        ae_bn_prepare<128>(a, l, 4, 4, nB, P_BN4G, false);
+        ae_bwd_means<128>(a, l, 11, nB);
+        ae_bn_bwd<128>(l, B0, B1, 128);                                                           // B0 = d f2
+        ae_store(act + A_DF2, B0, 128);
+        ae_fc_dgrad<256, 128>(W(P_F2W), B0, B2, B4);                                              // B2 = d y1f = g
+        ae_store(act + A_G, B2, 256);
+        ae_load(B1, act + A_F1, 256);
+        ae_bn_prepare<256>(a, l, 3, 3, nB, P_BN3G, false);
+        ae_chan_sums<1, 256, true>(l, B2, B1, slot(12));
+    } else if constexpr (PH == 14) {            // BN3 backward -> out_net.0 -> un-flatten -> net.3 conv -> BN2's output gradient
+        ae_load(B0, act + A_G, 256);
+        ae_load(B1, act + A_F1, 256);
+        ae_bn_prepare<256>(a, l, 3, 3, nB, P_BN3G, false);
+        ae_bwd_means<256>(a, l, 12, nB);
+        ae_bn_bwd<256>(l, B0, B1, 256);                                                           // B0 = d f1
+        ae_store(act + A_DF1, B0, 256);
+        ae_fc_dgrad<384, 256>(W(P_F1W), B0, B2, B4);                                              // B2 = d flat
+        for (int i = threadIdx.x; i < 384; i += AE_NT) B3[i] = B2[(i & 31) * 12 + (i >> 5)];      // d c4[l][c] = d flat[c * 12 + l]
+        __syncthreads();
+        ae_load(B0, act + A_C2, 14 * 64);
+        ae_bn_prepare<64>(a, l, 2, 2, nB * 14, P_BN2G, false);
+        ae_bn_act<64>(l, B1, B0, 14 * 64, 0.2f);                                                  // B1 = y2
+        ae_wgrad<14, 64, 12, 32, 3, 1, 0>(B1, B3, l.wl);
+        ae_unstage<64, 32, MapConvFwd<64, 3>>(part + Q_E3W, 32 * 64 * 3, l.wl);
+        ae_bias_grad<12, 32>(B3, part + Q_E3B, 32);
+        ae_stage<32, 64, MapConvDgrad<64, 3>>(W(P_E3W), 32 * 64 * 3, l.wl, 0, false);
+        ae_conv<12, 32, 14, 64, 3, 1, 2>(B3, l.wl, nullptr, 0, B4);                               // B4 = d y2
+        ae_act_bwd<64>(l, B4, B0, 14 * 64, 0.2f);
+        ae_store(act + A_G, B4, 14 * 64);
+        ae_chan_sums<14, 64, true>(l, B4, B0, slot(13));
+    } else if constexpr (PH == 15) {            // BN2 backward -> net.2 conv (stride 2) -> BN1's output gradient
+        ae_load(B0, act + A_G, 14 * 64);
+        ae_load(B1, act + A_C2, 14 * 64);
+        ae_bn_prepare<64>(a, l, 2, 2, nB * 14, P_BN2G, false);
+        ae_bwd_means<64>(a, l, 13, nB * 14);
+        ae_bn_bwd<64>(l, B0, B1, 14 * 64);                                                        // B0 = d c2
+        ae_load(B2, act + A_C1, 30 * 64);
+        ae_bn_prepare<64>(a, l, 1, 1, nB * 30, P_BN1G, false);
+        ae_bn_act<64>(l, B3, B2, 30 * 64, 0.2f);                                                  // B3 = y1
+        ae_wgrad<30, 64, 14, 64, 4, 2, 0>(B3, B0, l.wl);
+        ae_unstage<64, 64, MapConvFwd<64, 4>>(part + Q_E2W, 64 * 64 * 4, l.wl);
+        ae_bias_grad<14, 64>(B0, part + Q_E2B, 64);
+        // input gradient of the stride-2 conv as a stride-1 transposed conv over d c2 with a zero row between its rows
+        for (int i = threadIdx.x; i < 27 * 64; i += AE_NT) { const int r = i >> 6; B4[i] = (r & 1) ? 0.f : B0[(r >> 1) * 64 + (i & 63)]; }
+        __syncthreads();
+        ae_stage<64, 64, MapConvDgrad<64, 4>>(W(P_E2W), 64 * 64 * 4, l.wl, 0, false);
+        ae_conv<27, 64, 30, 64, 4, 1, 3>(B4, l.wl, nullptr, 0, B1);                               // B1 = d y1
+        ae_act_bwd<64>(l, B1, B2, 30 * 64, 0.2f);
+        ae_store(act + A_G, B1, 30 * 64);
+        ae_chan_sums<30, 64, true>(l, B1, B2, slot(14));
+    } else if constexpr (PH == 16) {            // BN1 backward -> net.1 conv -> BN0's output gradient
+        ae_load(B0, act + A_G, 30 * 64);
+        ae_load(B1, act + A_C1, 30 * 64);
+        ae_bn_prepare<64>(a, l, 1, 1, nB * 30, P_BN1G, false);
+        ae_bwd_means<64>(a, l, 14, nB * 30);
+        ae_bn_bwd<64>(l, B0, B1, 30 * 64);                                                        // B0 = d c1
+        ae_load(B2, act + A_C0, 32 * 32);
+        ae_bn_prepare<32>(a, l, 0, 0, nB * 32, P_BN0G, false);
+        ae_bn_act<32>(l, B3, B2, 32 * 32, 0.2f);                                                  // B3 = y0
+        ae_wgrad<32, 32, 30, 64, 3, 1, 0>(B3, B0, l.wl);
+        ae_unstage<32, 64, MapConvFwd<32, 3>>(part + Q_E1W, 64 * 32 * 3, l.wl);
+        ae_bias_grad<30, 64>(B0, part + Q_E1B, 64);
+        ae_stage<64, 32, MapConvDgrad<32, 3>>(W(P_E1W), 64 * 32 * 3, l.wl, 0, false);
+        ae_conv<30, 64, 32, 32, 3, 1, 2>(B0, l.wl, nullptr, 0, B4);                               // B4 = d y0
+        ae_act_bwd<32>(l, B4, B2, 32 * 32, 0.2f);
+        ae_store(act + A_G, B4, 32 * 32);
+        ae_chan_sums<32, 32, true>(l, B4, B2, slot(15));
+    } else if constexpr (PH == 17) {            // BN0 backward -> net.0 conv weight gradient
+        ae_load(B0, act + A_G, 32 * 32);
+        ae_load(B1, act + A_C0, 32 * 32);
+        ae_bn_prepare<32>(a, l, 0, 0, nB * 32, P_BN0G, false);
+        ae_bwd_means<32>(a, l, 15, nB * 32);
+        ae_bn_bwd<32>(l, B0, B1, 32 * 32);                                                        // B0 = d c0
+        ae_load_x<28>(B2, x);
+        ae_wgrad<34, 28, 32, 32, 3, 1, 0>(B2, B0, l.wl);
+        ae_unstage<28, 32, MapConvFwd<27, 3>>(part + Q_E0W, 32 * 27 * 3, l.wl);
+        ae_bias_grad<32, 32>(B0, part + Q_E0B, 32);
+    }
+}
+
+// ---- phase 18: gradients into the slab --------------------------------------------------------------------------------------------------
+struct AeFcLayer { int pw, n, k, x_off, dy_off, unit0, kc; };
+__constant__ AeFcLayer ae_fc_layers[6] = {
+    {P_F1W, 256, 384, A_FLAT, A_DF1, 0, 6},   {P_F2W, 128, 256, A_Y1F, A_DF2, 192, 4}, {P_F3W, 32, 128, A_Y2F, A_DF3, 256, 2},
+    {P_MUW, 32, 32, A_F3, A_DMU, 264, 1},     {P_D0W, 64, 32, A_MU, A_DP0, 268, 1},    {P_D1W, 136, 64, A_YP, A_DP3, 276, 1}};
+constexpr int AE_FC_UNITS = 293;
+constexpr int AE_RED_UNITS = (AE_PART / 4 + AE_NT - 1) / AE_NT;       // 20
+constexpr int AE_TAIL_UNITS = AE_FC_UNITS + AE_RED_UNITS + 1;
+__constant__ int ae_seg_begin[17] = {Q_E0W, Q_E0B, Q_E1W, Q_E1B, Q_E2W, Q_E2B, Q_E3W, Q_E3B, Q_T0W, Q_T0B, Q_T1W, Q_T1B, Q_C6W, Q_C6B, Q_C7W, Q_C7B, AE_PART};
+__constant__ int ae_seg_param[16] = {P_E0W, P_E0B, P_E1W, P_E1B, P_E2W, P_E2B, P_E3W, P_E3B, P_T0W, P_T0B, P_T1W, P_T1B, P_C6W, P_C6B, P_C7W, P_C7B};
+__constant__ int ae_bn_gamma[8] = {P_BN0G, P_BN1G, P_BN2G, P_BN3G, P_BN4G, P_BN5G, P_BN6G, P_BN7G};
+__constant__ int ae_bn_ch[8] = {32, 64, 64, 256, 128, 64, 32, 32};
+
+__global__ __launch_bounds__(AE_NT) void ae_tail_kernel(const AeArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[256 * 64];
+    __shared__ __attribute__((aligned(16))) float ds[256 * 8];
+    const int u = blockIdx.x, t = threadIdx.x, B = a.B;
+    if (u < AE_FC_UNITS) {
+        // linear layer weight gradient: rows [n0, n0 + 8) x columns [k0, k0 + 64) of dW = dy^T x, reduced over the batch here (batch order)
+        int li = 0;
+        while (li < 5 && u >= ae_fc_layers[li + 1].unit0) ++li;
+        const AeFcLayer L = ae_fc_layers[li];
+        const int lu = u - L.unit0, n0 = (lu / L.kc) * 8, k0 = (lu % L.kc) * 64;
+        for (int i = t; i < B * 16; i += AE_NT) {               // x[b][k0 .. k0 + 64) as 16-byte pieces
+            const int b = i >> 4, q = (i & 15) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + q < L.k) v = *reinterpret_cast<const f32x4*>(a.act + (size_t)b * AE_ACT + L.x_off + k0 + q);
+            *reinterpret_cast<f32x4*>(xs + b * 64 + q) = v;
+        }
+        for (int i = t; i < B * 8; i += AE_NT) {
+            const int b = i >> 3, r = i & 7;
+            ds[i] = n0 + r < L.n ? a.act[(size_t)b * AE_ACT + L.dy_off + n0 + r] : 0.f;
+        }
+        __syncthreads();
+        const int k = t & 63, r = t >> 6;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int b = 0; b < B; ++b) acc = fmaf(ds[b * 8 + r], xs[b * 64 + k], acc);
+        if (n0 + r < L.n && k0 + k < L.k) a.G[a.off[L.pw] + (size_t)(n0 + r) * L.k + k0 + k] = acc;
+        if (k0 == 0 && t < 8 && n0 + t < L.n) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += ds[b * 8 + t];
+            a.G[a.off[L.pw + 1] + n0 + t] = s;
+        }
+    } else if (u < AE_FC_UNITS + AE_RED_UNITS) {
+        // conv weight / bias gradients: the per-clip partials summed in clip order
+        const int i4 = (u - AE_FC_UNITS) * AE_NT + t;
+        if (i4 < AE_PART / 4) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int b = 0; b < B; ++b) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.part + (size_t)b * AE_PART + 4 * i4);
+                acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+            }
+            int s = 0;
+            while (4 * i4 >= ae_seg_begin[s + 1]) ++s;
+            *reinterpret_cast<f32x4*>(a.G + a.off[ae_seg_param[s]] + (4 * i4 - ae_seg_begin[s])) = acc;
+        }
+    } else {
+        // BatchNorm gamma / beta gradients = the backward sums (slot 15 - bn: sum g * xhat, sum g); loss; Adam step counter; sums back to zero
+        for (int bn = 0; bn < 8; ++bn) {
+            const double* s = a.sums + (size_t)(15 - bn) * 512;
+            for (int c = t; c < ae_bn_ch[bn]; c += AE_NT) {
+                a.G[a.off[ae_bn_gamma[bn]] + c] = (float)s[256 + c];
+                a.G[a.off[ae_bn_gamma[bn] + 1] + c] = (float)s[c];
+            }
+        }
+        if (t == 0) {
+            *a.loss = (float)a.sums[16 * 512];
+            if (a.step != nullptr) *a.step += 1;
+        }
+        __syncthreads();
+        for (int i = t; i < AE_SLOTS * 512; i += AE_NT) a.sums[i] = 0.0;
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" int32_t tg_ae_step_supported(int32_t B) { return B >= 2 && B <= 256 ? 1 : 0; }
+
+extern "C" int64_t tg_ae_step_ws_bytes(int32_t B) {
+    return (int64_t)AE_SLOTS * 512 * 8 + ((int64_t)B * AE_ACT + (int64_t)B * AE_PART) * 4;
+}
+
+extern "C" int tg_ae_train_step(const tg_ae_step_args* q, void* stream) {
+    TG_REQUIRE(q && q->x && q->params && q->grads && q->ws && q->loss, "tg_ae_train_step: null pointer");
+    TG_REQUIRE(tg_ae_step_supported(q->B), "tg_ae_train_step: batch %d outside [2, 256]", q->B);
+    TG_REQUIRE(q->ws_bytes >= tg_ae_step_ws_bytes(q->B), "tg_ae_train_step: workspace too small");
+    TG_REQUIRE(aligned16(q->x) && aligned16(q->params) && aligned16(q->grads) && aligned16(q->ws) && (q->feat == nullptr || aligned16(q->feat)),
+               "tg_ae_train_step: operands must be 16-byte aligned");
+    TG_REQUIRE(q->last_phase >= 0 && q->last_phase <= 18, "tg_ae_train_step: last_phase %d", q->last_phase);
+    AeArgs a;
+    a.x = q->x; a.P = q->params; a.G = q->grads;
+    for (int i = 0; i < P_COUNT; ++i) {
+        TG_REQUIRE(q->off[i] >= 0 && q->off[i] % 4 == 0, "tg_ae_train_step: parameter offset %d (entry %d) must be a non-negative multiple of 4 floats", q->off[i], i);
+        a.off[i] = q->off[i];
+    }
+    for (int i = 0; i < 8; ++i) {
+        TG_REQUIRE((q->running_mean[i] == nullptr) == (q->running_var[i] == nullptr), "tg_ae_train_step: running_mean / running_var go together");
+        a.rm[i] = q->running_mean[i]; a.rv[i] = q->running_var[i]; a.nbt[i] = (long long*)q->num_batches_tracked[i];
+    }
+    a.sums = (double*)q->ws;
+    a.act = (float*)((char*)q->ws + (size_t)AE_SLOTS * 512 * 8);
+    a.part = a.act + (size_t)q->B * AE_ACT;
+    a.loss = q->loss; a.recon = q->recon; a.feat = q->feat; a.step = q->step;
+    a.B = q->B; a.bn_eps = q->bn_eps; a.momentum = q->momentum;
+    hipStream_t s = (hipStream_t)stream;
+    const int last = q->last_phase == 0 ? 18 : q->last_phase;
+    const dim3 grid(q->B), block(AE_NT);
+#define TG_AE_PHASE(PH_)                                                                     \
+    do {                                                                                     \
+        if (last >= PH_) hipLaunchKernelGGL(ae_phase_kernel<PH_>, grid, block, 0, s, a);     \
+    } while (0)
+    TG_AE_PHASE(1); TG_AE_PHASE(2); TG_AE_PHASE(3); TG_AE_PHASE(4); TG_AE_PHASE(5); TG_AE_PHASE(6); TG_AE_PHASE(7); TG_AE_PHASE(8); TG_AE_PHASE(9);
+    TG_AE_PHASE(10); TG_AE_PHASE(11); TG_AE_PHASE(12); TG_AE_PHASE(13); TG_AE_PHASE(14); TG_AE_PHASE(15); TG_AE_PHASE(16); TG_AE_PHASE(17);
+#undef TG_AE_PHASE
+    if (last >= 18) hipLaunchKernelGGL(ae_tail_kernel, dim3(AE_TAIL_UNITS), block, 0, s, a);
+    return check_launch("tg_ae_train_step");
+}

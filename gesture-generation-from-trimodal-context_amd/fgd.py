@@ -143,20 +143,50 @@ def train_iter(args, epoch, target_data, net, optim):
 
 class AutoencoderTrainer:
     """train_feature_extractor.py:train_iter with variational_encoding=False: reconstruction L1 + L1 of frame differences,
-    summed over the batch; Adam(lr 5e-4, betas (0.5, 0.999))."""
+    summed over the batch; Adam(lr 5e-4, betas (0.5, 0.999)).
+    fused (default: where supported): the step up to the gradients as the 18 launches of csrc/ae_step.hip + the slab's Adam launch instead of the
+    ~105 launches of the layer-by-layer engine (kept for other shapes and as the test reference)."""
 
-    def __init__(self, net, lr=5e-4):
+    def __init__(self, net, lr=5e-4, fused=None):
         self.net, self.E = net, net.engine
         self.opt = FusedAdam(self.E, lr=lr, betas=(0.5, 0.999))
+        self.fused = fused
+        self._plan = None
+        self.last = {}
 
-    def train_iter(self, target):
+    def _fused_plan(self, target):
+        slab = self.E.slab.ensure()
+        B = target.shape[0]
+        if self.fused is False or not target.is_cuda or not ops.AeStep.supported(slab, B, target.shape):
+            if self.fused:
+                raise RuntimeError(f"fused autoencoder step: unsupported batch / shapes {tuple(target.shape)}")
+            return None
+        p = self._plan
+        if p is None or p.slab_ptr != slab.flat.data_ptr() or p.B != B:
+            assert not torch.cuda.is_current_stream_capturing(), "run one eager step before capturing (the plan allocates its workspace)"
+            slab.zero_grad()                 # fc_logvar gets no gradient (:58): its slots stay zero, every other one is written by each step
+            p = self._plan = ops.AeStep(slab, dict(self.net.named_buffers()), B)
+        return p
+
+    def train_iter(self, target, keep_outputs=False):
         E = self.E
-        E.slab.ensure().zero_grad()
         target = target.float().contiguous()
-        res = E.forward(target, training=True, save=True)
+        plan = self._fused_plan(target)
         loss = torch.empty(1, device=target.device)
+        if plan is not None:
+            recon = torch.empty_like(target) if keep_outputs else None
+            feat = torch.empty(target.shape[0], 32, device=target.device) if keep_outputs else None
+            plan.run(target, loss, recon=recon, feat=feat)
+            self.opt.step(counter_advanced=True)             # the step counter was advanced by the last launch of the plan
+            if keep_outputs:
+                self.last = {"recon": recon, "feat": feat}
+            return loss
+        E.slab.ensure().zero_grad()
+        res = E.forward(target, training=True, save=True)
         d_recon = torch.empty_like(target)
         ops.ae_loss(res["recon"], target, loss, d_recon)
         E.backward(res["tape"], d_recon)
         self.opt.step()
+        if keep_outputs:
+            self.last = {"recon": res["recon"], "feat": res["feat"]}
         return loss

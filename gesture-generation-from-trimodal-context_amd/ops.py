@@ -1144,6 +1144,76 @@ def ae_loss(recon, target, out, d_recon):
     call("tg_ae_loss", _p(recon), _p(target), B, T, D, _p(_flat(out, "out")), _p(d_recon), _stream())
 
 
+# ------------------------------------------------------------------------------------------------- fused autoencoder training step
+# csrc/ae_step.hip: the FGD autoencoder's training step up to the gradients in 18 launches (train_feature_extractor.py:54-97)
+_AE_E, _AE_D = "pose_encoder", "decoder"
+AE_PARAMS = ([(f"{_AE_E}.net.{i}.{j}.{w}", s) for i, (co, ci, kw) in enumerate(((32, 27, 3), (64, 32, 3), (64, 64, 4)))
+              for j, w, s in ((0, "weight", (co, ci, kw)), (0, "bias", (co,)), (1, "weight", (co,)), (1, "bias", (co,)))] +
+             [(f"{_AE_E}.net.3.weight", (32, 64, 3)), (f"{_AE_E}.net.3.bias", (32,)),
+              (f"{_AE_E}.out_net.0.weight", (256, 384)), (f"{_AE_E}.out_net.0.bias", (256,)), (f"{_AE_E}.out_net.1.weight", (256,)), (f"{_AE_E}.out_net.1.bias", (256,)),
+              (f"{_AE_E}.out_net.3.weight", (128, 256)), (f"{_AE_E}.out_net.3.bias", (128,)), (f"{_AE_E}.out_net.4.weight", (128,)), (f"{_AE_E}.out_net.4.bias", (128,)),
+              (f"{_AE_E}.out_net.6.weight", (32, 128)), (f"{_AE_E}.out_net.6.bias", (32,)), (f"{_AE_E}.fc_mu.weight", (32, 32)), (f"{_AE_E}.fc_mu.bias", (32,)),
+              (f"{_AE_D}.pre_net.0.weight", (64, 32)), (f"{_AE_D}.pre_net.0.bias", (64,)), (f"{_AE_D}.pre_net.1.weight", (64,)), (f"{_AE_D}.pre_net.1.bias", (64,)),
+              (f"{_AE_D}.pre_net.3.weight", (136, 64)), (f"{_AE_D}.pre_net.3.bias", (136,)),
+              (f"{_AE_D}.net.0.weight", (4, 32, 3)), (f"{_AE_D}.net.0.bias", (32,)), (f"{_AE_D}.net.1.weight", (32,)), (f"{_AE_D}.net.1.bias", (32,)),
+              (f"{_AE_D}.net.3.weight", (32, 32, 3)), (f"{_AE_D}.net.3.bias", (32,)), (f"{_AE_D}.net.4.weight", (32,)), (f"{_AE_D}.net.4.bias", (32,)),
+              (f"{_AE_D}.net.6.weight", (32, 32, 3)), (f"{_AE_D}.net.6.bias", (32,)), (f"{_AE_D}.net.7.weight", (27, 32, 3)), (f"{_AE_D}.net.7.bias", (27,))])
+AE_BNS = [f"{_AE_E}.net.0.1", f"{_AE_E}.net.1.1", f"{_AE_E}.net.2.1", f"{_AE_E}.out_net.1", f"{_AE_E}.out_net.4", f"{_AE_D}.pre_net.1", f"{_AE_D}.net.1", f"{_AE_D}.net.4"]
+assert len(AE_PARAMS) == 44
+
+
+class AeStep:
+    """The argument block and workspace of tg_ae_train_step for one parameter slab and batch size (built once; safe to capture)."""
+
+    @staticmethod
+    def supported(slab, B, poses_shape):
+        if tuple(poses_shape[1:]) != (34, 27) or not _lib.load().tg_ae_step_supported(int(B)):
+            return False
+        shapes = {n: tuple(p.shape) for n, p in zip(slab.names, slab.params)}
+        known = {n for n, _ in AE_PARAMS} | {f"{_AE_E}.fc_logvar.weight", f"{_AE_E}.fc_logvar.bias"}
+        return all(shapes.get(n) == s for n, s in AE_PARAMS) and set(shapes) <= known and not slab.frozen
+
+    def __init__(self, slab, buffers, B):
+        dev = slab.flat.device
+        self.slab_ptr, self.B = slab.flat.data_ptr(), int(B)
+        off = dict(zip(slab.names, slab.offsets))
+        q = _lib.AeStepArgs()
+        q.params, q.grads = slab.flat.data_ptr(), slab.grad.data_ptr()
+        for i, (n, _) in enumerate(AE_PARAMS):
+            q.off[i] = off[n]
+        self._keep = []
+        for i, bn in enumerate(AE_BNS):
+            rm, rv, nbt = buffers[bn + ".running_mean"], buffers[bn + ".running_var"], buffers[bn + ".num_batches_tracked"]
+            assert rm.is_cuda and rm.dtype == torch.float32 and nbt.dtype == torch.int64
+            q.running_mean[i], q.running_var[i], q.num_batches_tracked[i] = rm.data_ptr(), rv.data_ptr(), nbt.data_ptr()
+            self._keep += [rm, rv, nbt]
+        nbytes = _lib.load().tg_ae_step_ws_bytes(self.B)
+        self.ws = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev)
+        q.ws, q.ws_bytes = self.ws.data_ptr(), self.ws.numel() * 4
+        q.step = slab.step.data_ptr()
+        q.B, q.bn_eps, q.momentum = self.B, 1e-5, 0.1
+        self.q = q
+
+    def run(self, x, loss, recon=None, feat=None, last_phase=0):
+        _flat(x, "poses"); assert tuple(x.shape) == (self.B, 34, 27)
+        q = self.q
+        q.x, q.loss = x.data_ptr(), _flat(loss, "loss").data_ptr()
+        q.recon = None if recon is None else _flat(recon, "recon").data_ptr()
+        q.feat = None if feat is None else _flat(feat, "feat").data_ptr()
+        q.last_phase = int(last_phase)
+        call("tg_ae_train_step", C.byref(q), _stream())
+
+    def workspace_views(self):
+        """(sums [17, 2, 256] fp64, act [B, AE_ACT], part [B, AE_PART]) views of the workspace (tests)."""
+        n_act, n_part = 10256, 40700
+        assert _lib.load().tg_ae_step_ws_bytes(self.B) == 17 * 512 * 8 + self.B * (n_act + n_part) * 4
+        f = self.ws.view(torch.float32)
+        sums = self.ws[:17 * 512 * 2].view(torch.float64).view(17, 2, 256)
+        act = f[17 * 512 * 2:17 * 512 * 2 + self.B * n_act].view(self.B, n_act)
+        part = f[17 * 512 * 2 + self.B * n_act:17 * 512 * 2 + self.B * (n_act + n_part)].view(self.B, n_part)
+        return sums, act, part
+
+
 # ------------------------------------------------------------------------------------------------- optimiser
 def counter_inc(counter):
     assert counter.is_cuda and counter.dtype == torch.int32

@@ -552,6 +552,40 @@ int tg_pose_metrics(const float* out_dir_vec, const float* target_dir_vec, const
 int tg_ae_loss(const float* recon, const float* target, int32_t B, int32_t T, int32_t D, float* out, float* d_recon,
                void* stream);
 
+/* One FGD autoencoder training step up to the gradients (scripts/train_feature_extractor.py:54-97 on model/embedding_net.py:42-82,165-217:
+ * PoseEncoderConv + PoseDecoderConv, 34 frames x 27, variational_encoding = False) in 18 launches (ABI 5; csrc/ae_step.hip): forward in
+ * train mode (the eight BatchNorms' running statistics advance), loss = sum_b [mean |recon - x| + mean |d recon - d x|], and every parameter
+ * gradient WRITTEN (not accumulated) into `grads` at the parameter's offset; fc_logvar receives no gradient (:58) and is not touched.
+ * tg_adam_step over the slab completes the step; *step (device Adam counter, may be NULL) is advanced by one here.
+ * off[44]: offsets in floats (multiples of 4) of, in this order: pose_encoder.net.{0,1,2}: {0.weight, 0.bias, 1.weight, 1.bias} each; net.3.{weight,
+ * bias}; out_net.0.{weight, bias}, out_net.1.{weight, bias}, out_net.3.{..}, out_net.4.{..}, out_net.6.{..}; fc_mu.{..}; decoder.pre_net.0.{..},
+ * pre_net.1.{..}, pre_net.3.{..}; decoder.net.0.{..}, net.1.{..}, net.3.{..}, net.4.{..}, net.6.{..}, net.7.{..}.
+ * running_mean / running_var / num_batches_tracked[8]: the BatchNorms in forward order (encoder net.0-2, out_net.1, out_net.4, pre_net.1, decoder
+ * net.1, net.4); a NULL pair skips that update.  ws: tg_ae_step_ws_bytes(B) bytes, 16-byte aligned, ZERO before the first use; a complete step
+ * leaves its statistics block zero again (after an aborted step: zero it).  recon [B][34][27] and feat [B][32] (= mu) are optional outputs.
+ * last_phase: 0 = the whole step; 1..18 = stop after that launch (tests).  2 <= B <= 256 (tg_ae_step_supported). */
+typedef struct {
+    const float* x;                       /* [B][34][27] */
+    float* params;
+    float* grads;
+    int32_t off[44];
+    float* running_mean[8];
+    float* running_var[8];
+    int64_t* num_batches_tracked[8];
+    void* ws;
+    int64_t ws_bytes;
+    float* loss;                          /* [1] */
+    float* recon;
+    float* feat;
+    int32_t* step;
+    int32_t B;
+    float bn_eps, momentum;
+    int32_t last_phase;
+} tg_ae_step_args;
+int32_t tg_ae_step_supported(int32_t B);
+int64_t tg_ae_step_ws_bytes(int32_t B);
+int tg_ae_train_step(const tg_ae_step_args* args, void* stream);
+
 /* ---- optimiser (torch.optim.Adam, train.py:104-109): one fused launch over a flat parameter slab ------
  * step_dev: device int32 step counter, incremented by tg_counter_inc BEFORE the update (graph-replay safe). */
 int tg_counter_inc(int32_t* counter, void* stream);

@@ -34,6 +34,8 @@ def fuzz(lib_path=None):
             return (L.NtProblem * 2)() if mode else None
         if argtype == C.POINTER(L.TnProblem):
             return (L.TnProblem * 2)() if mode else None
+        if argtype == C.POINTER(L.AeStepArgs):
+            return C.byref(L.AeStepArgs()) if mode else None
         if argtype == C.POINTER(L.P):
             return (L.P * 8)() if mode else None
         raise TypeError(argtype)

@@ -453,6 +453,91 @@ def test_autoencoder_and_fgd(pkg, dev):
     assert torch.equal(sd["pose_encoder.fc_logvar.weight"].cpu(), ast["pose_encoder.fc_logvar.weight"])
 
 
+@pytest.mark.parametrize("B", [128, 37])
+def test_fused_autoencoder_step_matches_layer_engine_and_oracle(pkg, dev, B):
+    """csrc/ae_step.hip (the FGD autoencoder's training step in 18 launches, train_feature_extractor.py:54-97) against the layer-by-layer
+    engine from the same state -- every saved activation, the loss, every gradient, the parameters / Adam moments / BatchNorm buffers after
+    TWO steps (the second one checks that the first left its workspace and the step counter right) -- and its gradients against the fp64 oracle."""
+    from importlib import import_module
+    fgd = import_module(pkg.__name__ + ".fgd")
+    ops = pkg.ops
+    ast = O.make_autoencoder_state(5)
+    gp = torch.Generator().manual_seed(77 + B)
+    poses = [(0.1 * torch.randn(B, 34, 27, generator=gp)).to(dev) for _ in range(2)]
+    nets, trs = [], []
+    for fused in (True, False):
+        AE = pkg.EmbeddingNet(make_args(), 27, 34).to(dev)
+        AE.load_state_dict(O.clone_state(ast), strict=True)
+        AE.train()
+        nets.append(AE); trs.append(fgd.AutoencoderTrainer(AE, lr=5e-4, fused=fused))
+    # step 1: activations and gradients
+    l_f = trs[0].train_iter(poses[0], keep_outputs=True)
+    assert trs[0]._plan is not None
+    E = nets[1].engine
+    E.slab.ensure().zero_grad()
+    res = E.forward(poses[0], training=True, save=True)
+    l_e = torch.empty(1, device=dev); d_recon = torch.empty_like(poses[0])
+    ops.ae_loss(res["recon"], poses[0], l_e, d_recon)
+    E.backward(res["tape"], d_recon)
+    tp = res["tape"]
+    sums, act, part = trs[0]._plan.workspace_views()
+    assert float(sums.abs().max()) == 0.0                      # left zero for the next step
+    offs, o = {}, 0
+    for name, n in (("c0", 1024), ("c1", 1920), ("c2", 896), ("flat", 384), ("f1", 256), ("y1f", 256), ("f2", 128), ("y2f", 128), ("f3", 32), ("mu", 32),
+                    ("p0", 64), ("yp", 64), ("p3", 136), ("t0", 1152), ("t1", 1216)):
+        offs[name] = (o, n); o += n
+    ref_act = {"c0": tp["enc"][0][1].x, "c1": tp["enc"][1][1].x, "c2": tp["enc"][2][1].x, "flat": tp["flat"], "f1": tp["st1"].x, "y1f": tp["y1"],
+               "f2": tp["st2"].x, "y2f": tp["y2"], "f3": tp["f3"], "mu": res["feat"], "p0": tp["stp"].x, "yp": tp["yp"],
+               "p3": tp["x0"].permute(0, 2, 1), "t0": tp["s0"].x, "t1": tp["s1"].x}
+    for name, (o0, n) in offs.items():
+        got, want = act[:, o0:o0 + n], ref_act[name].reshape(B, n)
+        assert rel(got, want) < 2e-5, (name, rel(got, want))
+    assert rel(trs[0].last["recon"], res["recon"]) < 2e-5 and rel(trs[0].last["feat"], res["feat"]) < 2e-5
+    assert abs(l_f.item() - l_e.item()) < 1e-5 * abs(l_e.item())
+    _, Gf, _ = nets[0].engine.views()
+    _, Ge, _ = E.views()
+    for k in Ge:
+        if "fc_logvar" in k:
+            assert float(Gf[k].abs().max()) == 0.0
+            continue
+        if k in ZERO_GRAD_KEYS:                                # true gradient exactly zero: both sides hold rounding noise
+            assert float(Gf[k].abs().max()) < 1e-5, (k, float(Gf[k].abs().max()))
+            continue
+        sc = float(Ge[k].abs().max())
+        assert float((Gf[k] - Ge[k]).abs().max()) <= 1e-4 * sc + 1e-9, (k, float((Gf[k] - Ge[k]).abs().max()), sc)
+    g1 = {k: v.clone() for k, v in Ge.items()}
+    # ... and against the fp64 oracle
+    oast = O.clone_state(ast, torch.float64)
+    oret, ogr = O.ae_train_iter(oast, {}, poses[0].double().cpu())
+    assert abs(l_f.item() - oret["loss"]) < 1e-5 * oret["loss"]
+    e, zmax, key = grad_errors(Gf, {k: v for k, v in ogr.items() if v is not None})
+    assert e < 1e-4, (e, key)
+    # finish the reference's step 1, then step 2 on both: parameters, moments, counters, BatchNorm buffers
+    trs[1].opt.step()
+    sf, se = nets[0].state_dict(), nets[1].state_dict()
+    for k in se:                                                # the BatchNorm buffers after one step
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert float((sf[k] - se[k]).abs().max()) <= 2e-5 * float(se[k].abs().max()) + 1e-7, (k, float((sf[k] - se[k]).abs().max()))
+    l2f, l2e = trs[0].train_iter(poses[1]), trs[1].train_iter(poses[1])
+    assert abs(l2f.item() - l2e.item()) < 1e-5 * abs(l2e.item())
+    assert int(nets[0].engine.slab.step) == int(nets[1].engine.slab.step) == 2
+    sf, se = nets[0].state_dict(), nets[1].state_dict()
+    _, Ge2, _ = E.views()
+    for k in se:
+        if k.endswith("num_batches_tracked"):
+            assert int(sf[k]) == int(se[k]) == 2, k
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            # (the conv biases in front of a BatchNorm took noise-driven +-lr steps after step 1 and sit in the batch mean directly)
+            assert float((sf[k] - se[k]).abs().max()) <= 0.1 * 4 * 5e-4 + 1e-3 * float(se[k].abs().max()), (k, float((sf[k] - se[k]).abs().max()))
+        elif k in ZERO_GRAD_KEYS or "fc_logvar" in k:
+            continue                                            # Adam turns rounding noise into +-lr steps there / never stepped
+        else:
+            # elements whose gradient is real in both steps (Adam's first steps are ~ lr * sign: a gradient that is noise flips freely)
+            real = (g1[k].abs() > 1e-3 * g1[k].abs().max()) & (Ge2[k].abs() > 1e-3 * Ge2[k].abs().max())
+            assert bool(real.any()), k
+            assert float((sf[k] - se[k])[real].abs().max()) <= 5e-2 * 5e-4, (k, float((sf[k] - se[k])[real].abs().max()) / 5e-4)
+
+
 def test_graphed_step_equals_eager(pkg, dev):
     V, S, B = 64, 9, 8
     gst, dst = O.make_generator_state(7, V, S), O.make_discriminator_state(8)
