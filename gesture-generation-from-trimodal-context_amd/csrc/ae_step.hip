@@ -94,6 +94,7 @@ struct AeArgs {
     double* sums;
     float* act;
     float* part;
+    float* wt;
     float *loss, *recon, *feat;
     int* step;
     int B;
@@ -120,19 +121,31 @@ __device__ __forceinline__ AeLds ae_lds(float* smem) {
 
 __device__ __forceinline__ float ae_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-// n floats (n % 4 == 0), 16-byte aligned on both sides
-__device__ __forceinline__ void ae_load(float* __restrict__ dst, const float* __restrict__ src, int n) {
-    for (int i = threadIdx.x; i < n / 4; i += AE_NT) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+// A clip's [L][C] tensor lives in LDS with rows C + 4 floats apart (C = 32 / 64): the MFMA operand reads below take 16 rows at once, and a
+// row stride that is a multiple of 32 banks would serialise them 16-fold.  Vectors (L = 1) are plain arrays.
+__device__ __forceinline__ constexpr int ae_rs(int C) { return C + 4; }
+
+// global [L][C] (flat) <-> LDS [L][C + 4]
+template <int L, int C>
+__device__ __forceinline__ void ae_load(float* __restrict__ dst, const float* __restrict__ src) {
+    static_assert(C % 4 == 0, "16-byte pieces");
+    for (int i = threadIdx.x; i < L * C / 4; i += AE_NT) {
+        const int r = (4 * i) / C, c = (4 * i) % C;
+        *reinterpret_cast<f32x4*>(dst + r * ae_rs(C) + c) = reinterpret_cast<const f32x4*>(src)[i];
+    }
     __syncthreads();
 }
-__device__ __forceinline__ void ae_store(float* __restrict__ dst, const float* __restrict__ src, int n) {
-    for (int i = threadIdx.x; i < n / 4; i += AE_NT) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+template <int L, int C>
+__device__ __forceinline__ void ae_store(float* __restrict__ dst, const float* __restrict__ src) {
+    for (int i = threadIdx.x; i < L * C / 4; i += AE_NT) {
+        const int r = (4 * i) / C, c = (4 * i) % C;
+        reinterpret_cast<f32x4*>(dst)[i] = *reinterpret_cast<const f32x4*>(src + r * ae_rs(C) + c);
+    }
 }
-// the clip's poses [34][27] -> LDS [34][CP], padding columns zero
-template <int CP>
+// the clip's poses [34][27] -> LDS [34][36], columns 27.. zero
 __device__ __forceinline__ void ae_load_x(float* __restrict__ dst, const float* __restrict__ x) {
-    for (int i = threadIdx.x; i < 34 * CP; i += AE_NT) {
-        const int r = i / CP, c = i - r * CP;
+    for (int i = threadIdx.x; i < 34 * 36; i += AE_NT) {
+        const int r = i / 36, c = i - r * 36;
         dst[i] = c < 27 ? x[r * 27 + c] : 0.f;
     }
     __syncthreads();
@@ -170,36 +183,36 @@ __device__ __forceinline__ void ae_bwd_means(const AeArgs& a, const AeLds& l, in
     }
     __syncthreads();
 }
-// dst = LeakyReLU(BatchNorm(src)), [n / C][C]
-template <int C>
-__device__ __forceinline__ void ae_bn_act(const AeLds& l, float* __restrict__ dst, const float* __restrict__ src, int n, float slope) {
-    for (int i = threadIdx.x; i < n; i += AE_NT) {
-        const int c = i & (C - 1);
-        dst[i] = ae_lrelu((src[i] - l.mean[c]) * l.rstd[c] * l.ga[c] + l.be[c], slope);
+// dst = LeakyReLU(BatchNorm(src)), both [L][C + 4]
+template <int L, int C>
+__device__ __forceinline__ void ae_bn_act(const AeLds& l, float* __restrict__ dst, const float* __restrict__ src, float slope) {
+    for (int i = threadIdx.x; i < L * C; i += AE_NT) {
+        const int c = i & (C - 1), o = (i / C) * ae_rs(C) + c;
+        dst[o] = ae_lrelu((src[o] - l.mean[c]) * l.rstd[c] * l.ga[c] + l.be[c], slope);
     }
     __syncthreads();
 }
 // g = dy * act'(BatchNorm(raw)) in place (dy -> g)
-template <int C>
-__device__ __forceinline__ void ae_act_bwd(const AeLds& l, float* __restrict__ dy, const float* __restrict__ raw, int n, float slope) {
-    for (int i = threadIdx.x; i < n; i += AE_NT) {
-        const int c = i & (C - 1);
-        const float bnv = (raw[i] - l.mean[c]) * l.rstd[c] * l.ga[c] + l.be[c];
-        dy[i] = bnv > 0.f ? dy[i] : dy[i] * slope;
+template <int L, int C>
+__device__ __forceinline__ void ae_act_bwd(const AeLds& l, float* __restrict__ dy, const float* __restrict__ raw, float slope) {
+    for (int i = threadIdx.x; i < L * C; i += AE_NT) {
+        const int c = i & (C - 1), o = (i / C) * ae_rs(C) + c;
+        const float bnv = (raw[o] - l.mean[c]) * l.rstd[c] * l.ga[c] + l.be[c];
+        dy[o] = bnv > 0.f ? dy[o] : dy[o] * slope;
     }
     __syncthreads();
 }
 // BatchNorm backward in place: g -> dc = gamma * rstd * (g - mg - xhat * mgx)
-template <int C>
-__device__ __forceinline__ void ae_bn_bwd(const AeLds& l, float* __restrict__ g, const float* __restrict__ raw, int n) {
-    for (int i = threadIdx.x; i < n; i += AE_NT) {
-        const int c = i & (C - 1);
-        const float xh = (raw[i] - l.mean[c]) * l.rstd[c];
-        g[i] = l.ga[c] * l.rstd[c] * (g[i] - l.mg[c] - xh * l.mgx[c]);
+template <int L, int C>
+__device__ __forceinline__ void ae_bn_bwd(const AeLds& l, float* __restrict__ g, const float* __restrict__ raw) {
+    for (int i = threadIdx.x; i < L * C; i += AE_NT) {
+        const int c = i & (C - 1), o = (i / C) * ae_rs(C) + c;
+        const float xh = (raw[o] - l.mean[c]) * l.rstd[c];
+        g[o] = l.ga[c] * l.rstd[c] * (g[o] - l.mg[c] - xh * l.mgx[c]);
     }
     __syncthreads();
 }
-// per-channel sums of the clip's [L][C] tensor -> fp64 atomics.  BWD: (sum g, sum g * xhat) with xhat from `raw`; else (sum v, sum v^2)
+// per-channel sums of the clip's [L][C + 4] tensor -> fp64 atomics.  BWD: (sum g, sum g * xhat) with xhat from `raw`; else (sum v, sum v^2)
 template <int L, int C, bool BWD>
 __device__ __forceinline__ void ae_chan_sums(const AeLds& l, const float* __restrict__ v, const float* __restrict__ raw, double* __restrict__ slot) {
     static_assert(AE_NT % C == 0, "channels per workgroup");
@@ -207,9 +220,9 @@ __device__ __forceinline__ void ae_chan_sums(const AeLds& l, const float* __rest
     const int c = threadIdx.x % C, part = threadIdx.x / C;
     float s0 = 0.f, s1 = 0.f;
     for (int r = part; r < L; r += PARTS) {
-        const float x = v[r * C + c];
+        const float x = v[r * ae_rs(C) + c];
         s0 += x;
-        if constexpr (BWD) s1 += x * ((raw[r * C + c] - l.mean[c]) * l.rstd[c]);
+        if constexpr (BWD) s1 += x * ((raw[r * ae_rs(C) + c] - l.mean[c]) * l.rstd[c]);
         else s1 += x * x;
     }
     l.red[threadIdx.x] = s0; l.red[AE_NT + threadIdx.x] = s1;
@@ -223,83 +236,88 @@ __device__ __forceinline__ void ae_chan_sums(const AeLds& l, const float* __rest
     __syncthreads();
 }
 
-// ---- the one multiply routine of the conv-shaped layers -------------------------------------------------------------------------------
+// ---- the multiply routines of the conv-shaped layers: v_mfma_f32_16x16x4_f32 (exact fp32 products) -------------------------------------------
 // out[p][n] = bias[n] + sum_{kk < KW, m < CINP} in[p * S + kk - PAD][m] * wl[(kk * CINP + m) * (N + 1) + n]   (rows outside [0, LIN) are zero)
-// in: LDS [LIN][CINP], out: LDS [LOUT][N].  Thread = (output channel n, position group): lanes of a wave share the input row.
-template <int LIN, int CINP, int LOUT, int N, int KW, int S, int PAD>
+// in: LDS rows RS floats apart; out: LDS [LOUT][N + 4].  A wave owns (16 positions) x (16 channels) tiles: MFMA rows = positions, columns = channels;
+// lane (r16, kq) supplies in[position r16][k = 4 s + kq] and wl[k][channel r16] of reduction step s and holds out[4 kq + q][r16].
+template <int LIN, int CINP, int RS, int LOUT, int N, int KW, int S, int PAD>
 __device__ __forceinline__ void ae_conv(const float* __restrict__ in, const float* __restrict__ wl, const float* __restrict__ bias, int n_bias,
                                         float* __restrict__ out) {
-    static_assert(AE_NT % N == 0 && CINP % 4 == 0, "thread map");
-    constexpr int PG = AE_NT / N, PP = (LOUT + PG - 1) / PG, WS = N + 1;
-    constexpr bool SAFE = PAD == 0 && (LOUT - 1) * S + KW - 1 < LIN;
-    const int n = threadIdx.x % N, pg = threadIdx.x / N;
-    float acc[PP];
-    const float b0 = (bias != nullptr && n < n_bias) ? bias[n] : 0.f;
-#pragma unroll
-    for (int pp = 0; pp < PP; ++pp) acc[pp] = b0;
-    for (int kk = 0; kk < KW; ++kk) {
-#pragma unroll 2
-        for (int m = 0; m < CINP; m += 4) {
-            const float* wp = wl + (kk * CINP + m) * WS + n;
-            const float w0 = wp[0], w1 = wp[WS], w2 = wp[2 * WS], w3 = wp[3 * WS];
-#pragma unroll
-            for (int pp = 0; pp < PP; ++pp) {
-                const int p = pg + pp * PG;
-                const int row = p * S + kk - PAD;
-                if (p < LOUT && (SAFE || (row >= 0 && row < LIN))) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(in + row * CINP + m);
-                    acc[pp] = fmaf(x[0], w0, fmaf(x[1], w1, fmaf(x[2], w2, fmaf(x[3], w3, acc[pp]))));
-                }
-            }
+    static_assert(N % 16 == 0 && CINP % 4 == 0, "tiles");
+    constexpr int MT = (LOUT + 15) / 16, NTL = N / 16, WS = N + 1, OS = N + 4, KT = KW * CINP / 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
+    for (int tile = wave; tile < MT * NTL; tile += AE_NT / 64) {
+        const int rt = tile / NTL, ct = tile - rt * NTL;
+        const int n = ct * 16 + r16, p = rt * 16 + r16;
+        const float b0 = (bias != nullptr && n < n_bias) ? bias[n] : 0.f;
+        f32x4 acc = {b0, b0, b0, b0};
+        int kk = 0, m = kq;
+        const float* wp = wl + kq * WS + n;
+#pragma unroll 4
+        for (int s = 0; s < KT; ++s) {
+            const int row = p * S + kk - PAD;
+            const float av = (p < LOUT && row >= 0 && row < LIN) ? in[row * RS + m] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wp[0], acc, 0, 0, 0);
+            wp += 4 * WS;
+            m += 4;
+            if (m >= CINP) { m -= CINP; ++kk; }
         }
-    }
 #pragma unroll
-    for (int pp = 0; pp < PP; ++pp) {
-        const int p = pg + pp * PG;
-        if (p < LOUT) out[p * N + n] = acc[pp];
+        for (int q = 0; q < 4; ++q) {
+            const int po = rt * 16 + 4 * kq + q;
+            if (po < LOUT) out[po * OS + n] = acc[q];
+        }
     }
     __syncthreads();
 }
-// its weight gradient for one clip, in the staged layout: dwl[(kk * CINP + m) * (N + 1) + n] = sum_p dout[p][n] * in[p * S + kk - PAD][m]
-template <int LIN, int CINP, int LOUT, int N, int KW, int S, int PAD>
+// the same sum on the vector ALU for a 4-channel output (decoder.net.0's input gradient): thread = (channel, position)
+template <int LIN, int CINP, int RS, int LOUT, int KW>
+__device__ __forceinline__ void ae_conv_n4(const float* __restrict__ in, const float* __restrict__ wl, float* __restrict__ out) {
+    constexpr int WS = 5;
+    const int n = threadIdx.x & 3, p = threadIdx.x >> 2;
+    if (p < LOUT) {
+        float acc = 0.f;
+        for (int kk = 0; kk < KW; ++kk)
+            for (int m = 0; m < CINP; ++m) acc = fmaf(in[(p + kk) * RS + m], wl[(kk * CINP + m) * WS + n], acc);
+        out[p * 4 + n] = acc;
+    }
+    __syncthreads();
+}
+// weight gradient of one clip in the staged layout: dwl[(kk * CINP + m) * (N + 1) + n] = sum_p dout[p][n] * in[p * S + kk - PAD][m].
+// MFMA rows = (kk, m), columns = n, reduction over the positions p (steps of four)
+template <int LIN, int CINP, int RS, int LOUT, int N, int KW, int S, int PAD>
 __device__ __forceinline__ void ae_wgrad(const float* __restrict__ in, const float* __restrict__ dout, float* __restrict__ dwl) {
-    static_assert(AE_NT % N == 0, "thread map");
-    constexpr int GRP = AE_NT / N, KM = KW * CINP, NJ = (KM + GRP - 1) / GRP, WS = N + 1;
-    constexpr bool SAFE = PAD == 0 && (LOUT - 1) * S + KW - 1 < LIN;
-    const int n = threadIdx.x % N, g = threadIdx.x / N;
-    float acc[NJ];
-    int ioff[NJ], kro[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        int km = g + j * GRP;
-        if (km >= KM) km = KM - 1;                 // (computed and dropped)
-        const int kk = km / CINP, m = km - kk * CINP;
-        kro[j] = kk - PAD;
-        ioff[j] = (kk - PAD) * CINP + m;
-        acc[j] = 0.f;
-    }
-    for (int p = 0; p < LOUT; ++p) {
-        const float d = dout[p * N + n];
-        const float* ip = in + p * S * CINP;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int row = p * S + kro[j];
-            if (SAFE || (row >= 0 && row < LIN)) acc[j] = fmaf(d, ip[ioff[j]], acc[j]);
+    static_assert(N % 16 == 0, "tiles");
+    constexpr int KM = KW * CINP, MT = (KM + 15) / 16, NTL = N / 16, WS = N + 1, DS = N + 4, PT = (LOUT + 3) / 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
+    for (int tile = wave; tile < MT * NTL; tile += AE_NT / 64) {
+        const int rt = tile / NTL, ct = tile - rt * NTL;
+        const int km = rt * 16 + r16, n = ct * 16 + r16;
+        const bool km_ok = km < KM;
+        const int kk = km_ok ? km / CINP : 0, m = km_ok ? km - kk * CINP : 0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int s = 0; s < PT; ++s) {
+            const int p = 4 * s + kq;
+            const int row = p * S + kk - PAD;
+            const float av = (km_ok && p < LOUT && row >= 0 && row < LIN) ? in[row * RS + m] : 0.f;
+            const float bv = p < LOUT ? dout[p * DS + n] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
         }
-    }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int km = g + j * GRP;
-        if (km < KM) dwl[km * WS + n] = acc[j];
+        for (int q = 0; q < 4; ++q) {
+            const int ko = rt * 16 + 4 * kq + q;
+            if (ko < KM) dwl[ko * WS + n] = acc[q];
+        }
     }
     __syncthreads();
 }
-// bias gradient of the clip: db[n] = sum_p dout[p][n], n < N; entries [n_valid, n_store) are written as zero
+// bias gradient of the clip: db[n] = sum_p dout[p][n]; entries up to n_store are written (dout's padding channels hold zeros)
 template <int LOUT, int N>
 __device__ __forceinline__ void ae_bias_grad(const float* __restrict__ dout, float* __restrict__ part, int n_store) {
     if ((int)threadIdx.x < n_store) {
         float s = 0.f;
-        for (int p = 0; p < LOUT; ++p) s += dout[p * N + threadIdx.x];
+        for (int p = 0; p < LOUT; ++p) s += dout[p * (N + 4) + threadIdx.x];
         part[threadIdx.x] = s;
     }
 }
@@ -348,28 +366,34 @@ __device__ __forceinline__ void ae_unstage(float* __restrict__ part, int numel, 
 }
 
 // ---- linear layers of one clip --------------------------------------------------------------------------------------------------------
-// out[n] = b[n] + sum_k W[n][k] x[k]: a wave per output row, lanes along k (coalesced 16-byte weight reads), shuffle reduction
+// out[n] = b[n] + sum_k Wt[k][n] x[k] with the TRANSPOSED weight (phase 1 writes it once per step): lanes along n (coalesced), no cross-lane
+// reduction; the NT / N thread groups split k and meet in LDS
 template <int K, int N>
-__device__ __forceinline__ void ae_fc(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ x, float* __restrict__ out) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int n = wave; n < N; n += AE_NT / 64) {
+__device__ __forceinline__ void ae_fc(const AeLds& l, const float* __restrict__ Wt, const float* __restrict__ b, const float* __restrict__ x,
+                                      float* __restrict__ out) {
+    constexpr int KP = AE_NT / N, PER = (K + KP - 1) / KP;
+    static_assert(KP >= 1 && KP * N <= 2 * AE_NT, "scratch");
+    const int n = threadIdx.x % N, kp = threadIdx.x / N;
+    if (kp < KP) {
         float s = 0.f;
-        for (int k = lane * 4; k < K; k += 256) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)n * K + k);
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
-            s = fmaf(w[0], xv[0], fmaf(w[1], xv[1], fmaf(w[2], xv[2], fmaf(w[3], xv[3], s))));
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) out[n] = s + b[n];
+        const int k0 = kp * PER, k1 = k0 + PER < K ? k0 + PER : K;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) s = fmaf(Wt[(long)k * N + n], x[k], s);
+        l.red[kp * N + n] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < N) {
+        float s = b[threadIdx.x];
+        for (int q = 0; q < KP; ++q) s += l.red[q * N + threadIdx.x];
+        out[threadIdx.x] = s;
     }
     __syncthreads();
 }
-// dx[k] = sum_n W[n][k] dy[n]: a thread per four k and a slice of n, slices summed through LDS (scratch: >= AE_BUF floats)
+// dx[k] = sum_n W[n][k] dy[n]: a thread per four k and a slice of n, slices summed through LDS (scratch: AE_BUF floats)
 template <int K, int N>
 __device__ __forceinline__ void ae_fc_dgrad(const float* __restrict__ W, const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ scratch) {
-    constexpr int KQ = K / 4, NG0 = AE_NT / KQ, NG = NG0 < N ? NG0 : N, PER = (N + NG - 1) / NG;
-    static_assert(NG * K <= AE_BUF, "scratch");
+    constexpr int KQ = K / 4, NG0 = AE_NT / KQ, NG1 = NG0 < N ? NG0 : N, NG = NG1 * K <= AE_BUF ? NG1 : AE_BUF / K, PER = (N + NG - 1) / NG;
+    static_assert(NG >= 1 && NG * K <= AE_BUF, "scratch");
     const int kq = threadIdx.x % KQ, ng = threadIdx.x / KQ;
     if (ng < NG) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -393,6 +417,18 @@ __device__ __forceinline__ void ae_fc_dgrad(const float* __restrict__ W, const f
 
 __device__ __forceinline__ float ae_sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
+// transposed linear weights in the workspace (floats): [K][N] each
+constexpr int WT_F1 = 0;
+constexpr int WT_F2 = WT_F1 + 384 * 256;
+constexpr int WT_F3 = WT_F2 + 256 * 128;
+constexpr int WT_MU = WT_F3 + 128 * 32;
+constexpr int WT_D0 = WT_MU + 32 * 32;
+constexpr int WT_D1 = WT_D0 + 32 * 64;
+constexpr int AE_WT = WT_D1 + 64 * 136;
+struct AeWtLayer { int p, n, k, begin; };
+__constant__ AeWtLayer ae_wt_layers[7] = {{P_F1W, 256, 384, WT_F1}, {P_F2W, 128, 256, WT_F2}, {P_F3W, 32, 128, WT_F3}, {P_MUW, 32, 32, WT_MU},
+                                          {P_D0W, 64, 32, WT_D0},   {P_D1W, 136, 64, WT_D1},  {0, 0, 0, AE_WT}};
+
 // ---- phases 1..17 ----------------------------------------------------------------------------------------------------------------------
 template <int PH>
 __global__ __launch_bounds__(AE_NT) void ae_phase_kernel(const AeArgs a) {
@@ -407,264 +443,273 @@ __global__ __launch_bounds__(AE_NT) void ae_phase_kernel(const AeArgs a) {
     auto W = [&](int p) { return a.P + a.off[p]; };
     auto slot = [&](int s) { return a.sums + (size_t)s * 512; };
 
-    if constexpr (PH == 1) {                    // poses -> net.0 conv
-        ae_load_x<28>(B0, x);
+    if constexpr (PH == 1) {                    // poses -> net.0 conv; the linear layers' weights transposed for this step's forward
+        ae_load_x(B0, x);
+        for (int e = blockIdx.x * AE_NT + threadIdx.x; e < AE_WT; e += gridDim.x * AE_NT) {
+            int li = 0;
+            while (e >= ae_wt_layers[li + 1].begin) ++li;
+            const AeWtLayer L = ae_wt_layers[li];
+            const int r = e - L.begin, k = r / L.n, n = r - k * L.n;
+            a.wt[e] = a.P[a.off[L.p] + n * L.k + k];
+        }
         ae_stage<28, 32, MapConvFwd<27, 3>>(W(P_E0W), 32 * 27 * 3, l.wl, 3 * 28, true);
-        ae_conv<34, 28, 32, 32, 3, 1, 0>(B0, l.wl, W(P_E0B), 32, B1);
-        ae_store(act + A_C0, B1, 32 * 32);
+        ae_conv<34, 28, 36, 32, 32, 3, 1, 0>(B0, l.wl, W(P_E0B), 32, B1);
+        ae_store<32, 32>(act + A_C0, B1);
         ae_chan_sums<32, 32, false>(l, B1, nullptr, slot(0));
     } else if constexpr (PH == 2) {             // BN0 + LeakyReLU(0.2) -> net.1 conv
-        ae_load(B0, act + A_C0, 32 * 32);
+        ae_load<32, 32>(B0, act + A_C0);
         ae_bn_prepare<32>(a, l, 0, 0, nB * 32, P_BN0G, true);
-        ae_bn_act<32>(l, B1, B0, 32 * 32, 0.2f);
+        ae_bn_act<32, 32>(l, B1, B0, 0.2f);
         ae_stage<32, 64, MapConvFwd<32, 3>>(W(P_E1W), 64 * 32 * 3, l.wl, 0, false);
-        ae_conv<32, 32, 30, 64, 3, 1, 0>(B1, l.wl, W(P_E1B), 64, B2);
-        ae_store(act + A_C1, B2, 30 * 64);
+        ae_conv<32, 32, 36, 30, 64, 3, 1, 0>(B1, l.wl, W(P_E1B), 64, B2);
+        ae_store<30, 64>(act + A_C1, B2);
         ae_chan_sums<30, 64, false>(l, B2, nullptr, slot(1));
     } else if constexpr (PH == 3) {             // BN1 -> net.2 conv (k 4, stride 2)
-        ae_load(B0, act + A_C1, 30 * 64);
+        ae_load<30, 64>(B0, act + A_C1);
         ae_bn_prepare<64>(a, l, 1, 1, nB * 30, P_BN1G, true);
-        ae_bn_act<64>(l, B1, B0, 30 * 64, 0.2f);
+        ae_bn_act<30, 64>(l, B1, B0, 0.2f);
         ae_stage<64, 64, MapConvFwd<64, 4>>(W(P_E2W), 64 * 64 * 4, l.wl, 0, false);
-        ae_conv<30, 64, 14, 64, 4, 2, 0>(B1, l.wl, W(P_E2B), 64, B2);
-        ae_store(act + A_C2, B2, 14 * 64);
+        ae_conv<30, 64, 68, 14, 64, 4, 2, 0>(B1, l.wl, W(P_E2B), 64, B2);
+        ae_store<14, 64>(act + A_C2, B2);
         ae_chan_sums<14, 64, false>(l, B2, nullptr, slot(2));
     } else if constexpr (PH == 4) {             // BN2 -> net.3 conv -> flatten -> out_net.0
-        ae_load(B0, act + A_C2, 14 * 64);
+        ae_load<14, 64>(B0, act + A_C2);
         ae_bn_prepare<64>(a, l, 2, 2, nB * 14, P_BN2G, true);
-        ae_bn_act<64>(l, B1, B0, 14 * 64, 0.2f);
+        ae_bn_act<14, 64>(l, B1, B0, 0.2f);
         ae_stage<64, 32, MapConvFwd<64, 3>>(W(P_E3W), 32 * 64 * 3, l.wl, 0, false);
-        ae_conv<14, 64, 12, 32, 3, 1, 0>(B1, l.wl, W(P_E3B), 32, B2);
-        for (int i = threadIdx.x; i < 384; i += AE_NT) B3[i] = B2[(i % 12) * 32 + i / 12];       // flat[c * 12 + l] = c4[l][c]
+        ae_conv<14, 64, 68, 12, 32, 3, 1, 0>(B1, l.wl, W(P_E3B), 32, B2);
+        for (int i = threadIdx.x; i < 384; i += AE_NT) B3[i] = B2[(i % 12) * 36 + i / 12];       // flat[c * 12 + l] = c4[l][c]
         __syncthreads();
-        ae_store(act + A_FLAT, B3, 384);
-        ae_fc<384, 256>(W(P_F1W), W(P_F1B), B3, B4);
-        ae_store(act + A_F1, B4, 256);
+        ae_store<1, 384>(act + A_FLAT, B3);
+        ae_fc<384, 256>(l, a.wt + WT_F1, W(P_F1B), B3, B4);
+        ae_store<1, 256>(act + A_F1, B4);
         ae_chan_sums<1, 256, false>(l, B4, nullptr, slot(3));
     } else if constexpr (PH == 5) {             // BN3 (LeakyReLU(True): slope 1) -> out_net.3
-        ae_load(B0, act + A_F1, 256);
+        ae_load<1, 256>(B0, act + A_F1);
         ae_bn_prepare<256>(a, l, 3, 3, nB, P_BN3G, true);
-        ae_bn_act<256>(l, B1, B0, 256, 1.f);
-        ae_store(act + A_Y1F, B1, 256);
-        ae_fc<256, 128>(W(P_F2W), W(P_F2B), B1, B2);
-        ae_store(act + A_F2, B2, 128);
+        ae_bn_act<1, 256>(l, B1, B0, 1.f);
+        ae_store<1, 256>(act + A_Y1F, B1);
+        ae_fc<256, 128>(l, a.wt + WT_F2, W(P_F2B), B1, B2);
+        ae_store<1, 128>(act + A_F2, B2);
         ae_chan_sums<1, 128, false>(l, B2, nullptr, slot(4));
     } else if constexpr (PH == 6) {             // BN4 -> out_net.6 -> fc_mu (z = mu) -> decoder.pre_net.0
-        ae_load(B0, act + A_F2, 128);
+        ae_load<1, 128>(B0, act + A_F2);
         ae_bn_prepare<128>(a, l, 4, 4, nB, P_BN4G, true);
-        ae_bn_act<128>(l, B1, B0, 128, 1.f);
-        ae_store(act + A_Y2F, B1, 128);
-        ae_fc<128, 32>(W(P_F3W), W(P_F3B), B1, B2);
-        ae_store(act + A_F3, B2, 32);
-        ae_fc<32, 32>(W(P_MUW), W(P_MUB), B2, B3);
-        ae_store(act + A_MU, B3, 32);
-        if (a.feat != nullptr) ae_store(a.feat + (size_t)clip * 32, B3, 32);
-        ae_fc<32, 64>(W(P_D0W), W(P_D0B), B3, B4);
-        ae_store(act + A_P0, B4, 64);
+        ae_bn_act<1, 128>(l, B1, B0, 1.f);
+        ae_store<1, 128>(act + A_Y2F, B1);
+        ae_fc<128, 32>(l, a.wt + WT_F3, W(P_F3B), B1, B2);
+        ae_store<1, 32>(act + A_F3, B2);
+        ae_fc<32, 32>(l, a.wt + WT_MU, W(P_MUB), B2, B3);
+        ae_store<1, 32>(act + A_MU, B3);
+        if (a.feat != nullptr) ae_store<1, 32>(a.feat + (size_t)clip * 32, B3);
+        ae_fc<32, 64>(l, a.wt + WT_D0, W(P_D0B), B3, B4);
+        ae_store<1, 64>(act + A_P0, B4);
         ae_chan_sums<1, 64, false>(l, B4, nullptr, slot(5));
     } else if constexpr (PH == 7) {             // BN5 -> pre_net.3 -> view(4, 34) -> net.0 transposed conv
-        ae_load(B0, act + A_P0, 64);
+        ae_load<1, 64>(B0, act + A_P0);
         ae_bn_prepare<64>(a, l, 5, 5, nB, P_BN5G, true);
-        ae_bn_act<64>(l, B1, B0, 64, 1.f);
-        ae_store(act + A_YP, B1, 64);
-        ae_fc<64, 136>(W(P_D1W), W(P_D1B), B1, B2);
-        ae_store(act + A_P3, B2, 136);
-        for (int i = threadIdx.x; i < 136; i += AE_NT) B3[i] = B2[(i & 3) * 34 + (i >> 2)];       // x0[l][c] = p3[c * 34 + l]
+        ae_bn_act<1, 64>(l, B1, B0, 1.f);
+        ae_store<1, 64>(act + A_YP, B1);
+        ae_fc<64, 136>(l, a.wt + WT_D1, W(P_D1B), B1, B2);
+        ae_store<1, 136>(act + A_P3, B2);
+        for (int i = threadIdx.x; i < 136; i += AE_NT) B3[i] = B2[(i & 3) * 34 + (i >> 2)];       // x0[l][c] = p3[c * 34 + l], rows 4 floats apart
         __syncthreads();
         ae_stage<4, 32, MapConvTFwd<32, 3>>(W(P_T0W), 4 * 32 * 3, l.wl, 0, false);
-        ae_conv<34, 4, 36, 32, 3, 1, 2>(B3, l.wl, W(P_T0B), 32, B4);
-        ae_store(act + A_T0, B4, 36 * 32);
+        ae_conv<34, 4, 4, 36, 32, 3, 1, 2>(B3, l.wl, W(P_T0B), 32, B4);
+        ae_store<36, 32>(act + A_T0, B4);
         ae_chan_sums<36, 32, false>(l, B4, nullptr, slot(6));
     } else if constexpr (PH == 8) {             // BN6 -> net.3 transposed conv
-        ae_load(B0, act + A_T0, 36 * 32);
+        ae_load<36, 32>(B0, act + A_T0);
         ae_bn_prepare<32>(a, l, 6, 6, nB * 36, P_BN6G, true);
-        ae_bn_act<32>(l, B1, B0, 36 * 32, 0.2f);
+        ae_bn_act<36, 32>(l, B1, B0, 0.2f);
         ae_stage<32, 32, MapConvTFwd<32, 3>>(W(P_T1W), 32 * 32 * 3, l.wl, 0, false);
-        ae_conv<36, 32, 38, 32, 3, 1, 2>(B1, l.wl, W(P_T1B), 32, B2);
-        ae_store(act + A_T1, B2, 38 * 32);
+        ae_conv<36, 32, 36, 38, 32, 3, 1, 2>(B1, l.wl, W(P_T1B), 32, B2);
+        ae_store<38, 32>(act + A_T1, B2);
         ae_chan_sums<38, 32, false>(l, B2, nullptr, slot(7));
     } else if constexpr (PH == 9) {             // BN7 -> net.6, net.7 -> loss -> back through net.7, net.6 to BN7's output gradient
-        ae_load(B0, act + A_T1, 38 * 32);
+        ae_load<38, 32>(B0, act + A_T1);
         ae_bn_prepare<32>(a, l, 7, 7, nB * 38, P_BN7G, true);
-        ae_bn_act<32>(l, B1, B0, 38 * 32, 0.2f);                                                  // B1 = y(T1): net.6's input
+        ae_bn_act<38, 32>(l, B1, B0, 0.2f);                                                       // B1 = y(T1): net.6's input
         ae_stage<32, 32, MapConvFwd<32, 3>>(W(P_C6W), 32 * 32 * 3, l.wl, 0, false);
-        ae_conv<38, 32, 36, 32, 3, 1, 0>(B1, l.wl, W(P_C6B), 32, B2);                             // B2 = c6
+        ae_conv<38, 32, 36, 36, 32, 3, 1, 0>(B1, l.wl, W(P_C6B), 32, B2);                         // B2 = c6
         ae_stage<32, 32, MapConvFwd<32, 3>>(W(P_C7W), 27 * 32 * 3, l.wl, 3 * 32, true);
-        ae_conv<36, 32, 34, 32, 3, 1, 0>(B2, l.wl, W(P_C7B), 27, B3);                             // B3 = recon [34][32], columns 27.. zero
+        ae_conv<36, 32, 36, 34, 32, 3, 1, 0>(B2, l.wl, W(P_C7B), 27, B3);                         // B3 = recon [34][32 + 4], channels 27..31 zero
         if (a.recon != nullptr)
-            for (int i = threadIdx.x; i < 34 * 27; i += AE_NT) a.recon[(size_t)clip * 918 + i] = B3[(i / 27) * 32 + i % 27];
-        ae_load_x<32>(B4, x);
-        for (int i = threadIdx.x; i < 34 * 32; i += AE_NT) B4[i] = B3[i] - B4[i];                 // e = recon - target (padding columns 0)
+            for (int i = threadIdx.x; i < 34 * 27; i += AE_NT) a.recon[(size_t)clip * 918 + i] = B3[(i / 27) * 36 + i % 27];
+        ae_load_x(B4, x);
+        for (int i = threadIdx.x; i < 34 * 32; i += AE_NT) { const int o = (i >> 5) * 36 + (i & 31); B4[o] = B3[o] - B4[o]; }      // e = recon - target
         __syncthreads();
         {   // L1 + L1 of the frame differences, mean over (frame, joint) per clip, summed over the batch (:63-72)
             const float w1 = 1.f / (34.f * 27.f), w2 = 1.f / (33.f * 27.f);
             float s = 0.f;
             for (int i = threadIdx.x; i < 34 * 32; i += AE_NT) {
-                const int t = i >> 5;
-                const float e = B4[i];
+                const int t = i >> 5, o = t * 36 + (i & 31);
+                const float e = B4[o];
                 float g = ae_sgn(e) * w1;
                 s += fabsf(e) * w1;
-                if (t >= 1) { const float d = e - B4[i - 32]; s += fabsf(d) * w2; g += ae_sgn(d) * w2; }
-                if (t + 1 < 34) { const float d = B4[i + 32] - e; g -= ae_sgn(d) * w2; }
-                B3[i] = g;                                                                         // d(loss) / d(recon)
+                if (t >= 1) { const float d = e - B4[o - 36]; s += fabsf(d) * w2; g += ae_sgn(d) * w2; }
+                if (t + 1 < 34) { const float d = B4[o + 36] - e; g -= ae_sgn(d) * w2; }
+                B3[o] = g;                                                                         // d(loss) / d(recon)
             }
             l.red[threadIdx.x] = s;
             __syncthreads();
-            if (threadIdx.x == 0) {
+            if (threadIdx.x < 64) {
                 double tot = 0.0;
-                for (int i = 0; i < AE_NT; ++i) tot += (double)l.red[i];
-                atomicAdd(slot(16), tot);
+                for (int i = threadIdx.x; i < AE_NT; i += 64) tot += (double)l.red[i];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+                if (threadIdx.x == 0) atomicAdd(slot(16), tot);
             }
             __syncthreads();
         }
         // net.7: weight / bias gradient, input gradient
-        ae_wgrad<36, 32, 34, 32, 3, 1, 0>(B2, B3, l.wl);
+        ae_wgrad<36, 32, 36, 34, 32, 3, 1, 0>(B2, B3, l.wl);
         ae_unstage<32, 32, MapConvFwd<32, 3>>(part + Q_C7W, 27 * 32 * 3, l.wl);
         ae_bias_grad<34, 32>(B3, part + Q_C7B, 28);
         ae_stage<32, 32, MapConvDgrad<32, 3>>(W(P_C7W), 27 * 32 * 3, l.wl, 3 * 32, true);
-        ae_conv<34, 32, 36, 32, 3, 1, 2>(B3, l.wl, nullptr, 0, B4);                               // B4 = d c6
+        ae_conv<34, 32, 36, 36, 32, 3, 1, 2>(B3, l.wl, nullptr, 0, B4);                           // B4 = d c6
         // net.6
-        ae_wgrad<38, 32, 36, 32, 3, 1, 0>(B1, B4, l.wl);
+        ae_wgrad<38, 32, 36, 36, 32, 3, 1, 0>(B1, B4, l.wl);
         ae_unstage<32, 32, MapConvFwd<32, 3>>(part + Q_C6W, 32 * 32 * 3, l.wl);
         ae_bias_grad<36, 32>(B4, part + Q_C6B, 32);
         ae_stage<32, 32, MapConvDgrad<32, 3>>(W(P_C6W), 32 * 32 * 3, l.wl, 0, false);
-        ae_conv<36, 32, 38, 32, 3, 1, 2>(B4, l.wl, nullptr, 0, B2);                               // B2 = d y(T1)
-        ae_act_bwd<32>(l, B2, B0, 38 * 32, 0.2f);
-        ae_store(act + A_G, B2, 38 * 32);
+        ae_conv<36, 32, 36, 38, 32, 3, 1, 2>(B4, l.wl, nullptr, 0, B2);                           // B2 = d y(T1)
+        ae_act_bwd<38, 32>(l, B2, B0, 0.2f);
+        ae_store<38, 32>(act + A_G, B2);
         ae_chan_sums<38, 32, true>(l, B2, B0, slot(8));
     } else if constexpr (PH == 10) {            // BN7 backward -> net.3 (transposed conv) -> BN6's output gradient
-        ae_load(B0, act + A_G, 38 * 32);
-        ae_load(B1, act + A_T1, 38 * 32);
+        ae_load<38, 32>(B0, act + A_G);
+        ae_load<38, 32>(B1, act + A_T1);
         ae_bn_prepare<32>(a, l, 7, 7, nB * 38, P_BN7G, false);
         ae_bwd_means<32>(a, l, 8, nB * 38);
-        ae_bn_bwd<32>(l, B0, B1, 38 * 32);                                                        // B0 = d t1
-        ae_load(B2, act + A_T0, 36 * 32);
+        ae_bn_bwd<38, 32>(l, B0, B1);                                                             // B0 = d t1
+        ae_load<36, 32>(B2, act + A_T0);
         ae_bn_prepare<32>(a, l, 6, 6, nB * 36, P_BN6G, false);
-        ae_bn_act<32>(l, B3, B2, 36 * 32, 0.2f);                                                  // B3 = y(T0): the layer's input
-        ae_wgrad<36, 32, 38, 32, 3, 1, 2>(B3, B0, l.wl);
+        ae_bn_act<36, 32>(l, B3, B2, 0.2f);                                                       // B3 = y(T0): the layer's input
+        ae_wgrad<36, 32, 36, 38, 32, 3, 1, 2>(B3, B0, l.wl);
         ae_unstage<32, 32, MapConvTFwd<32, 3>>(part + Q_T1W, 32 * 32 * 3, l.wl);
         ae_bias_grad<38, 32>(B0, part + Q_T1B, 32);
         ae_stage<32, 32, MapConvTDgrad<32, 3>>(W(P_T1W), 32 * 32 * 3, l.wl, 0, false);
-        ae_conv<38, 32, 36, 32, 3, 1, 0>(B0, l.wl, nullptr, 0, B4);                               // B4 = d y(T0)
-        ae_act_bwd<32>(l, B4, B2, 36 * 32, 0.2f);
-        ae_store(act + A_G, B4, 36 * 32);
+        ae_conv<38, 32, 36, 36, 32, 3, 1, 0>(B0, l.wl, nullptr, 0, B4);                           // B4 = d y(T0)
+        ae_act_bwd<36, 32>(l, B4, B2, 0.2f);
+        ae_store<36, 32>(act + A_G, B4);
         ae_chan_sums<36, 32, true>(l, B4, B2, slot(9));
     } else if constexpr (PH == 11) {            // BN6 backward -> net.0 (transposed conv) -> pre_net.3 -> BN5's output gradient
-        ae_load(B0, act + A_G, 36 * 32);
-        ae_load(B1, act + A_T0, 36 * 32);
+        ae_load<36, 32>(B0, act + A_G);
+        ae_load<36, 32>(B1, act + A_T0);
         ae_bn_prepare<32>(a, l, 6, 6, nB * 36, P_BN6G, false);
         ae_bwd_means<32>(a, l, 9, nB * 36);
-        ae_bn_bwd<32>(l, B0, B1, 36 * 32);                                                        // B0 = d t0
-        ae_load(B2, act + A_P3, 136);
+        ae_bn_bwd<36, 32>(l, B0, B1);                                                             // B0 = d t0
+        ae_load<1, 136>(B2, act + A_P3);
         for (int i = threadIdx.x; i < 136; i += AE_NT) B3[i] = B2[(i & 3) * 34 + (i >> 2)];       // x0[l][c]
         __syncthreads();
-        ae_wgrad<34, 4, 36, 32, 3, 1, 2>(B3, B0, l.wl);
+        ae_wgrad<34, 4, 4, 36, 32, 3, 1, 2>(B3, B0, l.wl);
         ae_unstage<4, 32, MapConvTFwd<32, 3>>(part + Q_T0W, 4 * 32 * 3, l.wl);
         ae_bias_grad<36, 32>(B0, part + Q_T0B, 32);
         ae_stage<32, 4, MapConvTDgrad<32, 3>>(W(P_T0W), 4 * 32 * 3, l.wl, 0, false);
-        ae_conv<36, 32, 34, 4, 3, 1, 0>(B0, l.wl, nullptr, 0, B4);                                // B4 = d x0 [34][4]
+        ae_conv_n4<36, 32, 36, 34, 3>(B0, l.wl, B4);                                              // B4 = d x0 [34][4]
         for (int i = threadIdx.x; i < 136; i += AE_NT) B2[i] = B4[(i % 34) * 4 + i / 34];         // d p3[c * 34 + l]
         __syncthreads();
-        ae_store(act + A_DP3, B2, 136);
+        ae_store<1, 136>(act + A_DP3, B2);
         ae_fc_dgrad<64, 136>(W(P_D1W), B2, B3, B4);                                               // B3 = d yp = g (slope 1)
-        ae_store(act + A_G, B3, 64);
-        ae_load(B1, act + A_P0, 64);
+        ae_store<1, 64>(act + A_G, B3);
+        ae_load<1, 64>(B1, act + A_P0);
         ae_bn_prepare<64>(a, l, 5, 5, nB, P_BN5G, false);
         ae_chan_sums<1, 64, true>(l, B3, B1, slot(10));
     } else if constexpr (PH == 12) {            // BN5 backward -> pre_net.0 -> fc_mu -> out_net.6 -> BN4's output gradient
-        ae_load(B0, act + A_G, 64);
-        ae_load(B1, act + A_P0, 64);
+        ae_load<1, 64>(B0, act + A_G);
+        ae_load<1, 64>(B1, act + A_P0);
         ae_bn_prepare<64>(a, l, 5, 5, nB, P_BN5G, false);
         ae_bwd_means<64>(a, l, 10, nB);
-        ae_bn_bwd<64>(l, B0, B1, 64);                                                             // B0 = d p0
-        ae_store(act + A_DP0, B0, 64);
+        ae_bn_bwd<1, 64>(l, B0, B1);                                                              // B0 = d p0
+        ae_store<1, 64>(act + A_DP0, B0);
         ae_fc_dgrad<32, 64>(W(P_D0W), B0, B2, B4);                                                // B2 = d mu
-        ae_store(act + A_DMU, B2, 32);
+        ae_store<1, 32>(act + A_DMU, B2);
         ae_fc_dgrad<32, 32>(W(P_MUW), B2, B3, B4);                                                // B3 = d f3
-        ae_store(act + A_DF3, B3, 32);
+        ae_store<1, 32>(act + A_DF3, B3);
         ae_fc_dgrad<128, 32>(W(P_F3W), B3, B0, B4);                                               // B0 = d y2f = g
-        ae_store(act + A_G, B0, 128);
-        ae_load(B1, act + A_F2, 128);
+        ae_store<1, 128>(act + A_G, B0);
+        ae_load<1, 128>(B1, act + A_F2);
         ae_bn_prepare<128>(a, l, 4, 4, nB, P_BN4G, false);
         ae_chan_sums<1, 128, true>(l, B0, B1, slot(11));
     } else if constexpr (PH == 13) {            // BN4 backward -> out_net.3 -> BN3's output gradient
-        ae_load(B0, act + A_G, 128);
-        ae_load(B1, act + A_F2, 128);
+        ae_load<1, 128>(B0, act + A_G);
+        ae_load<1, 128>(B1, act + A_F2);
         ae_bn_prepare<128>(a, l, 4, 4, nB, P_BN4G, false);
         ae_bwd_means<128>(a, l, 11, nB);
-        ae_bn_bwd<128>(l, B0, B1, 128);                                                           // B0 = d f2
-        ae_store(act + A_DF2, B0, 128);
+        ae_bn_bwd<1, 128>(l, B0, B1);                                                             // B0 = d f2
+        ae_store<1, 128>(act + A_DF2, B0);
         ae_fc_dgrad<256, 128>(W(P_F2W), B0, B2, B4);                                              // B2 = d y1f = g
-        ae_store(act + A_G, B2, 256);
-        ae_load(B1, act + A_F1, 256);
+        ae_store<1, 256>(act + A_G, B2);
+        ae_load<1, 256>(B1, act + A_F1);
         ae_bn_prepare<256>(a, l, 3, 3, nB, P_BN3G, false);
         ae_chan_sums<1, 256, true>(l, B2, B1, slot(12));
     } else if constexpr (PH == 14) {            // BN3 backward -> out_net.0 -> un-flatten -> net.3 conv -> BN2's output gradient
-        ae_load(B0, act + A_G, 256);
-        ae_load(B1, act + A_F1, 256);
+        ae_load<1, 256>(B0, act + A_G);
+        ae_load<1, 256>(B1, act + A_F1);
         ae_bn_prepare<256>(a, l, 3, 3, nB, P_BN3G, false);
         ae_bwd_means<256>(a, l, 12, nB);
-        ae_bn_bwd<256>(l, B0, B1, 256);                                                           // B0 = d f1
-        ae_store(act + A_DF1, B0, 256);
+        ae_bn_bwd<1, 256>(l, B0, B1);                                                             // B0 = d f1
+        ae_store<1, 256>(act + A_DF1, B0);
         ae_fc_dgrad<384, 256>(W(P_F1W), B0, B2, B4);                                              // B2 = d flat
-        for (int i = threadIdx.x; i < 384; i += AE_NT) B3[i] = B2[(i & 31) * 12 + (i >> 5)];      // d c4[l][c] = d flat[c * 12 + l]
+        for (int i = threadIdx.x; i < 384; i += AE_NT) B3[(i >> 5) * 36 + (i & 31)] = B2[(i & 31) * 12 + (i >> 5)];      // d c4[l][c] = d flat[c * 12 + l]
         __syncthreads();
-        ae_load(B0, act + A_C2, 14 * 64);
+        ae_load<14, 64>(B0, act + A_C2);
         ae_bn_prepare<64>(a, l, 2, 2, nB * 14, P_BN2G, false);
-        ae_bn_act<64>(l, B1, B0, 14 * 64, 0.2f);                                                  // B1 = y2
-        ae_wgrad<14, 64, 12, 32, 3, 1, 0>(B1, B3, l.wl);
+        ae_bn_act<14, 64>(l, B1, B0, 0.2f);                                                       // B1 = y2
+        ae_wgrad<14, 64, 68, 12, 32, 3, 1, 0>(B1, B3, l.wl);
         ae_unstage<64, 32, MapConvFwd<64, 3>>(part + Q_E3W, 32 * 64 * 3, l.wl);
         ae_bias_grad<12, 32>(B3, part + Q_E3B, 32);
         ae_stage<32, 64, MapConvDgrad<64, 3>>(W(P_E3W), 32 * 64 * 3, l.wl, 0, false);
-        ae_conv<12, 32, 14, 64, 3, 1, 2>(B3, l.wl, nullptr, 0, B4);                               // B4 = d y2
-        ae_act_bwd<64>(l, B4, B0, 14 * 64, 0.2f);
-        ae_store(act + A_G, B4, 14 * 64);
+        ae_conv<12, 32, 36, 14, 64, 3, 1, 2>(B3, l.wl, nullptr, 0, B4);                           // B4 = d y2
+        ae_act_bwd<14, 64>(l, B4, B0, 0.2f);
+        ae_store<14, 64>(act + A_G, B4);
         ae_chan_sums<14, 64, true>(l, B4, B0, slot(13));
     } else if constexpr (PH == 15) {            // BN2 backward -> net.2 conv (stride 2) -> BN1's output gradient
-        ae_load(B0, act + A_G, 14 * 64);
-        ae_load(B1, act + A_C2, 14 * 64);
+        ae_load<14, 64>(B0, act + A_G);
+        ae_load<14, 64>(B1, act + A_C2);
         ae_bn_prepare<64>(a, l, 2, 2, nB * 14, P_BN2G, false);
         ae_bwd_means<64>(a, l, 13, nB * 14);
-        ae_bn_bwd<64>(l, B0, B1, 14 * 64);                                                        // B0 = d c2
-        ae_load(B2, act + A_C1, 30 * 64);
+        ae_bn_bwd<14, 64>(l, B0, B1);                                                             // B0 = d c2
+        ae_load<30, 64>(B2, act + A_C1);
         ae_bn_prepare<64>(a, l, 1, 1, nB * 30, P_BN1G, false);
-        ae_bn_act<64>(l, B3, B2, 30 * 64, 0.2f);                                                  // B3 = y1
-        ae_wgrad<30, 64, 14, 64, 4, 2, 0>(B3, B0, l.wl);
+        ae_bn_act<30, 64>(l, B3, B2, 0.2f);                                                       // B3 = y1
+        ae_wgrad<30, 64, 68, 14, 64, 4, 2, 0>(B3, B0, l.wl);
         ae_unstage<64, 64, MapConvFwd<64, 4>>(part + Q_E2W, 64 * 64 * 4, l.wl);
         ae_bias_grad<14, 64>(B0, part + Q_E2B, 64);
         // input gradient of the stride-2 conv as a stride-1 transposed conv over d c2 with a zero row between its rows
-        for (int i = threadIdx.x; i < 27 * 64; i += AE_NT) { const int r = i >> 6; B4[i] = (r & 1) ? 0.f : B0[(r >> 1) * 64 + (i & 63)]; }
+        for (int i = threadIdx.x; i < 27 * 64; i += AE_NT) { const int r = i >> 6, c = i & 63; B4[r * 68 + c] = (r & 1) ? 0.f : B0[(r >> 1) * 68 + c]; }
         __syncthreads();
         ae_stage<64, 64, MapConvDgrad<64, 4>>(W(P_E2W), 64 * 64 * 4, l.wl, 0, false);
-        ae_conv<27, 64, 30, 64, 4, 1, 3>(B4, l.wl, nullptr, 0, B1);                               // B1 = d y1
-        ae_act_bwd<64>(l, B1, B2, 30 * 64, 0.2f);
-        ae_store(act + A_G, B1, 30 * 64);
+        ae_conv<27, 64, 68, 30, 64, 4, 1, 3>(B4, l.wl, nullptr, 0, B1);                           // B1 = d y1
+        ae_act_bwd<30, 64>(l, B1, B2, 0.2f);
+        ae_store<30, 64>(act + A_G, B1);
         ae_chan_sums<30, 64, true>(l, B1, B2, slot(14));
     } else if constexpr (PH == 16) {            // BN1 backward -> net.1 conv -> BN0's output gradient
-        ae_load(B0, act + A_G, 30 * 64);
-        ae_load(B1, act + A_C1, 30 * 64);
+        ae_load<30, 64>(B0, act + A_G);
+        ae_load<30, 64>(B1, act + A_C1);
         ae_bn_prepare<64>(a, l, 1, 1, nB * 30, P_BN1G, false);
         ae_bwd_means<64>(a, l, 14, nB * 30);
-        ae_bn_bwd<64>(l, B0, B1, 30 * 64);                                                        // B0 = d c1
-        ae_load(B2, act + A_C0, 32 * 32);
+        ae_bn_bwd<30, 64>(l, B0, B1);                                                             // B0 = d c1
+        ae_load<32, 32>(B2, act + A_C0);
         ae_bn_prepare<32>(a, l, 0, 0, nB * 32, P_BN0G, false);
-        ae_bn_act<32>(l, B3, B2, 32 * 32, 0.2f);                                                  // B3 = y0
-        ae_wgrad<32, 32, 30, 64, 3, 1, 0>(B3, B0, l.wl);
+        ae_bn_act<32, 32>(l, B3, B2, 0.2f);                                                       // B3 = y0
+        ae_wgrad<32, 32, 36, 30, 64, 3, 1, 0>(B3, B0, l.wl);
         ae_unstage<32, 64, MapConvFwd<32, 3>>(part + Q_E1W, 64 * 32 * 3, l.wl);
         ae_bias_grad<30, 64>(B0, part + Q_E1B, 64);
         ae_stage<64, 32, MapConvDgrad<32, 3>>(W(P_E1W), 64 * 32 * 3, l.wl, 0, false);
-        ae_conv<30, 64, 32, 32, 3, 1, 2>(B0, l.wl, nullptr, 0, B4);                               // B4 = d y0
-        ae_act_bwd<32>(l, B4, B2, 32 * 32, 0.2f);
-        ae_store(act + A_G, B4, 32 * 32);
+        ae_conv<30, 64, 68, 32, 32, 3, 1, 2>(B0, l.wl, nullptr, 0, B4);                           // B4 = d y0
+        ae_act_bwd<32, 32>(l, B4, B2, 0.2f);
+        ae_store<32, 32>(act + A_G, B4);
         ae_chan_sums<32, 32, true>(l, B4, B2, slot(15));
     } else if constexpr (PH == 17) {            // BN0 backward -> net.0 conv weight gradient
-        ae_load(B0, act + A_G, 32 * 32);
-        ae_load(B1, act + A_C0, 32 * 32);
+        ae_load<32, 32>(B0, act + A_G);
+        ae_load<32, 32>(B1, act + A_C0);
         ae_bn_prepare<32>(a, l, 0, 0, nB * 32, P_BN0G, false);
         ae_bwd_means<32>(a, l, 15, nB * 32);
-        ae_bn_bwd<32>(l, B0, B1, 32 * 32);                                                        // B0 = d c0
-        ae_load_x<28>(B2, x);
-        ae_wgrad<34, 28, 32, 32, 3, 1, 0>(B2, B0, l.wl);
+        ae_bn_bwd<32, 32>(l, B0, B1);                                                             // B0 = d c0
+        ae_load_x(B2, x);
+        ae_wgrad<34, 28, 36, 32, 32, 3, 1, 0>(B2, B0, l.wl);
         ae_unstage<28, 32, MapConvFwd<27, 3>>(part + Q_E0W, 32 * 27 * 3, l.wl);
         ae_bias_grad<32, 32>(B0, part + Q_E0B, 32);
     }
@@ -676,14 +721,15 @@ __constant__ AeFcLayer ae_fc_layers[6] = {
     {P_F1W, 256, 384, A_FLAT, A_DF1, 0, 6},   {P_F2W, 128, 256, A_Y1F, A_DF2, 192, 4}, {P_F3W, 32, 128, A_Y2F, A_DF3, 256, 2},
     {P_MUW, 32, 32, A_F3, A_DMU, 264, 1},     {P_D0W, 64, 32, A_MU, A_DP0, 268, 1},    {P_D1W, 136, 64, A_YP, A_DP3, 276, 1}};
 constexpr int AE_FC_UNITS = 293;
-constexpr int AE_RED_UNITS = (AE_PART / 4 + AE_NT - 1) / AE_NT;       // 20
+constexpr int AE_RED_UNITS = (AE_PART / 4 + 511) / 512;       // 20
 constexpr int AE_TAIL_UNITS = AE_FC_UNITS + AE_RED_UNITS + 1;
 __constant__ int ae_seg_begin[17] = {Q_E0W, Q_E0B, Q_E1W, Q_E1B, Q_E2W, Q_E2B, Q_E3W, Q_E3B, Q_T0W, Q_T0B, Q_T1W, Q_T1B, Q_C6W, Q_C6B, Q_C7W, Q_C7B, AE_PART};
 __constant__ int ae_seg_param[16] = {P_E0W, P_E0B, P_E1W, P_E1B, P_E2W, P_E2B, P_E3W, P_E3B, P_T0W, P_T0B, P_T1W, P_T1B, P_C6W, P_C6B, P_C7W, P_C7B};
 __constant__ int ae_bn_gamma[8] = {P_BN0G, P_BN1G, P_BN2G, P_BN3G, P_BN4G, P_BN5G, P_BN6G, P_BN7G};
 __constant__ int ae_bn_ch[8] = {32, 64, 64, 256, 128, 64, 32, 32};
 
-__global__ __launch_bounds__(AE_NT) void ae_tail_kernel(const AeArgs a) {
+constexpr int AE_TAIL_NT = 512;
+__global__ __launch_bounds__(AE_TAIL_NT) void ae_tail_kernel(const AeArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[256 * 64];
     __shared__ __attribute__((aligned(16))) float ds[256 * 8];
     const int u = blockIdx.x, t = threadIdx.x, B = a.B;
@@ -693,13 +739,13 @@ __global__ __launch_bounds__(AE_NT) void ae_tail_kernel(const AeArgs a) {
         while (li < 5 && u >= ae_fc_layers[li + 1].unit0) ++li;
         const AeFcLayer L = ae_fc_layers[li];
         const int lu = u - L.unit0, n0 = (lu / L.kc) * 8, k0 = (lu % L.kc) * 64;
-        for (int i = t; i < B * 16; i += AE_NT) {               // x[b][k0 .. k0 + 64) as 16-byte pieces
+        for (int i = t; i < B * 16; i += AE_TAIL_NT) {               // x[b][k0 .. k0 + 64) as 16-byte pieces
             const int b = i >> 4, q = (i & 15) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (k0 + q < L.k) v = *reinterpret_cast<const f32x4*>(a.act + (size_t)b * AE_ACT + L.x_off + k0 + q);
             *reinterpret_cast<f32x4*>(xs + b * 64 + q) = v;
         }
-        for (int i = t; i < B * 8; i += AE_NT) {
+        for (int i = t; i < B * 8; i += AE_TAIL_NT) {
             const int b = i >> 3, r = i & 7;
             ds[i] = n0 + r < L.n ? a.act[(size_t)b * AE_ACT + L.dy_off + n0 + r] : 0.f;
         }
@@ -716,7 +762,7 @@ __global__ __launch_bounds__(AE_NT) void ae_tail_kernel(const AeArgs a) {
         }
     } else if (u < AE_FC_UNITS + AE_RED_UNITS) {
         // conv weight / bias gradients: the per-clip partials summed in clip order
-        const int i4 = (u - AE_FC_UNITS) * AE_NT + t;
+        const int i4 = (u - AE_FC_UNITS) * AE_TAIL_NT + t;
         if (i4 < AE_PART / 4) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
@@ -732,7 +778,7 @@ __global__ __launch_bounds__(AE_NT) void ae_tail_kernel(const AeArgs a) {
         // BatchNorm gamma / beta gradients = the backward sums (slot 15 - bn: sum g * xhat, sum g); loss; Adam step counter; sums back to zero
         for (int bn = 0; bn < 8; ++bn) {
             const double* s = a.sums + (size_t)(15 - bn) * 512;
-            for (int c = t; c < ae_bn_ch[bn]; c += AE_NT) {
+            for (int c = t; c < ae_bn_ch[bn]; c += AE_TAIL_NT) {
                 a.G[a.off[ae_bn_gamma[bn]] + c] = (float)s[256 + c];
                 a.G[a.off[ae_bn_gamma[bn] + 1] + c] = (float)s[c];
             }
@@ -742,7 +788,7 @@ __global__ __launch_bounds__(AE_NT) void ae_tail_kernel(const AeArgs a) {
             if (a.step != nullptr) *a.step += 1;
         }
         __syncthreads();
-        for (int i = t; i < AE_SLOTS * 512; i += AE_NT) a.sums[i] = 0.0;
+        for (int i = t; i < AE_SLOTS * 512; i += AE_TAIL_NT) a.sums[i] = 0.0;
     }
 }
 
@@ -753,7 +799,7 @@ using namespace tg;
 extern "C" int32_t tg_ae_step_supported(int32_t B) { return B >= 2 && B <= 256 ? 1 : 0; }
 
 extern "C" int64_t tg_ae_step_ws_bytes(int32_t B) {
-    return (int64_t)AE_SLOTS * 512 * 8 + ((int64_t)B * AE_ACT + (int64_t)B * AE_PART) * 4;
+    return (int64_t)AE_SLOTS * 512 * 8 + ((int64_t)B * AE_ACT + (int64_t)B * AE_PART + AE_WT) * 4;
 }
 
 extern "C" int tg_ae_train_step(const tg_ae_step_args* q, void* stream) {
@@ -776,6 +822,7 @@ extern "C" int tg_ae_train_step(const tg_ae_step_args* q, void* stream) {
     a.sums = (double*)q->ws;
     a.act = (float*)((char*)q->ws + (size_t)AE_SLOTS * 512 * 8);
     a.part = a.act + (size_t)q->B * AE_ACT;
+    a.wt = a.part + (size_t)q->B * AE_PART;
     a.loss = q->loss; a.recon = q->recon; a.feat = q->feat; a.step = q->step;
     a.B = q->B; a.bn_eps = q->bn_eps; a.momentum = q->momentum;
     hipStream_t s = (hipStream_t)stream;
@@ -788,6 +835,6 @@ extern "C" int tg_ae_train_step(const tg_ae_step_args* q, void* stream) {
     TG_AE_PHASE(1); TG_AE_PHASE(2); TG_AE_PHASE(3); TG_AE_PHASE(4); TG_AE_PHASE(5); TG_AE_PHASE(6); TG_AE_PHASE(7); TG_AE_PHASE(8); TG_AE_PHASE(9);
     TG_AE_PHASE(10); TG_AE_PHASE(11); TG_AE_PHASE(12); TG_AE_PHASE(13); TG_AE_PHASE(14); TG_AE_PHASE(15); TG_AE_PHASE(16); TG_AE_PHASE(17);
 #undef TG_AE_PHASE
-    if (last >= 18) hipLaunchKernelGGL(ae_tail_kernel, dim3(AE_TAIL_UNITS), block, 0, s, a);
+    if (last >= 18) hipLaunchKernelGGL(ae_tail_kernel, dim3(AE_TAIL_UNITS), dim3(AE_TAIL_NT), 0, s, a);
     return check_launch("tg_ae_train_step");
 }

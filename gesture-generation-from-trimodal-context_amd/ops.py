@@ -1206,7 +1206,7 @@ class AeStep:
     def workspace_views(self):
         """(sums [17, 2, 256] fp64, act [B, AE_ACT], part [B, AE_PART]) views of the workspace (tests)."""
         n_act, n_part = 10256, 40700
-        assert _lib.load().tg_ae_step_ws_bytes(self.B) == 17 * 512 * 8 + self.B * (n_act + n_part) * 4
+        assert _lib.load().tg_ae_step_ws_bytes(self.B) == 17 * 512 * 8 + (self.B * (n_act + n_part) + 146944) * 4      # (+ the transposed linear weights)
         f = self.ws.view(torch.float32)
         sums = self.ws[:17 * 512 * 2].view(torch.float64).view(17, 2, 256)
         act = f[17 * 512 * 2:17 * 512 * 2 + self.B * n_act].view(self.B, n_act)

