@@ -24,9 +24,9 @@
 namespace tg {
 
 constexpr int AE_NT = 512;
-constexpr int AE_WLD = 16640;            // staged weights: at most 256 rows of 64 + 1 floats (net.2: Conv1d(64, 64, 4))
+constexpr int AE_WLD = 16768;            // staged weights: at most 256 (+ 1 for the bias gradient) rows of 64 + 1 floats (net.2: Conv1d(64, 64, 4))
 constexpr int AE_BUF = 2048;             // one activation buffer (largest tensor of a clip: 30 x 64)
-constexpr int AE_NBUF = 5;
+constexpr int AE_NBUF = 6;
 
 // per-clip record of the activation workspace (floats)
 constexpr int A_C0 = 0;                  // pre-BatchNorm conv outputs, channel-last
@@ -101,21 +101,25 @@ struct AeArgs {
     float bn_eps, momentum;
 };
 
+struct AeBn { float *mean, *rstd, *ga, *be; };      // one BatchNorm's per-channel coefficients in LDS
 struct AeLds {
     float* wl;
     float* b[AE_NBUF];
-    float *mean, *rstd, *ga, *be, *mg, *mgx;
+    AeBn s1, s2;                          // a backward phase needs two BatchNorms at once (the one it differentiates, the one in front of it)
+    float *mg, *mgx;
     float* red;                           // [2][AE_NT]
 };
-constexpr int AE_LDS_FLOATS = AE_WLD + AE_NBUF * AE_BUF + 6 * 256 + 2 * AE_NT;
+constexpr int AE_LDS_FLOATS = AE_WLD + AE_NBUF * AE_BUF + 10 * 256 + 2 * AE_NT;
 
 __device__ __forceinline__ AeLds ae_lds(float* smem) {
     AeLds l;
     l.wl = smem;
     for (int i = 0; i < AE_NBUF; ++i) l.b[i] = smem + AE_WLD + i * AE_BUF;
     float* s = smem + AE_WLD + AE_NBUF * AE_BUF;
-    l.mean = s; l.rstd = s + 256; l.ga = s + 512; l.be = s + 768; l.mg = s + 1024; l.mgx = s + 1280;
-    l.red = s + 1536;
+    l.s1 = AeBn{s, s + 256, s + 512, s + 768};
+    l.s2 = AeBn{s + 1024, s + 1280, s + 1536, s + 1792};
+    l.mg = s + 2048; l.mgx = s + 2304;
+    l.red = s + 2560;
     return l;
 }
 
@@ -126,13 +130,19 @@ __device__ __forceinline__ float ae_lrelu(float v, float slope) { return v > 0.f
 __device__ __forceinline__ constexpr int ae_rs(int C) { return C + 4; }
 
 // global [L][C] (flat) <-> LDS [L][C + 4]
+// (the _t forms run on the thread subset [tid of nt] and end WITHOUT a barrier: a phase's prologue gives its independent global reads --
+// staged weights, saved tensors, BatchNorm sums -- to different waves and meets once)
 template <int L, int C>
-__device__ __forceinline__ void ae_load(float* __restrict__ dst, const float* __restrict__ src) {
+__device__ __forceinline__ void ae_load_t(float* __restrict__ dst, const float* __restrict__ src, int tid, int nt) {
     static_assert(C % 4 == 0, "16-byte pieces");
-    for (int i = threadIdx.x; i < L * C / 4; i += AE_NT) {
+    for (int i = tid; i < L * C / 4; i += nt) {
         const int r = (4 * i) / C, c = (4 * i) % C;
         *reinterpret_cast<f32x4*>(dst + r * ae_rs(C) + c) = reinterpret_cast<const f32x4*>(src)[i];
     }
+}
+template <int L, int C>
+__device__ __forceinline__ void ae_load(float* __restrict__ dst, const float* __restrict__ src) {
+    ae_load_t<L, C>(dst, src, threadIdx.x, AE_NT);
     __syncthreads();
 }
 template <int L, int C>
@@ -143,27 +153,30 @@ __device__ __forceinline__ void ae_store(float* __restrict__ dst, const float* _
     }
 }
 // the clip's poses [34][27] -> LDS [34][36], columns 27.. zero
-__device__ __forceinline__ void ae_load_x(float* __restrict__ dst, const float* __restrict__ x) {
-    for (int i = threadIdx.x; i < 34 * 36; i += AE_NT) {
+__device__ __forceinline__ void ae_load_x_t(float* __restrict__ dst, const float* __restrict__ x, int tid, int nt) {
+    for (int i = tid; i < 34 * 36; i += nt) {
         const int r = i / 36, c = i - r * 36;
         dst[i] = c < 27 ? x[r * 27 + c] : 0.f;
     }
+}
+__device__ __forceinline__ void ae_load_x(float* __restrict__ dst, const float* __restrict__ x) {
+    ae_load_x_t(dst, x, threadIdx.x, AE_NT);
     __syncthreads();
 }
 
 // BatchNorm `bn` from the fp64 sums of `slot`: mean / rstd / gamma / beta of its C channels into LDS; optionally (workgroup 0, forward
 // phases) the running statistics (momentum, unbiased variance, num_batches_tracked += 1)
 template <int C>
-__device__ __forceinline__ void ae_bn_prepare(const AeArgs& a, const AeLds& l, int bn, int slot, double n_el, int p_gamma, bool update_running) {
-    for (int c = threadIdx.x; c < C; c += AE_NT) {
+__device__ __forceinline__ void ae_bn_prepare_t(const AeArgs& a, const AeBn& o, int bn, int slot, double n_el, int p_gamma, bool update_running, int tid, int nt) {
+    for (int c = tid; c < C; c += nt) {
         const double* s = a.sums + (size_t)slot * 512;
         const double m = s[c] / n_el;
         double var = s[256 + c] / n_el - m * m;
         if (var < 0.0) var = 0.0;
         const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)a.bn_eps));
-        l.mean[c] = mf; l.rstd[c] = rs;
-        l.ga[c] = a.P[a.off[p_gamma] + c];
-        l.be[c] = a.P[a.off[p_gamma + 1] + c];
+        o.mean[c] = mf; o.rstd[c] = rs;
+        o.ga[c] = a.P[a.off[p_gamma] + c];
+        o.be[c] = a.P[a.off[p_gamma + 1] + c];
         if (update_running && blockIdx.x == 0 && a.rm[bn] != nullptr) {
             const double unbiased = n_el > 1.0 ? var * n_el / (n_el - 1.0) : var;
             a.rm[bn][c] = (1.f - a.momentum) * a.rm[bn][c] + a.momentum * mf;
@@ -171,21 +184,19 @@ __device__ __forceinline__ void ae_bn_prepare(const AeArgs& a, const AeLds& l, i
             if (c == 0 && a.nbt[bn] != nullptr) *a.nbt[bn] += 1;
         }
     }
-    __syncthreads();
 }
 // the sums of the backward: mg = sum(g) / n, mgx = sum(g * xhat) / n
 template <int C>
-__device__ __forceinline__ void ae_bwd_means(const AeArgs& a, const AeLds& l, int slot, double n_el) {
-    for (int c = threadIdx.x; c < C; c += AE_NT) {
+__device__ __forceinline__ void ae_bwd_means_t(const AeArgs& a, const AeLds& l, int slot, double n_el, int tid, int nt) {
+    for (int c = tid; c < C; c += nt) {
         const double* s = a.sums + (size_t)slot * 512;
         l.mg[c] = (float)(s[c] / n_el);
         l.mgx[c] = (float)(s[256 + c] / n_el);
     }
-    __syncthreads();
 }
 // dst = LeakyReLU(BatchNorm(src)), both [L][C + 4]
 template <int L, int C>
-__device__ __forceinline__ void ae_bn_act(const AeLds& l, float* __restrict__ dst, const float* __restrict__ src, float slope) {
+__device__ __forceinline__ void ae_bn_act(const AeBn& l, float* __restrict__ dst, const float* __restrict__ src, float slope) {
     for (int i = threadIdx.x; i < L * C; i += AE_NT) {
         const int c = i & (C - 1), o = (i / C) * ae_rs(C) + c;
         dst[o] = ae_lrelu((src[o] - l.mean[c]) * l.rstd[c] * l.ga[c] + l.be[c], slope);
@@ -194,7 +205,7 @@ __device__ __forceinline__ void ae_bn_act(const AeLds& l, float* __restrict__ ds
 }
 // g = dy * act'(BatchNorm(raw)) in place (dy -> g)
 template <int L, int C>
-__device__ __forceinline__ void ae_act_bwd(const AeLds& l, float* __restrict__ dy, const float* __restrict__ raw, float slope) {
+__device__ __forceinline__ void ae_act_bwd(const AeBn& l, float* __restrict__ dy, const float* __restrict__ raw, float slope) {
     for (int i = threadIdx.x; i < L * C; i += AE_NT) {
         const int c = i & (C - 1), o = (i / C) * ae_rs(C) + c;
         const float bnv = (raw[o] - l.mean[c]) * l.rstd[c] * l.ga[c] + l.be[c];
@@ -204,17 +215,17 @@ __device__ __forceinline__ void ae_act_bwd(const AeLds& l, float* __restrict__ d
 }
 // BatchNorm backward in place: g -> dc = gamma * rstd * (g - mg - xhat * mgx)
 template <int L, int C>
-__device__ __forceinline__ void ae_bn_bwd(const AeLds& l, float* __restrict__ g, const float* __restrict__ raw) {
+__device__ __forceinline__ void ae_bn_bwd(const AeLds& ll, const AeBn& l, float* __restrict__ g, const float* __restrict__ raw) {
     for (int i = threadIdx.x; i < L * C; i += AE_NT) {
         const int c = i & (C - 1), o = (i / C) * ae_rs(C) + c;
         const float xh = (raw[o] - l.mean[c]) * l.rstd[c];
-        g[o] = l.ga[c] * l.rstd[c] * (g[o] - l.mg[c] - xh * l.mgx[c]);
+        g[o] = l.ga[c] * l.rstd[c] * (g[o] - ll.mg[c] - xh * ll.mgx[c]);
     }
     __syncthreads();
 }
 // per-channel sums of the clip's [L][C + 4] tensor -> fp64 atomics.  BWD: (sum g, sum g * xhat) with xhat from `raw`; else (sum v, sum v^2)
 template <int L, int C, bool BWD>
-__device__ __forceinline__ void ae_chan_sums(const AeLds& l, const float* __restrict__ v, const float* __restrict__ raw, double* __restrict__ slot) {
+__device__ __forceinline__ void ae_chan_sums(const AeLds& l, const AeBn& bnc, const float* __restrict__ v, const float* __restrict__ raw, double* __restrict__ slot) {
     static_assert(AE_NT % C == 0, "channels per workgroup");
     constexpr int PARTS = AE_NT / C;
     const int c = threadIdx.x % C, part = threadIdx.x / C;
@@ -222,7 +233,7 @@ __device__ __forceinline__ void ae_chan_sums(const AeLds& l, const float* __rest
     for (int r = part; r < L; r += PARTS) {
         const float x = v[r * ae_rs(C) + c];
         s0 += x;
-        if constexpr (BWD) s1 += x * ((raw[r * ae_rs(C) + c] - l.mean[c]) * l.rstd[c]);
+        if constexpr (BWD) s1 += x * ((raw[r * ae_rs(C) + c] - bnc.mean[c]) * bnc.rstd[c]);
         else s1 += x * x;
     }
     l.red[threadIdx.x] = s0; l.red[AE_NT + threadIdx.x] = s1;
@@ -253,7 +264,8 @@ __device__ __forceinline__ void ae_conv(const float* __restrict__ in, const floa
         f32x4 acc = {b0, b0, b0, b0};
         int kk = 0, m = kq;
         const float* wp = wl + kq * WS + n;
-#pragma unroll 4
+        // (unrolled deep: the operand reads of many steps are in flight before the first MFMA needs them -- the chain is LDS latency otherwise)
+#pragma unroll 12
         for (int s = 0; s < KT; ++s) {
             const int row = p * S + kk - PAD;
             const float av = (p < LOUT && row >= 0 && row < LIN) ? in[row * RS + m] : 0.f;
@@ -284,11 +296,12 @@ __device__ __forceinline__ void ae_conv_n4(const float* __restrict__ in, const f
     __syncthreads();
 }
 // weight gradient of one clip in the staged layout: dwl[(kk * CINP + m) * (N + 1) + n] = sum_p dout[p][n] * in[p * S + kk - PAD][m].
-// MFMA rows = (kk, m), columns = n, reduction over the positions p (steps of four)
+// MFMA rows = (kk, m), columns = n, reduction over the positions p (steps of four).  Row KW * CINP is the BIAS gradient sum_p dout[p][n]
+// (an input of ones): ae_bias_out copies it out
 template <int LIN, int CINP, int RS, int LOUT, int N, int KW, int S, int PAD>
 __device__ __forceinline__ void ae_wgrad(const float* __restrict__ in, const float* __restrict__ dout, float* __restrict__ dwl) {
     static_assert(N % 16 == 0, "tiles");
-    constexpr int KM = KW * CINP, MT = (KM + 15) / 16, NTL = N / 16, WS = N + 1, DS = N + 4, PT = (LOUT + 3) / 4;
+    constexpr int KM = KW * CINP, MT = (KM + 1 + 15) / 16, NTL = N / 16, WS = N + 1, DS = N + 4, PT = (LOUT + 3) / 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
     for (int tile = wave; tile < MT * NTL; tile += AE_NT / 64) {
         const int rt = tile / NTL, ct = tile - rt * NTL;
@@ -296,30 +309,28 @@ __device__ __forceinline__ void ae_wgrad(const float* __restrict__ in, const flo
         const bool km_ok = km < KM;
         const int kk = km_ok ? km / CINP : 0, m = km_ok ? km - kk * CINP : 0;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll
         for (int s = 0; s < PT; ++s) {
             const int p = 4 * s + kq;
             const int row = p * S + kk - PAD;
-            const float av = (km_ok && p < LOUT && row >= 0 && row < LIN) ? in[row * RS + m] : 0.f;
+            float av = (km_ok && p < LOUT && row >= 0 && row < LIN) ? in[row * RS + m] : 0.f;
+            if (km == KM && p < LOUT) av = 1.f;
             const float bv = p < LOUT ? dout[p * DS + n] : 0.f;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ko = rt * 16 + 4 * kq + q;
-            if (ko < KM) dwl[ko * WS + n] = acc[q];
+            if (ko <= KM) dwl[ko * WS + n] = acc[q];
         }
     }
     __syncthreads();
 }
-// bias gradient of the clip: db[n] = sum_p dout[p][n]; entries up to n_store are written (dout's padding channels hold zeros)
-template <int LOUT, int N>
-__device__ __forceinline__ void ae_bias_grad(const float* __restrict__ dout, float* __restrict__ part, int n_store) {
-    if ((int)threadIdx.x < n_store) {
-        float s = 0.f;
-        for (int p = 0; p < LOUT; ++p) s += dout[p * (N + 4) + threadIdx.x];
-        part[threadIdx.x] = s;
-    }
+// the bias gradient row of ae_wgrad's result -> the partial record (dout's padding channels hold zeros, so entries past the layer's
+// channel count come out zero); call between ae_wgrad and the barrier that ends ae_unstage
+template <int KM, int N>
+__device__ __forceinline__ void ae_bias_out(const float* __restrict__ dwl, float* __restrict__ part, int n_store) {
+    if ((int)threadIdx.x < n_store) part[threadIdx.x] = dwl[KM * (N + 1) + threadIdx.x];
 }
 
 // weight index maps: parameter element idx -> (kk, m, n) of the staged layout
@@ -340,6 +351,15 @@ template <int CO, int KW> struct MapConvTDgrad {
     __device__ static void at(int idx, int& kk, int& m, int& n) { const int k = idx % KW, r = idx / KW; kk = k; m = r % CO; n = r / CO; }
 };
 
+template <int CINP, int N, class MAP>
+__device__ __forceinline__ void ae_stage_t(const float* __restrict__ W, int numel, float* __restrict__ wl, int tid, int nt) {
+    constexpr int WS = N + 1;
+    for (int idx = tid; idx < numel; idx += nt) {
+        int kk, m, n;
+        MAP::at(idx, kk, m, n);
+        wl[(kk * CINP + m) * WS + n] = W[idx];
+    }
+}
 template <int CINP, int N, class MAP>
 __device__ __forceinline__ void ae_stage(const float* __restrict__ W, int numel, float* __restrict__ wl, int rows, bool zero_first) {
     constexpr int WS = N + 1;
@@ -366,26 +386,31 @@ __device__ __forceinline__ void ae_unstage(float* __restrict__ part, int numel, 
 }
 
 // ---- linear layers of one clip --------------------------------------------------------------------------------------------------------
-// out[n] = b[n] + sum_k Wt[k][n] x[k] with the TRANSPOSED weight (phase 1 writes it once per step): lanes along n (coalesced), no cross-lane
-// reduction; the NT / N thread groups split k and meet in LDS
+// out[n] = b[n] + sum_k Wt[k][n] x[k] with the TRANSPOSED weight (phase 1 writes it once per step): a thread owns four consecutive n (one
+// 16-byte load per k, lanes contiguous) and a slice of k, no cross-lane reduction; the slices meet in LDS (scratch: AE_BUF floats)
 template <int K, int N>
-__device__ __forceinline__ void ae_fc(const AeLds& l, const float* __restrict__ Wt, const float* __restrict__ b, const float* __restrict__ x,
-                                      float* __restrict__ out) {
-    constexpr int KP = AE_NT / N, PER = (K + KP - 1) / KP;
-    static_assert(KP >= 1 && KP * N <= 2 * AE_NT, "scratch");
-    const int n = threadIdx.x % N, kp = threadIdx.x / N;
+__device__ __forceinline__ void ae_fc(const float* __restrict__ Wt, const float* __restrict__ b, const float* __restrict__ x, float* __restrict__ out,
+                                      float* __restrict__ scratch) {
+    static_assert(N % 4 == 0, "16-byte pieces");
+    constexpr int NQ = N / 4, KP0 = AE_NT / NQ, KP1 = KP0 < K ? KP0 : K, KP = KP1 * N <= AE_BUF ? KP1 : AE_BUF / N, PER = (K + KP - 1) / KP;
+    static_assert(KP >= 1 && KP * N <= AE_BUF, "scratch");
+    const int nq = threadIdx.x % NQ, kp = threadIdx.x / NQ;
     if (kp < KP) {
-        float s = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int k0 = kp * PER, k1 = k0 + PER < K ? k0 + PER : K;
-#pragma unroll 8
-        for (int k = k0; k < k1; ++k) s = fmaf(Wt[(long)k * N + n], x[k], s);
-        l.red[kp * N + n] = s;
+#pragma unroll 16
+        for (int k = k0; k < k1; ++k) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(Wt + (long)k * N + 4 * nq);
+            const float xv = x[k];
+            acc[0] = fmaf(w[0], xv, acc[0]); acc[1] = fmaf(w[1], xv, acc[1]); acc[2] = fmaf(w[2], xv, acc[2]); acc[3] = fmaf(w[3], xv, acc[3]);
+        }
+        *reinterpret_cast<f32x4*>(scratch + kp * N + 4 * nq) = acc;
     }
     __syncthreads();
-    if ((int)threadIdx.x < N) {
-        float s = b[threadIdx.x];
-        for (int q = 0; q < KP; ++q) s += l.red[q * N + threadIdx.x];
-        out[threadIdx.x] = s;
+    for (int n = threadIdx.x; n < N; n += AE_NT) {
+        float s_ = b[n];
+        for (int q = 0; q < KP; ++q) s_ += scratch[q * N + n];
+        out[n] = s_;
     }
     __syncthreads();
 }
@@ -398,7 +423,7 @@ __device__ __forceinline__ void ae_fc_dgrad(const float* __restrict__ W, const f
     if (ng < NG) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int n0 = ng * PER, n1 = n0 + PER < N ? n0 + PER : N;
-#pragma unroll 4
+#pragma unroll 16
         for (int n = n0; n < n1; ++n) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)n * K + 4 * kq);
             const float d = dy[n];
@@ -430,6 +455,10 @@ __constant__ AeWtLayer ae_wt_layers[7] = {{P_F1W, 256, 384, WT_F1}, {P_F2W, 128,
                                           {P_D0W, 64, 32, WT_D0},   {P_D1W, 136, 64, WT_D1},  {0, 0, 0, AE_WT}};
 
 // ---- phases 1..17 ----------------------------------------------------------------------------------------------------------------------
+// Every phase opens with a PROLOGUE in which the waves split the independent global reads -- waves 0-3 stage the first layer's weights,
+// waves 4-7 fetch the saved tensors and finish the BatchNorm statistics -- and meet at one barrier (three or four dependent round trips to
+// L2 became one).  A backward phase runs the input gradient FIRST (its sums leave as atomics as early as possible) and the layer's weight
+// gradient last: nothing in the phase waits for it.
 template <int PH>
 __global__ __launch_bounds__(AE_NT) void ae_phase_kernel(const AeArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[AE_LDS_FLOATS];
@@ -439,12 +468,15 @@ __global__ __launch_bounds__(AE_NT) void ae_phase_kernel(const AeArgs a) {
     float* const part = a.part + (size_t)clip * AE_PART;
     const float* const x = a.x + (size_t)clip * 34 * 27;
     const double nB = (double)a.B;
-    float *B0 = l.b[0], *B1 = l.b[1], *B2 = l.b[2], *B3 = l.b[3], *B4 = l.b[4];
+    float *B0 = l.b[0], *B1 = l.b[1], *B2 = l.b[2], *B3 = l.b[3], *B4 = l.b[4], *B5 = l.b[5];
     auto W = [&](int p) { return a.P + a.off[p]; };
     auto slot = [&](int s) { return a.sums + (size_t)s * 512; };
+    constexpr int H = AE_NT / 2;
+    const bool lo = (int)threadIdx.x < H;                 // waves 0-3 / waves 4-7 of the prologue
+    const int th = lo ? threadIdx.x : threadIdx.x - H;
 
     if constexpr (PH == 1) {                    // poses -> net.0 conv; the linear layers' weights transposed for this step's forward
-        ae_load_x(B0, x);
+        for (int i = threadIdx.x; i < 3 * 28 * 33; i += AE_NT) l.wl[i] = 0.f;
         for (int e = blockIdx.x * AE_NT + threadIdx.x; e < AE_WT; e += gridDim.x * AE_NT) {
             int li = 0;
             while (e >= ae_wt_layers[li + 1].begin) ++li;
@@ -452,91 +484,107 @@ __global__ __launch_bounds__(AE_NT) void ae_phase_kernel(const AeArgs a) {
             const int r = e - L.begin, k = r / L.n, n = r - k * L.n;
             a.wt[e] = a.P[a.off[L.p] + n * L.k + k];
         }
-        ae_stage<28, 32, MapConvFwd<27, 3>>(W(P_E0W), 32 * 27 * 3, l.wl, 3 * 28, true);
+        __syncthreads();
+        if (lo) ae_stage_t<28, 32, MapConvFwd<27, 3>>(W(P_E0W), 32 * 27 * 3, l.wl, th, H);
+        else ae_load_x_t(B0, x, th, H);
+        __syncthreads();
         ae_conv<34, 28, 36, 32, 32, 3, 1, 0>(B0, l.wl, W(P_E0B), 32, B1);
         ae_store<32, 32>(act + A_C0, B1);
-        ae_chan_sums<32, 32, false>(l, B1, nullptr, slot(0));
+        ae_chan_sums<32, 32, false>(l, l.s1, B1, nullptr, slot(0));
     } else if constexpr (PH == 2) {             // BN0 + LeakyReLU(0.2) -> net.1 conv
-        ae_load<32, 32>(B0, act + A_C0);
-        ae_bn_prepare<32>(a, l, 0, 0, nB * 32, P_BN0G, true);
-        ae_bn_act<32, 32>(l, B1, B0, 0.2f);
-        ae_stage<32, 64, MapConvFwd<32, 3>>(W(P_E1W), 64 * 32 * 3, l.wl, 0, false);
+        if (lo) ae_stage_t<32, 64, MapConvFwd<32, 3>>(W(P_E1W), 64 * 32 * 3, l.wl, th, H);
+        else { ae_load_t<32, 32>(B0, act + A_C0, th, H); ae_bn_prepare_t<32>(a, l.s1, 0, 0, nB * 32, P_BN0G, true, th, H); }
+        __syncthreads();
+        ae_bn_act<32, 32>(l.s1, B1, B0, 0.2f);
         ae_conv<32, 32, 36, 30, 64, 3, 1, 0>(B1, l.wl, W(P_E1B), 64, B2);
         ae_store<30, 64>(act + A_C1, B2);
-        ae_chan_sums<30, 64, false>(l, B2, nullptr, slot(1));
+        ae_chan_sums<30, 64, false>(l, l.s1, B2, nullptr, slot(1));
     } else if constexpr (PH == 3) {             // BN1 -> net.2 conv (k 4, stride 2)
-        ae_load<30, 64>(B0, act + A_C1);
-        ae_bn_prepare<64>(a, l, 1, 1, nB * 30, P_BN1G, true);
-        ae_bn_act<30, 64>(l, B1, B0, 0.2f);
-        ae_stage<64, 64, MapConvFwd<64, 4>>(W(P_E2W), 64 * 64 * 4, l.wl, 0, false);
+        if (lo) ae_stage_t<64, 64, MapConvFwd<64, 4>>(W(P_E2W), 64 * 64 * 4, l.wl, th, H);
+        else { ae_load_t<30, 64>(B0, act + A_C1, th, H); ae_bn_prepare_t<64>(a, l.s1, 1, 1, nB * 30, P_BN1G, true, th, H); }
+        __syncthreads();
+        ae_bn_act<30, 64>(l.s1, B1, B0, 0.2f);
         ae_conv<30, 64, 68, 14, 64, 4, 2, 0>(B1, l.wl, W(P_E2B), 64, B2);
         ae_store<14, 64>(act + A_C2, B2);
-        ae_chan_sums<14, 64, false>(l, B2, nullptr, slot(2));
+        ae_chan_sums<14, 64, false>(l, l.s1, B2, nullptr, slot(2));
     } else if constexpr (PH == 4) {             // BN2 -> net.3 conv -> flatten -> out_net.0
-        ae_load<14, 64>(B0, act + A_C2);
-        ae_bn_prepare<64>(a, l, 2, 2, nB * 14, P_BN2G, true);
-        ae_bn_act<14, 64>(l, B1, B0, 0.2f);
-        ae_stage<64, 32, MapConvFwd<64, 3>>(W(P_E3W), 32 * 64 * 3, l.wl, 0, false);
+        if (lo) ae_stage_t<64, 32, MapConvFwd<64, 3>>(W(P_E3W), 32 * 64 * 3, l.wl, th, H);
+        else { ae_load_t<14, 64>(B0, act + A_C2, th, H); ae_bn_prepare_t<64>(a, l.s1, 2, 2, nB * 14, P_BN2G, true, th, H); }
+        __syncthreads();
+        ae_bn_act<14, 64>(l.s1, B1, B0, 0.2f);
         ae_conv<14, 64, 68, 12, 32, 3, 1, 0>(B1, l.wl, W(P_E3B), 32, B2);
         for (int i = threadIdx.x; i < 384; i += AE_NT) B3[i] = B2[(i % 12) * 36 + i / 12];       // flat[c * 12 + l] = c4[l][c]
         __syncthreads();
         ae_store<1, 384>(act + A_FLAT, B3);
-        ae_fc<384, 256>(l, a.wt + WT_F1, W(P_F1B), B3, B4);
+        ae_fc<384, 256>(a.wt + WT_F1, W(P_F1B), B3, B4, B5);
         ae_store<1, 256>(act + A_F1, B4);
-        ae_chan_sums<1, 256, false>(l, B4, nullptr, slot(3));
+        ae_chan_sums<1, 256, false>(l, l.s1, B4, nullptr, slot(3));
     } else if constexpr (PH == 5) {             // BN3 (LeakyReLU(True): slope 1) -> out_net.3
-        ae_load<1, 256>(B0, act + A_F1);
-        ae_bn_prepare<256>(a, l, 3, 3, nB, P_BN3G, true);
-        ae_bn_act<1, 256>(l, B1, B0, 1.f);
+        if (lo) ae_load_t<1, 256>(B0, act + A_F1, th, H);
+        else ae_bn_prepare_t<256>(a, l.s1, 3, 3, nB, P_BN3G, true, th, H);
+        __syncthreads();
+        ae_bn_act<1, 256>(l.s1, B1, B0, 1.f);
         ae_store<1, 256>(act + A_Y1F, B1);
-        ae_fc<256, 128>(l, a.wt + WT_F2, W(P_F2B), B1, B2);
+        ae_fc<256, 128>(a.wt + WT_F2, W(P_F2B), B1, B2, B5);
         ae_store<1, 128>(act + A_F2, B2);
-        ae_chan_sums<1, 128, false>(l, B2, nullptr, slot(4));
+        ae_chan_sums<1, 128, false>(l, l.s1, B2, nullptr, slot(4));
     } else if constexpr (PH == 6) {             // BN4 -> out_net.6 -> fc_mu (z = mu) -> decoder.pre_net.0
-        ae_load<1, 128>(B0, act + A_F2);
-        ae_bn_prepare<128>(a, l, 4, 4, nB, P_BN4G, true);
-        ae_bn_act<1, 128>(l, B1, B0, 1.f);
+        if (lo) ae_load_t<1, 128>(B0, act + A_F2, th, H);
+        else ae_bn_prepare_t<128>(a, l.s1, 4, 4, nB, P_BN4G, true, th, H);
+        __syncthreads();
+        ae_bn_act<1, 128>(l.s1, B1, B0, 1.f);
         ae_store<1, 128>(act + A_Y2F, B1);
-        ae_fc<128, 32>(l, a.wt + WT_F3, W(P_F3B), B1, B2);
+        ae_fc<128, 32>(a.wt + WT_F3, W(P_F3B), B1, B2, B5);
         ae_store<1, 32>(act + A_F3, B2);
-        ae_fc<32, 32>(l, a.wt + WT_MU, W(P_MUB), B2, B3);
+        ae_fc<32, 32>(a.wt + WT_MU, W(P_MUB), B2, B3, B5);
         ae_store<1, 32>(act + A_MU, B3);
         if (a.feat != nullptr) ae_store<1, 32>(a.feat + (size_t)clip * 32, B3);
-        ae_fc<32, 64>(l, a.wt + WT_D0, W(P_D0B), B3, B4);
+        ae_fc<32, 64>(a.wt + WT_D0, W(P_D0B), B3, B4, B5);
         ae_store<1, 64>(act + A_P0, B4);
-        ae_chan_sums<1, 64, false>(l, B4, nullptr, slot(5));
+        ae_chan_sums<1, 64, false>(l, l.s1, B4, nullptr, slot(5));
     } else if constexpr (PH == 7) {             // BN5 -> pre_net.3 -> view(4, 34) -> net.0 transposed conv
-        ae_load<1, 64>(B0, act + A_P0);
-        ae_bn_prepare<64>(a, l, 5, 5, nB, P_BN5G, true);
-        ae_bn_act<1, 64>(l, B1, B0, 1.f);
+        if (lo) ae_stage_t<4, 32, MapConvTFwd<32, 3>>(W(P_T0W), 4 * 32 * 3, l.wl, th, H);
+        else { ae_load_t<1, 64>(B0, act + A_P0, th, H); ae_bn_prepare_t<64>(a, l.s1, 5, 5, nB, P_BN5G, true, th, H); }
+        __syncthreads();
+        ae_bn_act<1, 64>(l.s1, B1, B0, 1.f);
         ae_store<1, 64>(act + A_YP, B1);
-        ae_fc<64, 136>(l, a.wt + WT_D1, W(P_D1B), B1, B2);
+        ae_fc<64, 136>(a.wt + WT_D1, W(P_D1B), B1, B2, B5);
         ae_store<1, 136>(act + A_P3, B2);
         for (int i = threadIdx.x; i < 136; i += AE_NT) B3[i] = B2[(i & 3) * 34 + (i >> 2)];       // x0[l][c] = p3[c * 34 + l], rows 4 floats apart
         __syncthreads();
-        ae_stage<4, 32, MapConvTFwd<32, 3>>(W(P_T0W), 4 * 32 * 3, l.wl, 0, false);
         ae_conv<34, 4, 4, 36, 32, 3, 1, 2>(B3, l.wl, W(P_T0B), 32, B4);
         ae_store<36, 32>(act + A_T0, B4);
-        ae_chan_sums<36, 32, false>(l, B4, nullptr, slot(6));
+        ae_chan_sums<36, 32, false>(l, l.s1, B4, nullptr, slot(6));
     } else if constexpr (PH == 8) {             // BN6 -> net.3 transposed conv
-        ae_load<36, 32>(B0, act + A_T0);
-        ae_bn_prepare<32>(a, l, 6, 6, nB * 36, P_BN6G, true);
-        ae_bn_act<36, 32>(l, B1, B0, 0.2f);
-        ae_stage<32, 32, MapConvTFwd<32, 3>>(W(P_T1W), 32 * 32 * 3, l.wl, 0, false);
+        if (lo) ae_stage_t<32, 32, MapConvTFwd<32, 3>>(W(P_T1W), 32 * 32 * 3, l.wl, th, H);
+        else { ae_load_t<36, 32>(B0, act + A_T0, th, H); ae_bn_prepare_t<32>(a, l.s1, 6, 6, nB * 36, P_BN6G, true, th, H); }
+        __syncthreads();
+        ae_bn_act<36, 32>(l.s1, B1, B0, 0.2f);
         ae_conv<36, 32, 36, 38, 32, 3, 1, 2>(B1, l.wl, W(P_T1B), 32, B2);
         ae_store<38, 32>(act + A_T1, B2);
-        ae_chan_sums<38, 32, false>(l, B2, nullptr, slot(7));
+        ae_chan_sums<38, 32, false>(l, l.s1, B2, nullptr, slot(7));
     } else if constexpr (PH == 9) {             // BN7 -> net.6, net.7 -> loss -> back through net.7, net.6 to BN7's output gradient
-        ae_load<38, 32>(B0, act + A_T1);
-        ae_bn_prepare<32>(a, l, 7, 7, nB * 38, P_BN7G, true);
-        ae_bn_act<38, 32>(l, B1, B0, 0.2f);                                                       // B1 = y(T1): net.6's input
-        ae_stage<32, 32, MapConvFwd<32, 3>>(W(P_C6W), 32 * 32 * 3, l.wl, 0, false);
+        // all four staged operands of the phase at once (96 rows x 33 floats each; a fifth region takes the weight gradients): net.6 / net.7
+        // forward, net.7 / net.6 input gradient; net.7 has 27 channels: its padding columns / rows are zeroed here (disjoint from the scatter)
+        constexpr int R = 96 * 33;
+        float* const wg = l.wl + 4 * R;
+        if (lo) {
+            ae_stage_t<32, 32, MapConvFwd<32, 3>>(W(P_C6W), 32 * 32 * 3, l.wl, th, H);
+            ae_stage_t<32, 32, MapConvFwd<32, 3>>(W(P_C7W), 27 * 32 * 3, l.wl + R, th, H);
+            for (int i = th; i < 96 * 5; i += H) l.wl[R + (i / 5) * 33 + 27 + i % 5] = 0.f;
+            ae_stage_t<32, 32, MapConvDgrad<32, 3>>(W(P_C6W), 32 * 32 * 3, l.wl + 3 * R, th, H);
+        } else {
+            ae_load_t<38, 32>(B0, act + A_T1, th, H); ae_bn_prepare_t<32>(a, l.s1, 7, 7, nB * 38, P_BN7G, true, th, H);
+            ae_load_x_t(B4, x, th, H);
+            ae_stage_t<32, 32, MapConvDgrad<32, 3>>(W(P_C7W), 27 * 32 * 3, l.wl + 2 * R, th, H);
+            for (int i = th; i < 15 * 33; i += H) { const int r = i / 33; l.wl[2 * R + ((r / 5) * 32 + 27 + r % 5) * 33 + i % 33] = 0.f; }
+        }
+        __syncthreads();
+        ae_bn_act<38, 32>(l.s1, B1, B0, 0.2f);                                                    // B1 = y(T1): net.6's input
         ae_conv<38, 32, 36, 36, 32, 3, 1, 0>(B1, l.wl, W(P_C6B), 32, B2);                         // B2 = c6
-        ae_stage<32, 32, MapConvFwd<32, 3>>(W(P_C7W), 27 * 32 * 3, l.wl, 3 * 32, true);
-        ae_conv<36, 32, 36, 34, 32, 3, 1, 0>(B2, l.wl, W(P_C7B), 27, B3);                         // B3 = recon [34][32 + 4], channels 27..31 zero
+        ae_conv<36, 32, 36, 34, 32, 3, 1, 0>(B2, l.wl + R, W(P_C7B), 27, B3);                     // B3 = recon [34][32 + 4], channels 27..31 zero
         if (a.recon != nullptr)
             for (int i = threadIdx.x; i < 34 * 27; i += AE_NT) a.recon[(size_t)clip * 918 + i] = B3[(i / 27) * 36 + i % 27];
-        ae_load_x(B4, x);
         for (int i = threadIdx.x; i < 34 * 32; i += AE_NT) { const int o = (i >> 5) * 36 + (i & 31); B4[o] = B3[o] - B4[o]; }      // e = recon - target
         __syncthreads();
         {   // L1 + L1 of the frame differences, mean over (frame, joint) per clip, summed over the batch (:63-72)
@@ -562,66 +610,65 @@ __global__ __launch_bounds__(AE_NT) void ae_phase_kernel(const AeArgs a) {
             }
             __syncthreads();
         }
-        // net.7: weight / bias gradient, input gradient
-        ae_wgrad<36, 32, 36, 34, 32, 3, 1, 0>(B2, B3, l.wl);
-        ae_unstage<32, 32, MapConvFwd<32, 3>>(part + Q_C7W, 27 * 32 * 3, l.wl);
-        ae_bias_grad<34, 32>(B3, part + Q_C7B, 28);
-        ae_stage<32, 32, MapConvDgrad<32, 3>>(W(P_C7W), 27 * 32 * 3, l.wl, 3 * 32, true);
-        ae_conv<34, 32, 36, 36, 32, 3, 1, 2>(B3, l.wl, nullptr, 0, B4);                           // B4 = d c6
-        // net.6
-        ae_wgrad<38, 32, 36, 36, 32, 3, 1, 0>(B1, B4, l.wl);
-        ae_unstage<32, 32, MapConvFwd<32, 3>>(part + Q_C6W, 32 * 32 * 3, l.wl);
-        ae_bias_grad<36, 32>(B4, part + Q_C6B, 32);
-        ae_stage<32, 32, MapConvDgrad<32, 3>>(W(P_C6W), 32 * 32 * 3, l.wl, 0, false);
-        ae_conv<36, 32, 36, 38, 32, 3, 1, 2>(B4, l.wl, nullptr, 0, B2);                           // B2 = d y(T1)
-        ae_act_bwd<38, 32>(l, B2, B0, 0.2f);
-        ae_store<38, 32>(act + A_G, B2);
-        ae_chan_sums<38, 32, true>(l, B2, B0, slot(8));
+        // input gradients first: net.7 -> d c6 (B4), net.6 -> d y(T1) (B5)
+        ae_conv<34, 32, 36, 36, 32, 3, 1, 2>(B3, l.wl + 2 * R, nullptr, 0, B4);
+        ae_conv<36, 32, 36, 38, 32, 3, 1, 2>(B4, l.wl + 3 * R, nullptr, 0, B5);
+        ae_act_bwd<38, 32>(l.s1, B5, B0, 0.2f);
+        ae_store<38, 32>(act + A_G, B5);
+        ae_chan_sums<38, 32, true>(l, l.s1, B5, B0, slot(8));
+        // weight / bias gradients
+        ae_wgrad<36, 32, 36, 34, 32, 3, 1, 0>(B2, B3, wg);
+        ae_bias_out<96, 32>(wg, part + Q_C7B, 28);
+        ae_unstage<32, 32, MapConvFwd<32, 3>>(part + Q_C7W, 27 * 32 * 3, wg);
+        ae_wgrad<38, 32, 36, 36, 32, 3, 1, 0>(B1, B4, wg);
+        ae_bias_out<96, 32>(wg, part + Q_C6B, 32);
+        ae_unstage<32, 32, MapConvFwd<32, 3>>(part + Q_C6W, 32 * 32 * 3, wg);
     } else if constexpr (PH == 10) {            // BN7 backward -> net.3 (transposed conv) -> BN6's output gradient
-        ae_load<38, 32>(B0, act + A_G);
-        ae_load<38, 32>(B1, act + A_T1);
-        ae_bn_prepare<32>(a, l, 7, 7, nB * 38, P_BN7G, false);
-        ae_bwd_means<32>(a, l, 8, nB * 38);
-        ae_bn_bwd<38, 32>(l, B0, B1);                                                             // B0 = d t1
-        ae_load<36, 32>(B2, act + A_T0);
-        ae_bn_prepare<32>(a, l, 6, 6, nB * 36, P_BN6G, false);
-        ae_bn_act<36, 32>(l, B3, B2, 0.2f);                                                       // B3 = y(T0): the layer's input
-        ae_wgrad<36, 32, 36, 38, 32, 3, 1, 2>(B3, B0, l.wl);
-        ae_unstage<32, 32, MapConvTFwd<32, 3>>(part + Q_T1W, 32 * 32 * 3, l.wl);
-        ae_bias_grad<38, 32>(B0, part + Q_T1B, 32);
-        ae_stage<32, 32, MapConvTDgrad<32, 3>>(W(P_T1W), 32 * 32 * 3, l.wl, 0, false);
+        if (lo) ae_stage_t<32, 32, MapConvTDgrad<32, 3>>(W(P_T1W), 32 * 32 * 3, l.wl, th, H);
+        else {
+            ae_load_t<38, 32>(B0, act + A_G, th, H); ae_load_t<38, 32>(B1, act + A_T1, th, H); ae_load_t<36, 32>(B2, act + A_T0, th, H);
+            ae_bn_prepare_t<32>(a, l.s1, 7, 7, nB * 38, P_BN7G, false, th, H); ae_bwd_means_t<32>(a, l, 8, nB * 38, th, H);
+            ae_bn_prepare_t<32>(a, l.s2, 6, 6, nB * 36, P_BN6G, false, th, H);
+        }
+        __syncthreads();
+        ae_bn_bwd<38, 32>(l, l.s1, B0, B1);                                                       // B0 = d t1
         ae_conv<38, 32, 36, 36, 32, 3, 1, 0>(B0, l.wl, nullptr, 0, B4);                           // B4 = d y(T0)
-        ae_act_bwd<36, 32>(l, B4, B2, 0.2f);
+        ae_act_bwd<36, 32>(l.s2, B4, B2, 0.2f);
         ae_store<36, 32>(act + A_G, B4);
-        ae_chan_sums<36, 32, true>(l, B4, B2, slot(9));
+        ae_chan_sums<36, 32, true>(l, l.s2, B4, B2, slot(9));
+        ae_bn_act<36, 32>(l.s2, B3, B2, 0.2f);                                                    // B3 = y(T0): the layer's input
+        ae_wgrad<36, 32, 36, 38, 32, 3, 1, 2>(B3, B0, l.wl);
+        ae_bias_out<96, 32>(l.wl, part + Q_T1B, 32);
+        ae_unstage<32, 32, MapConvTFwd<32, 3>>(part + Q_T1W, 32 * 32 * 3, l.wl);
     } else if constexpr (PH == 11) {            // BN6 backward -> net.0 (transposed conv) -> pre_net.3 -> BN5's output gradient
-        ae_load<36, 32>(B0, act + A_G);
-        ae_load<36, 32>(B1, act + A_T0);
-        ae_bn_prepare<32>(a, l, 6, 6, nB * 36, P_BN6G, false);
-        ae_bwd_means<32>(a, l, 9, nB * 36);
-        ae_bn_bwd<36, 32>(l, B0, B1);                                                             // B0 = d t0
-        ae_load<1, 136>(B2, act + A_P3);
-        for (int i = threadIdx.x; i < 136; i += AE_NT) B3[i] = B2[(i & 3) * 34 + (i >> 2)];       // x0[l][c]
+        if (lo) ae_stage_t<32, 4, MapConvTDgrad<32, 3>>(W(P_T0W), 4 * 32 * 3, l.wl, th, H);
+        else {
+            ae_load_t<36, 32>(B0, act + A_G, th, H); ae_load_t<36, 32>(B1, act + A_T0, th, H); ae_load_t<1, 136>(B2, act + A_P3, th, H);
+            ae_load_t<1, 64>(B5, act + A_P0, th, H);
+            ae_bn_prepare_t<32>(a, l.s1, 6, 6, nB * 36, P_BN6G, false, th, H); ae_bwd_means_t<32>(a, l, 9, nB * 36, th, H);
+            ae_bn_prepare_t<64>(a, l.s2, 5, 5, nB, P_BN5G, false, th, H);
+        }
         __syncthreads();
-        ae_wgrad<34, 4, 4, 36, 32, 3, 1, 2>(B3, B0, l.wl);
-        ae_unstage<4, 32, MapConvTFwd<32, 3>>(part + Q_T0W, 4 * 32 * 3, l.wl);
-        ae_bias_grad<36, 32>(B0, part + Q_T0B, 32);
-        ae_stage<32, 4, MapConvTDgrad<32, 3>>(W(P_T0W), 4 * 32 * 3, l.wl, 0, false);
+        ae_bn_bwd<36, 32>(l, l.s1, B0, B1);                                                       // B0 = d t0
+        for (int i = threadIdx.x; i < 136; i += AE_NT) B3[i] = B2[(i & 3) * 34 + (i >> 2)];       // x0[l][c] (the weight gradient's input, below)
         ae_conv_n4<36, 32, 36, 34, 3>(B0, l.wl, B4);                                              // B4 = d x0 [34][4]
-        for (int i = threadIdx.x; i < 136; i += AE_NT) B2[i] = B4[(i % 34) * 4 + i / 34];         // d p3[c * 34 + l]
+        for (int i = threadIdx.x; i < 136; i += AE_NT) B1[i] = B4[(i % 34) * 4 + i / 34];         // d p3[c * 34 + l]
         __syncthreads();
-        ae_store<1, 136>(act + A_DP3, B2);
-        ae_fc_dgrad<64, 136>(W(P_D1W), B2, B3, B4);                                               // B3 = d yp = g (slope 1)
-        ae_store<1, 64>(act + A_G, B3);
-        ae_load<1, 64>(B1, act + A_P0);
-        ae_bn_prepare<64>(a, l, 5, 5, nB, P_BN5G, false);
-        ae_chan_sums<1, 64, true>(l, B3, B1, slot(10));
+        ae_store<1, 136>(act + A_DP3, B1);
+        ae_fc_dgrad<64, 136>(W(P_D1W), B1, B4, l.wl);                                             // B4 = d yp = g (slope 1); scratch: the staged weights are done
+        ae_store<1, 64>(act + A_G, B4);
+        ae_chan_sums<1, 64, true>(l, l.s2, B4, B5, slot(10));
+        ae_wgrad<34, 4, 4, 36, 32, 3, 1, 2>(B3, B0, l.wl);
+        ae_bias_out<12, 32>(l.wl, part + Q_T0B, 32);
+        ae_unstage<4, 32, MapConvTFwd<32, 3>>(part + Q_T0W, 4 * 32 * 3, l.wl);
     } else if constexpr (PH == 12) {            // BN5 backward -> pre_net.0 -> fc_mu -> out_net.6 -> BN4's output gradient
-        ae_load<1, 64>(B0, act + A_G);
-        ae_load<1, 64>(B1, act + A_P0);
-        ae_bn_prepare<64>(a, l, 5, 5, nB, P_BN5G, false);
-        ae_bwd_means<64>(a, l, 10, nB);
-        ae_bn_bwd<1, 64>(l, B0, B1);                                                              // B0 = d p0
+        if (lo) { ae_load_t<1, 64>(B0, act + A_G, th, H); ae_load_t<1, 64>(B1, act + A_P0, th, H); ae_load_t<1, 128>(B5, act + A_F2, th, H); }
+        else {
+            ae_bn_prepare_t<64>(a, l.s1, 5, 5, nB, P_BN5G, false, th, H); ae_bwd_means_t<64>(a, l, 10, nB, th, H);
+            ae_bn_prepare_t<128>(a, l.s2, 4, 4, nB, P_BN4G, false, th, H);
+        }
+        __syncthreads();
+        ae_bn_bwd<1, 64>(l, l.s1, B0, B1);                                                        // B0 = d p0
         ae_store<1, 64>(act + A_DP0, B0);
         ae_fc_dgrad<32, 64>(W(P_D0W), B0, B2, B4);                                                // B2 = d mu
         ae_store<1, 32>(act + A_DMU, B2);
@@ -629,89 +676,85 @@ __global__ __launch_bounds__(AE_NT) void ae_phase_kernel(const AeArgs a) {
         ae_store<1, 32>(act + A_DF3, B3);
         ae_fc_dgrad<128, 32>(W(P_F3W), B3, B0, B4);                                               // B0 = d y2f = g
         ae_store<1, 128>(act + A_G, B0);
-        ae_load<1, 128>(B1, act + A_F2);
-        ae_bn_prepare<128>(a, l, 4, 4, nB, P_BN4G, false);
-        ae_chan_sums<1, 128, true>(l, B0, B1, slot(11));
+        ae_chan_sums<1, 128, true>(l, l.s2, B0, B5, slot(11));
     } else if constexpr (PH == 13) {            // BN4 backward -> out_net.3 -> BN3's output gradient
-        ae_load<1, 128>(B0, act + A_G);
-        ae_load<1, 128>(B1, act + A_F2);
-        ae_bn_prepare<128>(a, l, 4, 4, nB, P_BN4G, false);
-        ae_bwd_means<128>(a, l, 11, nB);
-        ae_bn_bwd<1, 128>(l, B0, B1);                                                             // B0 = d f2
+        if (lo) { ae_load_t<1, 128>(B0, act + A_G, th, H); ae_load_t<1, 128>(B1, act + A_F2, th, H); ae_load_t<1, 256>(B5, act + A_F1, th, H); }
+        else {
+            ae_bn_prepare_t<128>(a, l.s1, 4, 4, nB, P_BN4G, false, th, H); ae_bwd_means_t<128>(a, l, 11, nB, th, H);
+            ae_bn_prepare_t<256>(a, l.s2, 3, 3, nB, P_BN3G, false, th, H);
+        }
+        __syncthreads();
+        ae_bn_bwd<1, 128>(l, l.s1, B0, B1);                                                       // B0 = d f2
         ae_store<1, 128>(act + A_DF2, B0);
         ae_fc_dgrad<256, 128>(W(P_F2W), B0, B2, B4);                                              // B2 = d y1f = g
         ae_store<1, 256>(act + A_G, B2);
-        ae_load<1, 256>(B1, act + A_F1);
-        ae_bn_prepare<256>(a, l, 3, 3, nB, P_BN3G, false);
-        ae_chan_sums<1, 256, true>(l, B2, B1, slot(12));
+        ae_chan_sums<1, 256, true>(l, l.s2, B2, B5, slot(12));
     } else if constexpr (PH == 14) {            // BN3 backward -> out_net.0 -> un-flatten -> net.3 conv -> BN2's output gradient
-        ae_load<1, 256>(B0, act + A_G);
-        ae_load<1, 256>(B1, act + A_F1);
-        ae_bn_prepare<256>(a, l, 3, 3, nB, P_BN3G, false);
-        ae_bwd_means<256>(a, l, 12, nB);
-        ae_bn_bwd<1, 256>(l, B0, B1);                                                             // B0 = d f1
+        if (lo) ae_stage_t<32, 64, MapConvDgrad<64, 3>>(W(P_E3W), 32 * 64 * 3, l.wl, th, H);
+        else {
+            ae_load_t<1, 256>(B0, act + A_G, th, H); ae_load_t<1, 256>(B1, act + A_F1, th, H); ae_load_t<14, 64>(B5, act + A_C2, th, H);
+            ae_bn_prepare_t<256>(a, l.s1, 3, 3, nB, P_BN3G, false, th, H); ae_bwd_means_t<256>(a, l, 12, nB, th, H);
+            ae_bn_prepare_t<64>(a, l.s2, 2, 2, nB * 14, P_BN2G, false, th, H);
+        }
+        __syncthreads();
+        ae_bn_bwd<1, 256>(l, l.s1, B0, B1);                                                       // B0 = d f1
         ae_store<1, 256>(act + A_DF1, B0);
         ae_fc_dgrad<384, 256>(W(P_F1W), B0, B2, B4);                                              // B2 = d flat
         for (int i = threadIdx.x; i < 384; i += AE_NT) B3[(i >> 5) * 36 + (i & 31)] = B2[(i & 31) * 12 + (i >> 5)];      // d c4[l][c] = d flat[c * 12 + l]
         __syncthreads();
-        ae_load<14, 64>(B0, act + A_C2);
-        ae_bn_prepare<64>(a, l, 2, 2, nB * 14, P_BN2G, false);
-        ae_bn_act<14, 64>(l, B1, B0, 0.2f);                                                       // B1 = y2
-        ae_wgrad<14, 64, 68, 12, 32, 3, 1, 0>(B1, B3, l.wl);
-        ae_unstage<64, 32, MapConvFwd<64, 3>>(part + Q_E3W, 32 * 64 * 3, l.wl);
-        ae_bias_grad<12, 32>(B3, part + Q_E3B, 32);
-        ae_stage<32, 64, MapConvDgrad<64, 3>>(W(P_E3W), 32 * 64 * 3, l.wl, 0, false);
         ae_conv<12, 32, 36, 14, 64, 3, 1, 2>(B3, l.wl, nullptr, 0, B4);                           // B4 = d y2
-        ae_act_bwd<14, 64>(l, B4, B0, 0.2f);
+        ae_act_bwd<14, 64>(l.s2, B4, B5, 0.2f);
         ae_store<14, 64>(act + A_G, B4);
-        ae_chan_sums<14, 64, true>(l, B4, B0, slot(13));
+        ae_chan_sums<14, 64, true>(l, l.s2, B4, B5, slot(13));
+        ae_bn_act<14, 64>(l.s2, B1, B5, 0.2f);                                                    // B1 = y2
+        ae_wgrad<14, 64, 68, 12, 32, 3, 1, 0>(B1, B3, l.wl);
+        ae_bias_out<192, 32>(l.wl, part + Q_E3B, 32);
+        ae_unstage<64, 32, MapConvFwd<64, 3>>(part + Q_E3W, 32 * 64 * 3, l.wl);
     } else if constexpr (PH == 15) {            // BN2 backward -> net.2 conv (stride 2) -> BN1's output gradient
-        ae_load<14, 64>(B0, act + A_G);
-        ae_load<14, 64>(B1, act + A_C2);
-        ae_bn_prepare<64>(a, l, 2, 2, nB * 14, P_BN2G, false);
-        ae_bwd_means<64>(a, l, 13, nB * 14);
-        ae_bn_bwd<14, 64>(l, B0, B1);                                                             // B0 = d c2
-        ae_load<30, 64>(B2, act + A_C1);
-        ae_bn_prepare<64>(a, l, 1, 1, nB * 30, P_BN1G, false);
-        ae_bn_act<30, 64>(l, B3, B2, 0.2f);                                                       // B3 = y1
-        ae_wgrad<30, 64, 68, 14, 64, 4, 2, 0>(B3, B0, l.wl);
-        ae_unstage<64, 64, MapConvFwd<64, 4>>(part + Q_E2W, 64 * 64 * 4, l.wl);
-        ae_bias_grad<14, 64>(B0, part + Q_E2B, 64);
-        // input gradient of the stride-2 conv as a stride-1 transposed conv over d c2 with a zero row between its rows
-        for (int i = threadIdx.x; i < 27 * 64; i += AE_NT) { const int r = i >> 6, c = i & 63; B4[r * 68 + c] = (r & 1) ? 0.f : B0[(r >> 1) * 68 + c]; }
+        if (lo) ae_stage_t<64, 64, MapConvDgrad<64, 4>>(W(P_E2W), 64 * 64 * 4, l.wl, th, H);
+        else {
+            ae_load_t<14, 64>(B0, act + A_G, th, H); ae_load_t<14, 64>(B1, act + A_C2, th, H); ae_load_t<30, 64>(B2, act + A_C1, th, H);
+            ae_bn_prepare_t<64>(a, l.s1, 2, 2, nB * 14, P_BN2G, false, th, H); ae_bwd_means_t<64>(a, l, 13, nB * 14, th, H);
+            ae_bn_prepare_t<64>(a, l.s2, 1, 1, nB * 30, P_BN1G, false, th, H);
+        }
         __syncthreads();
-        ae_stage<64, 64, MapConvDgrad<64, 4>>(W(P_E2W), 64 * 64 * 4, l.wl, 0, false);
-        ae_conv<27, 64, 68, 30, 64, 4, 1, 3>(B4, l.wl, nullptr, 0, B1);                           // B1 = d y1
-        ae_act_bwd<30, 64>(l, B1, B2, 0.2f);
-        ae_store<30, 64>(act + A_G, B1);
-        ae_chan_sums<30, 64, true>(l, B1, B2, slot(14));
+        ae_bn_bwd<14, 64>(l, l.s1, B0, B1);                                                       // B0 = d c2
+        // input gradient of the stride-2 conv as a stride-1 transposed conv over d c2 with a zero row between its rows
+        for (int i = threadIdx.x; i < 27 * 64; i += AE_NT) { const int r = i >> 6, c = i & 63; B5[r * 68 + c] = (r & 1) ? 0.f : B0[(r >> 1) * 68 + c]; }
+        __syncthreads();
+        ae_conv<27, 64, 68, 30, 64, 4, 1, 3>(B5, l.wl, nullptr, 0, B4);                           // B4 = d y1
+        ae_act_bwd<30, 64>(l.s2, B4, B2, 0.2f);
+        ae_store<30, 64>(act + A_G, B4);
+        ae_chan_sums<30, 64, true>(l, l.s2, B4, B2, slot(14));
+        ae_bn_act<30, 64>(l.s2, B3, B2, 0.2f);                                                    // B3 = y1
+        ae_wgrad<30, 64, 68, 14, 64, 4, 2, 0>(B3, B0, l.wl);
+        ae_bias_out<256, 64>(l.wl, part + Q_E2B, 64);
+        ae_unstage<64, 64, MapConvFwd<64, 4>>(part + Q_E2W, 64 * 64 * 4, l.wl);
     } else if constexpr (PH == 16) {            // BN1 backward -> net.1 conv -> BN0's output gradient
-        ae_load<30, 64>(B0, act + A_G);
-        ae_load<30, 64>(B1, act + A_C1);
-        ae_bn_prepare<64>(a, l, 1, 1, nB * 30, P_BN1G, false);
-        ae_bwd_means<64>(a, l, 14, nB * 30);
-        ae_bn_bwd<30, 64>(l, B0, B1);                                                             // B0 = d c1
-        ae_load<32, 32>(B2, act + A_C0);
-        ae_bn_prepare<32>(a, l, 0, 0, nB * 32, P_BN0G, false);
-        ae_bn_act<32, 32>(l, B3, B2, 0.2f);                                                       // B3 = y0
-        ae_wgrad<32, 32, 36, 30, 64, 3, 1, 0>(B3, B0, l.wl);
-        ae_unstage<32, 64, MapConvFwd<32, 3>>(part + Q_E1W, 64 * 32 * 3, l.wl);
-        ae_bias_grad<30, 64>(B0, part + Q_E1B, 64);
-        ae_stage<64, 32, MapConvDgrad<32, 3>>(W(P_E1W), 64 * 32 * 3, l.wl, 0, false);
+        if (lo) ae_stage_t<64, 32, MapConvDgrad<32, 3>>(W(P_E1W), 64 * 32 * 3, l.wl, th, H);
+        else {
+            ae_load_t<30, 64>(B0, act + A_G, th, H); ae_load_t<30, 64>(B1, act + A_C1, th, H); ae_load_t<32, 32>(B2, act + A_C0, th, H);
+            ae_bn_prepare_t<64>(a, l.s1, 1, 1, nB * 30, P_BN1G, false, th, H); ae_bwd_means_t<64>(a, l, 14, nB * 30, th, H);
+            ae_bn_prepare_t<32>(a, l.s2, 0, 0, nB * 32, P_BN0G, false, th, H);
+        }
+        __syncthreads();
+        ae_bn_bwd<30, 64>(l, l.s1, B0, B1);                                                       // B0 = d c1
         ae_conv<30, 64, 68, 32, 32, 3, 1, 2>(B0, l.wl, nullptr, 0, B4);                           // B4 = d y0
-        ae_act_bwd<32, 32>(l, B4, B2, 0.2f);
+        ae_act_bwd<32, 32>(l.s2, B4, B2, 0.2f);
         ae_store<32, 32>(act + A_G, B4);
-        ae_chan_sums<32, 32, true>(l, B4, B2, slot(15));
+        ae_chan_sums<32, 32, true>(l, l.s2, B4, B2, slot(15));
+        ae_bn_act<32, 32>(l.s2, B3, B2, 0.2f);                                                    // B3 = y0
+        ae_wgrad<32, 32, 36, 30, 64, 3, 1, 0>(B3, B0, l.wl);
+        ae_bias_out<96, 64>(l.wl, part + Q_E1B, 64);
+        ae_unstage<32, 64, MapConvFwd<32, 3>>(part + Q_E1W, 64 * 32 * 3, l.wl);
     } else if constexpr (PH == 17) {            // BN0 backward -> net.0 conv weight gradient
-        ae_load<32, 32>(B0, act + A_G);
-        ae_load<32, 32>(B1, act + A_C0);
-        ae_bn_prepare<32>(a, l, 0, 0, nB * 32, P_BN0G, false);
-        ae_bwd_means<32>(a, l, 15, nB * 32);
-        ae_bn_bwd<32, 32>(l, B0, B1);                                                             // B0 = d c0
-        ae_load_x(B2, x);
+        if (lo) { ae_load_t<32, 32>(B0, act + A_G, th, H); ae_load_t<32, 32>(B1, act + A_C0, th, H); }
+        else { ae_load_x_t(B2, x, th, H); ae_bn_prepare_t<32>(a, l.s1, 0, 0, nB * 32, P_BN0G, false, th, H); ae_bwd_means_t<32>(a, l, 15, nB * 32, th, H); }
+        __syncthreads();
+        ae_bn_bwd<32, 32>(l, l.s1, B0, B1);                                                       // B0 = d c0
         ae_wgrad<34, 28, 36, 32, 32, 3, 1, 0>(B2, B0, l.wl);
+        ae_bias_out<84, 32>(l.wl, part + Q_E0B, 32);
         ae_unstage<28, 32, MapConvFwd<27, 3>>(part + Q_E0W, 32 * 27 * 3, l.wl);
-        ae_bias_grad<32, 32>(B0, part + Q_E0B, 32);
     }
 }
 
@@ -721,7 +764,7 @@ __constant__ AeFcLayer ae_fc_layers[6] = {
     {P_F1W, 256, 384, A_FLAT, A_DF1, 0, 6},   {P_F2W, 128, 256, A_Y1F, A_DF2, 192, 4}, {P_F3W, 32, 128, A_Y2F, A_DF3, 256, 2},
     {P_MUW, 32, 32, A_F3, A_DMU, 264, 1},     {P_D0W, 64, 32, A_MU, A_DP0, 268, 1},    {P_D1W, 136, 64, A_YP, A_DP3, 276, 1}};
 constexpr int AE_FC_UNITS = 293;
-constexpr int AE_RED_UNITS = (AE_PART / 4 + 511) / 512;       // 20
+constexpr int AE_RED_UNITS = (AE_PART / 4 + 63) / 64;         // 159: 64 16-byte pieces per workgroup, eight batch slices each
 constexpr int AE_TAIL_UNITS = AE_FC_UNITS + AE_RED_UNITS + 1;
 __constant__ int ae_seg_begin[17] = {Q_E0W, Q_E0B, Q_E1W, Q_E1B, Q_E2W, Q_E2B, Q_E3W, Q_E3B, Q_T0W, Q_T0B, Q_T1W, Q_T1B, Q_C6W, Q_C6B, Q_C7W, Q_C7B, AE_PART};
 __constant__ int ae_seg_param[16] = {P_E0W, P_E0B, P_E1W, P_E1B, P_E2W, P_E2B, P_E3W, P_E3B, P_T0W, P_T0B, P_T1W, P_T1B, P_C6W, P_C6B, P_C7W, P_C7B};
@@ -761,18 +804,29 @@ __global__ __launch_bounds__(AE_TAIL_NT) void ae_tail_kernel(const AeArgs a) {
             a.G[a.off[L.pw + 1] + n0 + t] = s;
         }
     } else if (u < AE_FC_UNITS + AE_RED_UNITS) {
-        // conv weight / bias gradients: the per-clip partials summed in clip order
-        const int i4 = (u - AE_FC_UNITS) * AE_TAIL_NT + t;
+        // conv weight / bias gradients: the per-clip partials summed over the batch -- thread = (16-byte piece, one of eight batch slices), slices
+        // combined in slice order through LDS (a fixed order: no atomics)
+        const int pc = t & 63, sl = t >> 6;
+        const int i4 = (u - AE_FC_UNITS) * 64 + pc;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (i4 < AE_PART / 4) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-            for (int b = 0; b < B; ++b) {
+            const int per = (B + 7) / 8, b0 = sl * per, b1 = b0 + per < B ? b0 + per : B;
+#pragma unroll 16
+            for (int b = b0; b < b1; ++b) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(a.part + (size_t)b * AE_PART + 4 * i4);
                 acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
             }
-            int s = 0;
-            while (4 * i4 >= ae_seg_begin[s + 1]) ++s;
-            *reinterpret_cast<f32x4*>(a.G + a.off[ae_seg_param[s]] + (4 * i4 - ae_seg_begin[s])) = acc;
+        }
+        *reinterpret_cast<f32x4*>(xs + (sl * 64 + pc) * 4) = acc;
+        __syncthreads();
+        if (sl == 0 && i4 < AE_PART / 4) {
+            for (int q = 1; q < 8; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xs + (q * 64 + pc) * 4);
+                acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+            }
+            int sg = 0;
+            while (4 * i4 >= ae_seg_begin[sg + 1]) ++sg;
+            *reinterpret_cast<f32x4*>(a.G + a.off[ae_seg_param[sg]] + (4 * i4 - ae_seg_begin[sg])) = acc;
         }
     } else {
         // BatchNorm gamma / beta gradients = the backward sums (slot 15 - bn: sum g * xhat, sum g); loss; Adam step counter; sums back to zero

@@ -1,6 +1,6 @@
 """One training iteration as an ordered kernel timeline, from a rocprofv3 --kernel-trace CSV.
 
-usage: iter_timeline.py <rocprof dir> <out.txt> [marker kernel = iter_head_kernel] [iteration index from the end = 3]
+usage: iter_timeline.py <rocprof dir> <out.txt> [marker kernel = iter_head_kernel] [iteration index from the end = 3] [min ns between markers = 1000000]
 
 The iteration boundaries are the launches of the marker kernel that opens every iteration (the generator's RNG advance).  For the
 chosen iteration prints every launch in start order: start offset, duration, gap to the previous kernel's end, name, grid; then
@@ -14,6 +14,7 @@ from collections import defaultdict
 d, out = sys.argv[1], sys.argv[2]
 marker = sys.argv[3] if len(sys.argv) > 3 else "iter_head_kernel"
 back = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+min_gap = int(sys.argv[5]) if len(sys.argv) > 5 else 1_000_000
 rows = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -24,7 +25,7 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
 rows.sort()
 marks = [i for i, r in enumerate(rows) if r[2].startswith(marker)]
 # the generator and the discriminator each advance their RNG at the top of an iteration: keep the first of each close pair
-starts = [m for j, m in enumerate(marks) if j == 0 or rows[m][0] - rows[marks[j - 1]][0] > 1_000_000]
+starts = [m for j, m in enumerate(marks) if j == 0 or rows[m][0] - rows[marks[j - 1]][0] > min_gap]
 assert len(starts) > back + 1, (len(marks), len(starts))
 lo, hi = starts[-back - 1], starts[-back]
 it = rows[lo:hi]
