@@ -127,13 +127,34 @@ def evaluate_testset(test_data_loader, generator):
     return {"loss": s / n}
 
 
+def _ae_plan(net, target):
+    """The fused step's plan (ops.AeStep: argument block + workspace) for this network and batch size, cached on its engine; None where the
+    fused step does not apply (other shapes, CPU tensors)."""
+    E = net.engine
+    slab = E.slab.ensure()
+    B = target.shape[0]
+    if not target.is_cuda or not ops.AeStep.supported(slab, B, target.shape):
+        return None
+    p = getattr(E, "_ae_plan", None)
+    if p is None or p.slab_ptr != slab.flat.data_ptr() or p.B != B:
+        assert not torch.cuda.is_current_stream_capturing(), "run one eager step before capturing (the plan allocates its workspace)"
+        slab.zero_grad()                 # fc_logvar gets no gradient (:58): its slots stay zero, every other one is written by each step
+        p = E._ae_plan = ops.AeStep(slab, dict(net.named_buffers()), B)
+    return p
+
+
 def train_iter(args, epoch, target_data, net, optim):
     """scripts/train_feature_extractor.py:54-97 with variational_encoding=False; `optim` is a FusedAdam over `net`."""
     E = net.engine
-    E.slab.ensure().zero_grad()
     target = target_data.float().contiguous()
-    res = E.forward(target, training=True, save=True)
     loss = torch.empty(1, device=target.device)
+    plan = _ae_plan(net, target)
+    if plan is not None:                 # 18 launches + Adam (csrc/ae_step.hip)
+        plan.run(target, loss)
+        optim.step(counter_advanced=True)
+        return {"loss": float(loss)}
+    E.slab.ensure().zero_grad()
+    res = E.forward(target, training=True, save=True)
     d_recon = torch.empty_like(target)
     ops.ae_loss(res["recon"], target, loss, d_recon)
     E.backward(res["tape"], d_recon)
@@ -155,18 +176,11 @@ class AutoencoderTrainer:
         self.last = {}
 
     def _fused_plan(self, target):
-        slab = self.E.slab.ensure()
-        B = target.shape[0]
-        if self.fused is False or not target.is_cuda or not ops.AeStep.supported(slab, B, target.shape):
-            if self.fused:
-                raise RuntimeError(f"fused autoencoder step: unsupported batch / shapes {tuple(target.shape)}")
-            return None
-        p = self._plan
-        if p is None or p.slab_ptr != slab.flat.data_ptr() or p.B != B:
-            assert not torch.cuda.is_current_stream_capturing(), "run one eager step before capturing (the plan allocates its workspace)"
-            slab.zero_grad()                 # fc_logvar gets no gradient (:58): its slots stay zero, every other one is written by each step
-            p = self._plan = ops.AeStep(slab, dict(self.net.named_buffers()), B)
-        return p
+        plan = None if self.fused is False else _ae_plan(self.net, target)
+        if plan is None and self.fused:
+            raise RuntimeError(f"fused autoencoder step: unsupported batch / shapes {tuple(target.shape)}")
+        self._plan = plan
+        return plan
 
     def train_iter(self, target, keep_outputs=False):
         E = self.E

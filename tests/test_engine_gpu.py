@@ -536,6 +536,10 @@ def test_fused_autoencoder_step_matches_layer_engine_and_oracle(pkg, dev, B):
             real = (g1[k].abs() > 1e-2 * g1[k].abs().max()) & (Ge2[k].abs() > 1e-2 * Ge2[k].abs().max())
             assert bool(real.any()), k
             assert float((sf[k] - se[k])[real].abs().max()) <= 0.1 * 5e-4, (k, float((sf[k] - se[k])[real].abs().max()) / 5e-4)
+    # the reference's function form (train_feature_extractor.py:54 train_iter(args, epoch, target_data, net, optim)) rides the same plan
+    r3 = fgd.train_iter(make_args(), 0, poses[0], nets[0], trs[0].opt)
+    l3e = trs[1].train_iter(poses[0])
+    assert abs(r3["loss"] - l3e.item()) < 1e-3 * abs(l3e.item()) and int(nets[0].engine.slab.step) == int(nets[1].engine.slab.step) == 3
 
 
 def test_graphed_step_equals_eager(pkg, dev):
