@@ -255,7 +255,7 @@ def dominant_kernel_roofline(pkg, device, batch):
     dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, sv, save_rows=(batch, batch)), iters=20)      # as the trainer calls it (gates saved for call g2 only)
     ops.check_async_errors()
     flops = (T - 1) * 2 * Bs * H * 3 * H * 2
-    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape and call (profiles/r3_pmc_gru_fwd_cluster_x3.txt, re-measured on the round-3 build; tools/r3_pmc.sh):
+    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape and call (profiles/r4_pmc_gru_fwd_cluster_x3.txt, re-measured on the round-4 build; tools/r4_pmc.sh):
     # 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE.  Only valid for batch 128 (B_s = 384).
     traffic = PMC_TRAFFIC_GRU_FWD if batch == 128 else None
     if ops.get_math_mode() == "bf16":          # secondary tier: one bf16 MFMA per product -> price against the dense bf16 peak
@@ -272,7 +272,7 @@ def dominant_kernel_roofline(pkg, device, batch):
                     "(peak_bf16x3 = dense bf16 MFMA peak / 6, the ceiling of this arithmetic)"}
 
 
-PMC_TRAFFIC_GRU_FWD = 287.5e6      # bytes per launch: (2 x FETCH_SIZE 79 853 KB + WRITE_SIZE 121 030 KB) x 1024, profiles/r3_pmc_gru_fwd_cluster_x3.txt (round-3 build; gates saved for call g2 only)
+PMC_TRAFFIC_GRU_FWD = 197.7e6      # bytes per launch: (2 x FETCH_SIZE 56 353 KB + WRITE_SIZE 80 397 KB) x 1024, profiles/r4_pmc_gru_fwd_cluster_x3.txt (round-4 build: the same-XCD hand-off keeps its lines in L2; round 3: 287.5 MB; gates saved for call g2 only)
 
 
 def hbm_kernel_roofline(pkg, device):
