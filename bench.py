@@ -417,13 +417,13 @@ def ae_bench(pkg, a, args, device, world, rank):
             extra["cpu_baseline"] = cpu_baseline_ae(a.batch)
         line = (json.dumps({
             **extra,
-            # 1.04 M MAC per clip forward, twice that backward: the step is a chain of 19 dependent launches cut at the eight BatchNorms'
+            # 1.04 M MAC per clip forward, twice that backward: the step is a chain of 18 dependent launches cut at the eight BatchNorms'
             # batch statistics / gradient sums (csrc/ae_step.hip), so the figure that matters is microseconds per launch, not the fraction
-            "roofline": {"kernel": "ae_phase_kernel<1..17> + ae_tail_kernel + adam_kernel", "bound": "mfma", "achieved": 6 * 1.04e6 * a.batch / (dt / a.steps) / 1e12,
+            "roofline": {"kernel": "ae_phase_kernel<1..17> + ae_tail_kernel (Adam inside)", "bound": "mfma", "achieved": 6 * 1.04e6 * a.batch / (dt / a.steps) / 1e12,
                          "peak": 157.3, "unit": "TFLOP/s", "frac": 6 * 1.04e6 * a.batch / (dt / a.steps) / 1e12 / 157.3, "traffic": None,
                          "note": "latency bound by construction: fp32 MFMA peak as the reference ceiling; see latency"},
-            "latency": {"launches_per_step": 19 if getattr(tr, "_plan", None) is not None else None, "us_per_step": dt / a.steps * 1e6,
-                        "us_per_launch": dt / a.steps * 1e6 / 19 if getattr(tr, "_plan", None) is not None else None, "fused": getattr(tr, "_plan", None) is not None},
+            "latency": {"launches_per_step": 18 if getattr(tr, "_plan", None) is not None else None, "us_per_step": dt / a.steps * 1e6,
+                        "us_per_launch": dt / a.steps * 1e6 / 18 if getattr(tr, "_plan", None) is not None else None, "fused": getattr(tr, "_plan", None) is not None},
             "metric": "FGD autoencoder training clips/sec", "value": world * a.batch * a.steps / dt, "unit": "clips/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -39,7 +39,7 @@ class AeStepArgs(C.Structure):
     """struct tg_ae_step_args"""
     _fields_ = [("x", P), ("params", P), ("grads", P), ("off", I32 * 44), ("running_mean", P * 8), ("running_var", P * 8),
                 ("num_batches_tracked", P * 8), ("ws", P), ("ws_bytes", I64), ("loss", P), ("recon", P), ("feat", P), ("step", P), ("B", I32),
-                ("bn_eps", F32), ("momentum", F32), ("last_phase", I32)]
+                ("bn_eps", F32), ("momentum", F32), ("last_phase", I32), ("adam_m", P), ("adam_v", P), ("lr", F32), ("beta1", F32), ("beta2", F32), ("adam_eps", F32)]
 
 
 MAX_GROUP = 8

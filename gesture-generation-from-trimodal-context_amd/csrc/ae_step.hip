@@ -13,8 +13,10 @@
 // to be co-resident.
 // Phase 18 (453 workgroups, its own partition) turns the per-clip conv partials and the saved linear-layer vectors into the gradient slab:
 // linear weight gradients as (8 rows x 64 columns) tiles reduced over the batch inside one workgroup, conv partials summed over eight batch
-// slices in a fixed order, BatchNorm gamma / beta gradients straight from the backward sums; it also copies the loss, advances the Adam step
-// counter and re-zeroes the sums.  tg_adam_step then updates the slab as for every other network.  No float atomics on gradients: two runs are
+// slices in a fixed order, BatchNorm gamma / beta gradients straight from the backward sums; every thread then applies torch.optim.Adam to the
+// elements it has just finished (when the caller passes the moment slabs: the step is complete; fc_logvar has no gradient and is skipped like
+// a parameter whose .grad is None); it also copies the loss and re-zeroes the sums.  Adam's step counter advances in phase 1.  No float
+// atomics on gradients: two runs are
 // bit-identical up to the fp64 atomics of the statistics.
 //
 // Arithmetic: the conv-shaped layers and their weight gradients on v_mfma_f32_16x16x4_f32 (exact fp32 products; rows = 16 positions or 16
@@ -103,6 +105,8 @@ struct AeArgs {
     int* step;
     int B;
     float bn_eps, momentum;
+    float *M, *V;                         // Adam moments (slab images); NULL: gradients only
+    float lr, b1, b2, adam_eps;
 };
 
 struct AeBn { float *mean, *rstd, *ga, *be; };      // one BatchNorm's per-channel coefficients in LDS
@@ -480,6 +484,7 @@ __global__ __launch_bounds__(AE_NT) void ae_phase_kernel(const AeArgs a) {
     const int th = lo ? threadIdx.x : threadIdx.x - H;
 
     if constexpr (PH == 1) {                    // poses -> net.0 conv; the linear layers' weights transposed for this step's forward
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.step != nullptr) *a.step += 1;       // Adam's step counter (read by phase 18 only)
         for (int i = threadIdx.x; i < 3 * 28 * 33; i += AE_NT) l.wl[i] = 0.f;
         for (int e = blockIdx.x * AE_NT + threadIdx.x; e < AE_WT; e += gridDim.x * AE_NT) {
             int li = 0;
@@ -776,10 +781,28 @@ __constant__ int ae_bn_gamma[8] = {P_BN0G, P_BN1G, P_BN2G, P_BN3G, P_BN4G, P_BN5
 __constant__ int ae_bn_ch[8] = {32, 64, 64, 256, 128, 64, 32, 32};
 
 constexpr int AE_TAIL_NT = 512;
+// torch.optim.Adam on one element whose gradient this thread has just finished (same arithmetic as adam_kernel, elementwise.hip)
+__device__ __forceinline__ void ae_adam(const AeArgs& a, long i, float g, float step_size, float bc2s) {
+    a.G[i] = g;
+    if (a.M == nullptr) return;
+    const float m = a.M[i] + (g - a.M[i]) * (1.f - a.b1);
+    const float v = a.V[i] * a.b2 + g * g * (1.f - a.b2);
+    a.M[i] = m; a.V[i] = v;
+    a.P[i] -= step_size * m / (sqrtf(v) / bc2s + a.adam_eps);
+}
+
 __global__ __launch_bounds__(AE_TAIL_NT) void ae_tail_kernel(const AeArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[256 * 64];
     __shared__ __attribute__((aligned(16))) float ds[256 * 8];
+    __shared__ float coef[2];
     const int u = blockIdx.x, t = threadIdx.x, B = a.B;
+    if (t == 0) {                           // bias corrections in fp64 like the Python scalars torch.optim.Adam uses; the counter was advanced by phase 1
+        const double st = a.step != nullptr ? (double)*a.step : 1.0;
+        coef[0] = (float)((double)a.lr / (1.0 - pow((double)a.b1, st)));
+        coef[1] = (float)sqrt(1.0 - pow((double)a.b2, st));
+    }
+    __syncthreads();
+    const float step_size = coef[0], bc2s = coef[1];
     if (u < AE_FC_UNITS) {
         // linear layer weight gradient: rows [n0, n0 + 8) x columns [k0, k0 + 64) of dW = dy^T x, reduced over the batch here (batch order)
         int li = 0;
@@ -801,11 +824,11 @@ __global__ __launch_bounds__(AE_TAIL_NT) void ae_tail_kernel(const AeArgs a) {
         float acc = 0.f;
 #pragma unroll 4
         for (int b = 0; b < B; ++b) acc = fmaf(ds[b * 8 + r], xs[b * 64 + k], acc);
-        if (n0 + r < L.n && k0 + k < L.k) a.G[a.off[L.pw] + (size_t)(n0 + r) * L.k + k0 + k] = acc;
+        if (n0 + r < L.n && k0 + k < L.k) ae_adam(a, a.off[L.pw] + (long)(n0 + r) * L.k + k0 + k, acc, step_size, bc2s);
         if (k0 == 0 && t < 8 && n0 + t < L.n) {
             float s = 0.f;
             for (int b = 0; b < B; ++b) s += ds[b * 8 + t];
-            a.G[a.off[L.pw + 1] + n0 + t] = s;
+            ae_adam(a, a.off[L.pw + 1] + n0 + t, s, step_size, bc2s);
         }
     } else if (u < AE_FC_UNITS + AE_RED_UNITS) {
         // conv weight / bias gradients: the per-clip partials summed over the batch -- thread = (16-byte piece, one of eight batch slices), slices
@@ -830,20 +853,21 @@ __global__ __launch_bounds__(AE_TAIL_NT) void ae_tail_kernel(const AeArgs a) {
             }
             int sg = 0;
             while (4 * i4 >= ae_seg_begin[sg + 1]) ++sg;
-            *reinterpret_cast<f32x4*>(a.G + a.off[ae_seg_param[sg]] + (4 * i4 - ae_seg_begin[sg])) = acc;
+            const long o = a.off[ae_seg_param[sg]] + (4 * i4 - ae_seg_begin[sg]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ae_adam(a, o + q, acc[q], step_size, bc2s);
         }
     } else {
         // BatchNorm gamma / beta gradients = the backward sums (slot 15 - bn: sum g * xhat, sum g); loss; Adam step counter; sums back to zero
         for (int bn = 0; bn < 8; ++bn) {
             const double* s = a.sums + (size_t)(15 - bn) * 512;
             for (int c = t; c < ae_bn_ch[bn]; c += AE_TAIL_NT) {
-                a.G[a.off[ae_bn_gamma[bn]] + c] = (float)s[256 + c];
-                a.G[a.off[ae_bn_gamma[bn] + 1] + c] = (float)s[c];
+                ae_adam(a, a.off[ae_bn_gamma[bn]] + c, (float)s[256 + c], step_size, bc2s);
+                ae_adam(a, a.off[ae_bn_gamma[bn] + 1] + c, (float)s[c], step_size, bc2s);
             }
         }
         if (t == 0) {
             *a.loss = (float)a.sums[16 * 512];
-            if (a.step != nullptr) *a.step += 1;
         }
         __syncthreads();
         for (int i = t; i < AE_SLOTS * 512; i += AE_TAIL_NT) a.sums[i] = 0.0;
@@ -883,6 +907,10 @@ extern "C" int tg_ae_train_step(const tg_ae_step_args* q, void* stream) {
     a.wt = a.part + (size_t)q->B * AE_PART;
     a.loss = q->loss; a.recon = q->recon; a.feat = q->feat; a.step = q->step;
     a.B = q->B; a.bn_eps = q->bn_eps; a.momentum = q->momentum;
+    TG_REQUIRE((q->adam_m == nullptr) == (q->adam_v == nullptr), "tg_ae_train_step: adam_m / adam_v go together");
+    TG_REQUIRE(q->adam_m == nullptr || (q->lr > 0.f && q->beta1 >= 0.f && q->beta1 < 1.f && q->beta2 >= 0.f && q->beta2 < 1.f && q->adam_eps > 0.f),
+               "tg_ae_train_step: Adam hyper-parameters");
+    a.M = q->adam_m; a.V = q->adam_v; a.lr = q->lr; a.b1 = q->beta1; a.b2 = q->beta2; a.adam_eps = q->adam_eps;
     hipStream_t s = (hipStream_t)stream;
     const int last = q->last_phase == 0 ? 18 : q->last_phase;
     const dim3 grid(q->B), block(AE_NT);

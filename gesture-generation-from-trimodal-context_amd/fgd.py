@@ -143,15 +143,19 @@ def _ae_plan(net, target):
     return p
 
 
+def _adam_args(opt):
+    s = opt.slab
+    return s.m, s.v, opt.lr, opt.betas[0], opt.betas[1], opt.eps
+
+
 def train_iter(args, epoch, target_data, net, optim):
     """scripts/train_feature_extractor.py:54-97 with variational_encoding=False; `optim` is a FusedAdam over `net`."""
     E = net.engine
     target = target_data.float().contiguous()
     loss = torch.empty(1, device=target.device)
     plan = _ae_plan(net, target)
-    if plan is not None:                 # 18 launches + Adam (csrc/ae_step.hip)
-        plan.run(target, loss)
-        optim.step(counter_advanced=True)
+    if plan is not None:                 # 18 launches, the optimiser step inside the last one (csrc/ae_step.hip)
+        plan.run(target, loss, adam=_adam_args(optim))
         return {"loss": float(loss)}
     E.slab.ensure().zero_grad()
     res = E.forward(target, training=True, save=True)
@@ -165,8 +169,8 @@ def train_iter(args, epoch, target_data, net, optim):
 class AutoencoderTrainer:
     """train_feature_extractor.py:train_iter with variational_encoding=False: reconstruction L1 + L1 of frame differences,
     summed over the batch; Adam(lr 5e-4, betas (0.5, 0.999)).
-    fused (default: where supported): the step up to the gradients as the 18 launches of csrc/ae_step.hip + the slab's Adam launch instead of the
-    ~105 launches of the layer-by-layer engine (kept for other shapes and as the test reference)."""
+    fused (default: where supported): the whole step, optimiser included, as the 18 launches of csrc/ae_step.hip instead of the ~105 launches of
+    the layer-by-layer engine (kept for other shapes and as the test reference)."""
 
     def __init__(self, net, lr=5e-4, fused=None):
         self.net, self.E = net, net.engine
@@ -190,8 +194,7 @@ class AutoencoderTrainer:
         if plan is not None:
             recon = torch.empty_like(target) if keep_outputs else None
             feat = torch.empty(target.shape[0], 32, device=target.device) if keep_outputs else None
-            plan.run(target, loss, recon=recon, feat=feat)
-            self.opt.step(counter_advanced=True)             # the step counter was advanced by the last launch of the plan
+            plan.run(target, loss, recon=recon, feat=feat, adam=_adam_args(self.opt))          # gradients AND the Adam step
             if keep_outputs:
                 self.last = {"recon": recon, "feat": feat}
             return loss

@@ -1194,9 +1194,17 @@ class AeStep:
         q.B, q.bn_eps, q.momentum = self.B, 1e-5, 0.1
         self.q = q
 
-    def run(self, x, loss, recon=None, feat=None, last_phase=0):
+    def run(self, x, loss, recon=None, feat=None, last_phase=0, adam=None):
+        """adam = (m slab, v slab, lr, beta1, beta2, eps): the last launch also takes the optimiser step (torch.optim.Adam) -- the step is then
+        complete; None: gradients only (the caller runs FusedAdam.step(counter_advanced=True))."""
         _flat(x, "poses"); assert tuple(x.shape) == (self.B, 34, 27)
         q = self.q
+        if adam is None:
+            q.adam_m = q.adam_v = None
+        else:
+            m, v, lr, b1, b2, eps = adam
+            assert m.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0 and m.numel() == v.numel()
+            q.adam_m, q.adam_v, q.lr, q.beta1, q.beta2, q.adam_eps = m.data_ptr(), v.data_ptr(), float(lr), float(b1), float(b2), float(eps)
         q.x, q.loss = x.data_ptr(), _flat(loss, "loss").data_ptr()
         q.recon = None if recon is None else _flat(recon, "recon").data_ptr()
         q.feat = None if feat is None else _flat(feat, "feat").data_ptr()

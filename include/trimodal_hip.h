@@ -556,7 +556,9 @@ int tg_ae_loss(const float* recon, const float* target, int32_t B, int32_t T, in
  * PoseEncoderConv + PoseDecoderConv, 34 frames x 27, variational_encoding = False) in 18 launches (ABI 5; csrc/ae_step.hip): forward in
  * train mode (the eight BatchNorms' running statistics advance), loss = sum_b [mean |recon - x| + mean |d recon - d x|], and every parameter
  * gradient WRITTEN (not accumulated) into `grads` at the parameter's offset; fc_logvar receives no gradient (:58) and is not touched.
- * tg_adam_step over the slab completes the step; *step (device Adam counter, may be NULL) is advanced by one here.
+ * With adam_m / adam_v (the optimiser's moment slabs) the last launch also applies torch.optim.Adam(lr, betas, eps) to every parameter it has a
+ * gradient for -- the step is then complete (fc_logvar is skipped like a parameter whose .grad is None); without them tg_adam_step over the slab
+ * completes it.  *step (device Adam counter, may be NULL) is advanced by one by the first launch.
  * off[44]: offsets in floats (multiples of 4) of, in this order: pose_encoder.net.{0,1,2}: {0.weight, 0.bias, 1.weight, 1.bias} each; net.3.{weight,
  * bias}; out_net.0.{weight, bias}, out_net.1.{weight, bias}, out_net.3.{..}, out_net.4.{..}, out_net.6.{..}; fc_mu.{..}; decoder.pre_net.0.{..},
  * pre_net.1.{..}, pre_net.3.{..}; decoder.net.0.{..}, net.1.{..}, net.3.{..}, net.4.{..}, net.6.{..}, net.7.{..}.
@@ -581,6 +583,9 @@ typedef struct {
     int32_t B;
     float bn_eps, momentum;
     int32_t last_phase;
+    float* adam_m;                        /* Adam moments, slab images like params (both or neither) */
+    float* adam_v;
+    float lr, beta1, beta2, adam_eps;
 } tg_ae_step_args;
 int32_t tg_ae_step_supported(int32_t B);
 int64_t tg_ae_step_ws_bytes(int32_t B);
