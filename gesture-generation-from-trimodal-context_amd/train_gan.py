@@ -73,6 +73,8 @@ class GanTrainer:
         self.g_opt = FusedAdam(self.G, lr=self.hp["learning_rate"], betas=(0.5, 0.999))
         self.d_opt = FusedAdam(self.D, lr=self.hp["learning_rate"] * self.hp["discriminator_lr_weight"], betas=(0.5, 0.999))
         self.grad_sync = grad_sync          # ddp.GradSync or None
+        if grad_sync is not None:
+            self.G.audio_fork = False       # (engine._Engine.audio_fork: the second stream only pays while both streams share a hardware queue)
         self.keep_tape = False              # tests: keep the last stacked generator forward's tape in self.last_tape (holds its activations alive)
         self.last_tape = None
         self.prep = L.WeightPrep()          # transposed / packed weight operands, refreshed once per optimiser step

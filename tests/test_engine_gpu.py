@@ -542,6 +542,31 @@ def test_fused_autoencoder_step_matches_layer_engine_and_oracle(pkg, dev, B):
     assert abs(r3["loss"] - l3e.item()) < 1e-3 * abs(l3e.item()) and int(nets[0].engine.slab.step) == int(nets[1].engine.slab.step) == 3
 
 
+def test_audio_encoder_on_the_second_stream_changes_nothing(pkg, dev):
+    """engine._Engine.audio_fork: the audio encoder (forward) and the audio + speaker backward run on a second stream beside the text encoder.
+    Same state, same batch, same device RNG seeds: losses and every gradient agree with the one-stream order (float atomics aside)."""
+    V, S, B = 512, 9, 16
+    gst, dst = O.make_generator_state(3, V, S), O.make_discriminator_state(4)
+    text, audio, vid, poses = (t.to(dev) for t in O.make_batch(17, B, V, S))
+    out = []
+    for forked in (True, False):
+        args, G, D = build_models(pkg, dev, gst, dst, V, S)
+        G.engine.audio_fork = forked
+        tr = pkg.GanTrainer(G, D, args)
+        assert G.engine._audio_fork_on() == forked
+        r = tr.train_iter(11, text, audio, poses, vid).to_dict()
+        torch.cuda.synchronize()
+        _, Gg, _ = G.engine.views()
+        out.append((r, {k: v.clone() for k, v in Gg.items()}))
+    for k in out[0][0]:
+        assert abs(out[0][0][k] - out[1][0][k]) <= 1e-5 * max(1.0, abs(out[1][0][k])), (k, out[0][0][k], out[1][0][k])
+    for k, g1 in out[1][1].items():
+        if k in ZERO_GRAD_KEYS:                                # true gradient exactly zero: rounding noise on both sides
+            continue
+        sc = float(g1.abs().max())
+        assert float((out[0][1][k] - g1).abs().max()) <= 1e-4 * sc + 1e-9, k
+
+
 def test_graphed_step_equals_eager(pkg, dev):
     V, S, B = 64, 9, 8
     gst, dst = O.make_generator_state(7, V, S), O.make_discriminator_state(8)
