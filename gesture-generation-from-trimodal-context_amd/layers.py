@@ -479,7 +479,6 @@ class Fork:
         if self.enabled:
             key = (device.type, device.index)
             if key not in Fork._streams:
-                Fork._dummies = [torch.cuda.Stream(device=device) for _ in range(int(__import__("os").environ.get("TG_FORK_SKIP", "0")))]
                 Fork._streams[key] = torch.cuda.Stream(device=device)
             self.side = Fork._streams[key]
 
