@@ -88,6 +88,30 @@ def launch_ranks(n, argv, worker=None, port=None, poll_s=0.2, env_extra=None):
     return rc, (text[-1] if text else None)
 
 
+def host_cores(cap=64):
+    """CPU threads this process may really use: the affinity mask, cut down to the cgroup's CPU quota where one is set (a GPU box hands a
+    one-GPU job a share of the host -- an intra-op pool sized by the host's core count is throttled by the quota and runs many times
+    slower than one sized by the share), capped at `cap` (ATen's intra-op pool stops scaling far below a full host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:                                             # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    try:                                             # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, q // per))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def make_args():
     """config/multimodal_context.yml through the package's parse_args mirror (hidden 300, 4 layers, z_type speaker, batch 128 ...)."""
     return importlib.import_module(PKG + ".config").load_config("multimodal_context")
@@ -188,11 +212,7 @@ def cpu_baseline_decode(batch, budget_s=15.0, max_windows=8):
     """The oracle's eval forward (CPU port of multimodal_context_net.py:110-160, ATen fp32 kernels) on `batch` windows at a time."""
     from oracle import ref_model as O
     O.FAST = True
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    cores = host_cores()
     torch.set_num_threads(cores)
     gst = O.make_generator_state(0, V, S)
     g = torch.Generator().manual_seed(6)
@@ -217,11 +237,7 @@ def cpu_baseline_decode(batch, budget_s=15.0, max_windows=8):
 def cpu_baseline_ae(batch, budget_s=10.0, max_steps=20):
     """The oracle's autoencoder training iteration (CPU port of train_feature_extractor.py:54-97) at the same batch."""
     from oracle import ref_model as O
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    cores = host_cores()
     torch.set_num_threads(cores)
     st, opt = O.make_autoencoder_state(2), {}
     poses = 0.1 * torch.randn(batch, T, D, generator=torch.Generator().manual_seed(7))
@@ -289,57 +305,51 @@ def hbm_kernel_roofline(pkg, device):
             "frac": nbytes / dt / PEAK_HBM, "traffic": None, "launch_us": dt * 1e6, "bytes_per_launch": nbytes}
 
 
-def cpu_baseline(batch, budget_s=20.0, max_steps=3):
-    """The oracle (a CPU port of the reference path, verified against the reference's own outputs) on the host cores,
-    ATen native kernels (FAST), fp32, same workload shape.  Bounded sample: one warm-up iteration, then iterations until
-    ~budget_s of CPU time is spent (at least one)."""
+def cpu_baseline(batch, seed=1234, warm=2, max_steps=5, budget_s=60.0):
+    """The oracle (a CPU port of the reference path, verified against the reference's own outputs) on the host cores, ATen native kernels
+    (FAST), fp32, on the SAME inputs the GPU line is timed on (synthetic_batch(batch, seed)): SURVEY 8(d)'s 2 warm-up + 5 timed post-warm-up
+    iterations (the timed count shrinks only if 5 would take more than budget_s)."""
     from oracle import ref_model as O
     O.FAST = True
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))          # ATen's intra-op pool stops scaling (and oversubscribes) far below a full host
+    cores = host_cores()
     torch.set_num_threads(cores)
     gst, dst = O.make_generator_state(0, V, S), O.make_discriminator_state(1)
-    g = torch.Generator().manual_seed(5)
-    text = torch.zeros(batch, T, dtype=torch.int64)
-    text[:, ::4] = torch.randint(4, V, (batch, len(range(0, T, 4))), generator=g)
-    audio, poses = 0.1 * torch.randn(batch, A, generator=g), 0.1 * torch.randn(batch, T, D, generator=g)
-    vid = torch.randint(1, S, (batch,), generator=g)
+    text, audio, poses, vid = synthetic_batch(batch, seed, torch.device("cpu"))
     ga, da = {}, {}
-    O.train_iter_gan(gst, dst, ga, da, 11, text, audio, poses, vid, O.Rand(seed=1), fast_gru=True)
+    for w in range(warm):
+        O.train_iter_gan(gst, dst, ga, da, 11, text, audio, poses, vid, O.Rand(seed=1 + w), fast_gru=True)
     t0 = time.perf_counter()
     steps = 0
     while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
-        O.train_iter_gan(gst, dst, ga, da, 11, text, audio, poses, vid, O.Rand(seed=2 + steps), fast_gru=True)
+        O.train_iter_gan(gst, dst, ga, da, 11, text, audio, poses, vid, O.Rand(seed=10 + steps), fast_gru=True)
         steps += 1
     dt = (time.perf_counter() - t0) / steps
     O.FAST = False
     return {"value": batch / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} post-warm-up GAN iterations at batch {batch} after 1 warm-up, fp32 ATen kernels, {dt:.2f} s/iter"}
+            "sample": f"{steps} post-warm-up GAN iterations at batch {batch} after {warm} warm-up, on the benchmark's own synthetic batch (seed {seed}), "
+                      f"fp32 ATen kernels, {dt:.2f} s/iter"}
 
 
-def decode_bench(pkg, a, args, G, device, world, rank):
-    """Inference path (synthesize.py:82-160): every step is one 34-frame window for a.batch utterances in lock-step
-    (seed hand-over + cross-fade on device, hipGraph replay).  Replicas only under --gpus N: no collective."""
+def measure_decode(pkg, args, G, device, batch, steps, warmup, *, graph=True, world=1, rank=0, cpu=True, cpu_budget_s=15.0):
+    """Inference path (synthesize.py:82-160): every step is one 34-frame window for `batch` utterances in lock-step
+    (seed hand-over + cross-fade on device, hipGraph replay).  Replicas only under --gpus N: no collective.  Returns the JSON line's dict."""
     syn = importlib.import_module(PKG + ".synthesize")
     args.motion_resampling_framerate = 15
-    dec = syn.WindowDecoder(args, G, a.batch, device, graph=not a.no_graph)
+    dec = syn.WindowDecoder(args, G, batch, device, graph=graph)
     g = torch.Generator().manual_seed(77 + rank)
-    text = torch.zeros(a.batch, T, dtype=torch.int64)
-    text[:, ::5] = torch.randint(4, V, (a.batch, len(range(0, T, 5))), generator=g)
-    audio = (0.1 * torch.randn(a.batch, dec.audio_len, generator=g)).to(device)
-    text, vid = text.to(device), torch.randint(1, S, (a.batch,), generator=g).to(device)
+    text = torch.zeros(batch, T, dtype=torch.int64)
+    text[:, ::5] = torch.randint(4, V, (batch, len(range(0, T, 5))), generator=g)
+    audio = (0.1 * torch.randn(batch, dec.audio_len, generator=g)).to(device)
+    text, vid = text.to(device), torch.randint(1, S, (batch,), generator=g).to(device)
     dec.seed(None)
     dec.window(text, audio, vid, first=True)
-    for _ in range(max(a.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         dec.window(text, audio, vid, first=False)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         out = dec.window(text, audio, vid, first=False)
     torch.cuda.synchronize()
     if world > 1:
@@ -350,55 +360,60 @@ def decode_bench(pkg, a, args, G, device, world, rank):
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     assert bool(torch.isfinite(out).all())
-    line = None
-    if rank == 0:
-        fps = world * a.batch * T * a.steps / dt
-        extra = {"roofline": decode_kernel_roofline(pkg, device, a.batch)}
-        if world == 1 and not a.no_cpu_baseline:
-            extra["cpu_baseline"] = cpu_baseline_decode(a.batch)
-        line = (json.dumps({
-            **extra,
-            "metric": "inference pose-frames/sec (batched 34-frame synthesis windows)", "value": fps, "unit": "pose-frames/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "latency_us_per_window": dt / a.steps * 1e6,          # --batch 1 = the reference's own call (synthesize.py:131: one utterance)
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthesize.py window loop (BASELINE.json configs[3]): PoseGenerator eval forward + seed hand-over + cross-fade",
-                       "utterances_per_gpu": a.batch, "frames": T, "hipgraph": not a.no_graph, "parallelism": f"replicas x{world}"},
-            "step_roofline": {"bound": "mfma", "achieved": fps / world / T * 0.5217e9 / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                              "frac": fps / world / T * 0.5217e9 / PEAK_F32_MFMA, "note": "0.5217 GFLOP per window (SURVEY 8d)"}}))
-    finish(line, world > 1)
+    if rank != 0:
+        return None
+    fps = world * batch * T * steps / dt
+    extra = {"roofline": decode_kernel_roofline(pkg, device, batch)}
+    if world == 1 and cpu:
+        extra["cpu_baseline"] = cpu_baseline_decode(batch, budget_s=cpu_budget_s)
+    return {
+        **extra,
+        "metric": "inference pose-frames/sec (batched 34-frame synthesis windows)", "value": fps, "unit": "pose-frames/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+        "latency_us_per_window": dt / steps * 1e6,          # batch 1 = the reference's own call (synthesize.py:131: one utterance)
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "synthesize.py window loop (BASELINE.json configs[3]): PoseGenerator eval forward + seed hand-over + cross-fade",
+                   "utterances_per_gpu": batch, "frames": T, "hipgraph": graph, "parallelism": f"replicas x{world}"},
+        "step_roofline": {"bound": "mfma", "achieved": fps / world / T * 0.5217e9 / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                          "frac": fps / world / T * 0.5217e9 / PEAK_F32_MFMA, "frac_f32": fps / world / T * 0.5217e9 / PEAK_F32_MFMA,
+                          "frac_bf16x3": fps / world / T * 0.5217e9 / (PEAK_BF16_MFMA / 6), "note": "0.5217 GFLOP per window (SURVEY 8d)"}}
 
 
-def ae_bench(pkg, a, args, device, world, rank):
+def decode_bench(pkg, a, args, G, device, world, rank):
+    d = measure_decode(pkg, args, G, device, a.batch, a.steps, a.warmup, graph=not a.no_graph, world=world, rank=rank, cpu=not a.no_cpu_baseline)
+    finish(json.dumps(d) if d is not None else None, world > 1)
+
+
+def measure_ae(pkg, args, device, batch, steps, warmup, *, graph=True, world=1, rank=0, cpu=True, cpu_budget_s=10.0):
     """FGD autoencoder training (BASELINE.json configs[4], train_feature_extractor.py:54-97): one step = one Adam iteration
-    of the pose-mode EmbeddingNet on a.batch synthetic clips.  1.04 M MAC/clip forward: launch/latency bound, clips/s only.
-    Replicas only under --gpus N."""
+    of the pose-mode EmbeddingNet on `batch` synthetic clips.  1.04 M MAC/clip forward: launch/latency bound, clips/s only.
+    Replicas only under --gpus N.  Returns the JSON line's dict."""
     fgd = importlib.import_module(PKG + ".fgd")
     torch.manual_seed(0)
     net = pkg.EmbeddingNet(args, D, T, None, None, None, mode="pose").to(device)
     net.train()
     tr = fgd.AutoencoderTrainer(net)
     g = torch.Generator().manual_seed(4321 + rank)
-    poses = (0.1 * torch.randn(a.batch, T, D, generator=g)).to(device)
-    graph = None
-    if not a.no_graph:
+    poses = (0.1 * torch.randn(batch, T, D, generator=g)).to(device)
+    cg = None
+    if graph:
         side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
                 tr.train_iter(poses)
         torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        cg = torch.cuda.CUDAGraph()
         # thread-local capture mode when a process group exists (N > 1 replicas): RCCL's helper threads must not invalidate the capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"):
+        with torch.cuda.graph(cg, capture_error_mode="thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"):
             loss = tr.train_iter(poses)
-    step = graph.replay if graph is not None else (lambda: tr.train_iter(poses))
-    for _ in range(max(a.warmup, 1)):
+    step = cg.replay if cg is not None else (lambda: tr.train_iter(poses))
+    for _ in range(max(warmup, 1)):
         step()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         r = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -408,29 +423,99 @@ def ae_bench(pkg, a, args, device, world, rank):
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
-    lv = float((loss if graph is not None else r).item())
+    lv = float((loss if cg is not None else r).item())
     assert lv == lv and lv < 1e6
-    line = None
-    if rank == 0:
-        extra = {}
-        if world == 1 and not a.no_cpu_baseline:
-            extra["cpu_baseline"] = cpu_baseline_ae(a.batch)
-        line = (json.dumps({
-            **extra,
-            # 1.04 M MAC per clip forward, twice that backward: the step is a chain of 18 dependent launches cut at the eight BatchNorms'
-            # batch statistics / gradient sums (csrc/ae_step.hip), so the figure that matters is microseconds per launch, not the fraction
-            "roofline": {"kernel": "ae_phase_kernel<1..17> + ae_tail_kernel (Adam inside)", "bound": "mfma", "achieved": 6 * 1.04e6 * a.batch / (dt / a.steps) / 1e12,
-                         "peak": 157.3, "unit": "TFLOP/s", "frac": 6 * 1.04e6 * a.batch / (dt / a.steps) / 1e12 / 157.3, "traffic": None,
-                         "note": "latency bound by construction: fp32 MFMA peak as the reference ceiling; see latency"},
-            "latency": {"launches_per_step": 18 if getattr(tr, "_plan", None) is not None else None, "us_per_step": dt / a.steps * 1e6,
-                        "us_per_launch": dt / a.steps * 1e6 / 18 if getattr(tr, "_plan", None) is not None else None, "fused": getattr(tr, "_plan", None) is not None},
-            "metric": "FGD autoencoder training clips/sec", "value": world * a.batch * a.steps / dt, "unit": "clips/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "gesture_autoencoder training iteration (BASELINE.json configs[4]): pose-mode EmbeddingNet fwd+bwd+Adam",
-                       "batch_per_gpu": a.batch, "frames": T, "pose_dim": D, "hipgraph": not a.no_graph, "parallelism": f"replicas x{world}"},
-            "loss": lv}))
-    finish(line, world > 1)
+    if rank != 0:
+        return None
+    extra = {}
+    if world == 1 and cpu:
+        extra["cpu_baseline"] = cpu_baseline_ae(batch, budget_s=cpu_budget_s)
+    fused = getattr(tr, "_plan", None) is not None
+    return {
+        **extra,
+        # 1.04 M MAC per clip forward, twice that backward: the step is a chain of 18 dependent launches cut at the eight BatchNorms'
+        # batch statistics / gradient sums (csrc/ae_step.hip), so the figure that matters is microseconds per launch, not the fraction
+        "roofline": {"kernel": "ae_phase_kernel<1..17> + ae_tail_kernel (Adam inside)", "bound": "mfma", "achieved": 6 * 1.04e6 * batch / (dt / steps) / 1e12,
+                     "peak": 157.3, "unit": "TFLOP/s", "frac": 6 * 1.04e6 * batch / (dt / steps) / 1e12 / 157.3, "traffic": None,
+                     "note": "latency bound by construction: fp32 MFMA peak as the reference ceiling; see latency"},
+        "latency": {"launches_per_step": 18 if fused else None, "us_per_step": dt / steps * 1e6,
+                    "us_per_launch": dt / steps * 1e6 / 18 if fused else None, "fused": fused},
+        "metric": "FGD autoencoder training clips/sec", "value": world * batch * steps / dt, "unit": "clips/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "gesture_autoencoder training iteration (BASELINE.json configs[4]): pose-mode EmbeddingNet fwd+bwd+Adam",
+                   "batch_per_gpu": batch, "frames": T, "pose_dim": D, "hipgraph": graph, "parallelism": f"replicas x{world}"},
+        "loss": lv}
+
+
+def ae_bench(pkg, a, args, device, world, rank):
+    d = measure_ae(pkg, args, device, a.batch, a.steps, a.warmup, graph=not a.no_graph, world=world, rank=rank, cpu=not a.no_cpu_baseline)
+    finish(json.dumps(d) if d is not None else None, world > 1)
+
+
+def step_roofline(clips_per_s_per_gpu, epoch, dtype):
+    """The whole iteration against BOTH matrix ceilings: the fp32 matrix peak (fp32 is the arithmetic delivered) and the ceiling of the
+    arithmetic actually issued -- every big product is six bf16 MFMAs per MAC on exactly split operands (bf16 x 3), i.e. dense bf16 peak / 6;
+    the plain-bf16 tier (one MFMA per MAC) is priced against the dense bf16 peak."""
+    flop = FLOP_PER_CLIP if epoch > 10 else 2.101e9
+    ach = clips_per_s_per_gpu * flop
+    d = {"bound": "mfma", "achieved": ach / 1e12, "unit": "TFLOP/s", "frac_f32": ach / PEAK_F32_MFMA, "frac_bf16x3": ach / (PEAK_BF16_MFMA / 6),
+         "peak_f32": PEAK_F32_MFMA / 1e12, "peak_bf16x3": PEAK_BF16_MFMA / 6 / 1e12,
+         "note": "whole iteration, algorithmic " + ("2.735" if epoch > 10 else "2.101") + " GFLOP/clip (SURVEY 8d), per GPU"}
+    if dtype == "bf16":
+        d.update(peak=PEAK_BF16_MFMA / 1e12, frac=ach / PEAK_BF16_MFMA, frac_bf16=ach / PEAK_BF16_MFMA)
+    else:
+        d.update(peak=PEAK_F32_MFMA / 1e12, frac=ach / PEAK_F32_MFMA)
+    return d
+
+
+def secondary_lines(pkg, a, device, cpu_train):
+    """Short runs of the other BASELINE.json configurations, appended to the default single-GPU line so that the driver's one command times
+    them too: configs[1] as written ("training bf16": the plain-bf16 operand tier), configs[3] (synthesis windows at 128
+    utterances and at the reference's own single utterance), configs[4] (autoencoder training).  Each carries its own ms_per_step, roofline
+    and cpu_baseline; everything here runs AFTER the headline's timed region."""
+    out = {}
+    t_all = time.perf_counter()
+    # ---- configs[1], bf16 operand tier: same iteration, one bf16 MFMA per product in every big product (fp32 master weights, accumulators,
+    # BatchNorm, Adam); a fresh trainer because the math mode is baked into a captured graph
+    pkg.ops.set_math_mode("bf16")
+    try:
+        args, G, Dn = build(pkg, device, seed=0)
+        tr = pkg.GanTrainer(G, Dn, args)
+        text, audio, poses, vid = synthetic_batch(a.batch, 1234, device)
+        step = pkg.GraphedGanStep(tr, a.epoch, text, audio, poses, vid, warmup_iters=2)
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        n = 40
+        t0 = time.perf_counter()
+        for _ in range(n):
+            losses = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ld = losses.to_dict()
+        assert all(v == v and abs(v) < 1e6 for v in ld.values()), ld
+        cps = a.batch * n / dt
+        out["train_bf16"] = {"metric": "training clips/sec (34-frame, 27-dim pose), post-warm-up GAN iteration", "value": cps, "unit": "clips/s", "n_gpus": 1,
+                             "steps": n, "warmup": 10, "ms_per_step": dt / n * 1e3, "dtype": "bf16",
+                             "config": {"workload": "multimodal_context GAN training iteration, bf16 operand tier (BASELINE.json configs[1] as written)",
+                                        "batch_per_gpu": a.batch, "hipgraph": True},
+                             "tolerance": "losses 2e-2, gradients 5e-2, FGD within 1 % of the fp32 tier (tests/test_engine_gpu.py bf16 tier tests)",
+                             "step_roofline": step_roofline(cps, a.epoch, "bf16"), "roofline": dominant_kernel_roofline(pkg, device, a.batch),
+                             "cpu_baseline": cpu_train, "losses": ld}
+        del step, tr
+    finally:
+        pkg.ops.set_math_mode("f32")
+    # ---- configs[3]: synthesis windows, 128 utterances in lock-step and the reference's single utterance
+    args, G, _ = build(pkg, device, seed=0)
+    G.eval()
+    out["decode_b128"] = measure_decode(pkg, args, G, device, 128, 60, 10, cpu=cpu_train is not None, cpu_budget_s=3.0)
+    out["decode_b1"] = measure_decode(pkg, args, G, device, 1, 100, 10, cpu=cpu_train is not None, cpu_budget_s=2.0)
+    # ---- configs[4]: FGD autoencoder training
+    out["ae_train"] = measure_ae(pkg, make_args(), device, 128, 200, 20, cpu=cpu_train is not None, cpu_budget_s=3.0)
+    pkg.ops.check_async_errors()
+    out["wall_s"] = time.perf_counter() - t_all
+    return out
 
 
 def main():
@@ -455,6 +540,8 @@ def main():
                     help="feed every iteration from RAW stored samples through data.DeviceRecordFeeder: host packs records, one H2D copy, the "
                          "per-sample assembly of SpeechMotionDataset.__getitem__ + collate runs on the device (never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short runs of the other BASELINE configurations that the default single-GPU line appends (`secondary`)")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path (graph segments + RCCL) even with one rank")
     ap.add_argument("--deterministic", action="store_true",
                     help="tg_set_deterministic(1): fixed-order combines everywhere, bit-reproducible runs (cost line for DESIGN.md; never the headline value)")
@@ -486,13 +573,18 @@ def main():
     grad_sync = None
     if world > 1 or a.force_ddp:
         import torch.distributed as dist
-        assert int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8, "ddp.configure_environment() must run before the first HIP call"
+        if "GPU_MAX_HW_QUEUES" not in os.environ:
+            print("bench.py: GPU_MAX_HW_QUEUES is unset -- ddp.configure_environment() must run before the first HIP call", file=sys.stderr)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         quiet_stdout()
-        dist.init_process_group("nccl", device_id=device)
         ddp = importlib.import_module(PKG + ".ddp")
+        opts = ddp.process_group_options()
+        if opts is not None:
+            dist.init_process_group("nccl", device_id=device, pg_options=opts)
+        else:
+            dist.init_process_group("nccl", device_id=device)
         grad_sync = ddp.GradSync()
 
     args, G, Dn = build(pkg, device, seed=0)                 # same seed on every rank: identical replicas
@@ -574,7 +666,6 @@ def main():
     line = None
     if rank == 0:
         clips_per_s = world * a.batch * a.steps / dt
-        step_peak = PEAK_BF16_MFMA if a.dtype == "bf16" else PEAK_F32_MFMA
         out = {
             "metric": "training clips/sec (34-frame, 27-dim pose), " + ("post-warm-up GAN iteration" if a.epoch > 10 else "warm-up-phase iteration (epoch <= loss_warmup)")
                       + (" [host-fed, PCIe-inclusive]" if a.host_input else "") + (" [host-fed raw records, device-side batch assembly]" if a.host_records else "") + (" [deterministic mode]" if a.deterministic else ""),
@@ -585,9 +676,7 @@ def main():
                        "batch_per_gpu": a.batch, "global_batch": world * a.batch, "frames": T, "pose_dim": D,
                        "audio_samples": A, "n_words": V, "n_speakers": S - 1, "hipgraph": not a.no_graph,
                        "parallelism": f"dp{world}"},
-            "step_roofline": {"bound": "mfma", "achieved": clips_per_s / world * (FLOP_PER_CLIP if a.epoch > 10 else 2.101e9) / 1e12, "peak": step_peak / 1e12,
-                              "unit": "TFLOP/s", "frac": clips_per_s / world * (FLOP_PER_CLIP if a.epoch > 10 else 2.101e9) / step_peak,
-                              "note": "whole iteration, algorithmic " + ("2.735" if a.epoch > 10 else "2.101") + " GFLOP/clip (SURVEY 8d), per GPU"},
+            "step_roofline": step_roofline(clips_per_s / world, a.epoch, a.dtype),
             "losses": loss_dict,
         }
         if ddp_info is not None:
@@ -596,7 +685,11 @@ def main():
         out["roofline"] = dominant_kernel_roofline(pkg, device, a.batch)
         out["roofline_hbm"] = hbm_kernel_roofline(pkg, device)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.batch)
+            out["cpu_baseline"] = cpu_baseline(a.batch, seed=1234 + rank)
+        plain = (world == 1 and grad_sync is None and a.dtype == "f32" and a.epoch > 10 and not (a.no_graph or a.host_input or a.host_records or a.deterministic))
+        if plain and not a.no_secondary and not a.no_cpu_baseline:
+            del step
+            out["secondary"] = secondary_lines(pkg, a, device, out.get("cpu_baseline"))
         line = json.dumps(out)
     finish(line, world > 1 or a.force_ddp)
 

@@ -100,14 +100,15 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
     constexpr int B_PLANE = BN * 64, B_BUF = NS * B_PLANE;
     constexpr int B_BASE = 2 * A_BUF;                                      // [A buffer 0 | A buffer 1 | B slot 0 | B slot 1 | B slot 2]
     constexpr int GB = BN / 16, MAXGB = (GB + 3) / 4;                      // 16-row DMA groups of the weight tile; per mover wave
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BUF + 3 * B_BUF];
+    constexpr int DUMMY_OFF = 2 * A_BUF + 3 * B_BUF;                       // 1 KB behind the ring: target of the DMAs a wave issues for groups it does not own
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BUF + 3 * B_BUF + (GB % 4 ? 1024 : 0)];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int total_tiles = g.wg_begin[TG_MAX_GROUP];         // incl. the padding ids that round every problem's range up to a multiple of 8
     const int G = gridDim.x;
 
     // tile `vb` of the launch -> problem, origin, slab count; false for a padding id
-    auto decode = [&](int vb, int& pi, int& m0, int& n0, int& nslab) -> bool {
+    auto decode = [&](int vb, int& pi, int& m0, int& n0, int& nslab) __attribute__((always_inline)) -> bool {
         pi = group_find(g, vb);
         const NtProb& pr = g.p[pi];
         const int lid = xcd_chunked_id(vb - g.wg_begin[pi], g.wg_begin[pi + 1] - g.wg_begin[pi]);
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
         int kk = 0, c = 0, kcur = 0, K_a = 0, a_cw = 4, a_dil = 0, a_rows_in = 0;
         const float* a_ptr = g.p[0].A.ptr;
         unsigned a_bytes = 0;
-        auto next_tile_a = [&]() {
+        auto next_tile_a = [&]() __attribute__((always_inline)) {
             int pi = 0, m0 = 0, n0 = 0;
             do {
                 vb_a += G;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
             a_ptr = A.ptr; a_bytes = pr.a_bytes;
         };
         u32x4 ga[2][NPA];
-        auto fetch = [&](auto set_c) {
+        auto fetch = [&](auto set_c) __attribute__((always_inline)) {
             constexpr int set = decltype(set_c)::value;
             const __amdgpu_buffer_rsrc_t a_rsrc = mw_rsrc(a_ptr, a_bytes);
             const bool inb = kcur < K_a;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
             while (c >= a_cw) { c -= a_cw; ++kk; }
             if (live_a && ++s_a >= nslab_a) next_tile_a();     // (wave-uniform)
         };
-        auto stage = [&](auto set_c, int buf) {
+        auto stage = [&](auto set_c, int buf) __attribute__((always_inline)) {
             constexpr int set = decltype(set_c)::value;
             unsigned char* const lb = smem + buf * A_BUF;
             if constexpr (ABL & 2) {                              // loaded values stay live (the loads must still be waited for), nothing else
@@ -225,14 +226,20 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
         unsigned b_slab_b = 0, b_bytes = 0;                                    // bytes per 32-column slab of a plane; per plane
         const __bf16* b_ptr = g.p[0].Bpl;
         long b_plane = 0;
-        auto next_tile_b = [&]() {
+        auto next_tile_b = [&]() __attribute__((always_inline)) {
             int pi = 0, m0 = 0, n0 = 0;
             do {
                 vb_b += G;
                 if (vb_b >= total_tiles) { live_b = false; break; }
             } while (!decode(vb_b, pi, m0, n0, nslab_b));
             s_b = 0;
-            if (!live_b) return;
+            if (!live_b) {
+                // past this workgroup's last tile: the DMAs of the remaining steps are still ISSUED (a fixed number of vector-memory
+                // operations per step on every path, see `step`), every lane past num_records: they write zeros into a ring slot nobody reads
+#pragma unroll
+                for (int u = 0; u < MAXGB; ++u) b_voff[u] = MW_OOB;
+                return;
+            }
             const NtProb& pr = g.p[pi];
 #pragma unroll
             for (int u = 0; u < MAXGB; ++u) {
@@ -243,58 +250,67 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
             b_bytes = b_slab_b * (unsigned)((pr.A.K + 31) >> 5);
             b_ptr = pr.Bpl; b_plane = pr.bpl_plane;
         };
-        auto dma = [&](int slot) -> bool {                                     // the cursor's slab -> ring slot `slot`; false when nothing is left
-            if (!live_b) return false;
-            if constexpr (!(ABL & 8)) {
-                const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s_b * (int)b_slab_b);
+        // Every mover wave issues EXACTLY NS * MAXGB DMAs + NPA loads per step on every path.  hipcc counts outstanding vector-memory operations
+        // statically; round 3's form (DMAs skipped once the cursor had run out, `continue` for the groups a wave does not own, a `break` in
+        // the middle of the two-step loop body) left it with a lower bound of zero DMAs between a fetch and its use, and the ISA waited
+        // vmcnt(7 .. 4) at the top of every step -- i.e. for the DMAs and loads issued a few hundred cycles earlier -- plus a full
+        // vmcnt(0) behind every other barrier: a memory round trip per slab on the movers' path, whatever the tile (the "per-slab floor"
+        // of DESIGN.md section 9.2).  Order inside a step: DMAs FIRST (their slot was released by the barrier just passed: the longest
+        // possible time to land), then stage, then fetch.
+        {
+            constexpr int NG = MAXGB;
+            constexpr int ND = NS * NG;                                        // DMAs per step of every mover wave
+            auto dma = [&](int slot) __attribute__((always_inline)) {                                         // the cursor's slab -> ring slot `slot`
+                if constexpr (!(ABL & 8)) {
+                    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s_b * (int)b_slab_b);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const __amdgpu_buffer_rsrc_t rs = mw_rsrc(b_ptr + s * b_plane, b_bytes);
+                    for (int s = 0; s < NS; ++s) {
+                        const __amdgpu_buffer_rsrc_t rs = mw_rsrc(b_ptr + s * b_plane, b_bytes);
 #pragma unroll
-                    for (int u = 0; u < MAXGB; ++u) {
-                        const int grp = mw + 4 * u;
-                        if (grp >= GB) continue;                               // wave-uniform
-                        mw_dma16(rs, smem, (unsigned)(B_BASE + slot * B_BUF + s * B_PLANE + grp * 1024), b_voff[u], soff);
+                        for (int u = 0; u < NG; ++u) {
+                            // a group past the tile's GB (BN = 160: waves 2, 3 own two groups, not three) is still issued -- out of range, into
+                            // the spare KB behind the ring -- so that every wave's step has the same static count
+                            const int grp = mw + 4 * u;
+                            const bool own = (GB % 4 == 0) || grp < GB;
+                            mw_dma16(rs, smem, own ? (unsigned)(B_BASE + slot * B_BUF + s * B_PLANE + grp * 1024) : (unsigned)DUMMY_OFF,
+                                     own ? b_voff[u] : MW_OOB, soff);
+                        }
                     }
                 }
-            }
-            if (++s_b >= nslab_b) next_tile_b();
-            return true;
-        };
-        constexpr int ND_MIN = NS * (GB / 4);                                  // fewest DMAs a mover wave issues per slab
-
-        next_tile_a();
-        next_tile_b();
-        fetch(set0{});                                         // slab 0
-        fetch(set1{});                                         // slab 1 (past this workgroup's work: every piece out of range, zeros, no traffic)
-        dma(0);                                                // slabs 0, 1 of the weights
-        dma(1);
-        stage(set0{}, 0);
-        fetch(set0{});                                         // slab 2
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        MW_TIMED_BARRIER();
-        asm volatile("" ::: "memory");
-        // step n: the matrix waves multiply slab n (activation buffer n & 1, weight slot n % 3).  Slab n + 1 of the activation is staged into
-        // the other buffer (read last during step n - 1), slab n + 3 fetched into the register set just emptied, slab n + 2 of the weights
-        // sent to the slot slab n - 1 has left; before the step's barrier the weights of slab n + 1 (sent one step ago) must have landed:
-        // everything this wave issued after them -- one fetch, one slab of DMAs -- may stay in flight.
-        int n = 0, slot2 = 2;                                  // slot2 = (n + 2) % 3
-        auto step = [&](auto set_c, int abuf) {
-            if (n + 1 < total) stage(set_c, abuf);
-            fetch(set_c);
-            const bool sent = dma(slot2);
-            if (sent) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPA + ND_MIN) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPA) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (live_b && ++s_b >= nslab_b) next_tile_b();
+            };
+            next_tile_a();
+            next_tile_b();
+            fetch(set0{});                                         // slab 0
+            fetch(set1{});                                         // slab 1 (past this workgroup's work: every piece out of range, zeros, no traffic)
+            dma(0);                                                // slabs 0, 1 of the weights
+            dma(1);
+            stage(set0{}, 0);
+            fetch(set0{});                                         // slab 2
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             MW_TIMED_BARRIER();
             asm volatile("" ::: "memory");
-            ++n;
-            slot2 = slot2 == 2 ? 0 : slot2 + 1;
-        };
-        while (n < total) {
-            step(set1{}, 1);
-            if (n >= total) break;
-            step(set0{}, 0);
+            // step n: the matrix waves multiply slab n (activation buffer n & 1, weight slot n % 3).  Slab n + 2 of the weights is sent to the
+            // slot slab n - 1 has just left, slab n + 1 of the activation is staged into the other buffer (read last during step n - 1), slab
+            // n + 3 fetched into the register set just emptied; before the step's barrier the weights of slab n + 1 (sent one step ago)
+            // must have landed: everything issued in THIS step -- ND DMAs, then NPA loads -- may stay in flight.
+            int n = 0, slot2 = 2;                                  // slot2 = (n + 2) % 3
+            auto step = [&](auto set_c, int abuf) __attribute__((always_inline)) {
+                dma(slot2);
+                if (n + 1 < total) stage(set_c, abuf);
+                fetch(set_c);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPA + ND) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                MW_TIMED_BARRIER();
+                asm volatile("" ::: "memory");
+                ++n;
+                slot2 = slot2 == 2 ? 0 : slot2 + 1;
+            };
+            while (n + 2 <= total) {
+                step(set1{}, 1);
+                step(set0{}, 0);
+            }
+            if (n < total) step(set1{}, 1);
         }
     } else {
         // ============================================================================================ matrix waves (0-7)

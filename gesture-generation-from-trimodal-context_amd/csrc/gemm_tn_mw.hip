@@ -77,7 +77,7 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
     const int G = gridDim.x;
 
     // work item `vb` -> problem, tile origin, row range; false for a padding id
-    auto decode = [&](int vb, int& pi, int& n0, int& k0, int& m_begin, int& m_end) -> bool {
+    auto decode = [&](int vb, int& pi, int& n0, int& k0, int& m_begin, int& m_end) __attribute__((always_inline)) -> bool {
         pi = group_find(g, vb);
         const TnProb& pr = g.p[pi];
         const int lid = xcd_chunked_id(vb - g.wg_begin[pi], g.wg_begin[pi + 1] - g.wg_begin[pi]);
@@ -113,15 +113,16 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
         unsigned y_off[NPY];                                   // byte offset of (row m_begin + yrow, column n0 + ycol) in dY
         bool y_cok[NPY];
         unsigned x_cb[NPX];                                    // byte offset of the piece's channel inside a source row
-        int x_tapd[NPX], x_mb[NPX], x_mr[NPX], x_one[NPX];     // tap row displacement; batch / row of the piece's m; element that is the ones column (or -1)
+        int x_tapd[NPX];                                       // tap row displacement
         bool x_ok[NPX];
+        int x_one = -1;                                        // 4 i + q: element q of X piece i is the ones column of this item (at most one piece of a thread holds column K), or -1
         unsigned y_slab_b = 0;                                 // bytes between slabs in dY
         const float* y_ptr = g.p[0].dY;
         const float* a_ptr = g.p[0].A.ptr;
-        unsigned y_bytes = 0, a_bytes = 0, rs4 = 0;
-        long a_bs = 0;
+        unsigned y_bytes = 0, a_bytes = 0, rs4 = 0, a_bs4 = 0;
         int a_rows_out = 1, a_rows_in = 0, a_step = 1;
-        auto next_item = [&]() {
+        float a_inv_ro = 1.f;
+        auto next_item = [&]() __attribute__((always_inline)) {
             int pi = 0, n0 = 0, k0 = 0, mb = 0, me = 0;        // (locals: a captured variable passed by reference here ends up in scratch memory)
             do {
                 vb_f += G;
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
 #pragma unroll
                 for (int i = 0; i < NPY; ++i) y_cok[i] = false;
 #pragma unroll
-                for (int i = 0; i < NPX; ++i) { x_ok[i] = false; x_one[i] = -1; }
+                for (int i = 0; i < NPX; ++i) x_ok[i] = false;
+                x_one = -1;
                 m_cur = 0; m_end_f = 0;
                 return;
             }
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
                 y_off[i] = (unsigned)(((long)(mb + yrow[i]) * pr.ldy + n0 + ycol[i]) * 4);
             }
             const bool bias_here = pr.dbias != nullptr && k0 <= A.K && A.K < k0 + BK;       // this tile holds the padding column K
+            x_one = -1;
 #pragma unroll
             for (int i = 0; i < NPX; ++i) {
                 const int ak = k0 + xcol[i];
@@ -155,56 +158,65 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
                 const int tap = kc / A.cw;
                 x_cb[i] = (unsigned)((kc - tap * A.cw) * 4);
                 x_tapd[i] = A.shift + tap * A.dil;
-                const int m = mb + xrow[i];
-                x_mb[i] = m / A.rows_out;
-                x_mr[i] = m - x_mb[i] * A.rows_out;
-                x_one[i] = (bias_here && ak <= A.K && A.K < ak + 4) ? A.K - ak : -1;
+                if (bias_here && ak <= A.K && A.K < ak + 4) x_one = 4 * i + (A.K - ak);
             }
             y_slab_b = (unsigned)(32 * pr.ldy * 4);
             y_ptr = pr.dY; y_bytes = pr.y_bytes;
-            a_ptr = A.ptr; a_bytes = pr.a_bytes; rs4 = (unsigned)(A.rs * 4); a_bs = A.bs;
+            a_ptr = A.ptr; a_bytes = pr.a_bytes; rs4 = (unsigned)(A.rs * 4); a_bs4 = (unsigned)(A.bs * 4);
             a_rows_out = A.rows_out; a_rows_in = A.rows_in; a_step = A.step;
+            a_inv_ro = 1.f / (float)A.rows_out;
         };
-        u32x4 gy[NPY], gx[NPX];
-        unsigned rowok = 0;                                    // bit i = X piece i's row lies inside the item's range (ones column)
-        int one_el[NPX];                                       // the ones column belongs to the item the registers were FETCHED for
-        auto fetch = [&]() {
-#pragma unroll
-            for (int i = 0; i < NPX; ++i) one_el[i] = x_one[i];
-            const __amdgpu_buffer_rsrc_t yr = tw_rsrc(y_ptr, y_bytes), ar = tw_rsrc(a_ptr, a_bytes);
+        // TWO register sets of loads in flight (round 5).  Round 3's single set was staged at the top of a step and refilled right behind it: its
+        // loads had only the rest of that step to land, the ISA drained vmcnt down to 0 at the top of every step, and a step cost the staging
+        // arithmetic PLUS a memory round trip (3.4 us per 32-row slab against 1.4-1.6 us of matrix pipe).  Now slab n + 3 is fetched while slab
+        // n + 1 is staged: two full steps for the loads.  All addresses of a fetch are formed before its first load so that the loads issue
+        // back to back (a fixed number of vector-memory operations per step on every path: hipcc's static counts then come out exact).
+        u32x4 gy[2][NPY], gx[2][NPX];
+        int one_el[2] = {-1, -1};                              // 4 i + q of the ones column for the slab the set was FETCHED for (-1: none, or its row lies past the item's range)
+        auto fetch = [&](auto set_c) __attribute__((always_inline)) {
+            constexpr int set = decltype(set_c)::value;
+            int oe = -1;
             const unsigned ysoff = (unsigned)__builtin_amdgcn_readfirstlane(s_f * (int)y_slab_b);
+            unsigned yo[NPY], xo[NPX];
 #pragma unroll
             for (int i = 0; i < NPY; ++i) {
                 const bool ok = y_cok[i] & (m_cur + yrow[i] < m_end_f);
-                gy[i] = __builtin_amdgcn_raw_buffer_load_b128(yr, ok ? y_off[i] : TW_OOB, ysoff, 0);
+                yo[i] = ok ? y_off[i] : TW_OOB;
             }
-            unsigned rk = 0u;
 #pragma unroll
             for (int i = 0; i < NPX; ++i) {
-                const int sr = x_mr[i] * a_step + x_tapd[i];
-                const bool rin = m_cur + xrow[i] < m_end_f;
+                // (batch, row) of the piece's m: m / rows_out by a float reciprocal -- exact for m < 2^21 (the planner refuses longer reductions)
+                const int m = m_cur + xrow[i];
+                const int b = (int)(((float)m + 0.5f) * a_inv_ro);
+                const int r = m - b * a_rows_out;
+                const int sr = r * a_step + x_tapd[i];
+                const bool rin = m < m_end_f;
                 const bool ok = x_ok[i] & rin & ((unsigned)sr < (unsigned)a_rows_in);
-                gx[i] = __builtin_amdgcn_raw_buffer_load_b128(ar, ok ? (unsigned)(x_mb[i] * a_bs * 4) + (unsigned)sr * rs4 + x_cb[i] : TW_OOB, 0, 0);
-                rk |= rin ? (1u << i) : 0u;
-                x_mr[i] += 32;
-                while (x_mr[i] >= a_rows_out) { x_mr[i] -= a_rows_out; ++x_mb[i]; }
+                xo[i] = ok ? (unsigned)b * a_bs4 + (unsigned)sr * rs4 + x_cb[i] : TW_OOB;
+                oe = (rin && (x_one >> 2) == i) ? x_one : oe;
             }
-            rowok = rk;
+            one_el[set] = oe;
+            const __amdgpu_buffer_rsrc_t yr = tw_rsrc(y_ptr, y_bytes), ar = tw_rsrc(a_ptr, a_bytes);
+#pragma unroll
+            for (int i = 0; i < NPY; ++i) gy[set][i] = __builtin_amdgcn_raw_buffer_load_b128(yr, yo[i], ysoff, 0);
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) gx[set][i] = __builtin_amdgcn_raw_buffer_load_b128(ar, xo[i], 0, 0);
             m_cur += 32;
             if (live && ++s_f >= nslab_f) next_item();
         };
-        auto stage = [&](int buf) {
+        auto stage = [&](auto set_c, int buf) __attribute__((always_inline)) {
+            constexpr int set = decltype(set_c)::value;
 #pragma unroll
             for (int i = 0; i < NPY; ++i) {
                 u32x2 o[NS];
-                tw_split4<NS>(__builtin_bit_cast(f32x4, gy[i]), o);
+                tw_split4<NS>(__builtin_bit_cast(f32x4, gy[set][i]), o);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&ys[buf][s][0] + ypos[i]) = o[s];
             }
 #pragma unroll
             for (int i = 0; i < NPX; ++i) {
-                f32x4 v = __builtin_bit_cast(f32x4, gx[i]);
-                const int e = ((rowok >> i) & 1u) ? one_el[i] : -1;
+                f32x4 v = __builtin_bit_cast(f32x4, gx[set][i]);
+                const int e = one_el[set] - 4 * i;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = e == q ? 1.0f : v[q];
                 u32x2 o[NS];
@@ -213,22 +225,32 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&xs[buf][s][0] + xpos[i]) = o[s];
             }
         };
+        using set0 = std::integral_constant<int, 0>;
+        using set1 = std::integral_constant<int, 1>;
         next_item();
-        fetch();                                               // slab 0
-        stage(0);
-        fetch();                                               // slab 1
+        fetch(set0{});                                         // slab 0
+        fetch(set1{});                                         // slab 1
+        stage(set0{}, 0);
+        fetch(set0{});                                         // slab 2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // step n: the matrix waves multiply slab n out of buffer n & 1; slab n + 1 (fetched during step n - 1) is staged into the other
-        // buffer (read last during step n - 1) and slab n + 2 fetched into the registers just emptied: a full step for its loads to land
-        for (int n = 0; n < total; ++n) {
-            if (n + 1 < total) stage((n + 1) & 1);
-            fetch();
+        // step n: the matrix waves multiply slab n out of buffer n & 1; slab n + 1 (fetched two steps ago into set (n + 1) & 1) is staged into
+        // the other buffer (read last during step n - 1) and slab n + 3 fetched into the set just emptied
+        int n = 0;
+        auto step = [&](auto set_c, int buf) __attribute__((always_inline)) {
+            if (n + 1 < total) stage(set_c, buf);
+            fetch(set_c);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            ++n;
+        };
+        while (n + 2 <= total) {
+            step(set1{}, 1);
+            step(set0{}, 0);
         }
+        if (n < total) step(set1{}, 1);
     } else {
         // ============================================================================================ matrix waves (0-7)
         const int wn = wave / WKW, wk = wave % WKW;
@@ -368,7 +390,7 @@ bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid) {
         const long batches = cdiv(p.M, A.rows_out);
         const long a_el = (batches - 1) * A.bs + (long)(A.rows_in - 1) * A.rs + A.cw;
         const long y_el = (long)(p.M - 1) * p.ldy + p.N;
-        if (a_el <= 0 || a_el >= (1l << 29) || y_el >= (1l << 29)) return false;
+        if (a_el <= 0 || a_el >= (1l << 29) || y_el >= (1l << 29) || p.M >= (1 << 20)) return false;     // (M: the movers' reciprocal division)
         p.a_bytes = (unsigned)(a_el * 4);
         p.y_bytes = (unsigned)(y_el * 4);
         tiles += (long)cdiv(p.N, BN) * cdiv(A.K, BK);

@@ -14,7 +14,8 @@ import warnings
 import torch
 import torch.distributed as dist
 
-HW_QUEUES = 8
+HW_QUEUES = int(os.environ.get("TG_DDP_HW_QUEUES", "8"))          # what configure_environment() asks for unless GPU_MAX_HW_QUEUES is already set
+HIGH_PRIORITY_STREAM = os.environ.get("TG_DDP_PRIO", "0") != "0"  # RCCL's stream created with high priority (its own hardware queue)
 
 
 def configure_environment():
@@ -22,16 +23,32 @@ def configure_environment():
     GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin; with the handful of streams a process creates (capture, warm-up, RCCL's)
     the collective's stream regularly lands on the compute stream's queue, and a gradient bucket's RCCL kernel then runs IN LINE with the
     graph segment behind it instead of beside it.  Measured on one rank (tools/ddp_overlap_probe.sh, profiles/r4_l_ddp_overlap.txt): with 4
-    queues every segment started ~10 us after the bucket's kernel had finished; with 8 it starts 35-40 us before."""
+    queues every segment started ~10 us after the bucket's kernel had finished; with 8 it starts 35-40 us before.
+    An explicitly exported GPU_MAX_HW_QUEUES is honoured (probes set it)."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(HW_QUEUES))
+
+
+def process_group_options():
+    """backend options for init_process_group("nccl", ...): with HIGH_PRIORITY_STREAM, RCCL's internal stream is created with high priority --
+    the runtime keeps a separate hardware queue per priority level, so the collectives never share the compute stream's queue whatever the
+    stream creation order.  None otherwise (or when this torch build has no such option)."""
+    if not HIGH_PRIORITY_STREAM:
+        return None
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except Exception:
+        return None
 
 
 class GradSync:
     def __init__(self, group=None, chunk_floats=8 * 1024 * 1024):
         assert dist.is_initialized(), "init_process_group first"
-        if dist.get_backend(group) == "nccl" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < HW_QUEUES:
-            warnings.warn("GPU_MAX_HW_QUEUES < 8: RCCL's stream may share a hardware queue with the compute stream, which serialises every "
-                          "gradient bucket with the backward it is meant to overlap (call ddp.configure_environment() before the first HIP call)")
+        if dist.get_backend(group) == "nccl" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8 and not HIGH_PRIORITY_STREAM:
+            warnings.warn("GPU_MAX_HW_QUEUES < 8 and RCCL's stream has normal priority: it may share a hardware queue with the compute stream, which "
+                          "serialises every gradient bucket with the backward it is meant to overlap (call ddp.configure_environment() before the "
+                          "first HIP call)")
         self.group = group
         self.world = dist.get_world_size(group)
         self.chunk = int(chunk_floats)

@@ -136,10 +136,11 @@ def _ae_plan(net, target):
     if not target.is_cuda or not ops.AeStep.supported(slab, B, target.shape):
         return None
     p = getattr(E, "_ae_plan", None)
-    if p is None or p.slab_ptr != slab.flat.data_ptr() or p.B != B:
+    buffers = dict(net.named_buffers())
+    if p is None or p.cache_key != ops.AeStep.key(slab, buffers, B):
         assert not torch.cuda.is_current_stream_capturing(), "run one eager step before capturing (the plan allocates its workspace)"
         slab.zero_grad()                 # fc_logvar gets no gradient (:58): its slots stay zero, every other one is written by each step
-        p = E._ae_plan = ops.AeStep(slab, dict(net.named_buffers()), B)
+        p = E._ae_plan = ops.AeStep(slab, buffers, B)
     return p
 
 

@@ -179,6 +179,7 @@ class ConvDiscriminator(nn.Module):
         self.out2 = nn.Linear(28, 1)
         self.do_flatten_parameters = False
         self._engine = None
+        self._replay_draws = []      # parity tests: queue of {'d.gru.drop<l>': mask}, one entry consumed per forward call
 
     @property
     def engine(self) -> DiscriminatorEngine:
@@ -191,9 +192,10 @@ class ConvDiscriminator(nn.Module):
         eng.rng.advance()
         params_need = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         need_grad = params_need or (torch.is_grad_enabled() and poses.requires_grad)
+        inject = self._replay_draws.pop(0) if self._replay_draws else None
 
         def runner(poses_in):
-            res = eng.forward(poses_in.float(), training=self.training, save=need_grad)
+            res = eng.forward(poses_in.float(), training=self.training, save=need_grad, inject=inject)
 
             def back(d_prob):
                 from . import ops

@@ -294,7 +294,9 @@ TN_TWO_PASS_ROWS = 32768     # reductions at least this long combine their parti
 
 
 def set_deterministic(on):
-    """tg_set_deterministic: fixed-order combines everywhere (no float atomics) -- two runs from the same state are bit-identical.  Here:
+    """tg_set_deterministic: fixed-order combines on the GAN training iteration's path (no float atomics there) -- two runs from the same state
+    are bit-identical.  The autoencoder trainer and the evaluation helpers (ae_loss, l1_mean, the small single-launch BatchNorm kernels) are
+    outside its scope (include/trimodal_hip.h).  Here:
     every weight-gradient product takes the two-pass workspace and its bias gradient goes through colsum; the engines take the generic
     forms of the two fused backward kernels that combine by atomics (speaker_bwd_supported, engine.DiscriminatorEngine.backward)."""
     call("tg_set_deterministic", int(bool(on)))
@@ -1173,9 +1175,18 @@ class AeStep:
         known = {n for n, _ in AE_PARAMS} | {f"{_AE_E}.fc_logvar.weight", f"{_AE_E}.fc_logvar.bias"}
         return all(shapes.get(n) == s for n, s in AE_PARAMS) and set(shapes) <= known and not slab.frozen
 
+    @staticmethod
+    def key(slab, buffers, B):
+        """Every raw device pointer the argument block holds (+ the batch size): the plan is valid exactly while this is unchanged -- a
+        re-allocated slab, gradient slab, step counter or BatchNorm buffer (load_state_dict(assign=True), module re-materialisation) gives a
+        new key instead of a step that writes through stale pointers."""
+        bufs = tuple(buffers[bn + sfx].data_ptr() for bn in AE_BNS for sfx in (".running_mean", ".running_var", ".num_batches_tracked"))
+        return (int(B), slab.flat.data_ptr(), slab.grad.data_ptr(), slab.step.data_ptr()) + bufs
+
     def __init__(self, slab, buffers, B):
         dev = slab.flat.device
         self.slab_ptr, self.B = slab.flat.data_ptr(), int(B)
+        self.cache_key = AeStep.key(slab, buffers, B)
         off = dict(zip(slab.names, slab.offsets))
         q = _lib.AeStepArgs()
         q.params, q.grads = slab.flat.data_ptr(), slab.grad.data_ptr()

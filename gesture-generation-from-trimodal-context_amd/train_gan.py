@@ -74,7 +74,10 @@ class GanTrainer:
         self.d_opt = FusedAdam(self.D, lr=self.hp["learning_rate"] * self.hp["discriminator_lr_weight"], betas=(0.5, 0.999))
         self.grad_sync = grad_sync          # ddp.GradSync or None
         if grad_sync is not None:
-            self.G.audio_fork = False       # (engine._Engine.audio_fork: the second stream only pays while both streams share a hardware queue)
+            # data parallel: the forward keeps the audio encoder on its second stream; in the backward the audio branch runs on the main stream
+            # BEHIND the {text, speaker} bucket's hand-over, so that bucket's all-reduce has the audio backward (~250 us) as its cover and a
+            # graph segment never ends with an un-joined branch
+            self.G.audio_fork_bwd = False
         self.keep_tape = False              # tests: keep the last stacked generator forward's tape in self.last_tape (holds its activations alive)
         self.last_tape = None
         self.prep = L.WeightPrep()          # transposed / packed weight operands, refreshed once per optimiser step
@@ -219,8 +222,9 @@ class GanTrainer:
         # the audio encoder's bucket is the backward's last (engine.GeneratorEngine.backward): launched and awaited in ONE action, so that a
         # segmented graph is cut once there, not twice around an empty segment
         self._waited = False
-        def on_ready(prefixes):
-            last = tuple(prefixes) == ("audio_encoder",)
+        def on_ready(prefixes, last=False):
+            # `last` comes from the engine (the bucket it hands over at the very end of its backward), not from the bucket's name
+            assert not self._waited, "a gradient bucket was handed over after the backward's last one"
             self._sync("bucket_wait" if last else "bucket", G.slab, prefixes)
             self._waited = last
         G.backward(st["res"]["tape"], d_out, d_mu, d_lv, b0=st["i2"] * B, nb=B, on_ready=on_ready if self.grad_sync is not None else None)
@@ -230,6 +234,8 @@ class GanTrainer:
         if not getattr(self, "_waited", False):
             self._sync("wait")
         self._waited = False
+        if self.grad_sync is not None and self._cut is None:
+            assert not self.grad_sync.pending, "a gradient bucket is still in flight at the optimiser step"
         self.g_opt.step(counter_advanced=True)
 
 

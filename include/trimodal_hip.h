@@ -28,12 +28,16 @@ extern "C" {
 
 int tg_version(void);
 
-/* Deterministic mode (ABI 5).  on != 0: every combine across workgroups runs in a fixed order -- weight-gradient splits through the two-pass
+/* Deterministic mode (ABI 5).  Scope: the GAN TRAINING ITERATION (train_eval/train_gan.py:13-103 as train_gan.GanTrainer issues it).
+ * on != 0: every combine across workgroups on that path runs in a fixed order -- weight-gradient splits through the two-pass
  * fp64 reduce (the caller passes a workspace for every problem and takes bias gradients through tg_colsum), embedding scatters with one
  * writer per table row, the discriminator head's parameter gradients and tg_colsum by one workgroup, BatchNorm partial sums in thread order --
  * so two runs from the same state give bit-identical results (the reference on CPU is reproducible given a seed; float atomics are not).
  * The fused discriminator front-end backward (tg_d_preconv_bwd) and the fused speaker backward (tg_speaker_bwd) combine by float atomics and
- * are not to be called in this mode (the host mirror takes their generic forms).  Process-wide, like tg_set_math_mode. */
+ * are not to be called in this mode (the host mirror takes their generic forms).  Process-wide, like tg_set_math_mode.
+ * NOT covered (they keep their atomics whatever the mode): the autoencoder path (tg_ae_train_step's fp64 BatchNorm / loss sums, tg_ae_loss),
+ * tg_l1_mean and the single-launch BatchNorm statistics kernels for tensors under 16 K elements (tg_bn_train_stats / tg_bn_backward: fp64
+ * atomics, whose order-dependence is below fp32 resolution but not zero).  tests/test_trajectory_gpu.py pins the guarantee at B = 64. */
 int tg_set_deterministic(int32_t on);
 int tg_get_deterministic(void);
 const char* tg_last_error(void);

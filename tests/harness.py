@@ -183,7 +183,7 @@ def tcn_gate_sides(tape, gate_log, call, B, tag="g2", rel_window=5e-6):
 
 
 MAX_GATE_FLIPS = 8
-NEAR_TIE_FRESH, NEAR_TIE_AFTER_FLIP = 2e-6, 5e-4
+NEAR_TIE_FRESH, NEAR_TIE_AFTER_FLIP = 2e-6, 1e-5
 
 
 def assert_gate_flips_are_near_ties(flips, what=""):
@@ -191,8 +191,8 @@ def assert_gate_flips_are_near_ties(flips, what=""):
     wav_gate_flips results, one list per iteration in order (or a single iteration's list).  While both sides still step identical
     weights a gate may differ only where the fp64 pre-activation is within 2e-6 of zero (fp32 rounding of an O(1) value).  Once a gate
     has flipped, the audio encoder's gradients of that iteration differ by up to ~7e-3 of their max, Adam carries that into the weights
-    (lr * 7e-3 per entry) and the NEXT iterations' pre-activations differ by ~1e-4: from then on the window is 5e-4.  At most 8 flips in
-    all.  Returns the total number of flipped gates."""
+    (lr * 7e-3 per entry) and the NEXT iterations' pre-activations can differ by more than fp32 rounding: from then on the window is 1e-5
+    (the largest flipped pre-activation ever measured is 2.3e-6; round 4 allowed 5e-4 here).  At most 8 flips in all.  Returns the total number of flipped gates."""
     iters = flips if isinstance(flips[0], list) else [flips]
     total, window = 0, NEAR_TIE_FRESH
     for it, fl in enumerate(iters):

@@ -176,7 +176,7 @@ def _fake_trainer_worker(rank, world, port, out):
                     lo, hi = ddp.GradSync.bucket_range(s, bk)
                     s.grad[lo:hi] = full[lo:hi]
                     order.append(("ready", bk))
-                    on_ready(bk)
+                    on_ready(bk, last=bk is BUCKETS[-1])     # as engine.GeneratorEngine.backward: the last bucket is named by the engine
 
         class FakeD:
             def __init__(self, mod): self.slab = importlib.import_module(PKG + ".params").ParamSlab(mod); self.rng = type("R", (), {"state": None})()

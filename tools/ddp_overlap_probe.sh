@@ -8,6 +8,7 @@ python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --force-ddp > gpurun_o
 rm -rf /tmp/prof_$tag
 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$tag -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --force-ddp > gpurun_out/${tag}_prof.log 2>&1
 python3 tools/iter_timeline.py /tmp/prof_$tag gpurun_out/${tag}_timeline.txt > /dev/null
+set -e
 python3 - <<PY
 import json
 d = json.load(open("gpurun_out/${tag}_bench.json"))
