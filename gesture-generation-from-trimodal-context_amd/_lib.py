@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrimodal_hip.so")
+# (TG_LIB_PATH: another build of the same library -- same-box A/B timing against an older build, tools/ab_bench.sh; the lab library of the
+# ablation tools.  Unset in every test and in bench.py's default run.)
+LIB_PATH = os.environ.get("TG_LIB_PATH") or os.path.join(_HERE, "libtrimodal_hip.so")
 
 
 class Window(C.Structure):

@@ -684,8 +684,9 @@ using namespace tg;
 extern "C" int tg_get_math_mode(void);
 int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s);
 int tg_gemm_tn_split_launch(const TnGroup& g, int total_wgs, int tnw, int tkw, hipStream_t s);
-bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid);
+bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid, const long* ws_floats);
 int tg_gemm_tn_mw_launch(const TnGroup& g, int grid, int splits, hipStream_t s);
+int tg_gemm_tn_mw_reduce_launch(const TnGroup& g, const int* splits, hipStream_t s);
 static bool use_split_path() {
     static int x3 = -1;
     if (x3 < 0) {
@@ -976,11 +977,20 @@ static int tn_group_impl(const tg_gemm_tn_problem* problems, int32_t n, void* st
     for (int i = n; i <= TG_MAX_GROUP; ++i) g.wg_begin[i] = wg;
     for (int i = n; i < TG_MAX_GROUP; ++i) g.p[i] = g.p[0];
     hipStream_t s = (hipStream_t)stream;
-    if (mw_ok && !two_pass) {       // big gradients whose 192 x 160 tiles fill the chip: mover-wave kernel (gemm_tn_mw.hip), bf16 x 3 or plain bf16
+    bool all_ws = true;
+    for (int i = 0; i < n; ++i) all_ws = all_ws && problems[i].ws != nullptr;
+    if (mw_ok && (!two_pass || all_ws)) {
+        // big gradients whose 192 x 160 tiles fill the chip: mover-wave kernel (gemm_tn_mw.hip), bf16 x 3 or plain bf16.  Row splits are
+        // combined by float atomics, or -- when EVERY problem brings a workspace -- through tile-sized partial images and a fixed-order second
+        // pass (deterministic, and faster: the atomics all land at the end of the launch)
         int grid = 0, mw_splits[TG_MAX_GROUP];
-        if (tg_gemm_tn_mw_plan(g, mw_splits, &grid)) {
+        long wsf[TG_MAX_GROUP];
+        TnGroup g2 = g;
+        for (int i = 0; i < n; ++i) wsf[i] = (long)problems[i].ws_floats;
+        if (tg_gemm_tn_mw_plan(g2, mw_splits, &grid, wsf)) {
             if (plan_only) { *plan_only = 2; return 0; }
-            return tg_gemm_tn_mw_launch(g, grid, tg_get_math_mode() == 1 ? 1 : 3, s);
+            if (int e = tg_gemm_tn_mw_launch(g2, grid, tg_get_math_mode() == 1 ? 1 : 3, s)) return e;
+            return all_ws ? tg_gemm_tn_mw_reduce_launch(g2, mw_splits, s) : 0;
         }
     }
     if (plan_only) { *plan_only = x3 ? 1 : 0; return 0; }

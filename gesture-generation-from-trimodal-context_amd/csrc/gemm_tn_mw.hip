@@ -58,7 +58,9 @@ __device__ __forceinline__ void tw_split4(const f32x4 v, u32x2 (&out)[NS]) {
 
 // wave tile (16 TNT) x (16 TKT) of dW; matrix waves WNW (n) x WKW (k); workgroup tile BN x BK.  NS = 3: bf16 x 3 (fp32-accurate); NS = 1: plain
 // bf16 operands (math mode 1)
-template <int TNT, int TKT, int WNW, int WKW, int NS>
+// ABL (lab builds only, -DTG_LAB_ABLATE, tools/tn_mw_ablate.py; results are WRONG by construction): bit 0 drops the MFMAs, bit 1 the movers' split
+// arithmetic + LDS stores, bit 2 the movers' global loads, bit 3 the matrix waves' LDS fragment reads, bit 4 the epilogue's atomics
+template <int TNT, int TKT, int WNW, int WKW, int NS, int ABL = 0>
 __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
     static_assert(WNW * WKW == 8, "eight matrix waves");
     constexpr int BN = 16 * TNT * WNW, BK = 16 * TKT * WKW;
@@ -77,10 +79,12 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
     const int G = gridDim.x;
 
     // work item `vb` -> problem, tile origin, row range; false for a padding id
+    int lid_last = 0;                                          // item index inside its problem (the slot of its partial tile) of the last decode
     auto decode = [&](int vb, int& pi, int& n0, int& k0, int& m_begin, int& m_end) __attribute__((always_inline)) -> bool {
         pi = group_find(g, vb);
         const TnProb& pr = g.p[pi];
         const int lid = xcd_chunked_id(vb - g.wg_begin[pi], g.wg_begin[pi + 1] - g.wg_begin[pi]);
+        lid_last = lid;
         const int tn_n = lid % pr.n_nt, tn_k = (lid / pr.n_nt) % pr.n_kt, tn_s = lid / (pr.n_nt * pr.n_kt);
         n0 = tn_n * BN; k0 = tn_k * BK;
         m_begin = tn_s * pr.rows_per_split;
@@ -96,116 +100,148 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
     if (wave >= 8) {
         // ============================================================================================ movers (waves 8-11)
         const int mt = t - 512;
-        int yrow[NPY], ycol[NPY], ypos[NPY], xrow[NPX], xcol[NPX], xpos[NPX];
+        // piece i of this thread: slab row (mt + 256 i) / PY, columns 4 ((mt + 256 i) % PY) .. + 3 (PX for the A image).  Only the LDS positions
+        // stay in registers; next_item() re-derives rows and columns from a laundered copy of mt (compile-time divisors: a few instructions per
+        // item) -- as loop invariants they would cost 22 registers of the 168 a wave has here
+        int ypos[NPY], xpos[NPX];
 #pragma unroll
         for (int i = 0; i < NPY; ++i) {
             const int p = mt + 256 * i;
-            yrow[i] = p / PY; ycol[i] = 4 * (p - yrow[i] * PY); ypos[i] = YI::at(yrow[i], ycol[i]);
+            ypos[i] = YI::at(p / PY, 4 * (p % PY));
         }
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
             const int p = mt + 256 * i;
-            xrow[i] = p / PX; xcol[i] = 4 * (p - xrow[i] * PX); xpos[i] = XI::at(xrow[i], xcol[i]);
+            xpos[i] = XI::at(p / PX, 4 * (p % PX));
         }
         // fetch cursor: item vb_f, slab s_f of nslab_f; runs three slabs ahead of the slab the matrix waves multiply
-        int vb_f = blockIdx.x - G, s_f = 0, nslab_f = 0, m_cur = 0, m_end_f = 0;
+        int vb_f = blockIdx.x - G, s_f = 0, nslab_f = 0;
         bool live = true;
-        unsigned y_off[NPY];                                   // byte offset of (row m_begin + yrow, column n0 + ycol) in dY
-        bool y_cok[NPY];
-        unsigned x_cb[NPX];                                    // byte offset of the piece's channel inside a source row
+        // Per-slab address work is kept to a few full-rate instructions per piece (round 5: the float-reciprocal row division, the row-range
+        // compares and four 32-bit integer multiplies per A piece had made the fetch as expensive as the staging arithmetic -- ~680 vector
+        // instructions per mover wave and slab, the movers then set the pace of the kernel):
+        //   * dY: the piece's offset is fixed per item (TW_OOB for columns past N) and the slab advances through the instruction's scalar
+        //     offset; rows past the item's range read ZERO because the buffer descriptor ends at the item's last row -- and with dY zero there
+        //     the A rows (and the ones column of the bias trick) need no row check at all: 0 x finite = 0;
+        //   * A: offset and row-in-batch advance by increments (one compare-and-select per slab for the batch wrap: windows have >= 32 rows
+        //     per batch on this path), the padding check (r * step + tap displacement inside [0, rows_in)) only for windows that have padding.
+        unsigned y_off[NPY];                                   // byte offset of (row m_begin + yrow, column n0 + ycol) in dY, or TW_OOB
+        unsigned x_off[NPX];                                   // byte offset of the piece for the cursor's slab (valid columns), advanced per slab
+        int x_r[NPX];                                          // its row inside the batch (before step / tap displacement)
         int x_tapd[NPX];                                       // tap row displacement
-        bool x_ok[NPX];
         int x_one = -1;                                        // 4 i + q: element q of X piece i is the ones column of this item (at most one piece of a thread holds column K), or -1
         unsigned y_slab_b = 0;                                 // bytes between slabs in dY
         const float* y_ptr = g.p[0].dY;
         const float* a_ptr = g.p[0].A.ptr;
-        unsigned y_bytes = 0, a_bytes = 0, rs4 = 0, a_bs4 = 0;
-        int a_rows_out = 1, a_rows_in = 0, a_step = 1;
-        float a_inv_ro = 1.f;
+        unsigned y_bytes = 0, a_bytes = 0, x_inc = 0, x_wrap = 0;
+        int a_rows_out = 32, a_rows_in = 0, a_step = 1;
+        bool a_pad = false;
         auto next_item = [&]() __attribute__((always_inline)) {
             int pi = 0, n0 = 0, k0 = 0, mb = 0, me = 0;        // (locals: a captured variable passed by reference here ends up in scratch memory)
             do {
                 vb_f += G;
                 if (vb_f >= total_items) { live = false; break; }
             } while (!decode(vb_f, pi, n0, k0, mb, me));
-            m_end_f = me;
             s_f = 0;
+            int mt_l = mt;
+            asm volatile("" : "+v"(mt_l));                       // (keeps the row / column arithmetic below inside this function)
             if (!live) {
 #pragma unroll
-                for (int i = 0; i < NPY; ++i) y_cok[i] = false;
+                for (int i = 0; i < NPY; ++i) y_off[i] = TW_OOB;
 #pragma unroll
-                for (int i = 0; i < NPX; ++i) x_ok[i] = false;
+                for (int i = 0; i < NPX; ++i) x_off[i] = TW_OOB;
                 x_one = -1;
-                m_cur = 0; m_end_f = 0;
+                y_slab_b = 0; x_inc = 0; x_wrap = 0;
                 return;
             }
             const TnProb& pr = g.p[pi];
             const Win A = pr.A;
-            nslab_f = (m_end_f - mb + 31) >> 5;
-            m_cur = mb;
+            nslab_f = (me - mb + 31) >> 5;
 #pragma unroll
             for (int i = 0; i < NPY; ++i) {
-                y_cok[i] = n0 + ycol[i] < pr.N;
-                y_off[i] = (unsigned)(((long)(mb + yrow[i]) * pr.ldy + n0 + ycol[i]) * 4);
+                const int p = mt_l + 256 * i, yrow = p / PY, ycol = 4 * (p % PY);
+                y_off[i] = n0 + ycol < pr.N ? (unsigned)(((long)(mb + yrow) * pr.ldy + n0 + ycol) * 4) : TW_OOB;
             }
             const bool bias_here = pr.dbias != nullptr && k0 <= A.K && A.K < k0 + BK;       // this tile holds the padding column K
             x_one = -1;
+            const unsigned rs4 = (unsigned)(A.rs * 4), bs4 = (unsigned)(A.bs * 4);
 #pragma unroll
             for (int i = 0; i < NPX; ++i) {
-                const int ak = k0 + xcol[i];
-                x_ok[i] = ak < A.K;
-                const int kc = x_ok[i] ? ak : 0;
+                const int p = mt_l + 256 * i, xrow = p / PX, xcol = 4 * (p % PX);
+                const int ak = k0 + xcol;
+                const bool cok = ak < A.K;
+                const int kc = cok ? ak : 0;
                 const int tap = kc / A.cw;
-                x_cb[i] = (unsigned)((kc - tap * A.cw) * 4);
                 x_tapd[i] = A.shift + tap * A.dil;
+                const int m = mb + xrow;
+                const int b = m / A.rows_out;
+                x_r[i] = m - b * A.rows_out;
+                // (unsigned wrap-around arithmetic: a row before the tensor's start gives an offset the padding check replaces anyway.  A
+                // column past K starts at TW_OOB: the increments of an item add up to less than the tensor's 2^31 bytes, so it stays past
+                // num_records for the item's life)
+                x_off[i] = cok ? (unsigned)b * bs4 + (unsigned)(x_r[i] * A.step + x_tapd[i]) * rs4 + (unsigned)((kc - tap * A.cw) * 4) : TW_OOB;
                 if (bias_here && ak <= A.K && A.K < ak + 4) x_one = 4 * i + (A.K - ak);
             }
             y_slab_b = (unsigned)(32 * pr.ldy * 4);
-            y_ptr = pr.dY; y_bytes = pr.y_bytes;
-            a_ptr = A.ptr; a_bytes = pr.a_bytes; rs4 = (unsigned)(A.rs * 4); a_bs4 = (unsigned)(A.bs * 4);
+            // dY's descriptor ends behind the item's last row: later rows of the last slab read zero
+            const long y_end = (long)me * pr.ldy * 4;
+            y_ptr = pr.dY; y_bytes = y_end < (long)pr.y_bytes ? (unsigned)y_end : pr.y_bytes;
+            a_ptr = A.ptr; a_bytes = pr.a_bytes;
             a_rows_out = A.rows_out; a_rows_in = A.rows_in; a_step = A.step;
-            a_inv_ro = 1.f / (float)A.rows_out;
+            x_inc = 32u * (unsigned)A.step * rs4;
+            x_wrap = bs4 - (unsigned)A.rows_out * (unsigned)A.step * rs4;                    // added when the row index wraps into the next batch
+            // padding anywhere in the window?  rows r * step + shift + tap * dil over r in [0, rows_out), tap in [0, K / cw)
+            const int taps = A.K / A.cw;
+            const long lo = (A.step >= 0 ? 0 : (long)(A.rows_out - 1) * A.step) + A.shift + (A.dil >= 0 ? 0 : (long)(taps - 1) * A.dil);
+            const long hi = (A.step >= 0 ? (long)(A.rows_out - 1) * A.step : 0) + A.shift + (A.dil >= 0 ? (long)(taps - 1) * A.dil : 0);
+            a_pad = lo < 0 || hi >= A.rows_in;
         };
         // TWO register sets of loads in flight (round 5).  Round 3's single set was staged at the top of a step and refilled right behind it: its
-        // loads had only the rest of that step to land, the ISA drained vmcnt down to 0 at the top of every step, and a step cost the staging
-        // arithmetic PLUS a memory round trip (3.4 us per 32-row slab against 1.4-1.6 us of matrix pipe).  Now slab n + 3 is fetched while slab
-        // n + 1 is staged: two full steps for the loads.  All addresses of a fetch are formed before its first load so that the loads issue
-        // back to back (a fixed number of vector-memory operations per step on every path: hipcc's static counts then come out exact).
+        // loads had only the rest of that step to land and the ISA drained vmcnt down to 0 at the top of every step.  Now slab n + 3 is fetched
+        // while slab n + 1 is staged: two full steps for the loads.  All addresses of a fetch are formed before its first load so that the loads
+        // issue back to back (a fixed number of vector-memory operations per step on every path: hipcc's static counts then come out exact).
         u32x4 gy[2][NPY], gx[2][NPX];
-        int one_el[2] = {-1, -1};                              // 4 i + q of the ones column for the slab the set was FETCHED for (-1: none, or its row lies past the item's range)
+        int one_el[2] = {-1, -1};                              // 4 i + q of the ones column for the item the set was FETCHED for (-1: none)
         auto fetch = [&](auto set_c) __attribute__((always_inline)) {
             constexpr int set = decltype(set_c)::value;
-            int oe = -1;
+            one_el[set] = x_one;
             const unsigned ysoff = (unsigned)__builtin_amdgcn_readfirstlane(s_f * (int)y_slab_b);
-            unsigned yo[NPY], xo[NPX];
+            unsigned xo[NPX];
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                xo[i] = x_off[i];
+                if (a_pad) {                                   // (wave-uniform)
+                    const int sr = __mul24(x_r[i], a_step) + x_tapd[i];
+                    xo[i] = (unsigned)sr < (unsigned)a_rows_in ? xo[i] : TW_OOB;
+                }
+                // advance to the next slab: 32 rows on, at most one batch wrap (rows_out >= 32: checked by the planner)
+                const int r2 = x_r[i] + 32;
+                const bool wrap = r2 >= a_rows_out;
+                x_r[i] = wrap ? r2 - a_rows_out : r2;
+                x_off[i] += x_inc + (wrap ? x_wrap : 0u);
+            }
+            const __amdgpu_buffer_rsrc_t yr = tw_rsrc(y_ptr, y_bytes), ar = tw_rsrc(a_ptr, a_bytes);
 #pragma unroll
             for (int i = 0; i < NPY; ++i) {
-                const bool ok = y_cok[i] & (m_cur + yrow[i] < m_end_f);
-                yo[i] = ok ? y_off[i] : TW_OOB;
+                if constexpr (ABL & 4) gy[set][i] = u32x4{0x3f800000u + (unsigned)lane, 0x40000000u, y_off[i] | 0x3f000000u, ysoff | 0x3e800000u};
+                else gy[set][i] = __builtin_amdgcn_raw_buffer_load_b128(yr, y_off[i], ysoff, 0);
             }
 #pragma unroll
             for (int i = 0; i < NPX; ++i) {
-                // (batch, row) of the piece's m: m / rows_out by a float reciprocal -- exact for m < 2^21 (the planner refuses longer reductions)
-                const int m = m_cur + xrow[i];
-                const int b = (int)(((float)m + 0.5f) * a_inv_ro);
-                const int r = m - b * a_rows_out;
-                const int sr = r * a_step + x_tapd[i];
-                const bool rin = m < m_end_f;
-                const bool ok = x_ok[i] & rin & ((unsigned)sr < (unsigned)a_rows_in);
-                xo[i] = ok ? (unsigned)b * a_bs4 + (unsigned)sr * rs4 + x_cb[i] : TW_OOB;
-                oe = (rin && (x_one >> 2) == i) ? x_one : oe;
+                if constexpr (ABL & 4) gx[set][i] = u32x4{0x3f800000u + (unsigned)lane, 0x40400000u, xo[i] | 0x3f000000u, 0x3e800000u};
+                else gx[set][i] = __builtin_amdgcn_raw_buffer_load_b128(ar, xo[i], 0, 0);
             }
-            one_el[set] = oe;
-            const __amdgpu_buffer_rsrc_t yr = tw_rsrc(y_ptr, y_bytes), ar = tw_rsrc(a_ptr, a_bytes);
-#pragma unroll
-            for (int i = 0; i < NPY; ++i) gy[set][i] = __builtin_amdgcn_raw_buffer_load_b128(yr, yo[i], ysoff, 0);
-#pragma unroll
-            for (int i = 0; i < NPX; ++i) gx[set][i] = __builtin_amdgcn_raw_buffer_load_b128(ar, xo[i], 0, 0);
-            m_cur += 32;
             if (live && ++s_f >= nslab_f) next_item();
         };
         auto stage = [&](auto set_c, int buf) __attribute__((always_inline)) {
             constexpr int set = decltype(set_c)::value;
+            if constexpr (ABL & 2) {                              // loaded values stay live (the loads must still be waited for), nothing else
+#pragma unroll
+                for (int i = 0; i < NPY; ++i) asm volatile("" :: "v"(gy[set][i]));
+#pragma unroll
+                for (int i = 0; i < NPX; ++i) asm volatile("" :: "v"(gx[set][i]));
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NPY; ++i) {
                 u32x2 o[NS];
@@ -259,15 +295,25 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
         bf16x8 fa[2][NS], fb[NS][TKT];
         auto load_fa = [&](bf16x8 (&f)[NS], int buf, int nt) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) f[s] = YI::frag(&ys[buf][s][0], wn * (16 * TNT) + nt * 16, r16, kq);
+            for (int s = 0; s < NS; ++s) {
+                if constexpr (ABL & 8) { u32x4 c4 = {0x3f803f80u + (unsigned)lane + nt, 0x3f003f00u + s, 0x3f803f80u, 0x3e803e80u + buf}; f[s] = __builtin_bit_cast(bf16x8, c4); }
+                else f[s] = YI::frag(&ys[buf][s][0], wn * (16 * TNT) + nt * 16, r16, kq);
+            }
         };
         auto load_fb = [&](int buf, auto kt_c) {
             constexpr int kt = decltype(kt_c)::value;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) fb[s][kt] = XI::frag(&xs[buf][s][0], wk * (16 * TKT) + kt * 16, r16, kq);
+            for (int s = 0; s < NS; ++s) {
+                if constexpr (ABL & 8) { u32x4 c4 = {0x3f803f80u + (unsigned)lane + kt, 0x3f003f00u + s, 0x3f803f80u, 0x3e803e80u + buf}; fb[s][kt] = __builtin_bit_cast(bf16x8, c4); }
+                else fb[s][kt] = XI::frag(&xs[buf][s][0], wk * (16 * TKT) + kt * 16, r16, kq);
+            }
         };
         auto mma = [&](const bf16x8 (&f)[NS], auto nt_c, auto kt_c) {       // the six significant partial products, smallest first
             constexpr int nt = decltype(nt_c)::value, kt = decltype(kt_c)::value;
+            if constexpr (ABL & 1) {                   // fragments stay live, no matrix instruction
+                asm volatile("" :: "v"(f[0]), "v"(f[NS - 1]), "v"(fb[0][kt]), "v"(fb[NS - 1][kt]));
+                return;
+            }
             f32x4 cc = acc[nt][kt];
             if constexpr (NS == 3) {
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], fb[0][kt], cc, 0, 0, 0);
@@ -338,14 +384,28 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
                 for (int j = 0; j < TKT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int nslab = (m_end - m_begin + 31) >> 5;
             for (int s = 0; s < nslab; ++s) slab();
-            // ---- combine: float atomics (or the split's partial tile) straight from the accumulators; column K of a biased problem is dbias
+            // ---- combine.  With a workspace (TnProb.partial): the accumulators leave AS THEY ARE -- 16-byte stores, a wave instruction covers
+            // 1 KB of contiguous memory -- into this item's slot [wave][nt][kt][lane][4] and tn_mw_reduce_kernel adds the splits of a tile in
+            // split order (fixed order: run-to-run reproducible) and scatters the sum into dW / dbias.  Round 5: the float-atomic combine below
+            // was 28 of the 116 us of a GRU layer's launch (tools/tn_mw_ablate.py: every item finishes at the same time and 7.4 M atomics meet
+            // in the L2s with nothing left to overlap them).  Without a workspace: float atomics straight from the accumulators; column K of
+            // a biased problem is dbias.
             const TnProb& pr = g.p[pi];
+            float* __restrict__ partial = pr.partial;
+            if (partial) {
+                if constexpr (!(ABL & 16)) {
+                    float* pt = partial + (long)lid_last * (BN * BK) + (long)wave * (TNT * TKT * 256) + lane * 4;
+#pragma unroll
+                    for (int nt = 0; nt < TNT; ++nt)
+#pragma unroll
+                        for (int kt = 0; kt < TKT; ++kt) *reinterpret_cast<f32x4*>(pt + (nt * TKT + kt) * 256) = acc[nt][kt];
+                }
+                continue;
+            }
             const int N = pr.N, K = pr.A.K, cw = pr.A.cw, out_kw = pr.out_kw;
             float* __restrict__ dW = pr.dW;
-            float* __restrict__ partial = pr.partial;
             float* __restrict__ dbias = pr.dbias;
             const long ldw = pr.ldw;
-            const int tn_s = m_begin / pr.rows_per_split;
 #pragma unroll
             for (int nt = 0; nt < TNT; ++nt)
 #pragma unroll
@@ -356,15 +416,49 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
                     for (int i = 0; i < 4; ++i) {
                         const int nrow = n0 + wn * (16 * TNT) + nt * 16 + kq * 4 + i;
                         if (nrow >= N) continue;
-                        if (kcol < K) {
-                            if (partial) partial[((long)tn_s * N + nrow) * K + kcol] = acc[nt][kt][i];
-                            else atomicAdd(&dW[(long)nrow * ldw + off], acc[nt][kt][i]);
-                        } else if (kcol == K && dbias) {
-                            atomicAdd(&dbias[nrow], acc[nt][kt][i]);
-                        }
+                        if constexpr (ABL & 16) { if (acc[nt][kt][i] == 1.2345e-30f) dW[0] = 1.f; continue; }
+                        if (kcol < K) atomicAdd(&dW[(long)nrow * ldw + off], acc[nt][kt][i]);
+                        else if (kcol == K && dbias) atomicAdd(&dbias[nrow], acc[nt][kt][i]);
                     }
                 }
         }
+    }
+}
+
+// Second pass of the workspace combine: one thread per 16-byte slot of a TILE's register image sums that slot over the tile's row splits in
+// split order (fp64, one rounding) and adds the four values into dW (rows 4 kq .. 4 kq + 3 of the MFMA tile, column r16: 64-byte segments per
+// 16 lanes) -- every output element has exactly one writer, so plain read-modify-writes.  Column K of a biased problem goes to dbias.
+struct TnMwSplits { int s[TG_MAX_GROUP]; int tile_begin[TG_MAX_GROUP + 1]; };
+template <int TNT, int TKT, int WNW, int WKW>
+__global__ __launch_bounds__(256) void tn_mw_reduce_kernel(const TnGroup g, const TnMwSplits sp) {
+    constexpr int BN = 16 * TNT * WNW, BK = 16 * TKT * WKW, SLOTS = BN * BK / 4, BPT = SLOTS / 256;      // 16-byte slots / workgroups per tile
+    static_assert(SLOTS % 256 == 0, "whole workgroups per tile");
+    const int tile = blockIdx.x / BPT, slot = (blockIdx.x % BPT) * 256 + threadIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < TG_MAX_GROUP; ++q) pi += (q < g.n && tile >= sp.tile_begin[q]) ? 1 : 0;
+    const TnProb& pr = g.p[pi];
+    const int tl = tile - sp.tile_begin[pi], n_tiles = pr.n_nt * pr.n_kt;
+    const int tn_n = tl % pr.n_nt, tn_k = tl / pr.n_nt;
+    const int wave = slot / (TNT * TKT * 64), rem = slot % (TNT * TKT * 64);
+    const int nt = rem / (TKT * 64), kt = (rem / 64) % TKT, lane = rem % 64;
+    const int wn = wave / WKW, wk = wave % WKW, r16 = lane & 15, kq = lane >> 4;
+    const float* __restrict__ src = pr.partial + (long)tl * (BN * BK) + (long)slot * 4;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int q = 0; q < sp.s[pi]; ++q) {                       // item (tile, split q) has index tl + n_tiles * q inside its problem
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)q * n_tiles * (BN * BK));
+        a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+    }
+    const float r[4] = {(float)a0, (float)a1, (float)a2, (float)a3};
+    const int kcol = tn_k * BK + wk * (16 * TKT) + kt * 16 + r16;
+    const int K = pr.A.K, cw = pr.A.cw, out_kw = pr.out_kw;
+    const long off = out_kw > 0 ? (long)(kcol % cw) * out_kw + kcol / cw : (long)kcol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int nrow = tn_n * BN + wn * (16 * TNT) + nt * 16 + kq * 4 + i;
+        if (nrow >= pr.N) continue;
+        if (kcol < K) pr.dW[(long)nrow * pr.ldw + off] += r[i];
+        else if (kcol == K && pr.dbias) pr.dbias[nrow] += r[i];
     }
 }
 
@@ -374,7 +468,7 @@ using namespace tg;
 
 // Plan for the mover-wave kernel, or false when the group should stay on gemm_tn_split_kernel.  Fills n_nt / n_kt / rows_per_split / extents
 // of every problem and the workgroup ranges; *grid receives the launch size.
-bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid) {
+bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid, const long* ws_floats) {
     static const int env_on = [] { const char* e = getenv("TG_TN_MW"); return e ? atoi(e) : 1; }();
     if (!env_on) return false;
     constexpr int BN = 192, BK = 160;
@@ -385,12 +479,11 @@ bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid) {
         constexpr int min_k = 100;      // K = 108: the GRU's first layer (68 % of a 160-wide tile)
         if (!p.vec_y || !p.vec_a || p.N % 4 != 0 || A.K % 4 != 0 || p.N < 150 || A.K < min_k || p.M < 2048) return false;
         if (p.dbias && A.K % BK == 0) return false;                               // no padding column for the ones trick
-        if (p.partial) return false;                                              // two-pass combines keep their own split plan (gemm.hip tn_plan)
-        if (A.bs < 0 || A.rs < 0 || A.rows_out <= 0 || p.ldy < p.N) return false;
+        if (A.bs < 0 || A.rs < 0 || A.rows_out < 32 || A.step < 0 || p.ldy < p.N) return false;           // (rows_out >= 32: one batch wrap per slab at most in the movers' row walk)
         const long batches = cdiv(p.M, A.rows_out);
         const long a_el = (batches - 1) * A.bs + (long)(A.rows_in - 1) * A.rs + A.cw;
         const long y_el = (long)(p.M - 1) * p.ldy + p.N;
-        if (a_el <= 0 || a_el >= (1l << 29) || y_el >= (1l << 29) || p.M >= (1 << 20)) return false;     // (M: the movers' reciprocal division)
+        if (a_el <= 0 || a_el >= (1l << 29) || y_el >= (1l << 29) || (long)A.rows_in * (A.step > 0 ? A.step : 1) >= (1l << 23)) return false;     // (rows: the movers' 24-bit multiply)
         p.a_bytes = (unsigned)(a_el * 4);
         p.y_bytes = (unsigned)(y_el * 4);
         tiles += (long)cdiv(p.N, BN) * cdiv(A.K, BK);
@@ -424,6 +517,8 @@ bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid) {
         p.rows_per_split = rows;
         splits_out[i] = cdiv(p.M, rows);
         p.n_nt = cdiv(p.N, BN); p.n_kt = cdiv(p.A.K, BK);
+        // workspace combine: every item of the problem owns one tile-sized slot
+        if (p.partial && ws_floats[i] < (long)p.n_nt * p.n_kt * splits_out[i] * (BN * BK)) return false;
         g.wg_begin[i] = wg;
         wg += (p.n_nt * p.n_kt * splits_out[i] + 7) / 8 * 8;
     }
@@ -432,7 +527,32 @@ bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid) {
     return true;
 }
 
+int tg_gemm_tn_mw_reduce_launch(const TnGroup& g, const int* splits, hipStream_t s) {
+    TnMwSplits sp;
+    int tiles = 0;
+    for (int i = 0; i < TG_MAX_GROUP; ++i) {
+        sp.s[i] = i < g.n ? splits[i] : 0;
+        sp.tile_begin[i] = tiles;
+        if (i < g.n) tiles += g.p[i].n_nt * g.p[i].n_kt;
+    }
+    sp.tile_begin[TG_MAX_GROUP] = tiles;
+    constexpr int BPT = 192 * 160 / 4 / 256;
+    hipLaunchKernelGGL((tn_mw_reduce_kernel<3, 5, 4, 2>), dim3(tiles * BPT), dim3(256), 0, s, g, sp);
+    return check_launch("tg_gemm_tn(mover waves, workspace combine)");
+}
+
 int tg_gemm_tn_mw_launch(const TnGroup& g, int grid, int splits, hipStream_t s) {
+#ifdef TG_LAB_ABLATE
+    {
+        const char* e = getenv("TG_TNMW_ABL");
+        const int abl = e ? atoi(e) : 0;
+        if (abl && splits == 3) {
+#define TG_ABL(A_) case A_: hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 3, A_>), dim3(grid), dim3(768), 0, s, g); return check_launch("tg_gemm_tn(mover waves, ablated)")
+            switch (abl) { TG_ABL(1); TG_ABL(2); TG_ABL(4); TG_ABL(6); TG_ABL(8); TG_ABL(9); TG_ABL(16); TG_ABL(14); TG_ABL(15); default: break; }
+#undef TG_ABL
+        }
+    }
+#endif
     if (splits == 3) hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 3>), dim3(grid), dim3(768), 0, s, g);
     else hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 1>), dim3(grid), dim3(768), 0, s, g);
     return check_launch("tg_gemm_tn(mover waves)");

@@ -306,7 +306,11 @@ def deterministic():
     return bool(_lib.load().tg_get_deterministic())
 
 
-def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None):
+import os as _os
+TN_MW_WS = _os.environ.get("TG_TN_MW_WS", "1") != "0"              # mover-wave weight gradients combine their row splits through a workspace + fixed-order second pass (not float atomics)
+
+
+def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None, force_ws=False):
     _f32(dY, "dY"); _f32(dW, "dW")
     assert dY.dim() == 2 and dY.stride(1) == 1 and dY.shape[0] == A.M, (dY.shape, A.M)
     M, N = dY.shape
@@ -316,7 +320,7 @@ def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None):
     if (M - 1) * dY.stride(0) + N - 1 >= _room(dY):
         raise ValueError("gemm_tn: dY exceeds its tensor")
     ws, nws = None, 0
-    if M >= TN_TWO_PASS_ROWS or (out_kw > 0 and M >= 1024 and N * A.K >= 8192) or deterministic():
+    if M >= TN_TWO_PASS_ROWS or (out_kw > 0 and M >= 1024 and N * A.K >= 8192) or deterministic() or force_ws:
         # two-pass (partial tiles + fp64 combine): long reductions for accuracy, and every conv-layout output (out_kw > 0) of >= 8 K entries
         # (the discriminator's 16 x 81 ... 8 x 24 conv gradients are a few hundred atomics: the combine launch cost more than it saved):
         # the permuted (Co, Ci, kw) scatter makes the one-pass float atomics uncoalesced (measured 224 -> 39 us on the audio
@@ -350,9 +354,7 @@ def _det_bias(problems):
 def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
     """dW[n, perm(k)] += sum_m dY[m, n] * A(m, k); dbias[n] += sum_m dY[m, n] when given.
     dY: 2-D view [M, N]; dW: contiguous, N rows of K floats."""
-    p, = _det_bias([dict(dY=dY, A=A, dW=dW, out_kw=out_kw, dbias=dbias)])
-    q, ws = _tn_problem(**p)
-    call("tg_gemm_tn_group", C.byref(q), 1, _stream())
+    gemm_tn_group([dict(dY=dY, A=A, dW=dW, out_kw=out_kw, dbias=dbias)])
     return dW
 
 
@@ -361,7 +363,15 @@ def gemm_tn_group(problems):
     assert 1 <= len(problems) <= _lib.MAX_GROUP
     problems = _det_bias(problems)
     keep = []
-    arr = (_lib.TnProblem * len(problems))(*[_tn_problem(keep=keep, **p)[0] for p in problems])
+    qs = [_tn_problem(keep=keep, **p)[0] for p in problems]
+    arr = (_lib.TnProblem * len(qs))(*qs)
+    if TN_MW_WS and not all(q.ws for q in qs) and all(q.M >= 2048 and q.N >= 150 for q in qs):
+        # a group the mover-wave kernel takes (csrc/gemm_tn_mw.hip): give every problem the workspace, so that its row splits are combined by
+        # the fixed-order second pass instead of float atomics (28 of 116 us of a GRU layer's launch, and the one order-dependent sum left
+        # on the default path's big weight gradients)
+        if int(_lib.load().tg_gemm_tn_kernel_plan(arr, len(qs))) == 2:
+            qs = [_tn_problem(keep=keep, force_ws=True, **p)[0] for p in problems]
+            arr = (_lib.TnProblem * len(qs))(*qs)
     call("tg_gemm_tn_group", arr, len(problems), _stream())
 
 
@@ -398,6 +408,30 @@ def _gru_cluster_ws(dev, B, H, bwd=False):
         ws = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev)
         _gru_ws[key] = ws
     return ws
+
+
+_cluster_caps = {}
+
+
+def gru_cluster_chunks(B, H, bwd=False):
+    """Row ranges [(row0, rows)] in which the cluster kernels walk a batch of B rows: one launch while it fits the chip (forward: 384 rows at
+    H = 300 -- 2 directions x 12 tiles of 32 rows x 10 workgroups; backward: 192), otherwise equal chunks of whole 32-row tiles run back to
+    back on ONE workspace (its flag words are numbered by generation, so a launch can follow another without a zero fill).  The recurrence
+    of a batch row never needs another row, so chunking changes nothing but the launch count: --batch 256 (768 stacked rows) stays on the
+    persistent kernels instead of falling to one launch per time step.  None when no chunk size is supported (H > 320, no device)."""
+    lib = _lib.load()
+    sup = lib.tg_gru_cluster_bwd_supported if bwd else lib.tg_gru_cluster_supported
+    if sup(int(B), int(H)):
+        return [(0, B)]
+    key = (int(H), bool(bwd), torch.cuda.current_device())
+    if key not in _cluster_caps:
+        _cluster_caps[key] = max([c for c in range(32, 1025, 32) if sup(c, int(H))], default=0)
+    cap = _cluster_caps[key]
+    if cap == 0:
+        return None
+    n = -(-B // cap)
+    per = -(-B // (32 * n)) * 32
+    return [(r, min(per, B - r)) for r in range(0, B, per)]
 
 
 _dpre_ws = {}             # (device, Bs) -> zero-initialised workspace of the fused discriminator front end (timeout word first)
@@ -494,15 +528,22 @@ def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None, save_rows=
         call("tg_gru_h64_forward", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
              B * T * 4 * H, _p(drop_mask), _p(y_drop), B, T, _stream())
         return y
-    if GRU_CLUSTER and H > 64 and _lib.load().tg_gru_cluster_supported(B, H):
+    chunks = gru_cluster_chunks(B, H) if (GRU_CLUSTER and H > 64) else None
+    if chunks is not None:
         if drop_mask is not None:
             _flat(drop_mask, "drop_mask"); _flat(y_drop, "y_drop")
             assert tuple(drop_mask.shape) == tuple(y.shape) == tuple(y_drop.shape)
-        ws = _gru_cluster_ws(gi.device, B, H)
         r0, rn = (0, B) if save_rows is None else (int(save_rows[0]), int(save_rows[1]))
         assert 0 <= r0 and rn >= 0 and r0 + rn <= B
-        call("tg_gru_forward_cluster_rows", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
-             B * T * 4 * H, _p(drop_mask), _p(y_drop), C.c_void_p(ws.data_ptr()), ws.numel() * 4, B, T, H, r0, rn, _stream())
+        ws = _gru_cluster_ws(gi.device, chunks[0][1], H)         # (the first chunk is the largest)
+        at = lambda t_, c0, row_floats: C.c_void_p(0) if t_ is None else C.c_void_p(t_.data_ptr() + 4 * c0 * row_floats)
+        for c0, cn in chunks:
+            # rows [c0, c0 + cn) of every operand; the direction strides stay those of the whole batch.  Gates are saved for the part of
+            # [r0, r0 + rn) that falls into the chunk
+            s0, s1 = max(r0, c0), min(r0 + rn, c0 + cn)
+            call("tg_gru_forward_cluster_rows", at(gi, c0, T * H3), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), at(y, c0, T * 2 * H),
+                 at(save, c0, T * 4 * H), B * T * 4 * H, at(drop_mask, c0, T * 2 * H), at(y_drop, c0, T * 2 * H), C.c_void_p(ws.data_ptr()), ws.numel() * 4,
+                 cn, T, H, max(0, s0 - c0), max(0, s1 - s0), _stream())
         return y
     assert drop_mask is None and y_drop is None, "fused dropout: H = 64 or the cluster kernels only"
     call("tg_gru_forward", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
@@ -530,12 +571,16 @@ def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None, dy
         call("tg_gru_h64_backward", _p(dy), _p(dy_mask), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
              _p(dgi), _p(dgh), nb * T * 3 * H, nb, T, _stream())
         return
-    if GRU_CLUSTER and H > 64 and _lib.load().tg_gru_cluster_bwd_supported(nb, H):
+    chunks = gru_cluster_chunks(nb, H, bwd=True) if (GRU_CLUSTER and H > 64) else None
+    if chunks is not None:
         if dy_mask is not None:
             _flat(dy_mask, "dy_mask"); assert tuple(dy_mask.shape) == tuple(dy.shape)
-        ws = _gru_cluster_ws(dy.device, nb, H, bwd=True)
-        call("tg_gru_backward_cluster", _p(dy), _p(dy_mask), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
-             _p(dgi), _p(dgh), nb * T * 3 * H, C.c_void_p(ws.data_ptr()), ws.numel() * 4, nb, T, H, _stream())
+        ws = _gru_cluster_ws(dy.device, chunks[0][1], H, bwd=True)
+        at = lambda t_, c0, row_floats: C.c_void_p(0) if t_ is None else C.c_void_p(t_.data_ptr() + 4 * c0 * row_floats)
+        for c0, cn in chunks:                                    # (row chunks of one workspace, as in gru_forward)
+            call("tg_gru_backward_cluster", at(dy, c0, T * 2 * H), at(dy_mask, c0, T * 2 * H), at(ys, c0, T * 2 * H), at(ss, c0, T * 4 * H), B * T * 4 * H,
+                 _p(w_hh_t[0]), _p(w_hh_t[1]), at(dgi, c0, T * 3 * H), at(dgh, c0, T * 3 * H), nb * T * 3 * H, C.c_void_p(ws.data_ptr()), ws.numel() * 4,
+                 cn, T, H, _stream())
         return
     assert dy_mask is None, "fused dropout backward: H = 64 or the cluster kernels only"
     call("tg_gru_backward", _p(dy), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),

@@ -132,11 +132,14 @@ def test_gru_layer_fwd_bwd(pkg, dev, B, T, H, Kin):
             assert rel(G2[f"gru.{k}"], v.grad) < 1e-4, k
 
 
-@pytest.mark.parametrize("B", [3, 37, 128, 384])
+@pytest.mark.parametrize("B", [3, 37, 128, 384, 768])
 def test_gru_cluster_kernels_match_step_launches(pkg, dev, B):
     """The persistent cluster-synchronised recurrence (csrc/gru_cluster.hip) against the per-step launches (csrc/gru.hip): same
     K-slicing and summation order, so they agree to rounding; a stale inter-workgroup hand-off would show as an O(1e-2) error.
-    Repeated on the same buffers (the L2s then hold the previous run's lines of the exchange buffer)."""
+    Repeated on the same buffers (the L2s then hold the previous run's lines of the exchange buffer).
+    (A hand-off soak, not the kernels' parity test: that comes from the B = 128 golden / trajectory tests, which assert the cluster kernels
+    ran.)  B = 768 = the stacked forward of --batch 256: two row chunks of 384 on one workspace (ops.gru_cluster_chunks), backward of a
+    256-row group as two chunks of 128."""
     ops = pkg.ops
     T, H = 34, 300
     g = torch.Generator().manual_seed(B)
@@ -154,7 +157,7 @@ def test_gru_cluster_kernels_match_step_launches(pkg, dev, B):
                 y = torch.full((B, T, 2 * H), float("nan"), device=dev)
                 sv = torch.full((2, B, T, 4 * H), float("nan"), device=dev)
                 ops.gru_forward(gi, w, b, y, sv)
-                nb = min(B, 128)                                   # backward of one 128-row group of the stacked forward
+                nb = min(B, 128) if B < 768 else 256               # backward of one group of the stacked forward
                 b0 = (B - nb) // 2
                 dgi = torch.full((2, nb, T, 3 * H), float("nan"), device=dev)
                 dgh = torch.full((2, nb, T, 3 * H), float("nan"), device=dev)
@@ -164,6 +167,8 @@ def test_gru_cluster_kernels_match_step_launches(pkg, dev, B):
             for a, c in zip(out[False], out[True]):
                 assert bool(torch.isfinite(c).all())
                 assert float((a - c).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), (B, rep)
+        if B == 768:
+            assert ops.gru_cluster_chunks(768, H) == [(0, 384), (384, 384)] and ops.gru_cluster_chunks(256, H, bwd=True) == [(0, 128), (128, 128)]
     finally:
         ops.GRU_CLUSTER = prev
 
@@ -931,19 +936,33 @@ def test_gemm_tn_mover_wave_kernel(pkg, dev):
     dgi = [(torch.randn(M, 3 * H, generator=g) * torch.pow(10.0, torch.randint(-3, 3, (M, 1), generator=g).float())).to(dev) for _ in range(2)]
     x = torch.randn(M, 2 * H, generator=g).to(dev)
     hp = torch.randn(M, H, generator=g).to(dev)
-    probs, refs = [], []
-    for d in range(2):
-        for A, Kc in ((x, 2 * H), (hp, H)):
-            dW = torch.randn(3 * H, Kc, generator=g).to(dev)
-            db = torch.randn(3 * H, generator=g).to(dev)
-            refs.append((dW.double() + dgi[d].double().t() @ A.double(), db.double() + dgi[d].double().sum(0)))
-            probs.append(dict(dY=dgi[d], A=Win.plain(A), dW=dW, dbias=db))
-    assert ops.tn_kernel_plan(probs) == 2
-    ops.gemm_tn_group(probs)
-    for p, (rw, rb) in zip(probs, refs):
-        e_w = float((p["dW"].double() - rw).abs().max() / rw.abs().max())
-        e_b = float((p["dbias"].double() - rb).abs().max() / rb.abs().max())
-        assert e_w < 1e-5 and e_b < 1e-5, (e_w, e_b)
+    # both combines of the row splits: workspace + fixed-order second pass (ops.TN_MW_WS, the default: two runs must agree bit for bit) and
+    # float atomics
+    prev = ops.TN_MW_WS
+    try:
+        for use_ws in (True, True, False):
+            ops.TN_MW_WS = use_ws
+            gq = torch.Generator().manual_seed(22)
+            probs, refs = [], []
+            for d in range(2):
+                for A, Kc in ((x, 2 * H), (hp, H)):
+                    dW = torch.randn(3 * H, Kc, generator=gq).to(dev)
+                    db = torch.randn(3 * H, generator=gq).to(dev)
+                    refs.append((dW.double() + dgi[d].double().t() @ A.double(), db.double() + dgi[d].double().sum(0)))
+                    probs.append(dict(dY=dgi[d], A=Win.plain(A), dW=dW, dbias=db))
+            assert ops.tn_kernel_plan(probs) == 2
+            ops.gemm_tn_group(probs)
+            for p, (rw, rb) in zip(probs, refs):
+                e_w = float((p["dW"].double() - rw).abs().max() / rw.abs().max())
+                e_b = float((p["dbias"].double() - rb).abs().max() / rb.abs().max())
+                assert e_w < 1e-5 and e_b < 1e-5, (use_ws, e_w, e_b)
+            if use_ws:
+                got = [(p["dW"].clone(), p["dbias"].clone()) for p in probs]
+                if "first" in locals():
+                    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(first, got)), "workspace combine is not reproducible"
+                first = got
+    finally:
+        ops.TN_MW_WS = prev
     # conv window with causal padding: dW[co][tap * Ci + ci] += sum_(b, t) dy[b][t][co] * x[b][t - (1 - tap) * d][ci]  (zero before the clip)
     B, T, C, d = 128, 34, 300, 4
     xs = torch.randn(B, T, C, generator=g).to(dev)
