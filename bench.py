@@ -514,6 +514,19 @@ def secondary_lines(pkg, a, device, cpu_train):
     # ---- configs[4]: FGD autoencoder training
     out["ae_train"] = measure_ae(pkg, make_args(), device, 128, 200, 20, cpu=cpu_train is not None, cpu_budget_s=3.0)
     pkg.ops.check_async_errors()
+    # ---- configs[2]'s code path on this one rank: graph segments + RCCL collectives (a world of one: every exchange still launches), in a
+    # child process because the queue configuration must be in the environment before the first HIP call.  Reported beside the plain rate so
+    # that the N = 1 point of a scaling curve is known to start from HERE, not from the headline
+    try:
+        env = dict(os.environ)
+        env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--force-ddp", "--steps", "60", "--warmup", "15", "--no-cpu-baseline",
+                            "--batch", str(a.batch)], env=env, capture_output=True, text=True, timeout=180)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        out["ddp_single_rank"] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "ddp": d.get("ddp"),
+                                  "config": {"workload": "the data-parallel code path (BASELINE.json configs[2]) on one rank: bench.py --force-ddp"}}
+    except Exception as e:                       # never fail the headline line over the secondary probe
+        out["ddp_single_rank"] = {"error": f"{type(e).__name__}: {e}"}
     out["wall_s"] = time.perf_counter() - t_all
     return out
 

@@ -14,8 +14,15 @@ import warnings
 import torch
 import torch.distributed as dist
 
-HW_QUEUES = int(os.environ.get("TG_DDP_HW_QUEUES", "8"))          # what configure_environment() asks for unless GPU_MAX_HW_QUEUES is already set
-HIGH_PRIORITY_STREAM = os.environ.get("TG_DDP_PRIO", "0") != "0"  # RCCL's stream created with high priority (its own hardware queue)
+# Hardware queues configure_environment() asks for unless GPU_MAX_HW_QUEUES is already set.  Round 5: 4 (the runtime's default) -- the audio
+# encoder's second stream in the forward only pays while both compute streams share a queue (engine._Engine.audio_fork: 8 queues replay the
+# two-branch graph at 8.6 ms), and on this software stack RCCL's stream does land on another queue than the compute stream's at 4 (the
+# {out, gru} bucket's kernel overlaps the next segment by 27 us, profiles/r5_g_q4_overlap.txt; round 4 had seen it in line and used 8).
+# Same box, one rank: plain 4.50 / 4 queues 4.81 / 8 queues 4.88 ms (profiles/r5_f_ddp.txt).  TG_DDP_HW_QUEUES=8 restores round 4's setting.
+HW_QUEUES = int(os.environ.get("TG_DDP_HW_QUEUES", "4"))
+# RCCL's stream created with high priority: measured WORSE (5.45 against 4.81 ms, profiles/r5_f_ddp.txt: a third queue class beside the two
+# compute streams); kept as a switch for other stacks
+HIGH_PRIORITY_STREAM = os.environ.get("TG_DDP_PRIO", "0") != "0"
 
 
 def configure_environment():
@@ -26,6 +33,12 @@ def configure_environment():
     queues every segment started ~10 us after the bucket's kernel had finished; with 8 it starts 35-40 us before.
     An explicitly exported GPU_MAX_HW_QUEUES is honoured (probes set it)."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(HW_QUEUES))
+    if os.environ.get("TG_DDP_CAPTURE", "0") != "0":
+        # collectives captured inside the iteration's hipGraph: torch's NCCL backend recycles the events of finished work through a cache, and
+        # an event last recorded inside a capture may come back for an EAGER collective (bench.py's closing barrier), where the watchdog's
+        # hipEventQuery on it aborts the process ("operation not permitted on an event last recorded in a capturing stream", rounds 3-4).
+        # Without the cache every work object owns its events.
+        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
 
 
 def process_group_options():

@@ -75,9 +75,12 @@ class GanTrainer:
         self.grad_sync = grad_sync          # ddp.GradSync or None
         if grad_sync is not None:
             # data parallel: the forward keeps the audio encoder on its second stream; in the backward the audio branch runs on the main stream
-            # BEHIND the {text, speaker} bucket's hand-over, so that bucket's all-reduce has the audio backward (~250 us) as its cover and a
-            # graph segment never ends with an un-joined branch
-            self.G.audio_fork_bwd = False
+            # BEHIND the {text, speaker} bucket's hand-over, so that bucket's all-reduce (30 MB with the word embedding) has the audio
+            # backward (~250 us) as its cover and a graph segment never ends with an un-joined branch.  TG_DDP_BWD_FORK=1: backward forked
+            # too -- {audio} and {text, speaker} then become final together and leave in ONE exchange with nothing left to cover it
+            # (GeneratorEngine.backward merges them); on one rank the two orders are level (4.90 / 4.91 ms against plain 4.63,
+            # profiles/r5_g_ddp.txt: what the fork saves, the exposed 31 MB exchange costs), with real peers the covered order wins
+            self.G.audio_fork_bwd = os.environ.get("TG_DDP_BWD_FORK", "0") != "0"
         self.keep_tape = False              # tests: keep the last stacked generator forward's tape in self.last_tape (holds its activations alive)
         self.last_tape = None
         self.prep = L.WeightPrep()          # transposed / packed weight operands, refreshed once per optimiser step

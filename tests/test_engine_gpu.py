@@ -916,8 +916,12 @@ def test_data_parallel_graph_segments_single_rank(pkg, dev, tmp_path):
             dist.destroy_process_group()
 
 
-def test_gradient_buckets_leave_in_backward_order_beside_the_backward(pkg, dev):
-    """Where the data-parallel trainer starts each gradient exchange (scripts/train.py:93-96 -> ddp.GradSync; SURVEY 8e: "as each bucket's
+@pytest.mark.parametrize("bwd_fork", [False, True])
+def test_gradient_buckets_leave_in_backward_order_beside_the_backward(pkg, dev, monkeypatch, bwd_fork):
+    """(bwd_fork = False, the default: the audio backward on the main stream behind the text bucket -- three generator buckets; True
+    (TG_DDP_BWD_FORK=1): the audio backward on the second stream beside the text encoder's, {audio} and {text, speaker} leave together as the
+    last exchange.)
+    Where the data-parallel trainer starts each gradient exchange (scripts/train.py:93-96 -> ddp.GradSync; SURVEY 8e: "as each bucket's
     gradients are final"): a recording stand-in for GradSync notes, at every sync action, how many C entry points the iteration had called
     so far.  {out, gru} must leave right behind the last backward recurrence of the generator -- BEFORE the text encoder's backward
     (tg_act_mask_bwd2, the weight-norm backward, the embedding scatter) and the audio encoder's -- {text, speaker} behind the embedding
@@ -938,16 +942,23 @@ def test_gradient_buckets_leave_in_backward_order_beside_the_backward(pkg, dev):
     def call(name, *a):
         calls.append(name)
         return orig(name, *a)
+    monkeypatch.setenv("TG_DDP_BWD_FORK", "1" if bwd_fork else "0")
     tr = pkg.GanTrainer(G, Dn, args, grad_sync=Recorder())
+    forked = bwd_fork and G.engine._audio_fork_on(bwd=True)
     pkg.ops.call = call
     try:
         tr.train_iter(11, text, audio, poses, vid).to_dict()
     finally:
         pkg.ops.call = orig
     kinds = [(m[0], m[1]) for m in marks]
-    assert kinds == [("all", None), ("bucket", ("out", "gru")), ("bucket", ("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder")),
-                     ("bucket_wait", ("audio_encoder",))], kinds
+    text_bucket = ("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder")
+    if forked:
+        assert kinds == [("all", None), ("bucket", ("out", "gru")), ("bucket_wait", ("audio_encoder",) + text_bucket)], kinds
+    else:
+        assert kinds == [("all", None), ("bucket", ("out", "gru")), ("bucket", text_bucket), ("bucket_wait", ("audio_encoder",))], kinds
     at = {m[1] or m[0]: m[2] for m in marks}
+    if forked:      # both buckets leave in the one last exchange
+        at[text_bucket] = at[("audio_encoder",)] = at[("audio_encoder",) + text_bucket]
     where = lambda name: [i for i, c in enumerate(calls) if c.startswith(name)]          # (tg_act_mask_bwd2 runs as tg_act_mask_bwd2_drop here)
     last = lambda name: max(where(name))
     first_after = lambda name, i0: min(i for i in where(name) if i >= i0)
@@ -961,7 +972,9 @@ def test_gradient_buckets_leave_in_backward_order_beside_the_backward(pkg, dev):
         assert where(name) and min(where(name)) > i_gru, (name, where(name), i_gru)
     i_text = at[("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder")]
     assert last("tg_embed_scatter_add") < i_text and last("tg_weight_norm_bwd_batch") < i_text and last("tg_speaker_bwd") < i_text
-    assert first_after("tg_wav_conv2_wgrad", 0) > i_text and last("tg_wav_conv2_wgrad") < at[("audio_encoder",)]
+    if not forked:
+        assert first_after("tg_wav_conv2_wgrad", 0) > i_text
+    assert last("tg_wav_conv2_wgrad") < at[("audio_encoder",)]
     n_between = i_text - i_gru
     print(f"{{out, gru}} leaves at launch {i_gru} of {len(calls)}; {n_between} launches of the text-encoder / speaker backward and "
           f"{at[('audio_encoder',)] - i_text} of the audio encoder's run beside it")
