@@ -220,53 +220,72 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
         if (cur >= 0 && cur < n_rows) atomicAdd(&dtable[cur * D + c], acc);
     }
 }
-// Deterministic form (tg_set_deterministic): the one-wave workgroup i owns index i.  If an earlier position holds the same id it does nothing;
-// otherwise it is the id's FIRST occurrence: the wave collects the later positions of that id IN ORDER (64 positions per ballot, 1 024 per LDS
-// list -- the padding id of a word batch occurs thousands of times) and adds those rows, in position order, to the table row: no atomics, one
-// writer per row, a fixed summation order.  D <= 512 (eight columns per lane).
+// Deterministic form (tg_set_deterministic): workgroup i (16 waves) owns index i.  If an earlier position holds the same id it does nothing;
+// otherwise it is the id's FIRST occurrence: wave 0 lists the positions of that id from i on, in order (64 positions per ballot, 1 024 per LDS
+// list -- the padding id of a word batch occurs thousands of times), wave w adds the rows of list entries w, w + 16, .. in that order, and the
+// sixteen partial rows are added in wave order into the table row: no atomics, one writer per row, a FIXED summation order (a tree of fixed
+// shape, not position order; round 5 -- the one-wave form walked the padding id's ~3 000 rows alone, 350 us per launch).  D <= 512.
 constexpr int SCATTER_DET_LIST = 1024;
-__global__ __launch_bounds__(64) void embed_scatter_det_kernel(const float* __restrict__ dout, const int64_t* __restrict__ idx,
-                                                               float* __restrict__ dtable, int n_idx, int D, int n_rows) {
+constexpr int SCATTER_DET_WAVES = 16;
+__global__ __launch_bounds__(64 * SCATTER_DET_WAVES) void embed_scatter_det_kernel(const float* __restrict__ dout, const int64_t* __restrict__ idx,
+                                                                                   float* __restrict__ dtable, int n_idx, int D, int n_rows) {
     __shared__ int pos[SCATTER_DET_LIST];
-    const int i = blockIdx.x, lane = threadIdx.x;
+    __shared__ float part[SCATTER_DET_WAVES][512];
+    __shared__ int s_n, s_next, s_skip;
+    const int i = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t id = idx[i];
-    if (id < 0 || id >= n_rows) return;
-    for (int j0 = 0; j0 < i; j0 += 64) {                  // an earlier occurrence owns the row
+    if (id < 0 || id >= n_rows) return;                   // (workgroup-uniform)
+    if (threadIdx.x == 0) s_skip = 0;
+    __syncthreads();
+    for (int j0 = 64 * w; j0 < i; j0 += 64 * SCATTER_DET_WAVES) {          // an earlier occurrence owns the row
         const int j = j0 + lane;
-        if (__any(j < i && idx[j] == id)) return;
+        if (__any(j < i && idx[j] == id)) { if (lane == 0) s_skip = 1; break; }
     }
+    __syncthreads();
+    if (s_skip) return;
     float acc[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = lane + 64 * q < D ? dout[(long)i * D + lane + 64 * q] : 0.f;
-    int j0 = i + 1;
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    int j0 = i;
     while (j0 < n_idx) {
-        int n = 0;                                        // the next (up to) 1 024 occurrences, in order
-        for (; j0 < n_idx && n + 64 <= SCATTER_DET_LIST; j0 += 64) {
-            const int j = j0 + lane;
-            const bool hit = j < n_idx && idx[j] == id;
-            const unsigned long long m = __ballot(hit);
-            if (hit) pos[n + __popcll(m & ((1ull << lane) - 1ull))] = j;
-            n += __popcll(m);
+        if (w == 0) {                                     // the next (up to) 1 024 occurrences, in order
+            int n = 0, j = j0;
+            for (; j < n_idx && n + 64 <= SCATTER_DET_LIST; j += 64) {
+                const int jj = j + lane;
+                const bool hit = jj < n_idx && idx[jj] == id;
+                const unsigned long long m = __ballot(hit);
+                if (hit) pos[n + __popcll(m & ((1ull << lane) - 1ull))] = jj;
+                n += __popcll(m);
+            }
+            if (lane == 0) { s_n = n; s_next = j; }
         }
         __syncthreads();
-        for (int q4 = 0; q4 < n; q4 += 4) {               // four independent row loads in flight per column; added in list order
-            float v[4][8];
+        const int n = s_n;
+        j0 = s_next;
+        for (int q2 = w; q2 < n; q2 += 2 * SCATTER_DET_WAVES) {           // two independent row loads in flight per column; added in list order
+            const long r0 = pos[q2], r1 = pos[min(q2 + SCATTER_DET_WAVES, n - 1)];
+            const bool has1 = q2 + SCATTER_DET_WAVES < n;
+            float v0[8], v1[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long r = pos[min(q4 + u, n - 1)];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[u][q] = (q4 + u < n && lane + 64 * q < D) ? dout[r * D + lane + 64 * q] : 0.f;
+            for (int q = 0; q < 8; ++q) {
+                const bool c = lane + 64 * q < D;
+                v0[q] = c ? dout[r0 * D + lane + 64 * q] : 0.f;
+                v1[q] = (c && has1) ? dout[r1 * D + lane + 64 * q] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] += v[u][q];
+            for (int q = 0; q < 8; ++q) { acc[q] += v0[q]; acc[q] += v1[q]; }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-        if (lane + 64 * q < D) dtable[id * D + lane + 64 * q] += acc[q];
+    for (int q = 0; q < 8; ++q) part[w][lane + 64 * q] = acc[q];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 64 * SCATTER_DET_WAVES) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < SCATTER_DET_WAVES; ++q) t += part[q][c];
+        dtable[id * D + c] += t;
+    }
 }
 
 __global__ void permute3_kernel(const float* __restrict__ in, float* __restrict__ out, int d0, int d1, int d2, int p0, int p1, int p2) {
@@ -892,7 +911,7 @@ int tg_embed_scatter_add(const float* dout, const int64_t* idx, float* dtable, i
     TG_REQUIRE(dout && idx && dtable && n_idx > 0 && D > 0 && n_rows > 0, "tg_embed_scatter_add: bad arguments");
     if (deterministic()) {
         TG_REQUIRE(D <= 512, "tg_embed_scatter_add (deterministic): D = %d > 512", D);
-        hipLaunchKernelGGL(embed_scatter_det_kernel, dim3(n_idx), dim3(64), 0, ST, dout, idx, dtable, n_idx, D, n_rows);
+        hipLaunchKernelGGL(embed_scatter_det_kernel, dim3(n_idx), dim3(64 * SCATTER_DET_WAVES), 0, ST, dout, idx, dtable, n_idx, D, n_rows);
         return check_launch("tg_embed_scatter_add(deterministic)");
     }
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(cdiv(n_idx, SCATTER_CHUNK)), dim3(256), 0, ST, dout, idx, dtable, n_idx, D, n_rows);

@@ -648,29 +648,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     if (rp == 0 && n < N) atomicAdd(&out[n], red[0][cidx] + red[1][cidx] + red[2][cidx] + red[3][cidx]);
 }
 
-// Deterministic column sums (tg_set_deterministic): one workgroup per 64 columns walks ALL rows (16 row lanes per column, fp64), the lanes'
-// sums meet in LDS in lane order; no split over workgroups, no atomics.
+// Deterministic column sums (tg_set_deterministic): one workgroup per CW columns walks ALL rows (1024 / CW row lanes per column, fp64: lane r adds
+// rows r, r + RL, .. in order), the lanes' sums meet in LDS in lane order; no split over workgroups, no atomics.  CW = 16 where 64-column
+// workgroups would leave the chip empty (N = 900: 15 workgroups took 23 us per launch, 57 take a quarter of that; 64-byte row segments).
+template <int CW>
 __global__ __launch_bounds__(1024) void colsum_det_kernel(const float* __restrict__ X, long ldx, int M, int N, float* __restrict__ out, int accumulate) {
-    __shared__ double red[16][64];
-    const int cidx = threadIdx.x & 63, rp = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + cidx;
+    constexpr int RL = 1024 / CW;
+    __shared__ double red[RL][CW];
+    const int cidx = threadIdx.x % CW, rp = threadIdx.x / CW;
+    const int n = blockIdx.x * CW + cidx;
     double s = 0.0;
     if (n < N) {
         int m = rp;
-        for (; m + 7 * 16 < M; m += 8 * 16) {             // eight independent loads in flight, added in row order
+        for (; m + 7 * RL < M; m += 8 * RL) {             // eight independent loads in flight, added in row order
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = X[(long)(m + 16 * u) * ldx + n];
+            for (int u = 0; u < 8; ++u) v[u] = X[(long)(m + RL * u) * ldx + n];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; m < M; m += 16) s += X[(long)m * ldx + n];
+        for (; m < M; m += RL) s += X[(long)m * ldx + n];
     }
     red[rp][cidx] = s;
     __syncthreads();
     if (rp == 0 && n < N) {
         double t = 0.0;
-        for (int q = 0; q < 16; ++q) t += red[q][cidx];
+        for (int q = 0; q < RL; ++q) t += red[q][cidx];
         out[n] = (accumulate ? out[n] : 0.f) + (float)t;
     }
 }
@@ -1029,7 +1032,8 @@ extern "C" int tg_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, floa
     TG_REQUIRE(X && out && M > 0 && N > 0 && ldx >= N, "tg_colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (deterministic()) {
-        hipLaunchKernelGGL(colsum_det_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, s, X, (long)ldx, M, N, out, accumulate);
+        if (cdiv(N, 64) >= 64 || M < 1024) hipLaunchKernelGGL(colsum_det_kernel<64>, dim3(cdiv(N, 64)), dim3(1024), 0, s, X, (long)ldx, M, N, out, accumulate);
+        else hipLaunchKernelGGL(colsum_det_kernel<16>, dim3(cdiv(N, 16)), dim3(1024), 0, s, X, (long)ldx, M, N, out, accumulate);
         return check_launch("tg_colsum(deterministic)");
     }
     if (!accumulate) {

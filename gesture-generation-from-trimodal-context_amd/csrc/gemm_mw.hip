@@ -299,7 +299,8 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                 dma(slot2);
                 if (n + 1 < total) stage(set_c, abuf);
                 fetch(set_c);
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPA + ND) : "memory");
+                if constexpr (ABL & 32) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPA + 2 * ND) : "memory");       // lab: the DMAs get one more step (results wrong)
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPA + ND) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 MW_TIMED_BARRIER();
                 asm volatile("" ::: "memory");
@@ -597,7 +598,7 @@ int tg_gemm_nt_mw_launch(NtGroup& g, int tm, int tn, int splits, hipStream_t s) 
         const int abl = e ? atoi(e) : 0;
         if (abl && tm == 4 && tn == 6 && splits == 3) {
 #define TG_ABL(A_) case A_: hipLaunchKernelGGL((gemm_nt_mw_kernel<4, 3, 2, 4, 3, A_>), grid, dim3(768), 0, s, g); return check_launch("tg_gemm_nt(mover waves, ablated)")
-            switch (abl) { TG_ABL(1); TG_ABL(2); TG_ABL(6); TG_ABL(8); TG_ABL(14); TG_ABL(15); TG_ABL(16); default: break; }
+            switch (abl) { TG_ABL(1); TG_ABL(2); TG_ABL(6); TG_ABL(8); TG_ABL(14); TG_ABL(15); TG_ABL(16); TG_ABL(32); TG_ABL(33); default: break; }
 #undef TG_ABL
         }
     }

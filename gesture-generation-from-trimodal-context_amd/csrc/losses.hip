@@ -262,10 +262,7 @@ __global__ __launch_bounds__(1024) void d_head_bwd_det_kernel(const float* __res
             a_b1 += dl1;
             if (lane < H) {
                 const long o = ((long)b * T + t) * (2 * H) + lane;
-                const float dv = dl1 * w1[lane];
                 a_w1 += dl1 * (y[o] + y[o + H]);
-                dy[o] = dv;
-                dy[o + H] = dv;
             }
         }
     }
@@ -360,6 +357,10 @@ int tg_d_head_bwd(const float* d_logit, const float* y, const float* l1, const f
     TG_REQUIRE((dw1 != nullptr) == (db1 != nullptr) && (dw1 != nullptr) == (dw2 != nullptr) && (dw1 != nullptr) == (db2 != nullptr),
                "tg_d_head_bwd: parameter gradients are all given or all NULL");
     if (dw1 && deterministic()) {
+        // the input gradient by the parallel kernel (no parameter gradients: nothing to combine), the four parameter gradients by ONE workgroup
+        // in a fixed summation order, no atomics (round 5: that workgroup used to write dy for the whole batch as well, 216 us)
+        hipLaunchKernelGGL(d_head_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, d_logit, y, l1, w1, w2, dy, (float*)nullptr,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, B, T, H);
         hipLaunchKernelGGL(d_head_bwd_det_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_logit, y, l1, w1, w2, dy, dw1, db1, dw2, db2, B, T, H);
         return check_launch("tg_d_head_bwd(deterministic)");
     }

@@ -361,8 +361,18 @@ def gemm_tn(dY, A: Win, dW, *, out_kw=0, dbias=None):
 def gemm_tn_group(problems):
     """Several independent weight gradients in ONE launch.  problems: list of dicts with the arguments of gemm_tn."""
     assert 1 <= len(problems) <= _lib.MAX_GROUP
-    problems = _det_bias(problems)
     keep = []
+    if deterministic() and TN_MW_WS and any(p.get("dbias") is not None for p in problems):
+        # deterministic mode: a group the mover-wave kernel takes WITH workspaces keeps its bias gradients in the product (column K of the
+        # tile, combined by the fixed-order second pass like every other column): no separate column-sum launch (50 of them, 23 us each,
+        # were the largest single cost of the mode)
+        qs = [_tn_problem(keep=keep, **p)[0] for p in problems]
+        arr = (_lib.TnProblem * len(qs))(*qs)
+        if all(q.ws for q in qs) and int(_lib.load().tg_gemm_tn_kernel_plan(arr, len(qs))) == 2:
+            call("tg_gemm_tn_group", arr, len(problems), _stream())
+            return
+        keep = []
+    problems = _det_bias(problems)
     qs = [_tn_problem(keep=keep, **p)[0] for p in problems]
     arr = (_lib.TnProblem * len(qs))(*qs)
     if TN_MW_WS and not all(q.ws for q in qs) and all(q.M >= 2048 and q.N >= 150 for q in qs):

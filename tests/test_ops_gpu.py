@@ -355,6 +355,65 @@ def test_embedding_gather_scatter(pkg, dev):
     assert rel(dt, ref) < 1e-5
 
 
+def test_deterministic_forms_match_the_default_ones(pkg, dev):
+    """tg_set_deterministic(1) swaps the float-atomic combines for fixed-order ones (csrc/elementwise.hip embed_scatter_det_kernel: sixteen
+    waves per first occurrence, partial rows added in wave order; csrc/losses.hip: the head's parameter gradients by one workgroup).  The
+    bit-identity test in test_trajectory_gpu.py only says that they are REPRODUCIBLE; here they are held to the same fp64 references as the
+    default forms -- a word batch's index pattern (a padding id that occurs thousands of times, ids that occur once), accumulation into a
+    non-zero table -- and run twice for bit-identity."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(77)
+    V, D, n = 2000, 300, 128 * 34
+    idx = torch.zeros(n, dtype=torch.int64)
+    hot = torch.randperm(n, generator=g)[:1300]
+    idx[hot] = torch.randint(4, V, (1300,), generator=g)
+    idx[5] = V - 1; idx[n - 1] = 7; idx[0] = 7
+    dout = torch.randn(n, D, generator=g)
+    base = torch.randn(V, D, generator=g)
+    ref = base.double().index_add_(0, idx, dout.double())
+    B, T, H = 256, 28, 64
+    y, l1 = torch.randn(B, T, 2 * H, generator=g).to(dev), torch.randn(B, T, generator=g).to(dev)
+    w1, w2 = torch.randn(H, generator=g).to(dev), torch.randn(T, generator=g).to(dev)
+    dl = torch.randn(B, generator=g).to(dev)
+    outs = {}
+    try:
+        for det in (False, True, True):
+            ops.set_deterministic(det)
+            dt = ops.embed_scatter_add(dout.to(dev), idx.to(dev), base.clone().to(dev))
+            assert rel(dt, ref) < 1e-5, det
+            gr = [torch.zeros(H, device=dev), torch.zeros(1, device=dev), torch.zeros(T, device=dev), torch.zeros(1, device=dev)]
+            dy = ops.d_head_bwd(dl, y, l1, w1, w2, torch.empty_like(y), gr)
+            if det and True in outs:
+                assert torch.equal(outs[True][0], dt) and all(torch.equal(a, b) for a, b in zip(outs[True][1], gr)) and torch.equal(outs[True][2], dy)
+            outs[det] = (dt, gr, dy)
+    finally:
+        ops.set_deterministic(False)
+    assert torch.equal(outs[False][2], outs[True][2])                       # the input gradient has no cross-workgroup sum: same bits
+    for a, b in zip(outs[False][1], outs[True][1]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (a, b)
+    # the head's parameter gradients against fp64
+    ys = (y[:, :, :H] + y[:, :, H:]).double()
+    dl1 = dl.double()[:, None] * w2.double()[None, :]
+    assert rel(outs[True][1][0], (dl1[:, :, None] * ys).sum((0, 1))) < 1e-5 and rel(outs[True][1][2], (dl.double()[:, None] * l1.double()).sum(0)) < 1e-5
+    assert rel(outs[True][1][1], dl1.sum().reshape(1)) < 1e-5 and rel(outs[True][1][3], dl.double().sum().reshape(1)) < 1e-5
+    # column sums (bias gradients outside the products): both workgroup shapes of the deterministic kernel, accumulate and overwrite
+    for M, N in ((4352, 900), (7168, 192), (300, 27), (5000, 4160)):
+        X = torch.randn(M, N + 3, generator=g).to(dev)[:, :N]
+        acc0 = torch.randn(N, generator=g).to(dev)
+        res = {}
+        for det in (False, True, True):
+            ops.set_deterministic(det)
+            try:
+                a = ops.colsum(X, acc0.clone(), accumulate=True)
+                b = ops.colsum(X, torch.full((N,), 7.0, device=dev), accumulate=False)
+            finally:
+                ops.set_deterministic(False)
+            assert rel(a, acc0.double() + X.double().sum(0)) < 1e-5 and rel(b, X.double().sum(0)) < 1e-5, (M, N, det)
+            if det and True in res:
+                assert torch.equal(res[True][0], a) and torch.equal(res[True][1], b)
+            res[det] = (a, b)
+
+
 def test_weight_norm_and_dgrad_pack(pkg, dev):
     ops = pkg.ops
     Co, Ci, kw = 300, 300, 2

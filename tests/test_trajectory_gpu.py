@@ -357,13 +357,16 @@ def test_full_size_trajectory_b128_dropout_on_matches_fp64_oracle(pkg, dev):
     assert int(dsd["pre_conv.1.num_batches_tracked"]) == 1 * n_warm + 3 * n_post
 
 
-def test_deterministic_mode_runs_are_bit_identical(pkg, dev):
+@pytest.mark.parametrize("B", [64, 128])
+def test_deterministic_mode_runs_are_bit_identical(pkg, dev, B):
     """tg_set_deterministic(1) (ops.set_deterministic): every cross-workgroup combine in a fixed order -- two-pass weight gradients, bias
     gradients by fixed-order column sums, one-writer embedding scatters, the generic forms of the two fused backward kernels that combine by
     float atomics.  Two runs of five hipGraph replays from the SAME state must leave bit-identical weights, gradients, Adam moments, BatchNorm
     buffers and RNG counters (the reference on CPU is reproducible given a seed); five eager iterations from that state land on the same
     bits as well (same kernels, same order)."""
-    V, S, B = 256, 9, 64
+    # (B = 128: the headline batch -- size-dependent kernel choices such as the two-launch BatchNorm and the cluster recurrences are the ones
+    # the benchmark runs)
+    V, S = 256, 9
     gst, dst = O.make_generator_state(7, V, S), O.make_discriminator_state(8)
     text, audio, vid, poses = (t.to(dev) for t in O.make_batch(11, B, V, S))
     pkg.ops.set_deterministic(True)

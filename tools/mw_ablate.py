@@ -24,8 +24,9 @@ outs = [torch.empty(M, N, device=dev) for _ in range(2)]
 probs = [dict(A=Win.plain(x), W=w, bias=None, out=o, w_planes=ops.split3_planes(w)) for w, o in zip(ws, outs)]
 assert ops.nt_kernel_plan(probs) == (2, 128, 192)
 names = {0: "full kernel", 1: "no MFMA", 2: "movers: no split, no LDS stores", 6: "movers: weight DMAs only", 8: "no weight DMAs",
-         14: "movers idle", 15: "barriers + fragment reads + epilogue", 16: "no epilogue traffic"}
-for abl in (0, 1, 2, 6, 8, 14, 15, 16, 0):
+         14: "movers idle", 15: "barriers + fragment reads + epilogue", 16: "no epilogue traffic", 32: "weight DMAs awaited one step later",
+         33: "no MFMA, weight DMAs awaited one step later"}
+for abl in (0, 1, 2, 6, 8, 14, 15, 16, 32, 33, 0):
     os.environ["TG_MW_ABL"] = str(abl)
     us = t(lambda: ops.gemm_nt_group(probs))
     print(f"ABL {abl:2d}  {names[abl]:50s} {us:7.1f} us", flush=True)
