@@ -93,6 +93,50 @@ def test_train_iter_odd_batch_sizes(pkg, dev, batch):
     assert worst < 1e-4, worst
 
 
+def test_batch_256_iteration_runs_on_chunked_cluster_recurrences(pkg, dev):
+    """--batch 256 (the batch cliff): the stacked generator forward is 768 rows, the differentiated group 256 -- beyond what ONE
+    cluster launch holds (384 / 192 rows).  The trainer's recurrences must then run as row chunks of the cluster kernels (ops.gru_cluster_chunks),
+    never as per-step launches, and the iteration must still match the fp64 oracle: losses, the generator's GRU / output-MLP gradients and the
+    discriminator's within 1e-4; the encoders below ReLU / LeakyReLU gates with the near-tie allowance (at this size a gate within rounding of
+    zero will sit on the other side somewhere: DESIGN.md section 7)."""
+    V, S, B = 512, 17, 256
+    gst0, dst0 = O.make_generator_state(3, V, S), O.make_discriminator_state(4)
+    text, audio, vid, poses = O.make_batch(321, B, V, S)
+    og, od = O.clone_state(gst0, torch.float64), O.clone_state(dst0, torch.float64)
+    rand = O.Rand(seed=4242)
+    oret, extra = O.train_iter_gan(og, od, {}, {}, 11, text, audio.double(), poses.double(), vid, rand, dict(O.HP), want_grads=True)
+    args, G, D = build_models(pkg, dev, gst0, dst0, V, S, make_args())
+    tr = pkg.GanTrainer(G, D, args)
+    names = []
+    orig = pkg.ops.call
+    def call(name, *a):
+        names.append(name)
+        return orig(name, *a)
+    pkg.ops.call = call
+    try:
+        ret = tr.train_iter(11, text.to(dev), audio.to(dev), poses.to(dev), vid.to(dev), inject=to_device_inject(rand.rec, dev)).to_dict()
+    finally:
+        pkg.ops.call = orig
+    pkg.ops.check_async_errors()
+    assert names.count("tg_gru_forward_cluster_rows") == 2 * 4 and names.count("tg_gru_backward_cluster") == 2 * 4      # two row chunks per layer
+    assert "tg_gru_forward" not in names and "tg_gru_backward" not in names
+    assert sorted(ret) == sorted(oret)
+    for k in oret:
+        assert abs(ret[k] - oret[k]) <= 1e-4 * max(abs(oret[k]), 1e-6), (k, ret[k], oret[k])
+    _, Gg, _ = tr.G.views()
+    _, Dg, _ = tr.D.views()
+    worst = 0.0
+    for mine, ref in ((Gg, extra["g_grads"]), (Dg, extra["d_grads"])):
+        for k, r in ref.items():
+            if r is None or k in ZERO_GRAD_KEYS:
+                continue
+            e = rel(mine[k], r)
+            below_gates = k.startswith("audio_encoder") or k.startswith("text_encoder")
+            assert e < (5e-3 if below_gates else 1e-4), (k, e)
+            worst = max(worst, 0.0 if below_gates else e)
+    print(f"B = 256 iteration on chunked cluster launches: worst gradient error outside the gated encoders {worst:.1e}")
+
+
 def test_train_iter_matches_reference_golden(pkg, dev):
     """Replays the dropout masks / eps / permutation recorded from the reference's own train_iter_gan run."""
     from test_oracle_golden import unpack_masks

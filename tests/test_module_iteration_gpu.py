@@ -153,3 +153,50 @@ def test_reference_iteration_order_through_module_api_matches_g2(pkg, dev, label
     n_d = int(D.state_dict()["pre_conv.1.num_batches_tracked"])
     assert (n_g, n_d) == ((3, 3) if epoch > 10 else (2, 1)), (n_g, n_d)
     print(f"module-API iteration ({label}): worst gradient error {worst:.1e}, worst post-step parameter error {step_worst:.1e} lr")
+
+
+def test_reference_iteration_order_through_module_api_full_size_g3(pkg, dev):
+    """The same call sequence at the benchmark's size against the reference's OWN B = 128 iteration (g3 fixture: epoch 11, every dropout off,
+    the reference's eps / permutation draws): the module API then runs the kernels of the headline number -- mover-wave GEMMs at 4 352 and
+    13 056... no stacking here: three separate 128-clip generator calls, the cluster recurrences at B = 128 -- under torch.optim.Adam.  Losses,
+    every gradient's norm and 64 sampled entries; audio-encoder tensors with the near-tie allowance of the engine-level g3 test."""
+    g = np.load(os.path.join(GOLDEN, "g3_train_b128.npz"), allow_pickle=False)
+    V, S, B = int(g["n_words"]), int(g["n_speakers"]), int(g["batch"])
+    gst, dst = O.make_generator_state(int(g["g_seed"]), V, S), O.make_discriminator_state(int(g["d_seed"]))
+    text, audio, vid, poses = (t.to(dev) for t in O.make_batch(int(g["batch_seed"]), B, V, S))
+    from harness import make_args
+    args, G, D = build_models(pkg, dev, gst, dst, V, S, make_args(dropout_prob=0.0))
+    G.train(); D.train()
+    ones = lambda *s: torch.ones(*s, device=dev)
+    for e in g["eps"]:
+        call = {"g.eps": torch.from_numpy(e).to(dev), "g.emb_drop": ones(B, 34, 300)}
+        for l in range(3):
+            call[f"g.gru.drop{l}"] = ones(B, 34, 600)
+        G._replay_draws.append(call)
+    for _ in range(3):
+        D._replay_draws.append({f"d.gru.drop{l}": ones(B, 28, 128) for l in range(3)})
+    g_opt = torch.optim.Adam(G.parameters(), lr=args.learning_rate, betas=(0.5, 0.999))
+    d_opt = torch.optim.Adam(D.parameters(), lr=args.learning_rate * args.discriminator_lr_weight, betas=(0.5, 0.999))
+    ret = gan_iteration_in_reference_order(args, 11, text, audio, poses, vid, G, D, g_opt, d_opt, torch.from_numpy(g["perm"]).to(dev))
+    pkg.ops.check_async_errors()
+    assert not G._replay_draws and not D._replay_draws
+    for k, v in zip(g["loss_keys"], g["loss_vals"]):
+        assert abs(ret[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, ret[k], v)
+    bad, worst = [], 0.0
+    for k, p in G.named_parameters():
+        if k in ZERO_GRAD_KEYS or "ggn/" + k not in g.files:
+            continue
+        gr = p.grad
+        e_n = abs(float(gr.double().norm()) - float(g["ggn/" + k])) / (float(g["ggn/" + k]) + 1e-30)
+        mine = gr.reshape(-1).cpu().numpy()[sample_idx(gr.numel(), 64)]
+        e_s = float(np.abs(mine - g["gg/" + k]).max()) / float(gr.abs().max())
+        tol_s, tol_n = (5e-3, 1e-3) if k.startswith("audio_encoder") else (1e-4, 1e-4)      # (LeakyReLU near-ties: test_engine_gpu's g3 test)
+        worst = max(worst, e_n if not k.startswith("audio_encoder") else 0.0)
+        if e_n > tol_n or e_s > tol_s:
+            bad.append((k, e_n, e_s))
+    assert not bad, bad
+    for sd, pre in ((G.state_dict(), "gp/"), (D.state_dict(), "dp/")):
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked") and pre + k in g.files:
+                assert int(v) == int(g[pre + k]), k
+    print(f"module-API iteration at B = 128 (g3): worst gradient-norm error outside the audio encoder {worst:.1e}")
