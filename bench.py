@@ -476,44 +476,62 @@ def secondary_lines(pkg, a, device, cpu_train):
     and cpu_baseline; everything here runs AFTER the headline's timed region."""
     out = {}
     t_all = time.perf_counter()
+
+    def guarded(name, fn):
+        """a secondary run must never cost the headline its line: its failure is reported in its own slot"""
+        try:
+            out[name] = fn()
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+
     # ---- configs[1], bf16 operand tier: same iteration, one bf16 MFMA per product in every big product (fp32 master weights, accumulators,
     # BatchNorm, Adam); a fresh trainer because the math mode is baked into a captured graph
-    pkg.ops.set_math_mode("bf16")
-    try:
-        args, G, Dn = build(pkg, device, seed=0)
-        tr = pkg.GanTrainer(G, Dn, args)
-        text, audio, poses, vid = synthetic_batch(a.batch, 1234, device)
-        step = pkg.GraphedGanStep(tr, a.epoch, text, audio, poses, vid, warmup_iters=2)
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize()
-        n = 40
-        t0 = time.perf_counter()
-        for _ in range(n):
-            losses = step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        ld = losses.to_dict()
-        assert all(v == v and abs(v) < 1e6 for v in ld.values()), ld
-        cps = a.batch * n / dt
-        out["train_bf16"] = {"metric": "training clips/sec (34-frame, 27-dim pose), post-warm-up GAN iteration", "value": cps, "unit": "clips/s", "n_gpus": 1,
-                             "steps": n, "warmup": 10, "ms_per_step": dt / n * 1e3, "dtype": "bf16",
-                             "config": {"workload": "multimodal_context GAN training iteration, bf16 operand tier (BASELINE.json configs[1] as written)",
-                                        "batch_per_gpu": a.batch, "hipgraph": True},
-                             "tolerance": "losses 2e-2, gradients 5e-2, FGD within 1 % of the fp32 tier (tests/test_engine_gpu.py bf16 tier tests)",
-                             "step_roofline": step_roofline(cps, a.epoch, "bf16"), "roofline": dominant_kernel_roofline(pkg, device, a.batch),
-                             "cpu_baseline": cpu_train, "losses": ld}
-        del step, tr
-    finally:
-        pkg.ops.set_math_mode("f32")
+    def bf16_tier():
+        pkg.ops.set_math_mode("bf16")
+        try:
+            args, G, Dn = build(pkg, device, seed=0)
+            tr = pkg.GanTrainer(G, Dn, args)
+            text, audio, poses, vid = synthetic_batch(a.batch, 1234, device)
+            step = pkg.GraphedGanStep(tr, a.epoch, text, audio, poses, vid, warmup_iters=2)
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            n = 40
+            t0 = time.perf_counter()
+            for _ in range(n):
+                losses = step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ld = losses.to_dict()
+            assert all(v == v and abs(v) < 1e6 for v in ld.values()), ld
+            cps = a.batch * n / dt
+            return {"metric": "training clips/sec (34-frame, 27-dim pose), post-warm-up GAN iteration", "value": cps, "unit": "clips/s", "n_gpus": 1,
+                    "steps": n, "warmup": 10, "ms_per_step": dt / n * 1e3, "dtype": "bf16",
+                    "config": {"workload": "multimodal_context GAN training iteration, bf16 operand tier (BASELINE.json configs[1] as written)",
+                               "batch_per_gpu": a.batch, "hipgraph": True},
+                    "tolerance": "losses 2e-2, gradients 5e-2, FGD within 1 % of the fp32 tier (tests/test_engine_gpu.py bf16 tier tests)",
+                    "step_roofline": step_roofline(cps, a.epoch, "bf16"), "roofline": dominant_kernel_roofline(pkg, device, a.batch),
+                    "cpu_baseline": cpu_train, "losses": ld}
+        finally:
+            pkg.ops.set_math_mode("f32")
+    guarded("train_bf16", bf16_tier)
     # ---- configs[3]: synthesis windows, 128 utterances in lock-step and the reference's single utterance
-    args, G, _ = build(pkg, device, seed=0)
-    G.eval()
-    out["decode_b128"] = measure_decode(pkg, args, G, device, 128, 60, 10, cpu=cpu_train is not None, cpu_budget_s=3.0)
-    out["decode_b1"] = measure_decode(pkg, args, G, device, 1, 100, 10, cpu=cpu_train is not None, cpu_budget_s=2.0)
+    def decode(batch, steps, budget):
+        args, G, _ = build(pkg, device, seed=0)
+        G.eval()
+        return measure_decode(pkg, args, G, device, batch, steps, 10, cpu=cpu_train is not None, cpu_budget_s=budget)
+    guarded("decode_b128", lambda: decode(128, 60, 3.0))
+    guarded("decode_b1", lambda: decode(1, 100, 2.0))
     # ---- configs[4]: FGD autoencoder training
-    out["ae_train"] = measure_ae(pkg, make_args(), device, 128, 200, 20, cpu=cpu_train is not None, cpu_budget_s=3.0)
-    pkg.ops.check_async_errors()
+    guarded("ae_train", lambda: measure_ae(pkg, make_args(), device, 128, 200, 20, cpu=cpu_train is not None, cpu_budget_s=3.0))
+    try:
+        pkg.ops.check_async_errors()
+    except Exception as e:
+        out["async_error"] = str(e)
     # ---- configs[2]'s code path on this one rank: graph segments + RCCL collectives (a world of one: every exchange still launches), in a
     # child process because the queue configuration must be in the environment before the first HIP call.  Reported beside the plain rate so
     # that the N = 1 point of a scaling curve is known to start from HERE, not from the headline
@@ -702,7 +720,10 @@ def main():
         plain = (world == 1 and grad_sync is None and a.dtype == "f32" and a.epoch > 10 and not (a.no_graph or a.host_input or a.host_records or a.deterministic))
         if plain and not a.no_secondary and not a.no_cpu_baseline:
             del step
-            out["secondary"] = secondary_lines(pkg, a, device, out.get("cpu_baseline"))
+            try:
+                out["secondary"] = secondary_lines(pkg, a, device, out.get("cpu_baseline"))
+            except Exception as e:               # (every item inside is guarded too: the headline line never depends on a secondary run)
+                out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         line = json.dumps(out)
     finish(line, world > 1 or a.force_ddp)
 
