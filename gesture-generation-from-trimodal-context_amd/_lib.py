@@ -121,6 +121,7 @@ SIGNATURES = {
     "tg_gan_g_loss": [P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32, F32, I32, P, P, P, P, P, P, P],
     "tg_d_head_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, P],
     "tg_d_head_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
+    "tg_d_head_step": [P] * 17 + [I32, I32, F32, F32, I32, I32, P],
     "tg_l1_mean": [P, P, I64, P, P],
     "tg_sigmoid": [P, P, I64, P],
     "tg_sigmoid_bwd": [P, P, P, I64, P],
@@ -131,7 +132,7 @@ SIGNATURES = {
     "tg_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, P, P],
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

@@ -318,6 +318,121 @@ __global__ __launch_bounds__(256) void d_head_bwd_kernel(const float* __restrict
     }
 }
 
+// Head forward + the GAN loss terms of the clips + head backward in ONE launch (train_gan.py:36-41 and :55-57,86-88 over
+// multimodal_context_net.py:243-252): the clip's logit is all its loss term and d_logit need (both GAN losses are means of per-clip terms),
+// so the three launches d_head_fwd / loss / d_head_bwd have no cross-clip dependency except the scalar loss itself, which -- when asked
+// for -- the LAST workgroup to finish sums in a fixed order (terms[], the arrival counter resets itself).  Rows [0, nb) are scored as
+// "should be real" (term log(s + 1e-8), d_logit = -scale_real s (1 - s) / (s + 1e-8)), rows [nb, B) as "should be fake" (log(1 - s + 1e-8),
+// +scale_fake ...): the discriminator step has B = 2 nb and both scales 1 / nb, the generator step B = nb and scale_real = w_gan / B.
+// dw1 == NULL: input gradient only (the generator step; deterministic mode adds the parameter gradients with d_head_bwd_det_kernel from
+// the l1 / d_logit written here).
+__device__ __forceinline__ float wave_allsum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(1024) void d_head_step_kernel(const float* __restrict__ y, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ l1,
+                                                            float* __restrict__ logit, float* __restrict__ prob, float* __restrict__ d_logit,
+                                                            float* __restrict__ terms, float* __restrict__ out, unsigned* __restrict__ counter,
+                                                            float* __restrict__ dy, float* __restrict__ dw1, float* __restrict__ db1,
+                                                            float* __restrict__ dw2, float* __restrict__ db2, int B, int nb, float scale_real, float scale_fake, int T,
+                                                            int H) {
+    // 1024 threads = 4 clips x 4 waves; wave q of a clip owns frames q, q + 4, ... (<= 8 of them), lane j hidden unit j.  (One wave per clip
+    // walking all T frames measured 19.6 us: ~4 000 dependent instructions on one wave; here a wave runs ~1/8 of that.)
+    __shared__ float s_l[4][32], s_w1[16][64], s_b1[16], s_dl[4], sh[4];
+    __shared__ unsigned s_last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = wv >> 2, q = wv & 3, b = blockIdx.x * 4 + c;
+    const bool on = b < B, jn = lane < H;
+    const float w1j = jn ? w1[lane] : 0.f;
+    const float w2t = lane < T ? w2[lane] : 0.f;
+    const long row = (long)b * T * (2 * H) + lane;
+    float ya[8], yc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                              // every load of the wave in flight before the first use
+        const int t = q + 4 * i;
+        const bool ld = on && jn && t < T;
+        ya[i] = ld ? y[row + t * 2 * H] : 0.f;
+        yc[i] = ld ? y[row + t * 2 * H + H] : 0.f;
+    }
+    if (lane < 8) s_l[c][q + 4 * lane] = 0.f;                  // (frames beyond T)
+    const float b1v = b1[0];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int t = q + 4 * i;
+        ya[i] += yc[i];                                        // the direction sum, kept for the backward half
+        if (t < T) {                                           // (uniform)
+            const float p = wave_allsum(ya[i] * w1j) + b1v;
+            if (lane == 0) { s_l[c][t] = p; if (on) l1[(long)b * T + t] = p; }
+        }
+    }
+    __syncthreads();
+    const float l1_mine = lane < 32 ? s_l[c][lane] : 0.f;      // lane t: the frame's logit
+    const float lg = wave_allsum(l1_mine * w2t) + b2[0];
+    const float s = sigmoidf_(lg);
+    const bool real = b < nb;
+    const float term = real ? logf(s + 1e-8f) : logf(1.f - s + 1e-8f);
+    const float dl = !on ? 0.f : real ? -scale_real * s * (1.f - s) / (s + 1e-8f) : scale_fake * s * (1.f - s) / (1.f - s + 1e-8f);
+    if (on && q == 0 && lane == 0) {
+        logit[b] = lg; prob[b] = s; d_logit[b] = dl;
+        // written through to memory (agent scope) and awaited below: the last workgroup may run on another XCD, whose L2 is a different one.
+        // (No __threadfence(): at agent scope it writes back every dirty L2 line of the XCD -- dy included -- and cost 10+ us per launch.)
+        __hip_atomic_store(&terms[b], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float a_w1 = 0.f, a_b1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int t = q + 4 * i;
+        const float dl1 = dl * __shfl(w2t, t & 31, 64);        // (w2t is 0 beyond T)
+        a_b1 += dl1;
+        a_w1 += dl1 * ya[i];
+        if (on && jn && t < T) {
+            const float dv = dl1 * w1j;
+            dy[row + t * 2 * H] = dv;
+            dy[row + t * 2 * H + H] = dv;
+        }
+    }
+    if (dw1) {                                                 // (uniform)
+        s_w1[wv][lane] = a_w1;
+        if (lane == 0) { s_b1[wv] = a_b1; if (q == 0) s_dl[c] = dl; }
+    }
+    __builtin_amdgcn_s_waitcnt(0);                             // terms[] of this workgroup at memory before its arrival is counted
+    __syncthreads();
+    if (dw1 && wv == 0) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t1 += s_w1[k][lane];
+        if (lane < 32)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t2 += s_dl[k] * s_l[k][lane];
+        if (lane < H) atomicAdd(&dw1[lane], t1);
+        if (lane < T) atomicAdd(&dw2[lane], t2);
+        if (lane == 0) {
+            float u = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) u += s_b1[k];
+            atomicAdd(db1, u);
+            atomicAdd(db2, s_dl[0] + s_dl[1] + s_dl[2] + s_dl[3]);
+        }
+    }
+    if (!out) return;                                          // (uniform) the caller sums terms[] itself
+    if (threadIdx.x == 0) s_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;                                       // (uniform)
+    float sum = 0.f;                                           // the summation order of gan_d_loss_kernel (256 threads, then 4 wave sums)
+    if (threadIdx.x < 256)
+        for (int i = threadIdx.x; i < nb; i += 256) {
+            sum += __hip_atomic_load(&terms[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (nb + i < B) sum += __hip_atomic_load(&terms[nb + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    sum = wave_sum(sum);
+    if (lane == 0 && wv < 4) sh[wv] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = -(sh[0] + sh[1] + sh[2] + sh[3]) / (float)nb;
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -367,6 +482,21 @@ int tg_d_head_bwd(const float* d_logit, const float* y, const float* l1, const f
     hipLaunchKernelGGL(d_head_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, d_logit, y, l1, w1, w2, dy, dw1, db1, dw2, db2, B,
                        T, H);
     return check_launch("tg_d_head_bwd");
+}
+int tg_d_head_step(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, float* l1, float* logit, float* prob,
+                   float* d_logit, float* terms, float* out, uint32_t* counter, float* dy, float* dw1, float* db1, float* dw2, float* db2,
+                   int32_t n_rows, int32_t n_real, float scale_real, float scale_fake, int32_t T, int32_t H, void* stream) {
+    TG_REQUIRE(y && w1 && b1 && w2 && b2 && l1 && logit && prob && d_logit && terms && (out == nullptr || counter) && dy && n_rows > 0 &&
+                   n_real > 0 && n_real <= n_rows && T > 0 && T <= 32 && H > 0 && H <= 64, "tg_d_head_step: bad arguments (T <= 32, H <= 64, 0 < n_real <= n_rows)");
+    TG_REQUIRE((dw1 != nullptr) == (db1 != nullptr) && (dw1 != nullptr) == (dw2 != nullptr) && (dw1 != nullptr) == (db2 != nullptr),
+               "tg_d_head_step: parameter gradients are all given or all NULL");
+    const bool det = dw1 && deterministic();
+    hipLaunchKernelGGL(d_head_step_kernel, dim3(cdiv(n_rows, 4)), dim3(1024), 0, (hipStream_t)stream, y, w1, b1, w2, b2, l1, logit, prob, d_logit,
+                       terms, out, counter, dy, det ? nullptr : dw1, det ? nullptr : db1, det ? nullptr : dw2, det ? nullptr : db2, n_rows, n_real,
+                       scale_real, scale_fake, T, H);
+    if (det)       // parameter gradients by ONE workgroup in a fixed order (as tg_d_head_bwd does in this mode)
+        hipLaunchKernelGGL(d_head_bwd_det_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_logit, y, l1, w1, w2, dy, dw1, db1, dw2, db2, n_rows, T, H);
+    return check_launch("tg_d_head_step");
 }
 int tg_l1_mean(const float* a, const float* b, int64_t n, float* out, void* stream) {
     TG_REQUIRE(a && b && out && n > 0, "tg_l1_mean: bad arguments");

@@ -1170,6 +1170,30 @@ def d_head_bwd(d_logit, y, l1, w1, w2, dy, grads=None):
     return dy
 
 
+_head_step_counter = {}        # device -> the zero word tg_d_head_step counts its workgroups' arrivals in (the kernel leaves it at zero)
+
+
+def d_head_step(y, w1, b1, w2, b2, n_real, scale_real, scale_fake, out=None, grads=None):
+    """ConvDiscriminator head forward + per-clip GAN loss terms + head backward in ONE launch (tg_d_head_step).  y [n_rows, T, 2H]: rows
+    [0, n_real) scored as real, the rest as fake.  Discriminator step (train_gan.py:36-41): y = [real ; fake], n_real = B, both scales 1 / B.
+    Generator step (:55-57, 86-88): n_real = n_rows = B, scale_real = loss_gan_weight / B, grads None.
+    Returns dict(l1, logit, prob, d_logit, terms, dy); the loss is -terms.sum() / n_real -- written to out[0] when out is given (serial
+    last-workgroup tail in the kernel), else left to the caller.  grads = (dw1, db1, dw2, db2) accumulate, or None."""
+    _flat(y, "y"); n_rows, T, H2 = y.shape; H = H2 // 2
+    assert 0 < n_real <= n_rows and w1.numel() == H and b1.numel() == 1 and w2.numel() == T and b2.numel() == 1 and H <= 64 and T <= 32
+    dev = y.device
+    key = (dev.type, dev.index)
+    if key not in _head_step_counter:
+        _head_step_counter[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    e = lambda *shape: torch.empty(*shape, device=dev)
+    o = dict(l1=e(n_rows, T), logit=e(n_rows, 1), prob=e(n_rows, 1), d_logit=e(n_rows), terms=e(n_rows), dy=e(n_rows, T, H2))
+    g = (None,) * 4 if grads is None else tuple(_flat(t, "grad") for t in grads)
+    call("tg_d_head_step", _p(y), _p(_flat(w1, "w1")), _p(b1), _p(_flat(w2, "w2")), _p(b2), _p(o["l1"]), _p(o["logit"]), _p(o["prob"]),
+         _p(o["d_logit"]), _p(o["terms"]), _p(None if out is None else _flat(out, "out")), _p(_head_step_counter[key]), _p(o["dy"]), _p(g[0]),
+         _p(g[1]), _p(g[2]), _p(g[3]), n_rows, int(n_real), float(scale_real), float(scale_fake), T, H, _stream())
+    return o
+
+
 def l1_mean(a, b, out):
     call("tg_l1_mean", _p(a), _p(b), _same(a, b), _p(_flat(out, "out")), _stream()); return out
 

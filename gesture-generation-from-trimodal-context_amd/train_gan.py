@@ -11,6 +11,7 @@ Same order of operations and the same losses as the reference; what changes is t
     deferred read (StepLosses.to_dict()).
 With static shapes the whole iteration is captured into a hipGraph (GraphedGanStep).
 """
+import math
 import os
 
 import torch
@@ -37,7 +38,8 @@ class StepLosses:
             ret["DIV_REG"] = hp["loss_reg_weight"] * g[2]
         if self.post:
             ret["gen"] = hp["loss_gan_weight"] * g[3]
-            ret["dis"] = float(self.d.item())
+            d = self.d.tolist()       # dis_error itself (separate loss kernel), or the 2 B per-clip log terms of the fused discriminator head
+            ret["dis"] = float(d[0]) if len(d) == 1 else -math.fsum(d) / (len(d) // 2)
         return ret
 
 
@@ -61,6 +63,8 @@ def _stack_inject(inject, tags, prefix):
 
 
 class GanTrainer:
+    FUSED_D_HEAD = os.environ.get("TG_D_HEAD_FUSED", "1") != "0"      # the discriminator step's head + loss + head backward as one launch
+
     def __init__(self, generator, discriminator, args, grad_sync=None):
         self.gen, self.dis = generator, discriminator
         self.G, self.D = generator.engine, discriminator.engine
@@ -185,12 +189,20 @@ class GanTrainer:
         D, B = self.D, st["B"]
         D.slab.ensure().zero_grad()
         self._assert_no_pending_exchange()                    # the fused front-end kernels (csrc/d_preconv.hip) meet at device-wide barriers
-        dres = D.forward(st["d_in"], training=True, groups=2, save=True, inject=_stack_inject(inject, ["d_real", "d_fake"], "d"), tag="d")
-        logit = dres["logit"].view(-1)
-        d_logit = torch.empty_like(logit)
-        st["d_scalar"] = torch.empty(1, device=logit.device)
-        ops.gan_d_loss(logit[:B], logit[B:], st["d_scalar"], d_logit[:B], d_logit[B:])
-        D.backward(dres["tape"], d_logit.view(-1, 1), b0=0, nb=2 * B, param_grads=True)
+        if self.FUSED_D_HEAD:
+            # head forward + the clips' loss terms (:41) + head backward in one launch: dis_error is a mean of per-clip terms of the clip's own
+            # logit; the mean itself is taken when the losses are read (StepLosses.to_dict)
+            dres = D.forward(st["d_in"], training=True, groups=2, save=True, inject=_stack_inject(inject, ["d_real", "d_fake"], "d"), tag="d",
+                             head_step=(B, 1.0 / B, 1.0 / B, True))
+            st["d_scalar"] = dres["terms"]
+            D.backward(dres["tape"], None, b0=0, nb=2 * B, param_grads=True)
+        else:
+            st["d_scalar"] = torch.empty(1, device=st["d_in"].device)
+            dres = D.forward(st["d_in"], training=True, groups=2, save=True, inject=_stack_inject(inject, ["d_real", "d_fake"], "d"), tag="d")
+            logit = dres["logit"].view(-1)
+            d_logit = torch.empty_like(logit)
+            ops.gan_d_loss(logit[:B], logit[B:], st["d_scalar"], d_logit[:B], d_logit[B:])
+            D.backward(dres["tape"], d_logit.view(-1, 1), b0=0, nb=2 * B, param_grads=True)
         self._sync("all", D.slab)
         self.d_opt.step(counter_advanced=True)
 
@@ -201,7 +213,11 @@ class GanTrainer:
         G.slab.ensure().zero_grad()
         out2 = st["out2"].contiguous()
         self._assert_no_pending_exchange()
-        dres = D.forward(out2, training=True, groups=1, save=post, inject=inject, tag="d_out")   # runs in warm-up too (:55)
+        # after warm-up the head's backward for the generator's GAN term (:57, 86-88) runs inside the head's forward launch (its d_logit
+        # depends on the clip's own logit only); the loss kernel below still reads the logits for the gen_error scalar
+        fused_head = post and self.FUSED_D_HEAD
+        dres = D.forward(out2, training=True, groups=1, save=post, inject=inject, tag="d_out",   # runs in warm-up too (:55)
+                         head_step=(B, hp["loss_gan_weight"] / B, 0.0, False) if fused_head else None)
         d_out = torch.empty_like(out2)
         d_logit = torch.empty(B, device=dev)
         st["g_scalars"] = torch.empty(5, device=dev)
@@ -220,7 +236,8 @@ class GanTrainer:
         if not speaker_terms:
             d_mu = d_lv = None
         if post:
-            D.backward(dres["tape"], d_logit.view(B, 1), param_grads=False, need_dposes=True, dposes_into=d_out)      # d_out += dD/dposes (:86-88)
+            D.backward(dres["tape"], None if fused_head else d_logit.view(B, 1), param_grads=False, need_dposes=True,
+                       dposes_into=d_out)                                                                 # d_out += dD/dposes (:86-88)
         self._assert_no_pending_exchange()                    # the generator's backward recurrences come next
         # the audio encoder's bucket is the backward's last (engine.GeneratorEngine.backward): launched and awaited in ONE action, so that a
         # segmented graph is cut once there, not twice around an empty segment

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 5
+#define TG_ABI_VERSION 6
 
 int tg_version(void);
 
@@ -533,6 +533,18 @@ int tg_d_head_fwd(const float* y, const float* w1, const float* b1, const float*
                   int32_t B, int32_t T, int32_t H, void* stream);
 int tg_d_head_bwd(const float* d_logit, const float* y, const float* l1, const float* w1, const float* w2, float* dy, float* dw1, float* db1,
                   float* dw2, float* db2, int32_t B, int32_t T, int32_t H, void* stream);
+
+/* Head forward, per-clip GAN loss terms and head backward in ONE launch: what tg_d_head_fwd + (tg_gan_d_loss | the d_logit part of
+ * tg_gan_g_loss) + tg_d_head_bwd compute in three.  y [n_rows][T][2H]; rows [0, n_real) are scored as real -- term = log(s + 1e-8),
+ * d_logit = -scale_real s (1 - s) / (s + 1e-8) -- and rows [n_real, n_rows) as fake -- log(1 - s + 1e-8), +scale_fake s (1 - s) / (1 - s + 1e-8).
+ * Discriminator step (train_gan.py:36-41): the stacked batch [real ; fake], n_rows = 2 n_real, both scales 1 / n_real, dis_error =
+ * -sum(terms) / n_real.  Generator step (:55-57, 86-88): n_rows = n_real = B, scale_real = loss_gan_weight / B (0 in warm-up), no parameter
+ * gradients, gen_error = -sum(terms) / B.  terms [n_rows]; out[0] = -sum(terms) / n_real summed by the last workgroup in the order of
+ * tg_gan_d_loss, or out == NULL: the caller sums terms itself (saves the serial tail); counter (needed with out): one zero-initialised
+ * device word the kernel leaves at zero (never shared by launches that may run concurrently).  dw1/db1/dw2/db2 accumulate (all NULL: none). */
+int tg_d_head_step(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, float* l1, float* logit, float* prob,
+                   float* d_logit, float* terms, float* out, uint32_t* counter, float* dy, float* dw1, float* db1, float* dw2, float* db2,
+                   int32_t n_rows, int32_t n_real, float scale_real, float scale_fake, int32_t T, int32_t H, void* stream);
 
 /* out[0] = mean |a - b| over n elements (F.l1_loss, train.py:282). */
 int tg_l1_mean(const float* a, const float* b, int64_t n, float* out, void* stream);

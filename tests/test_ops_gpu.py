@@ -414,6 +414,67 @@ def test_deterministic_forms_match_the_default_ones(pkg, dev):
             res[det] = (a, b)
 
 
+@pytest.mark.parametrize("nb,step", [(128, "d"), (5, "d"), (1, "d"), (128, "g"), (7, "g")])
+def test_head_and_gan_loss_terms_in_one_launch(pkg, dev, nb, step):
+    """tg_d_head_step (head forward + per-clip GAN loss terms + head backward, multimodal_context_net.py:243-252 under train_gan.py:36-41
+    for the discriminator step's stacked [real ; fake] batch and :55-57,86-88 for the generator step) against fp64 autograd of the same
+    expression and against the three launches it replaces; twice on the same arrival counter (the kernel must leave it at zero), with and
+    without the in-kernel loss scalar, and in deterministic mode (parameter gradients by the fixed-order kernel)."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(900 + nb)
+    T, H, w_gan = 28, 64, 5.0
+    n_rows = 2 * nb if step == "d" else nb
+    y = torch.randn(n_rows, T, 2 * H, generator=g)
+    w1, b1 = torch.randn(H, generator=g) * 0.2, torch.randn(1, generator=g)
+    w2, b2 = torch.randn(T, generator=g) * 0.2, torch.randn(1, generator=g)
+    yd, pr = y.double().requires_grad_(True), [t.double().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    l1_ref = (yd[:, :, :H] + yd[:, :, H:]) @ pr[0] + pr[1]
+    logit_ref = l1_ref @ pr[2] + pr[3]
+    p_ref = torch.sigmoid(logit_ref)
+    if step == "d":
+        loss_ref = -torch.mean(torch.log(p_ref[:nb] + 1e-8) + torch.log(1 - p_ref[nb:] + 1e-8))          # dis_error (:41)
+        loss_ref.backward()
+        scales = (1.0 / nb, 1.0 / nb)
+    else:
+        loss_ref = -torch.mean(torch.log(p_ref + 1e-8))                                                  # gen_error (:57), weighted in the total (:86)
+        (w_gan * loss_ref).backward()
+        scales = (w_gan / nb, 0.0)
+    loss_ref = float(loss_ref.detach())
+    yg, (w1g, b1g, w2g, b2g) = y.to(dev), [t.to(dev) for t in (w1, b1, w2, b2)]
+    l1_s, logit_s, prob_s = ops.d_head_fwd(yg, w1g, b1g, w2g, b2g)                                       # the separate launches
+    if step == "d":
+        out_s, dl_s = torch.empty(1, device=dev), torch.empty(2 * nb, device=dev)
+        ops.gan_d_loss(logit_s.view(-1)[:nb], logit_s.view(-1)[nb:], out_s, dl_s[:nb], dl_s[nb:])
+        assert abs(float(out_s) - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
+    runs = []
+    try:
+        for det in (False, False, True, True):
+            ops.set_deterministic(det)
+            base = [torch.full((H,), 0.5, device=dev), torch.full((1,), -1.0, device=dev), torch.zeros(T, device=dev), torch.zeros(1, device=dev)]
+            gr = [t.clone() for t in base] if step == "d" else None
+            out = torch.full((1,), 7.0, device=dev)
+            o = ops.d_head_step(yg, w1g, b1g, w2g, b2g, nb, scales[0], scales[1], out, gr)
+            assert rel(o["l1"], l1_ref.detach()) < 1e-5 and rel(o["logit"].view(-1), logit_ref.detach()) < 1e-5 and rel(o["prob"].view(-1), p_ref.detach()) < 1e-5
+            assert abs(float(out) - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref)), (float(out), loss_ref, det)
+            assert abs(-math.fsum(o["terms"].tolist()) / nb - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
+            assert rel(o["dy"], yd.grad) < 1e-5
+            assert rel(o["l1"], l1_s.double()) < 1e-5
+            if step == "d":
+                for got, b0, ref in zip(gr, base, (t.grad for t in pr)):
+                    assert rel(got - b0, ref.reshape(got.shape)) < 2e-5, det       # accumulated onto what the gradient slab held
+                assert rel(o["d_logit"], dl_s.double()) < 1e-5
+            o2 = ops.d_head_step(yg, w1g, b1g, w2g, b2g, nb, scales[0], scales[1], None, None)     # no scalar, input gradient only
+            assert all(torch.equal(o[k], o2[k]) for k in o)
+            runs.append((o, gr, out))
+    finally:
+        ops.set_deterministic(False)
+    for a, b in ((runs[0], runs[1]), (runs[2], runs[3])):
+        assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and torch.equal(a[2], b[2])      # (also: the counter was left at zero)
+    if step == "d":
+        assert all(torch.equal(x, z) for x, z in zip(runs[2][1], runs[3][1]))                     # deterministic mode: same bits twice
+    assert torch.equal(runs[0][0]["dy"], runs[2][0]["dy"])
+
+
 def test_weight_norm_and_dgrad_pack(pkg, dev):
     ops = pkg.ops
     Co, Ci, kw = 300, 300, 2
