@@ -519,13 +519,15 @@ __global__ __launch_bounds__(1024) void iter_head_kernel(uint64_t* rng_a, uint64
     if (blockIdx.x == 0) {
         __shared__ uint64_t keys[1024];
         __shared__ int perm_sh[1024];
+        __shared__ uint64_t s_rng[2];
         const int i = threadIdx.x;
         if (i == 0) {
-            if (rng_a) rng_a[1] += 1;
+            // rng_a's new step reaches the other threads of this workgroup through LDS (a __threadfence() here wrote back the XCD's dirty L2
+            // lines -- the previous iteration's optimiser step -- at the head of the iteration's critical path)
+            if (rng_a) { s_rng[0] = rng_a[0]; s_rng[1] = rng_a[1] + 1; rng_a[1] = s_rng[1]; }
             if (rng_b) rng_b[1] += 1;
             if (cnt_a) *cnt_a += 1;
             if (cnt_b) *cnt_b += 1;
-            __threadfence();
         }
         __syncthreads();
         if (!vid_s) return;
@@ -535,8 +537,7 @@ __global__ __launch_bounds__(1024) void iter_head_kernel(uint64_t* rng_a, uint64
             } else {
                 if (i < B) {
                     uint32_t r[4];
-                    const uint64_t seed = __hip_atomic_load(rng_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint64_t step = __hip_atomic_load(rng_a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the value thread 0 just wrote
+                    const uint64_t seed = s_rng[0], step = s_rng[1];          // the step thread 0 just wrote
                     philox4x32(seed, (uint64_t)i, perm_site, (uint32_t)step, r);
                     keys[i] = ((uint64_t)r[0] << 32) | r[1];
                 }

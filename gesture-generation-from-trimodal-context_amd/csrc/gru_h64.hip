@@ -268,6 +268,40 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
         };
         using s0 = std::integral_constant<int, 0>;
         using s1 = std::integral_constant<int, 1>;
+        // lab (ABL bit 7): what would the NEXT layer's input projection cost if the movers took it?  72 MFMAs per mover wave and step on the
+        // record of step t - 2 (96 of the next layer's 384 gate rows x K = 64), 144 VGPRs of resident weight fragments, six 16-byte stores
+        bf16x8 pw[6][2][NS];
+        const int pr16 = lane & 15, pkq = lane >> 4;
+        if constexpr (ABL & 128) {
+#pragma unroll
+            for (int tl = 0; tl < 6; ++tl)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const float* p = whh0 + (long)((((wave - 4) * 6 + tl) * 16 + pr16) % 192) * HS + 32 * ks + 8 * pkq;
+                    split8_ns<NS>(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), pw[tl][ks]);
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) pin_fragment(pw[tl][ks][sp]);
+                }
+        }
+        auto project = [&](int buf, int step_o) {
+            if constexpr (ABL & 128) {
+                const int tau_o = dir ? T - 1 - step_o : step_o;
+                const float* rec = &obuf[buf][pr16 & (RW - 1)][(DROP ? HS : 0) + 8 * pkq];
+                bf16x8 fbp[2][NS];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    split8_ns<NS>(*reinterpret_cast<const f32x4*>(rec + 32 * ks), *reinterpret_cast<const f32x4*>(rec + 32 * ks + 4), fbp[ks]);
+                const int rowg = min((int)blockIdx.x * RW + (pr16 & (RW - 1)), B - 1);
+                float* dst = save + dir * save_ds + ((long)rowg * T + tau_o) * (4 * HS) + 4 * pkq;
+#pragma unroll
+                for (int tl = 0; tl < 6; ++tl) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) acc = mma_ns<NS>(pw[tl][ks], fbp[ks], acc);
+                    if (pr16 < RW) *reinterpret_cast<f32x4*>(dst + 16 * tl) = acc;
+                }
+            }
+        };
         load_step(s0{}, 0);
         stage(s0{}, 0);                                                      // operands of step 0
         load_step(s1{}, 1);                                                  // set 1 <- step 1 (staged during step 0)
@@ -284,6 +318,7 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
                 load_step(set_c, t + 3);
                 flush(t & 1, t > 1 ? t - 2 : 0);
                 __builtin_amdgcn_sched_barrier(0);
+                project(t & 1, t > 1 ? t - 2 : 0);
             }
             lds_barrier();
         };
@@ -766,7 +801,7 @@ extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const 
                 switch (abl) {
                     TG_H64_ABL_CASE(1) TG_H64_ABL_CASE(2) TG_H64_ABL_CASE(4) TG_H64_ABL_CASE(8) TG_H64_ABL_CASE(16) TG_H64_ABL_CASE(32) TG_H64_ABL_CASE(64)
                     TG_H64_ABL_CASE(96) TG_H64_ABL_CASE(3) TG_H64_ABL_CASE(6) TG_H64_ABL_CASE(7) TG_H64_ABL_CASE(15) TG_H64_ABL_CASE(31) TG_H64_ABL_CASE(30)
-                    TG_H64_ABL_CASE(9) TG_H64_ABL_CASE(22)
+                    TG_H64_ABL_CASE(9) TG_H64_ABL_CASE(22) TG_H64_ABL_CASE(128)
                     default: break;
                 }
 #undef TG_H64_ABL_CASE

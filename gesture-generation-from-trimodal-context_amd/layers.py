@@ -400,9 +400,9 @@ class GRUTape:
     __slots__ = ("x", "y", "save", "masks", "B", "T", "H")
 
 
-def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save=False, inject=None, tag="g", save_rows=None):
+def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save=False, inject=None, tag="g", save_rows=None, drawn=None):
     """Multi-layer bidirectional GRU.  x: (B, T, Kin) contiguous.  P: name -> parameter tensor.
-    Returns (y_last (B,T,2H), tape)."""
+    Returns (y_last (B,T,2H), tape).  drawn: the (n_layers - 1, B, T, 2H) fused inter-layer dropout masks drawn by the caller beforehand."""
     B, T, _ = x.shape
     tape = GRUTape()
     tape.x, tape.y, tape.save, tape.masks = [], [], [], []
@@ -411,8 +411,9 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     # the inter-layer dropout rides in the recurrence kernels (csrc/gru_h64.hip, csrc/gru_cluster_x3.hip): the masks of all layers of
     # the pass come from ONE draw launch (or from the parity tests)
     fused_drop = ops.gru_fused_dropout(B, H) and training and n_layers > 1 and (p_drop > 0 or inject is not None)
-    drawn = None
-    if fused_drop and p_drop > 0 and not (inject is not None and all(f"{tag}.gru.drop{l}" in inject for l in range(n_layers - 1))):
+    if drawn is not None:
+        assert fused_drop and tuple(drawn.shape) == (n_layers - 1, B, T, 2 * H)
+    if drawn is None and fused_drop and p_drop > 0 and not (inject is not None and all(f"{tag}.gru.drop{l}" in inject for l in range(n_layers - 1))):
         drawn = ops.dropout_mask(empty(n_layers - 1, B, T, 2 * H, like=x), p_drop, rng.state, rng.site(f"{tag}.gru.drop"))
     for l in range(n_layers):
         Kin = cur.shape[2]

@@ -64,6 +64,7 @@ def _stack_inject(inject, tags, prefix):
 
 class GanTrainer:
     FUSED_D_HEAD = os.environ.get("TG_D_HEAD_FUSED", "1") != "0"      # the discriminator step's head + loss + head backward as one launch
+    EARLY_SIDE_WORK = os.environ.get("TG_EARLY_SIDE_WORK", "1") != "0"   # gradient zeroing + discriminator dropout draws on the forward's audio fork
 
     def __init__(self, generator, discriminator, args, grad_sync=None):
         self.gen, self.dis = generator, discriminator
@@ -172,13 +173,26 @@ class GanTrainer:
                                              permute_last=speaker and self.use_reg, perm_in=perm_in, perm_site=G.rng.site("perm"),
                                              row_floats=G.in_size,         # the seed poses land in the GRU input rows directly
                                              target_copy=d_in[:B] if post else None)
+        # launches of the later phases that depend on nothing but the RNG state -- zeroing both gradient slabs, the discriminator's dropout
+        # draws -- go out on the generator forward's forked audio branch (bandwidth-sized kernels beside the text encoder's products); without
+        # that fork (data-parallel schedule, text-only contexts) the phases issue them themselves, where the chain used to wait for them
+        early = {}
+        def side_work():
+            G.slab.ensure().zero_grad()
+            if post:
+                D.slab.ensure().zero_grad()
+            if inject is None:
+                early["d_out"] = D.draw_drop_masks(B, "d_out")
+                if post:
+                    early["d"] = D.draw_drop_masks(2 * B, "d")
         res = G.forward(pre_s, text_s, in_audio.float(), vid_s, training=True, groups=ng, save=True,
                         inject=_stack_inject(inject, tags, "g"), tag="g", save_rows=(i2 * B, B),     # only call g2 is differentiated (:50-88)
-                        out_into=d_in[B:] if post else None)
+                        out_into=d_in[B:] if post else None, side_work=side_work if self.EARLY_SIDE_WORK else None)
+        early["zeroed"] = res.get("side_work_ran", False)
         if self.keep_tape:
             self.last_tape = res["tape"]
         sl = lambda t, i: None if t is None else t[i * B:(i + 1) * B]
-        st = dict(B=B, target=target, res=res, i2=i2, ng=ng, out2=sl(res["out"], i2), out3=sl(res["out"], ng - 1),
+        st = dict(B=B, target=target, res=res, i2=i2, ng=ng, early=early, out2=sl(res["out"], i2), out3=sl(res["out"], ng - 1),
                   z2=sl(res["z"], i2), z3=sl(res["z"], ng - 1), mu2=sl(res["mu"], i2), lv2=sl(res["logvar"], i2))
         if post:
             st["d_in"] = d_in[:2 * B]                                   # [target ; out1]: D(real) first, then D(fake.detach())
@@ -187,18 +201,20 @@ class GanTrainer:
     # ---- phase 2: discriminator step (train_gan.py:27-43)
     def phase_d_step(self, st, inject):
         D, B = self.D, st["B"]
-        D.slab.ensure().zero_grad()
+        if not st["early"]["zeroed"]:
+            D.slab.ensure().zero_grad()
         self._assert_no_pending_exchange()                    # the fused front-end kernels (csrc/d_preconv.hip) meet at device-wide barriers
         if self.FUSED_D_HEAD:
             # head forward + the clips' loss terms (:41) + head backward in one launch: dis_error is a mean of per-clip terms of the clip's own
             # logit; the mean itself is taken when the losses are read (StepLosses.to_dict)
             dres = D.forward(st["d_in"], training=True, groups=2, save=True, inject=_stack_inject(inject, ["d_real", "d_fake"], "d"), tag="d",
-                             head_step=(B, 1.0 / B, 1.0 / B, True))
+                             head_step=(B, 1.0 / B, 1.0 / B, True), drop_masks=st["early"].get("d"))
             st["d_scalar"] = dres["terms"]
             D.backward(dres["tape"], None, b0=0, nb=2 * B, param_grads=True)
         else:
             st["d_scalar"] = torch.empty(1, device=st["d_in"].device)
-            dres = D.forward(st["d_in"], training=True, groups=2, save=True, inject=_stack_inject(inject, ["d_real", "d_fake"], "d"), tag="d")
+            dres = D.forward(st["d_in"], training=True, groups=2, save=True, inject=_stack_inject(inject, ["d_real", "d_fake"], "d"), tag="d",
+                             drop_masks=st["early"].get("d"))
             logit = dres["logit"].view(-1)
             d_logit = torch.empty_like(logit)
             ops.gan_d_loss(logit[:B], logit[B:], st["d_scalar"], d_logit[:B], d_logit[B:])
@@ -210,14 +226,15 @@ class GanTrainer:
     def phase_g_backward(self, st, post, inject):
         G, D, B, hp = self.G, self.D, st["B"], self.hp
         dev = st["target"].device
-        G.slab.ensure().zero_grad()
+        if not st["early"]["zeroed"]:
+            G.slab.ensure().zero_grad()
         out2 = st["out2"].contiguous()
         self._assert_no_pending_exchange()
         # after warm-up the head's backward for the generator's GAN term (:57, 86-88) runs inside the head's forward launch (its d_logit
         # depends on the clip's own logit only); the loss kernel below still reads the logits for the gen_error scalar
         fused_head = post and self.FUSED_D_HEAD
         dres = D.forward(out2, training=True, groups=1, save=post, inject=inject, tag="d_out",   # runs in warm-up too (:55)
-                         head_step=(B, hp["loss_gan_weight"] / B, 0.0, False) if fused_head else None)
+                         head_step=(B, hp["loss_gan_weight"] / B, 0.0, False) if fused_head else None, drop_masks=st["early"].get("d_out"))
         d_out = torch.empty_like(out2)
         d_logit = torch.empty(B, device=dev)
         st["g_scalars"] = torch.empty(5, device=dev)

@@ -180,7 +180,7 @@ def _fake_trainer_worker(rank, world, port, out):
 
         class FakeD:
             def __init__(self, mod): self.slab = importlib.import_module(PKG + ".params").ParamSlab(mod); self.rng = type("R", (), {"state": None})()
-            def forward(self, poses, **kw): return {"logit": torch.zeros(poses.shape[0], 1), "tape": {}}
+            def forward(self, poses, **kw): return {"logit": torch.zeros(poses.shape[0], 1), "tape": {}, "terms": torch.zeros(poses.shape[0])}
             def backward(self, tape, d_logit, **kw):
                 if kw.get("param_grads", True):
                     self.slab.grad.copy_(grad_of(self.slab, 2000 + rank))
