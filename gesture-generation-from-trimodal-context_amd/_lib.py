@@ -166,6 +166,9 @@ def load():
     lib.tg_set_deterministic.restype = C.c_int
     lib.tg_set_deterministic.argtypes = [I32]
     lib.tg_get_deterministic.restype = C.c_int
+    lib.tg_set_tn_workgroup_cap.restype = C.c_int
+    lib.tg_set_tn_workgroup_cap.argtypes = [I32]
+    lib.tg_get_tn_workgroup_cap.restype = C.c_int
     lib.tg_set_nt_mover_waves.restype = C.c_int
     lib.tg_set_nt_mover_waves.argtypes = [I32]
     lib.tg_gru_cluster_fused_dropout.restype = C.c_int32

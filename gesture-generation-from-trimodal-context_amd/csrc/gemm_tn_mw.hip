@@ -466,6 +466,10 @@ __global__ __launch_bounds__(256) void tn_mw_reduce_kernel(const TnGroup g, cons
 
 using namespace tg;
 
+static int g_tn_wg_cap = 0;
+extern "C" int tg_set_tn_workgroup_cap(int32_t n) { g_tn_wg_cap = n > 0 ? n : 0; return 0; }
+extern "C" int tg_get_tn_workgroup_cap(void) { return g_tn_wg_cap; }
+
 // Plan for the mover-wave kernel, or false when the group should stay on gemm_tn_split_kernel.  Fills n_nt / n_kt / rows_per_split / extents
 // of every problem and the workgroup ranges; *grid receives the launch size.
 bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid, const long* ws_floats) {
@@ -473,11 +477,12 @@ bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid, const long* ws_f
     if (!env_on) return false;
     constexpr int BN = 192, BK = 160;
     long tiles = 0;
+    const int min_rows = g_tn_wg_cap > 0 ? 1024 : 2048;          // (a capped launch is sized to run beside another kernel, not to fill the chip)
     for (int i = 0; i < g.n; ++i) {
         TnProb& p = g.p[i];
         const Win& A = p.A;
         constexpr int min_k = 100;      // K = 108: the GRU's first layer (68 % of a 160-wide tile)
-        if (!p.vec_y || !p.vec_a || p.N % 4 != 0 || A.K % 4 != 0 || p.N < 150 || A.K < min_k || p.M < 2048) return false;
+        if (!p.vec_y || !p.vec_a || p.N % 4 != 0 || A.K % 4 != 0 || p.N < 150 || A.K < min_k || p.M < min_rows) return false;
         if (p.dbias && A.K % BK == 0) return false;                               // no padding column for the ones trick
         if (A.bs < 0 || A.rs < 0 || A.rows_out < 32 || A.step < 0 || p.ldy < p.N) return false;           // (rows_out >= 32: one batch wrap per slab at most in the movers' row walk)
         const long batches = cdiv(p.M, A.rows_out);
@@ -488,11 +493,13 @@ bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid, const long* ws_f
         p.y_bytes = (unsigned)(y_el * 4);
         tiles += (long)cdiv(p.N, BN) * cdiv(A.K, BK);
     }
-    static const int n_cu = [] {
+    static const int dev_cu = [] {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus >= 8 ? cus / 8 * 8 : 8;
     }();
+    // tg_set_tn_workgroup_cap: plan for (and occupy) at most that many CUs -- a launch meant to run BESIDE another kernel that needs the rest
+    const int n_cu = (g_tn_wg_cap > 0 && g_tn_wg_cap < dev_cu) ? (g_tn_wg_cap >= 8 ? g_tn_wg_cap / 8 * 8 : 8) : dev_cu;
     // one item per CU for the group as a whole: row splits = CUs / tiles (every split costs one float atomic per output element), at
     // least 256 rows each
     long items = 0;

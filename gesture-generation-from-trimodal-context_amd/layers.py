@@ -4,6 +4,8 @@ Activations are channel-last (batch, time, channels) everywhere, so every Conv1d
 row-window GEMM (ops.Win) and im2col is never materialised.  Each backward routine accumulates parameter
 gradients straight into the caller's gradient views (which live in one flat slab per network, see params.py).
 """
+import os
+
 import torch
 
 from . import ops, _lib
@@ -15,18 +17,34 @@ def empty(*shape, like=None, device=None, dtype=torch.float32):
 
 
 class WeightPrep:
-    """Weight-derived GEMM operands (transposes, conv packs) of slab-resident parameters, refreshed ONCE per optimiser step by one
-    batched launch instead of one small permute launch per use (~60 per training iteration = 0.26 ms of launch overhead).
+    """Weight-derived GEMM operands (transposes, conv packs, bf16 planes) of slab-resident parameters, refreshed ONCE per optimiser step by
+    batched launches instead of one small permute launch per use (~60 per training iteration = 0.26 ms of launch overhead).
 
     A trainer registers its parameter slabs as groups, activates the cache around its iteration (`with prep.active():`) and calls
     refresh(group) where that group's weights may have changed (start of the iteration; after the discriminator's optimiser
     step).  transpose2d / pack_conv_weight then return the cached operand for sources that live in a registered slab.  Entries are
     discovered on first use in eager mode (computed in place, then kept); under graph capture unknown sources fall back to the
-    inline permute, so a capture never allocates or uploads a table."""
+    inline permute, so a capture never allocates or uploads a table.
+
+    Every operand belongs to the PART of the iteration that first reads it, and each part has its own table and launch (refresh(gid, part)),
+    so only what the head of the dependency chain really reads is refreshed there (GanTrainer; refresh(gid) launches all parts, as before):
+      "main0"  read on the main stream before the generator forward's fork is joined           -> refreshed at the start, main stream
+      "side0"  read on the forked branch, or on the main stream after the join (`zone`)        -> head of the forked branch
+      "late"   first read after the generator's forward (`late`: backward passes, discriminator) -> on the forked branch, behind the encoder
+    A later request from an EARLIER part than the operand's own promotes it (eager) or raises (under capture: the table is frozen)."""
+    PARTS = ("main0", "side0", "late")
 
     def __init__(self):
         self.by_key = {}            # (src ptr, dims, perm) -> dst tensor
-        self.groups = {}            # gid -> {"range": (lo, hi), "jobs": [(src3, dst, perm)], "desc": tensor | None, "wgs": int}
+        self.part_of = {}           # same key -> part
+        self.groups = {}            # gid -> {"range": (lo, hi), "jobs": [(src3, dst, perm)], "desc": {part: tensor}, "wgs": {part: int}, "n": {part: int}}
+        self.late = False           # set by the trainer once the generator's forward is enqueued
+        self.zone = "pre_join"      # set by the generator engine: "post_join" between its fork's join and the end of its forward
+
+    def _part_now(self):
+        if self.late:
+            return "late"
+        return "side0" if (Fork.on_side or self.zone == "post_join") else "main0"
 
     def add_slab(self, gid, flat):
         lo = flat.data_ptr()
@@ -34,8 +52,10 @@ class WeightPrep:
         if g is None or g["range"][0] != lo:          # new or re-allocated slab: forget what pointed into the old one
             if g is not None:
                 for src3, _, perm in g["jobs"]:
-                    self.by_key.pop((src3.data_ptr(), tuple(src3.shape), perm), None)
-            self.groups[gid] = {"range": (lo, lo + flat.numel() * flat.element_size()), "jobs": [], "desc": None, "wgs": 0}
+                    key = (src3.data_ptr(), tuple(src3.shape), perm)
+                    self.by_key.pop(key, None)
+                    self.part_of.pop(key, None)
+            self.groups[gid] = {"range": (lo, lo + flat.numel() * flat.element_size()), "jobs": [], "desc": {}, "wgs": {}, "n": {}}
 
     def _group_of(self, ptr):
         for gid, g in self.groups.items():
@@ -43,12 +63,44 @@ class WeightPrep:
                 return gid
         return None
 
+    def _rebuild(self, g, device):
+        for part in self.PARTS:
+            rows, wg0 = [], 0
+            for s3, d, pm in g["jobs"]:
+                if self.part_of[(s3.data_ptr(), tuple(s3.shape), pm)] != part:
+                    continue
+                if pm[0] == 8:                                        # table entry: d0 = rows, d1 = cw, d2 = cwp
+                    nwg = max(1, min(512, (d.numel() // 3 + 16383) // 16384))
+                    rows.append([s3.data_ptr(), d.data_ptr(), s3.shape[1], s3.shape[2], d.shape[2], 8, 0, 0, wg0, nwg])
+                    wg0 += nwg
+                    continue
+                # ~2 LDS tiles (32 x 32 per batch index) per workgroup.  Counted in TILES, not elements: a conv pack (Co, Ci, kw) is Co small
+                # tiles -- sized by elements it got one workgroup that walked 16-64 tiles one after the other (16-27 us per launch)
+                tiles = s3.shape[0] * ((s3.shape[1] + 31) // 32) * ((s3.shape[2] + 31) // 32) if tuple(pm) == (0, 2, 1) else (d.numel() + 1023) // 1024
+                nwg = max(1, min(512, (tiles + 1) // 2))
+                rows.append([s3.data_ptr(), d.data_ptr(), *s3.shape, *pm, wg0, nwg])
+                wg0 += nwg
+            if g.setdefault("rows", {}).get(part) == rows:
+                continue                                              # this part's table is unchanged
+            if g["desc"].get(part) is not None:
+                g.setdefault("retired", []).append(g["desc"][part])   # a captured graph may still read the previous table: never freed
+            g["desc"][part] = torch.tensor(rows, dtype=torch.int64).to(device) if rows else None
+            g["wgs"][part], g["n"][part], g["rows"][part] = wg0, len(rows), rows
+
     def get(self, src3, perm, out_shape):
         """The permuted copy of src3 (3-D view of a slab parameter) or None when the caller has to permute inline.
         perm = (9, stride, 0) is the conv input-gradient pack (ops.conv_dgrad_pack) of a (Co, Ci, kw) weight."""
         key = (src3.data_ptr(), tuple(src3.shape), perm)
         hit = self.by_key.get(key)
         if hit is not None:
+            now, own = self._part_now(), self.part_of[key]
+            if self.PARTS.index(now) < self.PARTS.index(own):
+                # read earlier in the iteration than the part that refreshes it: it would be read stale, or while it is being rewritten
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError(f"WeightPrep: operand {tuple(src3.shape)} perm {perm} is refreshed in part '{own}' but read in '{now}' "
+                                       "during a capture; run an eager iteration of this configuration first")
+                self.part_of[key] = now
+                self._rebuild(self.groups[self._group_of(src3.data_ptr())], src3.device)
             return hit
         gid = self._group_of(src3.data_ptr())
         if gid is None or torch.cuda.is_current_stream_capturing():
@@ -64,29 +116,17 @@ class WeightPrep:
         g = self.groups[gid]
         g["jobs"].append((src3, dst, perm))
         self.by_key[key] = dst
-        rows, wg0 = [], 0
-        for s3, d, pm in g["jobs"]:
-            if pm[0] == 8:                                        # table entry: d0 = rows, d1 = cw, d2 = cwp
-                nwg = max(1, min(512, (d.numel() // 3 + 16383) // 16384))
-                rows.append([s3.data_ptr(), d.data_ptr(), s3.shape[1], s3.shape[2], d.shape[2], 8, 0, 0, wg0, nwg])
-                wg0 += nwg
-                continue
-            # ~2 LDS tiles (32 x 32 per batch index) per workgroup.  Counted in TILES, not elements: a conv pack (Co, Ci, kw) is Co small
-            # tiles -- sized by elements it got one workgroup that walked 16-64 tiles one after the other (16-27 us per launch)
-            tiles = s3.shape[0] * ((s3.shape[1] + 31) // 32) * ((s3.shape[2] + 31) // 32) if tuple(pm) == (0, 2, 1) else (d.numel() + 1023) // 1024
-            nwg = max(1, min(512, (tiles + 1) // 2))
-            rows.append([s3.data_ptr(), d.data_ptr(), *s3.shape, *pm, wg0, nwg])
-            wg0 += nwg
-        if g["desc"] is not None:
-            g.setdefault("retired", []).append(g["desc"])      # a captured graph may still read the previous table: never freed
-        g["desc"] = torch.tensor(rows, dtype=torch.int64).to(src3.device)
-        g["wgs"] = wg0
+        self.part_of[key] = self._part_now()
+        self._rebuild(g, src3.device)
         return dst
 
-    def refresh(self, gid):
+    def refresh(self, gid, which="all"):
         g = self.groups.get(gid)
-        if g is not None and g["jobs"]:
-            ops.permute3_batch(g["desc"], len(g["jobs"]), g["wgs"])
+        if g is None:
+            return
+        for part in (self.PARTS if which == "all" else (which,)):
+            if g["n"].get(part, 0):
+                ops.permute3_batch(g["desc"][part], g["n"][part], g["wgs"][part])
 
     def active(self):
         return _PrepScope(self)
@@ -108,6 +148,12 @@ class _PrepScope:
 
 
 _PREP = None
+
+
+def prep_zone(zone):
+    """The generator engine tells the active WeightPrep where its forward stands ('pre_join' / 'post_join' of the forked audio branch)."""
+    if _PREP is not None:
+        _PREP.zone = zone
 
 
 def transpose2d(w):
@@ -470,15 +516,17 @@ class Fork:
 
     Buffers read by side-stream work must stay referenced until join(): pass them to keep()."""
     _streams = {}
+    on_side = False             # launches currently go to a forked stream
 
-    def __init__(self, device, enabled=True):
+    def __init__(self, device, enabled=True, slot=0):
+        """slot: which of the device's side streams (forks that are open at the same time take different slots)."""
         self.enabled = enabled and device.type == "cuda"
         self.side = None
         self._ctx = None
         self._keep = []
         self.dirty = False
         if self.enabled:
-            key = (device.type, device.index)
+            key = (device.type, device.index, slot)
             if key not in Fork._streams:
                 Fork._streams[key] = torch.cuda.Stream(device=device)
             self.side = Fork._streams[key]
@@ -492,12 +540,14 @@ class Fork:
             self._ctx = torch.cuda.stream(self.side)
             self._ctx.__enter__()
             self.dirty = True
+            Fork.on_side = True
         return self
 
     def __exit__(self, *exc):
         if self.enabled:
             self._ctx.__exit__(*exc)
             self._ctx = None
+            Fork.on_side = False
         return False
 
     def join(self):
@@ -507,19 +557,44 @@ class Fork:
         self._keep = []
 
 
-def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=True, param_grads=True, fork=None, defer=None):
+TN_SIDE_FRACTION = float(os.environ.get("TG_TN_SIDE_FRAC", "0.40"))     # share of a GRU layer's weight-gradient rows that runs beside the next layer's recurrence (gru_stack_bwd side_split)
+
+
+def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=True, param_grads=True, fork=None, defer=None, side_split=None):
     """dy: (nb, T, 2H) gradient w.r.t. the last layer's output for rows [b0, b0+nb) of the taped forward.
     Accumulates into G[...] and returns dx (nb, T, Kin0).  With `fork`, each layer's weight-gradient GEMMs run on the side
     stream while the main stream goes on with dx and the next layer's recurrence; the caller joins.  With `defer` (a list), the
     weight-gradient problems are appended to it instead of launched: the caller groups them (tn_group_deferred) -- they are off the
-    dependency chain, and on the small H = 64 stack one launch per layer is mostly launch and tail."""
+    dependency chain, and on the small H = 64 stack one launch per layer is mostly launch and tail.
+    side_split (a Fork; the cluster-synchronised backward at H > 64): the recurrence is latency-bound and leaves 256 - 160 CUs idle, and the
+    weight gradients are off the dependency chain.  The LAST batch rows of every layer's weight-gradient products (TN_SIDE_FRACTION of them)
+    are therefore launched on the fork's stream right before the NEXT layer's recurrence, planned for exactly the CUs that recurrence
+    leaves free (ops.tn_workgroup_cap) so that all its cluster members stay co-resident; the other rows run on the main stream as before.
+    The caller joins the fork before anybody reads the gradients."""
     B, T, H = tape.B, tape.T, tape.H
     nb = B - b0 if nb is None else nb
     rows = slice(b0, b0 + nb)
     dh = empty(4 * nb * H, like=dy)
     fk = fork if fork is not None else Fork(dy.device, enabled=False)
     scaled = False               # dy already carries the dropout scale of the layer below (applied in the input-gradient GEMM's epilogue)
+    side_pending = None          # (problems, CU cap, tensors to keep) of the layer above
+    free_cus = ops.gru_cluster_bwd_free_cus(nb, H) if (side_split is not None and side_split.enabled and param_grads and defer is None) else 0
+    nb_side = int(nb * TN_SIDE_FRACTION) if free_cus >= 64 else 0
+    if nb_side * T < 1024 or (nb - nb_side) * T < 2048:          # (the persistent weight-gradient kernel wants 2 048 rows, 1 024 under a cap)
+        nb_side = 0
+    def launch_side_rows():
+        nonlocal side_pending
+        if side_pending is not None:
+            probs_s, keep_s = side_pending
+            side_split.keep(*keep_s)
+            with side_split:                                     # ordered behind the mark: the layer above is complete
+                with ops.tn_workgroup_cap(free_cus):
+                    ops.gemm_tn_group(probs_s)
+            side_pending = None
     for l in range(n_layers - 1, -1, -1):
+        # The side rows are enqueued BEFORE the recurrence they run beside.  (Round 5, profiles/r5_z_tn_side_rows.txt: captured the other way
+        # round -- recurrence first, an event for the side rows -- hipGraph ran the whole side branch after everything else, 5.00 ms.)
+        launch_side_rows()
         dy_mask = None
         if tape.masks[l] is not None and not scaled:
             if ops.gru_fused_dropout(nb, H, bwd=True):
@@ -534,20 +609,32 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
         Kin = x_l.shape[2]
         y_l = tape.y[l][rows]
         if param_grads:
-            fk.keep(dgi, dgh, x_l, y_l)
-            with fk:
-                probs = []
-                x_win = Win.plain(x_l.reshape(nb * T, Kin))
+            def layer_probs(r0, r1):
+                """the layer's four weight gradients (+ four bias gradients) over batch rows [r0, r1)"""
+                n, probs = r1 - r0, []
+                x_win = Win.plain(x_l[r0:r1].reshape(n * T, Kin))
                 for d, sfx in enumerate(("", "_reverse")):
-                    gi2, gh2 = dgi[d].view(nb * T, 3 * H), dgh[d].view(nb * T, 3 * H)
+                    gi2, gh2 = dgi[d][r0:r1].view(n * T, 3 * H), dgh[d][r0:r1].view(n * T, 3 * H)
                     probs.append(dict(dY=gi2, A=x_win, dW=G[f"{prefix}.weight_ih_l{l}{sfx}"], dbias=G[f"{prefix}.bias_ih_l{l}{sfx}"]))
                     # h_{t-1} of direction d is the layer output one step back (forward) / ahead (reverse), zero at the ends
-                    hwin = Win.taps(y_l[:, :, d * H:(d + 1) * H], 1, shift=(1 if d else -1), dil=1, rows_out=T)
+                    hwin = Win.taps(y_l[r0:r1, :, d * H:(d + 1) * H], 1, shift=(1 if d else -1), dil=1, rows_out=T)
                     probs.append(dict(dY=gh2, A=hwin, dW=G[f"{prefix}.weight_hh_l{l}{sfx}"], dbias=G[f"{prefix}.bias_hh_l{l}{sfx}"]))
+                return probs
+            split = 0
+            if nb_side and l > 0:
+                # only if the capped plan takes the side part on the persistent kernel (anything else floods the chip with short workgroups)
+                with ops.tn_workgroup_cap(free_cus):
+                    if ops.tn_kernel_plan(layer_probs(nb - nb_side, nb)) == 2:
+                        split = nb_side
+            fk.keep(dgi, dgh, x_l, y_l)
+            with fk:
+                probs = layer_probs(0, nb - split)
                 if defer is not None:
                     defer.extend(probs)
                 else:
-                    ops.gemm_tn_group(probs)             # the layer's four weight gradients (+ four bias gradients), one launch
+                    ops.gemm_tn_group(probs)             # one launch
+            if split:
+                side_pending = (layer_probs(nb - split, nb), (dgi, dgh, x_l, y_l))
         dx = None
         if need_dx or l > 0:
             dx = empty(nb * T, Kin, like=dy)

@@ -6,6 +6,8 @@ the GPU (kernels themselves only guard their own tile edges).
 """
 import ctypes as C
 
+import contextlib
+
 import torch
 
 from . import _lib
@@ -375,7 +377,7 @@ def gemm_tn_group(problems):
     problems = _det_bias(problems)
     qs = [_tn_problem(keep=keep, **p)[0] for p in problems]
     arr = (_lib.TnProblem * len(qs))(*qs)
-    if TN_MW_WS and not all(q.ws for q in qs) and all(q.M >= 2048 and q.N >= 150 for q in qs):
+    if TN_MW_WS and not all(q.ws for q in qs) and all(q.M >= 1024 and q.N >= 150 for q in qs):
         # a group the mover-wave kernel takes (csrc/gemm_tn_mw.hip): give every problem the workspace, so that its row splits are combined by
         # the fixed-order second pass instead of float atomics (28 of 116 us of a GRU layer's launch, and the one order-dependent sum left
         # on the default path's big weight gradients)
@@ -383,6 +385,26 @@ def gemm_tn_group(problems):
             qs = [_tn_problem(keep=keep, force_ws=True, **p)[0] for p in problems]
             arr = (_lib.TnProblem * len(qs))(*qs)
     call("tg_gemm_tn_group", arr, len(problems), _stream())
+
+
+@contextlib.contextmanager
+def tn_workgroup_cap(n):
+    """Weight-gradient launches inside are planned for, and occupy, at most n CUs (tg_set_tn_workgroup_cap): for launches on a second stream
+    beside a kernel that needs the other CUs to itself."""
+    call("tg_set_tn_workgroup_cap", int(n))
+    try:
+        yield
+    finally:
+        call("tg_set_tn_workgroup_cap", 0)
+
+
+def gru_cluster_bwd_free_cus(nb, H):
+    """CUs the cluster-synchronised GRU backward leaves free (0: it is not the kernel that would run, or it runs in several launches):
+    2 directions x ceil(nb / 16) batch tiles x ceil(H / 32) members, one workgroup per CU (csrc/gru_cluster.hip cluster_plan_bwd)."""
+    if not (GRU_CLUSTER and H > 64) or gru_cluster_chunks(nb, H, bwd=True) != [(0, nb)]:
+        return 0
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return max(0, cus - 2 * (-(-nb // 16)) * (-(-H // 32)))
 
 
 def tn_kernel_plan(problems):

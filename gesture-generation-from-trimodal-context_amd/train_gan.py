@@ -139,9 +139,12 @@ class GanTrainer:
         self.prep.add_slab("D", self.D.slab.ensure().flat)
         with self.prep.active():
             # both networks may have been changed since the last call (optimiser steps, load_state_dict): one batched launch each
-            self.prep.refresh("G")
-            self.prep.refresh("D")
-            st = self.phase_forward(post, in_text, in_audio, target, vid, inject)
+            # (the operands that the main stream does not read before the forward's fork is joined are refreshed from phase_forward, on the
+            # forked branch: layers.WeightPrep's parts)
+            self.prep.late = False
+            self.prep.refresh("G", "main0")
+            st = self.phase_forward(post, in_text, in_audio, target, vid, inject)      # (refreshes the discriminator's operands too)
+            self.prep.late = True
             if post:
                 self.phase_d_step(st, inject)
                 self.prep.refresh("D")                     # the discriminator's weights moved (train_gan.py:43)
@@ -178,17 +181,27 @@ class GanTrainer:
         # that fork (data-parallel schedule, text-only contexts) the phases issue them themselves, where the chain used to wait for them
         early = {}
         def side_work():
+            self.prep.refresh("G", "late")
+            self.prep.refresh("D")                          # first read in the discriminator step / the generator step's D(out)
             G.slab.ensure().zero_grad()
+            if ops.OUT_MLP_COMPOSED:
+                early["out_acc"] = ops.zeros(G.pose_dim * G.H + G.pose_dim, device=dev)      # accumulators of the output MLP's backward
             if post:
                 D.slab.ensure().zero_grad()
             if inject is None:
                 early["d_out"] = D.draw_drop_masks(B, "d_out")
                 if post:
                     early["d"] = D.draw_drop_masks(2 * B, "d")
+        forks = self.EARLY_SIDE_WORK and hasattr(G, "forks_in_forward") and G.forks_in_forward(True)
+        if not forks:
+            self.prep.refresh("G", "side0")
         res = G.forward(pre_s, text_s, in_audio.float(), vid_s, training=True, groups=ng, save=True,
                         inject=_stack_inject(inject, tags, "g"), tag="g", save_rows=(i2 * B, B),     # only call g2 is differentiated (:50-88)
-                        out_into=d_in[B:] if post else None, side_work=side_work if self.EARLY_SIDE_WORK else None)
+                        out_into=d_in[B:] if post else None, **(dict(side_work=side_work, side_head=lambda: self.prep.refresh("G", "side0")) if forks else {}))
         early["zeroed"] = res.get("side_work_ran", False)
+        if not early["zeroed"]:
+            self.prep.refresh("G", "late")
+            self.prep.refresh("D")
         if self.keep_tape:
             self.last_tape = res["tape"]
         sl = lambda t, i: None if t is None else t[i * B:(i + 1) * B]
@@ -264,7 +277,8 @@ class GanTrainer:
             assert not self._waited, "a gradient bucket was handed over after the backward's last one"
             self._sync("bucket_wait" if last else "bucket", G.slab, prefixes)
             self._waited = last
-        G.backward(st["res"]["tape"], d_out, d_mu, d_lv, b0=st["i2"] * B, nb=B, on_ready=on_ready if self.grad_sync is not None else None)
+        G.backward(st["res"]["tape"], d_out, d_mu, d_lv, b0=st["i2"] * B, nb=B, on_ready=on_ready if self.grad_sync is not None else None,
+                   **({"out_acc": st["early"]["out_acc"]} if "out_acc" in st["early"] else {}))
 
     # ---- phase 4: generator update (train_gan.py:92)
     def phase_g_update(self):

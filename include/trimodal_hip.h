@@ -40,6 +40,13 @@ int tg_version(void);
  * atomics, whose order-dependence is below fp32 resolution but not zero).  tests/test_trajectory_gpu.py pins the guarantee at B = 64. */
 int tg_set_deterministic(int32_t on);
 int tg_get_deterministic(void);
+/* Workgroup cap of the persistent weight-gradient kernel (tg_gemm_tn / tg_gemm_tn_group on the mover-wave kernel; process-wide, 0 = none):
+ * with n > 0 those launches are planned for, and occupy, at most n CUs -- for a launch issued on a second stream BESIDE a kernel that needs
+ * the other CUs to itself (the cluster-synchronised GRU backward keeps 160 of 256; train_eval/train_gan.py:89 is the backward it belongs
+ * to).  A group the capped plan cannot take is refused by tg_gemm_tn_kernel_plan (code 0) exactly as without the cap; callers check that
+ * before they fork. */
+int tg_set_tn_workgroup_cap(int32_t n);
+int tg_get_tn_workgroup_cap(void);
 const char* tg_last_error(void);
 
 /* Math mode of the GEMM-shaped kernels (process-wide, like cublasSetMathMode):

@@ -1102,6 +1102,23 @@ def test_gemm_tn_mover_wave_kernel(pkg, dev):
         assert float((p["dbias"].double() - rb).abs().max() / rb.abs().max()) < 1e-5
     # small groups stay on the staged-slab kernel
     assert ops.tn_kernel_plan([dict(dY=dgi[0][:1100, :52], A=Win.plain(x[:1100, :76]), dW=torch.zeros(52, 76, device=dev))]) in (0, 1)
+    # tg_set_tn_workgroup_cap (layers.gru_stack_bwd side_split): the last 61 clips' rows of a GRU layer's group planned for the 96 CUs the
+    # cluster recurrence leaves free -- same kernel, same answers, the cap gone afterwards
+    rows = slice(M - 61 * 34, M)
+    gq = torch.Generator().manual_seed(23)
+    probs, refs = [], []
+    for d in range(2):
+        for A, Kc in ((x, 2 * H), (hp, H)):
+            dW, db = torch.randn(3 * H, Kc, generator=gq).to(dev), torch.randn(3 * H, generator=gq).to(dev)
+            refs.append((dW.double() + dgi[d][rows].double().t() @ A[rows].double(), db.double() + dgi[d][rows].double().sum(0)))
+            probs.append(dict(dY=dgi[d][rows], A=Win.plain(A[rows]), dW=dW, dbias=db))
+    with ops.tn_workgroup_cap(96):
+        assert pkg._lib.load().tg_get_tn_workgroup_cap() == 96 and ops.tn_kernel_plan(probs) == 2
+        ops.gemm_tn_group(probs)
+    assert pkg._lib.load().tg_get_tn_workgroup_cap() == 0
+    for p, (rw, rb) in zip(probs, refs):
+        assert float((p["dW"].double() - rw).abs().max() / rw.abs().max()) < 1e-5
+        assert float((p["dbias"].double() - rb).abs().max() / rb.abs().max()) < 1e-5
 
 
 def test_gemm_tn_split_with_conv_window(pkg, dev):
