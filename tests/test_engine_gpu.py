@@ -1,6 +1,7 @@
 """Network-level parity on the GPU, through the C ABI: HIP path vs (a) golden vectors from the real reference and
 (b) the fp64 oracle on the same weights / inputs / random draws.  Tolerances: forward 1e-5, gradients 1e-4
 normalised max error."""
+import importlib
 import os
 
 import numpy as np
@@ -1087,6 +1088,64 @@ def test_weight_prep_follows_external_weight_changes(pkg, dev):
     _, g1, _ = tr1.G.views(); _, g2, _ = tr2.G.views()
     for k in ("gru.weight_ih_l1", "gru.weight_hh_l0_reverse", "audio_encoder.feat_extractor.3.weight", "out.0.weight"):
         assert rel(g1[k], g2[k]) < 1e-3, k
+
+
+def test_weight_prep_parts_follow_the_first_reader(pkg, dev):
+    """layers.WeightPrep files an operand under the part of the iteration that first reads it ('main0': main stream before the forward's fork is
+    joined, 'side0': the forked branch or behind the join, 'late': after the forward) and refreshes the parts separately.  An operand read
+    EARLIER than its part would be read stale: eager requests promote it (and the tables follow), a request during a capture raises.  After a
+    training iteration nothing of the generator sits in 'main0' (the iteration's head launches no refresh) and every part's refresh reproduces
+    the operands from changed weights."""
+    L = importlib.import_module(pkg.__name__ + ".layers")
+    prep = L.WeightPrep()
+    slab = torch.randn(4 * 64 * 48, device=dev)
+    prep.add_slab("X", slab)
+    w = [slab[i * 64 * 48:(i + 1) * 64 * 48].view(64, 48) for i in range(4)]
+    with prep.active():
+        prep.late = False
+        t0 = L.transpose2d(w[0])                                   # main stream, before any join
+        prep.zone = "post_join"
+        t1 = L.transpose2d(w[1])
+        prep.zone = "pre_join"
+        prep.late = True
+        t2, t3 = L.transpose2d(w[2]), L.transpose2d(w[3])
+        key = lambda x: (x.data_ptr(), (1, 64, 48), (0, 2, 1))
+        assert [prep.part_of[key(x)] for x in w] == ["main0", "side0", "late", "late"]
+        g = prep.groups["X"]
+        assert (g["n"]["main0"], g["n"]["side0"], g["n"]["late"]) == (1, 1, 2)
+        slab.mul_(-2.0)                                            # an optimiser step: every cached operand is stale now
+        prep.refresh("X", "late")
+        assert torch.equal(t2, w[2].t()) and torch.equal(t3, w[3].t()) and not torch.equal(t0, w[0].t()) and not torch.equal(t1, w[1].t())
+        prep.refresh("X", "side0"); prep.refresh("X", "main0")
+        assert torch.equal(t0, w[0].t()) and torch.equal(t1, w[1].t())
+        # read earlier than its part: promoted, the tables follow
+        prep.late = False
+        assert L.transpose2d(w[2]) is t2 and prep.part_of[key(w[2])] == "main0"
+        assert (g["n"]["main0"], g["n"]["side0"], g["n"]["late"]) == (2, 1, 1)
+        slab.add_(1.0)
+        prep.refresh("X")                                          # all parts
+        assert all(torch.equal(t, x.t()) for t, x in zip((t0, t1, t2, t3), w))
+        # ... but not inside a capture, where the tables are frozen
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            graph.capture_begin()
+            try:
+                with pytest.raises(RuntimeError, match="refreshed in part 'late'"):
+                    L.transpose2d(w[3])
+            finally:
+                graph.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+    # a real iteration: the generator's group has no 'main0' operand, the discriminator's are all 'late'
+    V, S, B = 64, 9, 4
+    text, audio, vid, poses = (t.to(dev) for t in O.make_batch(31, B, V, S))
+    args, G, Dn = build_models(pkg, dev, O.make_generator_state(5, V, S), O.make_discriminator_state(6), V, S)
+    tr = pkg.GanTrainer(G, Dn, args)
+    tr.train_iter(11, text, audio, poses, vid)
+    gg, gd = tr.prep.groups["G"], tr.prep.groups["D"]
+    assert gg["n"].get("main0", 0) == 0 and gg["n"]["side0"] > 0 and gg["n"]["late"] > 0
+    assert gd["n"].get("main0", 0) == 0 and gd["n"].get("side0", 0) == 0 and gd["n"]["late"] > 0
 
 
 def test_ragged_batch_synthesis(pkg, dev):
