@@ -1090,6 +1090,53 @@ def test_weight_prep_follows_external_weight_changes(pkg, dev):
         assert rel(g1[k], g2[k]) < 1e-3, k
 
 
+def test_gru_weight_gradient_side_rows_change_nothing(pkg, dev):
+    """layers.gru_stack_bwd side_split at B = 128: the last rows of the weight gradients of GRU layers 3 .. 1 are launched on a third stream under
+    tg_set_tn_workgroup_cap, beside the next layer's cluster recurrence.  Captured and replayed (the schedule the benchmark times), two iterations
+    from the same state with and without the split: same losses, same parameters after both optimiser steps within the rounding of a different
+    summation grouping; the call log shows three capped launches and the cap gone afterwards."""
+    V, S, B = 512, 9, 128
+    gst, dst = O.make_generator_state(3, V, S), O.make_discriminator_state(4)
+    text, audio, vid, poses = (t.to(dev) for t in O.make_batch(17, B, V, S))
+    runs = []
+    for split in (True, False):
+        args, G, D = build_models(pkg, dev, gst, dst, V, S)
+        G.engine.tn_side_split = split
+        tr = pkg.GanTrainer(G, D, args)
+        names, orig = [], pkg.ops.call
+        def call(name, *a):
+            names.append((name, a[0] if name == "tg_set_tn_workgroup_cap" else None))
+            return orig(name, *a)
+        pkg.ops.call = call
+        try:
+            tr.train_iter(11, text, audio, poses, vid)              # eager (also fills the operand cache)
+        finally:
+            pkg.ops.call = orig
+        caps = [c for n, c in names if n == "tg_set_tn_workgroup_cap" and c]
+        if split:
+            assert G.engine._audio_fork_on(bwd=True), "the forked schedules are off on this box: nothing to test"
+            # per split layer: one capped plan query + one capped launch; the cluster backward of 128 rows leaves 96 CUs
+            assert caps == [96] * 6, caps
+            assert pkg._lib.load().tg_get_tn_workgroup_cap() == 0
+        else:
+            assert not caps
+        snap = tr.snapshot()
+        step = pkg.GraphedGanStep(tr, 11, text, audio, poses, vid, warmup_iters=1)
+        tr.restore(snap)
+        losses = [step().to_dict() for _ in range(2)]
+        torch.cuda.synchronize()
+        pkg.ops.check_async_errors()
+        runs.append((losses, {k: v.detach().clone() for k, v in G.named_parameters()}))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for k in b:
+            assert abs(a[k] - b[k]) <= 2e-5 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    lr = 5e-4
+    for k, v in runs[1][1].items():
+        if k in ZERO_GRAD_KEYS:                                 # true gradient exactly zero: Adam normalises rounding noise to +- lr on both sides
+            continue                                            # (and the running statistics behind such a bias follow it: parameters only)
+        assert float((runs[0][1][k] - v).abs().max()) <= 0.05 * lr, k       # Adam turns a 1e-6 relative gradient difference into << lr
+
+
 def test_weight_prep_parts_follow_the_first_reader(pkg, dev):
     """layers.WeightPrep files an operand under the part of the iteration that first reads it ('main0': main stream before the forward's fork is
     joined, 'side0': the forked branch or behind the join, 'late': after the forward) and refreshes the parts separately.  An operand read
