@@ -1134,7 +1134,11 @@ def test_gru_weight_gradient_side_rows_change_nothing(pkg, dev):
     for k, v in runs[1][1].items():
         if k in ZERO_GRAD_KEYS:                                 # true gradient exactly zero: Adam normalises rounding noise to +- lr on both sides
             continue                                            # (and the running statistics behind such a bias follow it: parameters only)
-        assert float((runs[0][1][k] - v).abs().max()) <= 0.05 * lr, k       # Adam turns a 1e-6 relative gradient difference into << lr
+        # Adam turns a 1e-6 relative gradient difference into << lr, except where the gradient itself is at rounding level (the element then
+        # moves by a fraction of lr in a direction rounding decides): a quarter of lr bounds those, a wrong or missing row block would move
+        # whole matrices by ~lr
+        assert float((runs[0][1][k] - v).abs().max()) <= 0.25 * lr, k
+        assert float((runs[0][1][k] - v).abs().mean()) <= 0.002 * lr, k
 
 
 def test_weight_prep_parts_follow_the_first_reader(pkg, dev):
