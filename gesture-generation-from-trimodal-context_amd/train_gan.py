@@ -9,6 +9,8 @@ Same order of operations and the same losses as the reference; what changes is t
   * the discriminator gradients produced by the generator step are never formed (the reference discards them);
   * nothing reads a loss back to the host inside the iteration; the five .item() calls of :94-102 become one
     deferred read (StepLosses.to_dict()).
+  * launches that wait for nothing (gradient zeroing, weight-operand refreshes, the discriminator's dropout draws) ride on the generator
+    forward's forked audio branch; the discriminator's head, loss terms and head backward are one launch per pass.
 With static shapes the whole iteration is captured into a hipGraph (GraphedGanStep).
 """
 import math
@@ -176,9 +178,11 @@ class GanTrainer:
                                              permute_last=speaker and self.use_reg, perm_in=perm_in, perm_site=G.rng.site("perm"),
                                              row_floats=G.in_size,         # the seed poses land in the GRU input rows directly
                                              target_copy=d_in[:B] if post else None)
-        # launches of the later phases that depend on nothing but the RNG state -- zeroing both gradient slabs, the discriminator's dropout
-        # draws -- go out on the generator forward's forked audio branch (bandwidth-sized kernels beside the text encoder's products); without
-        # that fork (data-parallel schedule, text-only contexts) the phases issue them themselves, where the chain used to wait for them
+        # launches of the later phases that depend on nothing but the weights or the RNG state -- the refresh of the weight operands only the
+        # backward passes and the discriminator read (layers.WeightPrep part "late"), zeroing both gradient slabs and the output MLP's
+        # accumulators, the discriminator's dropout draws -- go out on the generator forward's forked audio branch (bandwidth-sized kernels beside
+        # the text encoder's products); without that fork (text-only contexts, 8 hardware queues) the phases issue them themselves, where the
+        # chain used to wait for them.  The operands the forward itself reads behind the join go first on that branch (side_head).
         early = {}
         def side_work():
             self.prep.refresh("G", "late")
