@@ -557,7 +557,7 @@ class Fork:
         self._keep = []
 
 
-TN_SIDE_FRACTION = float(os.environ.get("TG_TN_SIDE_FRAC", "0.40"))     # share of a GRU layer's weight-gradient rows that runs beside the next layer's recurrence (gru_stack_bwd side_split)
+TN_SIDE_FRACTION = float(os.environ.get("TG_TN_SIDE_FRAC", "0.48"))     # share of a GRU layer's weight-gradient rows that runs beside the next layer's recurrence (gru_stack_bwd side_split)
 
 
 def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=True, param_grads=True, fork=None, defer=None, side_split=None):
