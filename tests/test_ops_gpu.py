@@ -500,6 +500,15 @@ def test_weight_norm_and_dgrad_pack(pkg, dev):
         dg1, dv1 = torch.full((Co,), 0.5, device=dev), torch.full_like(vg, 0.25)
         ops.weight_norm_bwd(dws[i], vs[i], gs[i], dg1, dv1)
         assert torch.equal(dg1, dgs_b[i]) and torch.equal(dv1, dvs_b[i])
+    # the batched forward (16-channel LDS tiles; Co = 300 leaves a ragged last tile): packed rows and the transposed pack, per conv
+    wp_b, wt_b = ops.weight_norm_fwd_batch(vs, gs)
+    for i in range(3):
+        wi = vs[i].double() * (gs[i].double().view(-1, 1, 1) / vs[i].double().flatten(1).norm(dim=1).view(-1, 1, 1))
+        assert rel(wp_b[i].view(Co, kw, Ci), wi.permute(0, 2, 1)) < 1e-6
+        assert rel(wt_b[i].view(Ci, kw, Co), wi.permute(1, 2, 0)) < 1e-6
+        assert torch.equal(wt_b[i].view(Ci, kw, Co), wp_b[i].view(Co, kw, Ci).permute(2, 1, 0))      # the two packs hold the same numbers
+    wp_n, wt_n = ops.weight_norm_fwd_batch(vs[:1], gs[:1], want_t=False)
+    assert wt_n is None and torch.equal(wp_n[0], wp_b[0])
     w2 = rnd(8, 5, 15, seed=38).to(dev)
     packed = ops.conv_dgrad_pack(w2, torch.empty(6, 5, 3 * 8, device=dev), 6).cpu().view(6, 5, 3, 8)
     for r in range(6):
