@@ -28,7 +28,7 @@ class NtProblem(C.Structure):
                 ("c_batch_stride", I64), ("c_row_stride", I64), ("c_rows_out", I32), ("M", I32), ("N", I32), ("act_slope", F32),
                 ("accumulate", I32), ("out_scale", P), ("b_planes", P), ("b_plane_stride", I64), ("b_rows", I32), ("b_row0", I32),
                 ("gate", P), ("res", P), ("C2", P), ("res_slope", F32), ("drop_site", U32), ("drop_state", P), ("drop_index0", I64),
-                ("drop_p", F32), ("reserved4", I32)]
+                ("drop_p", F32), ("reserved4", I32), ("b_planes_kind", I32), ("reserved5", I32), ("b_inv_scale", P), ("a_row_scale", P)]
 
 
 class TnProblem(C.Structure):
@@ -53,6 +53,9 @@ SIGNATURES = {
     "tg_gemm_tn_group": [C.POINTER(TnProblem), I32, P],
     "tg_ae_train_step": [C.POINTER(AeStepArgs), P],
     "tg_split3_planes": [P, I64, I32, I32, P, I32, I64, P],
+    "tg_split2h_planes": [P, I64, I32, I32, P, I32, I64, P, P],
+    "tg_win_row_absmax": [WP, I32, P, P],
+    "tg_h2_row_scales": [WP, I32, P, P, P],
     "tg_gemm_tn": [P, I64, WP, P, I64, I32, I32, I32, P, P, I64, P],
     "tg_colsum": [P, I64, I32, I32, P, I32, P],
     "tg_gru_forward": [P, I64, P, P, P, P, P, P, I64, I32, I32, I32, P],
@@ -132,7 +135,7 @@ SIGNATURES = {
     "tg_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, P, P],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

@@ -98,6 +98,11 @@ struct NtProb {
     const __bf16* Bpl;           // optional pre-split weights: plane 0 of a slab-tiled plane buffer (plane_tiled_off) that holds Bw's N rows of K columns
     long bpl_plane;              //   from buffer row b_row0 on; planes bpl_plane elements apart; b_slab_rows = rows of the buffer + 1 (its zero row last)
     int b_slab_rows, b_row0;
+    // fp16 x 2 (h2 != 0): Bpl holds TWO fp16 planes (hi / lo of the scaled rows, tg_split2h_planes), b_inv[buffer row] = 1 / that row's scale,
+    // a_scale[m] = the power-of-two scale of product row m (tg_h2_row_scales: 2^(141 - e) for the largest magnitude over the row's K values)
+    const float* a_scale;
+    const float* b_inv;
+    int h2;
 };
 
 struct NtGroup {
@@ -196,6 +201,81 @@ __device__ __forceinline__ void split3_write_piece(const float* __restrict__ x, 
     *reinterpret_cast<tg_u32x4*>(planes + o) = tg_u32x4{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])};
     *reinterpret_cast<tg_u32x4*>(planes + plane_stride + o) = tg_u32x4{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])};
     *reinterpret_cast<tg_u32x4*>(planes + 2 * plane_stride + o) = tg_u32x4{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])};
+}
+
+// ---- two-term fp16 split of an fp32 value ("fp16 x 2": three matrix instructions per product instead of bf16 x 3's six) -------------------
+// x * s = hi + lo + eps: hi = fp16(x * s) (round to nearest even), lo = fp16(x * s - hi) (the residual is exact in fp32), |eps| <= 2^-23 |x s|
+// while lo is a normal fp16.  s is an exact power of two PER ROW of the operand (per output channel for weights): with e the biased fp32
+// exponent of the row's largest magnitude, s = 2^(141 - e) puts that magnitude into [2^14, 2^15) -- nothing overflows fp16's 65 504, and
+// every element within 2^-17 of the row's largest keeps a normal lo (22-23 significand bits against fp32's 24; smaller elements degrade
+// gracefully: their absolute error stays below 2^-40 of the row's largest even where the matrix cores flush fp16 subnormals).  The product
+// hi_a hi_b + hi_a lo_b + lo_a hi_b (lo lo dropped: 2^-22 relative) accumulates in fp32 and is scaled back by the exact 2^(e_a - 141) 2^(e_b - 141)
+// in the epilogue.  Exponents are clamped to [32, 250]: rows whose largest magnitude is below 2^-95 (or zero) use the scale of 2^-95, an
+// infinity / NaN in a row reaches the output as one.
+typedef _Float16 tg_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 tg_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __host__ __forceinline__ int h2_exp_of_bits(unsigned absmax_bits) {
+    const int e = (int)((absmax_bits & 0x7fffffffu) >> 23);
+    return e < 32 ? 32 : (e > 250 ? 250 : e);
+}
+__device__ __forceinline__ float h2_scale_of_exp(int e) { return __uint_as_float((unsigned)(268 - e) << 23); }     // 2^(141 - e)
+__device__ __forceinline__ float h2_inv_of_exp(int e) { return __uint_as_float((unsigned)(e - 14) << 23); }        // 2^(e - 141)
+__device__ __forceinline__ float h2_inv_of_scale(float s) { return __uint_as_float(0x7f000000u - __float_as_uint(s)); }   // 1 / s for a power of two s
+// two already scaled values -> one dword of their hi terms, one of their lo terms (first value in the low half)
+__device__ __forceinline__ void h2_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const tg_f16x2 h = {(_Float16)a, (_Float16)b};
+    const float ha = (float)h[0], hb = (float)h[1];
+    const tg_f16x2 l = {(_Float16)(a - ha), (_Float16)(b - hb)};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// wave-wide maximum of non-negative float bit patterns (unsigned compare == float compare for them)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = v > w ? v : w; }
+    return v;
+}
+
+// One WAVE writes row r (r <= rows; r == rows is the all-zero row) of the fp16 x 2 plane buffer of an fp32 matrix [rows][cw] (row stride ldx):
+// two fp16 planes (hi / lo of x * s_r) in the slab-tiled layout of plane_tiled_off, `plane_stride` elements apart, and inv[r] = 1 / s_r.
+__device__ __forceinline__ void h2_write_row(const float* __restrict__ x, long ldx, int rows, int cw, int cwp, _Float16* __restrict__ planes,
+                                             long plane_stride, float* __restrict__ inv, long r, int lane, bool vec) {
+    const int c8n = cwp / 8;
+    const bool live = r < rows;
+    unsigned mx = 0;
+    if (live) {
+        for (int c = lane * 4; c < cw; c += 256) {
+            if (vec && c + 4 <= cw) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float f = v[q]; const unsigned b = __float_as_uint(f) & 0x7fffffffu; mx = mx > b ? mx : b; }
+            } else {
+                for (int q = 0; q < 4 && c + q < cw; ++q) { const unsigned b = __float_as_uint(x[r * ldx + c + q]) & 0x7fffffffu; mx = mx > b ? mx : b; }
+            }
+        }
+        mx = wave_max_u32(mx);
+    }
+    const int e = h2_exp_of_bits(mx);
+    const float s = h2_scale_of_exp(e);
+    if (lane == 0) inv[r] = live ? h2_inv_of_exp(e) : 0.f;
+    for (int p8 = lane; p8 < c8n; p8 += 64) {
+        const int c = p8 * 8;
+        float v[8];
+        if (live && vec && c + 8 <= cw) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * ldx + c), b = *reinterpret_cast<const f32x4*>(x + r * ldx + c + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = a[q]; v[4 + q] = b[q]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (live && c + q < cw) ? x[r * ldx + c + q] : 0.f;
+        }
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h2_split2(v[2 * q] * s, v[2 * q + 1] * s, h[q], l[q]);
+        const long o = plane_tiled_off(r, c, rows);
+        *reinterpret_cast<tg_u32x4*>(planes + o) = tg_u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<tg_u32x4*>(planes + plane_stride + o) = tg_u32x4{l[0], l[1], l[2], l[3]};
+    }
 }
 
 // ---- Philox4x32-10 ------------------------------------------------------------------------------------

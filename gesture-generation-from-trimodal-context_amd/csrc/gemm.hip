@@ -796,6 +796,7 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
     p.M = q.M; p.N = q.N; p.slope = q.act_slope; p.accumulate = q.accumulate; p.n_nt = 0;
     p.a_bytes = p.b_bytes = 0;
     p.Bpl = nullptr; p.bpl_plane = 0; p.b_slab_rows = 0; p.b_row0 = 0;
+    p.h2 = 0; p.a_scale = nullptr; p.b_inv = nullptr;
     if (q.b_planes) {
         const int64_t kp = ((int64_t)q.A.K + 31) / 32 * 32;
         TG_REQUIRE(q.b_seg_k == 0 && q.b_rows >= q.N && q.b_row0 >= 0 && q.b_row0 + (int64_t)q.N <= q.b_rows && aligned16(q.b_planes) &&
@@ -803,6 +804,11 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
                    "tg_gemm_nt: bad weight planes (problem %d): one weight matrix, its N=%d rows inside the buffer's %d, plane stride >= (rows + 1) * K "
                    "rounded up to 32, 16-byte aligned", idx, q.N, q.b_rows);
         p.Bpl = reinterpret_cast<const __bf16*>(q.b_planes); p.bpl_plane = (long)q.b_plane_stride; p.b_slab_rows = q.b_rows + 1; p.b_row0 = q.b_row0;
+        if (q.b_planes_kind == 1) {
+            TG_REQUIRE(q.b_inv_scale && q.a_row_scale && aligned16(q.b_inv_scale) && q.b_row0 % 4 == 0,
+                       "tg_gemm_nt: fp16 x 2 weight planes (problem %d) need b_inv_scale (16-byte aligned), a_row_scale and b_row0 %% 4 == 0", idx);
+            p.h2 = 1; p.a_scale = q.a_row_scale; p.b_inv = q.b_inv_scale;
+        } else TG_REQUIRE(q.b_planes_kind == 0, "tg_gemm_nt: b_planes_kind=%d (problem %d): 0 (bf16 x 3) or 1 (fp16 x 2)", q.b_planes_kind, idx);
     }
     TG_REQUIRE((q.res == nullptr) == (q.C2 == nullptr), "tg_gemm_nt: res and C2 go together (problem %d)", idx);
     p.gate = q.gate; p.res = q.res; p.C2 = q.C2; p.res_slope = q.res_slope;

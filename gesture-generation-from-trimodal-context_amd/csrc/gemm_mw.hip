@@ -43,14 +43,21 @@ constexpr unsigned MW_OOB = 0x80000000u;            // voffset of a piece that m
 typedef __attribute__((address_space(3))) void mw_lds_void;
 
 template <int NS>
-__device__ __forceinline__ void mw_split4(const f32x4 v, u32x2 (&out)[NS]) {
-    if constexpr (NS == 1) {                         // plain bf16 tier: round to nearest even
+__device__ __forceinline__ void mw_split4(const f32x4 v, const float scale, u32x2 (&out)[NS]) {
+    if constexpr (NS == 2) {                         // fp16 x 2 (common.hpp): hi / lo of the scaled values
+        const float x0 = v[0] * scale, x1 = v[1] * scale, x2 = v[2] * scale, x3 = v[3] * scale;
+        unsigned h0, l0, h1, l1;
+        h2_split2(x0, x1, h0, l0);
+        h2_split2(x2, x3, h1, l1);
+        out[0] = u32x2{h0, h1};
+        out[1] = u32x2{l0, l1};
+    } else if constexpr (NS == 1) {                         // plain bf16 tier: round to nearest even
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         bf16x4 r;
         r[0] = (__bf16)v[0]; r[1] = (__bf16)v[1]; r[2] = (__bf16)v[2]; r[3] = (__bf16)v[3];
         out[0] = __builtin_bit_cast(u32x2, r);
     } else {
-        static_assert(NS == 3, "1 or 3 terms");
+        static_assert(NS == 3, "1, 2 or 3 terms");
         unsigned h[4], m[4], l[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
         unsigned a_boff[NPA];
         int a_r[NPA];
         bool a_ok[NPA];
+        float a_s[NPA];                                        // fp16 x 2: the row's power-of-two scale
         unsigned rs4 = 0;
         int kk = 0, c = 0, kcur = 0, K_a = 0, a_cw = 4, a_dil = 0, a_rows_in = 0;
         const float* a_ptr = g.p[0].A.ptr;
@@ -167,14 +175,17 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
             }
             const NtProb& pr = g.p[pi];
             const Win A = pr.A;
+            const float* __restrict__ a_scale = pr.a_scale;
+            const int M_a = pr.M;
 #pragma unroll
             for (int q = 0; q < NPA; ++q) {
                 const int m = m0 + sr0 + 32 * q;
-                a_ok[q] = m < pr.M;
+                a_ok[q] = m < M_a;
                 const int mm = a_ok[q] ? m : 0;
                 const int b = mm / A.rows_out;
                 a_boff[q] = (unsigned)(((long)b * A.bs) * 4);
                 a_r[q] = (mm - b * A.rows_out) * A.step + A.shift;
+                if constexpr (NS == 2) a_s[q] = a_scale[mm];
             }
             rs4 = (unsigned)(A.rs * 4);
             a_cw = A.cw; a_dil = A.dil; a_rows_in = A.rows_in; K_a = A.K;
@@ -183,8 +194,14 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
             a_ptr = A.ptr; a_bytes = pr.a_bytes;
         };
         u32x4 ga[2][NPA];
+        float ga_s[2][NPA];                                    // fp16 x 2: the scales of the rows a register set holds (the cursor may move on to the next tile
+                                                               // -- other rows, other scales -- while the set still waits to be staged)
         auto fetch = [&](auto set_c) __attribute__((always_inline)) {
             constexpr int set = decltype(set_c)::value;
+            if constexpr (NS == 2) {
+#pragma unroll
+                for (int q = 0; q < NPA; ++q) ga_s[set][q] = a_s[q];
+            }
             const __amdgpu_buffer_rsrc_t a_rsrc = mw_rsrc(a_ptr, a_bytes);
             const bool inb = kcur < K_a;
             const unsigned c4 = (unsigned)(c * 4);
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
 #pragma unroll
             for (int q = 0; q < NPA; ++q) {
                 u32x2 o[NS];
-                mw_split4<NS>(__builtin_bit_cast(f32x4, ga[set][q]), o);
+                mw_split4<NS>(__builtin_bit_cast(f32x4, ga[set][q]), NS == 2 ? ga_s[set][q] : 1.f, o);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(lb + s * A_PLANE + (sr0 + 32 * q) * 64 + sp_wb) = o[s];
             }
@@ -340,6 +357,16 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                 return;
             }
             // term-major over the row tiles: the MFMAs that accumulate into one tile are I1 - I0 issues apart (smallest terms first)
+            if constexpr (NS == 2) {                   // fp16 x 2: lo_w hi_x + hi_w lo_x + hi_w hi_x
+                auto h = [](const bf16x8& v) { return __builtin_bit_cast(tg_f16x8, v); };
+#pragma unroll
+                for (int i = I0; i < I1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(fb[1]), h(fa[0][i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = I0; i < I1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(fb[0]), h(fa[1][i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = I0; i < I1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(fb[0]), h(fa[0][i]), acc[i][j], 0, 0, 0);
+                return;
+            }
             if constexpr (NS == 3) {
 #pragma unroll
                 for (int i = I0; i < I1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[2][i], acc[i][j], 0, 0, 0);
@@ -437,6 +464,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
             const int cR = pr.cR, accumulate = pr.accumulate, M = pr.M, N = pr.N;
             long ro[TM];
             bool rok[TM];
+            float inv_a[TM];                                   // fp16 x 2: 1 / scale of the product row (an exact power of two)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = m0 + wm * (16 * TM) + i * 16 + r16;
@@ -444,6 +472,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                 const int rr = rok[i] ? row : 0;
                 const int cb = rr / cR;
                 ro[i] = (long)cb * pr.cbs + (long)(rr - cb * cR) * pr.crs;
+                if constexpr (NS == 2) inv_a[i] = h2_inv_of_scale(pr.a_scale[rr]);
             }
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -452,6 +481,8 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                 const bool cok = col < N;                      // N % 4 == 0: a piece is inside or outside as a whole
                 const int cc0 = cok ? col : 0;
                 const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + cc0) : z4;
+                f32x4 inv_w = z4;                              // fp16 x 2: 1 / scale of the weight rows (zero past N)
+                if constexpr (NS == 2) { if (cok) inv_w = *reinterpret_cast<const f32x4*>(pr.b_inv + pr.b_row0 + cc0); }
                 constexpr int RB = TM > 2 ? 2 : TM;            // row tiles per batch: the batch's reads first, from always-valid addresses
 #pragma unroll
                 for (int i0 = 0; i0 < TM; i0 += RB) {
@@ -469,7 +500,9 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                     for (int u = 0; u < RB; ++u) {
                         const int i = i0 + u;
                         const long o = ro[i] + cc0;
-                        f32x4 v = acc[i][j] + bv;
+                        f32x4 v = acc[i][j];
+                        if constexpr (NS == 2) v = (v * inv_a[i]) * inv_w;      // two exact power-of-two steps: the pair's product could leave fp32's range
+                        v += bv;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q], slope);
                         if (mul || drop) v *= mv[u];
@@ -569,6 +602,7 @@ bool tg_gemm_nt_mw_eligible(NtGroup& g, int* tm, int* tn) {
         NtProb& p = g.p[i];
         if (!p.vec_c || p.A.cw % 4 != 0 || p.A.K % 4 != 0 || p.Bpl == nullptr || p.b_seg_k != p.A.K) return false;
         if (!mw_extents(p)) return false;
+        if (p.h2 != g.p[0].h2) return false;                   // one operand format per launch
     }
     MwTile tl;
     if (!mw_pick_tile(g, &tl)) return false;
@@ -606,7 +640,8 @@ int tg_gemm_nt_mw_launch(NtGroup& g, int tm, int tn, int splits, hipStream_t s) 
     // 128 x 192: matrix waves 2 x 4, wave tile 64 x 48; 128 x 160: 4 x 2, wave tile 32 x 80
 #define TG_MW(TM_, TN_, WM_, WN_)                                                                                          \
     do {                                                                                                                   \
-        if (splits == 3) hipLaunchKernelGGL((gemm_nt_mw_kernel<TM_, TN_, WM_, WN_, 3>), grid, dim3(768), 0, s, g);         \
+        if (g.p[0].h2) hipLaunchKernelGGL((gemm_nt_mw_kernel<TM_, TN_, WM_, WN_, 2>), grid, dim3(768), 0, s, g);          \
+        else if (splits == 3) hipLaunchKernelGGL((gemm_nt_mw_kernel<TM_, TN_, WM_, WN_, 3>), grid, dim3(768), 0, s, g);    \
         else hipLaunchKernelGGL((gemm_nt_mw_kernel<TM_, TN_, WM_, WN_, 1>), grid, dim3(768), 0, s, g);                     \
     } while (0)
     if (tm == 4 && tn == 6) TG_MW(4, 3, 2, 4);

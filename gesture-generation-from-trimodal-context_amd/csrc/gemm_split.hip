@@ -652,7 +652,10 @@ int tg_gemm_nt_mw_launch(NtGroup& g, int tm, int tn, int splits, hipStream_t s);
 int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
     {   // many-row products whose big tiles fill the chip: mover-wave kernel (gemm_mw.hip)
         int tm = 0, tn = 0;
-        if (tg_gemm_nt_mw_eligible(g, &tm, &tn)) return tg_gemm_nt_mw_launch(g, tm, tn, g_math_mode == 1 ? 1 : 3, s);
+        if (tg_gemm_nt_mw_eligible(g, &tm, &tn)) {
+            TG_REQUIRE(!(g.p[0].h2 && g_math_mode == 1), "tg_gemm_nt: fp16 x 2 weight planes belong to the fp32-accurate mode, not to the bf16 tier");
+            return tg_gemm_nt_mw_launch(g, tm, tn, g_math_mode == 1 ? 1 : 3, s);
+        }
     }
     for (int i = 0; i < g.n; ++i)
         TG_REQUIRE(g.p[i].drop_state == nullptr || g.p[i].vec_c, "tg_gemm_nt: regenerated dropout needs a vectorisable C (N %% 4 == 0, strides %% 4 == 0, "

@@ -125,7 +125,7 @@ class Drop:
 
 
 def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, M=None,
-                b_seg=None, out_scale=None, gate=None, res=None, out2=None, res_slope=0.0, w_planes=None, w_row0=0):
+                b_seg=None, out_scale=None, gate=None, res=None, out2=None, res_slope=0.0, w_planes=None, w_row0=0, a_row_scale=None):
     """Checked tg_gemm_nt_problem.  b_seg = (seg_k, seg_stride_floats): K-concatenated weights, W is the first [N, seg_k] segment and
     segment s starts seg_stride_floats * s floats after it (the caller keeps every segment alive).
     Epilogue extensions (big-product path only, nt_ext_supported): gate -- keep the result where gate > 0, zero elsewhere; res + out2 --
@@ -156,6 +156,13 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
     if w_planes is not None:                   # Planes that hold W's rows from w_row0 on (split3_planes / layers.weight_planes): mover-wave kernel
         assert b_seg is None and w_planes.cw == A.K and 0 <= w_row0 and w_row0 + N <= w_planes.rows and w_planes.t.is_cuda, (w_planes.rows, N, w_planes.cw, A.K)
         q.b_planes, q.b_plane_stride, q.b_rows, q.b_row0 = w_planes.t.data_ptr(), w_planes.plane_stride, w_planes.rows, int(w_row0)
+        if w_planes.kind == "h2":              # fp16 x 2 planes: the product rows' power-of-two scales ride along (h2_row_scales unless the caller has them)
+            assert w_row0 % 4 == 0, w_row0
+            if a_row_scale is None:
+                a_row_scale = h2_row_scales(A, M)
+            _f32(a_row_scale, "a_row_scale"); assert a_row_scale.numel() >= M and a_row_scale.is_contiguous()
+            q.b_planes_kind, q.b_inv_scale, q.a_row_scale = 1, w_planes.inv.data_ptr(), a_row_scale.data_ptr()
+            q._keep = (a_row_scale,)
     if isinstance(out_scale, Drop):            # the dropout scale regenerated in the epilogue: `out` must be the contiguous tensor the mask was drawn for
         assert out_scale.numel() == M * N and out_scale.index0 % 4 == 0 and N % 4 == 0, (out_scale.shape, M, N)
         assert c_row_stride == N and (c_rows_out >= M or c_batch_stride == c_rows_out * c_row_stride), "regenerated dropout needs a contiguous output"
@@ -230,13 +237,15 @@ GEMM_PLANES = True
 
 
 class Planes:
-    """bf16 x 3 planes of an fp32 matrix [rows][cw]: 3 x (rows + 1) x cwp bf16 (cwp = cw rounded up to 32), each plane slab-tiled
-    [cwp / 32][rows + 1][32] with an all-zero row `rows` in every slab (include/trimodal_hip.h).  `t` is that memory as a flat-ish
-    [3][rows + 1][cwp] tensor: index it through element_view(), never as a row-major matrix."""
-    __slots__ = ("t", "rows", "cw", "cwp")
+    """Pre-split planes of an fp32 matrix [rows][cw], each plane slab-tiled [cwp / 32][rows + 1][32] (cwp = cw rounded up to 32) with an
+    all-zero row `rows` in every slab (include/trimodal_hip.h).  kind 'x3': three bf16 planes, x = hi + mid + lo exactly, `t` is
+    [3][rows + 1][cwp] bf16.  kind 'h2': two fp16 planes of the rows scaled by their own power of two (tg_split2h_planes), `t` is
+    [2][rows + 1][cwp] fp16 and `inv` the rows' inverse scales (rows + 1 floats).  Index `t` through element_view(), never as a row-major
+    matrix."""
+    __slots__ = ("t", "rows", "cw", "cwp", "kind", "inv")
 
-    def __init__(self, t, rows, cw, cwp):
-        self.t, self.rows, self.cw, self.cwp = t, rows, cw, cwp
+    def __init__(self, t, rows, cw, cwp, kind="x3", inv=None):
+        self.t, self.rows, self.cw, self.cwp, self.kind, self.inv = t, rows, cw, cwp, kind, inv
 
     @property
     def plane_stride(self):
@@ -244,7 +253,8 @@ class Planes:
 
     def element_view(self):
         """[3][rows + 1][cwp] view in matrix order (a permuted view of the tiled memory, for tests)."""
-        return self.t.view(3, self.cwp // 32, self.rows + 1, 32).permute(0, 2, 1, 3).reshape(3, self.rows + 1, self.cwp)
+        n = self.t.shape[0]
+        return self.t.view(n, self.cwp // 32, self.rows + 1, 32).permute(0, 2, 1, 3).reshape(n, self.rows + 1, self.cwp)
 
 
 def planes_cwp(cw):
@@ -262,6 +272,46 @@ def split3_planes(x2d, out=None):
     assert tuple(t.shape) == (3, rows + 1, cwp) and t.is_contiguous() and t.dtype == torch.bfloat16
     call("tg_split3_planes", _p(x2d), x2d.stride(0), rows, cw, C.c_void_p(t.data_ptr()), cwp, (rows + 1) * cwp, _stream())
     return Planes(t, rows, cw, cwp)
+
+
+def h2_planes_alloc(rows, cw, device):
+    """Storage of an fp16 x 2 plane buffer: ONE fp16 tensor [2 planes | inverse scales as fp32], so that a batched refresh addresses it by one pointer."""
+    cwp = planes_cwp(cw)
+    n16 = 2 * (rows + 1) * cwp
+    buf = torch.empty(n16 + 2 * ((rows + 1 + 3) // 4 * 4), device=device, dtype=torch.float16)
+    return buf, buf[:n16].view(2, rows + 1, cwp), buf[n16:].view(torch.float32)
+
+
+def split2h_planes(x2d, buf=None):
+    """fp32 [rows][cw] view (unit inner stride) -> fp16 x 2 Planes (hi / lo of every row scaled by its own power of two + inverse scales)."""
+    _f32(x2d, "x"); assert x2d.dim() == 2 and x2d.stride(1) == 1
+    rows, cw = x2d.shape
+    if (rows - 1) * x2d.stride(0) + cw - 1 >= _room(x2d):
+        raise ValueError("split2h_planes: x exceeds its tensor")
+    cwp = planes_cwp(cw)
+    if buf is None:
+        buf = h2_planes_alloc(rows, cw, x2d.device)[0]
+    n16 = 2 * (rows + 1) * cwp
+    t, inv = buf[:n16].view(2, rows + 1, cwp), buf[n16:].view(torch.float32)
+    call("tg_split2h_planes", _p(x2d), x2d.stride(0), rows, cw, C.c_void_p(t.data_ptr()), cwp, (rows + 1) * cwp, C.c_void_p(inv.data_ptr()), _stream())
+    pl = Planes(t, rows, cw, cwp, "h2", inv)
+    return pl
+
+
+def win_row_absmax(A: Win, out=None):
+    """Largest magnitude of every source row of the window's tensor: [batches * rows_in] floats."""
+    n = A.batches * A.s.rows_in
+    out = torch.empty(n, device=A.t.device, dtype=torch.float32) if out is None else out
+    call("tg_win_row_absmax", C.byref(A.s), A.batches, C.c_void_p(out.data_ptr()), _stream())
+    return out
+
+
+def h2_row_scales(A: Win, M=None, src_rowmax=None, out=None):
+    """Power-of-two scale of every product row of the window (tg_gemm_nt_problem.a_row_scale): [M] floats."""
+    M = A.M if M is None else M
+    out = torch.empty(M, device=A.t.device, dtype=torch.float32) if out is None else out
+    call("tg_h2_row_scales", C.byref(A.s), M, C.c_void_p(src_rowmax.data_ptr()) if src_rowmax is not None else None, C.c_void_p(out.data_ptr()), _stream())
+    return out
 
 
 def zero_(t):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 6
+#define TG_ABI_VERSION 7
 
 int tg_version(void);
 
@@ -131,6 +131,17 @@ typedef struct tg_gemm_nt_problem {
     int64_t drop_index0;
     float drop_p;
     int32_t reserved4;
+    /* ABI 7 -- fp16 x 2 operands (three matrix instructions per product instead of bf16 x 3's six, csrc/common.hpp "two-term fp16 split"):
+     * b_planes_kind == 1 says b_planes is the TWO-plane fp16 buffer tg_split2h_planes writes (hi / lo of every row scaled by its own power of
+     * two) and b_inv_scale its per-row inverse scales (b_rows + 1 floats, 16-byte aligned, b_row0 % 4 == 0); a_row_scale then holds the
+     * power-of-two scale of every product row m < M of the window A (M floats, tg_h2_row_scales: the row's largest magnitude over its K values
+     * scaled into [2^14, 2^15)) by which the kernel multiplies the row before splitting it.  b_planes_kind == 0: bf16 x 3
+     * planes as before, both pointers ignored.  Same arithmetic contract as before: fp32 nn.Linear / nn.Conv1d / nn.GRU input projections
+     * (model/multimodal_context_net.py:98-104, model/tcn.py:19-25) within the fp32 tolerance. */
+    int32_t b_planes_kind;
+    int32_t reserved5;
+    const float* b_inv_scale;
+    const float* a_row_scale;
 } tg_gemm_nt_problem;
 /* tg_gemm_nt_group: up to 8 independent tg_gemm_nt products in ONE launch (both GRU directions' input projections, the stride
  * phases of a conv input-gradient ...).  All problems must fall into the same kernel family as problem 0 (big / narrow / small);
@@ -158,6 +169,17 @@ int tg_gemm_nt(const tg_window* A, const float* Bw, int64_t ldb, const float* bi
  * ((c / 32) * (rows + 1) + r) * 32 + c % 32; zero past cw and in row `rows` of every slab), so that one 32-deep K slab of 16 consecutive rows
  * is 1 KB of contiguous memory.  tg_gemm_nt_problem.b_planes takes weights in this form (mover-wave kernel, csrc/gemm_mw.hip). */
 int tg_split3_planes(const float* x, int64_t ldx, int32_t rows, int32_t cw, void* planes, int32_t cwp, int64_t plane_stride, void* stream);
+/* fp16 x 2 form of the same buffer (ABI 7): TWO fp16 planes, same slab tiling, holding hi = fp16(x s_r), lo = fp16(x s_r - hi) with s_r the
+ * power of two that puts row r's largest magnitude into [2^14, 2^15); inv_scale[r] = 1 / s_r for r < rows, 0 for the zero row (rows + 1 floats).
+ * Weights of nn.GRU / weight-normed nn.Conv1d as the matrix cores' fp16 operand (multimodal_context_net.py:98-99, model/tcn.py:19-25). */
+int tg_split2h_planes(const float* x, int64_t ldx, int32_t rows, int32_t cw, void* planes, int32_t cwp, int64_t plane_stride, float* inv_scale, void* stream);
+/* rowmax[b * A->rows_in + r] = max_c |A->ptr[b * batch_stride + r * row_stride + c]|, c < A->cw, for b < batches, r < A->rows_in: the largest magnitude
+ * of every SOURCE row of a window operand (one pass over the tensor; several windows over one tensor share it). */
+int tg_win_row_absmax(const tg_window* A, int32_t batches, float* rowmax, void* stream);
+/* row_scale[m] = 2^(141 - e_m), e_m the biased fp32 exponent (clamped to [32, 250]) of the largest magnitude among the K values of product row m of
+ * the window A -- tg_gemm_nt_problem.a_row_scale.  src_rowmax == NULL: read from the tensor itself (a row with t taps is read t times);
+ * else from tg_win_row_absmax's output for that tensor (batch b = m / rows_out, source rows (m % rows_out) * row_step + shift + tap * dil). */
+int tg_h2_row_scales(const tg_window* A, int32_t M, const float* src_rowmax, float* row_scale, void* stream);
 
 /* tg_gemm_tn (weight gradient, accumulates): dW[n*ldw + perm(k)] += sum_m dY[m*ldy + n] * A(m, k).
  *   out_kw == 0: perm(k) = k.  out_kw == K/cw: perm(k) = (k % cw) * out_kw + k / cw, i.e. the gradient lands in
