@@ -364,6 +364,18 @@ __global__ __launch_bounds__(256) void permute3_batch_kernel(const long* __restr
         }
         return;
     }
+    if (p0 == 10) {
+        // fp16 x 2 planes of a weight matrix (planes.hip tg_split2h_planes): src [d0 rows][d1 = cw] fp32 contiguous -> [2][d0 + 1][d2 = cwp] fp16 followed
+        // by the rows' inverse scales (d0 + 1 floats); one wave per row
+        const int rows = d[0], cw = d[1], cwp = d[2];
+        const long plane = (long)(rows + 1) * cwp;
+        _Float16* const planes = reinterpret_cast<_Float16*>(out);
+        float* const inv = reinterpret_cast<float*>(planes + 2 * plane);
+        const bool vec = (cw % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
+        for (long r = ((long)blockIdx.x - wg0) * 4 + (threadIdx.x >> 6); r <= rows; r += nwg * 4)
+            h2_write_row(in, (long)cw, rows, cw, cwp, planes, plane, inv, r, (int)(threadIdx.x & 63), vec);
+        return;
+    }
     if (p0 == 9) {
         // conv input-gradient pack (conv_dgrad_pack_kernel): src (Co, Ci, kw) -> [stride][Ci][J * Co], stride = p1, zero taps past kw
         const int Co = d[0], Ci = d[1], kw = d[2], st = p1, J = (kw + st - 1) / st;

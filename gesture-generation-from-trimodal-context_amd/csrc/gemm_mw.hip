@@ -631,7 +631,8 @@ int tg_gemm_nt_mw_launch(NtGroup& g, int tm, int tn, int splits, hipStream_t s) 
         const char* e = getenv("TG_MW_ABL");
         const int abl = e ? atoi(e) : 0;
         if (abl && tm == 4 && tn == 6 && splits == 3) {
-#define TG_ABL(A_) case A_: hipLaunchKernelGGL((gemm_nt_mw_kernel<4, 3, 2, 4, 3, A_>), grid, dim3(768), 0, s, g); return check_launch("tg_gemm_nt(mover waves, ablated)")
+#define TG_ABL(A_) case A_: if (g.p[0].h2) hipLaunchKernelGGL((gemm_nt_mw_kernel<4, 3, 2, 4, 2, A_>), grid, dim3(768), 0, s, g); \
+                            else hipLaunchKernelGGL((gemm_nt_mw_kernel<4, 3, 2, 4, 3, A_>), grid, dim3(768), 0, s, g); return check_launch("tg_gemm_nt(mover waves, ablated)")
             switch (abl) { TG_ABL(1); TG_ABL(2); TG_ABL(6); TG_ABL(8); TG_ABL(14); TG_ABL(15); TG_ABL(16); TG_ABL(32); TG_ABL(33); default: break; }
 #undef TG_ABL
         }

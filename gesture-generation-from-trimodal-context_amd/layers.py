@@ -74,6 +74,11 @@ class WeightPrep:
                     rows.append([s3.data_ptr(), d.data_ptr(), s3.shape[1], s3.shape[2], d.shape[2], 8, 0, 0, wg0, nwg])
                     wg0 += nwg
                     continue
+                if pm[0] == 10:                                       # fp16 x 2 planes: d = the flat buffer [2 planes | inverse scales], one wave per row
+                    nwg = max(1, min(512, (s3.shape[1] + 16) // 16))
+                    rows.append([s3.data_ptr(), d.data_ptr(), s3.shape[1], s3.shape[2], ops.planes_cwp(s3.shape[2]), 10, 0, 0, wg0, nwg])
+                    wg0 += nwg
+                    continue
                 # ~2 LDS tiles (32 x 32 per batch index) per workgroup.  Counted in TILES, not elements: a conv pack (Co, Ci, kw) is Co small
                 # tiles -- sized by elements it got one workgroup that walked 16-64 tiles one after the other (16-27 us per launch)
                 tiles = s3.shape[0] * ((s3.shape[1] + 31) // 32) * ((s3.shape[2] + 31) // 32) if tuple(pm) == (0, 2, 1) else (d.numel() + 1023) // 1024
@@ -107,6 +112,9 @@ class WeightPrep:
             return None
         if perm[0] == 8:                                          # bf16 x 3 planes of a weight [rows][cw] (src3 = (1, rows, cw)): [3][rows + 1][cwp] bf16
             dst = ops.split3_planes(src3[0]).t
+        elif perm[0] == 10:                                       # fp16 x 2 planes + inverse scales of the same: one flat fp16 buffer (ops.h2_planes_alloc)
+            dst = ops.h2_planes_alloc(src3.shape[1], src3.shape[2], src3.device)[0]
+            ops.split2h_planes(src3[0], buf=dst)
         elif perm[0] == 9:
             dst = empty(*out_shape, like=src3)
             ops.conv_dgrad_pack(src3, dst, perm[1])
@@ -183,13 +191,19 @@ def pack_conv_weight(w):
 
 
 def weight_planes(w2d):
-    """bf16 x 3 planes (ops.Planes) of a weight matrix [N][K]: refreshed once per optimiser step by an active WeightPrep, split inline otherwise."""
+    """Pre-split planes (ops.Planes) of a weight matrix [N][K] -- fp16 x 2 (ops.GEMM_H2, the default) or bf16 x 3 -- refreshed once per optimiser
+    step by an active WeightPrep, split inline otherwise."""
     N, K = w2d.shape
+    h2 = ops.gemm_h2()
     if _PREP is not None and w2d.is_contiguous():
-        hit = _PREP.get(w2d.view(1, N, K), (8, 0, 0), None)
+        hit = _PREP.get(w2d.view(1, N, K), (10 if h2 else 8, 0, 0), None)
         if hit is not None:
+            if h2:
+                cwp = ops.planes_cwp(K)
+                n16 = 2 * (N + 1) * cwp
+                return ops.Planes(hit[:n16].view(2, N + 1, cwp), N, K, cwp, "h2", hit[n16:].view(torch.float32))
             return ops.Planes(hit, N, K, hit.shape[2])
-    return ops.split3_planes(w2d)
+    return ops.split_planes(w2d)
 
 
 def dgrad_pack(w, stride):

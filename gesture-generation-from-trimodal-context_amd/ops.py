@@ -7,6 +7,7 @@ the GPU (kernels themselves only guard their own tile edges).
 import ctypes as C
 
 import contextlib
+import os
 
 import torch
 
@@ -234,6 +235,19 @@ def gemm_nt_group(problems):
 # csrc/planes.hip: weight matrices split ONCE per optimiser step (layers.WeightPrep) into hi / mid / lo bf16 planes; on the many-row products
 # of the stacked forward the mover waves of gemm_mw.hip fetch them global -> LDS by DMA while the matrix waves multiply.
 GEMM_PLANES = True
+# Round 6: the planes hold the fp16 x 2 split (two fp16 planes of every row scaled by its own power of two: three matrix instructions per
+# product instead of six, csrc/common.hpp); TG_GEMM_H2=0 keeps bf16 x 3 planes (A/B timing).  Never in the bf16 tier (set_math_mode('bf16')).
+GEMM_H2 = os.environ.get("TG_GEMM_H2", "1") != "0"
+
+
+def gemm_h2():
+    return GEMM_H2 and _lib.load().tg_get_math_mode() == 0
+
+
+def split_planes(x2d):
+    """Planes of the active operand format (split2h_planes / split3_planes)."""
+    return split2h_planes(x2d) if gemm_h2() else split3_planes(x2d)
+
 
 
 class Planes:

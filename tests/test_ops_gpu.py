@@ -716,9 +716,15 @@ def _mm64(x, w):
     return x.double() @ w.double().t()
 
 
+def _planes_of(ops, fmt):
+    """The weight-plane splitter of an operand format: 'h2' = fp16 x 2 (round 6: three matrix instructions per product), 'x3' = bf16 x 3 (six)."""
+    return {"h2": ops.split2h_planes, "x3": ops.split3_planes}[fmt]
+
+
+@pytest.mark.parametrize("fmt", ["h2", "x3"])
 @pytest.mark.parametrize("M,N,K,tile", [(13000, 900, 600, (128, 192)), (13056, 900, 108, (128, 192)), (13056, 300, 600, (128, 160)),
                                         (9999, 596, 1000, (128, 160))])
-def test_gemm_nt_mover_wave_kernel_is_fp32_accurate(pkg, dev, M, N, K, tile):
+def test_gemm_nt_mover_wave_kernel_is_fp32_accurate(pkg, dev, M, N, K, tile, fmt):
     """csrc/gemm_mw.hip (512-thread workgroups: four mover waves stage + split the operands, four matrix waves multiply; big tiles, one
     workgroup per CU) on the shapes it is chosen for -- the stacked forward's GRU input projections (multimodal_context_net.py:98-99: N =
     900, K = 600 / 108) and the TCN convs (model/tcn.py:19-46: N = 300) -- against fp64 at the fp32 tolerance: ragged tails in M, N and K,
@@ -731,7 +737,8 @@ def test_gemm_nt_mover_wave_kernel_is_fp32_accurate(pkg, dev, M, N, K, tile):
     xd = x.to(dev)
     outs = [torch.full((M, N + 8), float("nan"), device=dev) for _ in range(2)]
     wd = [w.to(dev) for w in ws]
-    probs = [dict(A=Win.plain(xd), W=w, bias=b.to(dev), out=o[:, 4:4 + N], act_slope=0.3, w_planes=ops.split3_planes(w)) for w, b, o in zip(wd, bs, outs)]
+    split = _planes_of(ops, fmt)
+    probs = [dict(A=Win.plain(xd), W=w, bias=b.to(dev), out=o[:, 4:4 + N], act_slope=0.3, w_planes=split(w)) for w, b, o in zip(wd, bs, outs)]
     assert ops.nt_kernel_plan([{k: v for k, v in p.items() if k != "w_planes"} for p in probs])[0] == 1      # without pre-split weights: staged-slab kernel
     plan = ops.nt_kernel_plan(probs)
     assert plan == (2,) + tile, plan                          # this test is about the mover-wave kernel: fail if the dispatcher chose another
@@ -741,7 +748,7 @@ def test_gemm_nt_mover_wave_kernel_is_fp32_accurate(pkg, dev, M, N, K, tile):
         assert _row_err(o[:, 4:4 + N], ref) < 1e-5
         assert bool(torch.isnan(o[:, :4]).all()) and bool(torch.isnan(o[:, 4 + N:]).all())
     # the weights' rows may sit anywhere inside a bigger plane buffer (w_row0): both matrices stacked in one buffer, accumulate form
-    both = ops.split3_planes(torch.cat(wd, 0))
+    both = split(torch.cat(wd, 0))
     acc_p = [dict(A=Win.plain(xd), W=wd[1], bias=None, out=outs[0][:, 4:4 + N], accumulate=True, w_planes=both, w_row0=N)]
     assert ops.nt_kernel_plan(acc_p)[0] == 2
     ops.gemm_nt_group(acc_p)
@@ -749,7 +756,8 @@ def test_gemm_nt_mover_wave_kernel_is_fp32_accurate(pkg, dev, M, N, K, tile):
     assert _row_err(outs[0][:, 4:4 + N], ref2) < 1e-5
 
 
-def test_gemm_nt_mover_wave_kernel_windows_and_epilogues(pkg, dev):
+@pytest.mark.parametrize("fmt", ["h2", "x3"])
+def test_gemm_nt_mover_wave_kernel_windows_and_epilogues(pkg, dev, fmt):
     """The same kernel behind the windows and epilogues of the text encoder at the stacked forward's size (B_s = 384 clips x 34 frames):
     the dilated causal conv with its zero padding (rows before the clip read as zero through the buffer descriptor's range check),
     ReLU + dropout scale + the block's closing relu(out + x) as second output (forward form, model/tcn.py:27-46), the input-gradient
@@ -766,7 +774,8 @@ def test_gemm_nt_mover_wave_kernel_windows_and_epilogues(pkg, dev):
     wp = Lm.pack_conv_weight(w.float().to(dev))
     a_win = Win.conv(xd, 2, pad=d, dil=d, rows_out=T)
     out, out2 = torch.full((B, T, Cc), float("nan"), device=dev), torch.full((B, T, Cc), float("nan"), device=dev)
-    wpl = ops.split3_planes(wp)
+    split = _planes_of(ops, fmt)
+    wpl = split(wp)
     assert ops.nt_kernel_plan([dict(A=a_win, W=wp, bias=b.float().to(dev), out=out, c_batch_stride=out.stride(0), c_row_stride=out.stride(1),
                                     c_rows_out=T, w_planes=wpl)])[0] == 2
     o = Lm.conv_fwd(xd, wp, b.float().to(dev), 2, pad=d, dil=d, rows_out=T, act_slope=0.0, out_scale=mask.to(dev), res=res.to(dev), out2=out2, out=out,
@@ -785,7 +794,7 @@ def test_gemm_nt_mover_wave_kernel_windows_and_epilogues(pkg, dev):
     a_back = Win.taps(dyd, 2, shift=0, dil=d, rows_out=T)
     acc = base.to(dev).clone()
     wTd = wT.to(dev)
-    probs = [dict(A=a_back, W=wTd, bias=None, out=acc, gate=gate.to(dev), accumulate=True, w_planes=ops.split3_planes(wTd))]
+    probs = [dict(A=a_back, W=wTd, bias=None, out=acc, gate=gate.to(dev), accumulate=True, w_planes=split(wTd))]
     assert ops.nt_kernel_plan(probs)[0] == 2
     ops.gemm_nt_group(probs)
     dyp = torch.cat([dy.double(), torch.zeros(B, d, Cc, dtype=torch.float64)], dim=1)
@@ -805,7 +814,8 @@ def test_gemm_nt_mover_wave_kernel_windows_and_epilogues(pkg, dev):
     assert float((outc.double() - refc).abs().max() / refc.abs().max()) < 1e-5
 
 
-def test_regenerated_dropout_equals_stored_mask(pkg, dev):
+@pytest.mark.parametrize("fmt", ["h2", "x3"])
+def test_regenerated_dropout_equals_stored_mask(pkg, dev, fmt):
     """ops.Drop: the text encoder's dropout scale masks are not stored -- the conv epilogues (mover-wave and staged-slab kernels), the gated
     input-gradient epilogue and act_mask_bwd / act_mask_bwd2 regenerate their elements from the counter RNG (model/tcn.py:22-29 forward and
     backward).  Every consumer must produce BIT-IDENTICAL results to the stored mask of the same draw (tg_dropout_mask), including on the row
@@ -820,7 +830,7 @@ def test_regenerated_dropout_equals_stored_mask(pkg, dev):
     x = torch.randn(B, T, Cc, generator=g).to(dev)
     wp = (torch.randn(Cc, 2 * Cc, generator=g) * 0.05).to(dev)
     b = torch.randn(Cc, generator=g).to(dev)
-    wpl = ops.split3_planes(wp)
+    wpl = _planes_of(ops, fmt)(wp)
     res = torch.randn(B, T, Cc, generator=g).to(dev)
     outs = []
     for m in (mask, drop):                                  # forward conv on the mover-wave kernel, with the residual second output
@@ -1235,6 +1245,51 @@ def test_split3_planes_are_exact(pkg, dev):
     xs = torch.zeros(50, 200, device=dev); xs[:, 3:111] = rnd(50, 108, seed=52).to(dev)
     pv = ops.split3_planes(xs[:, 3:111]).element_view()                    # unaligned strided view: scalar path
     assert torch.equal((pv[0].double() + pv[1].double() + pv[2].double())[:50, :108].float(), xs[:, 3:111])
+
+
+def test_split2h_planes_and_row_scales(pkg, dev):
+    """fp16 x 2 planes (csrc/planes.hip tg_split2h_planes): every row scaled by the power of two that puts its largest magnitude into
+    [2^14, 2^15); (hi + lo) * inv reproduces x to 2^-22 of the row's largest (fp16 hi and lo, round to nearest); padding columns and the
+    extra row are zero; same slab tiling as the bf16 x 3 planes.  Rows spanning 30 decades, a zero row, an unaligned strided source.
+    tg_h2_row_scales / tg_win_row_absmax: the product rows' scales of plain and tap windows (zero padding does not count), computed from the
+    tensor and from its per-source-row magnitudes alike."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    x = rnd(37, 108, seed=51) * torch.logspace(-15, 15, 37)[:, None]
+    x[11] = 0
+    xd = x.to(dev)
+    pl = ops.split2h_planes(xd)
+    assert pl.kind == "h2" and pl.cwp == 128 and pl.t.shape == (2, 38, 128) and pl.t.dtype == torch.float16 and pl.inv.numel() >= 38
+    ev = pl.element_view().double().cpu()
+    inv = pl.inv[:38].double().cpu()
+    rowmax = x.double().abs().amax(dim=1)
+    back = (ev[0] + ev[1]) * inv[:, None]
+    assert float(((back[:37, :108] - x.double()).abs() / rowmax.clamp_min(1e-300)[:, None]).max()) <= 2.0 ** -22
+    assert float(back[:37, 108:].abs().max()) == 0 and float(back[37].abs().max()) == 0 and float(inv[37]) == 0 and float(back[11].abs().max()) == 0
+    live = rowmax > 0
+    scaled_max = (ev[0] + ev[1]).abs().amax(dim=1)[:37][live]
+    assert float(scaled_max.min()) >= 2.0 ** 14 and float(scaled_max.max()) <= 2.0 ** 15           # the row's largest sits in [2^14, 2^15]
+    assert bool(((torch.log2(inv[:37][live]) % 1) == 0).all())                                     # exact powers of two
+    raw = pl.t.view(2, -1).double().cpu()
+    o = (2 * 38 + 5) * 32                                                                          # slab 2 (columns 64..95) of row 5
+    assert float(((raw[0, o:o + 32] + raw[1, o:o + 32]) * inv[5] - x[5, 64:96].double()).abs().max()) <= 2.0 ** -22 * float(rowmax[5])
+    xs = torch.zeros(50, 200, device=dev); xs[:, 3:111] = rnd(50, 108, seed=52).to(dev)
+    pu = ops.split2h_planes(xs[:, 3:111])                                                          # unaligned strided view: scalar path
+    bu = (pu.element_view()[0].double() + pu.element_view()[1].double()) * pu.inv[:51].double()[:, None]
+    assert float((bu[:50, :108] - xs[:, 3:111].double()).abs().max()) <= 2.0 ** -22 * float(xs.abs().max())
+    # product-row scales: plain rows, and a dilated causal conv window whose early rows reach into the zero padding
+    sc = ops.h2_row_scales(Win.plain(xd)).double().cpu()
+    assert torch.equal(sc[live] * inv[:37][live], torch.ones(int(live.sum()), dtype=torch.float64))
+    B, T, Cc, d = 5, 34, 20, 4
+    a = (rnd(B, T, Cc, seed=53) * torch.logspace(-3, 3, T)[None, :, None]).to(dev)
+    win = Win.conv(a, 2, pad=d, dil=d, rows_out=T)
+    s1 = ops.h2_row_scales(win)
+    s2 = ops.h2_row_scales(win, src_rowmax=ops.win_row_absmax(win))
+    am = a.double().abs().amax(dim=2).cpu()                                                        # (B, T)
+    pad = torch.cat([torch.zeros(B, d, dtype=torch.float64), am], dim=1)
+    want_max = torch.maximum(pad[:, :T], pad[:, d:d + T]).reshape(-1)                              # taps t - d and t
+    assert torch.equal(s1, s2)
+    prod = want_max * s1.double().cpu()
+    assert float(prod.min()) >= 2.0 ** 14 and float(prod.max()) < 2.0 ** 15
 
 
 @pytest.mark.parametrize("B,T1", [(3, 217), (5, 1313), (2, 7891)])

@@ -21,7 +21,14 @@ M, N, K = 13056, 900, 600
 x = torch.randn(M, K, device=dev)
 ws = [torch.randn(N, K, device=dev) * 0.05 for _ in range(2)]
 outs = [torch.empty(M, N, device=dev) for _ in range(2)]
-probs = [dict(A=Win.plain(x), W=w, bias=None, out=o, w_planes=ops.split3_planes(w)) for w, o in zip(ws, outs)]
+H2 = os.environ.get("TG_ABL_H2", "0") == "1"          # round 6: the fp16 x 2 instantiation (three MFMAs per product, two planes)
+A = Win.plain(x)
+if H2:
+    sc = ops.h2_row_scales(A)
+    probs = [dict(A=A, W=w, bias=None, out=o, w_planes=ops.split2h_planes(w), a_row_scale=sc) for w, o in zip(ws, outs)]
+else:
+    probs = [dict(A=A, W=w, bias=None, out=o, w_planes=ops.split3_planes(w)) for w, o in zip(ws, outs)]
+print("# operands:", "fp16 x 2" if H2 else "bf16 x 3")
 assert ops.nt_kernel_plan(probs) == (2, 128, 192)
 names = {0: "full kernel", 1: "no MFMA", 2: "movers: no split, no LDS stores", 6: "movers: weight DMAs only", 8: "no weight DMAs",
          14: "movers idle", 15: "barriers + fragment reads + epilogue", 16: "no epilogue traffic", 32: "weight DMAs awaited one step later",
