@@ -101,8 +101,15 @@ struct NtProb {
     // fp16 x 2 (h2 != 0): Bpl holds TWO fp16 planes (hi / lo of the scaled rows, tg_split2h_planes), b_inv[buffer row] = 1 / that row's scale,
     // a_scale[m] = the power-of-two scale of product row m (tg_h2_row_scales: 2^(141 - e) for the largest magnitude over the row's K values)
     const float* a_scale;
+    // ... or (a_rmax != nullptr, windows of at most two taps) the largest magnitude of every SOURCE row, index batch * rows_in + source row, written by
+    // the activation's producer (non-negative floats; combined with atomic unsigned max): the kernel derives the product rows' scales itself
+    const float* a_rmax;
     const float* b_inv;
     int h2;
+    // optional outputs for the NEXT product's a_rmax: c_rmax[m] / c2_rmax[m] = max(old, largest magnitude of row m of C / C2) by atomic unsigned
+    // max (the caller zeroes them once per pass; rows are product rows: M floats)
+    float* c_rmax;
+    float* c2_rmax;
 };
 
 struct NtGroup {

@@ -742,6 +742,8 @@ static int nt_launch(NtGroup& g, hipStream_t s) {
     }
     if (fam == 0 && use_split_path()) return tg_gemm_nt_split_launch(g, s);
     for (int i = 0; i < g.n; ++i)
+        TG_REQUIRE(!g.p[i].c_rmax && !g.p[i].c2_rmax, "tg_gemm_nt: c_rowmax / c2_rowmax are outputs of the mover-wave kernel only (tg_gemm_nt_kernel_plan == 2; problem %d)", i);
+    for (int i = 0; i < g.n; ++i)
         TG_REQUIRE(!nt_has_ext(g.p[i]), "tg_gemm_nt: gate / res / C2 / regenerated dropout need the big-product split path (tg_gemm_nt_ext_supported; problem %d)", i);
     if (fam == 0) {
         int Mx = 0, Nx = 0;
@@ -796,7 +798,9 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
     p.M = q.M; p.N = q.N; p.slope = q.act_slope; p.accumulate = q.accumulate; p.n_nt = 0;
     p.a_bytes = p.b_bytes = 0;
     p.Bpl = nullptr; p.bpl_plane = 0; p.b_slab_rows = 0; p.b_row0 = 0;
-    p.h2 = 0; p.a_scale = nullptr; p.b_inv = nullptr;
+    p.h2 = 0; p.a_scale = nullptr; p.a_rmax = nullptr; p.b_inv = nullptr;
+    p.c_rmax = q.c_rowmax; p.c2_rmax = q.c2_rowmax;
+    TG_REQUIRE(!q.c2_rowmax || q.C2, "tg_gemm_nt: c2_rowmax without C2 (problem %d)", idx);
     if (q.b_planes) {
         const int64_t kp = ((int64_t)q.A.K + 31) / 32 * 32;
         TG_REQUIRE(q.b_seg_k == 0 && q.b_rows >= q.N && q.b_row0 >= 0 && q.b_row0 + (int64_t)q.N <= q.b_rows && aligned16(q.b_planes) &&
@@ -805,9 +809,11 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
                    "rounded up to 32, 16-byte aligned", idx, q.N, q.b_rows);
         p.Bpl = reinterpret_cast<const __bf16*>(q.b_planes); p.bpl_plane = (long)q.b_plane_stride; p.b_slab_rows = q.b_rows + 1; p.b_row0 = q.b_row0;
         if (q.b_planes_kind == 1) {
-            TG_REQUIRE(q.b_inv_scale && q.a_row_scale && aligned16(q.b_inv_scale) && q.b_row0 % 4 == 0,
-                       "tg_gemm_nt: fp16 x 2 weight planes (problem %d) need b_inv_scale (16-byte aligned), a_row_scale and b_row0 %% 4 == 0", idx);
-            p.h2 = 1; p.a_scale = q.a_row_scale; p.b_inv = q.b_inv_scale;
+            TG_REQUIRE(q.b_inv_scale && ((q.a_row_scale != nullptr) != (q.a_rowmax != nullptr)) && aligned16(q.b_inv_scale) && q.b_row0 % 4 == 0,
+                       "tg_gemm_nt: fp16 x 2 weight planes (problem %d) need b_inv_scale (16-byte aligned), exactly one of a_row_scale / a_rowmax and b_row0 %% 4 == 0", idx);
+            TG_REQUIRE(!q.a_rowmax || q.A.K <= 2 * q.A.cw, "tg_gemm_nt: a_rowmax serves windows of at most two taps (problem %d: %d); pass a_row_scale (tg_h2_row_scales)",
+                       idx, q.A.K / q.A.cw);
+            p.h2 = 1; p.a_scale = q.a_row_scale; p.a_rmax = q.a_rowmax; p.b_inv = q.b_inv_scale;
         } else TG_REQUIRE(q.b_planes_kind == 0, "tg_gemm_nt: b_planes_kind=%d (problem %d): 0 (bf16 x 3) or 1 (fp16 x 2)", q.b_planes_kind, idx);
     }
     TG_REQUIRE((q.res == nullptr) == (q.C2 == nullptr), "tg_gemm_nt: res and C2 go together (problem %d)", idx);

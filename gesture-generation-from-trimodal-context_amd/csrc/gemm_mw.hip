@@ -176,6 +176,8 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
             const NtProb& pr = g.p[pi];
             const Win A = pr.A;
             const float* __restrict__ a_scale = pr.a_scale;
+            const float* __restrict__ a_rmax = pr.a_rmax;      // fp16 x 2, second form: magnitudes of the SOURCE rows (one or two taps): the scale is derived here
+            const int two_taps = A.K > A.cw;
             const int M_a = pr.M;
 #pragma unroll
             for (int q = 0; q < NPA; ++q) {
@@ -185,7 +187,16 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                 const int b = mm / A.rows_out;
                 a_boff[q] = (unsigned)(((long)b * A.bs) * 4);
                 a_r[q] = (mm - b * A.rows_out) * A.step + A.shift;
-                if constexpr (NS == 2) a_s[q] = a_scale[mm];
+                if constexpr (NS == 2) {
+                    // (branch-free: two loads from always-valid addresses, then selects)
+                    const float* __restrict__ rm = a_rmax ? a_rmax + (long)b * A.rows_in : a_scale;
+                    const int s0 = a_r[q], s1 = s0 + A.dil;
+                    const bool ok0 = (unsigned)s0 < (unsigned)A.rows_in, ok1 = two_taps && (unsigned)s1 < (unsigned)A.rows_in;
+                    const unsigned v0 = __float_as_uint(rm[a_rmax ? (ok0 ? s0 : 0) : mm]);
+                    const unsigned v1 = __float_as_uint(rm[a_rmax ? (ok1 ? s1 : 0) : mm]);
+                    const unsigned vm = (ok0 ? v0 : 0u) > (ok1 ? v1 : 0u) ? (ok0 ? v0 : 0u) : (ok1 ? v1 : 0u);
+                    a_s[q] = a_rmax ? h2_scale_of_exp(h2_exp_of_bits(vm)) : __uint_as_float(v0);
+                }
             }
             rs4 = (unsigned)(A.rs * 4);
             a_cw = A.cw; a_dil = A.dil; a_rows_in = A.rows_in; K_a = A.K;
@@ -472,9 +483,25 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                 const int rr = rok[i] ? row : 0;
                 const int cb = rr / cR;
                 ro[i] = (long)cb * pr.cbs + (long)(rr - cb * cR) * pr.crs;
-                if constexpr (NS == 2) inv_a[i] = h2_inv_of_scale(pr.a_scale[rr]);
+                if constexpr (NS == 2) {
+                    if (pr.a_rmax) {
+                        const int ab = rr / pr.A.rows_out;
+                        const int s0 = (rr - ab * pr.A.rows_out) * pr.A.step + pr.A.shift, s1 = s0 + pr.A.dil;
+                        const float* __restrict__ rm = pr.a_rmax + (long)ab * pr.A.rows_in;
+                        const unsigned v0 = (unsigned)s0 < (unsigned)pr.A.rows_in ? __float_as_uint(rm[s0]) : 0u;
+                        const unsigned v1 = (pr.A.K > pr.A.cw && (unsigned)s1 < (unsigned)pr.A.rows_in) ? __float_as_uint(rm[s1]) : 0u;
+                        inv_a[i] = h2_inv_of_exp(h2_exp_of_bits(v0 > v1 ? v0 : v1));
+                    } else inv_a[i] = h2_inv_of_scale(pr.a_scale[rr]);
+                }
             }
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            // optional row magnitudes of what this tile writes (the next product's a_rmax): per lane over its columns here, across the row's four
+            // lanes and into memory after the column loop
+            float* const c_rmax = pr.c_rmax;
+            float* const c2_rmax = pr.c2_rmax;
+            unsigned mx1[TM], mx2[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) mx1[i] = mx2[i] = 0u;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn * (16 * TN) + j * 16 + 4 * kq;
@@ -514,12 +541,38 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                         const bool ok = rok[i] & cok;
                         if constexpr (ABL & 16) { if (v[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(C + o) = v; continue; }
                         if (ok) *reinterpret_cast<f32x4*>(C + o) = v;
+                        if (c_rmax && cok) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { const float f = v[q]; const unsigned b = __float_as_uint(f) & 0x7fffffffu; mx1[i] = mx1[i] > b ? mx1[i] : b; }
+                        }
                         if (res) {
                             f32x4 w = v + rv[u];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) w[q] = act_fn(w[q], slope2);
                             if (ok) *reinterpret_cast<f32x4*>(C2 + o) = w;
+                            if (c2_rmax && cok) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) { const float f = w[q]; const unsigned b = __float_as_uint(f) & 0x7fffffffu; mx2[i] = mx2[i] > b ? mx2[i] : b; }
+                            }
                         }
+                    }
+                }
+            }
+            if (c_rmax || c2_rmax) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = m0 + wm * (16 * TM) + i * 16 + r16;
+                    if (c_rmax) {
+                        unsigned m = mx1[i];
+                        unsigned w = (unsigned)__shfl_xor((int)m, 16, 64); m = m > w ? m : w;
+                        w = (unsigned)__shfl_xor((int)m, 32, 64); m = m > w ? m : w;
+                        if (kq == 0 && rok[i]) atomicMax(reinterpret_cast<unsigned*>(c_rmax) + row, m);
+                    }
+                    if (c2_rmax) {
+                        unsigned m = mx2[i];
+                        unsigned w = (unsigned)__shfl_xor((int)m, 16, 64); m = m > w ? m : w;
+                        w = (unsigned)__shfl_xor((int)m, 32, 64); m = m > w ? m : w;
+                        if (kq == 0 && rok[i]) atomicMax(reinterpret_cast<unsigned*>(c2_rmax) + row, m);
                     }
                 }
             }

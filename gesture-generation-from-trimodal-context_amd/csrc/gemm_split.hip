@@ -658,6 +658,8 @@ int tg_gemm_nt_split_launch(NtGroup& g, hipStream_t s) {
         }
     }
     for (int i = 0; i < g.n; ++i)
+        TG_REQUIRE(!g.p[i].c_rmax && !g.p[i].c2_rmax, "tg_gemm_nt: c_rowmax / c2_rowmax are outputs of the mover-wave kernel only (tg_gemm_nt_kernel_plan == 2; problem %d)", i);
+    for (int i = 0; i < g.n; ++i)
         TG_REQUIRE(g.p[i].drop_state == nullptr || g.p[i].vec_c, "tg_gemm_nt: regenerated dropout needs a vectorisable C (N %% 4 == 0, strides %% 4 == 0, "
                    "16-byte aligned; problem %d)", i);
     int Mx = 0, Nx = 0;

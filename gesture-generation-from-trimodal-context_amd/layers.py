@@ -246,9 +246,10 @@ def conv_out_len(L, kw, stride=1, pad=0, dil=1):
 
 
 def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=1.0, rows_out=None, out_scale=None, res=None, out2=None,
-             res_slope=0.0, w_planes=None, w_row0=0):
+             res_slope=0.0, w_planes=None, w_row0=0, **scales):
     """x: (B, L, Ci) view; w_packed: [Co, kw*Ci]; out: (B, Lout, Co) view (may be a channel slice of a wider buffer).
-    res / out2 (ops.nt_ext_supported only): out2 = leaky_relu(out + res, res_slope) written by the same launch."""
+    res / out2 (ops.nt_ext_supported only): out2 = leaky_relu(out + res, res_slope) written by the same launch.
+    scales: the fp16 x 2 row-magnitude operands of ops.gemm_nt (a_rowmax, out_rowmax, out2_rowmax)."""
     B, L, _ = x.shape
     Lo = conv_out_len(L, kw, stride, pad, dil) if rows_out is None else rows_out
     Co = w_packed.shape[0]
@@ -257,7 +258,7 @@ def conv_fwd(x, w_packed, b, kw, *, stride=1, pad=0, dil=1, out=None, act_slope=
     assert tuple(out.shape) == (B, Lo, Co) and out.stride(2) == 1
     A = Win.conv(x, kw, stride=stride, pad=pad, dil=dil, rows_out=Lo)
     ops.gemm_nt(A, w_packed, b, out, act_slope=act_slope, c_batch_stride=out.stride(0), c_row_stride=out.stride(1),
-                c_rows_out=Lo, out_scale=out_scale, res=res, out2=out2, res_slope=res_slope, w_planes=w_planes, w_row0=w_row0)
+                c_rows_out=Lo, out_scale=out_scale, res=res, out2=out2, res_slope=res_slope, w_planes=w_planes, w_row0=w_row0, **scales)
     return out
 
 
@@ -481,8 +482,14 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
         a_win = Win.plain(cur.view(B * T, Kin))
         # many-row projections (the stacked forward): pre-split weights let the mover-wave kernel take them (csrc/gemm_mw.hip)
         wpl = (lambda w: weight_planes(w)) if (ops.GEMM_PLANES and B * T >= 8192 and H > 64) else (lambda w: None)
+        # fp16 x 2 operands: a layer above the first reads GRU outputs through an inverted dropout -- |h| < 1 by construction (a convex
+        # combination of tanh values and the previous h), so |x| <= 1 / (1 - p) is a bound the row scales can take without a pass over x
+        # (injected masks may hold anything: those runs measure the rows)
+        bound = None
+        if l > 0 and inject is None:
+            bound = ops.const_rowmax(B * T, 1.0 / (1.0 - p_drop) if (training and p_drop > 0) else 1.0, x.device)
         ops.gemm_nt_group([dict(A=a_win, W=P[f"{prefix}.weight_ih_l{l}{sfx}"], bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
-                                out=gi[d].view(B * T, 3 * H), w_planes=wpl(P[f"{prefix}.weight_ih_l{l}{sfx}"]))
+                                out=gi[d].view(B * T, 3 * H), w_planes=wpl(P[f"{prefix}.weight_ih_l{l}{sfx}"]), a_rowmax=bound)
                            for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
         y = empty(B, T, 2 * H, like=x)
         sv = empty(2, B, T, 4 * H, like=x) if save else None

@@ -126,7 +126,7 @@ class Drop:
 
 
 def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, M=None,
-                b_seg=None, out_scale=None, gate=None, res=None, out2=None, res_slope=0.0, w_planes=None, w_row0=0, a_row_scale=None):
+                b_seg=None, out_scale=None, gate=None, res=None, out2=None, res_slope=0.0, w_planes=None, w_row0=0, a_row_scale=None, a_rowmax=None, out_rowmax=None, out2_rowmax=None):
     """Checked tg_gemm_nt_problem.  b_seg = (seg_k, seg_stride_floats): K-concatenated weights, W is the first [N, seg_k] segment and
     segment s starts seg_stride_floats * s floats after it (the caller keeps every segment alive).
     Epilogue extensions (big-product path only, nt_ext_supported): gate -- keep the result where gate > 0, zero elsewhere; res + out2 --
@@ -159,11 +159,16 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
         q.b_planes, q.b_plane_stride, q.b_rows, q.b_row0 = w_planes.t.data_ptr(), w_planes.plane_stride, w_planes.rows, int(w_row0)
         if w_planes.kind == "h2":              # fp16 x 2 planes: the product rows' power-of-two scales ride along (h2_row_scales unless the caller has them)
             assert w_row0 % 4 == 0, w_row0
-            if a_row_scale is None:
-                a_row_scale = h2_row_scales(A, M)
-            _f32(a_row_scale, "a_row_scale"); assert a_row_scale.numel() >= M and a_row_scale.is_contiguous()
-            q.b_planes_kind, q.b_inv_scale, q.a_row_scale = 1, w_planes.inv.data_ptr(), a_row_scale.data_ptr()
-            q._keep = (a_row_scale,)
+            q.b_planes_kind, q.b_inv_scale = 1, w_planes.inv.data_ptr()
+            if a_rowmax is not None:           # the source rows' magnitudes (their producer's out_rowmax, win_row_absmax, const_rowmax): one or two taps
+                _f32(a_rowmax, "a_rowmax"); assert a_rowmax.numel() >= A.batches * A.s.rows_in and a_rowmax.is_contiguous() and A.K <= 2 * A.s.cw
+                q.a_rowmax = a_rowmax.data_ptr()
+            else:
+                if a_row_scale is None:
+                    a_row_scale = h2_row_scales(A, M)
+                _f32(a_row_scale, "a_row_scale"); assert a_row_scale.numel() >= M and a_row_scale.is_contiguous()
+                q.a_row_scale = a_row_scale.data_ptr()
+            q._keep = (a_row_scale, a_rowmax)
     if isinstance(out_scale, Drop):            # the dropout scale regenerated in the epilogue: `out` must be the contiguous tensor the mask was drawn for
         assert out_scale.numel() == M * N and out_scale.index0 % 4 == 0 and N % 4 == 0, (out_scale.shape, M, N)
         assert c_row_stride == N and (c_rows_out >= M or c_batch_stride == c_rows_out * c_row_stride), "regenerated dropout needs a contiguous output"
@@ -181,6 +186,10 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
         q.gate = gate.data_ptr()
     if res is not None:
         q.res, q.C2, q.res_slope = res.data_ptr(), out2.data_ptr(), float(res_slope)
+    for name, t in (("c_rowmax", out_rowmax), ("c2_rowmax", out2_rowmax)):     # M floats, zeroed by the caller once per pass (mover-wave kernel only)
+        if t is not None:
+            _f32(t, name); assert t.numel() >= M and t.is_contiguous() and (name == "c_rowmax" or out2 is not None)
+            setattr(q, name, t.data_ptr())
     return q
 
 
@@ -215,10 +224,39 @@ def gemm_nt(A: Win, W, bias, out, **kw):
     return out
 
 
+def _share_row_scales(problems):
+    """fp16 x 2 problems of a group that read the SAME window (both GRU directions' projections) share one row-scale pre-pass."""
+    done, out = {}, []
+    for p in problems:
+        pl = p.get("w_planes")
+        if pl is not None and pl.kind == "h2" and p.get("a_row_scale") is None and p.get("a_rowmax") is None:
+            A = p["A"]
+            key = (bytes(A.s), p.get("M", A.M))
+            if key not in done:
+                done[key] = h2_row_scales(A, p.get("M", A.M))
+            p = dict(p, a_row_scale=done[key])
+        out.append(p)
+    return out
+
+
+_CONST_ROWMAX = {}
+
+
+def const_rowmax(n, bound, device):
+    """n floats all equal to `bound`: the a_rowmax of an activation whose magnitude is bounded by construction (a GRU layer's output through an
+    inverted dropout: |h| < 1, so |x| <= 1 / (1 - p)) -- no pass over the tensor.  Cached: the tensor is never written again (graph-safe)."""
+    key = (int(n), float(bound), str(device))
+    t = _CONST_ROWMAX.get(key)
+    if t is None:
+        t = _CONST_ROWMAX[key] = torch.full((int(n),), float(bound), device=device, dtype=torch.float32)
+    return t
+
+
 def gemm_nt_group(problems):
     """Several independent products in ONE launch.  problems: list of dicts with the arguments of gemm_nt (A, W, bias, out, ...).
     They must fall into one kernel family (all 'big', i.e. M >= 1024, N >= 48, K >= 64 -- or all narrow / all small); outputs must
     not overlap."""
+    problems = _share_row_scales(problems)
     qs = [_nt_problem(**p) for p in problems]
     fam = [_lib.load().tg_gemm_nt_family(C.byref(q)) for q in qs]
     i = 0

@@ -133,7 +133,7 @@ typedef struct tg_gemm_nt_problem {
     int32_t reserved4;
     /* ABI 7 -- fp16 x 2 operands (three matrix instructions per product instead of bf16 x 3's six, csrc/common.hpp "two-term fp16 split"):
      * b_planes_kind == 1 says b_planes is the TWO-plane fp16 buffer tg_split2h_planes writes (hi / lo of every row scaled by its own power of
-     * two) and b_inv_scale its per-row inverse scales (b_rows + 1 floats, 16-byte aligned, b_row0 % 4 == 0); a_row_scale then holds the
+     * two) and b_inv_scale its per-row inverse scales (b_rows + 1 floats, 16-byte aligned, b_row0 % 4 == 0); a_row_scale (or a_rowmax, below) then holds the
      * power-of-two scale of every product row m < M of the window A (M floats, tg_h2_row_scales: the row's largest magnitude over its K values
      * scaled into [2^14, 2^15)) by which the kernel multiplies the row before splitting it.  b_planes_kind == 0: bf16 x 3
      * planes as before, both pointers ignored.  Same arithmetic contract as before: fp32 nn.Linear / nn.Conv1d / nn.GRU input projections
@@ -142,6 +142,15 @@ typedef struct tg_gemm_nt_problem {
     int32_t reserved5;
     const float* b_inv_scale;
     const float* a_row_scale;
+    /* ... or, for windows of one or two taps, a_rowmax: the largest magnitude of every SOURCE row of A's tensor (index batch * rows_in + source row,
+     * non-negative floats: tg_win_row_absmax, or the product that wrote the tensor through c_rowmax below); the kernel derives the product rows'
+     * scales from it.  Exactly one of a_row_scale / a_rowmax with fp16 x 2 planes.
+     * c_rowmax / c2_rowmax (optional, mover-wave kernel only -- refused elsewhere): M floats each; row m's entry is raised (atomic unsigned max on the
+     * float's bits) to the largest magnitude the product wrote into row m of C / C2.  The caller zeroes them before the first product of a pass;
+     * a chain of convs (model/tcn.py:27-46) then needs no separate pass over an activation to scale it. */
+    const float* a_rowmax;
+    float* c_rowmax;
+    float* c2_rowmax;
 } tg_gemm_nt_problem;
 /* tg_gemm_nt_group: up to 8 independent tg_gemm_nt products in ONE launch (both GRU directions' input projections, the stride
  * phases of a conv input-gradient ...).  All problems must fall into the same kernel family as problem 0 (big / narrow / small);
