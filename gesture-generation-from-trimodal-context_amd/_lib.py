@@ -34,7 +34,7 @@ class NtProblem(C.Structure):
 class TnProblem(C.Structure):
     """struct tg_gemm_tn_problem"""
     _fields_ = [("dY", P), ("ldy", I64), ("A", Window), ("dW", P), ("ldw", I64), ("M", I32), ("N", I32), ("out_kw", I32), ("reserved", I32),
-                ("dbias", P), ("ws", P), ("ws_floats", I64)]
+                ("dbias", P), ("ws", P), ("ws_floats", I64), ("y_colmax", P), ("a_colmax", P)]
 
 
 class AeStepArgs(C.Structure):
@@ -56,6 +56,7 @@ SIGNATURES = {
     "tg_split2h_planes": [P, I64, I32, I32, P, I32, I64, P, P],
     "tg_win_row_absmax": [WP, I32, P, P],
     "tg_h2_row_scales": [WP, I32, P, P, P],
+    "tg_absmax_rows_cols": [P, I64, I32, I32, I32, P, P, P],
     "tg_gemm_tn": [P, I64, WP, P, I64, I32, I32, I32, P, P, I64, P],
     "tg_colsum": [P, I64, I32, I32, P, I32, P],
     "tg_gru_forward": [P, I64, P, P, P, P, P, P, I64, I32, I32, I32, P],

@@ -129,6 +129,10 @@ struct TnProb {
     float* dbias;
     int vec_y, vec_a, n_nt, n_kt;
     unsigned a_bytes, y_bytes;   // byte extents of the A tensor / dY from their base pointers (gemm_tn_mw.hip buffer descriptors; filled by its planner)
+    // fp16 x 2 (both non-null; mover-wave kernel): largest magnitude of every COLUMN of dY (N floats, 16-byte aligned) and of every channel of A's
+    // tensor (cw floats, shared by the taps) -- the reduction runs over rows, so the power-of-two scales belong to the columns
+    const float* y_cmax;
+    const float* a_cmax;
 };
 
 struct TnGroup {

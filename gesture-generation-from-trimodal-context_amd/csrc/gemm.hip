@@ -945,6 +945,9 @@ static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int group_ti
                (long)q.ws_floats, (long)splits * q.N * p.A.K, idx);
     p.dY = q.dY; p.ldy = (long)q.ldy; p.dW = q.dW; p.ldw = (long)q.ldw; p.M = q.M; p.N = q.N; p.rows_per_split = rows_per_split;
     p.out_kw = q.out_kw; p.partial = q.ws; p.dbias = q.dbias;
+    TG_REQUIRE((q.y_colmax == nullptr) == (q.a_colmax == nullptr) && aligned16(q.y_colmax) && aligned16(q.a_colmax),
+               "tg_gemm_tn: y_colmax and a_colmax go together, 16-byte aligned (problem %d)", idx);
+    p.y_cmax = q.y_colmax; p.a_cmax = q.a_colmax;
     p.vec_y = (q.ldy % 4 == 0) && aligned16(q.dY);
     p.vec_a = (p.A.cw % 4 == 0) && (p.A.bs % 4 == 0) && (p.A.rs % 4 == 0) && aligned16(p.A.ptr);
     p.n_nt = cdiv(q.N, bn); p.n_kt = cdiv(p.A.K, bk);
@@ -1004,6 +1007,8 @@ static int tn_group_impl(const tg_gemm_tn_problem* problems, int32_t n, void* st
         for (int i = 0; i < n; ++i) wsf[i] = (long)problems[i].ws_floats;
         if (tg_gemm_tn_mw_plan(g2, mw_splits, &grid, wsf)) {
             if (plan_only) { *plan_only = 2; return 0; }
+            if (tg_get_math_mode() == 1)
+                for (int i = 0; i < TG_MAX_GROUP; ++i) g2.p[i].y_cmax = g2.p[i].a_cmax = nullptr;       // the bf16 tier has its own operand format
             if (int e = tg_gemm_tn_mw_launch(g2, grid, tg_get_math_mode() == 1 ? 1 : 3, s)) return e;
             return all_ws ? tg_gemm_tn_mw_reduce_launch(g2, mw_splits, s) : 0;
         }

@@ -628,10 +628,12 @@ extern "C" int tg_set_nt_mover_waves(int32_t on) {
 static bool mw_pick_tile(const NtGroup& g, MwTile* out) {
     static const int env_on = [] { const char* e = getenv("TG_NT_MW"); return e ? atoi(e) : 1; }();
     if (!(g_mw_on < 0 ? env_on : g_mw_on)) return false;
-    const MwTile menu[2] = {{4, 6}, {4, 5}};
+    const MwTile menu[3] = {{4, 6}, {4, 5}, {4, 3}};
+    static const int forced = [] { const char* e = getenv("TG_MW_TILE"); return e ? atoi(e) : 0; }();     // lab: 46 / 45 / 43 forces that tile
     double best = 0.0;
     bool found = false;
     for (const MwTile& tl : menu) {
+        if (forced && forced != 10 * tl.tm + tl.tn) continue;
         const int bm = 32 * tl.tm, bn = 32 * tl.tn;
         long tiles = 0;
         double work = 0.0;
@@ -641,7 +643,7 @@ static bool mw_pick_tile(const NtGroup& g, MwTile* out) {
             const double per_tile = cdiv(g.p[i].A.K, 32) * (6.0 * tl.tm * tl.tn * 16.0) + 6000.0;        // cycles
             work += ti * per_tile;
         }
-        if (tiles < 150) continue;
+        if (tiles < 150 && !forced) continue;
         const double rounds = (double)cdiv(tiles, 256);
         const double cost = rounds * work / tiles;
         if (!found || cost < best) { best = cost; *out = tl; found = true; }
@@ -700,6 +702,7 @@ int tg_gemm_nt_mw_launch(NtGroup& g, int tm, int tn, int splits, hipStream_t s) 
     } while (0)
     if (tm == 4 && tn == 6) TG_MW(4, 3, 2, 4);
     else if (tm == 4 && tn == 5) TG_MW(2, 5, 4, 2);
+    else if (tm == 4 && tn == 3) TG_MW(2, 3, 4, 2);             // 128 x 96: matrix waves 4 x 2, wave tile 32 x 48
     else TG_REQUIRE(false, "tg_gemm_nt(mover waves): no %d x %d tile", bm, bn);
 #undef TG_MW
     return check_launch("tg_gemm_nt(mover waves)");

@@ -34,8 +34,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tw_rsrc(const void* base, unsi
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), TW_RSRC3);
 }
 
+// fp16 x 2: the piece's four COLUMNS each carry their own power-of-two scale 2^k (the reduction runs over rows, so scales are per column);
+// `kb` packs the four k as signed bytes, first column in the low byte
+__device__ __forceinline__ void tw_split4_h2(const f32x4 v, const int kb, u32x2 (&out)[2]) {
+    const float x0 = __builtin_ldexpf(v[0], (kb << 24) >> 24), x1 = __builtin_ldexpf(v[1], (kb << 16) >> 24);
+    const float x2 = __builtin_ldexpf(v[2], (kb << 8) >> 24), x3 = __builtin_ldexpf(v[3], kb >> 24);
+    unsigned h0, l0, h1, l1;
+    h2_split2(x0, x1, h0, l0);
+    h2_split2(x2, x3, h1, l1);
+    out[0] = u32x2{h0, h1};
+    out[1] = u32x2{l0, l1};
+}
+// four column magnitudes -> their packed scale exponents k = 141 - e (in [-109, 109])
+__device__ __forceinline__ int tw_pack_k(const f32x4 cm) {
+    int kb = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float f = cm[q]; kb |= ((141 - h2_exp_of_bits(__float_as_uint(f))) & 0xff) << (8 * q); }
+    return kb;
+}
+
 template <int NS>
 __device__ __forceinline__ void tw_split4(const f32x4 v, u32x2 (&out)[NS]) {
+    static_assert(NS != 2, "fp16 x 2 pieces go through tw_split4_h2");
     if constexpr (NS == 1) {                         // plain bf16 tier (math mode 1): round to nearest even
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         bf16x4 r;
@@ -73,6 +93,7 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
     constexpr int Y_PLANE = 32 * LDN, X_PLANE = 32 * LDK;      // bf16 elements
     __shared__ __attribute__((aligned(16))) __bf16 ys[2][NS][Y_PLANE];
     __shared__ __attribute__((aligned(16))) __bf16 xs[2][NS][X_PLANE];
+    __shared__ int kexp[NS == 2 ? 2 : 1][NS == 2 ? NPY + NPX : 1][NS == 2 ? 256 : 1];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int total_items = g.wg_begin[TG_MAX_GROUP];
@@ -130,6 +151,10 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
         int x_r[NPX];                                          // its row inside the batch (before step / tap displacement)
         int x_tapd[NPX];                                       // tap row displacement
         int x_one = -1;                                        // 4 i + q: element q of X piece i is the ones column of this item (at most one piece of a thread holds column K), or -1
+        // fp16 x 2: the pieces' packed column-scale exponents live in LDS, one private slot per thread, piece and item PARITY (the fetch cursor
+        // is at most one item ahead of the set being staged: items have >= 8 slabs): kept in registers they and their per-set copies cost 33
+        // of the 168 registers a wave has here
+        int item_par = 0;
         unsigned y_slab_b = 0;                                 // bytes between slabs in dY
         const float* y_ptr = g.p[0].dY;
         const float* a_ptr = g.p[0].A.ptr;
@@ -157,10 +182,12 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
             const TnProb& pr = g.p[pi];
             const Win A = pr.A;
             nslab_f = (me - mb + 31) >> 5;
+            item_par ^= 1;
 #pragma unroll
             for (int i = 0; i < NPY; ++i) {
                 const int p = mt_l + 256 * i, yrow = p / PY, ycol = 4 * (p % PY);
                 y_off[i] = n0 + ycol < pr.N ? (unsigned)(((long)(mb + yrow) * pr.ldy + n0 + ycol) * 4) : TW_OOB;
+                if constexpr (NS == 2) kexp[item_par][i][mt] = tw_pack_k(*reinterpret_cast<const f32x4*>(pr.y_cmax + (n0 + ycol < pr.N ? n0 + ycol : 0)));
             }
             const bool bias_here = pr.dbias != nullptr && k0 <= A.K && A.K < k0 + BK;       // this tile holds the padding column K
             x_one = -1;
@@ -181,6 +208,11 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
                 // num_records for the item's life)
                 x_off[i] = cok ? (unsigned)b * bs4 + (unsigned)(x_r[i] * A.step + x_tapd[i]) * rs4 + (unsigned)((kc - tap * A.cw) * 4) : TW_OOB;
                 if (bias_here && ak <= A.K && A.K < ak + 4) x_one = 4 * i + (A.K - ak);
+                if constexpr (NS == 2) {
+                    int kb = tw_pack_k(*reinterpret_cast<const f32x4*>(pr.a_cmax + (kc - tap * A.cw)));
+                    if (bias_here && ak <= A.K && A.K < ak + 4) kb &= ~(0xff << (8 * (A.K - ak)));          // the ones column keeps scale 1
+                    kexp[item_par][NPY + i][mt] = kb;
+                }
             }
             y_slab_b = (unsigned)(32 * pr.ldy * 4);
             // dY's descriptor ends behind the item's last row: later rows of the last slab read zero
@@ -201,10 +233,12 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
         // while slab n + 1 is staged: two full steps for the loads.  All addresses of a fetch are formed before its first load so that the loads
         // issue back to back (a fixed number of vector-memory operations per step on every path: hipcc's static counts then come out exact).
         u32x4 gy[2][NPY], gx[2][NPX];
+        int set_par[2] = {0, 0};                               // ... parity of the item each register set was fetched for
         int one_el[2] = {-1, -1};                              // 4 i + q of the ones column for the item the set was FETCHED for (-1: none)
         auto fetch = [&](auto set_c) __attribute__((always_inline)) {
             constexpr int set = decltype(set_c)::value;
             one_el[set] = x_one;
+            set_par[set] = item_par;
             const unsigned ysoff = (unsigned)__builtin_amdgcn_readfirstlane(s_f * (int)y_slab_b);
             unsigned xo[NPX];
 #pragma unroll
@@ -242,10 +276,16 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
                 for (int i = 0; i < NPX; ++i) asm volatile("" :: "v"(gx[set][i]));
                 return;
             }
+            int kk[NS == 2 ? NPY + NPX : 1];
+            if constexpr (NS == 2) {
+#pragma unroll
+                for (int i = 0; i < NPY + NPX; ++i) kk[i] = kexp[set_par[set]][i][mt];
+            }
 #pragma unroll
             for (int i = 0; i < NPY; ++i) {
                 u32x2 o[NS];
-                tw_split4<NS>(__builtin_bit_cast(f32x4, gy[set][i]), o);
+                if constexpr (NS == 2) tw_split4_h2(__builtin_bit_cast(f32x4, gy[set][i]), kk[i], o);
+                else tw_split4<NS>(__builtin_bit_cast(f32x4, gy[set][i]), o);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&ys[buf][s][0] + ypos[i]) = o[s];
             }
@@ -256,7 +296,8 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = e == q ? 1.0f : v[q];
                 u32x2 o[NS];
-                tw_split4<NS>(v, o);
+                if constexpr (NS == 2) tw_split4_h2(v, kk[NPY + i], o);
+                else tw_split4<NS>(v, o);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(&xs[buf][s][0] + xpos[i]) = o[s];
             }
@@ -315,6 +356,13 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
                 return;
             }
             f32x4 cc = acc[nt][kt];
+            if constexpr (NS == 2) {                   // fp16 x 2: lo hi + hi lo + hi hi
+                auto h = [](const bf16x8& v) { return __builtin_bit_cast(tg_f16x8, v); };
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(f[1]), h(fb[0][kt]), cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(f[0]), h(fb[1][kt]), cc, 0, 0, 0);
+                acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(f[0]), h(fb[0][kt]), cc, 0, 0, 0);
+                return;
+            }
             if constexpr (NS == 3) {
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], fb[0][kt], cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], fb[2][kt], cc, 0, 0, 0);
@@ -417,8 +465,14 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_mw_kernel(const TnGroup g) {
                         const int nrow = n0 + wn * (16 * TNT) + nt * 16 + kq * 4 + i;
                         if (nrow >= N) continue;
                         if constexpr (ABL & 16) { if (acc[nt][kt][i] == 1.2345e-30f) dW[0] = 1.f; continue; }
-                        if (kcol < K) atomicAdd(&dW[(long)nrow * ldw + off], acc[nt][kt][i]);
-                        else if (kcol == K && dbias) atomicAdd(&dbias[nrow], acc[nt][kt][i]);
+                        float v = acc[nt][kt][i];
+                        if constexpr (NS == 2) {
+                            const float iy = h2_inv_of_exp(h2_exp_of_bits(__float_as_uint(pr.y_cmax[nrow])));
+                            const float ia = kcol < K ? h2_inv_of_exp(h2_exp_of_bits(__float_as_uint(pr.a_cmax[kcol % cw]))) : 1.f;
+                            v = (v * iy) * ia;
+                        }
+                        if (kcol < K) atomicAdd(&dW[(long)nrow * ldw + off], v);
+                        else if (kcol == K && dbias) atomicAdd(&dbias[nrow], v);
                     }
                 }
         }
@@ -449,9 +503,18 @@ __global__ __launch_bounds__(256) void tn_mw_reduce_kernel(const TnGroup g, cons
         const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)q * n_tiles * (BN * BK));
         a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
     }
-    const float r[4] = {(float)a0, (float)a1, (float)a2, (float)a3};
+    float r[4] = {(float)a0, (float)a1, (float)a2, (float)a3};
     const int kcol = tn_k * BK + wk * (16 * TKT) + kt * 16 + r16;
     const int K = pr.A.K, cw = pr.A.cw, out_kw = pr.out_kw;
+    if (pr.y_cmax) {                                           // fp16 x 2: back through the columns' exact power-of-two scales
+        const float ia = kcol < K ? h2_inv_of_exp(h2_exp_of_bits(__float_as_uint(pr.a_cmax[kcol % cw]))) : 1.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nrow = tn_n * BN + wn * (16 * TNT) + nt * 16 + kq * 4 + i;
+            const float iy = h2_inv_of_exp(h2_exp_of_bits(__float_as_uint(pr.y_cmax[nrow < pr.N ? nrow : 0])));
+            r[i] = (r[i] * iy) * ia;
+        }
+    }
     const long off = out_kw > 0 ? (long)(kcol % cw) * out_kw + kcol / cw : (long)kcol;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -484,6 +547,7 @@ bool tg_gemm_tn_mw_plan(TnGroup& g, int* splits_out, int* grid, const long* ws_f
         constexpr int min_k = 100;      // K = 108: the GRU's first layer (68 % of a 160-wide tile)
         if (!p.vec_y || !p.vec_a || p.N % 4 != 0 || A.K % 4 != 0 || p.N < 150 || A.K < min_k || p.M < min_rows) return false;
         if (p.dbias && A.K % BK == 0) return false;                               // no padding column for the ones trick
+        if ((p.y_cmax != nullptr) != (g.p[0].y_cmax != nullptr)) return false;      // one operand format per launch
         if (A.bs < 0 || A.rs < 0 || A.rows_out < 32 || A.step < 0 || p.ldy < p.N) return false;           // (rows_out >= 32: one batch wrap per slab at most in the movers' row walk)
         const long batches = cdiv(p.M, A.rows_out);
         const long a_el = (batches - 1) * A.bs + (long)(A.rows_in - 1) * A.rs + A.cw;
@@ -554,13 +618,15 @@ int tg_gemm_tn_mw_launch(const TnGroup& g, int grid, int splits, hipStream_t s) 
         const char* e = getenv("TG_TNMW_ABL");
         const int abl = e ? atoi(e) : 0;
         if (abl && splits == 3) {
-#define TG_ABL(A_) case A_: hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 3, A_>), dim3(grid), dim3(768), 0, s, g); return check_launch("tg_gemm_tn(mover waves, ablated)")
+#define TG_ABL(A_) case A_: if (g.p[0].y_cmax) hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 2, A_>), dim3(grid), dim3(768), 0, s, g); \
+                            else hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 3, A_>), dim3(grid), dim3(768), 0, s, g); return check_launch("tg_gemm_tn(mover waves, ablated)")
             switch (abl) { TG_ABL(1); TG_ABL(2); TG_ABL(4); TG_ABL(6); TG_ABL(8); TG_ABL(9); TG_ABL(16); TG_ABL(14); TG_ABL(15); default: break; }
 #undef TG_ABL
         }
     }
 #endif
-    if (splits == 3) hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 3>), dim3(grid), dim3(768), 0, s, g);
+    if (splits == 3 && g.p[0].y_cmax) hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 2>), dim3(grid), dim3(768), 0, s, g);
+    else if (splits == 3) hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 3>), dim3(grid), dim3(768), 0, s, g);
     else hipLaunchKernelGGL((gemm_tn_mw_kernel<3, 5, 4, 2, 1>), dim3(grid), dim3(768), 0, s, g);
     return check_launch("tg_gemm_tn(mover waves)");
 }

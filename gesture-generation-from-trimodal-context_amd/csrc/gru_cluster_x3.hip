@@ -14,6 +14,7 @@
 // published, [member][plane][row][32 units], 64 bytes per row and plane -- a wave's epilogue stores cover whole 128-byte lines.
 // Per wave and step: <= 108 bf16 MFMAs of 16 cycles instead of 120 f32 MFMAs of 32.
 #include "common.hpp"
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -71,6 +72,26 @@ __device__ __forceinline__ void xc_split4(const f32x4 v, u32x2 (&out)[3]) {
     out[2] = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
 }
 
+// fp16 x 2 (common.hpp "two-term fp16 split"): eight / four consecutive fp32, already multiplied by their power-of-two scale, -> hi and lo planes
+__device__ __forceinline__ void xc_split8_h2(const f32x4 a, const f32x4 b, const float scale, bf16x8 (&out)[3]) {
+    unsigned h[4], l[4];
+    h2_split2(a[0] * scale, a[1] * scale, h[0], l[0]);
+    h2_split2(a[2] * scale, a[3] * scale, h[1], l[1]);
+    h2_split2(b[0] * scale, b[1] * scale, h[2], l[2]);
+    h2_split2(b[2] * scale, b[3] * scale, h[3], l[3]);
+    out[0] = as_bf16x8(u32x4{h[0], h[1], h[2], h[3]});
+    out[1] = as_bf16x8(u32x4{l[0], l[1], l[2], l[3]});
+    out[2] = out[1];
+}
+__device__ __forceinline__ void xc_split4_h2(const f32x4 v, const float scale, u32x2 (&out)[3]) {
+    unsigned h0, l0, h1, l1;
+    h2_split2(v[0] * scale, v[1] * scale, h0, l0);
+    h2_split2(v[2] * scale, v[3] * scale, h1, l1);
+    out[0] = u32x2{h0, h1};
+    out[1] = u32x2{l0, l1};
+    out[2] = out[1];
+}
+
 // plain-bf16 tier (math mode 1): one term per operand, rounded to nearest even; plane 0 of the exchange buffer carries it
 __device__ __forceinline__ bf16x8 xc_rne8(const f32x4 a, const f32x4 b) {
     bf16x8 r;
@@ -90,6 +111,12 @@ __device__ __forceinline__ u32x2 xc_rne4(const f32x4 v) {
 template <int NS>
 __device__ __forceinline__ f32x4 xc_mma(const bf16x8 (&wa)[2], const bf16x8 w_lo, const bf16x8 (&fb)[NS], f32x4 acc) {
     if constexpr (NS == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[0], acc, 0, 0, 0);
+    if constexpr (NS == 2) {                             // fp16 x 2: wa = hi / lo planes of the scaled weight rows, fb = hi / lo planes of h * 2^14
+        auto hh = [](const bf16x8& v) { return __builtin_bit_cast(tg_f16x8, v); };
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(hh(wa[1]), hh(fb[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(hh(wa[0]), hh(fb[1]), acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(hh(wa[0]), hh(fb[0]), acc, 0, 0, 0);
+    }
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo, fb[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], fb[1], acc, 0, 0, 0);
@@ -184,6 +211,39 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
 
     // W_hh rows (gate g, unit 32 m + 16 ut + r16), k = 32 (s_beg + p) + 8 kq .. +7: pre-split A fragments, resident
     bf16x8 wa[3][SPS][2];
+    // fp16 x 2: every W_hh row (gate g, unit) is scaled by its own power of two (largest magnitude over the row's H columns -> [2^14, 2^15)).  A row's
+    // columns are spread over the KS waves of its unit tile: partial maxima meet in LDS; the epilogue threads read the same table for the inverse.
+    __shared__ unsigned wmax[KS][2][3][16];
+    float wsc[3] = {1.f, 1.f, 1.f};
+    if constexpr (NS == 2) {
+        const int j = m * XC_UNITS + ut * 16 + r16;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            unsigned mx = 0u;
+#pragma unroll
+            for (int p = 0; p < SPS; ++p) {
+                const int k = 32 * (s_beg + p) + 8 * kq;
+                const float* src = whh + (long)(g * H + j) * H + k;
+                const bool ok = p < s_cnt && j < H;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned v = (ok && k + q < H) ? __float_as_uint(src[q]) & 0x7fffffffu : 0u;
+                    mx = mx > v ? mx : v;
+                }
+            }
+            unsigned w = (unsigned)__shfl_xor((int)mx, 16, 64); mx = mx > w ? mx : w;
+            w = (unsigned)__shfl_xor((int)mx, 32, 64); mx = mx > w ? mx : w;
+            if (kq == 0) wmax[ks][ut][g][r16] = mx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            unsigned mx = wmax[0][ut][g][r16];
+#pragma unroll
+            for (int q = 1; q < KS; ++q) { const unsigned v = wmax[q][ut][g][r16]; mx = mx > v ? mx : v; }
+            wsc[g] = h2_scale_of_exp(h2_exp_of_bits(mx));
+        }
+    }
     {
         const int j = m * XC_UNITS + ut * 16 + r16;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -198,9 +258,10 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
                 const f32x4 b = (ok && k + 4 < H) ? *reinterpret_cast<const f32x4*>(src + 4) : z;
                 bf16x8 pl[3];
                 if constexpr (NS == 1) { pl[0] = xc_rne8(a, b); pl[1] = pl[2] = pl[0]; }
+                else if constexpr (NS == 2) xc_split8_h2(a, b, wsc[g], pl);
                 else xc_split8(a, b, pl);
                 wa[g][p][0] = pl[0]; wa[g][p][1] = pl[1];
-                wlo[wave][g * SPS + p][lane] = pl[2];
+                if constexpr (NS == 3) wlo[wave][g * SPS + p][lane] = pl[2];
             }
     }
     // ---- epilogue role: thread e < 128 * MT finalises batch row (e / 8) of the tile, hidden units 4 * (e % 8) .. +3 of the slice
@@ -216,6 +277,22 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
 #pragma unroll
     for (int g = 0; g < 3; ++g) bh[g] = (epi && unit0 < H) ? *reinterpret_cast<const f32x4*>(bhh + g * H + unit0) : zero4;
     f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+    // fp16 x 2: h is published as hi / lo of h * 2^14 (|h| < 1 by construction: no measuring); the product of a gate row comes back through
+    // 1 / (row scale * 2^14), an exact power of two
+    constexpr float H_SCALE = 16384.f;
+    f32x4 winv[3] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+    if constexpr (NS == 2) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = (4 * ug + q) & 15;
+                unsigned mx = wmax[0][e_ut][g][rr];
+#pragma unroll
+                for (int k = 1; k < KS; ++k) { const unsigned v = wmax[k][e_ut][g][rr]; mx = mx > v ? mx : v; }
+                winv[g][q] = h2_inv_of_exp(h2_exp_of_bits(mx)) * (1.f / H_SCALE);
+            }
+    }
     __syncthreads();                                                   // wlo visible (read back by the same lane: ordering only)
 
     const int plane_bytes = b_pad * 64;
@@ -330,6 +407,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
 #pragma unroll
                     for (int q = 1; q < KS; ++q) s += red[q][e_ut][e_mt][g][e_lane];
                 }
+                if constexpr (NS == 2) s *= winv[g];
                 gh[g] = s;
             }
             mk = mkn;
@@ -348,6 +426,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
             // four whole 128-byte lines per plane
             u32x2 pl[3];
             if constexpr (NS == 1) pl[0] = xc_rne4(h);
+            else if constexpr (NS == 2) xc_split4_h2(h, H_SCALE, pl);
             else xc_split4(h, pl);
             const int woff = (dir * 2 + (step & 1)) * slot_bytes + m * 3 * plane_bytes + row * 64 + ug * 8;
             if constexpr (ABL & 16) { asm volatile("" :: "v"(pl[0]), "v"(woff)); }
@@ -608,8 +687,11 @@ int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, c
         }
     }
 #endif
-    if (mt == 1) { if (bf16) TG_XF(1, 1); else TG_XF(1, 3); }
-    else { if (bf16) TG_XF(2, 1); else TG_XF(2, 3); }
+    // fp32-accurate mode: fp16 x 2 operands (3 matrix instructions per product: h * 2^14 and per-row scaled W_hh as hi / lo fp16 planes) unless
+    // TG_GRU_H2=0 asks for bf16 x 3 (6; A/B timing)
+    static const int h2 = [] { const char* e = getenv("TG_GRU_H2"); return e ? atoi(e) : 1; }();
+    if (mt == 1) { if (bf16) TG_XF(1, 1); else if (h2) TG_XF(1, 2); else TG_XF(1, 3); }
+    else { if (bf16) TG_XF(2, 1); else if (h2) TG_XF(2, 2); else TG_XF(2, 3); }
 #undef TG_XF
     return check_launch("tg_gru_forward_cluster(x3)");
 }

@@ -98,9 +98,76 @@ __global__ __launch_bounds__(256) void h2_row_scales_kernel(const Win A, int M, 
     }
 }
 
+// row and column magnitudes of x[M][C] in one pass (tg_absmax_rows_cols): a wave walks whole rows (lane owns 4-column pieces lane, lane + 64, ...;
+// at most PIECES of them: C <= 256 PIECES), keeps the row's maximum (wave reduction) and its columns' maxima in registers; the four waves of a
+// workgroup combine their column maxima through LDS, one atomic per column and workgroup.  A workgroup's rows belong to ONE row group.
+template <int PIECES>
+__global__ __launch_bounds__(256) void absmax_rows_cols_kernel(const float* __restrict__ x, long ldx, int M, int C, int groups, int wgs_per_group,
+                                                               float* __restrict__ rowmax, float* __restrict__ colmax) {
+    __shared__ unsigned cm[4][256 * PIECES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = blockIdx.x / wgs_per_group, wg = blockIdx.x % wgs_per_group;
+    const int rows_g = M / groups;
+    const int c4n = C / 4;
+    unsigned cmx[PIECES][4];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cmx[p][q] = 0u;
+    for (int r = wg * 4 + wave; r < rows_g; r += wgs_per_group * 4) {
+        const float* row = x + ((long)grp * rows_g + r) * ldx;
+        unsigned rmx = 0u;
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) {
+            const int c4 = lane + 64 * p;
+            if (c4 < c4n) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * c4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float f = v[q];
+                    const unsigned b = __float_as_uint(f) & 0x7fffffffu;
+                    cmx[p][q] = cmx[p][q] > b ? cmx[p][q] : b;
+                    rmx = rmx > b ? rmx : b;
+                }
+            }
+        }
+        if (rowmax) {
+            rmx = wave_max_u32(rmx);
+            if (lane == 0) rowmax[(long)grp * rows_g + r] = __uint_as_float(rmx);
+        }
+    }
+    if (!colmax) return;
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cm[wave][(lane + 64 * p) * 4 + q] = cmx[p][q];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const unsigned a = cm[0][c], b = cm[1][c], d = cm[2][c], e = cm[3][c];
+        const unsigned m = (a > b ? a : b) > (d > e ? d : e) ? (a > b ? a : b) : (d > e ? d : e);
+        if (m) atomicMax(reinterpret_cast<unsigned*>(colmax) + (long)grp * C + c, m);
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
+
+extern "C" int tg_absmax_rows_cols(const float* x, int64_t ldx, int32_t M, int32_t C, int32_t groups, float* rowmax, float* colmax, void* stream) {
+    TG_REQUIRE(x && (rowmax || colmax) && M > 0 && C > 0 && groups > 0 && M % groups == 0 && ldx >= C, "tg_absmax_rows_cols: bad arguments");
+    TG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && aligned16(x) && C <= 2048, "tg_absmax_rows_cols: C=%d (a multiple of 4, at most 2048), ldx %% 4 == 0, x 16-byte aligned", C);
+    hipStream_t s = (hipStream_t)stream;
+    if (colmax && zero_async(colmax, sizeof(float) * (size_t)groups * C, s)) return 1;
+    const int rows_g = M / groups;
+    int wpg = cdiv(rows_g, 32);                                   // ~8 rows per wave
+    if (wpg * groups > 1024) wpg = 1024 / groups > 0 ? 1024 / groups : 1;
+    const dim3 grid(wpg * groups);
+    const int pieces = cdiv(C, 256);
+#define TG_AM(P_) hipLaunchKernelGGL(absmax_rows_cols_kernel<P_>, grid, dim3(256), 0, s, x, (long)ldx, M, C, groups, wpg, rowmax, colmax)
+    if (pieces <= 1) TG_AM(1); else if (pieces <= 2) TG_AM(2); else if (pieces <= 4) TG_AM(4); else TG_AM(8);
+#undef TG_AM
+    return check_launch("tg_absmax_rows_cols");
+}
 
 extern "C" int tg_h2_row_scales(const tg_window* A, int32_t M, const float* src_rowmax, float* row_scale, void* stream) {
     TG_REQUIRE(A && A->ptr && row_scale && M > 0 && A->rows_in > 0 && A->rows_out > 0 && A->cw > 0 && A->K % A->cw == 0, "tg_h2_row_scales: bad arguments");

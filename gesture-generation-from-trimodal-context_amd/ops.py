@@ -414,7 +414,22 @@ import os as _os
 TN_MW_WS = _os.environ.get("TG_TN_MW_WS", "1") != "0"              # mover-wave weight gradients combine their row splits through a workspace + fixed-order second pass (not float atomics)
 
 
-def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None, force_ws=False):
+def absmax_rows_cols(x2d, *, groups=1, want_rows=False, want_cols=True, rowmax=None, colmax=None):
+    """One pass over x2d [M][C] (unit inner stride): (rowmax [M] or None, colmax [groups][C] or None) -- the largest magnitudes the fp16 x 2
+    products scale their operands by (rows for gemm_nt's a_rowmax, columns for gemm_tn's y_colmax / a_colmax)."""
+    _f32(x2d, "x"); assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.shape[0] % groups == 0
+    M, Cc = x2d.shape
+    if (M - 1) * x2d.stride(0) + Cc - 1 >= _room(x2d):
+        raise ValueError("absmax_rows_cols: x exceeds its tensor")
+    if want_rows and rowmax is None:
+        rowmax = torch.empty(M, device=x2d.device, dtype=torch.float32)
+    if want_cols and colmax is None:
+        colmax = torch.empty(groups, Cc, device=x2d.device, dtype=torch.float32)
+    call("tg_absmax_rows_cols", _p(x2d), x2d.stride(0), M, Cc, groups, _p(rowmax), _p(colmax), _stream())
+    return rowmax, colmax
+
+
+def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None, force_ws=False, y_colmax=None, a_colmax=None):
     _f32(dY, "dY"); _f32(dW, "dW")
     assert dY.dim() == 2 and dY.stride(1) == 1 and dY.shape[0] == A.M, (dY.shape, A.M)
     M, N = dY.shape
@@ -438,6 +453,12 @@ def _tn_problem(dY, A: Win, dW, *, out_kw=0, dbias=None, keep=None, force_ws=Fal
     q.M, q.N, q.out_kw = M, N, int(out_kw)
     q.dbias = dbias.data_ptr() if dbias is not None else None
     q.ws, q.ws_floats = (ws.data_ptr() if ws is not None else None), nws
+    if y_colmax is not None or a_colmax is not None:       # fp16 x 2 on the mover-wave kernel: the columns' magnitudes (both or neither)
+        _f32(y_colmax, "y_colmax"); _f32(a_colmax, "a_colmax")
+        assert y_colmax.numel() >= N and a_colmax.numel() >= A.s.cw and y_colmax.is_contiguous() and a_colmax.is_contiguous()
+        q.y_colmax, q.a_colmax = y_colmax.data_ptr(), a_colmax.data_ptr()
+        if keep is not None:
+            keep.extend((y_colmax, a_colmax))
     return q, ws
 
 
@@ -479,14 +500,46 @@ def gemm_tn_group(problems):
     problems = _det_bias(problems)
     qs = [_tn_problem(keep=keep, **p)[0] for p in problems]
     arr = (_lib.TnProblem * len(qs))(*qs)
-    if TN_MW_WS and not all(q.ws for q in qs) and all(q.M >= 1024 and q.N >= 150 for q in qs):
-        # a group the mover-wave kernel takes (csrc/gemm_tn_mw.hip): give every problem the workspace, so that its row splits are combined by
-        # the fixed-order second pass instead of float atomics (28 of 116 us of a GRU layer's launch, and the one order-dependent sum left
-        # on the default path's big weight gradients)
-        if int(_lib.load().tg_gemm_tn_kernel_plan(arr, len(qs))) == 2:
+    if all(q.M >= 1024 and q.N >= 150 for q in qs) and (TN_MW_WS or gemm_h2()):
+        plan = int(_lib.load().tg_gemm_tn_kernel_plan(arr, len(qs)))
+        if plan == 2 and gemm_h2():
+            # the mover-wave kernel with fp16 x 2 operands: column magnitudes of every operand that does not bring them
+            problems = _auto_colmax(problems)
+        if plan == 2 and TN_MW_WS and not all(q.ws for q in qs):
+            # a group the mover-wave kernel takes (csrc/gemm_tn_mw.hip): give every problem the workspace, so that its row splits are combined by
+            # the fixed-order second pass instead of float atomics (28 of 116 us of a GRU layer's launch, and the one order-dependent sum left
+            # on the default path's big weight gradients)
             qs = [_tn_problem(keep=keep, force_ws=True, **p)[0] for p in problems]
             arr = (_lib.TnProblem * len(qs))(*qs)
+        elif plan == 2:
+            qs = [_tn_problem(keep=keep, **p)[0] for p in problems]
+            arr = (_lib.TnProblem * len(qs))(*qs)
     call("tg_gemm_tn_group", arr, len(problems), _stream())
+
+
+def _auto_colmax(problems):
+    """y_colmax / a_colmax for the problems of a mover-wave weight-gradient group that lack them: one absmax pass per distinct operand tensor
+    (operands shared inside the group -- the layer input of both directions' W_ih gradients -- are measured once).  A window whose batches are
+    not evenly strided keeps the problem (and so the group) on bf16 x 3."""
+    done, out = {}, []
+
+    def colmax_of(t2d):
+        key = (t2d.data_ptr(), tuple(t2d.shape), t2d.stride(0))
+        if key not in done:
+            done[key] = absmax_rows_cols(t2d)[1].view(-1)
+        return done[key]
+
+    for p in problems:
+        if p.get("y_colmax") is None:
+            A, dY = p["A"], p["dY"]
+            w = A.s
+            if not (w.batch_stride == w.rows_in * w.row_stride or A.batches == 1) or w.cw % 4 or w.row_stride % 4 or dY.shape[1] % 4 or dY.stride(0) % 4 \
+                    or w.cw > 2048 or dY.shape[1] > 2048 or A.t.data_ptr() % 16 or dY.data_ptr() % 16:
+                return problems
+            src = torch.as_strided(A.t, (A.batches * w.rows_in, w.cw), (w.row_stride, 1))
+            p = dict(p, y_colmax=colmax_of(dY), a_colmax=colmax_of(src))
+        out.append(p)
+    return out
 
 
 @contextlib.contextmanager

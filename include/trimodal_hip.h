@@ -189,6 +189,11 @@ int tg_win_row_absmax(const tg_window* A, int32_t batches, float* rowmax, void* 
  * the window A -- tg_gemm_nt_problem.a_row_scale.  src_rowmax == NULL: read from the tensor itself (a row with t taps is read t times);
  * else from tg_win_row_absmax's output for that tensor (batch b = m / rows_out, source rows (m % rows_out) * row_step + shift + tap * dil). */
 int tg_h2_row_scales(const tg_window* A, int32_t M, const float* src_rowmax, float* row_scale, void* stream);
+/* One pass over an fp32 matrix x[M][C] (row stride ldx): rowmax[m] = largest magnitude of row m (M floats, or NULL); colmax[g * C + c] = largest
+ * magnitude of column c within row group g (the M rows cut into `groups` equal consecutive parts, e.g. the two directions of a GRU layer's gate
+ * gradients [2][B * T][3H]; groups * C floats, or NULL).  colmax is zeroed and then raised by atomic unsigned max.  Feeds a_rowmax of
+ * tg_gemm_nt_problem and y_colmax / a_colmax of tg_gemm_tn_problem when the tensor's producer does not supply them. */
+int tg_absmax_rows_cols(const float* x, int64_t ldx, int32_t M, int32_t C, int32_t groups, float* rowmax, float* colmax, void* stream);
 
 /* tg_gemm_tn (weight gradient, accumulates): dW[n*ldw + perm(k)] += sum_m dY[m*ldy + n] * A(m, k).
  *   out_kw == 0: perm(k) = k.  out_kw == K/cw: perm(k) = (k % cw) * out_kw + k / cw, i.e. the gradient lands in
@@ -209,6 +214,13 @@ typedef struct tg_gemm_tn_problem {
     float* dbias;
     float* ws;
     int64_t ws_floats;
+    /* ABI 7 -- fp16 x 2 operands on the mover-wave kernel (both non-NULL, 16-byte aligned; ignored by the other kernels, which read the fp32
+     * operands): y_colmax[n] = largest magnitude of column n of dY over the M rows (N floats), a_colmax[c] = largest magnitude of channel c of A's
+     * tensor (cw floats, valid for every tap) -- tg_absmax_rows_cols or the kernels that wrote the tensors.  The sum runs over rows, so each
+     * COLUMN is scaled by its own power of two; the combine scales the sums back.  Same contract: the weight-gradient half of
+     * aten::convolution_backward / addmm backward within the fp32 tolerance. */
+    const float* y_colmax;
+    const float* a_colmax;
 } tg_gemm_tn_problem;
 /* tg_gemm_tn_group: up to 8 independent weight gradients in ONE launch (the four of a GRU layer: W_ih / W_hh of both directions). */
 int tg_gemm_tn_group(const tg_gemm_tn_problem* problems, int32_t n, void* stream);

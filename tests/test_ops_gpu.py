@@ -1064,7 +1064,17 @@ def test_gemm_tn_split_bf16x3_path_is_fp32_accurate(pkg, dev, M, N, K):
     assert float(((dw.double().cpu() - 2 * ref).abs() / scale).max()) < 1e-5
 
 
-def test_gemm_tn_mover_wave_kernel(pkg, dev):
+@pytest.fixture(params=["h2", "x3"])
+def operand_format(request, pkg):
+    """Both operand formats of the mover-wave products: 'h2' = fp16 x 2 (the default: three matrix instructions per product, per-row /
+    per-column power-of-two scales), 'x3' = bf16 x 3 (six; TG_GEMM_H2=0)."""
+    prev = pkg.ops.GEMM_H2
+    pkg.ops.GEMM_H2 = request.param == "h2"
+    yield request.param
+    pkg.ops.GEMM_H2 = prev
+
+
+def test_gemm_tn_mover_wave_kernel(pkg, dev, operand_format):
     """csrc/gemm_tn_mw.hip on the groups it is chosen for: the four weight gradients of a GRU layer at B = 128 (dW_ih, dW_hh of both
     directions with their bias gradients -- the bias gradient rides in the product as a column of ones; multimodal_context_net.py:98-99
     backward) and a text-encoder-sized group over a two-tap conv window with padding (model/tcn.py:19-46 backward), against fp64:

@@ -2,6 +2,8 @@
 running statistics, the device-side step / RNG counters and the warm-up -> GAN switch at epoch 10 -> 11
 (train_eval/train_gan.py:27,88; scripts/train.py:104-109) carried from one iteration into the next on BOTH sides -- no fresh state
 between iterations."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -38,11 +40,29 @@ def test_five_consecutive_iterations_match_fp64_oracle(pkg, dev):
         text, audio, vid, poses = O.make_batch(500 + it, B, V, S)          # a new batch every iteration
         rand = O.Rand(seed=2017 + it)
         pre = O.wav_preacts(og, audio.double())                     # LeakyReLU pre-activations of the audio encoder on this iteration's weights
+        before = copy.deepcopy((og, od, ga, da))                    # the oracle's complete training state at the start of the iteration
         oret, extra = O.train_iter_gan(og, od, ga, da, epoch, text, audio.double(), poses.double(), vid, rand, dict(O.HP), want_grads=True)
         ret = tr.train_iter(epoch, text.to(dev), audio.to(dev), poses.to(dev), vid.to(dev), inject=to_device_inject(rand.rec, dev)).to_dict()
         assert sorted(ret) == sorted(oret), (it, ret, oret)
         assert ("gen" in ret) == (epoch > 10) and ("dis" in ret) == (epoch > 10)           # the switch happens between epochs 10 and 11
-        flips_iter.append(wav_gate_flips(tr.last_tape, pre))
+        fl = wav_gate_flips(tr.last_tape, pre)
+        flips_iter.append(fl)
+        if sum(f[2] for f in fl):
+            # A LeakyReLU gate of the audio encoder on the other side of an fp64 NEAR-TIE (|pre-activation| < 2e-6, asserted right here, in every
+            # iteration -- round 6: the former 1e-5 window "after a first flip" is gone).  Both sides are correct evaluations of the reference
+            # there, but left alone the two weight trajectories drift apart through Adam and later iterations flip gates that are no ties at all.
+            # As in the full-size test below, the oracle REPEATS the iteration from the same state and draws with exactly those gates on the
+            # side the HIP path took; that run is the reference and the state carried on.
+            assert max(f[3] for f in fl if f[2]) < NEAR_TIE_FRESH, (it, fl)
+            for dst_, src_ in zip((og, od, ga, da), before):
+                dst_.clear(); dst_.update(src_)
+            O.wav_gate_override = wav_gate_sides(tr.last_tape, pre)
+            try:
+                oret, extra = O.train_iter_gan(og, od, ga, da, epoch, text, audio.double(), poses.double(), vid, O.Rand(seed=2017 + it), dict(O.HP),
+                                               want_grads=True)
+            finally:
+                O.wav_gate_override = None
+        del before
         e = max(abs(ret[k] - oret[k]) / max(abs(oret[k]), 1e-6) for k in oret)
         per_iter.append(e)
         # this iteration's gradients (the slabs hold them until the next backward zeroes them)
@@ -67,7 +87,9 @@ def test_five_consecutive_iterations_match_fp64_oracle(pkg, dev):
         fl = flips_iter[it]
         print(f"  iteration {it} (epoch {EPOCHS[it]}): worst G gradient error {ge:.1e} ({gk}), D {de:.1e} ({dk}); audio-encoder LeakyReLU gates "
               f"that differ from the fp64 oracle's (layer 1, 2, 3): {[f[2] for f in fl]} of {[f[0] for f in fl]}, near-ties {[f[1] for f in fl]}")
-    # the wide tolerances below are unlocked by flipped gates ONLY when those are a handful of fp64 near-ties (|pre| < 2e-6): anything else is a bug
+    # the wide tolerances below are unlocked by flipped gates ONLY when those are a handful of fp64 near-ties (|pre| < 2e-6 in EVERY iteration: the
+    # oracle follows the HIP path's side of such a gate, so no iteration inherits a difference): anything else is a bug
+    assert all(f[2] == 0 or f[3] < NEAR_TIE_FRESH for fl_ in flips_iter for f in fl_), flips_iter
     total_flips = assert_gate_flips_are_near_ties(flips_iter, "five-iteration trajectory")
     assert worst_loss <= 1e-4, per_iter
 
