@@ -54,6 +54,7 @@ SIGNATURES = {
     "tg_ae_train_step": [C.POINTER(AeStepArgs), P],
     "tg_split3_planes": [P, I64, I32, I32, P, I32, I64, P],
     "tg_split2h_planes": [P, I64, I32, I32, P, I32, I64, P, P],
+    "tg_split2h_planes_tcat": [P, P, I32, I32, P, I32, I64, P, P],
     "tg_win_row_absmax": [WP, I32, P, P],
     "tg_h2_row_scales": [WP, I32, P, P, P],
     "tg_absmax_rows_cols": [P, I64, I32, I32, I32, P, P, P],
@@ -66,6 +67,7 @@ SIGNATURES = {
     "tg_gru_forward_cluster": [P, I64, P, P, P, P, P, P, I64, P, P, P, I64, I32, I32, I32, P],
     "tg_gru_forward_cluster_rows": [P, I64, P, P, P, P, P, P, I64, P, P, P, I64, I32, I32, I32, I32, I32, P],
     "tg_gru_backward_cluster": [P, P, P, P, I64, P, P, P, P, I64, P, I64, I32, I32, I32, P],
+    "tg_gru_backward_cluster_stats": [P, P, P, P, I64, P, P, P, P, I64, P, I64, I32, I32, I32, P, I64, P, P, P],
     "tg_bn_train_stats": [P, I32, I32, I32, P, P, P, P, P, P, F32, F32, I32, P],
     "tg_bn_eval_stats": [P, P, I32, F32, P, P, P],
     "tg_bn_train_fused": [P, P, I32, I32, I32, P, P, P, P, P, P, P, F32, F32, F32, I32, P],

@@ -289,6 +289,51 @@ __device__ __forceinline__ void h2_write_row(const float* __restrict__ x, long l
     }
 }
 
+// fp16 x 2 planes of the K-CONCATENATED TRANSPOSE of two matrices: out row n (n < cols), column k (k < 2 rows) = w{k / rows}[k % rows][n], w0 / w1
+// [rows][cols] fp32 contiguous -- the weight operand of dx = [dgi_fwd | dgi_rev] @ [W_ih_fwd ; W_ih_rev] (one product over K = 6H) straight from
+// the two nn.GRU parameters.  One 256-thread workgroup per 32 output rows: thread (n_l = t % 32, kg = t / 32); every global read is 32 consecutive
+// floats of one source row.  `wg` of `nwg` workgroups walk the row blocks; planes as h2_write_row writes them (zero row `cols` included).
+__device__ __forceinline__ void h2_planes_tcat_block(const float* __restrict__ w0, const float* __restrict__ w1, int rows, int cols, int cwp,
+                                                     _Float16* __restrict__ planes, long plane_stride, float* __restrict__ inv, int wg, int nwg,
+                                                     unsigned (&smax)[8][32]) {
+    const int t = threadIdx.x, n_l = t & 31, kg = t >> 5;
+    const int K = 2 * rows;
+    for (int n0 = wg * 32; n0 <= cols; n0 += nwg * 32) {
+        const int n = n0 + n_l;
+        const bool live = n < cols;
+        unsigned mx = 0u;
+        if (live)
+            for (int k = kg; k < K; k += 8) {
+                const float v = (k < rows ? w0 : w1)[(long)(k < rows ? k : k - rows) * cols + n];
+                const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+                mx = mx > b ? mx : b;
+            }
+        smax[kg][n_l] = mx;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const unsigned b = smax[q][n_l]; mx = mx > b ? mx : b; }
+        __syncthreads();
+        const int e = h2_exp_of_bits(mx);
+        const float sc = h2_scale_of_exp(e);
+        if (kg == 0 && n <= cols) inv[n] = live ? h2_inv_of_exp(e) : 0.f;
+        if (n <= cols)
+            for (int p8 = kg; p8 < cwp / 8; p8 += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = 8 * p8 + q;
+                    v[q] = (live && k < K) ? (k < rows ? w0 : w1)[(long)(k < rows ? k : k - rows) * cols + n] : 0.f;
+                }
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h2_split2(v[2 * q] * sc, v[2 * q + 1] * sc, h[q], l[q]);
+                const long o = plane_tiled_off(n, 8 * p8, cols);
+                *reinterpret_cast<tg_u32x4*>(planes + o) = tg_u32x4{h[0], h[1], h[2], h[3]};
+                *reinterpret_cast<tg_u32x4*>(planes + plane_stride + o) = tg_u32x4{l[0], l[1], l[2], l[3]};
+            }
+    }
+}
+
 // ---- Philox4x32-10 ------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;

@@ -376,6 +376,16 @@ __global__ __launch_bounds__(256) void permute3_batch_kernel(const long* __restr
             h2_write_row(in, (long)cw, rows, cw, cwp, planes, plane, inv, r, (int)(threadIdx.x & 63), vec);
         return;
     }
+    if (p0 == 11) {
+        // fp16 x 2 planes of the K-concatenated transpose of two [d0 rows][d1 cols] matrices (src and the pointer in p1): common.hpp h2_planes_tcat_block
+        const int rows = d[0], cols = d[1], cwp = d[2];
+        const long plane = (long)(cols + 1) * cwp;
+        _Float16* const planes = reinterpret_cast<_Float16*>(out);
+        __shared__ unsigned smax[8][32];
+        h2_planes_tcat_block(in, reinterpret_cast<const float*>(e[6]), rows, cols, cwp, planes, plane, reinterpret_cast<float*>(planes + 2 * plane),
+                             (int)((long)blockIdx.x - wg0), (int)nwg, smax);
+        return;
+    }
     if (p0 == 9) {
         // conv input-gradient pack (conv_dgrad_pack_kernel): src (Co, Ci, kw) -> [stride][Ci][J * Co], stride = p1, zero taps past kw
         const int Co = d[0], Ci = d[1], kw = d[2], st = p1, J = (kw + st - 1) / st;

@@ -803,7 +803,8 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
     TG_REQUIRE(!q.c2_rowmax || q.C2, "tg_gemm_nt: c2_rowmax without C2 (problem %d)", idx);
     if (q.b_planes) {
         const int64_t kp = ((int64_t)q.A.K + 31) / 32 * 32;
-        TG_REQUIRE(q.b_seg_k == 0 && q.b_rows >= q.N && q.b_row0 >= 0 && q.b_row0 + (int64_t)q.N <= q.b_rows && aligned16(q.b_planes) &&
+        // (K-concatenated weight segments may bring planes too: the planes then hold the concatenation, all K columns of every row)
+        TG_REQUIRE(q.b_rows >= q.N && q.b_row0 >= 0 && q.b_row0 + (int64_t)q.N <= q.b_rows && aligned16(q.b_planes) &&
                        q.b_plane_stride >= ((int64_t)q.b_rows + 1) * kp && q.b_plane_stride % 8 == 0 && ((int64_t)q.b_rows + 1) * kp < (1LL << 30),
                    "tg_gemm_nt: bad weight planes (problem %d): one weight matrix, its N=%d rows inside the buffer's %d, plane stride >= (rows + 1) * K "
                    "rounded up to 32, 16-byte aligned", idx, q.N, q.b_rows);

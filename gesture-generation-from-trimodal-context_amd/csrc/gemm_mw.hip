@@ -601,14 +601,12 @@ extern "C" int tg_lab_mw_role_cycles(void* host_out, int64_t n_words) {
 // addressable that way (negative strides, >= 2 GB)
 static bool mw_extents(NtProb& p) {
     const Win& A = p.A;
-    if (A.bs < 0 || A.rs < 0 || p.ldb < 0 || p.b_seg_stride < 0 || A.rows_out <= 0) return false;
+    if (A.bs < 0 || A.rs < 0 || A.rows_out <= 0) return false;
     const long batches = cdiv(p.M, A.rows_out);
     const long a_el = (batches - 1) * A.bs + (long)(A.rows_in - 1) * A.rs + A.cw;
-    const long segs = A.K / p.b_seg_k;
-    const long b_el = (long)(p.N - 1) * p.ldb + (segs - 1) * p.b_seg_stride + p.b_seg_k;
-    if (a_el <= 0 || b_el <= 0 || a_el >= (1l << 29) || b_el >= (1l << 29)) return false;
+    if (a_el <= 0 || a_el >= (1l << 29)) return false;
     p.a_bytes = (unsigned)(a_el * 4);
-    p.b_bytes = (unsigned)(b_el * 4);
+    p.b_bytes = 0;                           // (the weights are read from their planes: Bw and its segments are never touched here)
     return true;
 }
 
@@ -655,7 +653,7 @@ static bool mw_pick_tile(const NtGroup& g, MwTile* out) {
 bool tg_gemm_nt_mw_eligible(NtGroup& g, int* tm, int* tn) {
     for (int i = 0; i < g.n; ++i) {
         NtProb& p = g.p[i];
-        if (!p.vec_c || p.A.cw % 4 != 0 || p.A.K % 4 != 0 || p.Bpl == nullptr || p.b_seg_k != p.A.K) return false;
+        if (!p.vec_c || p.A.cw % 4 != 0 || p.A.K % 4 != 0 || p.Bpl == nullptr) return false;            // (weight segments: the planes hold their concatenation)
         if (!mw_extents(p)) return false;
         if (p.h2 != g.p[0].h2) return false;                   // one operand format per launch
     }

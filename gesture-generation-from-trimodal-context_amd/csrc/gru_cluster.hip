@@ -25,6 +25,7 @@ int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, c
                          int H, int n_bt, int cw, int b_pad, int save_row0, int save_rows, hipStream_t s);
 int tg_gru_x3_bwd_launch(const float* dy, const float* dy_mask, const float* y, const float* save, long save_ds, const float* wt0, const float* wt1, float* dgi,
                          float* dgh, long dg_ds, void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
+                         float* gi_rmax, long rm_ds, float* gi_cmax, float* gh_cmax,
                          hipStream_t s);
 // Workgroups that can be co-resident at one per CU: the device's CU count (256 on a whole MI355X; fewer under CPX/DPX partitioning
 // or CU masking, where the cluster kernels must not be used: a member that can never become resident stalls its cluster until
@@ -125,17 +126,20 @@ extern "C" int64_t tg_gru_cluster_bwd_ws_bytes(int32_t B, int32_t H) {
     return flag_words * 4 + tg_gru_x3_bwd_exchange_bytes(n_bt * 16, cw);
 }
 
-extern "C" int tg_gru_backward_cluster(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
+extern "C" int tg_gru_backward_cluster_stats(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
                                        const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
-                                       void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream) {
-    TG_REQUIRE(dy && y && save && w_hh_t_fwd && w_hh_t_rev && dgi && dgh && ws, "tg_gru_backward_cluster: null pointer");
-    TG_REQUIRE(dy_mask == nullptr || aligned16(dy_mask), "tg_gru_backward_cluster: dy_mask must be 16-byte aligned");
-    TG_REQUIRE(T > 0 && tg_gru_cluster_bwd_supported(B, H), "tg_gru_backward_cluster: unsupported shape B=%d H=%d", B, H);
-    TG_REQUIRE((int64_t)B * T * 4 * H * 4 < (1LL << 31), "tg_gru_backward_cluster: B * T * 4H floats must stay below 2 GB (32-bit buffer offsets), T=%d", T);
-    TG_REQUIRE(ws_bytes >= tg_gru_cluster_bwd_ws_bytes(B, H), "tg_gru_backward_cluster: workspace too small");
+                                       void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, float* gi_rowmax, int64_t rowmax_dir_stride,
+                                       float* gi_colmax, float* gh_colmax, void* stream) {
+    TG_REQUIRE((gi_rowmax != nullptr) == (gi_colmax != nullptr) && (gi_rowmax != nullptr) == (gh_colmax != nullptr) && rowmax_dir_stride >= 0,
+               "tg_gru_backward_cluster_stats: gi_rowmax, gi_colmax and gh_colmax go together");
+    TG_REQUIRE(dy && y && save && w_hh_t_fwd && w_hh_t_rev && dgi && dgh && ws, "tg_gru_backward_cluster_stats: null pointer");
+    TG_REQUIRE(dy_mask == nullptr || aligned16(dy_mask), "tg_gru_backward_cluster_stats: dy_mask must be 16-byte aligned");
+    TG_REQUIRE(T > 0 && tg_gru_cluster_bwd_supported(B, H), "tg_gru_backward_cluster_stats: unsupported shape B=%d H=%d", B, H);
+    TG_REQUIRE((int64_t)B * T * 4 * H * 4 < (1LL << 31), "tg_gru_backward_cluster_stats: B * T * 4H floats must stay below 2 GB (32-bit buffer offsets), T=%d", T);
+    TG_REQUIRE(ws_bytes >= tg_gru_cluster_bwd_ws_bytes(B, H), "tg_gru_backward_cluster_stats: workspace too small");
     TG_REQUIRE(aligned16(dy) && aligned16(y) && aligned16(save) && aligned16(w_hh_t_fwd) && aligned16(w_hh_t_rev) && aligned16(dgi) &&
                aligned16(dgh) && aligned16(ws) && save_dir_stride % 4 == 0 && dg_dir_stride % 4 == 0,
-               "tg_gru_backward_cluster: operands must be 16-byte aligned");
+               "tg_gru_backward_cluster_stats: operands must be 16-byte aligned");
     int n_bt, cw;
     cluster_plan_bwd(B, H, &n_bt, &cw);
     const int64_t flag_words = (int64_t)(2 * n_bt + 1) * GC_FLAG_STRIDE;
@@ -144,5 +148,12 @@ extern "C" int tg_gru_backward_cluster(const float* dy, const float* dy_mask, co
     unsigned* flags = tmo + GC_FLAG_STRIDE;
     float* gx = (float*)(tmo + flag_words);
     return tg_gru_x3_bwd_launch(dy, dy_mask, y, save, (long)save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, (long)dg_dir_stride, gx, flags, tmo, B, T, H,
-                                n_bt, cw, n_bt * 16, s);
+                                n_bt, cw, n_bt * 16, gi_rowmax, (long)rowmax_dir_stride, gi_colmax, gh_colmax, s);
+}
+
+extern "C" int tg_gru_backward_cluster(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
+                                       const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
+                                       void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream) {
+    return tg_gru_backward_cluster_stats(dy, dy_mask, y, save, save_dir_stride, w_hh_t_fwd, w_hh_t_rev, dgi, dgh, dg_dir_stride, ws, ws_bytes, B, T, H, nullptr, 0,
+                                         nullptr, nullptr, stream);
 }

@@ -469,7 +469,11 @@ template <int NS>
 __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     const float* __restrict__ dY, const float* __restrict__ dy_mask, const float* __restrict__ Y, const float* __restrict__ save, long save_ds,
     const float* __restrict__ wt0, const float* __restrict__ wt1, float* __restrict__ dgi, float* __restrict__ dgh, long dg_ds,
-    void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int CW, int b_pad) {
+    void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int CW, int b_pad,
+    float* __restrict__ gi_rmax, long rm_ds, float* __restrict__ gi_cmax, float* __restrict__ gh_cmax) {
+    // gi_rmax / gi_cmax / gh_cmax (all or none; zeroed by the caller): magnitudes of what this launch writes, for the fp16 x 2 products that read it --
+    // gi_rmax[dir * rm_ds + row * T + t] = largest |dgi| of that row (the input-gradient product's row scales), gi_cmax / gh_cmax[dir * 3H + c] =
+    // largest |dgi| / |dgh| of column c (the weight-gradient products' column scales); raised by atomic unsigned max behind the step's hand-off
     __shared__ __attribute__((aligned(16))) f32x4 red[XC_KSB][2][64];
     __shared__ __attribute__((aligned(16))) bf16x8 wlo[8][2 * XC_SPB8][64];
     __shared__ int same_xcd_s;
@@ -558,6 +562,11 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     const unsigned sv_v = e_ok ? (unsigned)((row * T * 4 * H + unit0) * 4) : OOB;           // + (tau * 4H + j * H) * 4
     const unsigned dg_v = e_ok ? (unsigned)((row * T * H3 + unit0) * 4) : OOB;              // + (tau * 3H + g * H) * 4
     f32x4 dy = zero, dm = zero, r = zero, z = zero, n = zero, hn = zero, hp = zero;         // operands of the NEXT step's cell
+    unsigned cmx[4][4];                                // running column maxima of this thread's four units: gates r, z, n (dgi) and n * r (dgh's third)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cmx[g][q] = 0u;
     auto prefetch = [&](int st) {
         const int sl = st < T ? st : T - 1;
         const int tl = dir ? sl : T - 1 - sl;
@@ -650,9 +659,46 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
             __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_z), gh_rsrc, dg_v, go + H * 4, 0);
             __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_nr), gh_rsrc, dg_v, go + 2 * H * 4, 0);
             prefetch(step + 1);
+            if (gi_rmax && e_ok) {                     // (behind the hand-off and the next step's requests: off the dependent chain)
+                unsigned rm = 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned br = __float_as_uint(g_r[q]) & 0x7fffffffu, bz = __float_as_uint(g_z[q]) & 0x7fffffffu;
+                    const unsigned bn = __float_as_uint(g_n[q]) & 0x7fffffffu, bnr = __float_as_uint(g_nr[q]) & 0x7fffffffu;
+                    cmx[0][q] = cmx[0][q] > br ? cmx[0][q] : br;
+                    cmx[1][q] = cmx[1][q] > bz ? cmx[1][q] : bz;
+                    cmx[2][q] = cmx[2][q] > bn ? cmx[2][q] : bn;
+                    cmx[3][q] = cmx[3][q] > bnr ? cmx[3][q] : bnr;
+                    const unsigned t3 = br > bz ? (br > bn ? br : bn) : (bz > bn ? bz : bn);
+                    rm = rm > t3 ? rm : t3;
+                }
+                atomicMax(reinterpret_cast<unsigned*>(gi_rmax) + dir * rm_ds + (long)row * T + tau, rm);
+            }
         }
     }
     if (m == 0 && threadIdx.x == 0 && T >= 2) __hip_atomic_store(cl_flags + XC_GEN_WORD, gen + (unsigned)(T + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gi_rmax && epi_wave) {
+        // column maxima: over the wave's eight rows (lanes 8 apart hold the same units), then one atomic per column and wave
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned v = cmx[g][q];
+#pragma unroll
+                for (int o = 8; o <= 32; o <<= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = v > w ? v : w; }
+                cmx[g][q] = v;
+            }
+        if (lane < 8 && unit0 < H) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = unit0 + q;
+                unsigned* ci = reinterpret_cast<unsigned*>(gi_cmax) + dir * H3;
+                unsigned* ch = reinterpret_cast<unsigned*>(gh_cmax) + dir * H3;
+                atomicMax(ci + c, cmx[0][q]); atomicMax(ci + H + c, cmx[1][q]); atomicMax(ci + 2 * H + c, cmx[2][q]);
+                atomicMax(ch + c, cmx[0][q]); atomicMax(ch + H + c, cmx[1][q]); atomicMax(ch + 2 * H + c, cmx[3][q]);
+            }
+        }
+    }
 }
 
 }  // namespace tg
@@ -698,12 +744,13 @@ int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, c
 
 int tg_gru_x3_bwd_launch(const float* dy, const float* dy_mask, const float* y, const float* save, long save_ds, const float* wt0, const float* wt1, float* dgi,
                          float* dgh, long dg_ds, void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int cw, int b_pad,
+                         float* gi_rmax, long rm_ds, float* gi_cmax, float* gh_cmax,
                          hipStream_t s) {
     if (tg_get_math_mode() == 1)
         hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel<1>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, dy_mask, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
-                           flags, tmo, B, T, H, n_bt, cw, b_pad);
+                           flags, tmo, B, T, H, n_bt, cw, b_pad, gi_rmax, rm_ds, gi_cmax, gh_cmax);
     else
         hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel<3>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, dy_mask, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
-                           flags, tmo, B, T, H, n_bt, cw, b_pad);
+                           flags, tmo, B, T, H, n_bt, cw, b_pad, gi_rmax, rm_ds, gi_cmax, gh_cmax);
     return check_launch("tg_gru_backward_cluster(x3)");
 }

@@ -30,6 +30,12 @@ __global__ __launch_bounds__(256) void split2h_planes_kernel(const float* __rest
         h2_write_row(x, ldx, rows, cw, cwp, planes, plane_stride, inv, r, lane, vec != 0);
 }
 
+__global__ __launch_bounds__(256) void split2h_planes_tcat_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int rows, int cols, int cwp,
+                                                                  _Float16* __restrict__ planes, long plane_stride, float* __restrict__ inv) {
+    __shared__ unsigned smax[8][32];
+    h2_planes_tcat_block(w0, w1, rows, cols, cwp, planes, plane_stride, inv, blockIdx.x, gridDim.x, smax);
+}
+
 // Largest magnitude of every SOURCE row of a window operand: rmax[b * rows_in + r] = max_c |ptr[b * bs + r * rs + c]|, c < cw -- what the
 // fp16 x 2 kernels derive the power-of-two scale of a product's row from (the maximum over the row's taps).  One wave per row, four rows
 // in flight per wave.
@@ -188,6 +194,16 @@ extern "C" int tg_split2h_planes(const float* x, int64_t ldx, int32_t rows, int3
     hipLaunchKernelGGL(split2h_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, rows, cw, cwp,
                        reinterpret_cast<_Float16*>(planes), (long)plane_stride, inv, vec);
     return check_launch("tg_split2h_planes");
+}
+
+extern "C" int tg_split2h_planes_tcat(const float* w0, const float* w1, int32_t rows, int32_t cols, void* planes, int32_t cwp, int64_t plane_stride, float* inv,
+                                      void* stream) {
+    TG_REQUIRE(w0 && w1 && planes && inv && rows > 0 && cols > 0, "tg_split2h_planes_tcat: bad arguments");
+    TG_REQUIRE(cwp >= 2 * rows && cwp % 32 == 0 && plane_stride >= (int64_t)(cols + 1) * cwp && plane_stride % 8 == 0 && aligned16(planes),
+               "tg_split2h_planes_tcat: cwp=%d must be a multiple of 32 >= 2 rows = %d, plane_stride >= (cols + 1) * cwp and a multiple of 8, planes 16-byte aligned", cwp, 2 * rows);
+    hipLaunchKernelGGL(split2h_planes_tcat_kernel, dim3(cdiv(cols + 1, 32)), dim3(256), 0, (hipStream_t)stream, w0, w1, rows, cols, cwp,
+                       reinterpret_cast<_Float16*>(planes), (long)plane_stride, inv);
+    return check_launch("tg_split2h_planes_tcat");
 }
 
 extern "C" int tg_win_row_absmax(const tg_window* A, int32_t batches, float* rmax, void* stream) {

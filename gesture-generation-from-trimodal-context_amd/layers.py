@@ -74,6 +74,11 @@ class WeightPrep:
                     rows.append([s3.data_ptr(), d.data_ptr(), s3.shape[1], s3.shape[2], d.shape[2], 8, 0, 0, wg0, nwg])
                     wg0 += nwg
                     continue
+                if pm[0] == 11:                                       # fp16 x 2 planes of [src^T | other^T] (pm[1] = the other matrix): 32 output rows per workgroup
+                    nwg = (s3.shape[2] + 32) // 32
+                    rows.append([s3.data_ptr(), d.data_ptr(), s3.shape[1], s3.shape[2], ops.planes_cwp(2 * s3.shape[1]), 11, pm[1], 0, wg0, nwg])
+                    wg0 += nwg
+                    continue
                 if pm[0] == 10:                                       # fp16 x 2 planes: d = the flat buffer [2 planes | inverse scales], one wave per row
                     nwg = max(1, min(512, (s3.shape[1] + 16) // 16))
                     rows.append([s3.data_ptr(), d.data_ptr(), s3.shape[1], s3.shape[2], ops.planes_cwp(s3.shape[2]), 10, 0, 0, wg0, nwg])
@@ -92,7 +97,7 @@ class WeightPrep:
             g["desc"][part] = torch.tensor(rows, dtype=torch.int64).to(device) if rows else None
             g["wgs"][part], g["n"][part], g["rows"][part] = wg0, len(rows), rows
 
-    def get(self, src3, perm, out_shape):
+    def get(self, src3, perm, out_shape, other=None):
         """The permuted copy of src3 (3-D view of a slab parameter) or None when the caller has to permute inline.
         perm = (9, stride, 0) is the conv input-gradient pack (ops.conv_dgrad_pack) of a (Co, Ci, kw) weight."""
         key = (src3.data_ptr(), tuple(src3.shape), perm)
@@ -115,6 +120,9 @@ class WeightPrep:
         elif perm[0] == 10:                                       # fp16 x 2 planes + inverse scales of the same: one flat fp16 buffer (ops.h2_planes_alloc)
             dst = ops.h2_planes_alloc(src3.shape[1], src3.shape[2], src3.device)[0]
             ops.split2h_planes(src3[0], buf=dst)
+        elif perm[0] == 11:                                       # ... of the K-concatenated transpose of src3[0] and `other`
+            dst = ops.h2_planes_alloc(src3.shape[2], 2 * src3.shape[1], src3.device)[0]
+            ops.split2h_planes_tcat(src3[0], other, buf=dst)
         elif perm[0] == 9:
             dst = empty(*out_shape, like=src3)
             ops.conv_dgrad_pack(src3, dst, perm[1])
@@ -204,6 +212,19 @@ def weight_planes(w2d):
                 return ops.Planes(hit[:n16].view(2, N + 1, cwp), N, K, cwp, "h2", hit[n16:].view(torch.float32))
             return ops.Planes(hit, N, K, hit.shape[2])
     return ops.split_planes(w2d)
+
+
+def weight_planes_tcat(w0, w1):
+    """fp16 x 2 Planes of [w0^T | w1^T] for two [rows][cols] parameters (the K-concatenated input-gradient operand of a bidirectional GRU layer):
+    refreshed once per optimiser step by an active WeightPrep, split inline otherwise."""
+    rows, cols = w0.shape
+    if _PREP is not None and w0.is_contiguous() and w1.is_contiguous():
+        hit = _PREP.get(w0.view(1, rows, cols), (11, w1.data_ptr(), 0), None, other=w1)
+        if hit is not None:
+            cwp = ops.planes_cwp(2 * rows)
+            n16 = 2 * (cols + 1) * cwp
+            return ops.Planes(hit[:n16].view(2, cols + 1, cwp), cols, 2 * rows, cwp, "h2", hit[n16:].view(torch.float32))
+    return ops.split2h_planes_tcat(w0, w1)
 
 
 def dgrad_pack(w, stride):
@@ -458,7 +479,7 @@ def wav_front_bwd_fused(dc2, w2, st, audio, w, b, gamma, dW, db, dgamma, dbeta, 
 
 # ----------------------------------------------------------------------------------------------- GRU stack
 class GRUTape:
-    __slots__ = ("x", "y", "save", "masks", "B", "T", "H")
+    __slots__ = ("x", "y", "save", "masks", "B", "T", "H", "xbound")
 
 
 def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save=False, inject=None, tag="g", save_rows=None, drawn=None):
@@ -468,6 +489,7 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
     tape = GRUTape()
     tape.x, tape.y, tape.save, tape.masks = [], [], [], []
     tape.B, tape.T, tape.H = B, T, H
+    tape.xbound = []                      # per layer: a bound on |layer input| known by construction (None: unknown), for the backward's fp16 x 2 scales
     cur = x
     # the inter-layer dropout rides in the recurrence kernels (csrc/gru_h64.hip, csrc/gru_cluster_x3.hip): the masks of all layers of
     # the pass come from ONE draw launch (or from the parity tests)
@@ -488,6 +510,7 @@ def gru_stack_fwd(x, P, prefix, n_layers, H, *, p_drop, training, rng=None, save
         bound = None
         if l > 0 and inject is None:
             bound = ops.const_rowmax(B * T, 1.0 / (1.0 - p_drop) if (training and p_drop > 0) else 1.0, x.device)
+        tape.xbound.append(None if bound is None else (1.0 / (1.0 - p_drop) if (training and p_drop > 0) else 1.0))
         ops.gemm_nt_group([dict(A=a_win, W=P[f"{prefix}.weight_ih_l{l}{sfx}"], bias=P[f"{prefix}.bias_ih_l{l}{sfx}"],
                                 out=gi[d].view(B * T, 3 * H), w_planes=wpl(P[f"{prefix}.weight_ih_l{l}{sfx}"]), a_rowmax=bound)
                            for d, sfx in enumerate(("", "_reverse"))])       # both directions, one launch
@@ -612,6 +635,13 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
                 with ops.tn_workgroup_cap(free_cus):
                     ops.gemm_tn_group(probs_s)
             side_pending = None
+    # fp16 x 2 operands for the products that read dgi / dgh: the cluster recurrence leaves the magnitudes of dgi's rows and of dgi's / dgh's columns
+    # behind its hand-offs (tg_gru_backward_cluster_stats), so neither the input-gradient product nor the weight gradients need a pass over them.
+    # One zeroed block for all layers: [layer][gi_rowmax 2 nb T | gi_colmax 2 x 3H | gh_colmax 2 x 3H]
+    want_stats = (ops.gemm_h2() and ops.GRU_CLUSTER and H > 64 and H % 4 == 0 and nb * T >= 2048
+                  and ops.gru_cluster_chunks(nb, H, bwd=True) is not None)
+    n_rm = (2 * nb * T + 3) // 4 * 4
+    stats_all = ops.zeros(n_layers, n_rm + 12 * H, device=dy.device) if want_stats else None
     for l in range(n_layers - 1, -1, -1):
         # The side rows are enqueued BEFORE the recurrence they run beside.  (Round 5, profiles/r5_z_tn_side_rows.txt: captured the other way
         # round -- recurrence first, an event for the side rows -- hipGraph ran the whole side branch after everything else, 5.00 ms.)
@@ -625,10 +655,26 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
         scaled = False
         wt = tuple(transpose2d(P[f"{prefix}.weight_hh_l{l}{s}"]) for s in ("", "_reverse"))
         dgi, dgh = empty(2, nb, T, 3 * H, like=dy), empty(2, nb, T, 3 * H, like=dy)
-        ops.gru_backward(dy.contiguous(), tape.y[l], tape.save[l], wt, dgi, dgh, dh, b0=b0, nb=nb, dy_mask=dy_mask)
+        stats = None
+        if stats_all is not None:
+            st = stats_all[l]
+            stats = (st[:2 * nb * T].view(2, nb * T), st[n_rm:n_rm + 6 * H].view(2, 3 * H), st[n_rm + 6 * H:].view(2, 3 * H))
+        if not ops.gru_backward(dy.contiguous(), tape.y[l], tape.save[l], wt, dgi, dgh, dh, b0=b0, nb=nb, dy_mask=dy_mask, stats=stats):
+            stats = None
         x_l = tape.x[l][rows]
         Kin = x_l.shape[2]
         y_l = tape.y[l][rows]
+        x_cmax = h_cmax = None
+        if stats is not None and param_grads:
+            # column magnitudes of the OTHER operands: h_{t-1} is a GRU output (|h| < 1), a layer input above the first is one through an inverted
+            # dropout (the bound the forward recorded); anything else is measured (the first layer's 108 columns)
+            h_cmax = ops.const_rowmax(H, 1.0, dy.device)
+            xb = tape.xbound[l] if getattr(tape, "xbound", None) else None
+            if xb is not None:
+                x_cmax = ops.const_rowmax(Kin, xb, dy.device)
+            elif Kin % 4 == 0 and x_l.is_contiguous():
+                x_cmax = ops.absmax_rows_cols(x_l.reshape(nb * T, Kin))[1].view(-1)
+            # (else: x_cmax stays None and the layer's weight gradients keep bf16 x 3)
         if param_grads:
             def layer_probs(r0, r1):
                 """the layer's four weight gradients (+ four bias gradients) over batch rows [r0, r1)"""
@@ -636,10 +682,12 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
                 x_win = Win.plain(x_l[r0:r1].reshape(n * T, Kin))
                 for d, sfx in enumerate(("", "_reverse")):
                     gi2, gh2 = dgi[d][r0:r1].view(n * T, 3 * H), dgh[d][r0:r1].view(n * T, 3 * H)
-                    probs.append(dict(dY=gi2, A=x_win, dW=G[f"{prefix}.weight_ih_l{l}{sfx}"], dbias=G[f"{prefix}.bias_ih_l{l}{sfx}"]))
+                    cm_i = dict(y_colmax=stats[1][d], a_colmax=x_cmax) if (stats is not None and x_cmax is not None) else {}
+                    cm_h = dict(y_colmax=stats[2][d], a_colmax=h_cmax) if (stats is not None and x_cmax is not None) else {}
+                    probs.append(dict(dY=gi2, A=x_win, dW=G[f"{prefix}.weight_ih_l{l}{sfx}"], dbias=G[f"{prefix}.bias_ih_l{l}{sfx}"], **cm_i))
                     # h_{t-1} of direction d is the layer output one step back (forward) / ahead (reverse), zero at the ends
                     hwin = Win.taps(y_l[r0:r1, :, d * H:(d + 1) * H], 1, shift=(1 if d else -1), dil=1, rows_out=T)
-                    probs.append(dict(dY=gh2, A=hwin, dW=G[f"{prefix}.weight_hh_l{l}{sfx}"], dbias=G[f"{prefix}.bias_hh_l{l}{sfx}"]))
+                    probs.append(dict(dY=gh2, A=hwin, dW=G[f"{prefix}.weight_hh_l{l}{sfx}"], dbias=G[f"{prefix}.bias_hh_l{l}{sfx}"], **cm_h))
                 return probs
             split = 0
             if nb_side and l > 0:
@@ -683,11 +731,16 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
                 a_cat = Win(dgi, batches=1, batch_stride=0, row_stride=3 * H, rows_in=2 * nb * T, rows_out=nb * T, cw=3 * H, K=6 * H,
                             dil=nb * T)
                 below = tape.masks[l - 1] if l > 0 else None
+                # fp16 x 2 on the mover-wave kernel (128 x 96 tiles: 238 of them for [4352 x 600]) when the recurrence left dgi's row magnitudes:
+                # the weight operand is the K-concatenated transpose of both directions' W_ih as pre-split planes (WeightPrep job 11)
+                h2kw = {}
+                if stats is not None and Kin >= 150 and Kin % 4 == 0:
+                    h2kw = dict(w_planes=weight_planes_tcat(P[f"{prefix}.weight_ih_l{l}"], P[f"{prefix}.weight_ih_l{l}_reverse"]), a_rowmax=stats[0].view(-1))
                 if below is not None and not ops.gru_fused_dropout(nb, H, bwd=True):
-                    ops.gemm_nt(a_cat, wt_ih[0], None, dx, b_seg=(3 * H, seg), out_scale=below[rows].reshape(nb * T, Kin))
+                    ops.gemm_nt(a_cat, wt_ih[0], None, dx, b_seg=(3 * H, seg), out_scale=below[rows].reshape(nb * T, Kin), **h2kw)
                     scaled = True
                 else:
-                    ops.gemm_nt(a_cat, wt_ih[0], None, dx, b_seg=(3 * H, seg))
+                    ops.gemm_nt(a_cat, wt_ih[0], None, dx, b_seg=(3 * H, seg), **h2kw)
             elif Kin == 8 and (3 * H) % 4 == 0:
                 # eight input channels (the discriminator's first layer): one bandwidth-sized pass instead of two 13 us narrow products;
                 # W_ih [3H][8] is the [K][8] operand as stored

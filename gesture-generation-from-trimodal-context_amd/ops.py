@@ -155,7 +155,7 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
     q.C, q.c_batch_stride, q.c_row_stride, q.c_rows_out = out.data_ptr(), c_batch_stride, c_row_stride, c_rows_out
     q.M, q.N, q.act_slope, q.accumulate = M, N, float(act_slope), int(bool(accumulate))
     if w_planes is not None:                   # Planes that hold W's rows from w_row0 on (split3_planes / layers.weight_planes): mover-wave kernel
-        assert b_seg is None and w_planes.cw == A.K and 0 <= w_row0 and w_row0 + N <= w_planes.rows and w_planes.t.is_cuda, (w_planes.rows, N, w_planes.cw, A.K)
+        assert w_planes.cw == A.K and 0 <= w_row0 and w_row0 + N <= w_planes.rows and w_planes.t.is_cuda, (w_planes.rows, N, w_planes.cw, A.K)
         q.b_planes, q.b_plane_stride, q.b_rows, q.b_row0 = w_planes.t.data_ptr(), w_planes.plane_stride, w_planes.rows, int(w_row0)
         if w_planes.kind == "h2":              # fp16 x 2 planes: the product rows' power-of-two scales ride along (h2_row_scales unless the caller has them)
             assert w_row0 % 4 == 0, w_row0
@@ -350,6 +350,19 @@ def split2h_planes(x2d, buf=None):
     return pl
 
 
+def split2h_planes_tcat(w0, w1, buf=None):
+    """fp16 x 2 Planes of [w0^T | w1^T] ([cols][2 rows]) for two contiguous [rows][cols] matrices (tg_split2h_planes_tcat)."""
+    _flat(w0, "w0"); _flat(w1, "w1"); assert w0.dim() == 2 and w0.shape == w1.shape
+    rows, cols = w0.shape
+    cwp = planes_cwp(2 * rows)
+    if buf is None:
+        buf = h2_planes_alloc(cols, 2 * rows, w0.device)[0]
+    n16 = 2 * (cols + 1) * cwp
+    t, inv = buf[:n16].view(2, cols + 1, cwp), buf[n16:].view(torch.float32)
+    call("tg_split2h_planes_tcat", _p(w0), _p(w1), rows, cols, C.c_void_p(t.data_ptr()), cwp, (cols + 1) * cwp, C.c_void_p(inv.data_ptr()), _stream())
+    return Planes(t, cols, 2 * rows, cwp, "h2", inv)
+
+
 def win_row_absmax(A: Win, out=None):
     """Largest magnitude of every source row of the window's tensor: [batches * rows_in] floats."""
     n = A.batches * A.s.rows_in
@@ -502,7 +515,7 @@ def gemm_tn_group(problems):
     arr = (_lib.TnProblem * len(qs))(*qs)
     if all(q.M >= 1024 and q.N >= 150 for q in qs) and (TN_MW_WS or gemm_h2()):
         plan = int(_lib.load().tg_gemm_tn_kernel_plan(arr, len(qs)))
-        if plan == 2 and gemm_h2():
+        if plan == 2 and gemm_h2() and TN_AUTO_COLMAX:
             # the mover-wave kernel with fp16 x 2 operands: column magnitudes of every operand that does not bring them
             problems = _auto_colmax(problems)
         if plan == 2 and TN_MW_WS and not all(q.ws for q in qs):
@@ -515,6 +528,12 @@ def gemm_tn_group(problems):
             qs = [_tn_problem(keep=keep, **p)[0] for p in problems]
             arr = (_lib.TnProblem * len(qs))(*qs)
     call("tg_gemm_tn_group", arr, len(problems), _stream())
+
+
+# Weight-gradient groups whose problems bring no column magnitudes: False (default) = they stay on bf16 x 3 -- a measuring pass over each operand
+# costs more than the fp16 x 2 kernel saves (profiles/r6_g_h2_tn_probe.txt: 17 us per [4352 x 900] operand against 12 us per group); True = measure
+# (tests, probes).  The training iteration supplies them from the kernels that write the operands (layers.gru_stack_bwd).
+TN_AUTO_COLMAX = False
 
 
 def _auto_colmax(problems):
@@ -738,10 +757,12 @@ def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None, save_rows=
     return y
 
 
-def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None, dy_mask=None):
+def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None, dy_mask=None, stats=None):
     """Backward through time for batch rows [b0, b0+nb) of a (possibly larger) stacked forward.
     dy: [nb, T, 2H]; y: [B, T, 2H]; save: [2, B, T, 4H]; w_hh_t: (fwd, rev) each [H, 3H]; dgi/dgh: [2, nb, T, 3H].
-    dy_mask ([nb, T, 2H], H = 64 only): multiplied into dy while it is loaded (fused dropout backward)."""
+    dy_mask ([nb, T, 2H], H = 64 only): multiplied into dy while it is loaded (fused dropout backward).
+    stats (cluster kernels only; returns True when they were filled): (gi_rowmax [2, nb * T], gi_colmax [2, 3H], gh_colmax [2, 3H]), ZEROED by the
+    caller -- the magnitudes of dgi's rows and of dgi's / dgh's columns that the fp16 x 2 products reading them scale by."""
     _flat(dy, "dy"); _flat(y, "y"); _flat(save, "save"); _flat(dgi, "dgi"); _flat(dgh, "dgh"); _flat(dh_scratch, "dh")
     B, T, H2 = y.shape
     H = H2 // 2
@@ -764,11 +785,20 @@ def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None, dy
             _flat(dy_mask, "dy_mask"); assert tuple(dy_mask.shape) == tuple(dy.shape)
         ws = _gru_cluster_ws(dy.device, chunks[0][1], H, bwd=True)
         at = lambda t_, c0, row_floats: C.c_void_p(0) if t_ is None else C.c_void_p(t_.data_ptr() + 4 * c0 * row_floats)
+        if stats is not None:
+            rm, ci, ch = stats
+            _flat(rm, "gi_rowmax"); _flat(ci, "gi_colmax"); _flat(ch, "gh_colmax")
+            assert tuple(rm.shape) == (2, nb * T) and tuple(ci.shape) == (2, 3 * H) == tuple(ch.shape)
         for c0, cn in chunks:                                    # (row chunks of one workspace, as in gru_forward)
-            call("tg_gru_backward_cluster", at(dy, c0, T * 2 * H), at(dy_mask, c0, T * 2 * H), at(ys, c0, T * 2 * H), at(ss, c0, T * 4 * H), B * T * 4 * H,
-                 _p(w_hh_t[0]), _p(w_hh_t[1]), at(dgi, c0, T * 3 * H), at(dgh, c0, T * 3 * H), nb * T * 3 * H, C.c_void_p(ws.data_ptr()), ws.numel() * 4,
-                 cn, T, H, _stream())
-        return
+            if stats is None:
+                call("tg_gru_backward_cluster", at(dy, c0, T * 2 * H), at(dy_mask, c0, T * 2 * H), at(ys, c0, T * 2 * H), at(ss, c0, T * 4 * H), B * T * 4 * H,
+                     _p(w_hh_t[0]), _p(w_hh_t[1]), at(dgi, c0, T * 3 * H), at(dgh, c0, T * 3 * H), nb * T * 3 * H, C.c_void_p(ws.data_ptr()), ws.numel() * 4,
+                     cn, T, H, _stream())
+            else:
+                call("tg_gru_backward_cluster_stats", at(dy, c0, T * 2 * H), at(dy_mask, c0, T * 2 * H), at(ys, c0, T * 2 * H), at(ss, c0, T * 4 * H),
+                     B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]), at(dgi, c0, T * 3 * H), at(dgh, c0, T * 3 * H), nb * T * 3 * H,
+                     C.c_void_p(ws.data_ptr()), ws.numel() * 4, cn, T, H, at(stats[0], c0, T), nb * T, _p(stats[1]), _p(stats[2]), _stream())
+        return stats is not None
     assert dy_mask is None, "fused dropout backward: H = 64 or the cluster kernels only"
     call("tg_gru_backward", _p(dy), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),
          _p(dgi), _p(dgh), nb * T * 3 * H, _p(dh_scratch), nb, T, H, _stream())

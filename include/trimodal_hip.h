@@ -182,6 +182,11 @@ int tg_split3_planes(const float* x, int64_t ldx, int32_t rows, int32_t cw, void
  * power of two that puts row r's largest magnitude into [2^14, 2^15); inv_scale[r] = 1 / s_r for r < rows, 0 for the zero row (rows + 1 floats).
  * Weights of nn.GRU / weight-normed nn.Conv1d as the matrix cores' fp16 operand (multimodal_context_net.py:98-99, model/tcn.py:19-25). */
 int tg_split2h_planes(const float* x, int64_t ldx, int32_t rows, int32_t cw, void* planes, int32_t cwp, int64_t plane_stride, float* inv_scale, void* stream);
+/* The same planes for the K-CONCATENATED TRANSPOSE of two [rows][cols] matrices: plane row n < cols, column k < 2 rows holds w{k / rows}[k % rows][n]
+ * (cwp >= 2 rows; inv_scale: cols + 1 floats) -- the weight operand of the GRU layer's input gradient dx = [dgi_fwd | dgi_rev] @ [W_ih_fwd ; W_ih_rev]
+ * as one product over K = 6H, straight from the two weight_ih parameters (nn.GRU backward, model/multimodal_context_net.py:98-99). */
+int tg_split2h_planes_tcat(const float* w0, const float* w1, int32_t rows, int32_t cols, void* planes, int32_t cwp, int64_t plane_stride, float* inv_scale,
+                           void* stream);
 /* rowmax[b * A->rows_in + r] = max_c |A->ptr[b * batch_stride + r * row_stride + c]|, c < A->cw, for b < batches, r < A->rows_in: the largest magnitude
  * of every SOURCE row of a window operand (one pass over the tensor; several windows over one tensor share it). */
 int tg_win_row_absmax(const tg_window* A, int32_t batches, float* rowmax, void* stream);
@@ -299,6 +304,15 @@ int64_t tg_gru_cluster_bwd_ws_bytes(int32_t B, int32_t H);
 int tg_gru_backward_cluster(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
                             const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
                             void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream);
+/* The same launch, also leaving the magnitudes of what it wrote for the fp16 x 2 products that read dgi / dgh next (ABI 7; all three or none, zeroed
+ * by the caller, raised by atomic unsigned max, so row chunks of one pass accumulate): gi_rowmax[dir * rowmax_dir_stride + b * T + t] = largest |dgi|
+ * of that row (a_rowmax of the input-gradient product dx = dgi @ W_ih), gi_colmax / gh_colmax[dir * 3H + c] = largest |dgi| / |dgh| of column c
+ * (y_colmax of the weight-gradient products).  Replaces nothing in the reference beyond tg_gru_backward_cluster's nn.GRU backward
+ * (model/multimodal_context_net.py:98-99). */
+int tg_gru_backward_cluster_stats(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
+                                  const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
+                                  void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, float* gi_rowmax, int64_t rowmax_dir_stride,
+                                  float* gi_colmax, float* gh_colmax, void* stream);
 
 /* ---- BatchNorm1d, channel-last [rows][C] (model/multimodal_context_net.py:14,17,20,215,218) -------------
  * Training statistics per group: the rows are split into `groups` equal consecutive slabs, each normalised with

@@ -119,7 +119,7 @@ def test_batch_256_iteration_runs_on_chunked_cluster_recurrences(pkg, dev):
     finally:
         pkg.ops.call = orig
     pkg.ops.check_async_errors()
-    assert names.count("tg_gru_forward_cluster_rows") == 2 * 4 and names.count("tg_gru_backward_cluster") == 2 * 4      # two row chunks per layer
+    assert names.count("tg_gru_forward_cluster_rows") == 2 * 4 and sum(names.count(n_) for n_ in ("tg_gru_backward_cluster", "tg_gru_backward_cluster_stats")) == 2 * 4      # two row chunks per layer
     assert "tg_gru_forward" not in names and "tg_gru_backward" not in names
     assert sorted(ret) == sorted(oret)
     for k in oret:

@@ -1068,10 +1068,10 @@ def test_gemm_tn_split_bf16x3_path_is_fp32_accurate(pkg, dev, M, N, K):
 def operand_format(request, pkg):
     """Both operand formats of the mover-wave products: 'h2' = fp16 x 2 (the default: three matrix instructions per product, per-row /
     per-column power-of-two scales), 'x3' = bf16 x 3 (six; TG_GEMM_H2=0)."""
-    prev = pkg.ops.GEMM_H2
-    pkg.ops.GEMM_H2 = request.param == "h2"
+    prev = pkg.ops.GEMM_H2, pkg.ops.TN_AUTO_COLMAX
+    pkg.ops.GEMM_H2 = pkg.ops.TN_AUTO_COLMAX = request.param == "h2"          # (weight gradients: column magnitudes measured by a pass of their own)
     yield request.param
-    pkg.ops.GEMM_H2 = prev
+    pkg.ops.GEMM_H2, pkg.ops.TN_AUTO_COLMAX = prev
 
 
 def test_gemm_tn_mover_wave_kernel(pkg, dev, operand_format):

@@ -34,7 +34,7 @@ def main():
     hp = torch.randn(M, H, generator=g).to(dev)
     res = {}
     for fmt in ("x3", "h2", "h2pre"):
-        ops.GEMM_H2 = fmt != "x3"
+        ops.GEMM_H2 = ops.TN_AUTO_COLMAX = fmt != "x3"
         probs, refs = [], []
         for d in range(2):
             for A, Kc in ((x, 2 * H), (hp, H)):
