@@ -28,7 +28,7 @@ class NtProblem(C.Structure):
                 ("c_batch_stride", I64), ("c_row_stride", I64), ("c_rows_out", I32), ("M", I32), ("N", I32), ("act_slope", F32),
                 ("accumulate", I32), ("out_scale", P), ("b_planes", P), ("b_plane_stride", I64), ("b_rows", I32), ("b_row0", I32),
                 ("gate", P), ("res", P), ("C2", P), ("res_slope", F32), ("drop_site", U32), ("drop_state", P), ("drop_index0", I64),
-                ("drop_p", F32), ("reserved4", I32), ("b_planes_kind", I32), ("reserved5", I32), ("b_inv_scale", P), ("a_row_scale", P), ("a_rowmax", P), ("c_rowmax", P), ("c2_rowmax", P)]
+                ("drop_p", F32), ("reserved4", I32), ("b_planes_kind", I32), ("reserved5", I32), ("b_inv_scale", P), ("a_row_scale", P), ("a_rowmax", P), ("c_rowmax", P), ("c2_rowmax", P), ("a_rowmax_rows", I32), ("reserved6", I32)]
 
 
 class TnProblem(C.Structure):

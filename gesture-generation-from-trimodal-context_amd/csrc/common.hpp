@@ -104,6 +104,7 @@ struct NtProb {
     // ... or (a_rmax != nullptr, windows of at most two taps) the largest magnitude of every SOURCE row, index batch * rows_in + source row, written by
     // the activation's producer (non-negative floats; combined with atomic unsigned max): the kernel derives the product rows' scales itself
     const float* a_rmax;
+    int a_rmax_div;          // source rows per a_rmax entry: entry (batch * rows_in + source row) / a_rmax_div (1: per row; T: one per clip of T rows)
     const float* b_inv;
     int h2;
     // optional outputs for the NEXT product's a_rmax: c_rmax[m] / c2_rmax[m] = max(old, largest magnitude of row m of C / C2) by atomic unsigned
@@ -291,19 +292,22 @@ __device__ __forceinline__ void h2_write_row(const float* __restrict__ x, long l
 
 // fp16 x 2 planes of the K-CONCATENATED TRANSPOSE of two matrices: out row n (n < cols), column k (k < 2 rows) = w{k / rows}[k % rows][n], w0 / w1
 // [rows][cols] fp32 contiguous -- the weight operand of dx = [dgi_fwd | dgi_rev] @ [W_ih_fwd ; W_ih_rev] (one product over K = 6H) straight from
-// the two nn.GRU parameters.  One 256-thread workgroup per 32 output rows: thread (n_l = t % 32, kg = t / 32); every global read is 32 consecutive
-// floats of one source row.  `wg` of `nwg` workgroups walk the row blocks; planes as h2_write_row writes them (zero row `cols` included).
+// the two nn.GRU parameters.  One 256-thread workgroup per 8 output rows: thread (n_l = t % 8, kg = t / 8): a read instruction fetches 32-byte
+// pieces of eight source rows, and a thread walks only 2 rows / 32 columns per pass (round 6, first form: 32 rows per workgroup -- 19 workgroups
+// per matrix, 225 dependent-latency loads per thread: 100 us for three layers).  `wg` of `nwg` workgroups walk the row blocks; planes as
+// h2_write_row writes them (zero row `cols` included).
+constexpr int H2_TCAT_ROWS = 8;
 __device__ __forceinline__ void h2_planes_tcat_block(const float* __restrict__ w0, const float* __restrict__ w1, int rows, int cols, int cwp,
                                                      _Float16* __restrict__ planes, long plane_stride, float* __restrict__ inv, int wg, int nwg,
-                                                     unsigned (&smax)[8][32]) {
-    const int t = threadIdx.x, n_l = t & 31, kg = t >> 5;
+                                                     unsigned (&smax)[32][H2_TCAT_ROWS]) {
+    const int t = threadIdx.x, n_l = t & 7, kg = t >> 3;
     const int K = 2 * rows;
-    for (int n0 = wg * 32; n0 <= cols; n0 += nwg * 32) {
+    for (int n0 = wg * H2_TCAT_ROWS; n0 <= cols; n0 += nwg * H2_TCAT_ROWS) {
         const int n = n0 + n_l;
         const bool live = n < cols;
         unsigned mx = 0u;
         if (live)
-            for (int k = kg; k < K; k += 8) {
+            for (int k = kg; k < K; k += 32) {
                 const float v = (k < rows ? w0 : w1)[(long)(k < rows ? k : k - rows) * cols + n];
                 const unsigned b = __float_as_uint(v) & 0x7fffffffu;
                 mx = mx > b ? mx : b;
@@ -311,13 +315,13 @@ __device__ __forceinline__ void h2_planes_tcat_block(const float* __restrict__ w
         smax[kg][n_l] = mx;
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const unsigned b = smax[q][n_l]; mx = mx > b ? mx : b; }
+        for (int q = 0; q < 32; ++q) { const unsigned b = smax[q][n_l]; mx = mx > b ? mx : b; }
         __syncthreads();
         const int e = h2_exp_of_bits(mx);
         const float sc = h2_scale_of_exp(e);
         if (kg == 0 && n <= cols) inv[n] = live ? h2_inv_of_exp(e) : 0.f;
         if (n <= cols)
-            for (int p8 = kg; p8 < cwp / 8; p8 += 8) {
+            for (int p8 = kg; p8 < cwp / 8; p8 += 32) {
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {

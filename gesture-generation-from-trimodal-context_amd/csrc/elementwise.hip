@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void permute3_batch_kernel(const long* __restr
         const int rows = d[0], cols = d[1], cwp = d[2];
         const long plane = (long)(cols + 1) * cwp;
         _Float16* const planes = reinterpret_cast<_Float16*>(out);
-        __shared__ unsigned smax[8][32];
+        __shared__ unsigned smax[32][H2_TCAT_ROWS];
         h2_planes_tcat_block(in, reinterpret_cast<const float*>(e[6]), rows, cols, cwp, planes, plane, reinterpret_cast<float*>(planes + 2 * plane),
                              (int)((long)blockIdx.x - wg0), (int)nwg, smax);
         return;

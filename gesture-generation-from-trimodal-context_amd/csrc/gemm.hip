@@ -798,7 +798,7 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
     p.M = q.M; p.N = q.N; p.slope = q.act_slope; p.accumulate = q.accumulate; p.n_nt = 0;
     p.a_bytes = p.b_bytes = 0;
     p.Bpl = nullptr; p.bpl_plane = 0; p.b_slab_rows = 0; p.b_row0 = 0;
-    p.h2 = 0; p.a_scale = nullptr; p.a_rmax = nullptr; p.b_inv = nullptr;
+    p.h2 = 0; p.a_scale = nullptr; p.a_rmax = nullptr; p.b_inv = nullptr; p.a_rmax_div = 1;
     p.c_rmax = q.c_rowmax; p.c2_rmax = q.c2_rowmax;
     TG_REQUIRE(!q.c2_rowmax || q.C2, "tg_gemm_nt: c2_rowmax without C2 (problem %d)", idx);
     if (q.b_planes) {
@@ -814,7 +814,8 @@ static int nt_fill(NtProb& p, const tg_gemm_nt_problem& q, int idx) {
                        "tg_gemm_nt: fp16 x 2 weight planes (problem %d) need b_inv_scale (16-byte aligned), exactly one of a_row_scale / a_rowmax and b_row0 %% 4 == 0", idx);
             TG_REQUIRE(!q.a_rowmax || q.A.K <= 2 * q.A.cw, "tg_gemm_nt: a_rowmax serves windows of at most two taps (problem %d: %d); pass a_row_scale (tg_h2_row_scales)",
                        idx, q.A.K / q.A.cw);
-            p.h2 = 1; p.a_scale = q.a_row_scale; p.a_rmax = q.a_rowmax; p.b_inv = q.b_inv_scale;
+            TG_REQUIRE(q.a_rowmax_rows >= 0 && (int64_t)cdiv(q.M, q.A.rows_out) * q.A.rows_in < (1LL << 31), "tg_gemm_nt: bad a_rowmax_rows=%d (problem %d)", q.a_rowmax_rows, idx);
+            p.h2 = 1; p.a_scale = q.a_row_scale; p.a_rmax = q.a_rowmax; p.b_inv = q.b_inv_scale; p.a_rmax_div = q.a_rowmax_rows > 0 ? q.a_rowmax_rows : 1;
         } else TG_REQUIRE(q.b_planes_kind == 0, "tg_gemm_nt: b_planes_kind=%d (problem %d): 0 (bf16 x 3) or 1 (fp16 x 2)", q.b_planes_kind, idx);
     }
     TG_REQUIRE((q.res == nullptr) == (q.C2 == nullptr), "tg_gemm_nt: res and C2 go together (problem %d)", idx);

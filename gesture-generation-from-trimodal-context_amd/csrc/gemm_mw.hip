@@ -178,6 +178,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
             const float* __restrict__ a_scale = pr.a_scale;
             const float* __restrict__ a_rmax = pr.a_rmax;      // fp16 x 2, second form: magnitudes of the SOURCE rows (one or two taps): the scale is derived here
             const int two_taps = A.K > A.cw;
+            const int rm_div = pr.a_rmax_div;                  // source rows per a_rmax entry (1: one entry per row; T: one per clip of T rows)
             const int M_a = pr.M;
 #pragma unroll
             for (int q = 0; q < NPA; ++q) {
@@ -189,11 +190,12 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                 a_r[q] = (mm - b * A.rows_out) * A.step + A.shift;
                 if constexpr (NS == 2) {
                     // (branch-free: two loads from always-valid addresses, then selects)
-                    const float* __restrict__ rm = a_rmax ? a_rmax + (long)b * A.rows_in : a_scale;
+                    const float* __restrict__ rm = a_rmax ? a_rmax : a_scale;
                     const int s0 = a_r[q], s1 = s0 + A.dil;
                     const bool ok0 = (unsigned)s0 < (unsigned)A.rows_in, ok1 = two_taps && (unsigned)s1 < (unsigned)A.rows_in;
-                    const unsigned v0 = __float_as_uint(rm[a_rmax ? (ok0 ? s0 : 0) : mm]);
-                    const unsigned v1 = __float_as_uint(rm[a_rmax ? (ok1 ? s1 : 0) : mm]);
+                    const int base = b * A.rows_in;
+                    const unsigned v0 = __float_as_uint(rm[a_rmax ? (base + (ok0 ? s0 : 0)) / rm_div : mm]);
+                    const unsigned v1 = __float_as_uint(rm[a_rmax ? (base + (ok1 ? s1 : 0)) / rm_div : mm]);
                     const unsigned vm = (ok0 ? v0 : 0u) > (ok1 ? v1 : 0u) ? (ok0 ? v0 : 0u) : (ok1 ? v1 : 0u);
                     a_s[q] = a_rmax ? h2_scale_of_exp(h2_exp_of_bits(vm)) : __uint_as_float(v0);
                 }
@@ -487,9 +489,10 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_mw_kernel(const NtGroup g) {
                     if (pr.a_rmax) {
                         const int ab = rr / pr.A.rows_out;
                         const int s0 = (rr - ab * pr.A.rows_out) * pr.A.step + pr.A.shift, s1 = s0 + pr.A.dil;
-                        const float* __restrict__ rm = pr.a_rmax + (long)ab * pr.A.rows_in;
-                        const unsigned v0 = (unsigned)s0 < (unsigned)pr.A.rows_in ? __float_as_uint(rm[s0]) : 0u;
-                        const unsigned v1 = (pr.A.K > pr.A.cw && (unsigned)s1 < (unsigned)pr.A.rows_in) ? __float_as_uint(rm[s1]) : 0u;
+                        const float* __restrict__ rm = pr.a_rmax;
+                        const int base = ab * pr.A.rows_in, dv = pr.a_rmax_div;
+                        const unsigned v0 = (unsigned)s0 < (unsigned)pr.A.rows_in ? __float_as_uint(rm[(base + s0) / dv]) : 0u;
+                        const unsigned v1 = (pr.A.K > pr.A.cw && (unsigned)s1 < (unsigned)pr.A.rows_in) ? __float_as_uint(rm[(base + s1) / dv]) : 0u;
                         inv_a[i] = h2_inv_of_exp(h2_exp_of_bits(v0 > v1 ? v0 : v1));
                     } else inv_a[i] = h2_inv_of_scale(pr.a_scale[rr]);
                 }

@@ -472,8 +472,10 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     void* gx, unsigned* flags, unsigned* tmo, int B, int T, int H, int n_bt, int CW, int b_pad,
     float* __restrict__ gi_rmax, long rm_ds, float* __restrict__ gi_cmax, float* __restrict__ gh_cmax) {
     // gi_rmax / gi_cmax / gh_cmax (all or none; zeroed by the caller): magnitudes of what this launch writes, for the fp16 x 2 products that read it --
-    // gi_rmax[dir * rm_ds + row * T + t] = largest |dgi| of that row (the input-gradient product's row scales), gi_cmax / gh_cmax[dir * 3H + c] =
-    // largest |dgi| / |dgh| of column c (the weight-gradient products' column scales); raised by atomic unsigned max behind the step's hand-off
+    // gi_rmax[dir * rm_ds + row] = largest |dgi| of batch row `row` over ALL its T steps (the input-gradient product scales a clip's rows by one power
+    // of two), gi_cmax / gh_cmax[dir * 3H + c] = largest |dgi| / |dgh| of column c (the weight-gradient products' column scales).  Running maxima
+    // in registers, behind each step's hand-off; atomic unsigned max ONCE, when the kernel leaves (a per-step atomic stayed in the memory queue
+    // for ~0.8 us and the next step's drain before its flag waited for it: +27 us per launch, profiles/r6_m_timeline.txt)
     __shared__ __attribute__((aligned(16))) f32x4 red[XC_KSB][2][64];
     __shared__ __attribute__((aligned(16))) bf16x8 wlo[8][2 * XC_SPB8][64];
     __shared__ int same_xcd_s;
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     const unsigned sv_v = e_ok ? (unsigned)((row * T * 4 * H + unit0) * 4) : OOB;           // + (tau * 4H + j * H) * 4
     const unsigned dg_v = e_ok ? (unsigned)((row * T * H3 + unit0) * 4) : OOB;              // + (tau * 3H + g * H) * 4
     f32x4 dy = zero, dm = zero, r = zero, z = zero, n = zero, hn = zero, hp = zero;         // operands of the NEXT step's cell
+    unsigned rmx = 0u;                                 // running maximum of this thread's dgi values over all steps (its batch row)
     unsigned cmx[4][4];                                // running column maxima of this thread's four units: gates r, z, n (dgi) and n * r (dgh's third)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -660,7 +663,6 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
             __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(g_nr), gh_rsrc, dg_v, go + 2 * H * 4, 0);
             prefetch(step + 1);
             if (gi_rmax && e_ok) {                     // (behind the hand-off and the next step's requests: off the dependent chain)
-                unsigned rm = 0u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const unsigned br = __float_as_uint(g_r[q]) & 0x7fffffffu, bz = __float_as_uint(g_z[q]) & 0x7fffffffu;
@@ -670,14 +672,20 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
                     cmx[2][q] = cmx[2][q] > bn ? cmx[2][q] : bn;
                     cmx[3][q] = cmx[3][q] > bnr ? cmx[3][q] : bnr;
                     const unsigned t3 = br > bz ? (br > bn ? br : bn) : (bz > bn ? bz : bn);
-                    rm = rm > t3 ? rm : t3;
+                    rmx = rmx > t3 ? rmx : t3;
                 }
-                atomicMax(reinterpret_cast<unsigned*>(gi_rmax) + dir * rm_ds + (long)row * T + tau, rm);
             }
         }
     }
     if (m == 0 && threadIdx.x == 0 && T >= 2) __hip_atomic_store(cl_flags + XC_GEN_WORD, gen + (unsigned)(T + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gi_rmax && epi_wave) {
+        // the batch row's maximum: over the eight threads of the row (consecutive lanes), one atomic per row and member
+        {
+            unsigned v = rmx;
+#pragma unroll
+            for (int o = 1; o <= 4; o <<= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = v > w ? v : w; }
+            if ((lane & 7) == 0 && epi && row < B) atomicMax(reinterpret_cast<unsigned*>(gi_rmax) + dir * rm_ds + row, v);
+        }
         // column maxima: over the wave's eight rows (lanes 8 apart hold the same units), then one atomic per column and wave
 #pragma unroll
         for (int g = 0; g < 4; ++g)

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void split2h_planes_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void split2h_planes_tcat_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int rows, int cols, int cwp,
                                                                   _Float16* __restrict__ planes, long plane_stride, float* __restrict__ inv) {
-    __shared__ unsigned smax[8][32];
+    __shared__ unsigned smax[32][H2_TCAT_ROWS];
     h2_planes_tcat_block(w0, w1, rows, cols, cwp, planes, plane_stride, inv, blockIdx.x, gridDim.x, smax);
 }
 
@@ -201,7 +201,7 @@ extern "C" int tg_split2h_planes_tcat(const float* w0, const float* w1, int32_t 
     TG_REQUIRE(w0 && w1 && planes && inv && rows > 0 && cols > 0, "tg_split2h_planes_tcat: bad arguments");
     TG_REQUIRE(cwp >= 2 * rows && cwp % 32 == 0 && plane_stride >= (int64_t)(cols + 1) * cwp && plane_stride % 8 == 0 && aligned16(planes),
                "tg_split2h_planes_tcat: cwp=%d must be a multiple of 32 >= 2 rows = %d, plane_stride >= (cols + 1) * cwp and a multiple of 8, planes 16-byte aligned", cwp, 2 * rows);
-    hipLaunchKernelGGL(split2h_planes_tcat_kernel, dim3(cdiv(cols + 1, 32)), dim3(256), 0, (hipStream_t)stream, w0, w1, rows, cols, cwp,
+    hipLaunchKernelGGL(split2h_planes_tcat_kernel, dim3(cdiv(cols + 1, H2_TCAT_ROWS)), dim3(256), 0, (hipStream_t)stream, w0, w1, rows, cols, cwp,
                        reinterpret_cast<_Float16*>(planes), (long)plane_stride, inv);
     return check_launch("tg_split2h_planes_tcat");
 }

@@ -74,8 +74,8 @@ class WeightPrep:
                     rows.append([s3.data_ptr(), d.data_ptr(), s3.shape[1], s3.shape[2], d.shape[2], 8, 0, 0, wg0, nwg])
                     wg0 += nwg
                     continue
-                if pm[0] == 11:                                       # fp16 x 2 planes of [src^T | other^T] (pm[1] = the other matrix): 32 output rows per workgroup
-                    nwg = (s3.shape[2] + 32) // 32
+                if pm[0] == 11:                                       # fp16 x 2 planes of [src^T | other^T] (pm[1] = the other matrix): 8 output rows per workgroup
+                    nwg = (s3.shape[2] + 8) // 8
                     rows.append([s3.data_ptr(), d.data_ptr(), s3.shape[1], s3.shape[2], ops.planes_cwp(2 * s3.shape[1]), 11, pm[1], 0, wg0, nwg])
                     wg0 += nwg
                     continue
@@ -637,10 +637,10 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
             side_pending = None
     # fp16 x 2 operands for the products that read dgi / dgh: the cluster recurrence leaves the magnitudes of dgi's rows and of dgi's / dgh's columns
     # behind its hand-offs (tg_gru_backward_cluster_stats), so neither the input-gradient product nor the weight gradients need a pass over them.
-    # One zeroed block for all layers: [layer][gi_rowmax 2 nb T | gi_colmax 2 x 3H | gh_colmax 2 x 3H]
+    # One zeroed block for all layers: [layer][gi_clipmax 2 nb | gi_colmax 2 x 3H | gh_colmax 2 x 3H]
     want_stats = (ops.gemm_h2() and ops.GRU_CLUSTER and H > 64 and H % 4 == 0 and nb * T >= 2048
                   and ops.gru_cluster_chunks(nb, H, bwd=True) is not None)
-    n_rm = (2 * nb * T + 3) // 4 * 4
+    n_rm = (2 * nb + 3) // 4 * 4
     stats_all = ops.zeros(n_layers, n_rm + 12 * H, device=dy.device) if want_stats else None
     for l in range(n_layers - 1, -1, -1):
         # The side rows are enqueued BEFORE the recurrence they run beside.  (Round 5, profiles/r5_z_tn_side_rows.txt: captured the other way
@@ -658,7 +658,7 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
         stats = None
         if stats_all is not None:
             st = stats_all[l]
-            stats = (st[:2 * nb * T].view(2, nb * T), st[n_rm:n_rm + 6 * H].view(2, 3 * H), st[n_rm + 6 * H:].view(2, 3 * H))
+            stats = (st[:2 * nb].view(2, nb), st[n_rm:n_rm + 6 * H].view(2, 3 * H), st[n_rm + 6 * H:].view(2, 3 * H))
         if not ops.gru_backward(dy.contiguous(), tape.y[l], tape.save[l], wt, dgi, dgh, dh, b0=b0, nb=nb, dy_mask=dy_mask, stats=stats):
             stats = None
         x_l = tape.x[l][rows]
@@ -735,7 +735,7 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
                 # the weight operand is the K-concatenated transpose of both directions' W_ih as pre-split planes (WeightPrep job 11)
                 h2kw = {}
                 if stats is not None and Kin >= 150 and Kin % 4 == 0:
-                    h2kw = dict(w_planes=weight_planes_tcat(P[f"{prefix}.weight_ih_l{l}"], P[f"{prefix}.weight_ih_l{l}_reverse"]), a_rowmax=stats[0].view(-1))
+                    h2kw = dict(w_planes=weight_planes_tcat(P[f"{prefix}.weight_ih_l{l}"], P[f"{prefix}.weight_ih_l{l}_reverse"]), a_rowmax=stats[0].view(-1), a_rowmax_rows=T)
                 if below is not None and not ops.gru_fused_dropout(nb, H, bwd=True):
                     ops.gemm_nt(a_cat, wt_ih[0], None, dx, b_seg=(3 * H, seg), out_scale=below[rows].reshape(nb * T, Kin), **h2kw)
                     scaled = True

@@ -126,7 +126,7 @@ class Drop:
 
 
 def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batch_stride=None, c_row_stride=None, c_rows_out=None, M=None,
-                b_seg=None, out_scale=None, gate=None, res=None, out2=None, res_slope=0.0, w_planes=None, w_row0=0, a_row_scale=None, a_rowmax=None, out_rowmax=None, out2_rowmax=None):
+                b_seg=None, out_scale=None, gate=None, res=None, out2=None, res_slope=0.0, w_planes=None, w_row0=0, a_row_scale=None, a_rowmax=None, out_rowmax=None, out2_rowmax=None, a_rowmax_rows=1):
     """Checked tg_gemm_nt_problem.  b_seg = (seg_k, seg_stride_floats): K-concatenated weights, W is the first [N, seg_k] segment and
     segment s starts seg_stride_floats * s floats after it (the caller keeps every segment alive).
     Epilogue extensions (big-product path only, nt_ext_supported): gate -- keep the result where gate > 0, zero elsewhere; res + out2 --
@@ -161,8 +161,9 @@ def _nt_problem(A: Win, W, bias, out, *, act_slope=1.0, accumulate=False, c_batc
             assert w_row0 % 4 == 0, w_row0
             q.b_planes_kind, q.b_inv_scale = 1, w_planes.inv.data_ptr()
             if a_rowmax is not None:           # the source rows' magnitudes (their producer's out_rowmax, win_row_absmax, const_rowmax): one or two taps
-                _f32(a_rowmax, "a_rowmax"); assert a_rowmax.numel() >= A.batches * A.s.rows_in and a_rowmax.is_contiguous() and A.K <= 2 * A.s.cw
-                q.a_rowmax = a_rowmax.data_ptr()
+                _f32(a_rowmax, "a_rowmax"); assert a_rowmax_rows >= 1 and a_rowmax.is_contiguous() and A.K <= 2 * A.s.cw
+                assert a_rowmax.numel() * a_rowmax_rows >= A.batches * A.s.rows_in, (a_rowmax.numel(), a_rowmax_rows, A.batches, A.s.rows_in)
+                q.a_rowmax, q.a_rowmax_rows = a_rowmax.data_ptr(), int(a_rowmax_rows)
             else:
                 if a_row_scale is None:
                     a_row_scale = h2_row_scales(A, M)
@@ -761,8 +762,8 @@ def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None, dy
     """Backward through time for batch rows [b0, b0+nb) of a (possibly larger) stacked forward.
     dy: [nb, T, 2H]; y: [B, T, 2H]; save: [2, B, T, 4H]; w_hh_t: (fwd, rev) each [H, 3H]; dgi/dgh: [2, nb, T, 3H].
     dy_mask ([nb, T, 2H], H = 64 only): multiplied into dy while it is loaded (fused dropout backward).
-    stats (cluster kernels only; returns True when they were filled): (gi_rowmax [2, nb * T], gi_colmax [2, 3H], gh_colmax [2, 3H]), ZEROED by the
-    caller -- the magnitudes of dgi's rows and of dgi's / dgh's columns that the fp16 x 2 products reading them scale by."""
+    stats (cluster kernels only; returns True when they were filled): (gi_clipmax [2, nb], gi_colmax [2, 3H], gh_colmax [2, 3H]), ZEROED by the
+    caller -- the magnitudes of dgi per batch row (over all T steps) and of dgi's / dgh's columns that the fp16 x 2 products reading them scale by."""
     _flat(dy, "dy"); _flat(y, "y"); _flat(save, "save"); _flat(dgi, "dgi"); _flat(dgh, "dgh"); _flat(dh_scratch, "dh")
     B, T, H2 = y.shape
     H = H2 // 2
@@ -788,7 +789,7 @@ def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None, dy
         if stats is not None:
             rm, ci, ch = stats
             _flat(rm, "gi_rowmax"); _flat(ci, "gi_colmax"); _flat(ch, "gh_colmax")
-            assert tuple(rm.shape) == (2, nb * T) and tuple(ci.shape) == (2, 3 * H) == tuple(ch.shape)
+            assert tuple(rm.shape) == (2, nb) and tuple(ci.shape) == (2, 3 * H) == tuple(ch.shape)
         for c0, cn in chunks:                                    # (row chunks of one workspace, as in gru_forward)
             if stats is None:
                 call("tg_gru_backward_cluster", at(dy, c0, T * 2 * H), at(dy_mask, c0, T * 2 * H), at(ys, c0, T * 2 * H), at(ss, c0, T * 4 * H), B * T * 4 * H,
@@ -797,7 +798,7 @@ def gru_backward(dy, y, save, w_hh_t, dgi, dgh, dh_scratch, *, b0=0, nb=None, dy
             else:
                 call("tg_gru_backward_cluster_stats", at(dy, c0, T * 2 * H), at(dy_mask, c0, T * 2 * H), at(ys, c0, T * 2 * H), at(ss, c0, T * 4 * H),
                      B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]), at(dgi, c0, T * 3 * H), at(dgh, c0, T * 3 * H), nb * T * 3 * H,
-                     C.c_void_p(ws.data_ptr()), ws.numel() * 4, cn, T, H, at(stats[0], c0, T), nb * T, _p(stats[1]), _p(stats[2]), _stream())
+                     C.c_void_p(ws.data_ptr()), ws.numel() * 4, cn, T, H, at(stats[0], c0, 1), nb, _p(stats[1]), _p(stats[2]), _stream())
         return stats is not None
     assert dy_mask is None, "fused dropout backward: H = 64 or the cluster kernels only"
     call("tg_gru_backward", _p(dy), _p(ys), C.c_void_p(ss.data_ptr()), B * T * 4 * H, _p(w_hh_t[0]), _p(w_hh_t[1]),

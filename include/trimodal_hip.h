@@ -151,6 +151,9 @@ typedef struct tg_gemm_nt_problem {
     const float* a_rowmax;
     float* c_rowmax;
     float* c2_rowmax;
+    int32_t a_rowmax_rows;     /* 0 / 1: a_rowmax has one entry per source row; n > 1: one entry per n consecutive source rows (entry (batch * rows_in +
+                                  source row) / n) -- e.g. one per clip of T frames, as tg_gru_backward_cluster_stats leaves them */
+    int32_t reserved6;
 } tg_gemm_nt_problem;
 /* tg_gemm_nt_group: up to 8 independent tg_gemm_nt products in ONE launch (both GRU directions' input projections, the stride
  * phases of a conv input-gradient ...).  All problems must fall into the same kernel family as problem 0 (big / narrow / small);
@@ -305,8 +308,9 @@ int tg_gru_backward_cluster(const float* dy, const float* dy_mask, const float* 
                             const float* w_hh_t_fwd, const float* w_hh_t_rev, float* dgi, float* dgh, int64_t dg_dir_stride,
                             void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream);
 /* The same launch, also leaving the magnitudes of what it wrote for the fp16 x 2 products that read dgi / dgh next (ABI 7; all three or none, zeroed
- * by the caller, raised by atomic unsigned max, so row chunks of one pass accumulate): gi_rowmax[dir * rowmax_dir_stride + b * T + t] = largest |dgi|
- * of that row (a_rowmax of the input-gradient product dx = dgi @ W_ih), gi_colmax / gh_colmax[dir * 3H + c] = largest |dgi| / |dgh| of column c
+ * by the caller, raised by atomic unsigned max when the kernel leaves, so row chunks of one pass accumulate): gi_rowmax[dir * rowmax_dir_stride + b] =
+ * largest |dgi| of batch row b over its T steps (a_rowmax of the input-gradient product dx = dgi @ W_ih with a_rowmax_rows = T: one scale per
+ * clip), gi_colmax / gh_colmax[dir * 3H + c] = largest |dgi| / |dgh| of column c
  * (y_colmax of the weight-gradient products).  Replaces nothing in the reference beyond tg_gru_backward_cluster's nn.GRU backward
  * (model/multimodal_context_net.py:98-99). */
 int tg_gru_backward_cluster_stats(const float* dy, const float* dy_mask, const float* y, const float* save, int64_t save_dir_stride,
