@@ -695,7 +695,7 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
                 with ops.tn_workgroup_cap(free_cus):
                     if ops.tn_kernel_plan(layer_probs(nb - nb_side, nb)) == 2:
                         split = nb_side
-            fk.keep(dgi, dgh, x_l, y_l)
+            fk.keep(dgi, dgh, x_l, y_l, stats_all, x_cmax, h_cmax)     # (the side stream reads them after this function's references are gone)
             with fk:
                 probs = layer_probs(0, nb - split)
                 if defer is not None:
@@ -703,7 +703,7 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
                 else:
                     ops.gemm_tn_group(probs)             # one launch
             if split:
-                side_pending = (layer_probs(nb - split, nb), (dgi, dgh, x_l, y_l))
+                side_pending = (layer_probs(nb - split, nb), (dgi, dgh, x_l, y_l, stats_all, x_cmax, h_cmax))
         dx = None
         if need_dx or l > 0:
             dx = empty(nb * T, Kin, like=dy)

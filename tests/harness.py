@@ -173,7 +173,11 @@ def tcn_gate_sides(tape, gate_log, call, B, tag="g2", rel_window=5e-6):
             site = f"{tag}.tcn{i}.relu{k}"
             pre = gate_log[site]                                                   # (B, C, T) fp64
             mine = act[rows].detach().double().cpu().transpose(1, 2)
-            valid = torch.ones_like(pre, dtype=torch.bool) if mask is None else (mask[rows].detach().cpu().transpose(1, 2) > 0)
+            if mask is not None and not isinstance(mask, torch.Tensor):              # ops.Drop: the mask is regenerated, not stored
+                mask = mask[rows].materialize()
+                valid = mask.detach().cpu().transpose(1, 2) > 0
+            else:
+                valid = torch.ones_like(pre, dtype=torch.bool) if mask is None else (mask[rows].detach().cpu().transpose(1, 2) > 0)
             flipped = (valid & ((mine > 0) != (pre > 0))).reshape(-1)
             idx = flipped.nonzero().view(-1)
             if idx.numel():

@@ -417,3 +417,125 @@ def test_deterministic_mode_runs_are_bit_identical(pkg, dev, B):
     print(f"deterministic mode: graph x5 vs graph x5: 0 differing entries; graph x5 vs eager x5: {sum(n_diff_e)} differing entries, worst normalised {worst:.1e}")
     assert worst <= 1e-6, (worst, n_diff_e)
     assert eager_losses == runs[0][0] or all(abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(b[k])) for a, b in zip(eager_losses, runs[0][0]) for k in a)
+
+
+def _device_draws(pkg, tr, B, T=34):
+    """Every random draw of the LAST iteration of `tr` (device RNG, nothing injected), regenerated from the Philox states it left behind -- a
+    draw is a pure function of (state, site, element index): ops.Drop / tg_normal / tg_randperm give the same values again until the next
+    iteration advances the states -- and renamed to the oracle's per-call names (oracle.ref_model.Rand)."""
+    ops = pkg.ops
+    inj = {}
+    for eng, stacked in ((tr.G, {"g": ["g1", "g2", "g3"]}), (tr.D, {"d": ["d_real", "d_fake"], "d_out": ["d_out"]})):
+        st, sites = eng.rng.state, eng.rng._sites
+        dev = st.device
+        for name, site in sites.items():
+            if name == "perm":
+                inj["perm"] = ops.randperm(torch.empty(B, dtype=torch.int64, device=dev), st, site).cpu()
+                continue
+            tag, what = name.split(".", 1)
+            calls = stacked[tag]
+            Bs = B * len(calls)
+            if what == "eps":
+                full = ops.normal(torch.empty(Bs, 16, device=dev), st, site)
+                parts = {"eps": full}
+            elif what == "emb_drop":
+                parts = {"emb_drop": ops.Drop(st, site, 0.1, (Bs, T, 300)).materialize()}
+            elif what == "tcn.drop":
+                full = ops.Drop(st, site, 0.3, (8, Bs, T, 300)).materialize()
+                parts = {f"tcn{j // 2}.drop{j % 2 + 1}": full[j] for j in range(8)}
+            elif what == "gru.drop":                      # the fused form: one draw for the three inter-layer masks
+                Td, C2 = (28, 128) if eng is tr.D else (T, 600)
+                full = ops.Drop(st, site, 0.3, (3, Bs, Td, C2)).materialize()
+                parts = {f"gru.drop{l}": full[l] for l in range(3)}
+            elif what.startswith("gru.drop"):
+                Td, C2 = (28, 128) if eng is tr.D else (T, 600)
+                parts = {what: ops.Drop(st, site, 0.3, (Bs, Td, C2)).materialize()}
+            else:
+                raise AssertionError(f"unknown draw site {name}")
+            for k, v in parts.items():
+                for ci, call in enumerate(calls):
+                    piece = v[ci * B:(ci + 1) * B]
+                    inj[f"{call}.{k}"] = (piece.transpose(1, 2) if k.startswith("tcn") else piece).contiguous().double().cpu()
+    return inj
+
+
+def test_captured_default_step_at_bench_size_matches_fp64_oracle(pkg, dev):
+    """What bench.py times, pinned directly: the hipGraph-captured DEFAULT iteration (GraphedGanStep: three streams, weight-gradient side rows,
+    device RNG, dropout masks regenerated by their consumers, fp16 x 2 products) at B = 128, V = 20 000 words, S = 1 371 speaker rows, epoch 11,
+    ONE replay from a known state -- against the fp64 oracle (train_eval/train_gan.py:13-103 restated) fed with the draws that replay used.
+    The draws are read back from the device: an eager iteration from the same state uses the same Philox states, and every draw is regenerated
+    from them by site (_device_draws); if the replay had drawn anything else its losses would disagree with the oracle's.  Gates: losses 1e-4,
+    every gradient's norm and 64 sampled entries 1e-4, as everywhere."""
+    from importlib import import_module
+    GraphedGanStep = import_module(pkg.__name__ + ".train_gan").GraphedGanStep
+    V, S, B = 20000, 1371, 128
+    gst0, dst0 = O.make_generator_state(20, V, S), O.make_discriminator_state(21)
+    text, audio, vid, poses = O.make_batch(1201, B, V, S)
+    args, G, D = build_models(pkg, dev, gst0, dst0, V, S, make_args())
+    tr = pkg.GanTrainer(G, D, args)
+    assert pkg.ops.get_math_mode() == "f32"
+    td, ad, pd, vd = text.to(dev), audio.to(dev), poses.to(dev), vid.to(dev)
+    snap = tr.snapshot()
+    step = GraphedGanStep(tr, 11, td, ad, pd, vd)                     # warm-up iterations + capture: advances weights, Adam and RNG counters
+    tr.restore(snap)
+    ret = step().to_dict()                                            # ONE replay from the snapshot's state
+    torch.cuda.synchronize()
+    pkg.ops.check_async_errors()
+    g_graph = {k: v.detach().double().cpu() for k, v in tr.G.views()[1].items()}
+    d_graph = {k: v.detach().double().cpu() for k, v in tr.D.views()[1].items()}
+    # the same iteration eagerly, from the same state: same Philox states -> the replay's draws; its tape shows which gates the HIP path took
+    tr.restore(snap)
+    tr.keep_tape = True
+    ret_eager = tr.train_iter(11, td, ad, pd, vd).to_dict()
+    for k in ret:
+        assert abs(ret[k] - ret_eager[k]) <= 1e-5 * max(1.0, abs(ret_eager[k])), (k, ret[k], ret_eager[k])      # (float-atomic order only)
+    inj = _device_draws(pkg, tr, B)
+    assert torch.equal(tr.last_tape["vid"][2 * B:].cpu(), vid[inj["perm"]]), "tg_randperm(site 'perm') is not the permutation the iteration used"
+    keep = [float((inj[f"g{c}.tcn0.drop1"] > 0).double().mean()) for c in (1, 2, 3)]
+    assert all(0.69 < k_ < 0.71 for k_ in keep), keep                 # real masks (p = 0.3), different per call
+    assert not torch.equal(inj["g1.emb_drop"], inj["g2.emb_drop"])
+    og, od = O.clone_state(gst0, torch.float64), O.clone_state(dst0, torch.float64)
+    pre = O.wav_preacts(og, audio.double())
+    before = copy.deepcopy((og, od))
+    O.relu_gate_log = {}
+    try:
+        oret, extra = O.train_iter_gan(og, od, {}, {}, 11, text, audio.double(), poses.double(), vid, O.Rand(inject=inj), dict(O.HP), fast_gru=True,
+                                       want_grads=True)
+    finally:
+        relu_log, O.relu_gate_log = O.relu_gate_log, None
+    fl = wav_gate_flips(tr.last_tape, pre)
+    tcn_sides, tcn_rep = tcn_gate_sides(tr.last_tape, relu_log, 1, B)
+    del relu_log
+    n_fl, n_tcn = sum(f[2] for f in fl), sum(r[1] for r in tcn_rep)
+    if n_fl or n_tcn:
+        # near-tie gates (asserted): the oracle repeats the iteration on the HIP path's side of them, as in the full-size trajectory test above
+        assert (not n_fl or max(f[3] for f in fl) < NEAR_TIE_FRESH) and n_fl + n_tcn <= 8 * MAX_GATE_FLIPS, (fl, tcn_rep)
+        assert all(r[2] < r[3] for r in tcn_rep), tcn_rep
+        og, od = before
+        O.wav_gate_override, O.relu_gate_override = wav_gate_sides(tr.last_tape, pre), tcn_sides
+        try:
+            oret, extra = O.train_iter_gan(og, od, {}, {}, 11, text, audio.double(), poses.double(), vid, O.Rand(inject=inj), dict(O.HP), fast_gru=True,
+                                           want_grads=True)
+        finally:
+            O.wav_gate_override = O.relu_gate_override = None
+    assert sorted(ret) == sorted(oret), (ret, oret)
+    e_loss = max(abs(ret[k] - oret[k]) / max(abs(oret[k]), 1e-6) for k in oret)
+    rows = []
+    for net, mine_all, grads in (("G.", g_graph, extra["g_grads"]), ("D.", d_graph, extra["d_grads"])):
+        for k, r in grads.items():
+            if r is None or k in ZERO_GRAD_KEYS:
+                continue
+            mine = mine_all[k]
+            e_n = abs(float(mine.norm()) - float(r.norm())) / (float(r.norm()) + 1e-30)
+            idx = torch.from_numpy(sample_idx(r.numel(), 64))
+            e_s = float((mine.reshape(-1)[idx] - r.reshape(-1)[idx]).abs().max() / r.abs().max().clamp_min(1e-30))
+            rows.append((net + k, e_n, e_s))
+    wk = max(rows, key=lambda r_: max(r_[1], r_[2]))
+    print(f"captured default replay at B = 128, V = 20 000 vs fp64 oracle on its own draws: loss error {e_loss:.1e}; worst gradient {wk[0]} norm "
+          f"{wk[1]:.1e} sampled {wk[2]:.1e}; near-tie gate flips: audio encoder {n_fl}, text encoder {n_tcn}")
+    assert e_loss <= 1e-4, (ret, oret)
+    bad = [r_ for r_ in rows if r_[1] > 1e-4 or r_[2] > 1e-4]
+    assert not bad, bad
+    eg = g_graph["text_encoder.embedding.weight"].norm(dim=1)
+    oe = extra["g_grads"]["text_encoder.embedding.weight"].double().norm(dim=1)
+    assert int((eg > 0).sum()) == int((oe > 0).sum()) and abs(float(eg[0]) - float(oe[0])) <= 1e-4 * float(oe[0])     # the PAD row's hot gradient, the touched rows
