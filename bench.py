@@ -253,14 +253,15 @@ def cpu_baseline_ae(batch, budget_s=10.0, max_steps=20):
 
 
 def dominant_kernel_roofline(pkg, device, batch):
-    """The single kernel with the largest share of the iteration (profiles/r2_*_by_shape.txt): the persistent cluster-synchronised GRU
-    recurrence of the generator's stacked forward, gru_seq_fwd_cluster_x3_kernel<2> at B = 3*batch, H = 300, T = 34 -- one launch per
+    """The single kernel with the largest share of the iteration (profiles/r6_fin_by_shape.txt): the persistent cluster-synchronised GRU
+    recurrence of the generator's stacked forward, gru_seq_fwd_cluster_x3_kernel<2, NS> at B = 3*batch, H = 300, T = 34 -- one launch per
     layer walks all 34 steps of both directions (csrc/gru_cluster_x3.hip).
     Algorithmic FLOPs per launch: (T-1) steps x 2 directions x B x 3H x H x 2 (the h_{t-1} @ W_hh^T products; gate maths excluded).
-    Peak = the fp32 matrix peak: the kernel computes an fp32-accurate product (each one issued as six bf16 MFMAs on exactly split
-    operands, i.e. 6 x the algorithmic FLOPs on the bf16 pipe).  It is bound by the per-step inter-workgroup hand-off latency, not
-    by MFMA issue or HBM: the fraction says how far.  The timed call is tg_gru_forward_cluster = the flag-zeroing kernel + the
-    persistent kernel on the launch stream (HIP events); rocprofv3's per-kernel average is the persistent kernel alone."""
+    Peak = the fp32 matrix peak: the kernel computes an fp32-accurate product.  Round 6: each product is THREE fp16 MFMAs on two-term split
+    operands (h * 2^14 and per-row scaled W_hh as hi / lo fp16 planes; TG_GRU_H2=0: six bf16 MFMAs on three-term splits), i.e. 3 x the
+    algorithmic FLOPs on the 16-bit matrix pipe: peak_f16x2 = dense fp16 peak / 3 is the ceiling of the arithmetic issued.  The kernel is
+    bound by the per-step inter-workgroup hand-off latency, not by MFMA issue or HBM: the fraction says how far.  The timed call is
+    tg_gru_forward_cluster on the launch stream (HIP events); rocprofv3's per-kernel average is the persistent kernel alone."""
     ops = pkg.ops
     Bs, H = 3 * batch, 300
     gi = torch.randn(2, Bs, T, 3 * H, device=device) * 0.1
@@ -271,24 +272,30 @@ def dominant_kernel_roofline(pkg, device, batch):
     dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, sv, save_rows=(batch, batch)), iters=20)      # as the trainer calls it (gates saved for call g2 only)
     ops.check_async_errors()
     flops = (T - 1) * 2 * Bs * H * 3 * H * 2
-    # HBM-side bytes per launch from rocprofv3 PMC passes at exactly this shape and call (profiles/r4_pmc_gru_fwd_cluster_x3.txt, re-measured on the round-4 build; tools/r4_pmc.sh):
-    # 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE.  Only valid for batch 128 (B_s = 384).
-    traffic = PMC_TRAFFIC_GRU_FWD if batch == 128 else None
+    # HBM-side bytes per launch: NOT measured in this run -- the figure of rocprofv3 PMC passes at exactly this shape and call on the round-6 build
+    # (tools/r6_pmc.sh -> profiles/r6_pmc_gru_fwd.txt): 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE.  Only valid for batch 128
+    # (B_s = 384) and the fp16 x 2 kernel; `traffic_source` in the line says where it comes from.
+    h2 = os.environ.get("TG_GRU_H2", "1") != "0"
+    traffic = PMC_TRAFFIC_GRU_FWD if (batch == 128 and h2 and ops.get_math_mode() == "f32") else None
     if ops.get_math_mode() == "bf16":          # secondary tier: one bf16 MFMA per product -> price against the dense bf16 peak
         return {"kernel": "gru_seq_fwd_cluster_x3_kernel<2, NS = 1>", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_BF16_MFMA / 1e12,
                 "unit": "TFLOP/s", "frac": flops / dt / PEAK_BF16_MFMA, "traffic": None, "launch_us": dt * 1e6,
                 "flop_per_launch": flops, "us_per_step": dt * 1e6 / T,
                 "note": "plain bf16 operands, one MFMA per MAC, fp32 accumulate; peak = dense bf16 matrix peak; the kernel is bound by the "
                         "per-step hand-off chain, not by MFMA issue"}
-    return {"kernel": "gru_seq_fwd_cluster_x3_kernel<2>", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-            "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": traffic, "launch_us": dt * 1e6,
-            "flop_per_launch": flops, "us_per_step": dt * 1e6 / T,
+    return {"kernel": "gru_seq_fwd_cluster_x3_kernel<2, NS = %d>" % (2 if h2 else 3), "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": traffic,
+            "traffic_source": "profiles/r6_pmc_gru_fwd.txt (rocprofv3 --pmc passes of the same call on the round-6 build; not measured in this run)" if traffic else None,
+            "launch_us": dt * 1e6, "flop_per_launch": flops, "us_per_step": dt * 1e6 / T, "mfma_per_mac": 3 if h2 else 6,
+            "peak_f16x2": PEAK_BF16_MFMA / 3 / 1e12, "frac_f16x2": flops / dt / (PEAK_BF16_MFMA / 3),
             "peak_bf16x3": PEAK_BF16_MFMA / 6 / 1e12, "frac_bf16x3": flops / dt / (PEAK_BF16_MFMA / 6),
-            "note": "fp32-accurate product issued as 6 bf16 MFMAs per MAC on split operands; peak = fp32 matrix peak "
-                    "(peak_bf16x3 = dense bf16 MFMA peak / 6, the ceiling of this arithmetic)"}
+            "note": ("fp32-accurate product issued as 3 fp16 MFMAs per MAC on two-term split operands (round 6); peak = fp32 matrix peak; "
+                     "peak_f16x2 = dense 16-bit MFMA peak / 3 is the ceiling of this arithmetic") if h2 else
+                    ("fp32-accurate product issued as 6 bf16 MFMAs per MAC on split operands; peak = fp32 matrix peak "
+                     "(peak_bf16x3 = dense bf16 MFMA peak / 6, the ceiling of this arithmetic)")}
 
 
-PMC_TRAFFIC_GRU_FWD = 197.7e6      # bytes per launch: (2 x FETCH_SIZE 56 353 KB + WRITE_SIZE 80 397 KB) x 1024, profiles/r4_pmc_gru_fwd_cluster_x3.txt (round-4 build: the same-XCD hand-off keeps its lines in L2; round 3: 287.5 MB; gates saved for call g2 only)
+PMC_TRAFFIC_GRU_FWD = 192.8e6      # bytes per launch: (2 x FETCH_SIZE 55 728 KB + WRITE_SIZE 76 850 KB) x 1024, profiles/r6_pmc_gru_fwd.txt (round-6 build, fp16 x 2: two exchange planes; round 4-5, bf16 x 3: 197.7 MB; gates saved for call g2 only)
 
 
 def hbm_kernel_roofline(pkg, device):
@@ -454,13 +461,16 @@ def ae_bench(pkg, a, args, device, world, rank):
 
 
 def step_roofline(clips_per_s_per_gpu, epoch, dtype):
-    """The whole iteration against BOTH matrix ceilings: the fp32 matrix peak (fp32 is the arithmetic delivered) and the ceiling of the
-    arithmetic actually issued -- every big product is six bf16 MFMAs per MAC on exactly split operands (bf16 x 3), i.e. dense bf16 peak / 6;
-    the plain-bf16 tier (one MFMA per MAC) is priced against the dense bf16 peak."""
+    """The whole iteration against the matrix ceilings: the fp32 matrix peak (fp32 is the arithmetic delivered) and the ceilings of the arithmetic
+    actually issued.  Round 6: the stacked forward's products, the forward recurrence, the GRU layers' input and weight gradients are three fp16
+    MFMAs per MAC on two-term split operands (fp16 x 2: dense 16-bit peak / 3); the backward recurrence and the text encoder's backward products
+    are still six bf16 MFMAs per MAC (bf16 x 3: peak / 6) -- both fractions are printed, the truth lies between them; the plain-bf16 tier (one
+    MFMA per MAC) is priced against the dense bf16 peak."""
     flop = FLOP_PER_CLIP if epoch > 10 else 2.101e9
     ach = clips_per_s_per_gpu * flop
-    d = {"bound": "mfma", "achieved": ach / 1e12, "unit": "TFLOP/s", "frac_f32": ach / PEAK_F32_MFMA, "frac_bf16x3": ach / (PEAK_BF16_MFMA / 6),
-         "peak_f32": PEAK_F32_MFMA / 1e12, "peak_bf16x3": PEAK_BF16_MFMA / 6 / 1e12,
+    d = {"bound": "mfma", "achieved": ach / 1e12, "unit": "TFLOP/s", "frac_f32": ach / PEAK_F32_MFMA, "frac_f16x2": ach / (PEAK_BF16_MFMA / 3),
+         "frac_bf16x3": ach / (PEAK_BF16_MFMA / 6), "peak_f32": PEAK_F32_MFMA / 1e12, "peak_f16x2": PEAK_BF16_MFMA / 3 / 1e12,
+         "peak_bf16x3": PEAK_BF16_MFMA / 6 / 1e12,
          "note": "whole iteration, algorithmic " + ("2.735" if epoch > 10 else "2.101") + " GFLOP/clip (SURVEY 8d), per GPU"}
     if dtype == "bf16":
         d.update(peak=PEAK_BF16_MFMA / 1e12, frac=ach / PEAK_BF16_MFMA, frac_bf16=ach / PEAK_BF16_MFMA)
