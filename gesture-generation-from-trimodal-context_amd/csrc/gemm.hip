@@ -958,6 +958,7 @@ static int tn_fill(TnProb& p, const tg_gemm_tn_problem& q, int idx, int group_ti
 }
 
 // plan_only != nullptr: decide the kernel (0 f32-MFMA, 1 bf16 x 3 staged slabs, 2 bf16 x 3 mover waves) and return without launching
+extern "C" int tg_get_tn_workgroup_cap(void);
 static int tn_group_impl(const tg_gemm_tn_problem* problems, int32_t n, void* stream, int32_t* plan_only) {
     TG_REQUIRE(problems && n >= 1 && n <= TG_MAX_GROUP, "tg_gemm_tn_group: 1..%d problems", TG_MAX_GROUP);
     TnGroup g;
@@ -999,6 +1000,14 @@ static int tn_group_impl(const tg_gemm_tn_problem* problems, int32_t n, void* st
     hipStream_t s = (hipStream_t)stream;
     bool all_ws = true;
     for (int i = 0; i < n; ++i) all_ws = all_ws && problems[i].ws != nullptr;
+    // The mover-wave kernel's workspace combine reduces ALL problems of the group in one launch with plain read-modify-writes (one writer per
+    // output element): two problems that accumulate into the same dW or dbias (the output MLP's pair does, below this kernel's size gate) would
+    // race there.  Such a group keeps the per-problem combines of the other kernels, which run one after the other.
+    bool aliased = false;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            aliased = aliased || problems[i].dW == problems[j].dW || (problems[i].dbias && problems[i].dbias == problems[j].dbias);
+    if (aliased && all_ws) mw_ok = false;
     if (mw_ok && (!two_pass || all_ws)) {
         // big gradients whose 192 x 160 tiles fill the chip: mover-wave kernel (gemm_tn_mw.hip), bf16 x 3 or plain bf16.  Row splits are
         // combined by float atomics, or -- when EVERY problem brings a workspace -- through tile-sized partial images and a fixed-order second
@@ -1016,6 +1025,11 @@ static int tn_group_impl(const tg_gemm_tn_problem* problems, int32_t n, void* st
         }
     }
     if (plan_only) { *plan_only = x3 ? 1 : 0; return 0; }
+    // tg_set_tn_workgroup_cap promises a launch that occupies at most that many CUs (it runs beside a cluster-synchronised recurrence whose
+    // workgroups must all stay resident): only the persistent mover-wave kernel keeps that promise -- the kernels below flood the chip with short
+    // workgroups.  A capped group they would take is refused; the caller probes the plan with the problems it will launch (ops.tn_kernel_plan).
+    TG_REQUIRE(tg_get_tn_workgroup_cap() == 0, "tg_gemm_tn_group: a workgroup cap of %d is set but this group does not run on the persistent "
+               "mover-wave kernel (tg_gemm_tn_kernel_plan != 2): launch it without the cap", tg_get_tn_workgroup_cap());
     if (x3) {
         if (int e = tg_gemm_tn_split_launch(g, wg, tnw, tkw, s)) return e;
     } else {

@@ -58,10 +58,12 @@ def process_group_options():
 class GradSync:
     def __init__(self, group=None, chunk_floats=8 * 1024 * 1024):
         assert dist.is_initialized(), "init_process_group first"
-        if dist.get_backend(group) == "nccl" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8 and not HIGH_PRIORITY_STREAM:
-            warnings.warn("GPU_MAX_HW_QUEUES < 8 and RCCL's stream has normal priority: it may share a hardware queue with the compute stream, which "
-                          "serialises every gradient bucket with the backward it is meant to overlap (call ddp.configure_environment() before the "
-                          "first HIP call)")
+        if dist.get_backend(group) == "nccl" and "GPU_MAX_HW_QUEUES" not in os.environ and not HIGH_PRIORITY_STREAM:
+            # (configure_environment() sets the variable -- to HW_QUEUES, 4 since round 5, where RCCL's stream was measured on its own queue; what
+            # is warned about is a process that never called it and so never made the choice)
+            warnings.warn("GPU_MAX_HW_QUEUES is unset: ddp.configure_environment() was not called before the first HIP call, so the hardware-queue "
+                          f"count (ddp.HW_QUEUES = {HW_QUEUES}) and the RCCL event-cache setting it applies are the runtime's defaults; RCCL's stream "
+                          "may then share a hardware queue with the compute stream and serialise every gradient bucket with the backward it is meant to overlap")
         self.group = group
         self.world = dist.get_world_size(group)
         self.chunk = int(chunk_floats)

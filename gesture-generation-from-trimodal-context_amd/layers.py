@@ -111,6 +111,9 @@ class WeightPrep:
                                        "during a capture; run an eager iteration of this configuration first")
                 self.part_of[key] = now
                 self._rebuild(self.groups[self._group_of(src3.data_ptr())], src3.device)
+                # ... and THIS iteration the operand's own (later) part has not refreshed it yet -- it still holds the weights from before the last
+                # optimiser step, or is being rewritten right now on the forked stream: recompute it here, on the reader's stream
+                self._compute(src3, hit, perm, other)
             return hit
         gid = self._group_of(src3.data_ptr())
         if gid is None or torch.cuda.is_current_stream_capturing():
@@ -135,6 +138,20 @@ class WeightPrep:
         self.part_of[key] = self._part_now()
         self._rebuild(g, src3.device)
         return dst
+
+    @staticmethod
+    def _compute(src3, dst, perm, other=None):
+        """One operand, inline on the current stream (what a table entry of the batched refresh does)."""
+        if perm[0] == 8:
+            ops.split3_planes(src3[0], out=dst)
+        elif perm[0] == 10:
+            ops.split2h_planes(src3[0], buf=dst)
+        elif perm[0] == 11:
+            ops.split2h_planes_tcat(src3[0], other, buf=dst)
+        elif perm[0] == 9:
+            ops.conv_dgrad_pack(src3, dst, perm[1])
+        else:
+            ops.permute3(src3, dst.view(-1), perm)
 
     def refresh(self, gid, which="all"):
         g = self.groups.get(gid)
@@ -693,7 +710,7 @@ def gru_stack_bwd(dy, tape, P, G, prefix, n_layers, *, b0=0, nb=None, need_dx=Tr
             if nb_side and l > 0:
                 # only if the capped plan takes the side part on the persistent kernel (anything else floods the chip with short workgroups)
                 with ops.tn_workgroup_cap(free_cus):
-                    if ops.tn_kernel_plan(layer_probs(nb - nb_side, nb)) == 2:
+                    if ops.tn_kernel_plan(layer_probs(nb - nb_side, nb), as_launched=True) == 2:
                         split = nb_side
             fk.keep(dgi, dgh, x_l, y_l, stats_all, x_cmax, h_cmax)     # (the side stream reads them after this function's references are gone)
             with fk:

@@ -582,12 +582,18 @@ def gru_cluster_bwd_free_cus(nb, H):
     return max(0, cus - 2 * (-(-nb // 16)) * (-(-H // 32)))
 
 
-def tn_kernel_plan(problems):
-    """0 = f32-MFMA tiles, 1 = bf16 x 3 staged slabs (gemm_split.hip), 2 = bf16 x 3 mover waves (gemm_tn_mw.hip) for a group given as
-    gemm_tn_group's list of dicts."""
+def tn_kernel_plan(problems, as_launched=False):
+    """0 = f32-MFMA tiles, 1 = bf16 x 3 staged slabs (gemm_split.hip), 2 = mover waves (gemm_tn_mw.hip) for a group given as gemm_tn_group's
+    list of dicts.  as_launched: plan the problems as gemm_tn_group would launch them -- with the workspaces of the fixed-order combine
+    (TN_MW_WS) when the group qualifies -- so that a caller who depends on the answer (a capped launch beside a cluster recurrence) probes
+    exactly what will run."""
     keep = []
     arr = (_lib.TnProblem * len(problems))(*[_tn_problem(keep=keep, **p)[0] for p in problems])
-    return int(_lib.load().tg_gemm_tn_kernel_plan(arr, len(problems)))
+    plan = int(_lib.load().tg_gemm_tn_kernel_plan(arr, len(problems)))
+    if as_launched and plan == 2 and TN_MW_WS and not all(q.ws for q in arr):
+        arr = (_lib.TnProblem * len(problems))(*[_tn_problem(keep=keep, force_ws=True, **p)[0] for p in problems])
+        plan = int(_lib.load().tg_gemm_tn_kernel_plan(arr, len(problems)))
+    return plan
 
 
 def colsum(X, out, *, accumulate=True):
