@@ -629,6 +629,8 @@ extern "C" int tg_set_nt_mover_waves(int32_t on) {
 static bool mw_pick_tile(const NtGroup& g, MwTile* out) {
     static const int env_on = [] { const char* e = getenv("TG_NT_MW"); return e ? atoi(e) : 1; }();
     if (!(g_mw_on < 0 ? env_on : g_mw_on)) return false;
+    // (round 6, measured and not kept: 256 x 192 for two-plane operands -- 96 accumulator registers push the epilogue into 388 spills, 138 us against
+    // 122 on the stacked projection: profiles/r6_s_tile_256x192_rejected.txt)
     const MwTile menu[3] = {{4, 6}, {4, 5}, {4, 3}};
     static const int forced = [] { const char* e = getenv("TG_MW_TILE"); return e ? atoi(e) : 0; }();     // lab: 46 / 45 / 43 forces that tile
     double best = 0.0;
