@@ -87,7 +87,9 @@ class GanTrainer:
             # too -- {audio} and {text, speaker} then become final together and leave in ONE exchange with nothing left to cover it
             # (GeneratorEngine.backward merges them); on one rank the two orders are level (4.90 / 4.91 ms against plain 4.63,
             # profiles/r5_g_ddp.txt: what the fork saves, the exposed 31 MB exchange costs), with real peers the covered order wins
-            self.G.audio_fork_bwd = os.environ.get("TG_DDP_BWD_FORK", "0") != "0"
+            # Round 6: forked by default -- on one rank captured + forked is the fastest form (4.60 against 4.68 ms, profiles/r6_ddp.txt), and the
+            # weight gradients' side rows (engine.GeneratorEngine.backward) ride on the same switch.  TG_DDP_BWD_FORK=0 restores the covered order.
+            self.G.audio_fork_bwd = os.environ.get("TG_DDP_BWD_FORK", "1") != "0"
         self.keep_tape = False              # tests: keep the last stacked generator forward's tape in self.last_tape (holds its activations alive)
         self.last_tape = None
         self.prep = L.WeightPrep()          # transposed / packed weight operands, refreshed once per optimiser step

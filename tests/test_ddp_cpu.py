@@ -259,3 +259,70 @@ def test_train_iter_exchange_schedule_over_gloo_world2():
     for rank, order, err_g, err_d, pending in res:
         assert order == want, (rank, order)
         assert err_g < 1e-6 and err_d < 1e-6 and pending == 0, (rank, err_g, err_d, pending)      # both optimisers consumed the MEAN gradient
+
+
+def _bench_size_worker(rank, world, port, out):
+    """Two data-parallel iterations of the generator's slab at the BENCHMARK's size (V = 20 000 words, 1 371 speaker rows: 13.2 M floats, the
+    word embedding inside the {text, speaker} bucket) through the bucket ranges and the exchange order the trainer uses -- the D-slab form first,
+    then {out, gru}, then {text, speaker} and {audio} -- with rank-dependent gradients and a host-side Adam on the reduced gradients."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module(PKG)
+        ddp = importlib.import_module(PKG + ".ddp")
+        params = importlib.import_module(PKG + ".params")
+        from tests.harness import make_args
+        torch.manual_seed(rank)                                        # replicas start DIFFERENT: the broadcast must make them rank 0's
+        G = pkg.PoseGenerator(make_args(), 27, 20000, 300, None, pkg.Vocab.speakers(1371))
+        slab = params.ParamSlab(G)
+        assert slab.numel >= 13_204_939
+        ddp.broadcast_parameters([slab])
+        sync = ddp.GradSync(chunk_floats=8 * 1024 * 1024)
+        buckets = (("out", "gru"), ("speaker_embedding", "speaker_mu", "speaker_logvar", "text_encoder"), ("audio_encoder",))
+        sizes = [sync.bucket_range(slab, b) for b in buckets]
+        m, v = torch.zeros_like(slab.flat), torch.zeros_like(slab.flat)
+        start = slab.flat.clone()
+        covered = torch.zeros(slab.numel, dtype=torch.bool)
+        for p_, off in zip(slab.params, slab.offsets):
+            covered[off:off + p_.numel()] = True
+        for it in range(2):
+            g = torch.Generator().manual_seed(1000 * it + rank)
+            # rank-dependent gradients on every parameter element; alignment padding between tensors stays zero, as zero_grad leaves it
+            slab.grad.copy_(torch.randn(slab.numel, generator=g) * (1.0 + rank) * covered)
+            sync.run(("bucket", slab, buckets[0]))                     # leaves behind the GRU stack's backward
+            sync.run(("bucket", slab, buckets[1]))
+            sync.run(("bucket_wait", slab, buckets[2]))                # the backward's last bucket: launched and awaited in one action
+            assert not sync.pending
+            # Adam(lr 5e-4, betas (0.5, 0.999)) on the reduced gradient, the same float ops on every rank
+            m.mul_(0.5).add_(slab.grad, alpha=0.5)
+            v.mul_(0.999).addcmul_(slab.grad, slab.grad, value=0.001)
+            mh, vh = m / (1 - 0.5 ** (it + 1)), v / (1 - 0.999 ** (it + 1))
+            slab.flat.sub_(5e-4 * mh / (vh.sqrt() + 1e-8))
+        bits = slab.flat.view(torch.int32).clone()
+        lo, hi = bits.clone(), bits.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        moved = float((slab.flat - start)[covered].abs().min())            # every parameter element took two Adam steps
+        out.put((rank, bool(torch.equal(lo, hi)), [hi_ - lo_ for lo_, hi_ in sizes], moved > 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_size_slab_stays_bit_equal_across_ranks_world2():
+    """after two iterations of the real bucket ranges of a V = 20 000 slab, every rank holds BIT-IDENTICAL parameters (the
+    replicas of scripts/train.py:93-96's DataParallel are one set of weights; here they stay one because every rank applies the same
+    reduced gradient)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_size_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, equal, sizes, moved in res:
+        assert equal and moved, (rank, equal, moved)
+        assert sizes[1] > 6_000_000 and sum(sizes) >= 13_000_000, sizes          # the word embedding sits inside the {text, speaker} bucket
