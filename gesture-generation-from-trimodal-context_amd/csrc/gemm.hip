@@ -769,6 +769,16 @@ static int nt_launch(NtGroup& g, hipStream_t s) {
             hipLaunchKernelGGL((gemm_nt_kernel<true, 1, 1, 2, 4>), grid4, dim3(256), 0, s, g);
             return check_launch("tg_gemm_nt");
         }
+        int Mmax = 0;
+        for (int i = 0; i < g.n; ++i) Mmax = Mmax > g.p[i].M ? Mmax : g.p[i].M;
+        if (fam == 2 && vec && wgs <= 64 && Kx >= 256 && Mmax <= 576) {
+            // a handful of 64 x 64 tiles with a long reduction and at most 576 rows (a synthesis window of up to 16 utterances: [34 x 300 x 600]
+            // text-encoder convs are five workgroups walking 150 dependent k-steps each, 25 us): 32 x 32 tiles whose four waves split K --
+            // four times the workgroups, an eighth of the chain: ~11 us (round 6: one utterance 883 -> 723 us per window, profiles/r6_z_decode_b1.txt)
+            const dim3 grid4(nt_layout(g, 32, 32));
+            hipLaunchKernelGGL((gemm_nt_kernel<true, 1, 1, 2, 4>), grid4, dim3(256), 0, s, g);
+            return check_launch("tg_gemm_nt");
+        }
         if (fam == 1) {
             if (vec && deep) hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 4>), grid, dim3(256), 0, s, g);
             else if (vec)    hipLaunchKernelGGL((gemm_nt_kernel<true, 4, 1, 1>), grid, dim3(256), 0, s, g);
