@@ -13,8 +13,17 @@ dgi = torch.randn(2, M, 3 * H, device=dev)
 wt = torch.randn(2, 2 * H, 3 * H, device=dev) * 0.05            # the two transposed W_ih, [Kin][3H] each, one allocation (seg = Kin * 3H floats)
 dx = torch.empty(M, 2 * H, device=dev)
 a_cat = Win(dgi, batches=1, batch_stride=0, row_stride=3 * H, rows_in=2 * M, rows_out=M, cw=3 * H, K=6 * H, dil=M)
+# round 6: the product as layers.gru_stack_bwd issues it now -- fp16 x 2 on the mover-wave kernel (128 x 96 tiles), planes of the K-concatenated
+# transposed W_ih pair, dgi's magnitudes per clip (TG_GEMM_H2=0: the round-5 staged-slab form)
+if ops.gemm_h2():
+    w_f, w_r = wt[0].t().contiguous(), wt[1].t().contiguous()                       # the parameters: [3H][Kin]
+    pl = ops.split2h_planes_tcat(w_f, w_r)
+    clipmax = dgi.view(2, nb, T * 3 * H).abs().amax(dim=2).contiguous().view(-1)   # what tg_gru_backward_cluster_stats leaves
 def gru_dx():
-    ops.gemm_nt(a_cat, wt[0], None, dx, b_seg=(3 * H, 2 * H * 3 * H))
+    if ops.gemm_h2():
+        ops.gemm_nt(a_cat, wt[0], None, dx, b_seg=(3 * H, 2 * H * 3 * H), w_planes=pl, a_rowmax=clipmax, a_rowmax_rows=T)
+    else:
+        ops.gemm_nt(a_cat, wt[0], None, dx, b_seg=(3 * H, 2 * H * 3 * H))
 d = 4
 dc3 = torch.randn(nb, T, 300, device=dev)
 wT = torch.randn(300, 600, device=dev) * 0.05

@@ -34,3 +34,11 @@ pass m5 tools/mw_pmc.py gemm_nt_mw_kernel WRITE_SIZE
 unset TG_PMC_N
 } > $out/r6_pmc_gemm_mw.txt 2>&1
 cat $out/r6_pmc_gemm_mw.txt
+{
+echo "# rocprofv3 --pmc <counters> --output-format csv -- python3 tools/nt_bwd_pmc.py   (gru_dx [4352 x 600 x 1800] on gemm_nt_mw_kernel<2, 3, 4, 2, 2>: fp16 x 2, 128 x 96 tiles, 238 of them; round-6 build)"
+python3 tools/nt_bwd_pmc.py --time
+pass b1 tools/nt_bwd_pmc.py gemm_nt_mw_kernel FETCH_SIZE
+pass b2 tools/nt_bwd_pmc.py gemm_nt_mw_kernel WRITE_SIZE
+pass b3 tools/nt_bwd_pmc.py gemm_nt_mw_kernel SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY
+} > $out/r6_pmc_nt_bwd.txt 2>&1
+cat $out/r6_pmc_nt_bwd.txt
