@@ -13,7 +13,11 @@ M, N, K, n = shapes[sys.argv[2] if len(sys.argv) > 2 else "gru"]
 x = torch.randn(M, K, device=dev)
 ws = [torch.randn(N, K, device=dev) * 0.05 for _ in range(n)]
 outs = [torch.empty(M, N, device=dev) for _ in range(n)]
-probs = [dict(A=Win.plain(x), W=w, bias=None, out=o, w_planes=ops.split3_planes(w)) for w, o in zip(ws, outs)]
+if os.environ.get("TG_ABL_H2", "0") == "1":          # round 6: the fp16 x 2 instantiation
+    sc = ops.h2_row_scales(Win.plain(x))
+    probs = [dict(A=Win.plain(x), W=w, bias=None, out=o, w_planes=ops.split2h_planes(w), a_row_scale=sc) for w, o in zip(ws, outs)]
+else:
+    probs = [dict(A=Win.plain(x), W=w, bias=None, out=o, w_planes=ops.split3_planes(w)) for w, o in zip(ws, outs)]
 os.environ["TG_MW_ABL"] = sys.argv[1] if len(sys.argv) > 1 else "0"
 for _ in range(20):
     ops.gemm_nt_group(probs)
