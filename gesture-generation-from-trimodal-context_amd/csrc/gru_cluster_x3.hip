@@ -731,7 +731,7 @@ int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, c
         const char* ae = getenv("TG_XC_ABL");
         const int abl = ae ? atoi(ae) : 0;
         if (abl && mt == 2 && !bf16) {
-#define TG_XF_ABL(A_) case A_: hipLaunchKernelGGL((gru_seq_fwd_cluster_x3_kernel<2, 3, A_>), grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, \
+#define TG_XF_ABL(A_) case A_: hipLaunchKernelGGL((gru_seq_fwd_cluster_x3_kernel<2, 2, A_>), grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, \
                                            drop_mask, y_drop, hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows); return check_launch("tg_gru_forward_cluster(x3, ablated)");
             switch (abl) {
                 TG_XF_ABL(1) TG_XF_ABL(2) TG_XF_ABL(4) TG_XF_ABL(8) TG_XF_ABL(16) TG_XF_ABL(32) TG_XF_ABL(64) TG_XF_ABL(80) TG_XF_ABL(3) TG_XF_ABL(7) TG_XF_ABL(15) TG_XF_ABL(31) TG_XF_ABL(127) TG_XF_ABL(6) TG_XF_ABL(96) TG_XF_ABL(81)

@@ -1,5 +1,5 @@
 """Timing ablation of the generator's cluster-synchronised forward recurrence (lab library, TG_XC_ABL selects a compile-time variant of
-gru_seq_fwd_cluster_x3_kernel<2, 3>; ablated launches compute garbage by construction): what is on the step's dependent chain?"""
+gru_seq_fwd_cluster_x3_kernel<2, 2> (round 6: the fp16 x 2 instantiation); ablated launches compute garbage by construction): what is on the step's dependent chain?"""
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("gesture-generation-from-trimodal-context_amd")
