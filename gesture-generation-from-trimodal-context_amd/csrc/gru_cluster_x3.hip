@@ -442,16 +442,16 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_cluster_x3_kernel(
         __syncthreads();                                       // (also: `red` is free again)
         if (threadIdx.x == 0 && T >= 2) __hip_atomic_store(my_flag, xc_flag_value(gen + (unsigned)(step + 1), my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (epi_wave && !(ABL & 32)) {                         // outputs for later kernels and the next step's inputs: off the critical path
-            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(h), y_rsrc, y_v, tau * 2 * H * 4, 0);
+            if constexpr (!(ABL & 256)) __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(h), y_rsrc, y_v, tau * 2 * H * 4, 0);     // (lab: 256 = no output stores, 128 = no prefetch)
             if (y_drop) __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(h * mk), yd_rsrc, y_v, tau * 2 * H * 4, 0);   // fused inter-layer dropout
-            if (save) {
+            if (save && !(ABL & 256)) {
                 const int so = tau * 4 * H * 4;
                 __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(r4), sv_rsrc, sv_v, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(z4), sv_rsrc, sv_v, so + H * 4, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(n4), sv_rsrc, sv_v, so + 2 * H * 4, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(hn4), sv_rsrc, sv_v, so + 3 * H * 4, 0);
             }
-            prefetch(step + 1);
+            if constexpr (!(ABL & 128)) prefetch(step + 1);
         }
     }
     if (m == 0 && threadIdx.x == 0 && T >= 2) __hip_atomic_store(cl_flags + XC_GEN_WORD, gen + (unsigned)(T + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -734,7 +734,7 @@ int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, c
 #define TG_XF_ABL(A_) case A_: hipLaunchKernelGGL((gru_seq_fwd_cluster_x3_kernel<2, 2, A_>), grid, dim3(512), 0, s, gi, gi_ds, w0, w1, b0, b1, y, save, save_ds, \
                                            drop_mask, y_drop, hx, flags, tmo, B, T, H, n_bt, cw, b_pad, save_row0, save_rows); return check_launch("tg_gru_forward_cluster(x3, ablated)");
             switch (abl) {
-                TG_XF_ABL(1) TG_XF_ABL(2) TG_XF_ABL(4) TG_XF_ABL(8) TG_XF_ABL(16) TG_XF_ABL(32) TG_XF_ABL(64) TG_XF_ABL(80) TG_XF_ABL(3) TG_XF_ABL(7) TG_XF_ABL(15) TG_XF_ABL(31) TG_XF_ABL(127) TG_XF_ABL(6) TG_XF_ABL(96) TG_XF_ABL(81)
+                TG_XF_ABL(1) TG_XF_ABL(2) TG_XF_ABL(4) TG_XF_ABL(8) TG_XF_ABL(16) TG_XF_ABL(32) TG_XF_ABL(64) TG_XF_ABL(80) TG_XF_ABL(3) TG_XF_ABL(7) TG_XF_ABL(15) TG_XF_ABL(31) TG_XF_ABL(127) TG_XF_ABL(6) TG_XF_ABL(96) TG_XF_ABL(81) TG_XF_ABL(128) TG_XF_ABL(256)
                 default: break;
             }
 #undef TG_XF_ABL

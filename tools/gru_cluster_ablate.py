@@ -23,9 +23,9 @@ def timed(iters=30):
     return e0.elapsed_time(e1) * 1e3 / iters
 names = {0: "full", 1: "no flag wait", 2: "no fragment loads", 4: "no MFMAs", 8: "no K-slice reduction / gates", 16: "no publishing stores", 32: "no output stores / prefetch",
          64: "no drain before the flag", 80: "no publishing stores, no drain", 3: "no wait, no loads", 7: "no wait / loads / MFMAs", 15: "+ no reduction / gates",
-         31: "+ no publishing stores", 127: "everything off: barriers + LDS only", 6: "no loads, no MFMAs", 96: "no output stores, no drain", 81: "no wait, no publish, no drain"}
+         31: "+ no publishing stores", 128: "no next-step gi prefetch (output stores kept)", 256: "no output stores (prefetch kept)", 127: "everything off: barriers + LDS only", 6: "no loads, no MFMAs", 96: "no output stores, no drain", 81: "no wait, no publish, no drain"}
 for rnd in range(2):
-    for abl in (0, 1, 2, 4, 8, 16, 32, 64, 80, 96, 3, 6, 7, 15, 31, 81, 127):
+    for abl in (0, 1, 2, 4, 8, 16, 32, 128, 256, 64, 80, 96, 3, 6, 7, 15, 31, 81, 127):
         os.environ["TG_XC_ABL"] = str(abl)
         t = timed()
         try:
