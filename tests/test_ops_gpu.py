@@ -1408,3 +1408,117 @@ def test_iter_begin_advances_counters(pkg, dev):
     ops.iter_begin(ra, rb, ca, None)
     ops.iter_begin(ra, None, ca, cb)
     assert ra.tolist() == [5, 2] and rb.tolist() == [6, 1] and int(ca) == 5 and int(cb) == 10
+
+
+# ------------------------------------------------------------------------------------------------ fp16 x 2 operand interface (ABI 7)
+def test_fp16x2_row_magnitudes_through_a_conv_chain(pkg, dev):
+    """The magnitude side channel of the fp16 x 2 products (tg_gemm_nt_problem.a_rowmax / c_rowmax / c2_rowmax): a dilated causal conv with
+    ReLU, dropout scale and the residual second output (model/tcn.py:27-46) reads its input's row magnitudes (tg_win_row_absmax) and leaves
+    EXACTLY the row magnitudes of both tensors it wrote -- the next conv of the chain is then scaled without a pass over its operand and
+    agrees with fp64 like the first."""
+    ops, Win, Lm = pkg.ops, pkg.ops.Win, pkg.layers
+    B, T, Cc, d = 384, 34, 300, 2
+    g = torch.Generator().manual_seed(61)
+    x = (torch.randn(B, T, Cc, generator=g) * torch.pow(10.0, torch.randint(-3, 3, (B, T, 1), generator=g).float())).to(dev)
+    w1, w2 = ((torch.randn(Cc, 2 * Cc, generator=g) * 0.05).to(dev) for _ in range(2))
+    b1 = torch.randn(Cc, generator=g).to(dev)
+    mask = ((torch.rand(B, T, Cc, generator=g) > 0.3).float() / 0.7).to(dev)
+    res = torch.randn(B, T, Cc, generator=g).to(dev)
+    pl1, pl2 = ops.split2h_planes(w1), ops.split2h_planes(w2)
+    rm = ops.zeros(3, B * T, device=dev)
+    a1 = Win.conv(x, 2, pad=d, dil=d, rows_out=T)
+    ops.win_row_absmax(a1, out=rm[0])
+    assert torch.equal(rm[0].view(B, T), x.abs().amax(dim=2))
+    o, o2 = torch.empty(B, T, Cc, device=dev), torch.empty(B, T, Cc, device=dev)
+    p1 = [dict(A=a1, W=w1, bias=b1, out=o, act_slope=0.0, out_scale=mask, res=res, out2=o2, res_slope=0.0, c_batch_stride=o.stride(0),
+               c_row_stride=o.stride(1), c_rows_out=T, w_planes=pl1, a_rowmax=rm[0], out_rowmax=rm[1], out2_rowmax=rm[2])]
+    assert ops.nt_kernel_plan(p1)[0] == 2
+    ops.gemm_nt_group(p1)
+    xp = torch.cat([torch.zeros(B, d, Cc, dtype=torch.float64, device=dev), x.double()], dim=1)
+    ref = torch.relu(xp[:, :T] @ w1[:, :Cc].double().t() + xp[:, d:d + T] @ w1[:, Cc:].double().t() + b1.double()) * mask.double()
+    rowsc = ref.abs().amax(dim=2, keepdim=True).clamp_min(1e-30)
+    assert float(((o.double() - ref).abs() / rowsc).max()) < 1e-5
+    assert torch.equal(rm[1].view(B, T), o.abs().amax(dim=2)) and torch.equal(rm[2].view(B, T), o2.abs().amax(dim=2))      # exact: maxima of what was stored
+    # the next conv of the chain: scaled by what the first one left
+    o3 = torch.empty(B, T, Cc, device=dev)
+    a2 = Win.conv(o2, 2, pad=2 * d, dil=2 * d, rows_out=T)
+    p2 = [dict(A=a2, W=w2, bias=None, out=o3, c_batch_stride=o3.stride(0), c_row_stride=o3.stride(1), c_rows_out=T, w_planes=pl2, a_rowmax=rm[2])]
+    assert ops.nt_kernel_plan(p2)[0] == 2
+    ops.gemm_nt_group(p2)
+    o2p = torch.cat([torch.zeros(B, 2 * d, Cc, dtype=torch.float64, device=dev), o2.double()], dim=1)
+    ref3 = o2p[:, :T] @ w2[:, :Cc].double().t() + o2p[:, 2 * d:2 * d + T] @ w2[:, Cc:].double().t()
+    assert float(((o3.double() - ref3).abs() / ref3.abs().amax(dim=2, keepdim=True).clamp_min(1e-30)).max()) < 1e-5
+    # refused where no kernel produces them
+    small = torch.empty(64, 48, device=dev)
+    with pytest.raises(Exception):
+        ops.gemm_nt(Win.plain(torch.randn(64, 64, device=dev)), torch.randn(48, 64, device=dev), None, small, out_rowmax=torch.zeros(64, device=dev))
+
+
+def test_fp16x2_gru_input_gradient_form(pkg, dev):
+    """The GRU layer's input gradient as layers.gru_stack_bwd issues it (multimodal_context_net.py:98-99 backward): dx = [dgi_fwd | dgi_rev] @
+    [W_ih_fwd ; W_ih_rev] as ONE product over K = 6H -- two taps of one window, the weight operand the K-concatenated TRANSPOSE of the two
+    parameters as fp16 x 2 planes (tg_split2h_planes_tcat: bit-identical to splitting the explicit concatenation), one power-of-two scale per
+    CLIP of T rows (a_rowmax_rows = T: what tg_gru_backward_cluster_stats leaves), on the mover-wave kernel's 128 x 96 tile; clips spanning six
+    decades; against fp64 at the fp32 tolerance, and the dropout scale of the layer below in the epilogue."""
+    ops, Win = pkg.ops, pkg.ops.Win
+    nb, T, H, Kin = 128, 34, 300, 600
+    M = nb * T
+    g = torch.Generator().manual_seed(62)
+    dgi = (torch.randn(2, nb, T, 3 * H, generator=g) * torch.pow(10.0, torch.randint(-7, -1, (2, nb, 1, 1), generator=g).float())).to(dev)
+    w_f, w_r = ((torch.randn(3 * H, Kin, generator=g) * 0.05).to(dev) for _ in range(2))
+    pl = ops.split2h_planes_tcat(w_f, w_r)
+    cat = torch.cat([w_f.t(), w_r.t()], dim=1).contiguous()                                        # [Kin][6H]
+    pl_ref = ops.split2h_planes(cat)
+    assert torch.equal(pl.t, pl_ref.t) and torch.equal(pl.inv[:Kin + 1], pl_ref.inv[:Kin + 1])
+    clipmax = dgi.abs().amax(dim=(2, 3)).contiguous()                                              # [2][nb]
+    wt = torch.stack([w_f.t().contiguous(), w_r.t().contiguous()])                                 # the fp32 segments the other kernels read
+    a_cat = Win(dgi, batches=1, batch_stride=0, row_stride=3 * H, rows_in=2 * M, rows_out=M, cw=3 * H, K=6 * H, dil=M)
+    mask = ((torch.rand(M, Kin, generator=g) > 0.3).float() / 0.7).to(dev)
+    dx = torch.empty(M, Kin, device=dev)
+    kw = dict(b_seg=(3 * H, Kin * 3 * H), out_scale=mask, w_planes=pl, a_rowmax=clipmax.view(-1), a_rowmax_rows=T)
+    assert ops.nt_kernel_plan([dict(A=a_cat, W=wt[0], bias=None, out=dx, **kw)]) == (2, 128, 96)
+    ops.gemm_nt(a_cat, wt[0], None, dx, **kw)
+    ref = (dgi[0].reshape(M, -1).double() @ w_f.double() + dgi[1].reshape(M, -1).double() @ w_r.double()) * mask.double()
+    err = (dx.double() - ref).abs() / ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+    assert float(err.max()) < 1e-5, float(err.max())
+
+
+def test_gru_backward_cluster_leaves_magnitudes(pkg, dev):
+    """tg_gru_backward_cluster_stats: the backward recurrence leaves max |dgi| per batch row (over all T steps) and the column maxima of dgi and
+    dgh -- exactly the maxima of what it stored (running maxima in registers, one atomic per row / column when the kernel exits); the
+    gradients themselves are those of the plain entry point bit for bit.  Row chunks (B = 256 backward = 2 x 128) accumulate."""
+    ops = pkg.ops
+    T, H = 34, 300
+    for B in (128, 256):
+        g = torch.Generator().manual_seed(B + 3)
+        w = [(torch.randn(3 * H, H, generator=g) * 0.08).to(dev) for _ in range(2)]
+        b = [(torch.randn(3 * H, generator=g) * 0.05).to(dev) for _ in range(2)]
+        wt = [x.t().contiguous() for x in w]
+        gi = (torch.randn(2, B, T, 3 * H, generator=g) * 0.5).to(dev)
+        dy = (torch.randn(B, T, 2 * H, generator=g) * torch.pow(10.0, torch.randint(-6, 0, (B, 1, 1), generator=g).float())).to(dev)
+        y, sv = torch.empty(B, T, 2 * H, device=dev), torch.empty(2, B, T, 4 * H, device=dev)
+        ops.gru_forward(gi, w, b, y, sv)
+        out = []
+        for with_stats in (False, True):
+            dgi, dgh = torch.empty(2, B, T, 3 * H, device=dev), torch.empty(2, B, T, 3 * H, device=dev)
+            stats = (ops.zeros(2, B, device=dev), ops.zeros(2, 3 * H, device=dev), ops.zeros(2, 3 * H, device=dev)) if with_stats else None
+            filled = ops.gru_backward(dy, y, sv, wt, dgi, dgh, torch.zeros(4 * B * H, device=dev), stats=stats)
+            assert bool(filled) == with_stats
+            out.append((dgi, dgh, stats))
+        ops.check_async_errors()
+        (dgi0, dgh0, _), (dgi1, dgh1, (rm, ci, ch)) = out
+        assert torch.equal(dgi0, dgi1) and torch.equal(dgh0, dgh1)
+        assert torch.equal(rm, dgi1.abs().amax(dim=(2, 3)))
+        assert torch.equal(ci, dgi1.abs().amax(dim=(1, 2))) and torch.equal(ch, dgh1.abs().amax(dim=(1, 2)))
+
+
+def test_absmax_rows_cols(pkg, dev):
+    """tg_absmax_rows_cols: row and per-group column magnitudes of a strided matrix in one pass, exact."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(64)
+    big = (torch.randn(2 * 1234, 1000, generator=g) * torch.logspace(-5, 5, 1000)).to(dev)
+    x = big[:, 52:52 + 900]                                                                      # row stride 1000, 16-byte aligned start
+    rm, cm = ops.absmax_rows_cols(x, groups=2, want_rows=True)
+    assert torch.equal(rm, x.abs().amax(dim=1)) and torch.equal(cm, x.view(2, 1234, 900).abs().amax(dim=1))
+    _, cm1 = ops.absmax_rows_cols(x)
+    assert torch.equal(cm1.view(-1), x.abs().amax(dim=0))
