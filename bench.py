@@ -275,7 +275,7 @@ def dominant_kernel_roofline(pkg, device, batch):
     # HBM-side bytes per launch: NOT measured in this run -- the figure of rocprofv3 PMC passes at exactly this shape and call on the round-6 build
     # (tools/r6_pmc.sh -> profiles/r6_pmc_gru_fwd.txt): 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE.  Only valid for batch 128
     # (B_s = 384) and the fp16 x 2 kernel; `traffic_source` in the line says where it comes from.
-    h2 = os.environ.get("TG_GRU_H2", "1") != "0"
+    h2 = int(os.environ.get("TG_GRU_H2", "3")) & 1 == 1          # mask: 1 = forward recurrence, 2 = backward recurrence
     traffic = PMC_TRAFFIC_GRU_FWD if (batch == 128 and h2 and ops.get_math_mode() == "f32") else None
     if ops.get_math_mode() == "bf16":          # secondary tier: one bf16 MFMA per product -> price against the dense bf16 peak
         return {"kernel": "gru_seq_fwd_cluster_x3_kernel<2, NS = 1>", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_BF16_MFMA / 1e12,

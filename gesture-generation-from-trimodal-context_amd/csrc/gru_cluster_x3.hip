@@ -92,6 +92,28 @@ __device__ __forceinline__ void xc_split4_h2(const f32x4 v, const float scale, u
     out[2] = out[1];
 }
 
+// fp16 x 2 exchange of the backward recurrence: a block's values are scaled to |v| < 2^11 (four binades below the usual target), so every lo
+// value is <= 1/2 in magnitude and bit 14 -- the top bit of its exponent field -- is clear.  The eight lo values a consumer lane loads for a
+// k-step carry the block's 8-bit exponent there: bit c in the low half of dword c, bit 4 + c in its high half.
+constexpr unsigned XC_GX_EXP_SHIFT = 4;
+__device__ __forceinline__ float xc_take_exp(bf16x8& lo) {
+    u32x4 d = __builtin_bit_cast(u32x4, lo);
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { t[i] = d[i] & 0x40004000u; d[i] ^= t[i]; }
+    const unsigned x = (t[0] >> 14) | (t[1] >> 13) | (t[2] >> 12) | (t[3] >> 11);
+    const unsigned e = (x & 0xFu) | ((x >> 12) & 0xF0u);
+    lo = __builtin_bit_cast(bf16x8, d);
+    return __uint_as_float((e - 14u) << 23);               // = h2_inv_of_exp(e)
+}
+// maximum over an aligned group of eight lanes (DPP: the two quad exchanges, then the half-row mirror)
+__device__ __forceinline__ unsigned xc_max8(unsigned v) {
+    unsigned w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = v > w ? v : w;    // quad_perm [1, 0, 3, 2]
+    w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); v = v > w ? v : w;             // quad_perm [2, 3, 0, 1]
+    w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = v > w ? v : w;            // row_half_mirror
+    return v;
+}
+
 // plain-bf16 tier (math mode 1): one term per operand, rounded to nearest even; plane 0 of the exchange buffer carries it
 __device__ __forceinline__ bf16x8 xc_rne8(const f32x4 a, const f32x4 b) {
     bf16x8 r;
@@ -477,7 +499,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     // in registers, behind each step's hand-off; atomic unsigned max ONCE, when the kernel leaves (a per-step atomic stayed in the memory queue
     // for ~0.8 us and the next step's drain before its flag waited for it: +27 us per launch, profiles/r6_m_timeline.txt)
     __shared__ __attribute__((aligned(16))) f32x4 red[XC_KSB][2][64];
-    __shared__ __attribute__((aligned(16))) bf16x8 wlo[8][2 * XC_SPB8][64];
+    __shared__ __attribute__((aligned(16))) bf16x8 wlo[NS == 3 ? 8 : 1][2 * XC_SPB8][64];
     __shared__ int same_xcd_s;
     const unsigned my_xcc = xc_my_xcc();
     bool fast = false;                                   // see the forward kernel
@@ -506,6 +528,44 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
 
     // W_hh^T rows (unit 32 m + 16 u + r16), u = 0, 1: k-step q = (gate g, member j) covers gate rows g * H + 32 j + 8 kq .. +7
     bf16x8 wa[2][XC_SPB8][2];
+    // fp16 x 2 (NS == 2): every W_hh^T row (unit) scaled by its own power of two over its 3H columns -- they are spread over the eight K-slice waves,
+    // partial maxima meet in LDS; the exchanged operand (this step's dgh tile, a GRADIENT: no bound known) carries one power-of-two scale per
+    // (batch row, member) -- the 96 values a member's epilogue threads hold for a row.  Its exponent travels INSIDE the lo plane (xc_take_exp;
+    // a separate word per block cost 24 us per launch in extra line requests, profiles/r6_bb): a k-step's product is scaled back by its
+    // block's inverse before it joins the wave's accumulator.
+    __shared__ unsigned wmaxb[XC_KSB][2][16];
+    float wscb[2] = {1.f, 1.f};
+    if constexpr (NS == 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = m * XC_UNITS + u * 16 + r16;
+            unsigned mx = 0u;
+#pragma unroll
+            for (int p = 0; p < XC_SPB8; ++p) {
+                const int q = s_beg + p;
+                const int g = q / CW, jm = q - g * CW;
+                const int ku = 32 * jm + 8 * kq;
+                const bool ok = p < s_cnt && j < H;
+                const float* src = wt + (long)(ok ? j : 0) * H3 + (ok ? g * H + ku : 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned v = (ok && ku + i < H) ? __float_as_uint(src[i]) & 0x7fffffffu : 0u;
+                    mx = mx > v ? mx : v;
+                }
+            }
+            unsigned w = (unsigned)__shfl_xor((int)mx, 16, 64); mx = mx > w ? mx : w;
+            w = (unsigned)__shfl_xor((int)mx, 32, 64); mx = mx > w ? mx : w;
+            if (kq == 0) wmaxb[ks][u][r16] = mx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            unsigned mx = wmaxb[0][u][r16];
+#pragma unroll
+            for (int k = 1; k < XC_KSB; ++k) { const unsigned v = wmaxb[k][u][r16]; mx = mx > v ? mx : v; }
+            wscb[u] = h2_scale_of_exp(h2_exp_of_bits(mx));
+        }
+    }
     {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -522,9 +582,10 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
                 const f32x4 b = (ok && ku + 4 < H) ? *reinterpret_cast<const f32x4*>(src + 4) : z;
                 bf16x8 pl[3];
                 if constexpr (NS == 1) { pl[0] = xc_rne8(a, b); pl[1] = pl[2] = pl[0]; }
+                else if constexpr (NS == 2) xc_split8_h2(a, b, wscb[u], pl);
                 else xc_split8(a, b, pl);
                 wa[u][p][0] = pl[0]; wa[u][p][1] = pl[1];
-                wlo[wave][u * XC_SPB8 + p][lane] = pl[2];
+                if constexpr (NS == 3) wlo[wave][u * XC_SPB8 + p][lane] = pl[2];
             }
     }
     __syncthreads();
@@ -536,6 +597,17 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
     const int unit0 = m * XC_UNITS + 4 * ug;
     const bool e_ok = epi && row < B && unit0 < H;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 winvb = {1.f, 1.f, 1.f, 1.f};                // fp16 x 2: 1 / scale of W_hh^T's rows = this thread's four units
+    if constexpr (NS == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = (4 * ug + q) & 15;
+            unsigned mx = wmaxb[0][e_ut][rr];
+#pragma unroll
+            for (int k = 1; k < XC_KSB; ++k) { const unsigned v = wmaxb[k][e_ut][rr]; mx = mx > v ? mx : v; }
+            winvb[q] = h2_inv_of_exp(h2_exp_of_bits(mx));
+        }
+    }
     f32x4 dhz = zero;                                  // dh * z of the step processed before
 
     const int plane_bytes = b_pad * 64;
@@ -599,18 +671,40 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
             if (step == 1) fast = __builtin_amdgcn_readfirstlane(same_xcd_s) != 0;
             const int off0 = (dir * 2 + ((step - 1) & 1)) * slot_bytes + b0 * 64;
             bf16x8 fb[XC_SPB8][NS];
+            if constexpr (NS == 2) {
+                // no branch around a k-step this wave does not own (p >= s_cnt): its loads go out of bounds (zeros) and its product is scaled by 0,
+                // so all eight loads are in flight together and the exponent decode overlaps the first products
+                float binv[XC_SPB8];                           // 1 / scale of (this lane's batch row, the k-step's member)
 #pragma unroll
-            for (int p = 0; p < XC_SPB8; ++p)
-                if (p < s_cnt) {
+                for (int p = 0; p < XC_SPB8; ++p) {
+                    const unsigned vo = p < s_cnt ? (unsigned)(r16 * 64 + kq * 16) : 0x80000000u;
+                    const int so = off0 + (p < s_cnt ? (s_beg + p) * 3 : 0) * plane_bytes;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        fb[p][s] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(gx_rsrc, r16 * 64 + kq * 16, off0 + ((s_beg + p) * 3 + s) * plane_bytes, 16));
+                    for (int s = 0; s < NS; ++s) fb[p][s] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(gx_rsrc, vo, so + s * plane_bytes, 16));
                 }
 #pragma unroll
-            for (int p = 0; p < XC_SPB8; ++p) {
-                if (p < s_cnt) {
+                for (int p = 0; p < XC_SPB8; ++p) {
+                    const float bi = xc_take_exp(fb[p][1]);
+                    binv[p] = p < s_cnt ? bi : 0.f;
+                }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[u] = xc_mma<NS>(wa[u][p], wlo[wave][u * XC_SPB8 + p][lane], fb[p], acc[u]);
+                for (int p = 0; p < XC_SPB8; ++p)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[u] += xc_mma<NS>(wa[u][p], wa[u][p][1], fb[p], zero) * binv[p];
+            } else {
+#pragma unroll
+                for (int p = 0; p < XC_SPB8; ++p)
+                    if (p < s_cnt) {
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+                            fb[p][s] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(gx_rsrc, r16 * 64 + kq * 16, off0 + ((s_beg + p) * 3 + s) * plane_bytes, 16));
+                    }
+#pragma unroll
+                for (int p = 0; p < XC_SPB8; ++p) {
+                    if (p < s_cnt) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) acc[u] = xc_mma<NS>(wa[u][p], wlo[wave][u * XC_SPB8 + p][lane], fb[p], acc[u]);
+                    }
                 }
             }
         }
@@ -623,6 +717,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
             f32x4 s = red[0][e_ut][e_lane];
 #pragma unroll
             for (int q = 1; q < XC_KSB; ++q) s += red[q][e_ut][e_lane];
+            if constexpr (NS == 2) s *= winvb;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float dyq = dy_mask ? dy[q] * dm[q] : dy[q];
@@ -637,6 +732,27 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_cluster_x3_kernel(
             const int woff = (dir * 2 + (step & 1)) * slot_bytes + row * 64 + ug * 8;
             u32x2 pl[3][3];
             if constexpr (NS == 1) { pl[0][0] = xc_rne4(g_r); pl[1][0] = xc_rne4(g_z); pl[2][0] = xc_rne4(g_nr); }
+            else if constexpr (NS == 2) {
+                // one power of two for the row's 96 values of this member: over this thread's twelve, then over the row's eight threads
+                unsigned mx = 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned b0_ = __float_as_uint(g_r[q]) & 0x7fffffffu, b1_ = __float_as_uint(g_z[q]) & 0x7fffffffu, b2_ = __float_as_uint(g_nr[q]) & 0x7fffffffu;
+                    const unsigned t3 = b0_ > b1_ ? (b0_ > b2_ ? b0_ : b2_) : (b1_ > b2_ ? b1_ : b2_);
+                    mx = mx > t3 ? mx : t3;
+                }
+                mx = xc_max8(mx);
+                const unsigned eb = (unsigned)h2_exp_of_bits(mx) + XC_GX_EXP_SHIFT;
+                const float sc = h2_scale_of_exp((int)eb);
+                xc_split4_h2(g_r, sc, pl[0]); xc_split4_h2(g_z, sc, pl[1]); xc_split4_h2(g_nr, sc, pl[2]);
+                // the exponent rides in bit 14 of the lo plane's values (clear by the choice of scale): the consumer's 16-byte chunk is two threads'
+                // values = dwords c = 2 (ug & 1) + k, dword c carries bit c (low half) and bit 4 + c (high half)
+                const int c0 = 2 * (ug & 1);
+                const unsigned in0 = (((eb >> c0) & 1u) << 14) | (((eb >> (4 + c0)) & 1u) << 30);
+                const unsigned in1 = (((eb >> (c0 + 1)) & 1u) << 14) | (((eb >> (5 + c0)) & 1u) << 30);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) { pl[g][1][0] |= in0; pl[g][1][1] |= in1; }
+            }
             else { xc_split4(g_r, pl[0]); xc_split4(g_z, pl[1]); xc_split4(g_nr, pl[2]); }
             if (fast) {
 #pragma unroll
@@ -715,6 +831,12 @@ using namespace tg;
 
 extern "C" int tg_get_math_mode(void);
 
+// fp32-accurate mode: fp16 x 2 operands in both recurrences; TG_GRU_H2 is a mask for A/B timing (1 = forward, 2 = backward; 0 = bf16 x 3 in both)
+static int gru_h2_on() {
+    static const int h2 = [] { const char* e = getenv("TG_GRU_H2"); return e ? atoi(e) : 3; }();
+    return h2;
+}
+
 // exchange-buffer bytes of the two kernels (the flag block in front of it is laid out by gru_cluster.hip)
 int64_t tg_gru_x3_fwd_exchange_bytes(int b_pad, int cw) { return 4LL * cw * 3 * b_pad * 64; }
 int64_t tg_gru_x3_bwd_exchange_bytes(int b_pad, int cw) { return 4LL * 3 * cw * 3 * b_pad * 64; }
@@ -743,7 +865,7 @@ int tg_gru_x3_fwd_launch(int mt, const float* gi, long gi_ds, const float* w0, c
 #endif
     // fp32-accurate mode: fp16 x 2 operands (3 matrix instructions per product: h * 2^14 and per-row scaled W_hh as hi / lo fp16 planes) unless
     // TG_GRU_H2=0 asks for bf16 x 3 (6; A/B timing)
-    static const int h2 = [] { const char* e = getenv("TG_GRU_H2"); return e ? atoi(e) : 1; }();
+    const int h2 = gru_h2_on() & 1;
     if (mt == 1) { if (bf16) TG_XF(1, 1); else if (h2) TG_XF(1, 2); else TG_XF(1, 3); }
     else { if (bf16) TG_XF(2, 1); else if (h2) TG_XF(2, 2); else TG_XF(2, 3); }
 #undef TG_XF
@@ -756,6 +878,9 @@ int tg_gru_x3_bwd_launch(const float* dy, const float* dy_mask, const float* y, 
                          hipStream_t s) {
     if (tg_get_math_mode() == 1)
         hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel<1>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, dy_mask, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
+                           flags, tmo, B, T, H, n_bt, cw, b_pad, gi_rmax, rm_ds, gi_cmax, gh_cmax);
+    else if (gru_h2_on() & 2)
+        hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel<2>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, dy_mask, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
                            flags, tmo, B, T, H, n_bt, cw, b_pad, gi_rmax, rm_ds, gi_cmax, gh_cmax);
     else
         hipLaunchKernelGGL(gru_seq_bwd_cluster_x3_kernel<3>, dim3(2 * n_bt * cw), dim3(512), 0, s, dy, dy_mask, y, save, save_ds, wt0, wt1, dgi, dgh, dg_ds, gx,
