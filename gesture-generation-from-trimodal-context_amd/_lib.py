@@ -66,6 +66,7 @@ SIGNATURES = {
     "tg_gru_h64_backward": [P, P, P, P, I64, P, P, P, P, I64, I32, I32, P],
     "tg_gru_forward_cluster": [P, I64, P, P, P, P, P, P, I64, P, P, P, I64, I32, I32, I32, P],
     "tg_gru_forward_cluster_rows": [P, I64, P, P, P, P, P, P, I64, P, P, P, I64, I32, I32, I32, I32, I32, P],
+    "tg_gru_forward_vec": [P, I64, P, P, P, P, P, P, I64, I32, I32, I32, P],
     "tg_gru_backward_cluster": [P, P, P, P, I64, P, P, P, P, I64, P, I64, I32, I32, I32, P],
     "tg_gru_backward_cluster_stats": [P, P, P, P, I64, P, P, P, P, I64, P, I64, I32, I32, I32, P, I64, P, P, P],
     "tg_bn_train_stats": [P, I32, I32, I32, P, P, P, P, P, P, F32, F32, I32, P],
@@ -138,7 +139,7 @@ SIGNATURES = {
     "tg_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, P, P],
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 
@@ -182,6 +183,12 @@ def load():
     lib.tg_gru_cluster_supported.argtypes = [I32, I32]
     lib.tg_gru_cluster_ws_bytes.restype = C.c_int64
     lib.tg_gru_cluster_ws_bytes.argtypes = [I32, I32]
+    lib.tg_gru_vec_supported.restype = C.c_int32
+    lib.tg_gru_vec_supported.argtypes = [I32, I32]
+    lib.tg_gru_vec_ws_bytes.restype = C.c_int64
+    lib.tg_gru_vec_ws_bytes.argtypes = [I32]
+    lib.tg_gru_vec_ws_header_bytes.restype = C.c_int32
+    lib.tg_gru_vec_ws_header_bytes.argtypes = []
     lib.tg_gru_cluster_bwd_supported.restype = C.c_int32
     lib.tg_gru_cluster_bwd_supported.argtypes = [I32, I32]
     lib.tg_gru_cluster_bwd_ws_bytes.restype = C.c_int64

@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtGroup g) {
 #pragma unroll
                             for (int nt = 0; nt < 2; ++nt)
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][v], fb[nt][v], acc[mt][nt], 0, 0, 0);
-                    load(jc);                               // the k-step R ahead (past K: a valid address, masked)
+                    // the k-step R ahead (past K: a valid address, masked); a ring sized to hold a whole K range (R >= 8, the few-row decode
+                    // products) skips the refill once nothing is left -- its single pass then ends without a second memory latency
+                    if constexpr (R >= 8) { if (k0 + 16 * R < K) load(jc); }
+                    else load(jc);
                 }
             });
         }
@@ -775,8 +778,11 @@ static int nt_launch(NtGroup& g, hipStream_t s) {
             // a handful of 64 x 64 tiles with a long reduction and at most 576 rows (a synthesis window of up to 16 utterances: [34 x 300 x 600]
             // text-encoder convs are five workgroups walking 150 dependent k-steps each, 25 us): 32 x 32 tiles whose four waves split K --
             // four times the workgroups, an eighth of the chain: ~11 us (round 6: one utterance 883 -> 723 us per window, profiles/r6_z_decode_b1.txt)
+            // Ring of ten k-steps when a wave's K range fits it (K <= 640): every operand of the wave is requested before its first MFMA, one
+            // memory latency per launch instead of five (the ring of two held 32 of a wave's 150 k: 11.4 -> see profiles/r6_bg_decode_ring.txt)
             const dim3 grid4(nt_layout(g, 32, 32));
-            hipLaunchKernelGGL((gemm_nt_kernel<true, 1, 1, 2, 4>), grid4, dim3(256), 0, s, g);
+            if (Kx <= 640) hipLaunchKernelGGL((gemm_nt_kernel<true, 1, 1, 10, 4>), grid4, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((gemm_nt_kernel<true, 1, 1, 2, 4>), grid4, dim3(256), 0, s, g);
             return check_launch("tg_gemm_nt");
         }
         if (fam == 1) {

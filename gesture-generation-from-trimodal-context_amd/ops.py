@@ -623,6 +623,31 @@ def _gru_cluster_ws(dev, B, H, bwd=False):
     return ws
 
 
+_gru_vec_ws_cache = {}
+GRU_VEC = os.environ.get("TG_GRU_VEC", "1") != "0"      # the few-row inference recurrence (csrc/gru_vec.hip) for B <= 4 forwards without saved gates
+
+
+def _gru_vec_fill(ws):
+    hdr = _lib.load().tg_gru_vec_ws_header_bytes() // 4
+    ws.fill_(-1)                 # every exchange word = the sentinel (all ones)
+    ws[:hdr].zero_()             # timeout block and launch counter
+    return ws
+
+
+def _gru_vec_ws(dev, H):
+    key = (dev, H)
+    ws = _gru_vec_ws_cache.get(key)
+    if ws is None:
+        ws = _gru_vec_fill(torch.empty((_lib.load().tg_gru_vec_ws_bytes(H) + 3) // 4, dtype=torch.int32, device=dev))
+        _gru_vec_ws_cache[key] = ws
+    return ws
+
+
+def gru_vec_takes(B, H, save, drop_mask):
+    """Will gru_forward run the few-row inference kernel for this call?"""
+    return bool(GRU_VEC and H > 64 and save is None and drop_mask is None and _lib.load().tg_gru_vec_supported(int(B), int(H)))
+
+
 _cluster_caps = {}
 
 
@@ -702,6 +727,12 @@ def check_async_errors():
         if int(ws[0].item()) != 0:
             ws.zero_()              # counters of the aborted launch are out of step: back to the state of a fresh allocation
             raise RuntimeError(f"fused discriminator front end timed out at a device-wide barrier (device, Bs) = {key}; results are invalid")
+    for key, ws in _gru_vec_ws_cache.items():
+        if int(ws[0].item()) != 0:
+            info = ws[:3].tolist()
+            _gru_vec_fill(ws)       # exchange words of the aborted launch are out of step: back to the state of a fresh allocation
+            raise RuntimeError(f"few-row GRU kernel timed out waiting for a member's h words (device, H) = {key}: step {info[1]}, workgroup {info[2]}; "
+                               "results are invalid")
     for key, ws in _gru_ws.items():
         if int(ws[0].item()) != 0:
             info = ws[:14].tolist()
@@ -740,6 +771,11 @@ def gru_forward(gi, w_hh, b_hh, y, save, drop_mask=None, y_drop=None, save_rows=
             assert tuple(drop_mask.shape) == tuple(y.shape) == tuple(y_drop.shape)
         call("tg_gru_h64_forward", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), _p(save),
              B * T * 4 * H, _p(drop_mask), _p(y_drop), B, T, _stream())
+        return y
+    if gru_vec_takes(B, H, save, drop_mask):
+        ws = _gru_vec_ws(gi.device, H)
+        call("tg_gru_forward_vec", _p(gi), B * T * H3, _p(w_hh[0]), _p(w_hh[1]), _p(b_hh[0]), _p(b_hh[1]), _p(y), C.c_void_p(ws.data_ptr()), ws.numel() * 4,
+             B, T, H, _stream())
         return y
     chunks = gru_cluster_chunks(B, H) if (GRU_CLUSTER and H > 64) else None
     if chunks is not None:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 7
+#define TG_ABI_VERSION 8
 
 int tg_version(void);
 
@@ -298,6 +298,18 @@ int tg_gru_forward_cluster_rows(const float* gi, int64_t gi_dir_stride, const fl
                                 const float* b_hh_fwd, const float* b_hh_rev, float* y, float* save, int64_t save_dir_stride,
                                 const float* drop_mask, float* y_drop, void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H,
                                 int32_t save_row0, int32_t save_rows, void* stream);
+
+/* Inference recurrence for a handful of sequences (1 <= B <= 4, 64 < H <= 320): the single-utterance synthesis window of
+ * scripts/synthesize.py:131-160 (one 34-frame window per generator call; multimodal_context_net.py:155, nn.GRU bidirectional, eval mode: no
+ * saved gates, no dropout).  h_t is exchanged as fp32 words that are their own flags (sentinel-polled), the product is fp32 FMAs on resident
+ * fp32 weights: no operand split at all, results at fp32 rounding of the reference's (csrc/gru_vec.hip).  Same operand layout as
+ * tg_gru_forward.  Workspace: tg_gru_vec_ws_bytes(H) bytes whose first tg_gru_vec_ws_header_bytes() are ZERO and every byte behind them 0xFF
+ * before the first use (and again after a timeout: word 0 is the sticky timeout word of tg_gru_forward_cluster's convention). */
+int32_t tg_gru_vec_supported(int32_t B, int32_t H);
+int64_t tg_gru_vec_ws_bytes(int32_t H);
+int32_t tg_gru_vec_ws_header_bytes(void);
+int tg_gru_forward_vec(const float* gi, int64_t gi_dir_stride, const float* w_hh_fwd, const float* w_hh_rev, const float* b_hh_fwd,
+                       const float* b_hh_rev, float* y, void* ws, int64_t ws_bytes, int32_t B, int32_t T, int32_t H, void* stream);
 
 /* Persistent cluster-synchronised variant of tg_gru_backward (B <= 192 at H = 300; no dh_scratch: the carried dh stays in
  * registers).  Same workspace / timeout-word convention as tg_gru_forward_cluster. */

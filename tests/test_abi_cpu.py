@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol(pkg):
     bound = set(pkg._lib.SIGNATURES) | {"tg_version", "tg_last_error", "tg_gemm_tn_ws_floats", "tg_set_math_mode", "tg_get_math_mode", "tg_set_deterministic", "tg_get_deterministic", "tg_set_tn_workgroup_cap", "tg_get_tn_workgroup_cap",
                                          "tg_gru_cluster_supported", "tg_gru_cluster_ws_bytes", "tg_gru_cluster_bwd_supported",
                                          "tg_gru_cluster_bwd_ws_bytes", "tg_gemm_nt_family", "tg_gemm_nt_ext_supported", "tg_gemm_nt_kernel_plan", "tg_gemm_tn_kernel_plan", "tg_set_nt_mover_waves", "tg_bn_fused_supported", "tg_gru_cluster_fused_dropout", "tg_ae_step_ws_bytes", "tg_ae_step_supported",
-                                         "tg_wav_front_ws_doubles", "tg_wav_front_fstat_doubles", "tg_wav_front_gate_words", "tg_bn2_supported", "tg_bn2_ws_doubles", "tg_speaker_bwd_max_rows", "tg_wav_conv2_wgrad_ws_floats", "tg_d_preconv_fwd_supported", "tg_d_preconv_ws_bytes"}
+                                         "tg_wav_front_ws_doubles", "tg_wav_front_fstat_doubles", "tg_wav_front_gate_words", "tg_bn2_supported", "tg_bn2_ws_doubles", "tg_speaker_bwd_max_rows", "tg_wav_conv2_wgrad_ws_floats", "tg_d_preconv_fwd_supported", "tg_d_preconv_ws_bytes",
+                                         "tg_gru_vec_supported", "tg_gru_vec_ws_bytes", "tg_gru_vec_ws_header_bytes"}
     assert declared == bound, declared ^ bound
     lib.tg_version.restype = ctypes.c_int
     assert lib.tg_version() == pkg._lib.ABI_VERSION

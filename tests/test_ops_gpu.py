@@ -1522,3 +1522,41 @@ def test_absmax_rows_cols(pkg, dev):
     assert torch.equal(rm, x.abs().amax(dim=1)) and torch.equal(cm, x.view(2, 1234, 900).abs().amax(dim=1))
     _, cm1 = ops.absmax_rows_cols(x)
     assert torch.equal(cm1.view(-1), x.abs().amax(dim=0))
+
+
+# ------------------------------------------------------------------------------------------------ few-row inference recurrence (ABI 8)
+@pytest.mark.parametrize("H", [300, 128, 320])
+def test_gru_vec_inference_recurrence(pkg, dev, H):
+    """csrc/gru_vec.hip (1 <= B <= 4 sequences, no saved gates) against torch.nn.GRU in fp64 and against the cluster kernels, launch after
+    launch on ONE workspace: the two exchange buffers alternate between launches, the batch size (row count template) and T change in
+    between, so every launch must find its buffer all-sentinel whatever the previous one left behind.  A stale or missed hand-off word would
+    show as an O(1e-2) error; the kernel's arithmetic is plain fp32."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(H)
+    gru = torch.nn.GRU(8, H, num_layers=1, batch_first=True, bidirectional=True).double()
+    w = [gru.weight_hh_l0.detach().float().to(dev).contiguous(), gru.weight_hh_l0_reverse.detach().float().to(dev).contiguous()]
+    b = [gru.bias_hh_l0.detach().float().to(dev).contiguous(), gru.bias_hh_l0_reverse.detach().float().to(dev).contiguous()]
+    wi = [gru.weight_ih_l0.detach(), gru.weight_ih_l0_reverse.detach()]
+    bi = [gru.bias_ih_l0.detach(), gru.bias_ih_l0_reverse.detach()]
+    assert ops.GRU_VEC
+    for B, T in [(1, 34), (4, 34), (2, 7), (1, 2), (3, 34), (1, 1), (1, 34), (4, 5), (1, 34), (1, 34)]:
+        assert ops.gru_vec_takes(B, H, None, None)
+        x = torch.randn(B, T, 8, generator=g, dtype=torch.float64)
+        with torch.no_grad():
+            ref, _ = gru(x)
+        gi = torch.stack([x @ wi[d].t() + bi[d] for d in range(2)]).float().to(dev).contiguous()
+        y = torch.full((B, T, 2 * H), float("nan"), device=dev)
+        ops.gru_forward(gi, w, b, y, None)
+        ops.check_async_errors()
+        assert bool(torch.isfinite(y).all()), (B, T)
+        assert float((y.double().cpu() - ref).abs().max()) < 5e-6, (B, T, float((y.double().cpu() - ref).abs().max()))
+        if H == 300 and T == 34:
+            prev = ops.GRU_VEC
+            ops.GRU_VEC = False
+            try:
+                yc = ops.gru_forward(gi, w, b, torch.empty_like(y), None)
+            finally:
+                ops.GRU_VEC = prev
+            assert float((y - yc).abs().max()) < 3e-6
+    # not taken: more rows, saved gates
+    assert not ops.gru_vec_takes(5, 300, None, None) and not ops.gru_vec_takes(1, 300, torch.empty(1), None) and not ops.gru_vec_takes(1, 64, None, None)
