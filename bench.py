@@ -203,6 +203,14 @@ def decode_kernel_roofline(pkg, device, batch):
     dt = time_kernel(lambda: ops.gru_forward(gi, w, b, y, None), iters=20)
     ops.check_async_errors()
     flops = (T - 1) * 2 * batch * H * 3 * H * 2
+    if ops.gru_vec_takes(batch, H, None, None):
+        # a handful of utterances: the few-row kernel (csrc/gru_vec.hip) -- fp32 FMAs on resident fp32 weights, no matrix instruction at all; priced
+        # against the fp32 VECTOR peak (256 CUs x 4 SIMDs x 16 lanes x 2 FLOP x 2.4 GHz = 78.6 TFLOP/s); what bounds it is the per-step hand-off
+        peak_valu = 256 * 4 * 16 * 2 * 2.4e9
+        return {"kernel": "gru_seq_fwd_vec_kernel<rows = %d> (eval, B = utterances <= 4)" % (1 if batch == 1 else 2 if batch == 2 else 4), "bound": "valu",
+                "achieved": flops / dt / 1e12, "peak": peak_valu / 1e12, "unit": "TFLOP/s", "frac": flops / dt / peak_valu, "traffic": None,
+                "launch_us": dt * 1e6, "flop_per_launch": flops, "us_per_step": dt * 1e6 / T,
+                "note": "latency-bound: one memory round trip per step (fp32 exchange words polled against a sentinel), 20 of 256 CUs; fp32 arithmetic"}
     return {"kernel": "gru_seq_fwd_cluster_x3_kernel (eval, B = utterances)", "bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12,
             "unit": "TFLOP/s", "frac": flops / dt / PEAK_F32_MFMA, "traffic": None, "launch_us": dt * 1e6, "flop_per_launch": flops,
             "us_per_step": dt * 1e6 / T, "note": "latency-bound per-step hand-off chain of the recurrence; fp32-accurate product on the bf16 matrix cores"}

@@ -16,6 +16,40 @@ def empty(*shape, like=None, device=None, dtype=torch.float32):
     return torch.empty(*shape, device=like.device if like is not None else device, dtype=dtype)
 
 
+# ----------------------------------------------------------------------------------------------- weights that stand still
+_FROZEN = None          # the memo of the active FrozenWeights scope
+
+
+class FrozenWeights:
+    """A scope in which the model's parameters and buffers do NOT change -- one synthesis call (scripts/synthesize.py:36-209 runs the generator in
+    eval mode, window after window, on fixed weights).  Inside it the operands of the eval forward that depend on weights only -- the
+    weight-normed TCN kernels, conv packs, eval-mode BatchNorm scale / shift, the composed output map -- are computed on first use and reused
+    by every later window (and left OUT of a window graph captured after the first, eager, window): 12 launches of the 54 a window had."""
+
+    def __init__(self):
+        self.memo = {}
+
+    def __enter__(self):
+        global _FROZEN
+        self._prev, _FROZEN = _FROZEN, self.memo
+        return self
+
+    def __exit__(self, *exc):
+        global _FROZEN
+        _FROZEN = self._prev
+        return False
+
+
+def frozen(key, make):
+    """make() once per FrozenWeights scope and key (a tag + the data pointers of the weights it reads); plain make() outside a scope."""
+    if _FROZEN is None:
+        return make()
+    v = _FROZEN.get(key)
+    if v is None:
+        v = _FROZEN[key] = make()
+    return v
+
+
 class WeightPrep:
     """Weight-derived GEMM operands (transposes, conv packs, bf16 planes) of slab-resident parameters, refreshed ONCE per optimiser step by
     batched launches instead of one small permute launch per use (~60 per training iteration = 0.26 ms of launch overhead).
@@ -201,11 +235,23 @@ def transpose2d(w):
     return out
 
 
+def _pack_frozen(w):
+    Co, Ci, kw = w.shape
+
+    def make():
+        out = empty(Co, kw * Ci, like=w)
+        ops.permute3(w, out, (0, 2, 1))
+        return out
+    return frozen(("pack", w.data_ptr(), Co, Ci, kw), make)
+
+
 def pack_conv_weight(w):
     """nn.Conv1d weight (Co, Ci, kw) -> tap-major [Co, kw*Ci], the B operand of the conv-as-GEMM."""
     Co, Ci, kw = w.shape
     if Ci == 1 or kw == 1:
         return w.reshape(Co, Ci * kw)          # same memory order
+    if _FROZEN is not None:
+        return _pack_frozen(w)
     if _PREP is not None and w.is_contiguous():
         hit = _PREP.get(w, (0, 2, 1), (Co, kw * Ci))
         if hit is not None:
@@ -383,6 +429,14 @@ class BNState:
     __slots__ = ("mean", "rstd", "groups", "x", "slope")
 
 
+def _eval_stats(running_mean, running_var, mean, rstd):
+    """Eval-mode BatchNorm's (mean, 1 / sqrt(var + eps)) from the running statistics: buffers, so once per FrozenWeights scope."""
+    def make():
+        ops.bn_eval_stats(running_mean, running_var, mean, rstd)
+        return mean, rstd
+    return frozen(("bn_eval", running_mean.data_ptr(), running_var.data_ptr()), make)
+
+
 def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, *, training, groups=1, act_slope=1.0, out=None, repeats=1):
     """x: (..., C) contiguous channel-last.  Returns (y, BNState)."""
     Cc = x.shape[-1]
@@ -403,7 +457,7 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, *, training, groups=1
         ws = torch.empty(2 * g * Cc, device=x.device, dtype=torch.float64)
         ops.bn_train_stats(x2, g, ws, st.mean, st.rstd, running_mean, running_var, nbt, repeats=repeats)
     else:
-        ops.bn_eval_stats(running_mean, running_var, st.mean, st.rstd)
+        st.mean, st.rstd = _eval_stats(running_mean, running_var, st.mean, st.rstd)
     y = torch.empty_like(x) if out is None else out
     ops.bn_apply(x2, y.view(-1, Cc), g, st.mean, st.rstd, gamma, beta, act_slope)
     return y, st
@@ -465,7 +519,7 @@ def wav_front_fwd(audio, w, b, gamma, beta, running_mean, running_var, nbt, *, s
             ops.wav_front_stats(audio[q * per:(q + 1) * per], w, b, stride, pad, st.mean[q], st.rstd[q], running_mean, running_var, nbt,
                                 st.fstat[q], repeats=repeats)
     else:
-        ops.bn_eval_stats(running_mean, running_var, st.mean, st.rstd)
+        st.mean, st.rstd = _eval_stats(running_mean, running_var, st.mean, st.rstd)
     for q in range(g):
         sl = slice(q * per, (q + 1) * per)
         ops.wav_front_apply(audio[sl], w, b, stride, pad, st.mean[q], st.rstd[q], gamma, beta, act_slope, y[sl],

@@ -15,7 +15,7 @@ import random
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, layers as L
 
 
 def words_in_time_range(word_list, start_time, end_time):
@@ -80,6 +80,9 @@ class WindowDecoder:
         self.tail = torch.zeros(batch, self.n_pre, self.D, device=device)
         self.seedwin = torch.zeros(batch, self.T, self.D, device=device)
         self.use_graph, self.graph = graph, None
+        # the generator's weights stand still for the lifetime of a decoder (one synthesis call): weight-only operands are formed by the first
+        # window and kept (layers.FrozenWeights) -- a decoder must not outlive a change of the parameters
+        self.frozen = L.FrozenWeights()
         pose_decoder.train(False)
 
     def seed(self, seed_seq=None):
@@ -113,7 +116,7 @@ class WindowDecoder:
             self.vid.copy_(vid, non_blocking=True)
         if draw is not None:
             self.draw.copy_(draw, non_blocking=True)
-        with torch.no_grad():
+        with torch.no_grad(), self.frozen:
             if not self.use_graph or first:
                 self._forward(first)
             else:
