@@ -1560,3 +1560,53 @@ def test_gru_vec_inference_recurrence(pkg, dev, H):
             assert float((y - yc).abs().max()) < 3e-6
     # not taken: more rows, saved gates
     assert not ops.gru_vec_takes(5, 300, None, None) and not ops.gru_vec_takes(1, 300, torch.empty(1), None) and not ops.gru_vec_takes(1, 64, None, None)
+
+
+def test_gru_backward_cluster_fp16x2_on_rows_of_very_different_scale(pkg, dev):
+    """The backward cluster recurrence exchanges a GRADIENT tile as fp16 x 2 planes: its producer scales every (batch row, member) block by the
+    block's own power of two and ships the exponent inside the lo plane (csrc/gru_cluster_x3.hip, xc_take_exp).  Rows of one launch whose
+    gradients differ by six decades -- what a mean over clips of different loss scale hands back -- must each come out at fp32 accuracy
+    RELATIVE TO THAT ROW (a shared scale would lose the small rows entirely, a wrong exponent bit shows as a factor of two), against an fp64
+    restatement of the recurrence on the same taped forward (multimodal_context_net.py:155, nn.GRU backward)."""
+    ops = pkg.ops
+    T, H = 34, 300
+    for B, scale in ((128, 1.0), (37, 1e-3), (64, 1e3)):
+        g = torch.Generator().manual_seed(11 + B)
+        gi = (torch.randn(2, B, T, 3 * H, generator=g) * 0.5).to(dev)
+        w = [(torch.randn(3 * H, H, generator=g) * 0.08).to(dev) for _ in range(2)]
+        b = [(torch.randn(3 * H, generator=g) * 0.05).to(dev) for _ in range(2)]
+        y = torch.empty(B, T, 2 * H, device=dev); sv = torch.empty(2, B, T, 4 * H, device=dev)
+        ops.gru_forward(gi, w, b, y, sv)
+        dy = (torch.randn(B, T, 2 * H, generator=g) * scale * torch.logspace(-5, 1, B).view(B, 1, 1)).to(dev)
+        dy[B // 2] = 0.0                                             # a row without any gradient: all-zero blocks
+        wt = [x.t().contiguous() for x in w]
+        dgi = torch.full((2, B, T, 3 * H), float("nan"), device=dev); dgh = torch.full_like(dgi, float("nan"))
+        ops.gru_backward(dy, y, sv, wt, dgi, dgh, torch.zeros(4 * B * H, device=dev))
+        ops.check_async_errors()
+        assert ops.gru_cluster_chunks(B, H, bwd=True) is not None     # the cluster kernel is what ran
+        # fp64 restatement from the taped gates (sv = r, z, n, W_hn h + b_hn per step)
+        r_gi, r_gh = [], []
+        for d in range(2):
+            W = w[d].double()
+            yd, s, dyd = y[..., d * H:(d + 1) * H].double(), sv[d].double(), dy[..., d * H:(d + 1) * H].double()
+            dh = torch.zeros(B, H, dtype=torch.float64, device=dev)
+            a, c = torch.zeros(B, T, 3 * H, dtype=torch.float64, device=dev), torch.zeros(B, T, 3 * H, dtype=torch.float64, device=dev)
+            for t in (range(T - 1, -1, -1) if d == 0 else range(T)):
+                tp = t - 1 if d == 0 else t + 1
+                hp = yd[:, tp] if 0 <= tp < T else torch.zeros(B, H, dtype=torch.float64, device=dev)
+                r, z, n, hn = s[:, t, :H], s[:, t, H:2 * H], s[:, t, 2 * H:3 * H], s[:, t, 3 * H:]
+                dht = dyd[:, t] + dh
+                dn = dht * (1 - z) * (1 - n * n)
+                dz = dht * (hp - n) * z * (1 - z)
+                dr = dn * hn * r * (1 - r)
+                a[:, t] = torch.cat([dr, dz, dn], 1); c[:, t] = torch.cat([dr, dz, dn * r], 1)
+                dh = dht * z + c[:, t] @ W
+            r_gi.append(a); r_gh.append(c)
+        r_gi, r_gh = torch.stack(r_gi), torch.stack(r_gh)
+        assert bool(torch.isfinite(dgi).all()) and bool(torch.isfinite(dgh).all())
+        rowmax = r_gi.abs().amax(dim=(0, 2, 3)).view(1, B, 1, 1)
+        live = (rowmax > 0).expand_as(r_gi)
+        e_gi = float((((dgi.double() - r_gi).abs() / rowmax.clamp_min(1e-300))[live]).max())
+        e_gh = float((((dgh.double() - r_gh).abs() / rowmax.clamp_min(1e-300))[live]).max())
+        assert e_gi < 1e-6 and e_gh < 1e-6, (B, scale, e_gi, e_gh)
+        assert float(dgi[:, B // 2].abs().max()) == 0.0 and float(dgh[:, B // 2].abs().max()) == 0.0
