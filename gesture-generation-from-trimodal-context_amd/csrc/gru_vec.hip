@@ -225,11 +225,16 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_vec_kernel(
 
 using namespace tg;
 
-static int vec_cus() {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return n;
+static int vec_cus() {                  // CU count of the current device (queried once per device; 0: no usable device)
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 0; }
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        cached[dev] = n > 0 ? n : -1;
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
 }
 
 // B rows of an inference forward this kernel takes: 1 .. 4 sequences, 64 < H <= 320 (H % 4 == 0), and a device on which the 2 * ceil(H / 32)
