@@ -635,6 +635,8 @@ def _gru_vec_fill(ws):
 
 
 def _gru_vec_ws(dev, H):
+    """One workspace per (device, H), like the cluster kernels': launches that share it must be stream-ordered (two decoders replaying on
+    different streams at the same time would need one each)."""
     key = (dev, H)
     ws = _gru_vec_ws_cache.get(key)
     if ws is None:
