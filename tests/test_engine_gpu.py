@@ -1260,6 +1260,55 @@ def test_ragged_batch_synthesis(pkg, dev):
         assert np.abs(a - c).max() <= 1e-5 * max(1.0, np.abs(c).max())   # replayed graph == eager launches
 
 
+def test_window_decoder_forms_weight_only_operands_once_and_a_new_decoder_sees_new_weights(pkg, dev):
+    """synthesize.WindowDecoder keeps the weight-only operands of the eval forward (weight-normed TCN kernels, conv packs, eval BatchNorm scale /
+    shift, the composed output map) for its lifetime (layers.FrozenWeights; one synthesis call runs on fixed weights, synthesize.py:36-209).
+    (a) A decoder's replayed windows equal eager windows computed WITHOUT the memo.  (b) After the parameters changed, a NEW decoder must give
+    the new weights' result -- nothing of the memo survives the decoder that owns it."""
+    from importlib import import_module
+    syn = import_module(pkg.__name__ + ".synthesize")
+    L = pkg.layers
+    V, S = 64, 9
+    args, G, D = build_models(pkg, dev, O.make_generator_state(5, V, S), O.make_discriminator_state(6), V, S)
+    args.motion_resampling_framerate = 15
+    G.eval()
+    gen = torch.Generator().manual_seed(9)
+
+    def windows(dec, n=3):
+        text = torch.zeros(1, 34, dtype=torch.int64); text[0, ::6] = torch.randint(4, V, (6,), generator=torch.Generator().manual_seed(3))
+        audio = 0.1 * torch.randn(1, dec.audio_len, generator=torch.Generator().manual_seed(4))
+        vid = torch.tensor([2])
+        draws = [torch.randn(1, 16, generator=torch.Generator().manual_seed(20 + i)) for i in range(n)]
+        dec.seed(None)
+        return [dec.window(text, audio, vid, first=(i == 0), draw=draws[i]).cpu().clone() for i in range(n)]
+
+    a = windows(syn.WindowDecoder(args, G, 1, dev, graph=True, replay_draws=True))
+    # the same windows eagerly, with the memo switched off (every operand formed by every window, as a training-time eval forward does)
+    class NoMemo:
+        def __enter__(self): return self
+        def __exit__(self, *e): return False
+    dec0 = syn.WindowDecoder(args, G, 1, dev, graph=False, replay_draws=True)
+    dec0.frozen = NoMemo()
+    b = windows(dec0)
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+    assert L._FROZEN is None                                     # no scope leaks out of a decoder's calls
+    # (b) change weights that only reach the output through memoised operands: a TCN conv's weight_g, a BatchNorm running_var, out.2.weight
+    with torch.no_grad():
+        sd = G.state_dict()
+        sd["text_encoder.tcn.network.0.conv1.weight_g"].mul_(1.7)
+        sd["audio_encoder.feat_extractor.1.running_var"].mul_(3.0)
+        sd["out.2.weight"].mul_(0.5)
+    G.engine.slab.ensure()
+    c = windows(syn.WindowDecoder(args, G, 1, dev, graph=True, replay_draws=True))
+    dec1 = syn.WindowDecoder(args, G, 1, dev, graph=False, replay_draws=True)
+    dec1.frozen = NoMemo()
+    d = windows(dec1)
+    for x, y in zip(c, d):
+        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+    assert float((c[0] - a[0]).abs().max()) > 1e-3               # and it IS a different result
+
+
 def test_freeze_wordembed_keeps_the_embedding_fixed(pkg, dev):
     """args.freeze_wordembed=True (multimodal_context_net.py:40-41, train.py:104: optim.Adam(generator.parameters()) skips parameters
     without gradient): the word table must stay bit-identical through a GAN iteration and every other parameter must move exactly as in
