@@ -148,8 +148,28 @@ constexpr int IB_LD = 4 * HS + 4;      // floats per LDS row of an operand recor
 constexpr int MOVER_LAG = 1;           // s_sleep argument of the movers after each barrier (64 cycles per unit)
 
 // eight consecutive fp32 -> NS bf16x8 fragments (NS == 1: rounded to nearest even; NS == 3: exact hi / mid / lo)
+// fp16 x 2: eight consecutive fp32 times their power-of-two scale -> hi / lo fp16 fragments (bit patterns in bf16x8 registers)
+__device__ __forceinline__ void split8_h2(const f32x4 a, const f32x4 b, const float scale, bf16x8 (&out)[2]) {
+    unsigned h[4], l[4];
+    h2_split2(a[0] * scale, a[1] * scale, h[0], l[0]);
+    h2_split2(a[2] * scale, a[3] * scale, h[1], l[1]);
+    h2_split2(b[0] * scale, b[1] * scale, h[2], l[2]);
+    h2_split2(b[2] * scale, b[3] * scale, h[3], l[3]);
+    out[0] = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+    out[1] = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+}
+// ... four consecutive fp32 -> two 8-byte LDS words
+__device__ __forceinline__ void split4_store_h2(const f32x4 v, const float scale, __bf16* p0, __bf16* p1) {
+    unsigned h0, l0, h1, l1;
+    h2_split2(v[0] * scale, v[1] * scale, h0, l0);
+    h2_split2(v[2] * scale, v[3] * scale, h1, l1);
+    *reinterpret_cast<u32x2*>(p0) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(p1) = u32x2{l0, l1};
+}
+
 template <int NS>
 __device__ __forceinline__ void split8_ns(const f32x4 a, const f32x4 b, bf16x8 (&out)[NS]) {
+    static_assert(NS != 2, "fp16 x 2 operands are split with their scale: split8_h2");
     if constexpr (NS == 1) {
         bf16x8 r;
 #pragma unroll
@@ -166,6 +186,7 @@ template <int NS>
 __device__ __forceinline__ void split4_store_ns(const f32x4 v, __bf16* p0, __bf16* p1, __bf16* p2) { split4_store(v, p0, p1, p2, NS == 1 ? 1 : 0); }
 template <int NS>
 __device__ __forceinline__ f32x4 mma_ns(const bf16x8 (&wa)[NS], const bf16x8 (&fb)[NS], f32x4 acc) {
+    static_assert(NS != 2, "lab projection: bf16 operands only");
     if constexpr (NS == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], fb[0], acc, 0, 0, 0);
     else {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2], fb[0], acc, 0, 0, 0);
@@ -180,10 +201,14 @@ __device__ __forceinline__ f32x4 mma_ns(const bf16x8 (&wa)[NS], const bf16x8 (&f
 // the chain of mma_ns over KS k-steps, one MFMA at a time: MFMA number i (k-step major, then the six terms smallest first)
 template <int NS, int KS>
 __device__ __forceinline__ f32x4 mma_one(int i, const bf16x8 (&wa)[KS][NS], const bf16x8 (&fb)[KS][NS], f32x4 acc) {
-    constexpr int PER = NS == 3 ? 6 : 1;
+    constexpr int PER = NS == 3 ? 6 : NS == 2 ? 3 : 1;
     const int ks = i / PER, t = i - ks * PER;
     if constexpr (NS == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks][0], fb[ks][0], acc, 0, 0, 0);
-    else {
+    else if constexpr (NS == 2) {
+        // fp16 x 2 (forward kernel): planes 0 / 1 = hi / lo fp16 of the scaled operand; lo_w hi_x, hi_w lo_x, hi_w hi_x (small terms first)
+        constexpr int WP2[3] = {1, 0, 0}, FP2[3] = {0, 1, 0};
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tg_f16x8, wa[ks][WP2[t]]), __builtin_bit_cast(tg_f16x8, fb[ks][FP2[t]]), acc, 0, 0, 0);
+    } else {
         constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, FP[6] = {0, 2, 1, 0, 1, 0};
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks][WP[t]], fb[ks][FP[t]], acc, 0, 0, 0);
     }
@@ -340,15 +365,48 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
     // one half of the step's output record
     const int rr = r16 & (RW - 1), half = r16 >> 3;
     bf16x8 wa[3][2][NS];
+    // fp16 x 2 (NS == 2): W_hh row (gate g, unit 16 wave + r16) scaled by its own power of two (largest magnitude over its 64 columns -> [2^14, 2^15):
+    // the row's columns sit in this lane's two fragments and in the three other lanes of the same r16), h as hi / lo of h * 2^14 (|h| < 1); a
+    // gate row's product comes back through 1 / (row scale * 2^14).  A lane's accumulators are units 16 wave + 4 kq + q: their rows' maxima are
+    // fetched from the lanes that hold them (wave-local shuffles: no LDS table, no extra barrier for the movers to match).
+    constexpr float H_SCALE = 16384.f;
+    f32x4 winv[3] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < 3; ++g) {
+        f32x4 wv[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float* p = whh + (long)(g * HS + 16 * wave + r16) * HS + 32 * ks + 8 * kq;
-            split8_ns<NS>(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), wa[g][ks]);
+            wv[ks][0] = *reinterpret_cast<const f32x4*>(p);
+            wv[ks][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+        if constexpr (NS == 2) {
+            unsigned mx = 0u;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const unsigned v = __float_as_uint(wv[ks][hf][q]) & 0x7fffffffu; mx = mx > v ? mx : v; }
+            unsigned o = (unsigned)__shfl_xor((int)mx, 16, 64); mx = mx > o ? mx : o;
+            o = (unsigned)__shfl_xor((int)mx, 32, 64); mx = mx > o ? mx : o;
+            const float wsc = h2_scale_of_exp(h2_exp_of_bits(mx));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned mq = (unsigned)__shfl((int)mx, 4 * kq + q, 64);          // row 16 wave + 4 kq + q lives in lanes with r16 = 4 kq + q
+                winv[g][q] = h2_inv_of_exp(h2_exp_of_bits(mq)) * (1.f / H_SCALE);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) split8_h2(wv[ks][0], wv[ks][1], wsc, wa[g][ks]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) split8_ns<NS>(wv[ks][0], wv[ks][1], wa[g][ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int s = 0; s < NS; ++s) pin_fragment(wa[g][ks][s]);
-        }
+    }
     const int u0 = 16 * wave + 4 * kq;
     f32x4 bh[3];
 #pragma unroll
@@ -401,16 +459,19 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
         // operation-major over the lane's four elements (an element-major order is one dependent chain: ~12 cycles per instruction).
         //   region A (r products): the record of step - 1 (zeros at step 0) leaves for obuf[(step - 1) & 1]; bias folded into the operands
         //   region B (n products): sigmoid(r);   region C (z products): tanh(.) of the n gate and hp - n;   tail: sigmoid(z), blend
-        constexpr int NM = NS == 3 ? 12 : 2;                  // MFMAs per gate
+        constexpr int NM = NS == 3 ? 12 : NS == 2 ? 6 : 2;    // MFMAs per gate
         constexpr float NL2E = -1.44269504088896341f;
+        // (fp16 x 2: the accumulators are the products times row scale * 2^14 -- the exact inverse rides in the multiplier the gate's first
+        // operation has anyway)
+        const f32x4 c_r = winv[0] * NL2E, c_z = winv[1] * NL2E;
         f32x4 acc[3] = {zero, zero, zero};
         f32x4 gb0, gb1;                                       // (gi + b_hh) * -log2(e) of the r and z gates
         f32x4 r4, z4, n4, hn4, h, tn, ta, tb;
         // sigmoid in four operations per element: t = acc * -log2e + gb; t = 2^t; t = 1 + t; t = 1 / t
-        auto sig_op = [&](auto kc, auto qc, f32x4& t, const f32x4& ac, const f32x4& gb) {
+        auto sig_op = [&](auto kc, auto qc, f32x4& t, const f32x4& ac, const f32x4& gb, const f32x4& cs) {
             constexpr int k = decltype(kc)::value, q = decltype(qc)::value;
             if constexpr (ABL & 2) { if constexpr (k == 0) t[q] = ac[q] + gb[q]; }
-            else if constexpr (k == 0) t[q] = __builtin_fmaf(ac[q], NL2E, gb[q]);
+            else if constexpr (k == 0) t[q] = __builtin_fmaf(ac[q], NS == 2 ? cs[q] : NL2E, gb[q]);
             else if constexpr (k == 1) t[q] = __builtin_amdgcn_exp2f(t[q]);
             else if constexpr (k == 2) t[q] = 1.f + t[q];
             else t[q] = __builtin_amdgcn_rcpf(t[q]);
@@ -419,7 +480,7 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
         auto tanh_op = [&](auto kc, auto qc) {
             constexpr int k = decltype(kc)::value, q = decltype(qc)::value;
             if constexpr (ABL & 2) { if constexpr (k == 0) { hn4[q] = acc[2][q]; n4[q] = gx[2][q] + r4[q] * hn4[q]; tb[q] = hp[q] - n4[q]; } }
-            else if constexpr (k == 0) hn4[q] = acc[2][q] + bh[2][q];
+            else if constexpr (k == 0) hn4[q] = NS == 2 ? __builtin_fmaf(acc[2][q], winv[2][q], bh[2][q]) : acc[2][q] + bh[2][q];
             else if constexpr (k == 1) tn[q] = __builtin_fmaf(r4[q], hn4[q], gx[2][q]);
             else if constexpr (k == 2) ta[q] = fabsf(tn[q]) * (2.f * NL2E);
             else if constexpr (k == 3) ta[q] = __builtin_amdgcn_exp2f(ta[q]);
@@ -442,7 +503,7 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
                 }
                 // 16 operand-folding operations, two per gap from gap NM - 8 on (all in the last gap at NM = 2)
                 static_for<16>([&](auto sc) {
-                    constexpr int sl = decltype(sc)::value, gap = NM >= 12 ? NM - 8 + sl / 2 : NM - 1;
+                    constexpr int sl = decltype(sc)::value, gap = NM >= 12 ? NM - 8 + sl / 2 : NM >= 6 ? NM - 4 + sl / 4 : NM - 1;
                     if constexpr (gap == i) {
                         constexpr int q = sl & 3, k = sl >> 2;
                         if constexpr (k == 0) gb0[q] = gx[0][q] + bh[0][q];
@@ -459,7 +520,7 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
             if constexpr (!(ABL & 4)) acc[2] = mma_one<NS, 2>(i, wa[2], fb, acc[2]);
             static_for<16>([&](auto sc) {                      // sigmoid(r): 16 slots over the NM gaps
                 constexpr int sl = decltype(sc)::value;
-                if constexpr (sl * NM / 16 == i) sig_op(std::integral_constant<int, sl / 4>{}, std::integral_constant<int, sl % 4>{}, r4, acc[0], gb0);
+                if constexpr (sl * NM / 16 == i) sig_op(std::integral_constant<int, sl / 4>{}, std::integral_constant<int, sl % 4>{}, r4, acc[0], gb0, c_r);
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -477,7 +538,7 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
         TG_STAMP(step, 2);                   // MFMA results back
         static_for<16>([&](auto sc) {
             constexpr int sl = decltype(sc)::value;
-            sig_op(std::integral_constant<int, sl / 4>{}, std::integral_constant<int, sl % 4>{}, z4, acc[1], gb1);
+            sig_op(std::integral_constant<int, sl / 4>{}, std::integral_constant<int, sl % 4>{}, z4, acc[1], gb1, c_z);
         });
 #pragma unroll
         for (int q = 0; q < 4; ++q) h[q] = __builtin_fmaf(z4[q], tb[q], n4[q]);        // (1 - z) n + z h_prev
@@ -490,7 +551,11 @@ __global__ __launch_bounds__(512) void gru_h64_fwd2_kernel(
         hp = h;
         TG_FORCE(h[0]); TG_FORCE(h[1]); TG_FORCE(h[2]); TG_FORCE(h[3]);
         TG_STAMP(step, 3);                   // gates done
-        if constexpr (!(ABL & 16)) { const int cs = swz_col(rr, u0); split4_store_ns<NS>(h, &hs[wb][0][rr][cs], &hs[wb][1][rr][cs], &hs[wb][2][rr][cs]); }
+        if constexpr (!(ABL & 16)) {
+            const int cs = swz_col(rr, u0);
+            if constexpr (NS == 2) split4_store_h2(h, H_SCALE, &hs[wb][0][rr][cs], &hs[wb][1][rr][cs]);
+            else split4_store_ns<NS>(h, &hs[wb][0][rr][cs], &hs[wb][1][rr][cs], &hs[wb][2][rr][cs]);
+        }
         else asm volatile("" :: "v"(h));
         TG_STAMP(step, 4);                   // h_t split and in LDS (stores complete)
         q_h = h; q_r = r4; q_z = z4; q_n = n4; q_hn = hn4;
@@ -808,7 +873,10 @@ extern "C" int tg_gru_h64_forward(const float* gi, int64_t gi_dir_stride, const 
             }
         }
 #endif
+        // fp32-accurate mode: fp16 x 2 operands (three MFMAs per product, round 6) unless TG_H64_H2=0 asks for bf16 x 3 (six)
+        static const int h2 = [] { const char* e = getenv("TG_H64_H2"); return e ? atoi(e) : 1; }();
         if (tg_get_math_mode() == 1) TG_H64_FWD2_NS(1);
+        else if (h2) TG_H64_FWD2_NS(2);
         else TG_H64_FWD2_NS(3);
 #undef TG_H64_FWD2_NS
 #undef TG_H64_FWD2_RW
