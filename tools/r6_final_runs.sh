@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, final measurements on ONE box (run on the GPU box from the repo root): profile + default bench line (with its secondary block) + the
-# same-box A/B of the round's arithmetic change (TG_GEMM_H2=0 TG_GRU_H2=0 = every big product back on bf16 x 3) + variants + the GPU suite
+# same-box A/B of the round's arithmetic change (TG_GEMM_H2=0 TG_GRU_H2=0 TG_H64_H2=0 = every product back on bf16 x 3) + variants + the GPU suite
 set -u
 export TMPDIR=/tmp
 o=gpurun_out
@@ -10,7 +10,7 @@ echo "default: $(head -c 240 $o/r6_fin_bench_default.json)"
 ms() { python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), round(d['value']), round(d['roofline']['frac'],3))"; }
 : > $o/r6_fin_ab_h2.txt
 for r in 1 2 3; do
-  a=$(TG_GEMM_H2=0 TG_GRU_H2=0 python3 bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | ms)
+  a=$(TG_GEMM_H2=0 TG_GRU_H2=0 TG_H64_H2=0 python3 bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | ms)
   b=$(python3 bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | ms)
   echo "round $r  bf16 x 3 everywhere (ms, clips/s, roofline.frac): $a   |   default, fp16 x 2: $b" | tee -a $o/r6_fin_ab_h2.txt
 done
